@@ -1,0 +1,231 @@
+/*
+ * same_rx.h -- C ABI of the MI355X batched SAME/EAS AFSK demodulator.
+ *
+ * This is the drop-in boundary for sameold's hot path: the per-sample receive chain
+ * inside `sameold::SameReceiver` (DC block -> AGC -> mark/space matched filters ->
+ * symbol-timing loop -> preamble code+power squelch -> DFE -> framer), run for
+ * thousands of independent audio channels at once by hand-written gfx950 HIP kernels.
+ *
+ * The reference is pure Rust and has no FFI of its own; the
+ * entry points below are what a `sameold-gpu` Rust shim would bind with `extern "C"`
+ * (see INTEGRATION.md).  Each one names the reference item it replaces; citations are
+ * file:line under crates/sameold/src/ ("rx/" = receiver/).
+ *
+ * Conventions: opaque handles; caller-owned input/output buffers; the library never
+ * retains caller pointers past a call; return 0 on success or a negative SAME_E* code
+ * where the reference would panic or where the GPU is unusable.  A handle is
+ * single-writer; distinct handles are independent (as `&mut self` makes them in Rust).
+ * No CPU fallback exists: without a usable gfx950 device every compute entry point
+ * fails with SAME_ENODEVICE.
+ */
+#ifndef SAME_RX_H
+#define SAME_RX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SAME_RX_ABI_VERSION 1
+
+/* ------------------------------------------------------------------ errors */
+enum {
+    SAME_OK = 0,
+    SAME_EINVAL = -1,        /* null/invalid argument */
+    SAME_EDCLEN = -2,        /* DC blocker length rounds to 0: reference panics, rx/dcblock.rs:74 via receiver.rs:509 */
+    SAME_EAGCLIMITS = -3,    /* agc min > max or NaN: f32::clamp panics, rx/agc.rs:75 */
+    SAME_EEQORDER = -4,      /* equalizer order beyond the device limit (SAME_MAX_EQ_TAPS) */
+    SAME_ENODEVICE = -5,     /* no usable HIP device / kernel image for this GPU */
+    SAME_EHIP = -6,          /* a HIP runtime call failed (same_last_error() has text) */
+    SAME_EOVERFLOW = -7,     /* event or burst pool overflow: results truncated */
+    SAME_ENOMEM = -8,
+    SAME_ERATE = -9          /* input rate too low for the matched filters (ntaps < 1) */
+};
+const char *same_last_error(void);
+uint32_t same_rx_abi_version(void);
+
+/* ------------------------------------------------------------------ builder
+ * Mirrors `SameReceiverBuilder` (rx/builder.rs:22-37): a plain copyable value with the
+ * reference's defaults (:50-67) and setter-side clamping (:95-279).  EqualizerBuilder
+ * (:359-425) is folded in as the four `eq_*` parameters. */
+typedef struct same_rx_builder same_rx_builder;
+
+same_rx_builder *same_rx_builder_new(uint32_t input_rate);            /* SameReceiverBuilder::new :50 */
+same_rx_builder *same_rx_builder_default(void);                       /* Default :352-356 (22050 Hz) */
+same_rx_builder *same_rx_builder_clone(const same_rx_builder *b);     /* #[derive(Clone, Copy)] :22 */
+void same_rx_builder_free(same_rx_builder *b);
+
+void same_rx_builder_with_dc_blocker_length(same_rx_builder *b, float len);                 /* :95-98 */
+void same_rx_builder_with_agc_bandwidth(same_rx_builder *b, float bw);                      /* :107-110 */
+void same_rx_builder_with_agc_gain_limits(same_rx_builder *b, float min, float max);        /* :120-123 */
+void same_rx_builder_with_timing_bandwidth(same_rx_builder *b, float unlocked, float locked); /* :139-143 */
+void same_rx_builder_with_timing_max_deviation(same_rx_builder *b, float max_dev);          /* :155-158 */
+void same_rx_builder_with_squelch_power(same_rx_builder *b, float open, float close);       /* :172-176 */
+void same_rx_builder_with_squelch_bandwidth(same_rx_builder *b, float bw);                  /* :187-190 */
+void same_rx_builder_with_preamble_max_errors(same_rx_builder *b, uint32_t max_err);        /* :204-207 */
+/* with_adaptive_equalizer(&EqualizerBuilder): with_filter_order/relaxation/regularization
+ * clamps of :393-425 are applied here */
+void same_rx_builder_with_adaptive_equalizer(same_rx_builder *b, uint32_t nfeedforward,
+                                             uint32_t nfeedback, float relaxation,
+                                             float regularization);                         /* :222-225 */
+void same_rx_builder_without_adaptive_equalizer(same_rx_builder *b);                        /* :231-234 */
+void same_rx_builder_with_frame_prefix_max_errors(same_rx_builder *b, uint32_t max_err);    /* :247-250 */
+void same_rx_builder_with_frame_max_invalid(same_rx_builder *b, uint32_t max_invalid);      /* :276-279 */
+
+uint32_t same_rx_builder_input_rate(const same_rx_builder *b);                              /* :282-285 */
+float same_rx_builder_dc_blocker_length(const same_rx_builder *b);                          /* :288-291 */
+float same_rx_builder_agc_bandwidth(const same_rx_builder *b);                              /* :294-297 */
+void same_rx_builder_agc_gain_limits(const same_rx_builder *b, float out[2]);               /* :300-303 */
+void same_rx_builder_timing_bandwidth(const same_rx_builder *b, float *unlocked, float *locked); /* :306-309 */
+float same_rx_builder_timing_max_deviation(const same_rx_builder *b);                       /* :312-315 */
+void same_rx_builder_squelch_power(const same_rx_builder *b, float *open, float *close);    /* :318-321 */
+float same_rx_builder_squelch_bandwidth(const same_rx_builder *b);                          /* :324-327 */
+uint32_t same_rx_builder_preamble_max_errors(const same_rx_builder *b);                     /* :330-333 */
+/* adaptive_equalizer(): returns 0 for None, 1 for Some and fills the four outputs */
+int same_rx_builder_adaptive_equalizer(const same_rx_builder *b, uint32_t *nfeedforward,
+                                       uint32_t *nfeedback, float *relaxation,
+                                       float *regularization);                              /* :336-339 */
+uint32_t same_rx_builder_frame_prefix_max_errors(const same_rx_builder *b);                 /* :342-345 */
+uint32_t same_rx_builder_frame_max_invalid(const same_rx_builder *b);                       /* :348-351 */
+
+#define SAME_MAX_EQ_TAPS 16
+
+/* ------------------------------------------------------------------ events
+ * Mirrors `SameReceiverEvent` / `SameEventType` / `LinkState` / `TransportState`
+ * (rx/output.rs:24-27, 166-180, 231-261, 306-318).  Burst bytes are copied into the
+ * caller's event; nothing is borrowed. */
+enum {
+    SAME_LINK_NO_CARRIER = 0,      /* LinkState::NoCarrier */
+    SAME_LINK_SEARCHING = 1,       /* LinkState::Searching */
+    SAME_LINK_READING = 2,         /* LinkState::Reading */
+    SAME_LINK_BURST = 3,           /* LinkState::Burst(Vec<u8>) */
+    SAME_TRANSPORT_IDLE = 16,      /* TransportState::Idle */
+    SAME_TRANSPORT_ASSEMBLING = 17,/* TransportState::Assembling */
+    SAME_TRANSPORT_MSG_START = 18, /* Message(Ok(StartOfMessage(hdr))): bytes = header text */
+    SAME_TRANSPORT_MSG_END = 19,   /* Message(Ok(EndOfMessage)) */
+    SAME_TRANSPORT_MSG_ERR = 20    /* Message(Err(e)): aux = 1 NotAscii, 2 UnrecognizedPrefix, 3 Malformed */
+};
+
+#define SAME_EVENT_MAX_BYTES 288   /* >= MAX_MESSAGE_LENGTH 268 (rx/assembler.rs:70) */
+
+typedef struct same_rx_event {
+    uint32_t kind;             /* SAME_LINK_* / SAME_TRANSPORT_* */
+    uint32_t channel;          /* channel index within the batch */
+    uint64_t sample_counter;   /* input_sample_counter() at emission, rx/output.rs:121-123 */
+    uint64_t symbol_count;     /* squelch symbol counter at emission (transport time base) */
+    uint32_t len;              /* true burst/header length; bytes[] holds min(len, MAX) */
+    uint32_t aux;              /* MSG_START: voting_byte_count; MSG_ERR: error code */
+    uint32_t aux2;             /* MSG_START: parity_error_count */
+    uint32_t reserved;
+    uint8_t bytes[SAME_EVENT_MAX_BYTES];
+} same_rx_event;
+
+/* ------------------------------------------------------------------ batched receiver
+ * `n_channels` independent `SameReceiver`s built from one builder
+ * (`SameReceiverBuilder::build`, rx/builder.rs:73-76 / receiver.rs:502-560), resident on
+ * one GPU.  All channels advance in lockstep: one call processes `n_samples` samples of
+ * every channel through the whole link layer (receiver.rs:343-474).
+ *
+ * Input layout (f32 PCM, unscaled i16-range values as the reference expects,
+ * lib.rs:78-81).  TIME_MAJOR is the native, coalesced layout:
+ *   SAME_LAYOUT_TIME_MAJOR     x[t * n_channels + c]
+ *   SAME_LAYOUT_CHANNEL_MAJOR  x[c * n_samples + t]   (transposed on the device first)
+ */
+enum { SAME_LAYOUT_TIME_MAJOR = 0, SAME_LAYOUT_CHANNEL_MAJOR = 1 };
+
+/* flags for same_batch_new */
+enum {
+    SAME_BATCH_LINK_ONLY = 1u << 0,   /* report link events only; skip the transport layer */
+    SAME_BATCH_TRACE_SYMBOLS = 1u << 1 /* record every soft symbol (debug / parity tests) */
+};
+
+typedef struct same_batch same_batch;
+
+/* build(): SAME_EDCLEN / SAME_EAGCLIMITS where the reference panics */
+int same_batch_new(const same_rx_builder *b, uint32_t n_channels, int device,
+                   uint32_t flags, same_batch **out);
+void same_batch_free(same_batch *rx);
+int same_batch_reset(same_batch *rx);                       /* SameReceiver::reset receiver.rs:182-198 */
+uint32_t same_batch_input_rate(const same_batch *rx);       /* input_rate() :167-169 */
+uint32_t same_batch_n_channels(const same_batch *rx);
+uint64_t same_batch_input_sample_counter(const same_batch *rx); /* input_sample_counter() :175-177 */
+int same_batch_device(const same_batch *rx);
+
+/* The hot path.  `d_x` is a DEVICE pointer to n_samples * n_channels floats that stays
+ * valid until the stream reaches the end of this call's work; `hip_stream` is a
+ * hipStream_t (NULL = the library's own stream).  Asynchronous: events become visible
+ * to same_batch_poll_events after same_batch_sync.  Replaces the sample loop of
+ * SameReceiver::process (receiver.rs:243-270) for every channel. */
+int same_batch_process_device(same_batch *rx, const float *d_x, size_t n_samples,
+                              uint32_t layout, void *hip_stream);
+/* int16 PCM on the device, cast to f32 without scaling in the kernel
+ * (crates/samedec/src/app.rs:112); 2 bytes/sample of HBM traffic */
+int same_batch_process_device_i16(same_batch *rx, const int16_t *d_x, size_t n_samples,
+                                  uint32_t layout, void *hip_stream);
+/* host-buffer convenience: copies to the device, processes, synchronises */
+int same_batch_process_host(same_batch *rx, const float *h_x, size_t n_samples, uint32_t layout);
+int same_batch_process_host_i16(same_batch *rx, const int16_t *h_x, size_t n_samples, uint32_t layout);
+/* SameReceiver::flush (receiver.rs:216-224): 4 * input_rate zero samples per channel.
+ * Unlike the reference it does not stop at the first message; all events are reported. */
+int same_batch_flush(same_batch *rx);
+/* wait for all queued work of this handle */
+int same_batch_sync(same_batch *rx);
+
+/* Drain events produced so far, ordered by (channel, sample_counter, emission order):
+ * per channel this is exactly the order iter_events() yields them (receiver.rs:238-269).
+ * Writes up to `cap` events, *n_out = number written, *n_left = events still queued. */
+int same_batch_poll_events(same_batch *rx, same_rx_event *out, size_t cap, size_t *n_out,
+                           size_t *n_left);
+size_t same_batch_pending_events(same_batch *rx);
+
+/* soft-symbol trace (SAME_BATCH_TRACE_SYMBOLS): SymbolEstimate stream of one channel
+ * (rx/symsync.rs:52-71) with the input sample counter of each TED instant */
+typedef struct same_symbol_trace {
+    uint64_t sample_counter;
+    float zero, sym, err, samples_until_next_ted;
+} same_symbol_trace;
+int same_batch_read_trace(same_batch *rx, uint32_t channel, same_symbol_trace *out,
+                          size_t cap, size_t *n_out);
+
+/* device timing of the demodulation kernel(s) of the last process call, measured with
+ * HIP events on the stream the kernel ran on (milliseconds); for bench.py's roofline */
+int same_batch_last_kernel_ms(same_batch *rx, float *ms);
+/* enable/disable that timing (off by default: two event records per call) */
+void same_batch_set_kernel_timing(same_batch *rx, int enable);
+/* name of the kernel variant the last call dispatched to (static string) */
+const char *same_batch_kernel_name(const same_batch *rx);
+
+/* ------------------------------------------------------------------ single receiver
+ * `SameReceiver` with the reference's pull semantics, as a 1-channel batch.
+ * same_rx_process mirrors iter_events()/process() (receiver.rs:119-130, 233-274):
+ * returns 1 with *ev filled after consuming *consumed <= n samples, or 0 when all n
+ * samples were consumed without an event.  The caller resumes at x + *consumed, exactly
+ * as the Rust iterator leaves its source.  (The device runs ahead over the whole slice;
+ * samples past *consumed must therefore be re-presented unchanged, which any iterator
+ * adaptor does.) */
+typedef struct same_rx same_rx;
+int same_rx_build(const same_rx_builder *b, int device, same_rx **out);  /* build() */
+void same_rx_free(same_rx *rx);
+int same_rx_process(same_rx *rx, const float *x, size_t n, size_t *consumed, same_rx_event *ev);
+int same_rx_flush(same_rx *rx, same_rx_event *msg);      /* flush(): 1 if a message was produced */
+int same_rx_reset(same_rx *rx);
+uint32_t same_rx_input_rate(const same_rx *rx);
+uint64_t same_rx_input_sample_counter(const same_rx *rx);
+
+/* ------------------------------------------------------------------ helpers
+ * device-side synthetic workload generator used by bench.py and the GPU tests: fills a
+ * TIME_MAJOR f32 buffer with seeded continuous-phase AFSK bursts (see DESIGN.md
+ * "Synthetic workload").  noise_sigma: AWGN std-dev relative to the carrier amplitude;
+ * flags bit 0: even integer samples/symbol like the reference's test modulator. */
+int same_synth_afsk_device(float *d_x, uint32_t n_channels, size_t n_samples,
+                           uint32_t input_rate, uint64_t seed, float noise_sigma,
+                           uint32_t flags, int device, void *hip_stream);
+/* the header text the generator transmits on `channel` (host-side mirror) */
+uint32_t same_synth_payload(uint64_t seed, uint32_t channel, uint8_t *out, uint32_t cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SAME_RX_H */

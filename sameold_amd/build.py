@@ -1,0 +1,79 @@
+"""Builds the gfx950 shared library (sameold_amd/libsame_rx.so) in-tree with hipcc.
+
+    python -m sameold_amd.build [--force]
+
+-ffp-contract=off is part of the arithmetic contract (host and device): the kernels
+reproduce the reference's one-rounding-per-operation f32 arithmetic bit for bit.
+"""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "libsame_rx.so")
+SOURCES = ["same_kernels.hip", "same_synth.hip", "same_batch.cpp", "same_config.cpp", "same_transport.cpp"]
+HEADERS = ["same_device.h", "same_launch.h", "same_config.h", "same_transport.h", "../../include/same_rx.h"]
+ARCH = "gfx950"
+
+
+def hipcc() -> str:
+    for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found: the MI355X library cannot be built (there is no CPU build)")
+
+
+def flags() -> list:
+    return [
+        f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC",
+        "-ffp-contract=off", "-fno-fast-math",
+        "-fhip-fp32-correctly-rounded-divide-sqrt",
+        "-fgpu-rdc" if False else "-fno-gpu-rdc",
+        "-Wall", "-Wno-unused-function", "-Wno-unused-variable",
+        "-x", "hip",
+    ]
+
+
+def is_stale() -> bool:
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    for f in SOURCES + HEADERS:
+        if os.path.getmtime(os.path.join(CSRC, f)) > t:
+            return True
+    return os.path.getmtime(__file__) > t
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    if not force and not is_stale():
+        return LIB
+    objs = []
+    cc = hipcc()
+    bdir = os.path.join(HERE, "build")
+    os.makedirs(bdir, exist_ok=True)
+    procs = []
+    for src in SOURCES:
+        obj = os.path.join(bdir, os.path.splitext(src)[0] + ".o")
+        cmd = [cc] + flags() + ["-c", os.path.join(CSRC, src), "-o", obj]
+        if verbose:
+            print(" ".join(cmd))
+        procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+        objs.append(obj)
+    for src, p in procs:
+        out, _ = p.communicate()
+        if p.returncode != 0:
+            sys.stderr.write(out.decode(errors="replace"))
+            raise RuntimeError(f"hipcc failed on {src}")
+        if verbose and out:
+            print(out.decode(errors="replace"))
+    cmd = [cc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB] + objs
+    subprocess.run(cmd, check=True)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose="-v" in sys.argv))

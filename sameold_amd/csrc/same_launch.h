@@ -1,0 +1,33 @@
+// same_launch.h -- host-callable launchers implemented in same_kernels.hip / same_synth.hip
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include "same_device.h"
+
+namespace same {
+
+hipError_t launch_demod(const Params &P, const State &S, const Output &O, const float4 *taps,
+                        const float *x, uint32_t n_samples, uint64_t counter0, hipStream_t stream);
+hipError_t launch_demod_i16(const Params &P, const State &S, const Output &O, const float4 *taps,
+                            const int16_t *x, uint32_t n_samples, uint64_t counter0, hipStream_t stream);
+size_t demod_lds_bytes(const Params &P);
+hipError_t launch_init_state(const Params &P, const State &S, int is_reset, hipStream_t stream);
+hipError_t launch_transpose_f32(const float *in, float *out, uint32_t n_channels, uint32_t n_samples,
+                                hipStream_t stream);
+hipError_t launch_transpose_i16(const int16_t *in, int16_t *out, uint32_t n_channels, uint32_t n_samples,
+                                hipStream_t stream);
+
+// synthetic workload (same_synth.hip)
+struct SynthParams {
+    uint32_t n_channels;
+    uint32_t input_rate;
+    uint64_t seed;
+    float noise_sigma;     // AWGN standard deviation relative to the carrier amplitude (0 = none)
+    uint32_t flags;        // bit 0: integer (even) samples per symbol like the reference's test modulator
+};
+hipError_t launch_synth(const SynthParams &sp, float *x, size_t n_samples, hipStream_t stream);
+// host mirror of the per-channel payload the generator transmits (header text)
+uint32_t synth_payload(uint64_t seed, uint32_t channel, uint8_t *out, uint32_t cap);
+
+}  // namespace same

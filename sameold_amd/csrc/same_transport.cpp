@@ -1,0 +1,252 @@
+// same_transport.cpp -- see same_transport.h.  Citations: file:line under
+// /root/reference/crates/sameold/src/ ("rx/" = receiver/) unless a crate is named.
+#include "same_transport.h"
+
+#include <algorithm>
+
+namespace same {
+
+uint64_t max_interburst_symbols()
+{
+    // ((1.05 * BAUD_HZ) + 17.0 * 8.0) as u64 in f32 arithmetic, rx/assembler.rs:85
+    const float baud = 520.83f;
+    float a = 1.05f * baud;
+    float b = 17.0f * 8.0f;
+    float c = a + b;
+    return (uint64_t)c;
+}
+uint64_t max_history_duration() { return 2 * (max_interburst_symbols() + 8 * (uint64_t)kMaxMessageLength); }
+
+bool is_allowed_byte(uint8_t c)
+{
+    switch (c) {
+    case '-': case '/': case '?': case '(': case ')': case '[': case ']': case '.': case '_': case ',':
+    case '+': case ' ':
+        return true;
+    default:
+        return (c >= '0' && c <= '9') || (c >= 'A' && c <= 'Z') || (c >= 'a' && c <= 'z');
+    }
+}
+
+void bit_vote_detect(uint8_t b0, uint8_t b1, uint8_t *out, uint32_t *errs)
+{
+    const uint8_t x = b0 ^ b1;
+    *out = x ? 0 : b0;                                   // b0 & !(0xff * (xor != 0))
+    *errs = (uint32_t)__builtin_popcount(x);
+}
+void bit_vote_correct(uint8_t b0, uint8_t b1, uint8_t b2, uint8_t *out, uint32_t *errs)
+{
+    const uint8_t p0 = (uint8_t)~(b0 ^ b1), p1 = (uint8_t)~(b1 ^ b2), p2 = (uint8_t)~(b0 ^ b2);
+    *out = (uint8_t)((b0 & p0) | (b2 & p1) | (b2 & p2));
+    *errs = 8u - (uint32_t)__builtin_popcount((uint8_t)(p0 & p1 & p2));
+}
+
+static bool alpha(uint8_t c) { return (c >= 'A' && c <= 'Z') || (c >= 'a' && c <= 'z'); }
+static bool digit(uint8_t c) { return c >= '0' && c <= '9'; }
+
+bool check_header(const uint8_t *h, size_t n, size_t *offset_time, size_t *hdr_len)
+{
+    // ^ZCZC-[[:alpha:]]{3}-[[:alpha:]]{3}(-[0-9]{6})+(\+[0-9]{4}-[0-9]{7}-.{3,8}-)
+    // The location group is greedy and group 2 must begin with '+', so giving back a
+    // repetition can never help; .{3,8} is greedy, so the longest callsign wins.
+    auto at = [&](size_t i, uint8_t c) { return i < n && h[i] == c; };
+    auto run = [&](size_t i, size_t k, bool (*pred)(uint8_t)) {
+        for (size_t j = 0; j < k; ++j) if (i + j >= n || !pred(h[i + j])) return false;
+        return true;
+    };
+    if (n < 5 || std::memcmp(h, "ZCZC-", 5) != 0) return false;
+    size_t p = 5;
+    if (!run(p, 3, alpha) || !at(p + 3, '-') || !run(p + 4, 3, alpha)) return false;
+    p += 7;
+    size_t nloc = 0;
+    while (at(p, '-') && run(p + 1, 6, digit)) { p += 7; ++nloc; }
+    if (!nloc) return false;
+    const size_t g2 = p;
+    if (!at(p, '+') || !run(p + 1, 4, digit) || !at(p + 5, '-') || !run(p + 6, 7, digit) || !at(p + 13, '-'))
+        return false;
+    p += 14;
+    for (size_t m = 8; m >= 3; --m) {
+        if (!at(p + m, '-')) continue;
+        bool ok = true;
+        for (size_t k = 0; k < m; ++k) if (h[p + k] == '\n') { ok = false; break; }
+        if (ok) { *offset_time = g2; *hdr_len = p + m + 1; return true; }
+    }
+    return false;
+}
+
+// Message::try_from((bytes, errs, counts)) crates/sameplace/src/message.rs:718-736, 184-230
+static void parse_message(const uint8_t *b, size_t n, const uint8_t *errs, const uint8_t *counts, MessageResult *out)
+{
+    *out = MessageResult{};
+    for (size_t i = 0; i < n; ++i)
+        if (b[i] & 0x80) { out->kind = SAME_TRANSPORT_MSG_ERR; out->err = 1; return; }
+    if (n >= 5 && std::memcmp(b, "ZCZC-", 5) == 0) {
+        size_t off = 0, hl = 0;
+        if (!check_header(b, n, &off, &hl)) { out->kind = SAME_TRANSPORT_MSG_ERR; out->err = 3; return; }
+        out->kind = SAME_TRANSPORT_MSG_START;
+        out->text.assign((const char *)b, hl);
+        out->offset_time = (uint32_t)off;
+        for (size_t i = 0; i < hl; ++i) {
+            out->parity_errors += errs[i];
+            out->voting_bytes += counts[i] >= 3 ? 1u : 0u;
+        }
+    } else if (n >= 2 && b[0] == 'N' && b[1] == 'N') {
+        out->kind = SAME_TRANSPORT_MSG_END;
+    } else {
+        out->kind = SAME_TRANSPORT_MSG_ERR; out->err = 2;
+    }
+}
+
+bool combine(const std::vector<const std::vector<uint8_t> *> &bursts, MessageResult *res)
+{
+    // estimate_message rx/combiner.rs:154-203
+    uint8_t msg[kMaxMessageLength], cnt[kMaxMessageLength], errs[kMaxMessageLength];
+    const size_t nb = std::min<size_t>(bursts.size(), 3);
+    size_t pos[3] = {0, 0, 0};
+    size_t n = 0;
+    while (n < kMaxMessageLength) {
+        uint8_t cur[3]; uint32_t k = 0; bool msb = false;
+        for (size_t i = 0; i < nb; ++i)
+            if (pos[i] < bursts[i]->size()) cur[k++] = (*bursts[i])[pos[i]++];
+        for (uint32_t i = 0; i < k; ++i) { msb |= (cur[i] & 0x80) != 0; cur[i] &= 0x7f; }
+        if (k == 0) break;
+        uint8_t est; uint32_t be = 0;
+        if (k == 1) est = cur[0];
+        else if (k == 2) bit_vote_detect(cur[0], cur[1], &est, &be);
+        else bit_vote_correct(cur[0], cur[1], cur[2], &est, &be);
+        if (!is_allowed_byte(est)) break;
+        msg[n] = est; cnt[n] = (uint8_t)k; errs[n] = (uint8_t)(be + (msb ? 1u : 0u));
+        ++n;
+    }
+    // combine rx/combiner.rs:32-80
+    if (n == 0) return false;
+    size_t good = 0;
+    while (good < n && cnt[good] >= 2) ++good;           // truncate_bytes_with_reference :264-273
+    parse_message(msg, good, errs, cnt, res);
+    if (res->kind != SAME_TRANSPORT_MSG_ERR) return true;
+    if (n >= 2 && msg[0] == 'N' && msg[1] == 'N') {      // Fast EOM :251-258
+        *res = MessageResult{};
+        res->kind = SAME_TRANSPORT_MSG_END;
+        return true;
+    }
+    return good != 0;
+}
+
+void Assembler::reset()
+{
+    history_.clear();
+    pending_ = false; have_prev_ = false;
+}
+void Assembler::prune_history(uint64_t now)
+{
+    // rx/assembler.rs:362-368
+    history_.erase(std::remove_if(history_.begin(), history_.end(),
+                                  [now](const Timed &t) { return t.deadline <= now; }),
+                   history_.end());
+    while (history_.size() > 2) history_.pop_front();
+}
+void Assembler::accept(const MessageResult &m, uint64_t now)
+{
+    // PendingResult::accept rx/assembler.rs:294-328
+    const uint64_t deadline = (m.kind == SAME_TRANSPORT_MSG_END) ? now : now + max_interburst_symbols();
+    if (pending_) {
+        bool replace;
+        if (pend_.kind == SAME_TRANSPORT_MSG_ERR) replace = true;
+        else if (pend_.kind == SAME_TRANSPORT_MSG_END && m.kind == SAME_TRANSPORT_MSG_START) replace = true;
+        else if (pend_.kind == SAME_TRANSPORT_MSG_START && m.kind == SAME_TRANSPORT_MSG_START)
+            replace = m.voting_bytes >= pend_.voting_bytes;
+        else replace = false;
+        if (replace) { pend_ = m; pend_deadline_ = deadline; }
+    } else {
+        pending_ = true; pend_ = m; pend_deadline_ = deadline;
+    }
+}
+uint32_t Assembler::idle(uint64_t now, MessageResult *msg)
+{
+    // rx/assembler.rs:205-234
+    prune_history(now);
+    if (pending_ && pend_deadline_ <= now) {             // PendingResult::poll :336-345
+        *msg = pend_;
+        pending_ = false;
+        if (msg->kind != SAME_TRANSPORT_MSG_ERR) {
+            have_prev_ = true; prev_ = *msg; prev_deadline_ = now + max_history_duration();
+        }
+        return msg->kind;
+    }
+    return history_.empty() ? SAME_TRANSPORT_IDLE : SAME_TRANSPORT_ASSEMBLING;
+}
+uint32_t Assembler::assemble(const uint8_t *burst, size_t n, uint64_t now, MessageResult *msg)
+{
+    // rx/assembler.rs:154-184
+    if (n == 0) return idle(now, msg);
+    prune_history(now);
+    if (have_prev_ && prev_deadline_ <= now) have_prev_ = false;   // prune_previous :371-376
+    Timed t;
+    t.data.assign(burst, burst + std::min(n, kMaxMessageLength));
+    t.deadline = now + max_history_duration();
+    history_.push_back(std::move(t));
+    std::vector<const std::vector<uint8_t> *> views;
+    for (const Timed &h : history_) views.push_back(&h.data);
+    MessageResult res;
+    if (combine(views, &res)) {
+        // deduplicate :245-265: messages are duplicates when string-equal
+        bool keep = true;
+        if (res.kind != SAME_TRANSPORT_MSG_ERR && have_prev_ && std::strcmp(prev_.as_str(), res.as_str()) == 0)
+            keep = false;
+        if (keep) accept(res, now);
+    }
+    return idle(now, msg);
+}
+
+void Transport::reset()
+{
+    asm_.reset();
+    state_kind_ = SAME_TRANSPORT_IDLE; state_msg_ = MessageResult{};
+    have_force_eom_ = false; dirty_ = true;
+}
+
+bool Transport::on_link_event(uint32_t kind, uint64_t sample_counter, uint64_t symbol_count,
+                              const uint8_t *bytes, uint32_t len, uint32_t input_rate, same_rx_event *out)
+{
+    // process_transportlayer receiver.rs:291-333
+    const uint64_t kMaxMessageDurationSecs = 135;        // receiver.rs:496
+    MessageResult msg;
+    uint32_t st;
+    if (kind == SAME_LINK_BURST) {
+        st = asm_.assemble(bytes, len, symbol_count, &msg);
+    } else if (kind == SAME_LINK_NO_CARRIER || kind == kDevTick) {
+        if (have_force_eom_ && sample_counter > force_eom_at_) {
+            st = SAME_TRANSPORT_MSG_END; msg.kind = st;
+        } else {
+            st = asm_.idle(symbol_count, &msg);
+        }
+    } else {
+        return false;
+    }
+    if (st == SAME_TRANSPORT_MSG_START) {
+        have_force_eom_ = true; dirty_ = true;
+        force_eom_at_ = sample_counter + kMaxMessageDurationSecs * (uint64_t)input_rate;
+    } else if (st == SAME_TRANSPORT_MSG_END) {
+        if (have_force_eom_) dirty_ = true;
+        have_force_eom_ = false;
+    }
+    const bool is_msg = st >= SAME_TRANSPORT_MSG_START;
+    const bool same = (st == state_kind_) && (!is_msg || msg == state_msg_);
+    if (same) return false;
+    state_kind_ = st;
+    state_msg_ = is_msg ? msg : MessageResult{};
+    std::memset(out, 0, offsetof(same_rx_event, bytes));
+    out->kind = st;
+    out->sample_counter = sample_counter;
+    out->symbol_count = symbol_count;
+    if (st == SAME_TRANSPORT_MSG_START) {
+        out->len = (uint32_t)msg.text.size();
+        std::memcpy(out->bytes, msg.text.data(), std::min<size_t>(msg.text.size(), SAME_EVENT_MAX_BYTES));
+        out->aux = msg.voting_bytes; out->aux2 = msg.parity_errors;
+    } else if (st == SAME_TRANSPORT_MSG_ERR) {
+        out->aux = msg.err;
+    }
+    return true;
+}
+
+}  // namespace same

@@ -1,0 +1,94 @@
+// same_transport.h -- host-side transport layer: turns the link events of one channel
+// into TransportState events (bursts -> 2-of-3 bit voting -> validated header text).
+//
+// This is SURVEY.md section 8f "next-1": rx/assembler.rs, rx/combiner.rs, rx/timeddata.rs,
+// receiver.rs:291-333 and the header check of crates/sameplace/src/message.rs:813-828.
+// It is symbol-rate integer/string work on a handful of bursts per message, so it runs
+// on the host over the events the device reports.
+//
+// The reference polls the assembler on every symbol whose link state is NoCarrier or
+// Burst (receiver.rs:292-315).  The device reports exactly those poll instants at which
+// the assembler's answer can change (link events plus SAME_DEV_TICK wake-ups, see
+// same_kernels.hip "transport wake-ups"); replaying the assembler at those instants
+// reproduces the reference's transport events with identical sample counters.
+#pragma once
+
+#include <cstdint>
+#include <cstring>
+#include <deque>
+#include <string>
+#include <vector>
+
+#include "../../include/same_rx.h"
+
+namespace same {
+
+constexpr uint32_t kDevTick = 8;                 // device-only event kind (never surfaced)
+constexpr size_t kMaxMessageLength = 268;        // rx/assembler.rs:70
+
+uint64_t max_interburst_symbols();               // rx/assembler.rs:85  (682)
+uint64_t max_history_duration();                 // rx/assembler.rs:92-93 (5652)
+
+// crates/sameplace/src/message.rs:813-828; returns true and fills offsets on a match
+bool check_header(const uint8_t *hdr, size_t n, size_t *offset_time, size_t *hdr_len);
+void bit_vote_detect(uint8_t b0, uint8_t b1, uint8_t *out, uint32_t *errs);   // rx/combiner.rs:216-222
+void bit_vote_correct(uint8_t b0, uint8_t b1, uint8_t b2, uint8_t *out, uint32_t *errs); // :234-249
+bool is_allowed_byte(uint8_t c);                 // rx/combiner.rs:105-137
+
+// MessageResult = Result<Message, MessageDecodeErr>
+struct MessageResult {
+    uint32_t kind = 0;               // SAME_TRANSPORT_MSG_START / _END / _ERR
+    uint32_t err = 0;                // 1 NotAscii, 2 UnrecognizedPrefix, 3 Malformed
+    std::string text;                // header text for StartOfMessage
+    uint32_t offset_time = 0, parity_errors = 0, voting_bytes = 0;
+    bool operator==(const MessageResult &o) const
+    {
+        return kind == o.kind && err == o.err && text == o.text && offset_time == o.offset_time &&
+               parity_errors == o.parity_errors && voting_bytes == o.voting_bytes;
+    }
+    const char *as_str() const { return kind == SAME_TRANSPORT_MSG_END ? "NNNN" : text.c_str(); }
+};
+
+// combine() rx/combiner.rs:32-80 over up to three bursts; false = None
+bool combine(const std::vector<const std::vector<uint8_t> *> &bursts, MessageResult *out);
+
+// Assembler rx/assembler.rs:108-266
+class Assembler {
+public:
+    void reset();
+    // both return the TransportState kind and fill *msg for Message states
+    uint32_t assemble(const uint8_t *burst, size_t n, uint64_t symbol_count, MessageResult *msg);
+    uint32_t idle(uint64_t symbol_count, MessageResult *msg);
+
+private:
+    struct Timed { std::vector<uint8_t> data; uint64_t deadline; };
+    void prune_history(uint64_t now);
+    void accept(const MessageResult &m, uint64_t now);
+    std::deque<Timed> history_;
+    bool pending_ = false; MessageResult pend_; uint64_t pend_deadline_ = 0;
+    bool have_prev_ = false; MessageResult prev_; uint64_t prev_deadline_ = 0;
+};
+
+// per-channel transport state of SameReceiver (receiver.rs:79, 85, 89, 291-333)
+class Transport {
+public:
+    void reset();
+    // Feed one device event (link event or tick) of this channel, in order.  Returns true
+    // and fills *out when the transport state changed (receiver.rs:256-265).
+    bool on_link_event(uint32_t kind, uint64_t sample_counter, uint64_t symbol_count,
+                       const uint8_t *bytes, uint32_t len, uint32_t input_rate, same_rx_event *out);
+    // force_eom_at_sample (receiver.rs:89): 0 = None
+    uint64_t force_eom_at() const { return have_force_eom_ ? force_eom_at_ : 0; }
+    bool force_eom_dirty() { bool d = dirty_; dirty_ = false; return d; }
+    void set_input_sample_counter_bias(int64_t) {}
+
+private:
+    Assembler asm_;
+    uint32_t state_kind_ = SAME_TRANSPORT_IDLE;
+    MessageResult state_msg_;
+    bool have_force_eom_ = false;
+    uint64_t force_eom_at_ = 0;
+    bool dirty_ = false;
+};
+
+}  // namespace same
