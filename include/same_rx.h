@@ -138,7 +138,8 @@ enum { SAME_LAYOUT_TIME_MAJOR = 0, SAME_LAYOUT_CHANNEL_MAJOR = 1 };
 /* flags for same_batch_new */
 enum {
     SAME_BATCH_LINK_ONLY = 1u << 0,   /* report link events only; skip the transport layer */
-    SAME_BATCH_TRACE_SYMBOLS = 1u << 1 /* record every soft symbol (debug / parity tests) */
+    SAME_BATCH_TRACE_SYMBOLS = 1u << 1,/* record every soft symbol (debug / parity tests) */
+    SAME_BATCH_GENERIC_KERNEL = 1u << 2 /* always use the any-configuration kernel (tests) */
 };
 
 typedef struct same_batch same_batch;

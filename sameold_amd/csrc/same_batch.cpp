@@ -9,6 +9,7 @@
 #include <algorithm>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <deque>
 #include <new>
@@ -67,6 +68,8 @@ struct same_batch {
     uint32_t *h_counters = nullptr;  // pinned
     bool in_flight = false;
     bool overflowed = false;
+    bool use_fast = false;           // configuration has a latency-optimised kernel
+    bool force_generic = false;      // SAME_BATCH_GENERIC_KERNEL (tests compare both kernels)
     // staging for host / channel-major inputs
     void *d_stage = nullptr; size_t stage_bytes = 0;
     void *d_stage2 = nullptr; size_t stage2_bytes = 0;
@@ -242,12 +245,25 @@ int process_time_major(same_batch *rx, const SampleT *d_x, size_t n_samples, hip
         HIP_TRY(hipMemsetAsync(rx->d_counters, 0, 3 * sizeof(uint32_t), stream));
         if (rx->timing) HIP_TRY(hipEventRecord(rx->ev_start, stream));
         const SampleT *xp = d_x + done * rx->P.n_channels;
-        hipError_t e;
-        if constexpr (sizeof(SampleT) == 4)
-            e = same::launch_demod(rx->P, rx->S, rx->O, rx->d_taps, (const float *)xp, (uint32_t)n, rx->counter, stream);
-        else
-            e = same::launch_demod_i16(rx->P, rx->S, rx->O, rx->d_taps, (const int16_t *)xp, (uint32_t)n, rx->counter, stream);
-        if (e != hipSuccess) return fail(SAME_EHIP, "demod kernel launch failed: %s", hipGetErrorString(e));
+        hipError_t e = hipSuccess;
+        // whole 16-sample blocks go to the latency-optimised kernel when the configuration
+        // has one; the generic kernel takes the remainder (and every other configuration)
+        size_t n_fast = (rx->use_fast && !rx->force_generic) ? (n / 16) * 16 : 0;
+        if (n_fast) {
+            if constexpr (sizeof(SampleT) == 4)
+                e = same::launch_demod_fast(rx->P, rx->S, rx->O, rx->d_taps, (const float *)xp, (uint32_t)(n_fast / 16), rx->counter, stream);
+            else
+                e = same::launch_demod_fast_i16(rx->P, rx->S, rx->O, rx->d_taps, (const int16_t *)xp, (uint32_t)(n_fast / 16), rx->counter, stream);
+            if (e != hipSuccess) return fail(SAME_EHIP, "fast demod kernel launch failed: %s", hipGetErrorString(e));
+        }
+        if (n_fast < n) {
+            const SampleT *xr = xp + n_fast * rx->P.n_channels;
+            if constexpr (sizeof(SampleT) == 4)
+                e = same::launch_demod(rx->P, rx->S, rx->O, rx->d_taps, (const float *)xr, (uint32_t)(n - n_fast), rx->counter + n_fast, stream);
+            else
+                e = same::launch_demod_i16(rx->P, rx->S, rx->O, rx->d_taps, (const int16_t *)xr, (uint32_t)(n - n_fast), rx->counter + n_fast, stream);
+            if (e != hipSuccess) return fail(SAME_EHIP, "demod kernel launch failed: %s", hipGetErrorString(e));
+        }
         if (rx->timing) HIP_TRY(hipEventRecord(rx->ev_stop, stream));
         HIP_TRY(hipMemcpyAsync(rx->h_counters, rx->d_counters, 3 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
         rx->in_flight = true;
@@ -367,6 +383,18 @@ int same_batch_new(const same_rx_builder *b, uint32_t n_channels, int device, ui
     TRY_OR_CLEAN(hipGetDeviceProperties(&prop, device));
     if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
         return cleanup(fail(SAME_ENODEVICE, "device %d is %s; this build carries gfx950 code only", device, prop.gcnArchName));
+    rx->use_fast = same::fast_kernel_supported(rx->P);
+    {
+        // thin wavefronts for small batches: aim at >= 2 wavefronts per SIMD (1024 SIMDs)
+        uint32_t lpw = 64;
+        while (lpw > 1 && (n_channels + lpw - 1) / lpw < 2048u) lpw >>= 1;
+        if (const char *e = std::getenv("SAME_LPW")) {
+            uint32_t v = (uint32_t)std::atoi(e);
+            if (v >= 1 && v <= 64 && (v & (v - 1)) == 0) lpw = v;
+        }
+        rx->P.lpw = lpw;
+    }
+    rx->force_generic = (flags & SAME_BATCH_GENERIC_KERNEL) != 0;
     if (same::demod_lds_bytes(rx->P) > 160 * 1024)
         return cleanup(fail(SAME_EINVAL, "configuration needs %zu bytes of LDS per wavefront (limit 160 KiB)", same::demod_lds_bytes(rx->P)));
     TRY_OR_CLEAN(hipStreamCreateWithFlags(&rx->own_stream, hipStreamNonBlocking));
@@ -528,6 +556,7 @@ int same_batch_last_kernel_ms(same_batch *rx, float *ms)
 const char *same_batch_kernel_name(const same_batch *rx)
 {
     if (!rx) return "";
+    if (rx->use_fast && !rx->force_generic) return "demod_fast_kernel";
     switch (rx->P.block_len) {
     case 16: return "demod_kernel<B=16>";
     case 8: return "demod_kernel<B=8>";

@@ -1,0 +1,651 @@
+// same_dev_common.h -- device functions shared by the demodulation kernels: the Rust f32
+// semantics, the per-lane register state, event emission and the whole symbol-rate path
+// (timing loop, squelch, equalizer, framer, transport wake-ups).
+//
+// Citations: file:line under /root/reference/crates/sameold/src/ ("rx/" = receiver/).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include "same_device.h"
+
+namespace same {
+
+// ---------------------------------------------------------------------------------
+// Rust f32 semantics
+// ---------------------------------------------------------------------------------
+__device__ __forceinline__ float rs_clamp(float x, float mn, float mx)
+{
+    // f32::clamp: NaN and the sign of zero pass through
+    x = (x < mn) ? mn : x;
+    x = (x > mx) ? mx : x;
+    return x;
+}
+__device__ __forceinline__ float rs_signum(float x)
+{
+    // f32::signum: +1 for +0.0, -1 for -0.0 (NaN inputs are outside the contract)
+    return __uint_as_float((__float_as_uint(x) & 0x80000000u) | 0x3f800000u);
+}
+__device__ __forceinline__ float rs_hypot(float re, float im)
+{
+    // Complex::norm() = re.hypot(im) -> glibc hypotf == (float)sqrt((double)x*x + (double)y*y)
+    double a = (double)re, b = (double)im;
+    double aa = a * a, bb = b * b;
+    return (float)sqrt(aa + bb);
+}
+
+// ---------------------------------------------------------------------------------
+// per-lane state held in registers for the duration of a launch
+// ---------------------------------------------------------------------------------
+struct Lane {
+    float sum0, sum1, gain;
+    float until_next_ted;
+    uint32_t ted_clock;
+    float h0, h1, h2, period_avg, period_inst;
+    uint32_t sq_data;
+    float sq_power;
+    uint32_t sq_phist, sq_fill;
+    int32_t sq_clock;
+    uint64_t sq_symbols;
+    uint32_t eq_word, eq_count;
+    uint32_t fr_word, fr_count, fr_invalid, fr_len;
+    uint32_t flags;
+    uint64_t tk_next, tk_last, wake_sample;
+};
+
+__device__ __forceinline__ void lane_load(Lane &L, const State &S, uint32_t c)
+{
+    L.sum0 = S.dc_sum0[c]; L.sum1 = S.dc_sum1[c]; L.gain = S.agc_gain[c];
+    L.until_next_ted = S.until_next_ted[c]; L.ted_clock = S.ted_clock[c];
+    L.h0 = S.ted_h0[c]; L.h1 = S.ted_h1[c]; L.h2 = S.ted_h2[c];
+    L.period_avg = S.period_avg[c]; L.period_inst = S.period_inst[c];
+    L.sq_data = S.sq_data[c]; L.sq_power = S.sq_power[c]; L.sq_phist = S.sq_phist[c];
+    L.sq_fill = S.sq_fill[c]; L.sq_clock = S.sq_clock[c]; L.sq_symbols = S.sq_symbols[c];
+    L.eq_word = S.eq_word[c]; L.eq_count = S.eq_count[c];
+    L.fr_word = S.fr_word[c]; L.fr_count = S.fr_count[c]; L.fr_invalid = S.fr_invalid[c];
+    L.fr_len = S.fr_len[c]; L.flags = S.flags[c];
+    L.tk_next = S.tk_next[c]; L.tk_last = S.tk_last[c]; L.wake_sample = S.wake_sample[c];
+}
+__device__ __forceinline__ void lane_store(const Lane &L, const State &S, uint32_t c)
+{
+    S.dc_sum0[c] = L.sum0; S.dc_sum1[c] = L.sum1; S.agc_gain[c] = L.gain;
+    S.until_next_ted[c] = L.until_next_ted; S.ted_clock[c] = L.ted_clock;
+    S.ted_h0[c] = L.h0; S.ted_h1[c] = L.h1; S.ted_h2[c] = L.h2;
+    S.period_avg[c] = L.period_avg; S.period_inst[c] = L.period_inst;
+    S.sq_data[c] = L.sq_data; S.sq_power[c] = L.sq_power; S.sq_phist[c] = L.sq_phist;
+    S.sq_fill[c] = L.sq_fill; S.sq_clock[c] = L.sq_clock; S.sq_symbols[c] = L.sq_symbols;
+    S.eq_word[c] = L.eq_word; S.eq_count[c] = L.eq_count;
+    S.fr_word[c] = L.fr_word; S.fr_count[c] = L.fr_count; S.fr_invalid[c] = L.fr_invalid;
+    S.fr_len[c] = L.fr_len; S.flags[c] = L.flags;
+    S.tk_next[c] = L.tk_next; S.tk_last[c] = L.tk_last; S.wake_sample[c] = L.wake_sample;
+}
+
+// ---------------------------------------------------------------------------------
+// events
+// ---------------------------------------------------------------------------------
+// Out of line, and fed scalars only: a by-reference struct argument would force the
+// kernel's Params/State/Lane copies out of registers into scratch around every call.
+static __device__ __noinline__ void emit_event_raw(DevEvent *events, uint32_t *counters, uint32_t event_cap,
+                                                   uint8_t *bursts, uint32_t burst_cap, const uint8_t *fr_row,
+                                                   uint32_t c, uint32_t kind, uint64_t sample_counter,
+                                                   uint64_t symbols, uint32_t burst_len)
+{
+    // counters: [0] events cursor, [1] bursts cursor, [2] overflow flags
+    uint32_t slot = 0xffffffffu;
+    if (kind == 3u) {  // SAME_LINK_BURST: copy the framer buffer row into the pool
+        uint32_t b = atomicAdd(counters + 1, 1u);
+        if (b < burst_cap) {
+            slot = b;
+            const uint4 *src = reinterpret_cast<const uint4 *>(fr_row);
+            uint4 *dst = reinterpret_cast<uint4 *>(bursts + (size_t)b * kBurstCap);
+#pragma unroll
+            for (int i = 0; i < kBurstCap / 16; ++i) dst[i] = src[i];
+        } else {
+            atomicOr(counters + 2, 2u);
+        }
+    }
+    uint32_t e = atomicAdd(counters, 1u);
+    if (e < event_cap) {
+        DevEvent ev;
+        ev.channel = c; ev.kind = kind; ev.sample_counter = sample_counter;
+        ev.symbol_count = symbols; ev.burst_len = burst_len; ev.burst_slot = slot;
+        events[e] = ev;
+    } else {
+        atomicOr(counters + 2, 1u);
+    }
+}
+__device__ __forceinline__ void emit_event(const Params &P, const State &S, const Output &O,
+                                           uint32_t c, uint32_t kind, uint64_t sample_counter,
+                                           uint64_t symbols, uint32_t burst_len)
+{
+    emit_event_raw(O.events, O.n_events, O.event_cap, O.bursts, O.burst_cap,
+                   S.fr_msg + (size_t)c * kBurstCap, c, kind, sample_counter, symbols, burst_len);
+}
+
+// ---------------------------------------------------------------------------------
+// framer (rx/framing.rs) -- integer work, one byte at a time
+// ---------------------------------------------------------------------------------
+__device__ __forceinline__ bool is_allowed_byte(uint32_t c)
+{
+    // rx/combiner.rs:105-137
+    return c == '-' || (c >= '0' && c <= '9') || (c >= 'A' && c <= 'Z') ||
+           (c >= 'a' && c <= 'z') || c == '/' || c == '?' || c == '(' || c == ')' ||
+           c == '[' || c == ']' || c == '.' || c == '_' || c == ',' || c == '+' || c == ' ';
+}
+__device__ __forceinline__ uint32_t fr_state(const Lane &L)
+{ return (L.flags & F_FR_STATE_MASK) >> F_FR_STATE_SHIFT; }
+__device__ __forceinline__ void fr_set_state(Lane &L, uint32_t s)
+{ L.flags = (L.flags & ~F_FR_STATE_MASK) | (s << F_FR_STATE_SHIFT); }
+// Framer::state() rx/framing.rs:191-197 -- framer state numbers equal LinkState kinds 0..2
+__device__ __forceinline__ uint32_t framer_state(const Lane &L) { return fr_state(L); }
+
+// Framer::end() rx/framing.rs:174-186.  Returns the LinkState kind; for a Burst, *burst_len
+// is its length and the bytes are still in S.fr_msg (emit_event copies them).
+__device__ __forceinline__ uint32_t framer_end(Lane &L, uint32_t *burst_len)
+{
+    uint32_t st = fr_state(L);
+    fr_set_state(L, 0);
+    if (st == 2u) { *burst_len = L.fr_len; return 3u; }
+    return 0u;
+}
+__device__ __forceinline__ void framer_push(Lane &L, const State &S, uint32_t c, uint32_t byte)
+{
+    if (L.fr_len < (uint32_t)kBurstCap) S.fr_msg[(size_t)c * kBurstCap + L.fr_len] = (uint8_t)byte;
+    L.fr_len += 1;
+}
+// the non-restart arm of Framer::input rx/framing.rs:124-164
+__device__ __forceinline__ uint32_t framer_feed(const Params &P, Lane &L, const State &S,
+                                                uint32_t c, uint32_t data, uint32_t *burst_len)
+{
+    uint32_t st = fr_state(L);
+    if (st == 0u) return 0u;
+    if (st == 1u) {
+        L.fr_word = (L.fr_word << 8) | data;
+        L.fr_count += 1;
+        uint32_t e0 = __popc(L.fr_word ^ 0x5a435a43u);   // "ZCZC" rx/framing.rs:235-243
+        uint32_t e1 = __popc(L.fr_word ^ 0x4e4e4e4eu);   // "NNNN"
+        if (min(e0, e1) <= P.fr_max_prefix_errors) {
+            L.fr_len = 0;
+            framer_push(L, S, c, (L.fr_word >> 24) & 0xff);
+            framer_push(L, S, c, (L.fr_word >> 16) & 0xff);
+            framer_push(L, S, c, (L.fr_word >> 8) & 0xff);
+            framer_push(L, S, c, L.fr_word & 0xff);
+            L.fr_invalid = 0;
+            fr_set_state(L, 2);
+        } else if (L.fr_count > 21u) {                   // PREFIX_SEARCH_LEN :201
+            fr_set_state(L, 0);
+        }
+        return framer_state(L);
+    }
+    L.fr_invalid += is_allowed_byte(data) ? 0u : 1u;
+    if (L.fr_invalid > P.fr_max_invalid) return framer_end(L, burst_len);
+    framer_push(L, S, c, data);
+    return framer_state(L);
+}
+
+// ---------------------------------------------------------------------------------
+// equalizer (rx/equalize.rs): NLMS decision-feedback equalizer, 16 samples -> 1 byte
+// ---------------------------------------------------------------------------------
+// Window arrays are stored oldest-first: w[0] oldest ... w[N-1] newest.
+// One Equalizer::estimate_symbol (rx/equalize.rs:249-308) on coefficient/window arrays held
+// in registers; returns the decided bit.  Window arrays are oldest-first.
+template <int NFF, int NFB>
+__device__ __forceinline__ uint32_t eq_symbol_core(const Params &P, Lane &L, float (&ffc)[NFF],
+                                                   float (&ffw)[NFF], float (&fbc)[NFB],
+                                                   float (&fbw)[NFB], float in0, float in1)
+{
+    uint32_t mode = (L.flags & F_EQ_MODE_MASK) >> F_EQ_MODE_SHIFT;
+    // feedforward_wind.push(input) rx/equalize.rs:253 (Window::push rx/filter.rs:258-275)
+    if (NFF >= 2) {
+#pragma unroll
+        for (int i = 0; i + 2 < NFF; ++i) ffw[i] = ffw[i + 2];
+        ffw[NFF >= 2 ? NFF - 2 : 0] = in0;
+        ffw[NFF - 1] = in1;
+    } else {
+        ffw[0] = in1;
+    }
+    // multiply_accumulate: newest sample times coeff[0] first (rx/filter.rs:363-377)
+    float ff = 0.0f;
+#pragma unroll
+    for (int i = 0; i < NFF; ++i) { float p = ffw[NFF - 1 - i] * ffc[i]; ff += p; }
+    float fb = 0.0f;
+#pragma unroll
+    for (int i = 0; i < NFB; ++i) { float p = fbw[NFB - 1 - i] * fbc[i]; fb += p; }
+    float sym_val = ff - fb;
+    float sym_est, err;
+    bool evolve = true;
+    if (mode == 2u) {                                  // EnabledTraining :278-301
+        float bit = (float)(L.eq_word & 1u);
+        float tb = 2.0f * bit;
+        sym_est = tb - 1.0f;
+        L.eq_word >>= 1;
+        err = sym_est - sym_val;
+        L.eq_count += 1;
+        if (L.eq_count >= 32u) mode = 1u;
+    } else if (mode == 1u) {                           // EnabledFeedback :266-277
+        sym_est = rs_signum(sym_val);
+        err = sym_est - sym_val;
+    } else {                                           // Disabled :262-265
+        sym_est = rs_signum(sym_val); err = 0.0f; evolve = false;
+    }
+    if (evolve) {
+        // nlms_update rx/equalize.rs:354-386: gain = relax / (reg + sum w^2, oldest first)
+        float sumsq = 0.0f;
+#pragma unroll
+        for (int i = 0; i < NFF; ++i) { float q = ffw[i] * ffw[i]; sumsq += q; }
+        float gain = P.eq_relaxation / (P.eq_regularization + sumsq);
+        float ge = gain * err;
+#pragma unroll
+        for (int i = 0; i < NFF; ++i) { float p = ge * ffw[NFF - 1 - i]; ffc[i] += p; }
+        float nerr = -err;
+        sumsq = 0.0f;
+#pragma unroll
+        for (int i = 0; i < NFB; ++i) { float q = fbw[i] * fbw[i]; sumsq += q; }
+        gain = P.eq_relaxation / (P.eq_regularization + sumsq);
+        ge = gain * nerr;
+#pragma unroll
+        for (int i = 0; i < NFB; ++i) { float p = ge * fbw[NFB - 1 - i]; fbc[i] += p; }
+    }
+    // feedback_wind.push(&[out.0, 0.0]) :304
+    if (NFB >= 2) {
+#pragma unroll
+        for (int i = 0; i + 2 < NFB; ++i) fbw[i] = fbw[i + 2];
+        fbw[NFB >= 2 ? NFB - 2 : 0] = sym_est;
+        fbw[NFB - 1] = 0.0f;
+    } else {
+        fbw[0] = 0.0f;
+    }
+    L.flags = (L.flags & ~F_EQ_MODE_MASK) | (mode << F_EQ_MODE_SHIFT);
+    return sym_est >= 0.0f ? 1u : 0u;
+}
+
+// the same with the state fetched from / returned to the HBM state arrays
+template <int NFF, int NFB>
+__device__ __forceinline__ uint32_t eq_symbols_regs(const Params &P, Lane &L, const State &S, uint32_t c,
+                                                    const float *samples, int nsym)
+{
+    const uint32_t C = P.n_channels;
+    float ffc[NFF], ffw[NFF], fbc[NFB], fbw[NFB];
+#pragma unroll
+    for (int i = 0; i < NFF; ++i) { ffc[i] = S.eq_ffc[i * C + c]; ffw[i] = S.eq_ffw[i * C + c]; }
+#pragma unroll
+    for (int i = 0; i < NFB; ++i) { fbc[i] = S.eq_fbc[i * C + c]; fbw[i] = S.eq_fbw[i * C + c]; }
+    uint32_t bits = 0;
+#pragma unroll 1
+    for (int b = 0; b < nsym; ++b)
+        bits |= eq_symbol_core<NFF, NFB>(P, L, ffc, ffw, fbc, fbw, samples[2 * b], samples[2 * b + 1]) << b;
+#pragma unroll
+    for (int i = 0; i < NFF; ++i) { S.eq_ffc[i * C + c] = ffc[i]; S.eq_ffw[i * C + c] = ffw[i]; }
+#pragma unroll
+    for (int i = 0; i < NFB; ++i) { S.eq_fbc[i * C + c] = fbc[i]; S.eq_fbw[i * C + c] = fbw[i]; }
+    return bits;
+}
+
+// any filter order up to kMaxEqTaps, working directly on the state arrays
+__device__ __forceinline__ uint32_t eq_symbols_generic(const Params &P, Lane &L, const State &S,
+                                                       uint32_t c, const float *samples, int nsym)
+{
+    const uint32_t C = P.n_channels;
+    const int NFF = (int)P.eq_nff, NFB = (int)P.eq_nfb;
+    float *ffc = S.eq_ffc + c, *ffw = S.eq_ffw + c, *fbc = S.eq_fbc + c, *fbw = S.eq_fbw + c;
+    uint32_t mode = (L.flags & F_EQ_MODE_MASK) >> F_EQ_MODE_SHIFT;
+    uint32_t byte = 0;
+    for (int b = 0; b < nsym; ++b) {
+        float in0 = samples[2 * b], in1 = samples[2 * b + 1];
+        if (NFF >= 2) {
+            for (int i = 0; i + 2 < NFF; ++i) ffw[i * C] = ffw[(i + 2) * C];
+            ffw[(NFF - 2) * C] = in0; ffw[(NFF - 1) * C] = in1;
+        } else {
+            ffw[0] = in1;
+        }
+        float ff = 0.0f;
+        for (int i = 0; i < NFF; ++i) { float p = ffw[(NFF - 1 - i) * C] * ffc[i * C]; ff += p; }
+        float fb = 0.0f;
+        for (int i = 0; i < NFB; ++i) { float p = fbw[(NFB - 1 - i) * C] * fbc[i * C]; fb += p; }
+        float sym_val = ff - fb;
+        float sym_est, err;
+        bool evolve = true;
+        if (mode == 2u) {
+            float bit = (float)(L.eq_word & 1u);
+            float tb = 2.0f * bit;
+            sym_est = tb - 1.0f;
+            L.eq_word >>= 1;
+            err = sym_est - sym_val;
+            L.eq_count += 1;
+            if (L.eq_count >= 32u) mode = 1u;
+        } else if (mode == 1u) {
+            sym_est = rs_signum(sym_val);
+            err = sym_est - sym_val;
+        } else {
+            sym_est = rs_signum(sym_val); err = 0.0f; evolve = false;
+        }
+        if (evolve) {
+            float sumsq = 0.0f;
+            for (int i = 0; i < NFF; ++i) { float v = ffw[i * C]; float q = v * v; sumsq += q; }
+            float gain = P.eq_relaxation / (P.eq_regularization + sumsq);
+            float ge = gain * err;
+            for (int i = 0; i < NFF; ++i) { float p = ge * ffw[(NFF - 1 - i) * C]; ffc[i * C] += p; }
+            float nerr = -err;
+            sumsq = 0.0f;
+            for (int i = 0; i < NFB; ++i) { float v = fbw[i * C]; float q = v * v; sumsq += q; }
+            gain = P.eq_relaxation / (P.eq_regularization + sumsq);
+            ge = gain * nerr;
+            for (int i = 0; i < NFB; ++i) { float p = ge * fbw[(NFB - 1 - i) * C]; fbc[i * C] += p; }
+        }
+        if (NFB >= 2) {
+            for (int i = 0; i + 2 < NFB; ++i) fbw[i * C] = fbw[(i + 2) * C];
+            fbw[(NFB - 2) * C] = sym_est; fbw[(NFB - 1) * C] = 0.0f;
+        } else {
+            fbw[0] = 0.0f;
+        }
+        byte |= (sym_est >= 0.0f ? 1u : 0u) << b;
+    }
+    L.flags = (L.flags & ~F_EQ_MODE_MASK) | (mode << F_EQ_MODE_SHIFT);
+    return byte;
+}
+
+// Equalizer::reset rx/equalize.rs:191-196 (mode is preserved)
+__device__ __forceinline__ void eq_reset(const Params &P, const State &S, uint32_t c)
+{
+    const uint32_t C = P.n_channels;
+    for (uint32_t i = 0; i < P.eq_nff; ++i) { S.eq_ffc[i * C + c] = (i == 0) ? 1.0f : 0.0f; S.eq_ffw[i * C + c] = 0.0f; }
+    for (uint32_t i = 0; i < P.eq_nfb; ++i) { S.eq_fbc[i * C + c] = (i == 0) ? 1.0f : 0.0f; S.eq_fbw[i * C + c] = 0.0f; }
+}
+
+// Where the symbol-rate state that is too big for registers lives.  GlobalCtx keeps the
+// squelch sample history and the equalizer in the HBM state arrays (any configuration);
+// the fast kernel supplies a context with the history in LDS and the equalizer in VGPRs.
+struct GlobalCtx {
+    const State &S;
+    uint32_t c, C;
+    __device__ __forceinline__ void hist_put(uint32_t slot, float v) const { S.sq_hist[slot * C + c] = v; }
+    __device__ __forceinline__ float hist_get(uint32_t slot) const { return S.sq_hist[slot * C + c]; }
+    // run the equalizer over nsym symbols (2 samples each); bit b of the result = symbol b
+    __device__ __forceinline__ uint32_t eq_symbols(const Params &P, Lane &L, const float *samples, int nsym) const
+    {
+        if (P.eq_nff == 6u && P.eq_nfb == 4u) return eq_symbols_regs<6, 4>(P, L, S, c, samples, nsym);
+        if (P.eq_nff == 1u && P.eq_nfb == 1u) return eq_symbols_regs<1, 1>(P, L, S, c, samples, nsym);
+        return eq_symbols_generic(P, L, S, c, samples, nsym);
+    }
+    __device__ __forceinline__ uint32_t eq_symbol1(const Params &P, Lane &L, float in0, float in1) const
+    { float two[2] = {in0, in1}; return eq_symbols(P, L, two, 1); }
+    __device__ __forceinline__ void eq_reset(const Params &P) const { same::eq_reset(P, S, c); }
+};
+
+// SameReceiver::end receiver.rs:479-490
+template <typename Ctx>
+__device__ __forceinline__ void rx_end(const Params &P, Lane &L, Ctx &X)
+{
+    L.flags &= ~(F_AGC_LOCKED | F_SQ_LOCK | F_BW_LOCKED | F_TED_PHASE);
+    L.sq_clock = -1;                                       // squelch.end() rx/codesquelch.rs:336-339
+    X.eq_reset(P);
+    // symsync.set_loop_bandwidth(unlocked); symsync.reset() rx/symsync.rs:166-170, 265-271
+    L.h0 = 0.0f; L.h1 = 0.0f; L.h2 = 0.0f;
+    L.period_avg = P.samples_per_ted; L.period_inst = P.samples_per_ted;
+}
+
+// ---------------------------------------------------------------------------------
+// symbol-rate processing: SameReceiver::process_linklayer_symbol receiver.rs:407-474
+// returns the LinkState kind
+// ---------------------------------------------------------------------------------
+template <typename Ctx>
+__device__ __forceinline__ uint32_t rx_symbol(const Params &P, Lane &L, const State &S, Ctx &X,
+                                              uint32_t c, float zero, float sym, uint32_t *burst_len)
+{
+    // --- CodeAndPowerSquelch::input rx/codesquelch.rs:228-304
+    uint32_t slot = (uint32_t)(2u * (uint32_t)L.sq_symbols) & 63u;
+    X.hist_put(slot, zero);
+    X.hist_put(slot + 1u, sym);
+    L.sq_fill = min(64u, L.sq_fill + 2u);
+    uint32_t bit = (sym >= 0.0f) ? 1u : 0u;                 // CodeCorrelator::search :421-428
+    L.sq_data = (L.sq_data >> 1) | (bit << 31);
+    uint32_t nerr = __popc(P.sync_word ^ L.sq_data);
+    float pw = sym * sym;                                   // PowerTracker::track :483-488
+    float dp = pw - L.sq_power;
+    float up = dp * P.sq_bw;
+    L.sq_power += up;
+    L.sq_power = fmaxf(L.sq_power, 0.0f);
+    float pwr = L.sq_power;
+    L.sq_phist = (L.sq_phist << 1) | ((pwr >= P.sq_power_close) ? 1u : 0u);
+    L.sq_symbols += 1;
+    const bool was_locked = (L.flags & F_SQ_LOCK) != 0;     // squelch sync lock before this symbol
+
+    enum { NO_CARRIER, DROPPED, READING, READY };
+    int st;
+    bool adjusted = false;
+    if (L.sq_fill < 64u) {
+        st = NO_CARRIER;
+    } else {
+        st = -1;
+        if (!(L.flags & F_SQ_LOCK) && nerr <= P.sq_max_errors && pwr >= P.sq_power_open) {
+            adjusted = (L.sq_clock != 0);
+            L.sq_clock = 0;
+        } else if (L.sq_clock >= 0 && !(L.sq_phist & 0x80000000u)) {
+            // power_history.front(): the flag pushed 31 symbols ago
+            L.flags &= ~F_SQ_LOCK; L.sq_clock = -1;
+            st = DROPPED;
+        }
+        if (st < 0) {
+            if (L.sq_clock < 0) st = NO_CARRIER;
+            else if (L.sq_clock == 0) { L.sq_clock = 1; st = READY; }
+            else { L.sq_clock = (L.sq_clock + 1) % 8; st = READING; }
+        }
+    }
+
+    // --- receiver.rs:409-443
+    if (st == NO_CARRIER) return framer_end(L, burst_len);
+    if (st == DROPPED) { rx_end(P, L, X); return framer_end(L, burst_len); }
+    // Equalizer schedule.  The reference runs the equalizer over the 8 symbols of a byte when
+    // the squelch's byte clock wraps (rx/codesquelch.rs:283-299 -> rx/equalize.rs:173-186): the
+    // symbols are the OLDEST 16 history samples, i.e. they were all known 24 symbols earlier.
+    // Once the framer has locked the squelch sync (receiver.rs:461-465) the byte clock can no
+    // longer be re-aligned, so the byte boundaries are known in advance and symbol j of the next
+    // byte can be equalized during the j-th "Reading" symbol before it is due: at that moment it
+    // sits at history offset 14/15 from the oldest sample.  The equalizer sees the same symbols
+    // in the same order, so its state and output are identical; what changes is that the
+    // work arrives as one short step per symbol instead of an 8-symbol burst per byte, which is
+    // what keeps a 64-lane wavefront from serialising on whichever lane has a byte due.  If the
+    // carrier drops mid-byte the partial progress is discarded by the reset in end(), exactly as
+    // the reference discards an equalizer that never saw those symbols.
+    const uint32_t head = (uint32_t)(2u * (uint32_t)L.sq_symbols) & 63u;   // oldest sample
+    if (st == READING) {
+        if (was_locked) {
+            const uint32_t j = (uint32_t)(L.sq_clock == 0 ? 7 : L.sq_clock - 1) - 1u;   // clock before - 1
+            uint32_t bit = X.eq_symbol1(P, L, X.hist_get((head + 14u) & 63u), X.hist_get((head + 15u) & 63u));
+            uint32_t bits = (j == 0u) ? 0u : ((L.flags & F_EQ_BITS_MASK) >> F_EQ_BITS_SHIFT);
+            bits |= bit << j;
+            L.flags = (L.flags & ~F_EQ_BITS_MASK) | (bits << F_EQ_BITS_SHIFT);
+        }
+        return framer_state(L);
+    }
+
+    if (adjusted) {
+        L.flags |= F_AGC_LOCKED | F_BW_LOCKED;              // agc.lock(true); locked loop bandwidth
+        L.flags = (L.flags & ~F_EQ_MODE_MASK) | (2u << F_EQ_MODE_SHIFT);   // equalizer.train()
+        L.eq_word = P.sync_word; L.eq_count = 0;
+    }
+    // --- equalizer receiver.rs:446
+    uint32_t byte;
+    if (was_locked) {
+        // symbols 0..6 of this byte were equalized as they became due; finish with symbol 7
+        uint32_t bit = X.eq_symbol1(P, L, X.hist_get((head + 14u) & 63u), X.hist_get((head + 15u) & 63u));
+        byte = ((L.flags & F_EQ_BITS_MASK) >> F_EQ_BITS_SHIFT) | (bit << 7);
+    } else {
+        // the oldest 16 samples of the history (rx/codesquelch.rs:288-294)
+        float samples[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) samples[i] = X.hist_get((head + i) & 63u);
+        byte = X.eq_symbols(P, L, samples, 8);
+    }
+
+    // --- framer receiver.rs:457-471, Framer::input rx/framing.rs:109-123
+    uint32_t link;
+    if (adjusted) {
+        uint32_t blen = 0;
+        uint32_t out = framer_end(L, &blen);
+        if (out == 3u) {
+            // the burst must be copied out before the restarted search overwrites nothing:
+            // fr_msg is only rewritten when a new prefix is found, which cannot happen on
+            // the first byte of a search, so the row is still intact when the caller emits.
+            *burst_len = blen;
+        }
+        fr_set_state(L, 1); L.fr_word = 0; L.fr_count = 0;
+        uint32_t dummy = 0;
+        (void)framer_feed(P, L, S, c, byte, &dummy);
+        link = (out == 3u) ? 3u : 1u;
+    } else {
+        link = framer_feed(P, L, S, c, byte, burst_len);
+    }
+    if (link == 2u) L.flags |= F_SQ_LOCK;                   // squelch.lock(true)
+    else if (link == 0u || link == 3u) rx_end(P, L, X);
+    return link;
+}
+
+// ---------------------------------------------------------------------------------
+// Transport wake-ups.  The reference polls its Assembler on every symbol whose link
+// state is NoCarrier or Burst (receiver.rs:292-315), but the answer can only change
+//   (1) at a Burst,
+//   (2) at the first poll on/after a pending message's deadline, burst + 682 symbols
+//       (rx/assembler.rs:294-299), or after the history empties, last burst + 5652,
+//   (3) at the first poll after the forced-EOM sample instant (receiver.rs:300-309),
+//   (4) at the poll following any of the above (a Message state decays to Assembling/Idle).
+// The device reports those poll instants as SAME_DEV_TICK events (kind 8) so the host can
+// replay the Assembler with identical sample counters.
+// ---------------------------------------------------------------------------------
+static constexpr uint64_t kNoDeadline = ~0ull;
+
+__device__ __forceinline__ uint64_t tick_min(const Lane &L, const State &S, uint32_t C, uint32_t c, uint32_t n)
+{
+    uint64_t m = L.tk_last;
+    if (n) { uint64_t f = S.tk_ring[c]; m = f < m ? f : m; }   // ring is oldest (smallest) first
+    return m;
+}
+__device__ __forceinline__ void tick_on_burst(const Params &P, Lane &L, const State &S, uint32_t c)
+{
+    const uint32_t C = P.n_channels;
+    uint32_t n = S.tk_n[c];
+    if (n == (uint32_t)kTickRing) {          // full: drop the oldest deadline
+        for (uint32_t i = 1; i < n; ++i) S.tk_ring[(i - 1) * C + c] = S.tk_ring[i * C + c];
+        n -= 1;
+    }
+    S.tk_ring[n * C + c] = L.sq_symbols + P.tick_interburst;
+    n += 1;
+    S.tk_n[c] = n;
+    L.tk_last = L.sq_symbols + P.tick_history;
+    L.tk_next = tick_min(L, S, C, c, n);
+    L.flags |= F_TICK_AGAIN;
+}
+__device__ __forceinline__ void tick_poll(const Params &P, Lane &L, const State &S, const Output &O,
+                                       uint32_t c, uint64_t counter)
+{
+    const uint32_t C = P.n_channels;
+    const uint64_t sym = L.sq_symbols;
+    const bool expired = sym >= L.tk_next;
+    const bool woke = L.wake_sample != 0 && counter > L.wake_sample;
+    emit_event(P, S, O, c, 8u, counter, sym, 0);
+    L.flags &= ~F_TICK_AGAIN;
+    if (woke) L.wake_sample = 0;
+    if (expired) {
+        uint32_t n = S.tk_n[c], drop = 0;
+        while (drop < n && S.tk_ring[drop * C + c] <= sym) ++drop;
+        if (drop) {
+            for (uint32_t i = drop; i < n; ++i) S.tk_ring[(i - drop) * C + c] = S.tk_ring[i * C + c];
+            n -= drop;
+            S.tk_n[c] = n;
+        }
+        if (L.tk_last <= sym) L.tk_last = kNoDeadline;
+        L.tk_next = tick_min(L, S, C, c, n);
+    }
+    if (expired || woke) L.flags |= F_TICK_AGAIN;
+}
+
+// ---------------------------------------------------------------------------------
+// One TED instant: matched filters -> timing loop -> (every other instant) a symbol.
+// process_linklayer_low_rate receiver.rs:376-395.  `newest` is the window-ring slot of
+// the sample on which the TED fired; `rem` is clock_remaining_sa; `counter` is
+// input_sample_counter at that sample.
+// ---------------------------------------------------------------------------------
+__device__ __forceinline__ float demod_now(const Params &P, const float4 *__restrict__ taps,
+                                           const float *win, uint32_t newest, uint32_t lane)
+{
+    // FskDemod::demod_now rx/demod.rs:156-164; multiply_accumulate rx/filter.rs:363-377:
+    // acc += window[newest - i] * h[i], i = 0 first, each product and each sum rounded.
+    const uint32_t mask = P.win_ring - 1u;
+    float mre = 0.0f, mim = 0.0f, sre = 0.0f, sim = 0.0f;
+    for (uint32_t i = 0; i < P.ntaps; ++i) {
+        float x = win[((newest - i) & mask) * kWave + lane];
+        float4 h = taps[i];                                 // wave-uniform: scalar load
+        float p0 = x * h.x, p1 = x * h.y, p2 = x * h.z, p3 = x * h.w;
+        mre += p0; mim += p1; sre += p2; sim += p3;
+    }
+    float d = rs_hypot(mre, mim) - rs_hypot(sre, sim);
+    return rs_clamp(d, -1.0f, 1.0f);
+}
+
+template <typename Ctx>
+__device__ __forceinline__ void ted_instant(const Params &P, Lane &L, const State &S,
+                                            const Output &O, Ctx &X, uint32_t c, float sa_low,
+                                            float rem, uint64_t counter)
+{
+    // ZeroCrossingTed::input rx/symsync.rs:278-287
+    L.h0 = L.h1; L.h1 = L.h2; L.h2 = sa_low;
+    L.flags ^= F_TED_PHASE;
+    const bool have = (L.flags & F_TED_PHASE) != 0;
+    float zero = L.h1, sym = L.h2, terr = 0.0f;
+    if (have) {
+        float d = rs_signum(L.h0) - rs_signum(L.h2);        // zero_crossing_metric :311-322
+        terr = L.h1 * d;
+    }
+    // TimingLoop::advance_loop rx/symsync.rs:219-244
+    float offset = rs_clamp(rem, -0.5f, 0.5f);
+    if (have) {
+        float q = offset / P.samples_per_ted;
+        float e0 = terr - q;
+        float e = rs_clamp(e0, -1.0f, 1.0f);
+        const bool locked = (L.flags & F_BW_LOCKED) != 0;
+        float alpha = locked ? P.alpha_locked : P.alpha_unlocked;
+        float beta = locked ? P.beta_locked : P.beta_unlocked;
+        float bi = beta * e;
+        L.period_avg += bi;
+        L.period_avg = rs_clamp(L.period_avg, P.period_min, P.period_max);
+        float ai = alpha * e;
+        float t = L.period_avg + ai;
+        L.period_inst = t + offset;
+        if (L.period_inst < 0.0f) L.period_inst = L.period_avg;
+    } else {
+        L.period_inst += offset;
+    }
+    L.until_next_ted = L.period_inst;                       // receiver.rs:382
+    if (!have) return;                                      // receiver.rs:383
+
+    if (P.trace_cap) {
+        uint32_t n = S.trace_n[c];
+        if (n < P.trace_cap) {
+            float *t = S.trace + ((size_t)c * P.trace_cap + n) * 4;
+            t[0] = zero; t[1] = sym; t[2] = terr; t[3] = L.until_next_ted;
+            S.trace_idx[(size_t)c * P.trace_cap + n] = counter;
+        }
+        S.trace_n[c] = n + 1;
+    }
+
+    uint32_t burst_len = 0;
+    uint32_t link = rx_symbol(P, L, S, X, c, zero, sym, &burst_len);
+    // receiver.rs:246-253: report on change (a Burst always differs from its predecessor)
+    uint32_t last = (L.flags & F_LINK_MASK) >> F_LINK_SHIFT;
+    if (link != last || link == 3u) {
+        L.flags = (L.flags & ~F_LINK_MASK) | (link << F_LINK_SHIFT);
+        emit_event(P, S, O, c, link, counter, L.sq_symbols, burst_len);
+    }
+    if (P.ticks) {
+        if (link == 3u) {
+            tick_on_burst(P, L, S, c);
+        } else if (link == 0u) {
+            if ((L.flags & F_TICK_AGAIN) || L.sq_symbols >= L.tk_next ||
+                (L.wake_sample != 0 && counter > L.wake_sample))
+                tick_poll(P, L, S, O, c, counter);
+        }
+    }
+}
+
+
+}  // namespace same

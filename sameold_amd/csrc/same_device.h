@@ -48,6 +48,10 @@ struct Params {
     uint32_t ticks;
     uint32_t tick_interburst; // MAX_INTERBURST_SYMBOLS  (rx/assembler.rs:85)
     uint32_t tick_history;    // MAX_HISTORY_DURATION    (rx/assembler.rs:92-93)
+    // channels (active lanes) per wavefront of the fast kernel, a power of two <= 64.  Small
+    // batches use thin wavefronts: the serial per-channel instruction stream, not lane count,
+    // bounds throughput, so fewer lanes per wave = less divergence and more waves in flight.
+    uint32_t lpw;
 };
 
 // flag bits of State::flags
@@ -63,6 +67,8 @@ enum : uint32_t {
     F_LINK_SHIFT = 8,           // 2 bits: last reported LinkState kind
     F_LINK_MASK = 3u << 8,
     F_TICK_AGAIN = 1u << 10,    // report the next transport poll instant too
+    F_EQ_BITS_SHIFT = 16,       // 8 bits: symbols of the current byte already equalized
+    F_EQ_BITS_MASK = 0xffu << 16,
 };
 constexpr int kTickRing = 8;     // pending burst+interburst deadlines per channel
 

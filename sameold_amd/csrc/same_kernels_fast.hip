@@ -1,0 +1,402 @@
+// same_kernels_fast.hip -- latency-optimised demodulation kernel for the standard sample
+// rates (22.05 / 44.1 / 48 kHz with the reference's default DC-blocker length).
+//
+// Same arithmetic contract and the same "deferred TED" schedule as demod_kernel in
+// same_kernels.hip (one lane = one channel, blocks of 16 samples, at most one TED
+// instant per lane per block), so results are bit-identical; what changes is where state
+// lives and how memory latency is taken off the critical path:
+//
+//   * DC blocker (22.05 kHz: window length 16 = block length): both moving-average
+//     windows are the previous block's 16 inputs / 16 averages, held in VGPRs with static
+//     indices -- no LDS traffic at all.  Other rates read all of a block's aged-off ring
+//     entries from LDS up front (they cannot alias this block's writes because the window
+//     is longer than a block).
+//   * the next block's 16 input samples are fetched while the current block is computed;
+//   * the TED instant of a lane is known in advance (the sample clock is a counter
+//     against a fixed period), so the per-sample clock test collapses to one compare per
+//     block;
+//   * matched filters: window samples are pulled from the LDS ring in batches and the
+//     four accumulation chains run as two v_pk_mul_f32 / v_pk_add_f32 pairs per tap
+//     (per-element IEEE, identical rounding to the scalar form);
+//   * squelch sample history lives in LDS, the equalizer's 20 floats in VGPRs.
+//
+// Citations: file:line under /root/reference/crates/sameold/src/ ("rx/" = receiver/).
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+
+#include "same_dev_common.h"
+#include "same_device.h"
+#include "same_launch.h"
+
+namespace same {
+
+typedef float float2v __attribute__((ext_vector_type(2)));
+
+constexpr int kB = 16;   // block length of the fast kernel
+
+template <int NFF, int NFB>
+struct FastCtx {
+    float *hist;                       // LDS column of this lane: slot i at hist[i * stride]
+    uint32_t stride;                   // lanes per wavefront
+    float ffc[NFF], ffw[NFF], fbc[NFB], fbw[NFB];
+    __device__ __forceinline__ void hist_put(uint32_t slot, float v) { hist[slot * stride] = v; }
+    __device__ __forceinline__ float hist_get(uint32_t slot) const { return hist[slot * stride]; }
+    __device__ __forceinline__ uint32_t eq_symbols(const Params &P, Lane &L, const float *samples, int nsym)
+    {
+        uint32_t bits = 0;
+#pragma unroll 1
+        for (int b = 0; b < nsym; ++b)
+            bits |= eq_symbol_core<NFF, NFB>(P, L, ffc, ffw, fbc, fbw, samples[2 * b], samples[2 * b + 1]) << b;
+        return bits;
+    }
+    __device__ __forceinline__ uint32_t eq_symbol1(const Params &P, Lane &L, float in0, float in1)
+    { return eq_symbol_core<NFF, NFB>(P, L, ffc, ffw, fbc, fbw, in0, in1); }
+    __device__ __forceinline__ void eq_reset(const Params &)
+    {
+        // Equalizer::reset rx/equalize.rs:191-196
+#pragma unroll
+        for (int i = 0; i < NFF; ++i) { ffc[i] = (i == 0) ? 1.0f : 0.0f; ffw[i] = 0.0f; }
+#pragma unroll
+        for (int i = 0; i < NFB; ++i) { fbc[i] = (i == 0) ? 1.0f : 0.0f; fbw[i] = 0.0f; }
+    }
+};
+
+// Sample count (since the last TED instant) at which the sample clock fires next:
+// receiver.rs:352-353 tests rem = samples_until_next_ted - clock after each increment and
+// fires when rem <= 0 || |rem| < 0.5, i.e. at the first count c > clock with
+// fl(s - c) < 0.5.  fl(s - c) is non-increasing in c, so the first hit can be searched
+// from just below s.
+__device__ __forceinline__ int next_fire_count(float s, uint32_t clock)
+{
+    float f = floorf(s) - 1.0f;
+    int c = (int)clock + 1;
+    if (f > (float)c) c = (int)f;
+    while (!((s - (float)c) < 0.5f)) ++c;
+    return c;
+}
+
+template <int NT, int RING>
+__device__ __forceinline__ float demod_fast(const float4 *__restrict__ taps, const float *wcol,
+                                            uint32_t lane, uint32_t newest, uint32_t lpw)
+{
+    // FskDemod::demod_now rx/demod.rs:156-164 over multiply_accumulate rx/filter.rs:363-377:
+    // acc += window[newest - i] * h[i], i = 0 first; (mark.re, mark.im) and (space.re, space.im)
+    // ride in the two halves of packed f32 operations.
+    //
+    // Taps are wave-uniform and come in through scalar loads, CH at a time: the chunk loop is
+    // deliberately NOT unrolled, otherwise all 4*NT tap words are hoisted into SGPRs at once
+    // and spill.  Window samples of a chunk are fetched from LDS before the arithmetic.
+    // Byte address of tap i in the ring: slot (newest - i) mod RING, lpw*4 bytes per slot, so
+    // stepping back one tap is "subtract the slot pitch, wrap at RING*pitch" (lane*4 < pitch
+    // stays intact because both are powers of two).
+    constexpr int CH = 7;
+    const uint32_t pitch = lpw * 4u;
+    const uint32_t WRAP = (uint32_t)RING * pitch - 1u;
+    float2v am = {0.0f, 0.0f}, as = {0.0f, 0.0f};
+    uint32_t addr = newest * pitch + lane * 4u;
+    const char *wbase = reinterpret_cast<const char *>(wcol - lane);
+#pragma unroll 1
+    for (int base = 0; base + CH <= NT; base += CH) {
+        float w[CH];
+#pragma unroll
+        for (int j = 0; j < CH; ++j) {
+            w[j] = *reinterpret_cast<const float *>(wbase + addr);
+            addr = (addr - pitch) & WRAP;
+        }
+        const float4 *h = taps + base;
+#pragma unroll
+        for (int j = 0; j < CH; ++j) {
+            const float4 t = h[j];
+            const float2v x2 = {w[j], w[j]};
+            const float2v hm = {t.x, t.y}, hs = {t.z, t.w};
+            const float2v pm = x2 * hm, ps = x2 * hs;
+            am += pm; as += ps;
+        }
+    }
+    constexpr int REM = NT % CH;
+    if (REM) {
+        float w[REM ? REM : 1];
+#pragma unroll
+        for (int j = 0; j < REM; ++j) {
+            w[j] = *reinterpret_cast<const float *>(wbase + addr);
+            addr = (addr - pitch) & WRAP;
+        }
+#pragma unroll
+        for (int j = 0; j < REM; ++j) {
+            const float4 t = taps[NT - REM + j];
+            const float2v x2 = {w[j], w[j]};
+            const float2v hm = {t.x, t.y}, hs = {t.z, t.w};
+            const float2v pm = x2 * hm, ps = x2 * hs;
+            am += pm; as += ps;
+        }
+    }
+    float d = rs_hypot(am.x, am.y) - rs_hypot(as.x, as.y);
+    return rs_clamp(d, -1.0f, 1.0f);
+}
+
+// One AGC step, rx/agc.rs:72-77:  gain += (!locked as f32) * (1 - |out|) * bandwidth, clamped.
+// `bw_eff` is the bandwidth for an unlocked AGC and 0.0 for a locked one: (1*e)*bw == e*bw
+// exactly, and (0*e)*bw and e*0 are both a zero whose sign cannot matter because the gain is
+// never -0.0 (it is a clamp output or the sum of a non-negative-zero gain and an update).
+// MED3: v_med3_f32 is bit-identical to f32::clamp for every non-NaN gain unless a bound is
+// -0.0 (the host checks the bounds); otherwise the compare/select form is used.
+template <bool MED3>
+__device__ __forceinline__ float agc_step(const Params &P, float y, float &gain, float bw_eff)
+{
+    float out = y * gain;
+    float e = 1.0f - fabsf(out);
+    float upd = e * bw_eff;
+    gain += upd;
+    if (MED3) gain = __builtin_amdgcn_fmed3f(gain, P.agc_min, P.agc_max);
+    else gain = rs_clamp(gain, P.agc_min, P.agc_max);
+    return out;
+}
+
+template <int NT, int DCL, int NFF, int NFB, bool MED3, typename SampleT>
+__global__ __launch_bounds__(kWave) void demod_fast_kernel(Params P, State S, Output O,
+                                                           const float4 *__restrict__ taps,
+                                                           const SampleT *__restrict__ x,
+                                                           uint32_t n_blocks, uint64_t counter0)
+{
+    constexpr int RING = (NT + kB - 1 <= 64) ? 64 : 128;
+    constexpr bool DC_REGS = (DCL == kB);
+    static_assert(DC_REGS || DCL > kB, "LDS DC path needs a window longer than a block");
+    static_assert(NT + kB - 1 <= 128, "window ring too small");
+    extern __shared__ float lds[];
+    const uint32_t lane = threadIdx.x;
+    const uint32_t C = P.n_channels;
+    const uint32_t LP = P.lpw;                                   // channels per wavefront
+    if (lane >= LP) return;                                      // no barriers below
+    // Workgroups are dealt round-robin over the 8 XCDs; give each XCD a contiguous range of
+    // channel groups so the wavefronts that share a 128-byte line of x[t][:] share an L2.
+    uint32_t grp = blockIdx.x;
+    if ((gridDim.x & 7u) == 0u) grp = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+    const uint32_t c = grp * LP + lane;
+    if (c >= C) return;
+    float *wcol = lds + lane;                                    // [RING][LP]
+    float *hcol = lds + RING * LP + lane;                        // [64][LP]
+    float *ffcol = lds + (RING + kSquelchHist) * LP + lane;      // [DCL][LP] (LDS DC path)
+    float *fbcol = ffcol + DCL * LP;
+
+    Lane L;
+    lane_load(L, S, c);
+    FastCtx<NFF, NFB> X;
+    X.hist = hcol;
+    X.stride = LP;
+#pragma unroll
+    for (int i = 0; i < NFF; ++i) { X.ffc[i] = S.eq_ffc[i * C + c]; X.ffw[i] = S.eq_ffw[i * C + c]; }
+#pragma unroll
+    for (int i = 0; i < NFB; ++i) { X.fbc[i] = S.eq_fbc[i * C + c]; X.fbw[i] = S.eq_fbw[i * C + c]; }
+    // state arrays are [slot][channel]: a wave-uniform row pointer plus the lane's channel
+    // index keeps the address arithmetic on the scalar unit
+#pragma unroll 2
+    for (int i = 0; i < RING; ++i) { const float *row = S.win_ring + (size_t)i * C; wcol[i * LP] = row[c]; }
+#pragma unroll 2
+    for (int i = 0; i < kSquelchHist; ++i) { const float *row = S.sq_hist + (size_t)i * C; hcol[i * LP] = row[c]; }
+
+    // ring positions common to all channels
+    uint32_t dpos = (uint32_t)(counter0 % (uint64_t)DCL);
+    uint32_t wpos = (uint32_t)(counter0 & (uint64_t)(RING - 1));
+    float xp[kB], mp[kB];              // DC_REGS: previous block's inputs / first-stage averages
+    if (DC_REGS) {
+#pragma unroll
+        for (int k = 0; k < kB; ++k) {
+            const uint32_t slot = (dpos + (uint32_t)k) & (uint32_t)(kB - 1);
+            const float *r0 = S.dc_ff_ring + (size_t)slot * C, *r1 = S.dc_fb_ring + (size_t)slot * C;
+            xp[k] = r0[c];
+            mp[k] = r1[c];
+        }
+    } else {
+#pragma unroll 2
+        for (int i = 0; i < DCL; ++i) {
+            const float *r0 = S.dc_ff_ring + (size_t)i * C, *r1 = S.dc_fb_ring + (size_t)i * C;
+            ffcol[i * LP] = r0[c];
+            fbcol[i * LP] = r1[c];
+        }
+    }
+
+    int cstar = next_fire_count(L.until_next_ted, L.ted_clock);
+    int until = cstar - (int)L.ted_clock - 1;      // block-relative index of the firing sample
+
+    float xn[kB];
+#pragma unroll
+    for (int k = 0; k < kB; ++k) { const SampleT *row = x + (size_t)k * C; xn[k] = (float)row[c]; }
+
+    for (uint32_t blk = 0; blk < n_blocks; ++blk) {
+        float xs[kB];
+#pragma unroll
+        for (int k = 0; k < kB; ++k) xs[k] = xn[k];
+        if (blk + 1 < n_blocks) {
+            const SampleT *xb = x + ((size_t)(blk + 1) * kB) * C;      // wave-uniform
+#pragma unroll
+            for (int k = 0; k < kB; ++k) { const SampleT *row = xb + (size_t)k * C; xn[k] = (float)row[c]; }
+        }
+
+        // ---- DC blocker rx/dcblock.rs:45-49, 104-108 --------------------------------
+        float ys[kB];
+        if (DC_REGS) {
+            float mnew[kB];
+#pragma unroll
+            for (int k = 0; k < kB; ++k) {
+                float d0 = xs[k] - xp[k];                    // input - aged
+                L.sum0 += d0;
+                float ma0 = L.sum0 * P.dc_inv_len;
+                float sig = (k + 1 < kB) ? xp[k + 1] : xs[0];   // window.front() after the push
+                float d1 = ma0 - mp[k];
+                L.sum1 += d1;
+                float ma1 = L.sum1 * P.dc_inv_len;
+                ys[k] = sig - ma1;                           // (len > 1) as f32 == 1.0: exact
+                mnew[k] = ma0;
+            }
+#pragma unroll
+            for (int k = 0; k < kB; ++k) { xp[k] = xs[k]; mp[k] = mnew[k]; }
+        } else {
+            float a0[kB + 1], a1[kB];
+            uint32_t slots[kB + 1];
+#pragma unroll
+            for (int k = 0; k <= kB; ++k) {
+                uint32_t s = dpos + (uint32_t)k;
+                slots[k] = (s >= (uint32_t)DCL) ? s - (uint32_t)DCL : s;
+            }
+#pragma unroll
+            for (int k = 0; k <= kB; ++k) a0[k] = ffcol[slots[k] * LP];
+#pragma unroll
+            for (int k = 0; k < kB; ++k) a1[k] = fbcol[slots[k] * LP];
+#pragma unroll
+            for (int k = 0; k < kB; ++k) {
+                float d0 = xs[k] - a0[k];
+                L.sum0 += d0;
+                float ma0 = L.sum0 * P.dc_inv_len;
+                float sig = a0[k + 1];                       // not yet overwritten: DCL > block
+                float d1 = ma0 - a1[k];
+                L.sum1 += d1;
+                float ma1 = L.sum1 * P.dc_inv_len;
+                ys[k] = sig - ma1;
+                ffcol[slots[k] * LP] = xs[k];
+                fbcol[slots[k] * LP] = ma0;
+            }
+            dpos = slots[kB];
+        }
+
+        // ---- AGC rx/agc.rs:72-77 and window push receiver.rs:345-346 -----------------
+        const float g0 = L.gain;
+        const float bw0 = (L.flags & F_AGC_LOCKED) ? 0.0f : P.agc_bw;
+#pragma unroll
+        for (int k = 0; k < kB; ++k) {
+            float out = agc_step<MED3>(P, ys[k], L.gain, bw0);
+            wcol[((wpos + (uint32_t)k) & (uint32_t)(RING - 1)) * LP] = out;
+        }
+
+        // ---- deferred TED instant ----------------------------------------------------
+        if (until < kB) {
+            const int fk = until;
+            const uint32_t newest = (wpos + (uint32_t)fk) & (uint32_t)(RING - 1);
+            const float sa_low = demod_fast<NT, RING>(taps, wcol, lane, newest, LP);
+            const float rem = L.until_next_ted - (float)cstar;          // receiver.rs:352
+            const uint32_t locked_before = L.flags & F_AGC_LOCKED;
+            ted_instant(P, L, S, O, X, c, sa_low, rem,
+                        counter0 + (uint64_t)blk * kB + (uint32_t)fk + 1u);
+            cstar = next_fire_count(L.until_next_ted, 0u);
+            until = fk + cstar;
+            if ((L.flags & F_AGC_LOCKED) != locked_before) {
+                // the lock changed at sample fk: redo the block's AGC with the old lock up
+                // to fk and the new one after it (rare: twice per burst)
+                const float bw1 = (L.flags & F_AGC_LOCKED) ? 0.0f : P.agc_bw;
+                float g = g0;
+#pragma unroll
+                for (int k = 0; k < kB; ++k) {
+                    float out = agc_step<MED3>(P, ys[k], g, (k <= fk) ? bw0 : bw1);
+                    wcol[((wpos + (uint32_t)k) & (uint32_t)(RING - 1)) * LP] = out;
+                }
+                L.gain = g;
+            }
+        }
+        until -= kB;
+        wpos = (wpos + kB) & (uint32_t)(RING - 1);
+    }
+
+    // ---- write the state back --------------------------------------------------------
+    L.ted_clock = (uint32_t)(cstar - until - 1);
+    lane_store(L, S, c);
+#pragma unroll
+    for (int i = 0; i < NFF; ++i) { S.eq_ffc[i * C + c] = X.ffc[i]; S.eq_ffw[i * C + c] = X.ffw[i]; }
+#pragma unroll
+    for (int i = 0; i < NFB; ++i) { S.eq_fbc[i * C + c] = X.fbc[i]; S.eq_fbw[i * C + c] = X.fbw[i]; }
+#pragma unroll 2
+    for (int i = 0; i < RING; ++i) { float *row = S.win_ring + (size_t)i * C; row[c] = wcol[i * LP]; }
+#pragma unroll 2
+    for (int i = 0; i < kSquelchHist; ++i) { float *row = S.sq_hist + (size_t)i * C; row[c] = hcol[i * LP]; }
+    if (DC_REGS) {
+#pragma unroll
+        for (int k = 0; k < kB; ++k) {
+            const uint32_t slot = (dpos + (uint32_t)k) & (uint32_t)(kB - 1);
+            float *r0 = S.dc_ff_ring + (size_t)slot * C, *r1 = S.dc_fb_ring + (size_t)slot * C;
+            r0[c] = xp[k];
+            r1[c] = mp[k];
+        }
+    } else {
+#pragma unroll 2
+        for (int i = 0; i < DCL; ++i) {
+            float *r0 = S.dc_ff_ring + (size_t)i * C, *r1 = S.dc_fb_ring + (size_t)i * C;
+            r0[c] = ffcol[i * LP];
+            r1[c] = fbcol[i * LP];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// dispatch
+// ---------------------------------------------------------------------------------
+template <int NT, int DCL>
+static constexpr size_t fast_lds_bytes(uint32_t lpw)
+{
+    constexpr int RING = (NT + kB - 1 <= 64) ? 64 : 128;
+    return (size_t)(RING + kSquelchHist + (DCL == kB ? 0 : 2 * DCL)) * lpw * sizeof(float);
+}
+
+template <int NT, int DCL, typename SampleT>
+static hipError_t launch_fast_cfg(const Params &P, const State &S, const Output &O, const float4 *taps,
+                                  const SampleT *x, uint32_t n_blocks, uint64_t counter0, hipStream_t stream)
+{
+    const uint32_t grid = (P.n_channels + P.lpw - 1) / P.lpw;
+    const size_t lds = fast_lds_bytes<NT, DCL>(P.lpw);
+    // v_med3_f32 == f32::clamp unless a bound is -0.0 (or NaN, which the builder rejects)
+    const bool med3 = !(P.agc_min == 0.0f && std::signbit(P.agc_min)) && !(P.agc_max == 0.0f && std::signbit(P.agc_max));
+#define SAME_FAST(NFF, NFB, M3)                                                                         \
+    hipLaunchKernelGGL((demod_fast_kernel<NT, DCL, NFF, NFB, M3, SampleT>), dim3(grid), dim3(kWave), lds, \
+                       stream, P, S, O, taps, x, n_blocks, counter0)
+    if (P.eq_nff == 6u && P.eq_nfb == 4u) { if (med3) SAME_FAST(6, 4, true); else SAME_FAST(6, 4, false); }
+    else { if (med3) SAME_FAST(1, 1, true); else SAME_FAST(1, 1, false); }
+#undef SAME_FAST
+    return hipGetLastError();
+}
+
+bool fast_kernel_supported(const Params &P)
+{
+    if (P.block_len != (uint32_t)kB || P.win_ring > 128u) return false;
+    const bool eq_ok = (P.eq_nff == 6u && P.eq_nfb == 4u) || (P.eq_nff == 1u && P.eq_nfb == 1u);
+    if (!eq_ok) return false;
+    return (P.ntaps == 42u && P.dc_len == 16u) || (P.ntaps == 92u && P.dc_len == 35u) ||
+           (P.ntaps == 84u && P.dc_len == 32u);
+}
+
+uint32_t fast_win_ring(const Params &P) { return (P.ntaps + kB - 1 <= 64u) ? 64u : 128u; }
+
+template <typename SampleT>
+static hipError_t launch_fast_t(const Params &P, const State &S, const Output &O, const float4 *taps,
+                                const SampleT *x, uint32_t n_blocks, uint64_t counter0, hipStream_t stream)
+{
+    if (P.ntaps == 42u) return launch_fast_cfg<42, 16, SampleT>(P, S, O, taps, x, n_blocks, counter0, stream);
+    if (P.ntaps == 92u) return launch_fast_cfg<92, 35, SampleT>(P, S, O, taps, x, n_blocks, counter0, stream);
+    return launch_fast_cfg<84, 32, SampleT>(P, S, O, taps, x, n_blocks, counter0, stream);
+}
+
+hipError_t launch_demod_fast(const Params &P, const State &S, const Output &O, const float4 *taps,
+                             const float *x, uint32_t n_blocks, uint64_t counter0, hipStream_t stream)
+{ return launch_fast_t<float>(P, S, O, taps, x, n_blocks, counter0, stream); }
+hipError_t launch_demod_fast_i16(const Params &P, const State &S, const Output &O, const float4 *taps,
+                                 const int16_t *x, uint32_t n_blocks, uint64_t counter0, hipStream_t stream)
+{ return launch_fast_t<int16_t>(P, S, O, taps, x, n_blocks, counter0, stream); }
+
+}  // namespace same

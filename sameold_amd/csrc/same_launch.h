@@ -12,6 +12,12 @@ hipError_t launch_demod(const Params &P, const State &S, const Output &O, const 
 hipError_t launch_demod_i16(const Params &P, const State &S, const Output &O, const float4 *taps,
                             const int16_t *x, uint32_t n_samples, uint64_t counter0, hipStream_t stream);
 size_t demod_lds_bytes(const Params &P);
+// latency-optimised kernel for the standard rates (same_kernels_fast.hip); whole blocks of 16
+bool fast_kernel_supported(const Params &P);
+hipError_t launch_demod_fast(const Params &P, const State &S, const Output &O, const float4 *taps,
+                             const float *x, uint32_t n_blocks, uint64_t counter0, hipStream_t stream);
+hipError_t launch_demod_fast_i16(const Params &P, const State &S, const Output &O, const float4 *taps,
+                                 const int16_t *x, uint32_t n_blocks, uint64_t counter0, hipStream_t stream);
 hipError_t launch_init_state(const Params &P, const State &S, int is_reset, hipStream_t stream);
 hipError_t launch_transpose_f32(const float *in, float *out, uint32_t n_channels, uint32_t n_samples,
                                 hipStream_t stream);

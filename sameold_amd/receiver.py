@@ -24,7 +24,7 @@ LIB_PATH = os.path.join(_HERE, "libsame_rx.so")
 LINK_NO_CARRIER, LINK_SEARCHING, LINK_READING, LINK_BURST = 0, 1, 2, 3
 TRANSPORT_IDLE, TRANSPORT_ASSEMBLING, TRANSPORT_MSG_START, TRANSPORT_MSG_END, TRANSPORT_MSG_ERR = 16, 17, 18, 19, 20
 LAYOUT_TIME_MAJOR, LAYOUT_CHANNEL_MAJOR = 0, 1
-BATCH_LINK_ONLY, BATCH_TRACE_SYMBOLS = 1, 2
+BATCH_LINK_ONLY, BATCH_TRACE_SYMBOLS, BATCH_GENERIC_KERNEL = 1, 2, 4
 EVENT_MAX_BYTES = 288
 
 ERRORS = {-1: "EINVAL", -2: "EDCLEN", -3: "EAGCLIMITS", -4: "EEQORDER", -5: "ENODEVICE",
@@ -272,18 +272,19 @@ class SameReceiverBuilder:
         return SameReceiver(self, device)
 
     def build_batch(self, n_channels: int, device: int = 0, link_only: bool = False,
-                    trace_symbols: bool = False) -> "SameBatchReceiver":
-        return SameBatchReceiver(self, n_channels, device, link_only, trace_symbols)
+                    trace_symbols: bool = False, generic_kernel: bool = False) -> "SameBatchReceiver":
+        return SameBatchReceiver(self, n_channels, device, link_only, trace_symbols, generic_kernel)
 
 
 class SameBatchReceiver:
     """n independent `SameReceiver`s advancing in lockstep on one MI355X."""
 
     def __init__(self, builder: SameReceiverBuilder, n_channels: int, device: int = 0,
-                 link_only: bool = False, trace_symbols: bool = False):
+                 link_only: bool = False, trace_symbols: bool = False, generic_kernel: bool = False):
         self._L = load_library()
         h = C.c_void_p()
-        flags = (BATCH_LINK_ONLY if link_only else 0) | (BATCH_TRACE_SYMBOLS if trace_symbols else 0)
+        flags = ((BATCH_LINK_ONLY if link_only else 0) | (BATCH_TRACE_SYMBOLS if trace_symbols else 0)
+                 | (BATCH_GENERIC_KERNEL if generic_kernel else 0))
         _check(self._L.same_batch_new(builder._h, n_channels, device, flags, C.byref(h)))
         self._h = h
 

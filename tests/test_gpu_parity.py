@@ -289,3 +289,49 @@ def test_hypot_matches_glibc(sa, ob):
         assert len(tr) == len(rt) > 400
         assert np.array_equal(tr["sym"].view(np.uint32), rt["sym"].view(np.uint32))
         assert np.array_equal(tr["sample_counter"], rt["sample_counter"])
+
+
+# ------------------------------------------------------------------ fast vs generic kernel
+@pytest.mark.parametrize("rate", [22050, 48000, 44100])
+def test_fast_kernel_equals_generic_kernel(sa, ob, rate):
+    """Standard rates dispatch to demod_fast_kernel; it must reproduce the any-configuration
+    kernel (and therefore the oracle) bit for bit, including when chunk sizes are not
+    multiples of the 16-sample block (remainder handled by the generic kernel)."""
+    import torch
+    n_ch, n = 128, rate * 3 + 7
+    x = mixed_batch(sa, n_ch, n, seed=rate + 1, rate=rate, noise=0.05)
+    xd = torch.from_numpy(x).cuda()
+    fast = sa.SameReceiverBuilder(rate).build_batch(n_ch, trace_symbols=True)
+    assert fast.kernel_name() == "demod_fast_kernel"
+    gen = sa.SameReceiverBuilder(rate).build_batch(n_ch, generic_kernel=True, trace_symbols=True)
+    assert gen.kernel_name().startswith("demod_kernel")
+    rng = np.random.default_rng(rate)
+    off = 0
+    while off < n:
+        k = int(rng.integers(1, 20000))
+        fast.process_tensor(xd[off:off + k].contiguous())
+        gen.process_tensor(xd[off:off + k].contiguous())
+        off += k
+    fast.sync(); gen.sync()
+    a, b = events_by_channel(fast), events_by_channel(gen)
+    assert a == b
+    for c in (0, 5, 127):
+        ta, tb = fast.read_trace(c), gen.read_trace(c)
+        assert np.array_equal(ta["sample_counter"], tb["sample_counter"])
+        assert np.array_equal(ta["sym"].view(np.uint32), tb["sym"].view(np.uint32))
+    cfg = ob.default_config(rate)
+    for c in range(0, n_ch, 9):
+        assert a.get(c, []) == oracle_events(ob, cfg, x[:, c]), f"channel {c}"
+
+
+def test_negative_zero_agc_bound_uses_exact_clamp(sa, ob):
+    """v_med3_f32 is only used when no AGC bound is -0.0; the other path must still match."""
+    n_ch, n = 64, 22050 * 2
+    x = mixed_batch(sa, n_ch, n, seed=3)
+    rx = sa.SameReceiverBuilder(22050).with_agc_gain_limits(-0.0, 1.0e6).build_batch(n_ch)
+    rx.process_host(x)
+    got = events_by_channel(rx)
+    cfg = ob.default_config(22050)
+    ob.lib().so_config_with_agc_gain_limits(C.byref(cfg), -0.0, 1.0e6)
+    for c in range(n_ch):
+        assert got.get(c, []) == oracle_events(ob, cfg, x[:, c]), f"channel {c}"

@@ -1,0 +1,25 @@
+#!/usr/bin/env python3
+"""One timed pass of the hot path for profiling: python tools/run_once.py [channels] [seconds] [reps]"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import sameold_amd as sa
+
+C = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+secs = float(sys.argv[2]) if len(sys.argv) > 2 else 2.0
+reps = int(sys.argv[3]) if len(sys.argv) > 3 else 3
+rate = int(sys.argv[4]) if len(sys.argv) > 4 else 22050
+T = int(rate * secs)
+x = sa.synth_afsk(C, T, rate, seed=1)
+torch.cuda.synchronize()
+rx = sa.SameReceiverBuilder(rate).build_batch(C, link_only=True)
+rx.set_kernel_timing(True)
+for r in range(reps):
+    t0 = time.perf_counter()
+    rx.process_tensor(x)
+    rx.sync()
+    dt = time.perf_counter() - t0
+    ms = rx.last_kernel_ms()
+    n = rx._L.same_batch_pending_events(rx._h)
+    print(f"rep {r}: kernel {ms:.3f} ms  wall {dt*1e3:.3f} ms  {C*T/ms/1e3:.1f} Msamples/s (kernel)  "
+          f"{4*C*T/ms/1e6:.2f} GB/s  events pending {n}  [{rx.kernel_name()}]", flush=True)
