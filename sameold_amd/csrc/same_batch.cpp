@@ -116,6 +116,8 @@ size_t carve_state(const same::Params &P, char *base, same::State &S)
     CARVE(eq_ffc, float, (size_t)P.eq_nff * C); CARVE(eq_fbc, float, (size_t)P.eq_nfb * C);
     CARVE(eq_ffw, float, (size_t)P.eq_nff * C); CARVE(eq_fbw, float, (size_t)P.eq_nfb * C);
     CARVE(eq_word, uint32_t, C); CARVE(eq_count, uint32_t, C);
+    CARVE(eq_snap_ffc, float, (size_t)P.eq_nff * C); CARVE(eq_snap_fbc, float, (size_t)P.eq_nfb * C);
+    CARVE(eq_snap_ffw, float, (size_t)P.eq_nff * C); CARVE(eq_snap_fbw, float, (size_t)P.eq_nfb * C);
     CARVE(fr_word, uint32_t, C); CARVE(fr_count, uint32_t, C); CARVE(fr_invalid, uint32_t, C);
     CARVE(fr_len, uint32_t, C);
     CARVE(fr_msg, uint8_t, (size_t)same::kBurstCap * C);
@@ -384,16 +386,6 @@ int same_batch_new(const same_rx_builder *b, uint32_t n_channels, int device, ui
     if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
         return cleanup(fail(SAME_ENODEVICE, "device %d is %s; this build carries gfx950 code only", device, prop.gcnArchName));
     rx->use_fast = same::fast_kernel_supported(rx->P);
-    {
-        // thin wavefronts for small batches: aim at >= 2 wavefronts per SIMD (1024 SIMDs)
-        uint32_t lpw = 64;
-        while (lpw > 1 && (n_channels + lpw - 1) / lpw < 2048u) lpw >>= 1;
-        if (const char *e = std::getenv("SAME_LPW")) {
-            uint32_t v = (uint32_t)std::atoi(e);
-            if (v >= 1 && v <= 64 && (v & (v - 1)) == 0) lpw = v;
-        }
-        rx->P.lpw = lpw;
-    }
     rx->force_generic = (flags & SAME_BATCH_GENERIC_KERNEL) != 0;
     if (same::demod_lds_bytes(rx->P) > 160 * 1024)
         return cleanup(fail(SAME_EINVAL, "configuration needs %zu bytes of LDS per wavefront (limit 160 KiB)", same::demod_lds_bytes(rx->P)));

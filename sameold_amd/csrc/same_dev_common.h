@@ -370,6 +370,16 @@ struct GlobalCtx {
     __device__ __forceinline__ uint32_t eq_symbol1(const Params &P, Lane &L, float in0, float in1) const
     { float two[2] = {in0, in1}; return eq_symbols(P, L, two, 1); }
     __device__ __forceinline__ void eq_reset(const Params &P) const { same::eq_reset(P, S, c); }
+    __device__ __forceinline__ void eq_snapshot(const Params &P) const
+    {
+        for (uint32_t i = 0; i < P.eq_nff; ++i) { S.eq_snap_ffc[i * C + c] = S.eq_ffc[i * C + c]; S.eq_snap_ffw[i * C + c] = S.eq_ffw[i * C + c]; }
+        for (uint32_t i = 0; i < P.eq_nfb; ++i) { S.eq_snap_fbc[i * C + c] = S.eq_fbc[i * C + c]; S.eq_snap_fbw[i * C + c] = S.eq_fbw[i * C + c]; }
+    }
+    __device__ __forceinline__ void eq_restore(const Params &P) const
+    {
+        for (uint32_t i = 0; i < P.eq_nff; ++i) { S.eq_ffc[i * C + c] = S.eq_snap_ffc[i * C + c]; S.eq_ffw[i * C + c] = S.eq_snap_ffw[i * C + c]; }
+        for (uint32_t i = 0; i < P.eq_nfb; ++i) { S.eq_fbc[i * C + c] = S.eq_snap_fbc[i * C + c]; S.eq_fbw[i * C + c] = S.eq_snap_fbw[i * C + c]; }
+    }
 };
 
 // SameReceiver::end receiver.rs:479-490
@@ -408,7 +418,7 @@ __device__ __forceinline__ uint32_t rx_symbol(const Params &P, Lane &L, const St
     float pwr = L.sq_power;
     L.sq_phist = (L.sq_phist << 1) | ((pwr >= P.sq_power_close) ? 1u : 0u);
     L.sq_symbols += 1;
-    const bool was_locked = (L.flags & F_SQ_LOCK) != 0;     // squelch sync lock before this symbol
+    const int32_t clock_before = L.sq_clock;                // byte clock before this symbol (-1: no sync)
 
     enum { NO_CARRIER, DROPPED, READING, READY };
     int st;
@@ -438,44 +448,42 @@ __device__ __forceinline__ uint32_t rx_symbol(const Params &P, Lane &L, const St
     // Equalizer schedule.  The reference runs the equalizer over the 8 symbols of a byte when
     // the squelch's byte clock wraps (rx/codesquelch.rs:283-299 -> rx/equalize.rs:173-186): the
     // symbols are the OLDEST 16 history samples, i.e. they were all known 24 symbols earlier.
-    // Once the framer has locked the squelch sync (receiver.rs:461-465) the byte clock can no
-    // longer be re-aligned, so the byte boundaries are known in advance and symbol j of the next
-    // byte can be equalized during the j-th "Reading" symbol before it is due: at that moment it
+    // While a channel stays in byte sync the byte boundaries are known in advance, so symbol j
+    // of the next byte is equalized during the j-th symbol before it is due; at that moment it
     // sits at history offset 14/15 from the oldest sample.  The equalizer sees the same symbols
-    // in the same order, so its state and output are identical; what changes is that the
-    // work arrives as one short step per symbol instead of an 8-symbol burst per byte, which is
-    // what keeps a 64-lane wavefront from serialising on whichever lane has a byte due.  If the
-    // carrier drops mid-byte the partial progress is discarded by the reset in end(), exactly as
-    // the reference discards an equalizer that never saw those symbols.
+    // in the same order, so its state and output are bit-identical; the work arrives as one
+    // short step per symbol instead of an 8-symbol burst per byte, which is what keeps a
+    // 64-lane wavefront from serialising on whichever lane has a byte due.
+    //  * carrier drop / end of burst mid-byte: end() resets the equalizer (receiver.rs:482),
+    //    exactly as the reference discards an equalizer that never saw those symbols;
+    //  * the byte clock is re-aligned while the squelch is still unlocked ("adjust byte sync",
+    //    rx/codesquelch.rs:255-264): the symbols equalized ahead belonged to a byte the
+    //    reference never forms, so the state saved at the last completed byte is restored
+    //    before training restarts.
     const uint32_t head = (uint32_t)(2u * (uint32_t)L.sq_symbols) & 63u;   // oldest sample
-    if (st == READING) {
-        if (was_locked) {
-            const uint32_t j = (uint32_t)(L.sq_clock == 0 ? 7 : L.sq_clock - 1) - 1u;   // clock before - 1
-            uint32_t bit = X.eq_symbol1(P, L, X.hist_get((head + 14u) & 63u), X.hist_get((head + 15u) & 63u));
-            uint32_t bits = (j == 0u) ? 0u : ((L.flags & F_EQ_BITS_MASK) >> F_EQ_BITS_SHIFT);
-            bits |= bit << j;
-            L.flags = (L.flags & ~F_EQ_BITS_MASK) | (bits << F_EQ_BITS_SHIFT);
-        }
-        return framer_state(L);
+    if (clock_before >= 0 && !adjusted) {
+        const uint32_t j = (uint32_t)(clock_before + 7) & 7u;   // clock 1..7 -> symbol 0..6, clock 0 -> 7
+        uint32_t bit = X.eq_symbol1(P, L, X.hist_get((head + 14u) & 63u), X.hist_get((head + 15u) & 63u));
+        uint32_t bits = (j == 0u) ? 0u : ((L.flags & F_EQ_BITS_MASK) >> F_EQ_BITS_SHIFT);
+        bits |= bit << j;
+        L.flags = (L.flags & ~F_EQ_BITS_MASK) | (bits << F_EQ_BITS_SHIFT);
     }
+    if (st == READING) return framer_state(L);
 
+    // --- Ready: a byte is due.  receiver.rs:423-446
+    uint32_t byte;
     if (adjusted) {
+        if (clock_before >= 0) X.eq_restore(P);             // drop the symbols equalized ahead
         L.flags |= F_AGC_LOCKED | F_BW_LOCKED;              // agc.lock(true); locked loop bandwidth
         L.flags = (L.flags & ~F_EQ_MODE_MASK) | (2u << F_EQ_MODE_SHIFT);   // equalizer.train()
         L.eq_word = P.sync_word; L.eq_count = 0;
-    }
-    // --- equalizer receiver.rs:446
-    uint32_t byte;
-    if (was_locked) {
-        // symbols 0..6 of this byte were equalized as they became due; finish with symbol 7
-        uint32_t bit = X.eq_symbol1(P, L, X.hist_get((head + 14u) & 63u), X.hist_get((head + 15u) & 63u));
-        byte = ((L.flags & F_EQ_BITS_MASK) >> F_EQ_BITS_SHIFT) | (bit << 7);
-    } else {
         // the oldest 16 samples of the history (rx/codesquelch.rs:288-294)
         float samples[16];
 #pragma unroll
         for (int i = 0; i < 16; ++i) samples[i] = X.hist_get((head + i) & 63u);
         byte = X.eq_symbols(P, L, samples, 8);
+    } else {
+        byte = (L.flags & F_EQ_BITS_MASK) >> F_EQ_BITS_SHIFT;   // symbol 7 was equalized just above
     }
 
     // --- framer receiver.rs:457-471, Framer::input rx/framing.rs:109-123
@@ -498,6 +506,8 @@ __device__ __forceinline__ uint32_t rx_symbol(const Params &P, Lane &L, const St
     }
     if (link == 2u) L.flags |= F_SQ_LOCK;                   // squelch.lock(true)
     else if (link == 0u || link == 3u) rx_end(P, L, X);
+    // a re-alignment is still possible: remember the equalizer as of this completed byte
+    if (L.sq_clock >= 0 && !(L.flags & F_SQ_LOCK)) X.eq_snapshot(P);
     return link;
 }
 

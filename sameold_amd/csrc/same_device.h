@@ -48,10 +48,6 @@ struct Params {
     uint32_t ticks;
     uint32_t tick_interburst; // MAX_INTERBURST_SYMBOLS  (rx/assembler.rs:85)
     uint32_t tick_history;    // MAX_HISTORY_DURATION    (rx/assembler.rs:92-93)
-    // channels (active lanes) per wavefront of the fast kernel, a power of two <= 64.  Small
-    // batches use thin wavefronts: the serial per-channel instruction stream, not lane count,
-    // bounds throughput, so fewer lanes per wave = less divergence and more waves in flight.
-    uint32_t lpw;
 };
 
 // flag bits of State::flags
@@ -100,6 +96,8 @@ struct State {
     float *eq_ffc, *eq_fbc;    // [nff][C], [nfb][C] coefficients
     float *eq_ffw, *eq_fbw;    // [nff][C], [nfb][C] windows, index 0 = oldest
     uint32_t *eq_word, *eq_count;
+    // equalizer as of the last completed byte (restored if the byte clock is re-aligned)
+    float *eq_snap_ffc, *eq_snap_fbc, *eq_snap_ffw, *eq_snap_fbw;
     // framer
     uint32_t *fr_word, *fr_count, *fr_invalid, *fr_len;
     uint8_t *fr_msg;       // [C][kBurstCap]

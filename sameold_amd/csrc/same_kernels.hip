@@ -195,8 +195,8 @@ __global__ void init_state_kernel(Params P, State S, int is_reset)
     S.sq_data[c] = 0; S.sq_power[c] = 0.0f; S.sq_phist[c] = 0; S.sq_fill[c] = 0;
     S.sq_clock[c] = -1; S.sq_symbols[c] = 0;
     for (uint32_t i = 0; i < (uint32_t)kSquelchHist; ++i) S.sq_hist[i * C + c] = 0.0f;
-    for (uint32_t i = 0; i < P.eq_nff; ++i) { S.eq_ffc[i * C + c] = (i == 0) ? 1.0f : 0.0f; S.eq_ffw[i * C + c] = 0.0f; }
-    for (uint32_t i = 0; i < P.eq_nfb; ++i) { S.eq_fbc[i * C + c] = (i == 0) ? 1.0f : 0.0f; S.eq_fbw[i * C + c] = 0.0f; }
+    for (uint32_t i = 0; i < P.eq_nff; ++i) { S.eq_ffc[i * C + c] = (i == 0) ? 1.0f : 0.0f; S.eq_ffw[i * C + c] = 0.0f; S.eq_snap_ffc[i * C + c] = (i == 0) ? 1.0f : 0.0f; S.eq_snap_ffw[i * C + c] = 0.0f; }
+    for (uint32_t i = 0; i < P.eq_nfb; ++i) { S.eq_fbc[i * C + c] = (i == 0) ? 1.0f : 0.0f; S.eq_fbw[i * C + c] = 0.0f; S.eq_snap_fbc[i * C + c] = (i == 0) ? 1.0f : 0.0f; S.eq_snap_fbw[i * C + c] = 0.0f; }
     // Equalizer::reset() preserves its mode, training word and count (rx/equalize.rs:191-196)
     if (!is_reset) { S.eq_word[c] = 0; S.eq_count[c] = 0; }
     S.fr_word[c] = 0; S.fr_count[c] = 0; S.fr_invalid[c] = 0; S.fr_len[c] = 0;

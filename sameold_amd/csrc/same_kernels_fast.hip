@@ -37,11 +37,25 @@ constexpr int kB = 16;   // block length of the fast kernel
 
 template <int NFF, int NFB>
 struct FastCtx {
-    float *hist;                       // LDS column of this lane: slot i at hist[i * stride]
-    uint32_t stride;                   // lanes per wavefront
+    float *hist;                       // LDS column of this lane: slot i at hist[i * kWave]
     float ffc[NFF], ffw[NFF], fbc[NFB], fbw[NFB];
-    __device__ __forceinline__ void hist_put(uint32_t slot, float v) { hist[slot * stride] = v; }
-    __device__ __forceinline__ float hist_get(uint32_t slot) const { return hist[slot * stride]; }
+    float sffc[NFF], sffw[NFF], sfbc[NFB], sfbw[NFB];   // equalizer at the last completed byte
+    __device__ __forceinline__ void eq_snapshot(const Params &)
+    {
+#pragma unroll
+        for (int i = 0; i < NFF; ++i) { sffc[i] = ffc[i]; sffw[i] = ffw[i]; }
+#pragma unroll
+        for (int i = 0; i < NFB; ++i) { sfbc[i] = fbc[i]; sfbw[i] = fbw[i]; }
+    }
+    __device__ __forceinline__ void eq_restore(const Params &)
+    {
+#pragma unroll
+        for (int i = 0; i < NFF; ++i) { ffc[i] = sffc[i]; ffw[i] = sffw[i]; }
+#pragma unroll
+        for (int i = 0; i < NFB; ++i) { fbc[i] = sfbc[i]; fbw[i] = sfbw[i]; }
+    }
+    __device__ __forceinline__ void hist_put(uint32_t slot, float v) { hist[slot * kWave] = v; }
+    __device__ __forceinline__ float hist_get(uint32_t slot) const { return hist[slot * kWave]; }
     __device__ __forceinline__ uint32_t eq_symbols(const Params &P, Lane &L, const float *samples, int nsym)
     {
         uint32_t bits = 0;
@@ -166,28 +180,28 @@ __global__ __launch_bounds__(kWave) void demod_fast_kernel(Params P, State S, Ou
     extern __shared__ float lds[];
     const uint32_t lane = threadIdx.x;
     const uint32_t C = P.n_channels;
-    const uint32_t LP = P.lpw;                                   // channels per wavefront
-    if (lane >= LP) return;                                      // no barriers below
-    // Workgroups are dealt round-robin over the 8 XCDs; give each XCD a contiguous range of
-    // channel groups so the wavefronts that share a 128-byte line of x[t][:] share an L2.
-    uint32_t grp = blockIdx.x;
-    if ((gridDim.x & 7u) == 0u) grp = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
-    const uint32_t c = grp * LP + lane;
-    if (c >= C) return;
-    float *wcol = lds + lane;                                    // [RING][LP]
-    float *hcol = lds + RING * LP + lane;                        // [64][LP]
-    float *ffcol = lds + (RING + kSquelchHist) * LP + lane;      // [DCL][LP] (LDS DC path)
+    constexpr uint32_t LP = kWave;                               // one lane per channel
+    const uint32_t c = blockIdx.x * kWave + lane;
+    if (c >= C) return;                                          // no barriers below
+    float *wcol = lds + lane;                                    // [RING][64]
+    float *hcol = lds + RING * LP + lane;                        // [64][64]
+    float *ffcol = lds + (RING + kSquelchHist) * LP + lane;      // [DCL][64] (LDS DC path)
     float *fbcol = ffcol + DCL * LP;
 
     Lane L;
     lane_load(L, S, c);
     FastCtx<NFF, NFB> X;
     X.hist = hcol;
-    X.stride = LP;
 #pragma unroll
-    for (int i = 0; i < NFF; ++i) { X.ffc[i] = S.eq_ffc[i * C + c]; X.ffw[i] = S.eq_ffw[i * C + c]; }
+    for (int i = 0; i < NFF; ++i) {
+        X.ffc[i] = S.eq_ffc[i * C + c]; X.ffw[i] = S.eq_ffw[i * C + c];
+        X.sffc[i] = S.eq_snap_ffc[i * C + c]; X.sffw[i] = S.eq_snap_ffw[i * C + c];
+    }
 #pragma unroll
-    for (int i = 0; i < NFB; ++i) { X.fbc[i] = S.eq_fbc[i * C + c]; X.fbw[i] = S.eq_fbw[i * C + c]; }
+    for (int i = 0; i < NFB; ++i) {
+        X.fbc[i] = S.eq_fbc[i * C + c]; X.fbw[i] = S.eq_fbw[i * C + c];
+        X.sfbc[i] = S.eq_snap_fbc[i * C + c]; X.sfbw[i] = S.eq_snap_fbw[i * C + c];
+    }
     // state arrays are [slot][channel]: a wave-uniform row pointer plus the lane's channel
     // index keeps the address arithmetic on the scalar unit
 #pragma unroll 2
@@ -320,9 +334,15 @@ __global__ __launch_bounds__(kWave) void demod_fast_kernel(Params P, State S, Ou
     L.ted_clock = (uint32_t)(cstar - until - 1);
     lane_store(L, S, c);
 #pragma unroll
-    for (int i = 0; i < NFF; ++i) { S.eq_ffc[i * C + c] = X.ffc[i]; S.eq_ffw[i * C + c] = X.ffw[i]; }
+    for (int i = 0; i < NFF; ++i) {
+        S.eq_ffc[i * C + c] = X.ffc[i]; S.eq_ffw[i * C + c] = X.ffw[i];
+        S.eq_snap_ffc[i * C + c] = X.sffc[i]; S.eq_snap_ffw[i * C + c] = X.sffw[i];
+    }
 #pragma unroll
-    for (int i = 0; i < NFB; ++i) { S.eq_fbc[i * C + c] = X.fbc[i]; S.eq_fbw[i * C + c] = X.fbw[i]; }
+    for (int i = 0; i < NFB; ++i) {
+        S.eq_fbc[i * C + c] = X.fbc[i]; S.eq_fbw[i * C + c] = X.fbw[i];
+        S.eq_snap_fbc[i * C + c] = X.sfbc[i]; S.eq_snap_fbw[i * C + c] = X.sfbw[i];
+    }
 #pragma unroll 2
     for (int i = 0; i < RING; ++i) { float *row = S.win_ring + (size_t)i * C; row[c] = wcol[i * LP]; }
 #pragma unroll 2
@@ -349,18 +369,18 @@ __global__ __launch_bounds__(kWave) void demod_fast_kernel(Params P, State S, Ou
 // dispatch
 // ---------------------------------------------------------------------------------
 template <int NT, int DCL>
-static constexpr size_t fast_lds_bytes(uint32_t lpw)
+static constexpr size_t fast_lds_bytes()
 {
     constexpr int RING = (NT + kB - 1 <= 64) ? 64 : 128;
-    return (size_t)(RING + kSquelchHist + (DCL == kB ? 0 : 2 * DCL)) * lpw * sizeof(float);
+    return (size_t)(RING + kSquelchHist + (DCL == kB ? 0 : 2 * DCL)) * kWave * sizeof(float);
 }
 
 template <int NT, int DCL, typename SampleT>
 static hipError_t launch_fast_cfg(const Params &P, const State &S, const Output &O, const float4 *taps,
                                   const SampleT *x, uint32_t n_blocks, uint64_t counter0, hipStream_t stream)
 {
-    const uint32_t grid = (P.n_channels + P.lpw - 1) / P.lpw;
-    const size_t lds = fast_lds_bytes<NT, DCL>(P.lpw);
+    const uint32_t grid = (P.n_channels + kWave - 1) / kWave;
+    const size_t lds = fast_lds_bytes<NT, DCL>();
     // v_med3_f32 == f32::clamp unless a bound is -0.0 (or NaN, which the builder rejects)
     const bool med3 = !(P.agc_min == 0.0f && std::signbit(P.agc_min)) && !(P.agc_max == 0.0f && std::signbit(P.agc_max));
 #define SAME_FAST(NFF, NFB, M3)                                                                         \
