@@ -9,14 +9,16 @@ f32, `--seconds` of audio per step (default 10 s = 220 500 samples/channel, 3.6 
 generated on the device so the timed region starts with the input resident in HBM.
 A "step" is one pass of the whole link layer (DC block -> AGC -> matched filters ->
 timing loop -> squelch -> DFE -> framer) over that batch through the C ABI, including
-the event log read-back and the host-side transport layer.  Channels shard across
-ranks with no data-path collective; each step ends with one RCCL gather of the decoded
-bursts to rank 0 (weak scaling: per-GPU work is fixed).
+the event-log read-back, ordering and the host-side transport layer.  Channels shard
+across ranks with no data-path collective; each step ends with one RCCL gather of the
+decoded bursts to rank 0 (weak scaling: per-GPU work is fixed).
 
-roofline: algorithmic bytes = 4 B per input sample, divided by the
-demod kernel's duration measured with HIP events on the stream it runs on.
-cpu_baseline: the oracle (a scalar C port of the reference's Rust path; the reference
-itself cannot be built here) on a bounded sample of the same input, all host cores.
+roofline: algorithmic bytes = 4 B per input sample divided by the
+demodulation kernel's duration, measured with HIP events on the stream the kernel runs on.
+cpu_baseline: the oracle (scalar C port of the reference's Rust path; the reference
+itself cannot be built in this image) on a bounded sample of the same input, all host
+cores.  `scaled`: the same kernel on 32 768 channels (the per-GPU shard of
+BASELINE.json configs[3]) -- reported beside, never instead of, the configs[1] value.
 """
 import argparse
 import json
@@ -40,9 +42,42 @@ def parse():
     ap.add_argument("--seconds", type=float, default=10.0, help="audio per channel per step")
     ap.add_argument("--cpu-channels", type=int, default=1024, help="channels of the CPU baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--check", type=int, default=8, help="channels of rank 0 verified against the oracle")
+    ap.add_argument("--no-scaled", action="store_true", help="skip the extra 32768-channel measurement")
+    ap.add_argument("--scaled-channels", type=int, default=32768)
+    ap.add_argument("--check", type=int, default=16, help="channels of rank 0 verified against the oracle")
     ap.add_argument("--traffic", type=float, default=None, help="HBM bytes/launch from a PMC pass (profiles/)")
     return ap.parse_args()
+
+
+def run_steps(sa, rx, x, T, stream, steps, warmup, gather, barrier):
+    """W untimed + K timed passes.  Returns (elapsed_s, mean kernel ms, events of pass 0,
+    bursts gathered in the last pass)."""
+    import torch
+    kernel_ms = []
+    first = None
+    last_bursts = 0
+
+    def step():
+        nonlocal first, last_bursts
+        rx.process_device_ptr(x.data_ptr(), T, sa.LAYOUT_TIME_MAJOR, stream)
+        rx.sync()
+        ev = rx.poll_events_np()
+        kernel_ms.append(rx.last_kernel_ms())
+        if first is None:
+            first = ev
+        last_bursts = gather(ev)
+
+    for _ in range(warmup):
+        step()
+    kernel_ms.clear()
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    barrier()
+    return time.perf_counter() - t0, sum(kernel_ms) / max(len(kernel_ms), 1), first, last_bursts
 
 
 def main():
@@ -58,10 +93,10 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
     torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    n_gpus = world
+        dist.init_process_group("nccl", device_id=dev)
 
     from sameold_amd import build as sbuild
     if rank == 0:
@@ -69,91 +104,43 @@ def main():
     if distributed:
         dist.barrier()
     import sameold_amd as sa
+    from sameold_amd import distributed as sd
 
     C = args.channels
     T = int(round(args.rate * args.seconds))
-    seed = 20260000 + rank
-    x = sa.synth_afsk(C, T, args.rate, seed=seed, device=local_rank)
+    first_ch = rank * C                       # weak scaling: every rank owns C channels
+    x = sa.synth_afsk(C, T, args.rate, seed=20260000 + rank, device=local_rank)
     torch.cuda.synchronize()
-
     rx = sa.SameReceiverBuilder(args.rate).build_batch(C, device=local_rank)
     rx.set_kernel_timing(True)
     stream = torch.cuda.current_stream(local_rank).cuda_stream
 
-    def gather_bursts(events):
-        """RCCL gather of decoded bursts to rank 0: counts, then padded records."""
+    def gather(ev):
+        b = ev[ev["kind"] == sa.LINK_BURST]
         if not distributed:
-            return len(events)
-        recs = [e for e in events if e.kind == sa.LINK_BURST]
-        n = torch.tensor([len(recs)], dtype=torch.int64, device="cuda")
-        counts = [torch.zeros_like(n) for _ in range(world)]
-        dist.all_gather(counts, n)
-        m = int(max(int(c.item()) for c in counts))
-        buf = torch.zeros((max(m, 1), 304), dtype=torch.uint8, device="cuda")
-        if recs:
-            host = np.zeros((len(recs), 304), dtype=np.uint8)
-            for i, e in enumerate(recs):
-                host[i, :4] = np.frombuffer(np.uint32(e.channel + rank * C).tobytes(), dtype=np.uint8)
-                host[i, 4:12] = np.frombuffer(np.uint64(e.sample_counter).tobytes(), dtype=np.uint8)
-                host[i, 12:16] = np.frombuffer(np.uint32(e.len).tobytes(), dtype=np.uint8)
-                d = e.data()
-                host[i, 16:16 + len(d)] = np.frombuffer(d, dtype=np.uint8)
-            buf[: len(recs)] = torch.from_numpy(host).cuda()
-        out = [torch.zeros_like(buf) for _ in range(world)] if rank == 0 else None
-        dist.gather(buf, out, dst=0)
-        return sum(int(c.item()) for c in counts)
+            return len(b)
+        recs = [(int(first_ch + r["channel"]), int(r["sample_counter"]), r["bytes"][: min(int(r["len"]), 288)].tobytes())
+                for r in b]
+        got = sd.gather_bursts(recs, dev)
+        return len(got) if got is not None else 0
 
-    kernel_ms = []
-    n_events = 0
+    def barrier():
+        if distributed:
+            dist.barrier()
 
-    def step():
-        nonlocal n_events
-        rx.process_device_ptr(x.data_ptr(), T, sa.LAYOUT_TIME_MAJOR, stream)
-        rx.sync()
-        evs = rx.poll_events()
-        n_events = len(evs)
-        kernel_ms.append(rx.last_kernel_ms())
-        return gather_bursts(evs), evs
-
-    first_events = None
-    for w in range(args.warmup):
-        _, evs = step()
-        if first_events is None:
-            first_events = evs
-    if first_events is None:
-        # keep a copy of the first pass for the parity spot-check even with --warmup 0
-        pass
-    kernel_ms.clear()
-
+    elapsed, k_ms, first, n_bursts = run_steps(sa, rx, x, T, stream, args.steps, args.warmup, gather, barrier)
     if distributed:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    total_bursts = 0
-    for k in range(args.steps):
-        nb, evs = step()
-        total_bursts = nb
-        if first_events is None and k == 0:
-            first_events = evs
-    torch.cuda.synchronize()
-    if distributed:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    if distributed:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    samples_per_step = C * T * n_gpus
-    value = samples_per_step * args.steps / elapsed / 1e6
-    k_ms = float(np.mean(kernel_ms)) if kernel_ms else float("nan")
+    value = C * T * world * args.steps / elapsed / 1e6
     achieved = 4.0 * C * T / (k_ms * 1e-3) / 1e9
-
     out = {
         "metric": "Msamples/s demodulated (batched 22.05 kHz channels) + % HBM roofline, 1/8 GPU",
         "value": round(value, 2),
         "unit": "Msamples/s",
-        "n_gpus": n_gpus,
+        "n_gpus": world,
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 3),
@@ -166,32 +153,33 @@ def main():
             "workload": f"{C} synthetic {args.rate / 1000:g} kHz AFSK channels per GPU, f32, "
                         f"{args.seconds:g} s ({T} samples) per channel per step (BASELINE.json configs[1])",
             "channels_per_gpu": C, "samples_per_channel": T, "input_rate": args.rate,
-            "layout": "time-major", "kernel": rx.kernel_name(), "parity": "bit-exact (strict op order)",
-            "bursts_gathered_last_step": int(total_bursts), "events_last_step_rank0": int(n_events),
+            "layout": "time-major x[t][channel]", "kernel": rx.kernel_name(),
+            "parity": "bit-exact (strict op order)",
+            "bursts_gathered_last_step": int(n_bursts), "events_first_step_rank0": int(len(first)),
         },
         "roofline": {
             "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": args.traffic,
             "kernel_ms": round(k_ms, 4), "algorithmic_bytes_per_launch": 4 * C * T,
+            "note": "latency/issue-bound at 64 wavefronts on 1024 SIMDs (DESIGN.md section 5)",
         },
     }
 
-    if rank == 0 and n_gpus == 1:
+    if rank == 0 and world == 1:
         from oracle import binding as ob
+        cfg = ob.default_config(args.rate)
         xs = None
-        # parity spot-check of this very run (first pass, state fresh): GPU events == oracle
-        if args.check and first_events is not None:
+        if args.check and args.warmup + args.steps > 0:
+            # parity spot-check of this very run: the first pass started from fresh state
             chk = min(args.check, C)
             xs = x[:, :max(chk, min(args.cpu_channels, C))].contiguous().cpu().numpy()
-            by = {}
-            for e in first_events:
-                if e.channel < chk:
-                    by.setdefault(e.channel, []).append(e.as_tuple())
             ok = True
             for c in range(chk):
-                ref = [e.as_tuple() for e in ob.Receiver(ob.default_config(args.rate)).run(np.ascontiguousarray(xs[:, c]))]
-                ok &= by.get(c, []) == ref
-            out["config"]["parity_check"] = f"{chk} channels vs oracle: {'OK' if ok else 'MISMATCH'}"
+                mine = first[first["channel"] == c]
+                got = [(int(r["kind"]), int(r["sample_counter"]), r["bytes"][: min(int(r["len"]), 288)].tobytes()) for r in mine]
+                ref = [e.as_tuple() for e in ob.Receiver(cfg).run(np.ascontiguousarray(xs[:, c]))]
+                ok &= got == ref
+            out["config"]["parity_check"] = f"{chk} channels of this run vs oracle: {'OK' if ok else 'MISMATCH'}"
             if not ok:
                 out["config"]["parity"] = "MISMATCH"
         if not args.no_cpu_baseline:
@@ -201,13 +189,30 @@ def main():
             xs = np.ascontiguousarray(xs[:, :cc])
             cores = len(os.sched_getaffinity(0))
             t1 = time.perf_counter()
-            n_ev, _ = ob.batch_run_time_major(ob.default_config(args.rate), xs, cores)
+            ob.batch_run_time_major(cfg, xs, cores)
             dt = time.perf_counter() - t1
             out["cpu_baseline"] = {
                 "value": round(cc * T / dt / 1e6, 2), "unit": "Msamples/s", "cores": cores, "kind": "port",
-                "sample": f"first {cc} channels x {T} samples of the same synthetic input, "
-                          f"link layer only, {dt:.1f} s wall, {cores} threads "
-                          "(scalar C restatement of sameold 0.6.0; the Rust reference cannot be built here)",
+                "sample": f"first {cc} channels x {T} samples of the same synthetic input, link layer only, "
+                          f"{dt:.2f} s wall on {cores} threads (scalar C restatement of sameold 0.6.0; "
+                          "the Rust reference cannot be built in this image)",
+            }
+        del xs
+        if not args.no_scaled:
+            # same kernel, the per-GPU shard of configs[3]: 32768 channels (2 s per step to bound memory)
+            del x
+            torch.cuda.empty_cache()
+            Cs, Ts = args.scaled_channels, int(args.rate * 2)
+            x2 = sa.synth_afsk(Cs, Ts, args.rate, seed=777, device=local_rank)
+            rx2 = sa.SameReceiverBuilder(args.rate).build_batch(Cs, device=local_rank)
+            rx2.set_kernel_timing(True)
+            e2, k2, _, _ = run_steps(sa, rx2, x2, Ts, stream, 3, 1, lambda ev: len(ev), lambda: None)
+            a2 = 4.0 * Cs * Ts / (k2 * 1e-3) / 1e9
+            out["scaled"] = {
+                "workload": f"{Cs} channels x {Ts} samples per step (per-GPU shard of BASELINE.json configs[3])",
+                "value": round(Cs * Ts * 3 / e2 / 1e6, 2), "unit": "Msamples/s", "kernel_ms": round(k2, 4),
+                "roofline": {"bound": "hbm", "achieved": round(a2, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": round(a2 / HBM_PEAK_GBS, 5)},
             }
     if rank == 0:
         print(json.dumps(out), flush=True)

@@ -104,7 +104,7 @@ __device__ __forceinline__ float demod_fast(const float4 *__restrict__ taps, con
     // Byte address of tap i in the ring: slot (newest - i) mod RING, lpw*4 bytes per slot, so
     // stepping back one tap is "subtract the slot pitch, wrap at RING*pitch" (lane*4 < pitch
     // stays intact because both are powers of two).
-    constexpr int CH = 7;
+    constexpr int CH = 14;
     const uint32_t pitch = lpw * 4u;
     const uint32_t WRAP = (uint32_t)RING * pitch - 1u;
     float2v am = {0.0f, 0.0f}, as = {0.0f, 0.0f};

@@ -203,6 +203,7 @@ void Transport::reset()
     asm_.reset();
     state_kind_ = SAME_TRANSPORT_IDLE; state_msg_ = MessageResult{};
     have_force_eom_ = false; dirty_ = true;
+    have_polled_ = false; last_polled_symbol_ = 0;
 }
 
 bool Transport::on_link_event(uint32_t kind, uint64_t sample_counter, uint64_t symbol_count,
@@ -212,6 +213,13 @@ bool Transport::on_link_event(uint32_t kind, uint64_t sample_counter, uint64_t s
     const uint64_t kMaxMessageDurationSecs = 135;        // receiver.rs:496
     MessageResult msg;
     uint32_t st;
+    // The reference polls once per symbol.  A wake-up tick that lands on the symbol of a link
+    // event just handled (e.g. a deadline that expired while the link was Searching is served
+    // by the NoCarrier transition itself) must not poll a second time.
+    if (kind == kDevTick && have_polled_ && symbol_count == last_polled_symbol_) return false;
+    if (kind == SAME_LINK_BURST || kind == SAME_LINK_NO_CARRIER || kind == kDevTick) {
+        have_polled_ = true; last_polled_symbol_ = symbol_count;
+    }
     if (kind == SAME_LINK_BURST) {
         st = asm_.assemble(bytes, len, symbol_count, &msg);
     } else if (kind == SAME_LINK_NO_CARRIER || kind == kDevTick) {

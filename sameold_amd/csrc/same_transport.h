@@ -89,6 +89,8 @@ private:
     bool have_force_eom_ = false;
     uint64_t force_eom_at_ = 0;
     bool dirty_ = false;
+    bool have_polled_ = false;
+    uint64_t last_polled_symbol_ = 0;
 };
 
 }  // namespace same

@@ -1,0 +1,73 @@
+"""Multi-GPU plumbing: channels shard embarrassingly across ranks (one process per GPU);
+the only collective is a gather of the decoded bursts to rank 0 at the end of a batch.
+
+The gather is two RCCL calls on fixed-size records (`backend="nccl"` is RCCL on ROCm): an
+all_gather of per-rank counts, then a gather of records padded to the largest count.
+Volume is a few hundred bytes per burst, so xGMI bandwidth is irrelevant; what matters is
+that there is no collective on the demodulation path itself.  The same code runs over
+gloo on CPU tensors, which is how the CPU test-suite covers it.
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+RECORD_BYTES = 304          # 4 channel + 8 sample_counter + 4 length + 288 burst bytes
+_HDR = 16
+
+
+def shard_channels(n_channels: int, rank: int, world: int) -> Tuple[int, int]:
+    """Contiguous block of channels owned by `rank`: [first, first + count)."""
+    base, rem = divmod(n_channels, world)
+    first = rank * base + min(rank, rem)
+    return first, base + (1 if rank < rem else 0)
+
+
+def pack_bursts(bursts: Sequence[Tuple[int, int, bytes]]) -> np.ndarray:
+    """(global_channel, sample_counter, bytes) -> uint8 [n, RECORD_BYTES]"""
+    out = np.zeros((len(bursts), RECORD_BYTES), dtype=np.uint8)
+    for i, (ch, ctr, data) in enumerate(bursts):
+        out[i, 0:4] = np.frombuffer(np.uint32(ch).tobytes(), dtype=np.uint8)
+        out[i, 4:12] = np.frombuffer(np.uint64(ctr).tobytes(), dtype=np.uint8)
+        n = min(len(data), RECORD_BYTES - _HDR)
+        out[i, 12:16] = np.frombuffer(np.uint32(n).tobytes(), dtype=np.uint8)
+        out[i, _HDR:_HDR + n] = np.frombuffer(data[:n], dtype=np.uint8)
+    return out
+
+
+def unpack_bursts(recs: np.ndarray) -> List[Tuple[int, int, bytes]]:
+    out = []
+    for r in recs:
+        ch = int(np.frombuffer(r[0:4].tobytes(), dtype=np.uint32)[0])
+        ctr = int(np.frombuffer(r[4:12].tobytes(), dtype=np.uint64)[0])
+        n = int(np.frombuffer(r[12:16].tobytes(), dtype=np.uint32)[0])
+        out.append((ch, ctr, r[_HDR:_HDR + n].tobytes()))
+    return out
+
+
+def gather_bursts(bursts: Sequence[Tuple[int, int, bytes]], device: torch.device,
+                  dst: int = 0) -> Optional[List[Tuple[int, int, bytes]]]:
+    """Gather every rank's bursts on rank `dst` (returns None on the other ranks).
+    Without an initialised process group this is the identity."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return list(bursts)
+    world, rank = dist.get_world_size(), dist.get_rank()
+    n = torch.tensor([len(bursts)], dtype=torch.int64, device=device)
+    counts = [torch.zeros_like(n) for _ in range(world)]
+    dist.all_gather(counts, n)
+    counts = [int(c.item()) for c in counts]
+    m = max(max(counts), 1)
+    buf = torch.zeros((m, RECORD_BYTES), dtype=torch.uint8, device=device)
+    if len(bursts):
+        buf[: len(bursts)] = torch.from_numpy(pack_bursts(bursts)).to(device)
+    out = [torch.zeros_like(buf) for _ in range(world)] if rank == dst else None
+    dist.gather(buf, out, dst=dst)
+    if rank != dst:
+        return None
+    res: List[Tuple[int, int, bytes]] = []
+    for r in range(world):
+        res += unpack_bursts(out[r][: counts[r]].cpu().numpy())
+    return res

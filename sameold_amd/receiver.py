@@ -73,6 +73,12 @@ class Event(C.Structure):
         return f"Event(ch{self.channel} {KIND_NAMES.get(self.kind, self.kind)}@{self.sample_counter}, {self.data()!r})"
 
 
+EVENT_DTYPE = np.dtype([("kind", "<u4"), ("channel", "<u4"), ("sample_counter", "<u8"), ("symbol_count", "<u8"),
+                        ("len", "<u4"), ("aux", "<u4"), ("aux2", "<u4"), ("reserved", "<u4"),
+                        ("bytes", "u1", (EVENT_MAX_BYTES,))])
+assert EVENT_DTYPE.itemsize == C.sizeof(Event)
+
+
 class SymbolTrace(C.Structure):
     _fields_ = [("sample_counter", C.c_uint64), ("zero", C.c_float), ("sym", C.c_float),
                 ("err", C.c_float), ("samples_until_next_ted", C.c_float)]
@@ -373,6 +379,18 @@ class SameBatchReceiver:
                 out.append(e)
             if left.value == 0 or n.value == 0:
                 break
+        return out
+
+    def poll_events_np(self, max_events: int = 1 << 22) -> np.ndarray:
+        """Drain events into one numpy structured array (no per-event Python objects)."""
+        n_pending = self._L.same_batch_pending_events(self._h)
+        n_take = min(n_pending, max_events)
+        out = np.zeros(n_take, dtype=EVENT_DTYPE)
+        if n_take:
+            n, left = C.c_size_t(), C.c_size_t()
+            _check(self._L.same_batch_poll_events(self._h, C.cast(out.ctypes.data, C.POINTER(Event)), n_take,
+                                                  C.byref(n), C.byref(left)))
+            out = out[: n.value]
         return out
 
     def read_trace(self, channel: int, cap: int = 4096) -> np.ndarray:

@@ -1,0 +1,80 @@
+"""N > 1 path on CPU: channel sharding and the burst gather over gloo, world_size 2.
+(The demodulation itself needs a GPU; what is distributed is only this plumbing.)"""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import ROOT
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from sameold_amd import distributed as sd
+    first, count = sd.shard_channels(10, rank, world)
+    # rank r decodes (r + 1) * 2 bursts on its own channels; rank 1 also sends none in round 2
+    mine = [(first + (i % count), 1000 * rank + i, bytes([65 + rank]) * (5 + i)) for i in range((rank + 1) * 2)]
+    got = sd.gather_bursts(mine, torch.device("cpu"))
+    got2 = sd.gather_bursts(mine if rank == 0 else [], torch.device("cpu"))
+    dist.barrier()
+    q.put((rank, first, count, got, got2))
+    dist.destroy_process_group()
+
+
+def test_shard_channels_partition():
+    from sameold_amd import distributed as sd
+    for n in (1, 7, 8, 4096, 262144, 1000003):
+        for w in (1, 2, 3, 8):
+            spans = [sd.shard_channels(n, r, w) for r in range(w)]
+            assert spans[0][0] == 0 and sum(c for _, c in spans) == n
+            for (f0, c0), (f1, _) in zip(spans, spans[1:]):
+                assert f0 + c0 == f1
+            assert max(c for _, c in spans) - min(c for _, c in spans) <= 1
+
+
+def test_pack_roundtrip():
+    from sameold_amd import distributed as sd
+    b = [(3, 12345678901, b"ZCZC-WXR-TOR-039173+0030-1591829-KCLE/NWS-\x00\x00"), (0, 0, b""), (2 ** 31, 2 ** 40, bytes(range(256)) + b"x" * 40)]
+    r = sd.unpack_bursts(sd.pack_bursts(b))
+    assert r[0] == b[0] and r[1] == b[1]
+    assert r[2][:2] == b[2][:2] and r[2][2] == b[2][2][:288]
+
+
+def test_gather_bursts_gloo_world2():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in range(world):
+        rank, first, count, got, got2 = q.get(timeout=120)
+        res[rank] = (first, count, got, got2)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res[0][:2] == (0, 5) and res[1][:2] == (5, 5)
+    assert res[1][2] is None and res[1][3] is None
+    got = res[0][2]
+    assert len(got) == 2 + 4
+    assert [g for g in got if g[2][:1] == b"A"] == [(0, 0, b"AAAAA"), (1, 1, b"AAAAAA")]
+    assert [g[1] for g in got if g[2][:1] == b"B"] == [1000, 1001, 1002, 1003]
+    assert len(res[0][3]) == 2   # a rank with nothing to send contributes nothing

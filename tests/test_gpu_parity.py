@@ -136,7 +136,7 @@ def mixed_batch(sa, n_ch, n_samples, seed, rate=22050, noise=0.0, integer_symbol
     return x
 
 
-@pytest.mark.parametrize("n_ch,seconds,noise", [(64, 6.0, 0.0), (200, 4.0, 0.05), (130, 5.0, 0.4)])
+@pytest.mark.parametrize("n_ch,seconds,noise", [(64, 6.0, 0.0), (200, 4.0, 0.05), (130, 5.0, 0.4), (96, 12.0, 0.0)])
 def test_synthetic_batch_bit_exact(sa, ob, n_ch, seconds, noise):
     n = int(22050 * seconds)
     x = mixed_batch(sa, n_ch, n, seed=11 + n_ch, noise=noise)
@@ -335,3 +335,46 @@ def test_negative_zero_agc_bound_uses_exact_clamp(sa, ob):
     ob.lib().so_config_with_agc_gain_limits(C.byref(cfg), -0.0, 1.0e6)
     for c in range(n_ch):
         assert got.get(c, []) == oracle_events(ob, cfg, x[:, c]), f"channel {c}"
+
+
+def test_byte_clock_realignment_mid_preamble(sa, ob):
+    """A bit slip inside the preamble makes the squelch re-align its byte clock while it is
+    still unlocked ("adjust byte sync", rx/codesquelch.rs:255-264).  The kernels equalize
+    symbols ahead of the byte clock and must roll that work back exactly."""
+    def bits_of(data):
+        return [(b >> i) & 1 for b in data for i in range(8)]
+
+    def modulate(bits, fs=22050):
+        # continuous-phase AFSK with the reference test modulator's symbol length (42 @ 22.05k)
+        by = bytearray()
+        acc = 0
+        for i, bit in enumerate(bits):
+            acc |= bit << (i % 8)
+            if i % 8 == 7:
+                by.append(acc); acc = 0
+        if len(bits) % 8:
+            by.append(acc)
+        wav = ob.modulate_afsk(bytes(by), fs)
+        return wav[: len(bits) * 42]
+
+    hdr = b"ZCZC-WXR-TOR-039173-039051+0030-1591829-KCLE/NWS-"
+    chans = []
+    for slip in ([1, 0, 1], [1], [0, 0, 1, 1, 0], [1, 1, 0, 1, 0, 1, 1]):
+        bits = bits_of(bytes([0xAB] * 9)) + slip + bits_of(bytes([0xAB] * 9) + hdr)
+        w = modulate(bits) * np.float32(12000.0)
+        chans.append(np.concatenate([np.zeros(3000, np.float32), w, np.zeros(22050, np.float32)]))
+    n = max(len(c) for c in chans)
+    x = np.zeros((n, 64), np.float32)
+    for i in range(64):
+        c = chans[i % len(chans)]
+        x[(i * 37) % 2000:(i * 37) % 2000 + len(c), i] = c[: n - (i * 37) % 2000]
+    cfg = ob.default_config(22050)
+    ref = [oracle_events(ob, cfg, x[:, c]) for c in range(64)]
+    decoded = sum(1 for r in ref for t in r if t[0] == sa.LINK_BURST and t[2].startswith(hdr))
+    assert decoded >= 48          # the slip is recovered from: the header still decodes
+    for generic in (False, True):
+        rx = sa.SameReceiverBuilder(22050).build_batch(64, generic_kernel=generic)
+        rx.process_host(x)
+        got = events_by_channel(rx)
+        for c in range(64):
+            assert got.get(c, []) == ref[c], f"generic={generic} channel {c}"
