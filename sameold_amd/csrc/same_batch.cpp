@@ -78,9 +78,11 @@ struct same_batch {
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;
     bool have_timing = false;
     // ordered host-side event queue
-    std::deque<same_rx_event> queue;
+    std::vector<same_rx_event> queue;   // events not yet polled: [queue_head, size)
+    size_t queue_head = 0;
     // transport layer, one assembler per channel (unless SAME_BATCH_LINK_ONLY)
     std::vector<same::Transport> transport;
+    std::vector<uint64_t> h_wake;    // host mirror of State::wake_sample
 };
 
 namespace {
@@ -181,6 +183,9 @@ int harvest(same_batch *rx)
     rx->in_flight = false;
     if (rx->timing) rx->have_timing = true;
     const uint32_t n_events = std::min(rx->h_counters[0], rx->event_cap);
+    if (std::getenv("SAME_DEBUG"))
+        std::fprintf(stderr, "[same] harvest: %u device events (%u bursts), cap %u/%u\n", rx->h_counters[0],
+                     rx->h_counters[1], rx->event_cap, rx->burst_cap);
     const uint32_t n_bursts = std::min(rx->h_counters[1], rx->burst_cap);
     if (rx->h_counters[2]) rx->overflowed = true;
     std::vector<same::DevEvent> evs(n_events);
@@ -194,8 +199,10 @@ int harvest(same_batch *rx)
     });
     const bool link_only = (rx->flags & SAME_BATCH_LINK_ONLY) != 0;
     std::vector<uint32_t> rearm;     // channels whose forced-EOM instant changed
+    rx->queue.reserve(rx->queue.size() + evs.size() + evs.size() / 2);
+    same_rx_event ev;
+    std::memset(&ev, 0, sizeof(ev));
     for (const same::DevEvent &d : evs) {
-        same_rx_event ev;
         std::memset(&ev, 0, offsetof(same_rx_event, bytes));
         ev.kind = d.kind; ev.channel = d.channel; ev.sample_counter = d.sample_counter;
         ev.symbol_count = d.symbol_count;
@@ -221,13 +228,17 @@ int harvest(same_batch *rx)
             }
             if (rx->transport[d.channel].force_eom_dirty()) rearm.push_back(d.channel);
         }
+        if (d.kind == SAME_LINK_BURST) std::memset(ev.bytes, 0, sizeof(ev.bytes));   // keep later events clean
     }
     // force_eom_at_sample (receiver.rs:321-328) lives on the host; tell the device when to
     // wake the transport layer for it.  Launches are capped well below the 135 s timeout,
     // so the instant is always armed before the device reaches it.
-    for (uint32_t c : rearm) {
-        const uint64_t at = rx->transport[c].force_eom_at();
-        HIP_TRY(hipMemcpy(rx->S.wake_sample + c, &at, sizeof(at), hipMemcpyHostToDevice));
+    if (!rearm.empty()) {
+        // one upload of the whole wake table (a device word the kernel already cleared is
+        // re-armed at worst to an instant in the past: one harmless extra poll)
+        if (rx->h_wake.size() != rx->P.n_channels) rx->h_wake.assign(rx->P.n_channels, 0);
+        for (uint32_t c : rearm) rx->h_wake[c] = rx->transport[c].force_eom_at();
+        HIP_TRY(hipMemcpy(rx->S.wake_sample, rx->h_wake.data(), rx->h_wake.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
     }
     return SAME_OK;
 }
@@ -437,8 +448,9 @@ int same_batch_reset(same_batch *rx)
     if (e != hipSuccess) return fail(SAME_EHIP, "reset launch failed: %s", hipGetErrorString(e));
     HIP_TRY(hipStreamSynchronize(rx->own_stream));
     rx->counter = 0;
-    rx->queue.clear();                       // event_queue.clear() receiver.rs:194
+    rx->queue.clear(); rx->queue_head = 0;   // event_queue.clear() receiver.rs:194
     for (auto &t : rx->transport) t.reset();
+    rx->h_wake.clear();
     rx->overflowed = false;
     return SAME_OK;
 }
@@ -491,7 +503,7 @@ size_t same_batch_pending_events(same_batch *rx)
     if (!rx) return 0;
     (void)hipSetDevice(rx->device);
     (void)harvest(rx);
-    return rx->queue.size();
+    return rx->queue.size() - rx->queue_head;
 }
 
 int same_batch_poll_events(same_batch *rx, same_rx_event *out, size_t cap, size_t *n_out, size_t *n_left)
@@ -500,10 +512,13 @@ int same_batch_poll_events(same_batch *rx, same_rx_event *out, size_t cap, size_
     HIP_TRY(hipSetDevice(rx->device));
     int rc = harvest(rx);
     if (rc) return rc;
-    size_t n = std::min(cap, rx->queue.size());
-    for (size_t i = 0; i < n; ++i) { out[i] = rx->queue.front(); rx->queue.pop_front(); }
+    const size_t avail = rx->queue.size() - rx->queue_head;
+    const size_t n = std::min(cap, avail);
+    if (n) std::memcpy(out, rx->queue.data() + rx->queue_head, n * sizeof(same_rx_event));
+    rx->queue_head += n;
+    if (rx->queue_head == rx->queue.size()) { rx->queue.clear(); rx->queue_head = 0; }
     if (n_out) *n_out = n;
-    if (n_left) *n_left = rx->queue.size();
+    if (n_left) *n_left = rx->queue.size() - rx->queue_head;
     return SAME_OK;
 }
 

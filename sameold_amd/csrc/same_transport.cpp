@@ -75,16 +75,20 @@ bool check_header(const uint8_t *h, size_t n, size_t *offset_time, size_t *hdr_l
 }
 
 // Message::try_from((bytes, errs, counts)) crates/sameplace/src/message.rs:718-736, 184-230
+static void clear_result(MessageResult *m)
+{ m->kind = 0; m->err = 0; m->len = 0; m->offset_time = 0; m->parity_errors = 0; m->voting_bytes = 0; }
+
 static void parse_message(const uint8_t *b, size_t n, const uint8_t *errs, const uint8_t *counts, MessageResult *out)
 {
-    *out = MessageResult{};
+    clear_result(out);
     for (size_t i = 0; i < n; ++i)
         if (b[i] & 0x80) { out->kind = SAME_TRANSPORT_MSG_ERR; out->err = 1; return; }
     if (n >= 5 && std::memcmp(b, "ZCZC-", 5) == 0) {
         size_t off = 0, hl = 0;
         if (!check_header(b, n, &off, &hl)) { out->kind = SAME_TRANSPORT_MSG_ERR; out->err = 3; return; }
         out->kind = SAME_TRANSPORT_MSG_START;
-        out->text.assign((const char *)b, hl);
+        out->len = (uint32_t)hl;
+        std::memcpy(out->text, b, hl);
         out->offset_time = (uint32_t)off;
         for (size_t i = 0; i < hl; ++i) {
             out->parity_errors += errs[i];
@@ -97,17 +101,17 @@ static void parse_message(const uint8_t *b, size_t n, const uint8_t *errs, const
     }
 }
 
-bool combine(const std::vector<const std::vector<uint8_t> *> &bursts, MessageResult *res)
+bool combine(const BurstBuf *bursts, uint32_t nbursts, MessageResult *res)
 {
     // estimate_message rx/combiner.rs:154-203
     uint8_t msg[kMaxMessageLength], cnt[kMaxMessageLength], errs[kMaxMessageLength];
-    const size_t nb = std::min<size_t>(bursts.size(), 3);
+    const size_t nb = std::min<size_t>(nbursts, 3);
     size_t pos[3] = {0, 0, 0};
     size_t n = 0;
     while (n < kMaxMessageLength) {
         uint8_t cur[3]; uint32_t k = 0; bool msb = false;
         for (size_t i = 0; i < nb; ++i)
-            if (pos[i] < bursts[i]->size()) cur[k++] = (*bursts[i])[pos[i]++];
+            if (pos[i] < bursts[i].len) cur[k++] = bursts[i].data[pos[i]++];
         for (uint32_t i = 0; i < k; ++i) { msb |= (cur[i] & 0x80) != 0; cur[i] &= 0x7f; }
         if (k == 0) break;
         uint8_t est; uint32_t be = 0;
@@ -125,7 +129,7 @@ bool combine(const std::vector<const std::vector<uint8_t> *> &bursts, MessageRes
     parse_message(msg, good, errs, cnt, res);
     if (res->kind != SAME_TRANSPORT_MSG_ERR) return true;
     if (n >= 2 && msg[0] == 'N' && msg[1] == 'N') {      // Fast EOM :251-258
-        *res = MessageResult{};
+        clear_result(res);
         res->kind = SAME_TRANSPORT_MSG_END;
         return true;
     }
@@ -134,16 +138,20 @@ bool combine(const std::vector<const std::vector<uint8_t> *> &bursts, MessageRes
 
 void Assembler::reset()
 {
-    history_.clear();
+    nhist_ = 0;
     pending_ = false; have_prev_ = false;
 }
 void Assembler::prune_history(uint64_t now)
 {
-    // rx/assembler.rs:362-368
-    history_.erase(std::remove_if(history_.begin(), history_.end(),
-                                  [now](const Timed &t) { return t.deadline <= now; }),
-                   history_.end());
-    while (history_.size() > 2) history_.pop_front();
+    // rx/assembler.rs:362-368: retain unexpired entries, then keep at most the two newest
+    uint32_t w = 0;
+    for (uint32_t i = 0; i < nhist_; ++i)
+        if (!(history_[i].deadline <= now)) { if (w != i) history_[w] = history_[i]; ++w; }
+    nhist_ = w;
+    while (nhist_ > 2) {
+        for (uint32_t i = 1; i < nhist_; ++i) history_[i - 1] = history_[i];
+        --nhist_;
+    }
 }
 void Assembler::accept(const MessageResult &m, uint64_t now)
 {
@@ -164,7 +172,7 @@ void Assembler::accept(const MessageResult &m, uint64_t now)
 uint32_t Assembler::idle(uint64_t now, MessageResult *msg)
 {
     // rx/assembler.rs:205-234
-    prune_history(now);
+    if (nhist_ > 2 || (nhist_ && history_[0].deadline <= now)) prune_history(now);   // deadlines are pushed in increasing order
     if (pending_ && pend_deadline_ <= now) {             // PendingResult::poll :336-345
         *msg = pend_;
         pending_ = false;
@@ -173,7 +181,7 @@ uint32_t Assembler::idle(uint64_t now, MessageResult *msg)
         }
         return msg->kind;
     }
-    return history_.empty() ? SAME_TRANSPORT_IDLE : SAME_TRANSPORT_ASSEMBLING;
+    return nhist_ == 0 ? SAME_TRANSPORT_IDLE : SAME_TRANSPORT_ASSEMBLING;
 }
 uint32_t Assembler::assemble(const uint8_t *burst, size_t n, uint64_t now, MessageResult *msg)
 {
@@ -181,18 +189,15 @@ uint32_t Assembler::assemble(const uint8_t *burst, size_t n, uint64_t now, Messa
     if (n == 0) return idle(now, msg);
     prune_history(now);
     if (have_prev_ && prev_deadline_ <= now) have_prev_ = false;   // prune_previous :371-376
-    Timed t;
-    t.data.assign(burst, burst + std::min(n, kMaxMessageLength));
+    BurstBuf &t = history_[nhist_++];                               // at most 2 survive the prune
+    t.len = (uint32_t)std::min(n, kMaxMessageLength);
+    std::memcpy(t.data, burst, t.len);
     t.deadline = now + max_history_duration();
-    history_.push_back(std::move(t));
-    std::vector<const std::vector<uint8_t> *> views;
-    for (const Timed &h : history_) views.push_back(&h.data);
     MessageResult res;
-    if (combine(views, &res)) {
+    if (combine(history_, nhist_, &res)) {
         // deduplicate :245-265: messages are duplicates when string-equal
         bool keep = true;
-        if (res.kind != SAME_TRANSPORT_MSG_ERR && have_prev_ && std::strcmp(prev_.as_str(), res.as_str()) == 0)
-            keep = false;
+        if (res.kind != SAME_TRANSPORT_MSG_ERR && have_prev_ && prev_.same_text(res)) keep = false;
         if (keep) accept(res, now);
     }
     return idle(now, msg);
@@ -201,7 +206,7 @@ uint32_t Assembler::assemble(const uint8_t *burst, size_t n, uint64_t now, Messa
 void Transport::reset()
 {
     asm_.reset();
-    state_kind_ = SAME_TRANSPORT_IDLE; state_msg_ = MessageResult{};
+    state_kind_ = SAME_TRANSPORT_IDLE; clear_result(&state_msg_);
     have_force_eom_ = false; dirty_ = true;
     have_polled_ = false; last_polled_symbol_ = 0;
 }
@@ -211,7 +216,7 @@ bool Transport::on_link_event(uint32_t kind, uint64_t sample_counter, uint64_t s
 {
     // process_transportlayer receiver.rs:291-333
     const uint64_t kMaxMessageDurationSecs = 135;        // receiver.rs:496
-    MessageResult msg;
+    MessageResult msg;          // trivially constructed: no heap, text left uninitialised
     uint32_t st;
     // The reference polls once per symbol.  A wake-up tick that lands on the symbol of a link
     // event just handled (e.g. a deadline that expired while the link was Searching is served
@@ -224,7 +229,7 @@ bool Transport::on_link_event(uint32_t kind, uint64_t sample_counter, uint64_t s
         st = asm_.assemble(bytes, len, symbol_count, &msg);
     } else if (kind == SAME_LINK_NO_CARRIER || kind == kDevTick) {
         if (have_force_eom_ && sample_counter > force_eom_at_) {
-            st = SAME_TRANSPORT_MSG_END; msg.kind = st;
+            st = SAME_TRANSPORT_MSG_END; clear_result(&msg); msg.kind = st;
         } else {
             st = asm_.idle(symbol_count, &msg);
         }
@@ -242,14 +247,14 @@ bool Transport::on_link_event(uint32_t kind, uint64_t sample_counter, uint64_t s
     const bool same = (st == state_kind_) && (!is_msg || msg == state_msg_);
     if (same) return false;
     state_kind_ = st;
-    state_msg_ = is_msg ? msg : MessageResult{};
+    if (is_msg) state_msg_ = msg; else clear_result(&state_msg_);
     std::memset(out, 0, offsetof(same_rx_event, bytes));
     out->kind = st;
     out->sample_counter = sample_counter;
     out->symbol_count = symbol_count;
     if (st == SAME_TRANSPORT_MSG_START) {
-        out->len = (uint32_t)msg.text.size();
-        std::memcpy(out->bytes, msg.text.data(), std::min<size_t>(msg.text.size(), SAME_EVENT_MAX_BYTES));
+        out->len = msg.len;
+        std::memcpy(out->bytes, msg.text, std::min<size_t>(msg.len, SAME_EVENT_MAX_BYTES));
         out->aux = msg.voting_bytes; out->aux2 = msg.parity_errors;
     } else if (st == SAME_TRANSPORT_MSG_ERR) {
         out->aux = msg.err;

@@ -35,22 +35,35 @@ void bit_vote_detect(uint8_t b0, uint8_t b1, uint8_t *out, uint32_t *errs);   //
 void bit_vote_correct(uint8_t b0, uint8_t b1, uint8_t b2, uint8_t *out, uint32_t *errs); // :234-249
 bool is_allowed_byte(uint8_t c);                 // rx/combiner.rs:105-137
 
-// MessageResult = Result<Message, MessageDecodeErr>
+// MessageResult = Result<Message, MessageDecodeErr>.  Fixed storage: this sits on the
+// per-event path of every channel, so it must not touch the heap.
 struct MessageResult {
     uint32_t kind = 0;               // SAME_TRANSPORT_MSG_START / _END / _ERR
     uint32_t err = 0;                // 1 NotAscii, 2 UnrecognizedPrefix, 3 Malformed
-    std::string text;                // header text for StartOfMessage
+    uint32_t len = 0;                // header length for StartOfMessage
     uint32_t offset_time = 0, parity_errors = 0, voting_bytes = 0;
+    char text[kMaxMessageLength + 4];
     bool operator==(const MessageResult &o) const
     {
-        return kind == o.kind && err == o.err && text == o.text && offset_time == o.offset_time &&
-               parity_errors == o.parity_errors && voting_bytes == o.voting_bytes;
+        return kind == o.kind && err == o.err && len == o.len && offset_time == o.offset_time &&
+               parity_errors == o.parity_errors && voting_bytes == o.voting_bytes &&
+               std::memcmp(text, o.text, len) == 0;
     }
-    const char *as_str() const { return kind == SAME_TRANSPORT_MSG_END ? "NNNN" : text.c_str(); }
+    // Message::as_str(): header text, or "NNNN" for EndOfMessage (sameplace message.rs:105-110)
+    bool same_text(const MessageResult &o) const
+    {
+        const char *a = kind == SAME_TRANSPORT_MSG_END ? "NNNN" : text;
+        const char *b = o.kind == SAME_TRANSPORT_MSG_END ? "NNNN" : o.text;
+        const uint32_t la = kind == SAME_TRANSPORT_MSG_END ? 4u : len, lb = o.kind == SAME_TRANSPORT_MSG_END ? 4u : o.len;
+        return la == lb && std::memcmp(a, b, la) == 0;
+    }
 };
 
+// one burst as the assembler keeps it (truncated to MAX_MESSAGE_LENGTH, rx/assembler.rs:163-169)
+struct BurstBuf { uint32_t len = 0; uint64_t deadline = 0; uint8_t data[kMaxMessageLength]; };
+
 // combine() rx/combiner.rs:32-80 over up to three bursts; false = None
-bool combine(const std::vector<const std::vector<uint8_t> *> &bursts, MessageResult *out);
+bool combine(const BurstBuf *bursts, uint32_t n, MessageResult *out);
 
 // Assembler rx/assembler.rs:108-266
 class Assembler {
@@ -61,10 +74,9 @@ public:
     uint32_t idle(uint64_t symbol_count, MessageResult *msg);
 
 private:
-    struct Timed { std::vector<uint8_t> data; uint64_t deadline; };
     void prune_history(uint64_t now);
     void accept(const MessageResult &m, uint64_t now);
-    std::deque<Timed> history_;
+    BurstBuf history_[3]; uint32_t nhist_ = 0;     // VecDeque<TimedData<Burst>>, oldest first
     bool pending_ = false; MessageResult pend_; uint64_t pend_deadline_ = 0;
     bool have_prev_ = false; MessageResult prev_; uint64_t prev_deadline_ = 0;
 };

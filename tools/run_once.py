@@ -12,7 +12,7 @@ rate = int(sys.argv[4]) if len(sys.argv) > 4 else 22050
 T = int(rate * secs)
 x = sa.synth_afsk(C, T, rate, seed=1)
 torch.cuda.synchronize()
-rx = sa.SameReceiverBuilder(rate).build_batch(C, link_only=True)
+rx = sa.SameReceiverBuilder(rate).build_batch(C, link_only=not os.environ.get('SAME_TRANSPORT'))
 rx.set_kernel_timing(True)
 for r in range(reps):
     t0 = time.perf_counter()
