@@ -174,8 +174,11 @@ int same_batch_flush(same_batch *rx);
 /* wait for all queued work of this handle */
 int same_batch_sync(same_batch *rx);
 
-/* Drain events produced so far, ordered by (channel, sample_counter, emission order):
- * per channel this is exactly the order iter_events() yields them (receiver.rs:238-269).
+/* Drain events already brought back to the host, ordered by (channel, sample_counter,
+ * emission order) within each process call: per channel this is exactly the order
+ * iter_events() yields them (receiver.rs:238-269).  Never blocks: a launch still running
+ * contributes its events after same_batch_sync (or after the next process call, which
+ * collects the previous launch while the new one runs).
  * Writes up to `cap` events, *n_out = number written, *n_left = events still queued. */
 int same_batch_poll_events(same_batch *rx, same_rx_event *out, size_t cap, size_t *n_out,
                            size_t *n_left);

@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -52,7 +53,6 @@ struct same_batch {
     same_rx_builder builder{};
     same::Params P{};
     same::State S{};
-    same::Output O{};
     int device = 0;
     uint32_t flags = 0;
     uint64_t counter = 0;            // input_sample_counter (common to all channels)
@@ -61,12 +61,21 @@ struct same_batch {
     float4 *d_taps = nullptr;
     void *d_state_blob = nullptr;    // one allocation backing every State array
     size_t state_bytes = 0;
-    // output buffers (grown on demand)
-    same::DevEvent *d_events = nullptr; uint32_t event_cap = 0;
-    uint8_t *d_bursts = nullptr; uint32_t burst_cap = 0;
-    uint32_t *d_counters = nullptr;  // [0] n_events [1] n_bursts [2] overflow
-    uint32_t *h_counters = nullptr;  // pinned
-    bool in_flight = false;
+    // Output of a launch: event log + burst pool + cursors.  Two slots, so the host can
+    // harvest launch k (copy back, order, transport layer) while launch k+1 runs.
+    struct Slot {
+        same::DevEvent *d_events = nullptr; uint32_t event_cap = 0;
+        uint8_t *d_bursts = nullptr; uint32_t burst_cap = 0;
+        uint32_t *d_counters = nullptr;  // [0] n_events [1] n_bursts [2] overflow
+        uint32_t *h_counters = nullptr;  // pinned, host-mapped
+        uint32_t *h_counters_dev = nullptr;  // device view of h_counters
+        hipEvent_t ev_start = nullptr, ev_stop = nullptr, ev_done = nullptr;
+        bool in_flight = false;
+        uint64_t seq = 0;                // launch order
+    } slot[2];
+    uint64_t launch_seq = 0;
+    hipStream_t copy_stream = nullptr;   // read-back of finished launches, beside the compute stream
+    float last_ms = 0.0f;
     bool overflowed = false;
     bool use_fast = false;           // configuration has a latency-optimised kernel
     bool force_generic = false;      // SAME_BATCH_GENERIC_KERNEL (tests compare both kernels)
@@ -75,7 +84,6 @@ struct same_batch {
     void *d_stage2 = nullptr; size_t stage2_bytes = 0;
     // kernel timing
     bool timing = false;
-    hipEvent_t ev_start = nullptr, ev_stop = nullptr;
     bool have_timing = false;
     // ordered host-side event queue
     std::vector<same_rx_event> queue;   // events not yet polled: [queue_head, size)
@@ -126,7 +134,7 @@ size_t carve_state(const same::Params &P, char *base, same::State &S)
     CARVE(flags, uint32_t, C);
     CARVE(tk_next, uint64_t, C); CARVE(tk_last, uint64_t, C);
     CARVE(tk_ring, uint64_t, (size_t)same::kTickRing * C);
-    CARVE(tk_n, uint32_t, C); CARVE(wake_sample, uint64_t, C);
+    CARVE(tk_n, uint32_t, C); CARVE(wake_sample, uint64_t, C); CARVE(wake_fired, uint64_t, C);
     if (P.trace_cap) {
         CARVE(trace_n, uint32_t, C);
         CARVE(trace, float, (size_t)P.trace_cap * 4 * C);
@@ -136,7 +144,7 @@ size_t carve_state(const same::Params &P, char *base, same::State &S)
     return (cv.off + 255) & ~size_t(255);
 }
 
-int ensure_output(same_batch *rx, size_t n_samples)
+int ensure_output(same_batch *rx, same_batch::Slot &sl, size_t n_samples, same::Output &O)
 {
     // Worst case per channel: an acquisition attempt (Searching ... NoCarrier) needs a
     // fresh byte sync, i.e. at least 32 symbols, so < 2 link events per 32 symbols; bursts
@@ -146,21 +154,21 @@ int ensure_output(same_batch *rx, size_t n_samples)
     const size_t per_chan_bursts = (size_t)(symbols / 160.0) + 4;   // a burst is >= 20 bytes
     size_t ecap = std::min<size_t>(per_chan_events * rx->P.n_channels, 0x7fffffffu / sizeof(same::DevEvent));
     size_t bcap = std::min<size_t>(per_chan_bursts * rx->P.n_channels, 0x7fffffffu / same::kBurstCap);
-    if (ecap > rx->event_cap) {
-        if (rx->d_events) HIP_TRY(hipFree(rx->d_events));
-        rx->d_events = nullptr; rx->event_cap = 0;
-        HIP_TRY(hipMalloc((void **)&rx->d_events, ecap * sizeof(same::DevEvent)));
-        rx->event_cap = (uint32_t)ecap;
+    if (ecap > sl.event_cap) {
+        if (sl.d_events) HIP_TRY(hipFree(sl.d_events));
+        sl.d_events = nullptr; sl.event_cap = 0;
+        HIP_TRY(hipMalloc((void **)&sl.d_events, ecap * sizeof(same::DevEvent)));
+        sl.event_cap = (uint32_t)ecap;
     }
-    if (bcap > rx->burst_cap) {
-        if (rx->d_bursts) HIP_TRY(hipFree(rx->d_bursts));
-        rx->d_bursts = nullptr; rx->burst_cap = 0;
-        HIP_TRY(hipMalloc((void **)&rx->d_bursts, bcap * same::kBurstCap));
-        rx->burst_cap = (uint32_t)bcap;
+    if (bcap > sl.burst_cap) {
+        if (sl.d_bursts) HIP_TRY(hipFree(sl.d_bursts));
+        sl.d_bursts = nullptr; sl.burst_cap = 0;
+        HIP_TRY(hipMalloc((void **)&sl.d_bursts, bcap * same::kBurstCap));
+        sl.burst_cap = (uint32_t)bcap;
     }
-    rx->O.events = rx->d_events; rx->O.event_cap = rx->event_cap;
-    rx->O.bursts = rx->d_bursts; rx->O.burst_cap = rx->burst_cap;
-    rx->O.n_events = rx->d_counters; rx->O.n_bursts = rx->d_counters + 1; rx->O.overflow = rx->d_counters + 2;
+    O.events = sl.d_events; O.event_cap = sl.event_cap;
+    O.bursts = sl.d_bursts; O.burst_cap = sl.burst_cap;
+    O.n_events = sl.d_counters; O.n_bursts = sl.d_counters + 1; O.overflow = sl.d_counters + 2;
     return SAME_OK;
 }
 
@@ -176,22 +184,32 @@ int ensure_stage(void **p, size_t *have, size_t need)
 
 // Collect the finished launch: copy its event log back, order it, run the transport
 // layer, append to the queue.
-int harvest(same_batch *rx)
+int harvest_slot(same_batch *rx, same_batch::Slot &sl)
 {
-    if (!rx->in_flight) return SAME_OK;
-    HIP_TRY(hipStreamSynchronize(rx->last_stream));
-    rx->in_flight = false;
-    if (rx->timing) rx->have_timing = true;
-    const uint32_t n_events = std::min(rx->h_counters[0], rx->event_cap);
-    if (std::getenv("SAME_DEBUG"))
-        std::fprintf(stderr, "[same] harvest: %u device events (%u bursts), cap %u/%u\n", rx->h_counters[0],
-                     rx->h_counters[1], rx->event_cap, rx->burst_cap);
-    const uint32_t n_bursts = std::min(rx->h_counters[1], rx->burst_cap);
-    if (rx->h_counters[2]) rx->overflowed = true;
+    if (!sl.in_flight) return SAME_OK;
+    const bool dbg = std::getenv("SAME_DEBUG") != nullptr;
+    auto t_begin = std::chrono::steady_clock::now();
+    // wait for THIS launch only (its cursors have landed in pinned memory); a later launch
+    // may still be running on the compute stream
+    HIP_TRY(hipEventSynchronize(sl.ev_done));
+    sl.in_flight = false;
+    if (rx->timing) {
+        HIP_TRY(hipEventElapsedTime(&rx->last_ms, sl.ev_start, sl.ev_stop));
+        rx->have_timing = true;
+    }
+    auto t_waited = std::chrono::steady_clock::now();
+    const uint32_t n_events = std::min(sl.h_counters[0], sl.event_cap);
+    if (dbg)
+        std::fprintf(stderr, "[same] harvest: %u device events (%u bursts), cap %u/%u\n", sl.h_counters[0],
+                     sl.h_counters[1], sl.event_cap, sl.burst_cap);
+    const uint32_t n_bursts = std::min(sl.h_counters[1], sl.burst_cap);
+    if (sl.h_counters[2]) rx->overflowed = true;
     std::vector<same::DevEvent> evs(n_events);
     std::vector<uint8_t> bursts((size_t)n_bursts * same::kBurstCap);
-    if (n_events) HIP_TRY(hipMemcpy(evs.data(), rx->d_events, (size_t)n_events * sizeof(same::DevEvent), hipMemcpyDeviceToHost));
-    if (n_bursts) HIP_TRY(hipMemcpy(bursts.data(), rx->d_bursts, bursts.size(), hipMemcpyDeviceToHost));
+    if (n_events) HIP_TRY(hipMemcpyAsync(evs.data(), sl.d_events, (size_t)n_events * sizeof(same::DevEvent), hipMemcpyDeviceToHost, rx->copy_stream));
+    if (n_bursts) HIP_TRY(hipMemcpyAsync(bursts.data(), sl.d_bursts, bursts.size(), hipMemcpyDeviceToHost, rx->copy_stream));
+    if (n_events || n_bursts) HIP_TRY(hipStreamSynchronize(rx->copy_stream));
+    auto t_copied = std::chrono::steady_clock::now();
     // per channel the device emits in time order; across lanes the atomic cursor interleaves
     std::stable_sort(evs.begin(), evs.end(), [](const same::DevEvent &a, const same::DevEvent &b) {
         if (a.channel != b.channel) return a.channel < b.channel;
@@ -238,7 +256,28 @@ int harvest(same_batch *rx)
         // re-armed at worst to an instant in the past: one harmless extra poll)
         if (rx->h_wake.size() != rx->P.n_channels) rx->h_wake.assign(rx->P.n_channels, 0);
         for (uint32_t c : rearm) rx->h_wake[c] = rx->transport[c].force_eom_at();
-        HIP_TRY(hipMemcpy(rx->S.wake_sample, rx->h_wake.data(), rx->h_wake.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
+        // the kernels only read this table (it is host-owned), so it may be updated while a
+        // later launch runs; launches are capped at 45 s, two launches < the 135 s timeout
+        HIP_TRY(hipMemcpyAsync(rx->S.wake_sample, rx->h_wake.data(), rx->h_wake.size() * sizeof(uint64_t), hipMemcpyHostToDevice, rx->copy_stream));
+        HIP_TRY(hipStreamSynchronize(rx->copy_stream));
+    }
+    if (dbg) {
+        auto t_end = std::chrono::steady_clock::now();
+        auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+        std::fprintf(stderr, "[same] harvest timing: wait %.2f ms, copy %.2f ms, order+transport %.2f ms\n",
+                     ms(t_begin, t_waited), ms(t_waited, t_copied), ms(t_copied, t_end));
+    }
+    return SAME_OK;
+}
+
+// harvest every launch still in flight, oldest first
+int harvest(same_batch *rx)
+{
+    same_batch::Slot *order[2] = {&rx->slot[0], &rx->slot[1]};
+    if (order[0]->seq > order[1]->seq) std::swap(order[0], order[1]);
+    for (same_batch::Slot *sl : order) {
+        int rc = harvest_slot(rx, *sl);
+        if (rc) return rc;
     }
     return SAME_OK;
 }
@@ -246,17 +285,21 @@ int harvest(same_batch *rx)
 template <typename SampleT>
 int process_time_major(same_batch *rx, const SampleT *d_x, size_t n_samples, hipStream_t stream)
 {
-    // keep one launch comfortably inside u32 sample indices and bounded output pools
-    const size_t kMaxChunk = std::min<size_t>((size_t)1 << 22, (size_t)rx->P.input_rate * 60);
+    // keep one launch comfortably inside u32 sample indices and bounded output pools, and
+    // well under the 135 s forced-EOM timeout the host arms one launch late (harvest)
+    const size_t kMaxChunk = std::min<size_t>((size_t)1 << 22, (size_t)rx->P.input_rate * 45);
     size_t done = 0;
     while (done < n_samples) {
         const size_t n = std::min(kMaxChunk, n_samples - done);
-        int rc = harvest(rx);
+        same_batch::Slot &sl = rx->slot[rx->launch_seq & 1];
+        same_batch::Slot &prev = rx->slot[(rx->launch_seq & 1) ^ 1];
+        int rc = harvest_slot(rx, sl);          // its buffers are about to be reused
         if (rc) return rc;
-        rc = ensure_output(rx, n);
+        same::Output O{};
+        rc = ensure_output(rx, sl, n, O);
         if (rc) return rc;
-        HIP_TRY(hipMemsetAsync(rx->d_counters, 0, 3 * sizeof(uint32_t), stream));
-        if (rx->timing) HIP_TRY(hipEventRecord(rx->ev_start, stream));
+        HIP_TRY(same::launch_counters(sl.d_counters, sl.h_counters_dev, 0, stream));
+        if (rx->timing) HIP_TRY(hipEventRecord(sl.ev_start, stream));
         const SampleT *xp = d_x + done * rx->P.n_channels;
         hipError_t e = hipSuccess;
         // whole 16-sample blocks go to the latency-optimised kernel when the configuration
@@ -264,25 +307,30 @@ int process_time_major(same_batch *rx, const SampleT *d_x, size_t n_samples, hip
         size_t n_fast = (rx->use_fast && !rx->force_generic) ? (n / 16) * 16 : 0;
         if (n_fast) {
             if constexpr (sizeof(SampleT) == 4)
-                e = same::launch_demod_fast(rx->P, rx->S, rx->O, rx->d_taps, (const float *)xp, (uint32_t)(n_fast / 16), rx->counter, stream);
+                e = same::launch_demod_fast(rx->P, rx->S, O, rx->d_taps, (const float *)xp, (uint32_t)(n_fast / 16), rx->counter, stream);
             else
-                e = same::launch_demod_fast_i16(rx->P, rx->S, rx->O, rx->d_taps, (const int16_t *)xp, (uint32_t)(n_fast / 16), rx->counter, stream);
+                e = same::launch_demod_fast_i16(rx->P, rx->S, O, rx->d_taps, (const int16_t *)xp, (uint32_t)(n_fast / 16), rx->counter, stream);
             if (e != hipSuccess) return fail(SAME_EHIP, "fast demod kernel launch failed: %s", hipGetErrorString(e));
         }
         if (n_fast < n) {
             const SampleT *xr = xp + n_fast * rx->P.n_channels;
             if constexpr (sizeof(SampleT) == 4)
-                e = same::launch_demod(rx->P, rx->S, rx->O, rx->d_taps, (const float *)xr, (uint32_t)(n - n_fast), rx->counter + n_fast, stream);
+                e = same::launch_demod(rx->P, rx->S, O, rx->d_taps, (const float *)xr, (uint32_t)(n - n_fast), rx->counter + n_fast, stream);
             else
-                e = same::launch_demod_i16(rx->P, rx->S, rx->O, rx->d_taps, (const int16_t *)xr, (uint32_t)(n - n_fast), rx->counter + n_fast, stream);
+                e = same::launch_demod_i16(rx->P, rx->S, O, rx->d_taps, (const int16_t *)xr, (uint32_t)(n - n_fast), rx->counter + n_fast, stream);
             if (e != hipSuccess) return fail(SAME_EHIP, "demod kernel launch failed: %s", hipGetErrorString(e));
         }
-        if (rx->timing) HIP_TRY(hipEventRecord(rx->ev_stop, stream));
-        HIP_TRY(hipMemcpyAsync(rx->h_counters, rx->d_counters, 3 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
-        rx->in_flight = true;
+        if (rx->timing) HIP_TRY(hipEventRecord(sl.ev_stop, stream));
+        HIP_TRY(same::launch_counters(sl.d_counters, sl.h_counters_dev, 1, stream));
+        HIP_TRY(hipEventRecord(sl.ev_done, stream));
+        sl.in_flight = true;
+        sl.seq = ++rx->launch_seq;
         rx->last_stream = stream;
         rx->counter += n;
         done += n;
+        // while this launch runs, bring in the previous one
+        rc = harvest_slot(rx, prev);
+        if (rc) return rc;
     }
     return SAME_OK;
 }
@@ -302,9 +350,7 @@ int process_device_any(same_batch *rx, const SampleT *d_x, size_t n_samples, uin
     if (rc) return rc;
     for (size_t t0 = 0; t0 < n_samples; t0 += slab) {
         const size_t n = std::min(slab, n_samples - t0);
-        // the previous slab's kernel must be done with the staging buffer
-        rc = harvest(rx);
-        if (rc) return rc;
+        // stream order keeps the previous slab's kernel ahead of this slab's staging writes
         // rows of the source are n_samples long; transpose a [C][n] window starting at t0
         hipError_t e;
         // a strided window is expressed by offsetting the base and keeping the row pitch:
@@ -401,16 +447,21 @@ int same_batch_new(const same_rx_builder *b, uint32_t n_channels, int device, ui
     if (same::demod_lds_bytes(rx->P) > 160 * 1024)
         return cleanup(fail(SAME_EINVAL, "configuration needs %zu bytes of LDS per wavefront (limit 160 KiB)", same::demod_lds_bytes(rx->P)));
     TRY_OR_CLEAN(hipStreamCreateWithFlags(&rx->own_stream, hipStreamNonBlocking));
-    TRY_OR_CLEAN(hipEventCreate(&rx->ev_start));
-    TRY_OR_CLEAN(hipEventCreate(&rx->ev_stop));
+    TRY_OR_CLEAN(hipStreamCreateWithFlags(&rx->copy_stream, hipStreamNonBlocking));
+    for (auto &sl : rx->slot) {
+        TRY_OR_CLEAN(hipEventCreate(&sl.ev_start));
+        TRY_OR_CLEAN(hipEventCreate(&sl.ev_stop));
+        TRY_OR_CLEAN(hipEventCreateWithFlags(&sl.ev_done, hipEventDisableTiming));
+        TRY_OR_CLEAN(hipMalloc((void **)&sl.d_counters, 4 * sizeof(uint32_t)));
+        TRY_OR_CLEAN(hipHostMalloc((void **)&sl.h_counters, 4 * sizeof(uint32_t), hipHostMallocMapped));
+        TRY_OR_CLEAN(hipHostGetDevicePointer((void **)&sl.h_counters_dev, sl.h_counters, 0));
+    }
     TRY_OR_CLEAN(hipMalloc((void **)&rx->d_taps, taps.size() * sizeof(float)));
     TRY_OR_CLEAN(hipMemcpy(rx->d_taps, taps.data(), taps.size() * sizeof(float), hipMemcpyHostToDevice));
     rx->state_bytes = carve_state(rx->P, nullptr, rx->S);
     TRY_OR_CLEAN(hipMalloc(&rx->d_state_blob, rx->state_bytes));
     TRY_OR_CLEAN(hipMemset(rx->d_state_blob, 0, rx->state_bytes));
     carve_state(rx->P, (char *)rx->d_state_blob, rx->S);
-    TRY_OR_CLEAN(hipMalloc((void **)&rx->d_counters, 4 * sizeof(uint32_t)));
-    TRY_OR_CLEAN(hipHostMalloc((void **)&rx->h_counters, 4 * sizeof(uint32_t), hipHostMallocDefault));
     TRY_OR_CLEAN(same::launch_init_state(rx->P, rx->S, 0, rx->own_stream));
     TRY_OR_CLEAN(hipStreamSynchronize(rx->own_stream));
 #undef TRY_OR_CLEAN
@@ -423,17 +474,21 @@ void same_batch_free(same_batch *rx)
 {
     if (!rx) return;
     (void)hipSetDevice(rx->device);
-    if (rx->in_flight && rx->last_stream) (void)hipStreamSynchronize(rx->last_stream);
+    if (rx->last_stream) (void)hipStreamSynchronize(rx->last_stream);
     if (rx->d_taps) (void)hipFree(rx->d_taps);
     if (rx->d_state_blob) (void)hipFree(rx->d_state_blob);
-    if (rx->d_events) (void)hipFree(rx->d_events);
-    if (rx->d_bursts) (void)hipFree(rx->d_bursts);
-    if (rx->d_counters) (void)hipFree(rx->d_counters);
-    if (rx->h_counters) (void)hipHostFree(rx->h_counters);
+    for (auto &sl : rx->slot) {
+        if (sl.d_events) (void)hipFree(sl.d_events);
+        if (sl.d_bursts) (void)hipFree(sl.d_bursts);
+        if (sl.d_counters) (void)hipFree(sl.d_counters);
+        if (sl.h_counters) (void)hipHostFree(sl.h_counters);
+        if (sl.ev_start) (void)hipEventDestroy(sl.ev_start);
+        if (sl.ev_stop) (void)hipEventDestroy(sl.ev_stop);
+        if (sl.ev_done) (void)hipEventDestroy(sl.ev_done);
+    }
+    if (rx->copy_stream) (void)hipStreamDestroy(rx->copy_stream);
     if (rx->d_stage) (void)hipFree(rx->d_stage);
     if (rx->d_stage2) (void)hipFree(rx->d_stage2);
-    if (rx->ev_start) (void)hipEventDestroy(rx->ev_start);
-    if (rx->ev_stop) (void)hipEventDestroy(rx->ev_stop);
     if (rx->own_stream) (void)hipStreamDestroy(rx->own_stream);
     delete rx;
 }
@@ -500,18 +555,14 @@ int same_batch_sync(same_batch *rx)
 
 size_t same_batch_pending_events(same_batch *rx)
 {
+    // events already brought back to the host; does not wait for launches still in flight
     if (!rx) return 0;
-    (void)hipSetDevice(rx->device);
-    (void)harvest(rx);
     return rx->queue.size() - rx->queue_head;
 }
 
 int same_batch_poll_events(same_batch *rx, same_rx_event *out, size_t cap, size_t *n_out, size_t *n_left)
 {
     if (!rx || (!out && cap)) return fail(SAME_EINVAL, "null argument");
-    HIP_TRY(hipSetDevice(rx->device));
-    int rc = harvest(rx);
-    if (rc) return rc;
     const size_t avail = rx->queue.size() - rx->queue_head;
     const size_t n = std::min(cap, avail);
     if (n) std::memcpy(out, rx->queue.data() + rx->queue_head, n * sizeof(same_rx_event));
@@ -553,11 +604,9 @@ void same_batch_set_kernel_timing(same_batch *rx, int enable) { if (rx) { rx->ti
 int same_batch_last_kernel_ms(same_batch *rx, float *ms)
 {
     if (!rx || !ms) return fail(SAME_EINVAL, "null argument");
-    HIP_TRY(hipSetDevice(rx->device));
-    int rc = harvest(rx);
-    if (rc) return rc;
+    // duration of the most recently collected launch; never waits for one still running
     if (!rx->have_timing) return fail(SAME_EINVAL, "no timed launch yet");
-    HIP_TRY(hipEventElapsedTime(ms, rx->ev_start, rx->ev_stop));
+    *ms = rx->last_ms;
     return SAME_OK;
 }
 const char *same_batch_kernel_name(const same_batch *rx)

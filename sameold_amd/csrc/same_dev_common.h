@@ -50,7 +50,7 @@ struct Lane {
     uint32_t eq_word, eq_count;
     uint32_t fr_word, fr_count, fr_invalid, fr_len;
     uint32_t flags;
-    uint64_t tk_next, tk_last, wake_sample;
+    uint64_t tk_next, tk_last, wake_sample, wake_fired;
 };
 
 __device__ __forceinline__ void lane_load(Lane &L, const State &S, uint32_t c)
@@ -64,7 +64,7 @@ __device__ __forceinline__ void lane_load(Lane &L, const State &S, uint32_t c)
     L.eq_word = S.eq_word[c]; L.eq_count = S.eq_count[c];
     L.fr_word = S.fr_word[c]; L.fr_count = S.fr_count[c]; L.fr_invalid = S.fr_invalid[c];
     L.fr_len = S.fr_len[c]; L.flags = S.flags[c];
-    L.tk_next = S.tk_next[c]; L.tk_last = S.tk_last[c]; L.wake_sample = S.wake_sample[c];
+    L.tk_next = S.tk_next[c]; L.tk_last = S.tk_last[c]; L.wake_sample = S.wake_sample[c]; L.wake_fired = S.wake_fired[c];
 }
 __device__ __forceinline__ void lane_store(const Lane &L, const State &S, uint32_t c)
 {
@@ -77,7 +77,7 @@ __device__ __forceinline__ void lane_store(const Lane &L, const State &S, uint32
     S.eq_word[c] = L.eq_word; S.eq_count[c] = L.eq_count;
     S.fr_word[c] = L.fr_word; S.fr_count[c] = L.fr_count; S.fr_invalid[c] = L.fr_invalid;
     S.fr_len[c] = L.fr_len; S.flags[c] = L.flags;
-    S.tk_next[c] = L.tk_next; S.tk_last[c] = L.tk_last; S.wake_sample[c] = L.wake_sample;
+    S.tk_next[c] = L.tk_next; S.tk_last[c] = L.tk_last; S.wake_fired[c] = L.wake_fired;   // wake_sample is the host's
 }
 
 // ---------------------------------------------------------------------------------
@@ -551,10 +551,10 @@ __device__ __forceinline__ void tick_poll(const Params &P, Lane &L, const State 
     const uint32_t C = P.n_channels;
     const uint64_t sym = L.sq_symbols;
     const bool expired = sym >= L.tk_next;
-    const bool woke = L.wake_sample != 0 && counter > L.wake_sample;
+    const bool woke = L.wake_sample != 0 && L.wake_sample != L.wake_fired && counter > L.wake_sample;
     emit_event(P, S, O, c, 8u, counter, sym, 0);
     L.flags &= ~F_TICK_AGAIN;
-    if (woke) L.wake_sample = 0;
+    if (woke) L.wake_fired = L.wake_sample;
     if (expired) {
         uint32_t n = S.tk_n[c], drop = 0;
         while (drop < n && S.tk_ring[drop * C + c] <= sym) ++drop;
@@ -651,7 +651,7 @@ __device__ __forceinline__ void ted_instant(const Params &P, Lane &L, const Stat
             tick_on_burst(P, L, S, c);
         } else if (link == 0u) {
             if ((L.flags & F_TICK_AGAIN) || L.sq_symbols >= L.tk_next ||
-                (L.wake_sample != 0 && counter > L.wake_sample))
+                (L.wake_sample != 0 && L.wake_sample != L.wake_fired && counter > L.wake_sample))
                 tick_poll(P, L, S, O, c, counter);
         }
     }

@@ -107,7 +107,8 @@ struct State {
     uint64_t *tk_last;     // last burst + MAX_HISTORY_DURATION (~0 = none / already reported)
     uint64_t *tk_ring;     // [kTickRing][C] burst + MAX_INTERBURST_SYMBOLS, oldest first
     uint32_t *tk_n;        // entries in tk_ring
-    uint64_t *wake_sample; // force-EOM instant (receiver.rs:321-324), 0 = none
+    uint64_t *wake_sample; // force-EOM instant (receiver.rs:321-324), 0 = none; HOST-owned, read-only here
+    uint64_t *wake_fired;  // the wake_sample value already reported (device-owned)
     // soft-symbol trace (optional)
     uint32_t *trace_n;     // [C]
     float *trace;          // [C][trace_cap][4]

@@ -204,9 +204,27 @@ __global__ void init_state_kernel(Params P, State S, int is_reset)
     // the framer goes idle and the reported link state returns to NoCarrier.
     uint32_t fl = is_reset ? (S.flags[c] & (F_EQ_MODE_MASK | F_BW_LOCKED)) : (1u << F_EQ_MODE_SHIFT);
     S.flags[c] = fl;
-    S.tk_next[c] = kNoDeadline; S.tk_last[c] = kNoDeadline; S.tk_n[c] = 0; S.wake_sample[c] = 0;
+    S.tk_next[c] = kNoDeadline; S.tk_last[c] = kNoDeadline; S.tk_n[c] = 0; S.wake_sample[c] = 0; S.wake_fired[c] = 0;
     for (uint32_t i = 0; i < (uint32_t)kTickRing; ++i) S.tk_ring[i * C + c] = kNoDeadline;
     if (P.trace_cap) S.trace_n[c] = 0;
+}
+
+// ---------------------------------------------------------------------------------
+// cursor housekeeping as kernels, so a launch is compute-queue work only (a memset or a
+// device-to-host copy in the stream drags the SDMA engine and host-resolved dependencies
+// between consecutive launches into the critical path)
+// ---------------------------------------------------------------------------------
+__global__ void counters_kernel(uint32_t *dev, volatile uint32_t *host, int publish)
+{
+    if (threadIdx.x < 3) {
+        if (publish) host[threadIdx.x] = dev[threadIdx.x];
+        else dev[threadIdx.x] = 0;
+    }
+}
+hipError_t launch_counters(uint32_t *dev, uint32_t *host_mapped, int publish, hipStream_t stream)
+{
+    hipLaunchKernelGGL(counters_kernel, dim3(1), dim3(64), 0, stream, dev, host_mapped, publish);
+    return hipGetLastError();
 }
 
 // ---------------------------------------------------------------------------------

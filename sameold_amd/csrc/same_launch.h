@@ -18,6 +18,8 @@ hipError_t launch_demod_fast(const Params &P, const State &S, const Output &O, c
                              const float *x, uint32_t n_blocks, uint64_t counter0, hipStream_t stream);
 hipError_t launch_demod_fast_i16(const Params &P, const State &S, const Output &O, const float4 *taps,
                                  const int16_t *x, uint32_t n_blocks, uint64_t counter0, hipStream_t stream);
+// zero the launch cursors (publish = 0) or copy them to host-mapped memory (publish = 1)
+hipError_t launch_counters(uint32_t *dev, uint32_t *host_mapped, int publish, hipStream_t stream);
 hipError_t launch_init_state(const Params &P, const State &S, int is_reset, hipStream_t stream);
 hipError_t launch_transpose_f32(const float *in, float *out, uint32_t n_channels, uint32_t n_samples,
                                 hipStream_t stream);

@@ -366,7 +366,8 @@ class SameBatchReceiver:
         return ms.value
 
     def poll_events(self, max_events: int = 1 << 20) -> List[Event]:
-        """Drain events ordered by (channel, sample_counter)."""
+        """Drain the events already on the host, ordered by (channel, sample_counter) within
+        each call's batch.  Non-blocking: call sync() first to include a launch in flight."""
         out: List[Event] = []
         buf = (Event * 1024)()
         while len(out) < max_events:

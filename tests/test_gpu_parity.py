@@ -378,3 +378,42 @@ def test_byte_clock_realignment_mid_preamble(sa, ob):
         got = events_by_channel(rx)
         for c in range(64):
             assert got.get(c, []) == ref[c], f"generic={generic} channel {c}"
+
+
+def test_forced_end_of_message_timeout(sa, ob):
+    """receiver.rs:300-309: 135 s after a StartOfMessage with no EOM, the receiver emits
+    EndOfMessage at the first idle symbol past the deadline.  The deadline lives on the host
+    and is armed on the device as a wake-up; timing must equal the oracle's."""
+    afsk = make_test_burst(ob, b"ZCZC-WXR-TOR-039173+0030-1591829-KCLE/NWS-", 3)
+    x = np.concatenate([afsk, np.zeros(22050 * 140, np.float32)])
+    ref = [e.as_tuple() for e in ob.Receiver(ob.default_config(22050)).run(x)]
+    assert [t[0] for t in ref].count(sa.TRANSPORT_MSG_END) == 1
+    rx = sa.SameReceiverBuilder(22050).build_batch(1)
+    # several calls, so the wake-up is armed between launches as in streaming use
+    for off in range(0, len(x), 22050 * 20):
+        rx.process_host(x[off:off + 22050 * 20])
+    got = [e.as_tuple() for e in rx.poll_events()]
+    assert got == ref
+
+
+def test_pipelined_calls_keep_event_order(sa, ob):
+    """Two launches in flight (harvest of k overlaps launch k+1): events still come out in
+    per-channel time order and equal the one-shot result."""
+    import torch
+    n_ch, n = 128, 22050 * 6
+    x = mixed_batch(sa, n_ch, n, seed=21)
+    xd = torch.from_numpy(x).cuda()
+    one = sa.SameReceiverBuilder(22050).build_batch(n_ch)
+    one.process_tensor(xd); one.sync()
+    want = events_by_channel(one)
+    rx = sa.SameReceiverBuilder(22050).build_batch(n_ch)
+    got = {}
+    step = 22050
+    for off in range(0, n, step):
+        rx.process_tensor(xd[off:off + step].contiguous())      # no sync between calls
+        for e in rx.poll_events():
+            got.setdefault(e.channel, []).append(e.as_tuple())
+    rx.sync()
+    for e in rx.poll_events():
+        got.setdefault(e.channel, []).append(e.as_tuple())
+    assert got == want
