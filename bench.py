@@ -155,6 +155,17 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # HBM bytes per launch from the committed PMC passes (FETCH_SIZE x2 on gfx950 + WRITE_SIZE,
+    # profiles/r01_fetch_calibration.txt); only valid for the workload it was collected on
+    traffic = args.traffic
+    if traffic is None:
+        try:
+            with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as f:
+                tj = json.load(f)
+            if tj.get("workload") == f"{C} ch x {T} samples":
+                traffic = tj["hbm_bytes_per_launch"]
+        except Exception:
+            traffic = None
     value = C * T * world * args.steps / elapsed / 1e6
     achieved = 4.0 * C * T / (k_ms * 1e-3) / 1e9
     out = {
@@ -180,7 +191,7 @@ def main():
         },
         "roofline": {
             "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": args.traffic,
+            "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
             "kernel_ms": round(k_ms, 4), "algorithmic_bytes_per_launch": 4 * C * T,
             "note": "latency/issue-bound at 64 wavefronts on 1024 SIMDs (DESIGN.md section 5)",
         },
