@@ -639,7 +639,11 @@ __device__ __forceinline__ void ted_instant(const Params &P, Lane &L, const Stat
     }
 
     uint32_t burst_len = 0;
+#if defined(SAME_ABLATE) && SAME_ABLATE == 1
+    uint32_t link = (L.flags & F_LINK_MASK) >> F_LINK_SHIFT; L.sq_symbols += 1; L.sq_power += sym + zero;   // ablation build: no symbol path
+#else
     uint32_t link = rx_symbol(P, L, S, X, c, zero, sym, &burst_len);
+#endif
     // receiver.rs:246-253: report on change (a Burst always differs from its predecessor)
     uint32_t last = (L.flags & F_LINK_MASK) >> F_LINK_SHIFT;
     if (link != last || link == 3u) {

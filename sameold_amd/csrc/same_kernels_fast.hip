@@ -306,7 +306,11 @@ __global__ __launch_bounds__(kWave) void demod_fast_kernel(Params P, State S, Ou
         if (until < kB) {
             const int fk = until;
             const uint32_t newest = (wpos + (uint32_t)fk) & (uint32_t)(RING - 1);
+#if defined(SAME_ABLATE) && SAME_ABLATE == 2
+            const float sa_low = wcol[newest * kWave] * 0.01f;   // ablation build: no matched filter
+#else
             const float sa_low = demod_fast<NT, RING>(taps, wcol, lane, newest, LP);
+#endif
             const float rem = L.until_next_ted - (float)cstar;          // receiver.rs:352
             const uint32_t locked_before = L.flags & F_AGC_LOCKED;
             ted_instant(P, L, S, O, X, c, sa_low, rem,
