@@ -402,49 +402,47 @@ template <typename Ctx>
 __device__ __forceinline__ uint32_t rx_symbol(const Params &P, Lane &L, const State &S, Ctx &X,
                                               uint32_t c, float zero, float sym, uint32_t *burst_len)
 {
+    // Written as straight-line selects wherever the work is a few integer operations: a
+    // 64-lane wavefront has lanes in every state at once, so every branch region executes
+    // anyway and each exec-mask region costs scalar work, hazards and register copies.
+    // Branches are kept only around the expensive or rare pieces (equalizer step, byte
+    // handling, end-of-burst reset, event emission).
+
     // --- CodeAndPowerSquelch::input rx/codesquelch.rs:228-304
-    uint32_t slot = (uint32_t)(2u * (uint32_t)L.sq_symbols) & 63u;
+    const uint32_t slot = (uint32_t)(2u * (uint32_t)L.sq_symbols) & 63u;
     X.hist_put(slot, zero);
     X.hist_put(slot + 1u, sym);
-    L.sq_fill = min(64u, L.sq_fill + 2u);
-    uint32_t bit = (sym >= 0.0f) ? 1u : 0u;                 // CodeCorrelator::search :421-428
+    const uint32_t fill = min(64u, L.sq_fill + 2u);
+    L.sq_fill = fill;
+    const uint32_t bit = (sym >= 0.0f) ? 1u : 0u;           // CodeCorrelator::search :421-428
     L.sq_data = (L.sq_data >> 1) | (bit << 31);
-    uint32_t nerr = __popc(P.sync_word ^ L.sq_data);
-    float pw = sym * sym;                                   // PowerTracker::track :483-488
-    float dp = pw - L.sq_power;
-    float up = dp * P.sq_bw;
+    const uint32_t nerr = __popc(P.sync_word ^ L.sq_data);
+    const float pw = sym * sym;                             // PowerTracker::track :483-488
+    const float dp = pw - L.sq_power;
+    const float up = dp * P.sq_bw;
     L.sq_power += up;
     L.sq_power = fmaxf(L.sq_power, 0.0f);
-    float pwr = L.sq_power;
+    const float pwr = L.sq_power;
     L.sq_phist = (L.sq_phist << 1) | ((pwr >= P.sq_power_close) ? 1u : 0u);
     L.sq_symbols += 1;
+
     const int32_t clock_before = L.sq_clock;                // byte clock before this symbol (-1: no sync)
+    const bool full = fill >= 64u;                          // sample_history.is_full() :237
+    const bool locked = (L.flags & F_SQ_LOCK) != 0;
+    // :244-265 sync acquired / re-affirmed / adjusted
+    const bool sync_now = full & !locked & (nerr <= P.sq_max_errors) & (pwr >= P.sq_power_open);
+    const bool adjusted = sync_now & (clock_before != 0);
+    // :266-273 lost sync: power_history.front() is the flag pushed 31 symbols ago
+    const bool drop = full & !sync_now & (clock_before >= 0) & ((L.sq_phist & 0x80000000u) == 0u);
+    int32_t clk = sync_now ? 0 : clock_before;
+    clk = drop ? -1 : clk;
+    // :277-303 byte clock
+    const bool ready = full & (clk == 0);
+    const bool reading = full & (clk > 0);
+    clk = ready ? 1 : (reading ? ((clk + 1) & 7) : clk);
+    L.sq_clock = clk;
+    if (drop) L.flags &= ~F_SQ_LOCK;                        // squelch.end() inside the squelch :336-339
 
-    enum { NO_CARRIER, DROPPED, READING, READY };
-    int st;
-    bool adjusted = false;
-    if (L.sq_fill < 64u) {
-        st = NO_CARRIER;
-    } else {
-        st = -1;
-        if (!(L.flags & F_SQ_LOCK) && nerr <= P.sq_max_errors && pwr >= P.sq_power_open) {
-            adjusted = (L.sq_clock != 0);
-            L.sq_clock = 0;
-        } else if (L.sq_clock >= 0 && !(L.sq_phist & 0x80000000u)) {
-            // power_history.front(): the flag pushed 31 symbols ago
-            L.flags &= ~F_SQ_LOCK; L.sq_clock = -1;
-            st = DROPPED;
-        }
-        if (st < 0) {
-            if (L.sq_clock < 0) st = NO_CARRIER;
-            else if (L.sq_clock == 0) { L.sq_clock = 1; st = READY; }
-            else { L.sq_clock = (L.sq_clock + 1) % 8; st = READING; }
-        }
-    }
-
-    // --- receiver.rs:409-443
-    if (st == NO_CARRIER) return framer_end(L, burst_len);
-    if (st == DROPPED) { rx_end(P, L, X); return framer_end(L, burst_len); }
     // Equalizer schedule.  The reference runs the equalizer over the 8 symbols of a byte when
     // the squelch's byte clock wraps (rx/codesquelch.rs:283-299 -> rx/equalize.rs:173-186): the
     // symbols are the OLDEST 16 history samples, i.e. they were all known 24 symbols earlier.
@@ -461,53 +459,58 @@ __device__ __forceinline__ uint32_t rx_symbol(const Params &P, Lane &L, const St
     //    reference never forms, so the state saved at the last completed byte is restored
     //    before training restarts.
     const uint32_t head = (uint32_t)(2u * (uint32_t)L.sq_symbols) & 63u;   // oldest sample
-    if (clock_before >= 0 && !adjusted) {
+    if ((clock_before >= 0) & !adjusted & (ready | reading)) {
         const uint32_t j = (uint32_t)(clock_before + 7) & 7u;   // clock 1..7 -> symbol 0..6, clock 0 -> 7
-        uint32_t bit = X.eq_symbol1(P, L, X.hist_get((head + 14u) & 63u), X.hist_get((head + 15u) & 63u));
+        const uint32_t ebit = X.eq_symbol1(P, L, X.hist_get((head + 14u) & 63u), X.hist_get((head + 15u) & 63u));
         uint32_t bits = (j == 0u) ? 0u : ((L.flags & F_EQ_BITS_MASK) >> F_EQ_BITS_SHIFT);
-        bits |= bit << j;
+        bits |= ebit << j;
         L.flags = (L.flags & ~F_EQ_BITS_MASK) | (bits << F_EQ_BITS_SHIFT);
     }
-    if (st == READING) return framer_state(L);
 
-    // --- Ready: a byte is due.  receiver.rs:423-446
-    uint32_t byte;
-    if (adjusted) {
-        if (clock_before >= 0) X.eq_restore(P);             // drop the symbols equalized ahead
-        L.flags |= F_AGC_LOCKED | F_BW_LOCKED;              // agc.lock(true); locked loop bandwidth
-        L.flags = (L.flags & ~F_EQ_MODE_MASK) | (2u << F_EQ_MODE_SHIFT);   // equalizer.train()
-        L.eq_word = P.sync_word; L.eq_count = 0;
-        // the oldest 16 samples of the history (rx/codesquelch.rs:288-294)
-        float samples[16];
-#pragma unroll
-        for (int i = 0; i < 16; ++i) samples[i] = X.hist_get((head + i) & 63u);
-        byte = X.eq_symbols(P, L, samples, 8);
-    } else {
-        byte = (L.flags & F_EQ_BITS_MASK) >> F_EQ_BITS_SHIFT;   // symbol 7 was equalized just above
-    }
-
-    // --- framer receiver.rs:457-471, Framer::input rx/framing.rs:109-123
     uint32_t link;
-    if (adjusted) {
-        uint32_t blen = 0;
-        uint32_t out = framer_end(L, &blen);
-        if (out == 3u) {
-            // the burst must be copied out before the restarted search overwrites nothing:
-            // fr_msg is only rewritten when a new prefix is found, which cannot happen on
-            // the first byte of a search, so the row is still intact when the caller emits.
-            *burst_len = blen;
+    if (ready) {
+        // --- Ready: a byte is due.  receiver.rs:423-446
+        uint32_t byte;
+        if (adjusted) {
+            if (clock_before >= 0) X.eq_restore(P);             // drop the symbols equalized ahead
+            L.flags |= F_AGC_LOCKED | F_BW_LOCKED;              // agc.lock(true); locked loop bandwidth
+            L.flags = (L.flags & ~F_EQ_MODE_MASK) | (2u << F_EQ_MODE_SHIFT);   // equalizer.train()
+            L.eq_word = P.sync_word; L.eq_count = 0;
+            // the oldest 16 samples of the history (rx/codesquelch.rs:288-294)
+            float samples[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) samples[i] = X.hist_get((head + i) & 63u);
+            byte = X.eq_symbols(P, L, samples, 8);
+        } else {
+            byte = (L.flags & F_EQ_BITS_MASK) >> F_EQ_BITS_SHIFT;   // symbol 7 was equalized just above
         }
-        fr_set_state(L, 1); L.fr_word = 0; L.fr_count = 0;
-        uint32_t dummy = 0;
-        (void)framer_feed(P, L, S, c, byte, &dummy);
-        link = (out == 3u) ? 3u : 1u;
+        // --- framer receiver.rs:457-471, Framer::input rx/framing.rs:109-123
+        if (adjusted) {
+            uint32_t blen = 0;
+            const uint32_t out = framer_end(L, &blen);
+            // fr_msg is only rewritten when a new prefix is found, which cannot happen on the
+            // first byte of a search, so the row is still intact when the caller emits it
+            if (out == 3u) *burst_len = blen;
+            fr_set_state(L, 1); L.fr_word = 0; L.fr_count = 0;
+            uint32_t dummy = 0;
+            (void)framer_feed(P, L, S, c, byte, &dummy);
+            link = (out == 3u) ? 3u : 1u;
+        } else {
+            link = framer_feed(P, L, S, c, byte, burst_len);
+        }
+        if (link == 2u) L.flags |= F_SQ_LOCK;                   // squelch.lock(true)
+        else if (link == 0u || link == 3u) rx_end(P, L, X);
+        // a re-alignment is still possible: remember the equalizer as of this completed byte
+        if (L.sq_clock >= 0 && !(L.flags & F_SQ_LOCK)) X.eq_snapshot(P);
     } else {
-        link = framer_feed(P, L, S, c, byte, burst_len);
+        // Reading: framer.state(); NoCarrier / DroppedCarrier: framer.end()  receiver.rs:410-422
+        const uint32_t fst = fr_state(L);
+        const bool was_reading_burst = !reading & (fst == 2u);
+        link = reading ? fst : (was_reading_burst ? 3u : 0u);
+        if (was_reading_burst) *burst_len = L.fr_len;
+        if (!reading) fr_set_state(L, 0);
+        if (drop) rx_end(P, L, X);
     }
-    if (link == 2u) L.flags |= F_SQ_LOCK;                   // squelch.lock(true)
-    else if (link == 0u || link == 3u) rx_end(P, L, X);
-    // a re-alignment is still possible: remember the equalizer as of this completed byte
-    if (L.sq_clock >= 0 && !(L.flags & F_SQ_LOCK)) X.eq_snapshot(P);
     return link;
 }
 
