@@ -153,34 +153,39 @@ __device__ __forceinline__ void framer_push(Lane &L, const State &S, uint32_t c,
     if (L.fr_len < (uint32_t)kBurstCap) S.fr_msg[(size_t)c * kBurstCap + L.fr_len] = (uint8_t)byte;
     L.fr_len += 1;
 }
-// the non-restart arm of Framer::input rx/framing.rs:124-164
+// the non-restart arm of Framer::input rx/framing.rs:124-164, with the two live states
+// evaluated side by side and committed by selects (only the byte stores are predicated)
 __device__ __forceinline__ uint32_t framer_feed(const Params &P, Lane &L, const State &S,
                                                 uint32_t c, uint32_t data, uint32_t *burst_len)
 {
-    uint32_t st = fr_state(L);
-    if (st == 0u) return 0u;
-    if (st == 1u) {
-        L.fr_word = (L.fr_word << 8) | data;
-        L.fr_count += 1;
-        uint32_t e0 = __popc(L.fr_word ^ 0x5a435a43u);   // "ZCZC" rx/framing.rs:235-243
-        uint32_t e1 = __popc(L.fr_word ^ 0x4e4e4e4eu);   // "NNNN"
-        if (min(e0, e1) <= P.fr_max_prefix_errors) {
-            L.fr_len = 0;
-            framer_push(L, S, c, (L.fr_word >> 24) & 0xff);
-            framer_push(L, S, c, (L.fr_word >> 16) & 0xff);
-            framer_push(L, S, c, (L.fr_word >> 8) & 0xff);
-            framer_push(L, S, c, L.fr_word & 0xff);
-            L.fr_invalid = 0;
-            fr_set_state(L, 2);
-        } else if (L.fr_count > 21u) {                   // PREFIX_SEARCH_LEN :201
-            fr_set_state(L, 0);
-        }
-        return framer_state(L);
+    const uint32_t st = fr_state(L);
+    const bool searching = st == 1u, reading = st == 2u;
+    // PrefixSearch :128-150
+    const uint32_t word = (L.fr_word << 8) | data;
+    const uint32_t count = L.fr_count + 1u;
+    const uint32_t e0 = __popc(word ^ 0x5a435a43u);          // "ZCZC" rx/framing.rs:235-243
+    const uint32_t e1 = __popc(word ^ 0x4e4e4e4eu);          // "NNNN"
+    const bool found = searching & (min(e0, e1) <= P.fr_max_prefix_errors);
+    const bool give_up = searching & !found & (count > 21u); // PREFIX_SEARCH_LEN :201
+    // DataRead :153-163
+    const uint32_t invalid = L.fr_invalid + (is_allowed_byte(data) ? 0u : 1u);
+    const bool over = reading & (invalid > P.fr_max_invalid);
+    const bool keep = reading & !over;
+
+    L.fr_word = searching ? word : L.fr_word;
+    L.fr_count = searching ? count : L.fr_count;
+    L.fr_invalid = found ? 0u : (reading ? invalid : L.fr_invalid);
+    if (found) {
+        uint8_t *row = S.fr_msg + (size_t)c * kBurstCap;     // the prefix as received seeds the burst :136-138
+        row[0] = (uint8_t)(word >> 24); row[1] = (uint8_t)(word >> 16);
+        row[2] = (uint8_t)(word >> 8); row[3] = (uint8_t)word;
     }
-    L.fr_invalid += is_allowed_byte(data) ? 0u : 1u;
-    if (L.fr_invalid > P.fr_max_invalid) return framer_end(L, burst_len);
-    framer_push(L, S, c, data);
-    return framer_state(L);
+    if (keep && L.fr_len < (uint32_t)kBurstCap) S.fr_msg[(size_t)c * kBurstCap + L.fr_len] = (uint8_t)data;
+    if (over) *burst_len = L.fr_len;                         // Framer::end(): the burst without this byte
+    L.fr_len = found ? 4u : (keep ? L.fr_len + 1u : L.fr_len);
+    const uint32_t nst = found ? 2u : ((give_up | over) ? 0u : st);
+    fr_set_state(L, nst);
+    return over ? 3u : nst;                                  // LinkState kind: framer state numbers coincide
 }
 
 // ---------------------------------------------------------------------------------
@@ -604,30 +609,26 @@ __device__ __forceinline__ void ted_instant(const Params &P, Lane &L, const Stat
     L.h0 = L.h1; L.h1 = L.h2; L.h2 = sa_low;
     L.flags ^= F_TED_PHASE;
     const bool have = (L.flags & F_TED_PHASE) != 0;
-    float zero = L.h1, sym = L.h2, terr = 0.0f;
-    if (have) {
-        float d = rs_signum(L.h0) - rs_signum(L.h2);        // zero_crossing_metric :311-322
-        terr = L.h1 * d;
-    }
-    // TimingLoop::advance_loop rx/symsync.rs:219-244
-    float offset = rs_clamp(rem, -0.5f, 0.5f);
-    if (have) {
-        float q = offset / P.samples_per_ted;
-        float e0 = terr - q;
-        float e = rs_clamp(e0, -1.0f, 1.0f);
-        const bool locked = (L.flags & F_BW_LOCKED) != 0;
-        float alpha = locked ? P.alpha_locked : P.alpha_unlocked;
-        float beta = locked ? P.beta_locked : P.beta_unlocked;
-        float bi = beta * e;
-        L.period_avg += bi;
-        L.period_avg = rs_clamp(L.period_avg, P.period_min, P.period_max);
-        float ai = alpha * e;
-        float t = L.period_avg + ai;
-        L.period_inst = t + offset;
-        if (L.period_inst < 0.0f) L.period_inst = L.period_avg;
-    } else {
-        L.period_inst += offset;
-    }
+    const float zero = L.h1, sym = L.h2;
+    const float dsg = rs_signum(L.h0) - rs_signum(L.h2);    // zero_crossing_metric :311-322
+    const float terr = L.h1 * dsg;
+    // TimingLoop::advance_loop rx/symsync.rs:219-244 -- both arms computed, one committed
+    const float offset = rs_clamp(rem, -0.5f, 0.5f);
+    const float q = offset / P.samples_per_ted;
+    const float e0 = terr - q;
+    const float e = rs_clamp(e0, -1.0f, 1.0f);
+    const bool bw_locked = (L.flags & F_BW_LOCKED) != 0;
+    const float alpha = bw_locked ? P.alpha_locked : P.alpha_unlocked;
+    const float beta = bw_locked ? P.beta_locked : P.beta_unlocked;
+    const float bi = beta * e;
+    const float avg1 = rs_clamp(L.period_avg + bi, P.period_min, P.period_max);
+    const float ai = alpha * e;
+    const float t = avg1 + ai;
+    float inst1 = t + offset;
+    inst1 = (inst1 < 0.0f) ? avg1 : inst1;
+    const float inst0 = L.period_inst + offset;              // no symbol this time: period_inst += offset
+    L.period_avg = have ? avg1 : L.period_avg;
+    L.period_inst = have ? inst1 : inst0;
     L.until_next_ted = L.period_inst;                       // receiver.rs:382
     if (!have) return;                                      // receiver.rs:383
 
