@@ -91,39 +91,40 @@ __device__ __forceinline__ int next_fire_count(float s, uint32_t clock)
 }
 
 template <int NT, int RING>
-__device__ __forceinline__ float demod_fast(const float4 *__restrict__ taps, const float *wcol,
-                                            uint32_t lane, uint32_t newest, uint32_t lpw)
+__device__ __forceinline__ float demod_fast(const float4 *tlds, const float *wcol, uint32_t lane,
+                                            uint32_t newest)
 {
     // FskDemod::demod_now rx/demod.rs:156-164 over multiply_accumulate rx/filter.rs:363-377:
     // acc += window[newest - i] * h[i], i = 0 first; (mark.re, mark.im) and (space.re, space.im)
-    // ride in the two halves of packed f32 operations.
+    // ride in the two halves of packed f32 operations (per-element IEEE: same roundings).
     //
-    // Taps are wave-uniform and come in through scalar loads, CH at a time: the chunk loop is
-    // deliberately NOT unrolled, otherwise all 4*NT tap words are hoisted into SGPRs at once
-    // and spill.  Window samples of a chunk are fetched from LDS before the arithmetic.
-    // Byte address of tap i in the ring: slot (newest - i) mod RING, lpw*4 bytes per slot, so
-    // stepping back one tap is "subtract the slot pitch, wrap at RING*pitch" (lane*4 < pitch
-    // stays intact because both are powers of two).
+    // Taps live in LDS and are read with a wave-uniform address (a broadcast, no bank
+    // conflict): the scalar-cache round trip of s_load'ing 4*CH tap words per chunk was the
+    // largest s_waitcnt item of the kernel, and holding all 4*NT words in SGPRs spills them.
+    // The chunk loop stays rolled so the tap registers of one chunk are reused.
+    // Byte address of tap i in the ring: slot (newest - i) mod RING, 256 bytes per slot, so
+    // stepping back one tap is "subtract 256, wrap at RING*256" (lane*4 < 256 stays intact).
     constexpr int CH = 14;
-    const uint32_t pitch = lpw * 4u;
-    const uint32_t WRAP = (uint32_t)RING * pitch - 1u;
+    constexpr uint32_t PITCH = kWave * 4u;
+    constexpr uint32_t WRAP = (uint32_t)RING * PITCH - 1u;
     float2v am = {0.0f, 0.0f}, as = {0.0f, 0.0f};
-    uint32_t addr = newest * pitch + lane * 4u;
+    uint32_t addr = newest * PITCH + lane * 4u;
     const char *wbase = reinterpret_cast<const char *>(wcol - lane);
 #pragma unroll 1
     for (int base = 0; base + CH <= NT; base += CH) {
         float w[CH];
+        float4 h[CH];
 #pragma unroll
         for (int j = 0; j < CH; ++j) {
             w[j] = *reinterpret_cast<const float *>(wbase + addr);
-            addr = (addr - pitch) & WRAP;
+            addr = (addr - PITCH) & WRAP;
         }
-        const float4 *h = taps + base;
+#pragma unroll
+        for (int j = 0; j < CH; ++j) h[j] = tlds[base + j];
 #pragma unroll
         for (int j = 0; j < CH; ++j) {
-            const float4 t = h[j];
             const float2v x2 = {w[j], w[j]};
-            const float2v hm = {t.x, t.y}, hs = {t.z, t.w};
+            const float2v hm = {h[j].x, h[j].y}, hs = {h[j].z, h[j].w};
             const float2v pm = x2 * hm, ps = x2 * hs;
             am += pm; as += ps;
         }
@@ -134,11 +135,11 @@ __device__ __forceinline__ float demod_fast(const float4 *__restrict__ taps, con
 #pragma unroll
         for (int j = 0; j < REM; ++j) {
             w[j] = *reinterpret_cast<const float *>(wbase + addr);
-            addr = (addr - pitch) & WRAP;
+            addr = (addr - PITCH) & WRAP;
         }
 #pragma unroll
         for (int j = 0; j < REM; ++j) {
-            const float4 t = taps[NT - REM + j];
+            const float4 t = tlds[NT - REM + j];
             const float2v x2 = {w[j], w[j]};
             const float2v hm = {t.x, t.y}, hs = {t.z, t.w};
             const float2v pm = x2 * hm, ps = x2 * hs;
@@ -181,11 +182,17 @@ __global__ __launch_bounds__(kWave) void demod_fast_kernel(Params P, State S, Ou
     const uint32_t lane = threadIdx.x;
     const uint32_t C = P.n_channels;
     constexpr uint32_t LP = kWave;                               // one lane per channel
+    // matched-filter taps: [NT] float4 at the start of LDS, staged by the first NT lanes (before
+    // the tail-wave exit below, so every wavefront has them)
+    float4 *tlds = reinterpret_cast<float4 *>(lds);
+    for (uint32_t i = lane; i < (uint32_t)NT; i += kWave) tlds[i] = taps[i];
+    constexpr uint32_t TAPF = (uint32_t)((NT * 4 + 63) / 64 * 64);   // floats reserved for the taps
     const uint32_t c = blockIdx.x * kWave + lane;
     if (c >= C) return;                                          // no barriers below
-    float *wcol = lds + lane;                                    // [RING][64]
-    float *hcol = lds + RING * LP + lane;                        // [64][64]
-    float *ffcol = lds + (RING + kSquelchHist) * LP + lane;      // [DCL][64] (LDS DC path)
+    float *wring = lds + TAPF;
+    float *wcol = wring + lane;                                  // [RING][64]
+    float *hcol = wring + RING * LP + lane;                      // [64][64]
+    float *ffcol = wring + (RING + kSquelchHist) * LP + lane;    // [DCL][64] (LDS DC path)
     float *fbcol = ffcol + DCL * LP;
 
     Lane L;
@@ -309,7 +316,7 @@ __global__ __launch_bounds__(kWave) void demod_fast_kernel(Params P, State S, Ou
 #if defined(SAME_ABLATE) && SAME_ABLATE == 2
             const float sa_low = wcol[newest * kWave] * 0.01f;   // ablation build: no matched filter
 #else
-            const float sa_low = demod_fast<NT, RING>(taps, wcol, lane, newest, LP);
+            const float sa_low = demod_fast<NT, RING>(tlds, wcol, lane, newest);
 #endif
             const float rem = L.until_next_ted - (float)cstar;          // receiver.rs:352
             const uint32_t locked_before = L.flags & F_AGC_LOCKED;
@@ -376,7 +383,8 @@ template <int NT, int DCL>
 static constexpr size_t fast_lds_bytes()
 {
     constexpr int RING = (NT + kB - 1 <= 64) ? 64 : 128;
-    return (size_t)(RING + kSquelchHist + (DCL == kB ? 0 : 2 * DCL)) * kWave * sizeof(float);
+    constexpr size_t TAPF = (size_t)((NT * 4 + 63) / 64 * 64);
+    return (TAPF + (size_t)(RING + kSquelchHist + (DCL == kB ? 0 : 2 * DCL)) * kWave) * sizeof(float);
 }
 
 template <int NT, int DCL, typename SampleT>
