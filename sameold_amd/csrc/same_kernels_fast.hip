@@ -24,6 +24,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cmath>
+#include <cstdlib>
 
 #include "same_dev_common.h"
 #include "same_device.h"
@@ -90,8 +91,13 @@ __device__ __forceinline__ int next_fire_count(float s, uint32_t clock)
     return c;
 }
 
-template <int NT, int RING>
-__device__ __forceinline__ float demod_fast(const float4 *tlds, const float *wcol, uint32_t lane,
+// Window storage in LDS.  The ring position is relative to the first sample of the launch, so
+// a block of 16 pushes starts at a multiple of 16 and never wraps inside the block (immediate
+// offsets from one base address).  MIRROR: every sample is stored at slot s and s + RING, and
+// the filters read tap i at slot (newest + RING) - i, which never wraps either -- the per-tap
+// address arithmetic (2-3 VALU per tap, 42 taps) disappears at the price of 16 KB of LDS.
+template <int NT, int RING, bool MIRROR>
+__device__ __forceinline__ float demod_fast(const float4 *tlds, const float *wring, uint32_t lane,
                                             uint32_t newest)
 {
     // FskDemod::demod_now rx/demod.rs:156-164 over multiply_accumulate rx/filter.rs:363-377:
@@ -102,23 +108,30 @@ __device__ __forceinline__ float demod_fast(const float4 *tlds, const float *wco
     // conflict): the scalar-cache round trip of s_load'ing 4*CH tap words per chunk was the
     // largest s_waitcnt item of the kernel, and holding all 4*NT words in SGPRs spills them.
     // The chunk loop stays rolled so the tap registers of one chunk are reused.
-    // Byte address of tap i in the ring: slot (newest - i) mod RING, 256 bytes per slot, so
-    // stepping back one tap is "subtract 256, wrap at RING*256" (lane*4 < 256 stays intact).
     constexpr int CH = 14;
     constexpr uint32_t PITCH = kWave * 4u;
     constexpr uint32_t WRAP = (uint32_t)RING * PITCH - 1u;
     float2v am = {0.0f, 0.0f}, as = {0.0f, 0.0f};
+    // !MIRROR: byte address of tap i is slot (newest - i) mod RING, 256 bytes per slot, so
+    // stepping back one tap is "subtract 256, wrap at RING*256" (lane*4 < 256 stays intact)
     uint32_t addr = newest * PITCH + lane * 4u;
-    const char *wbase = reinterpret_cast<const char *>(wcol - lane);
+    const char *wbase = reinterpret_cast<const char *>(wring);
+    // MIRROR: tap i of the current chunk sits at wm[(CH - 1 - i) * 64]
+    const float *wm = wring + ((int)newest + RING - (CH - 1)) * (int)kWave + (int)lane;
 #pragma unroll 1
     for (int base = 0; base + CH <= NT; base += CH) {
         float w[CH];
         float4 h[CH];
 #pragma unroll
         for (int j = 0; j < CH; ++j) {
-            w[j] = *reinterpret_cast<const float *>(wbase + addr);
-            addr = (addr - PITCH) & WRAP;
+            if (MIRROR) {
+                w[j] = wm[(CH - 1 - j) * (int)kWave];
+            } else {
+                w[j] = *reinterpret_cast<const float *>(wbase + addr);
+                addr = (addr - PITCH) & WRAP;
+            }
         }
+        if (MIRROR) wm -= CH * (int)kWave;
 #pragma unroll
         for (int j = 0; j < CH; ++j) h[j] = tlds[base + j];
 #pragma unroll
@@ -134,8 +147,12 @@ __device__ __forceinline__ float demod_fast(const float4 *tlds, const float *wco
         float w[REM ? REM : 1];
 #pragma unroll
         for (int j = 0; j < REM; ++j) {
-            w[j] = *reinterpret_cast<const float *>(wbase + addr);
-            addr = (addr - PITCH) & WRAP;
+            if (MIRROR) {
+                w[j] = wm[(CH - 1 - j) * (int)kWave];
+            } else {
+                w[j] = *reinterpret_cast<const float *>(wbase + addr);
+                addr = (addr - PITCH) & WRAP;
+            }
         }
 #pragma unroll
         for (int j = 0; j < REM; ++j) {
@@ -168,7 +185,7 @@ __device__ __forceinline__ float agc_step(const Params &P, float y, float &gain,
     return out;
 }
 
-template <int NT, int DCL, int NFF, int NFB, bool MED3, typename SampleT>
+template <int NT, int DCL, int NFF, int NFB, bool MED3, bool MIRROR, typename SampleT>
 __global__ __launch_bounds__(kWave) void demod_fast_kernel(Params P, State S, Output O,
                                                            const float4 *__restrict__ taps,
                                                            const SampleT *__restrict__ x,
@@ -189,10 +206,11 @@ __global__ __launch_bounds__(kWave) void demod_fast_kernel(Params P, State S, Ou
     constexpr uint32_t TAPF = (uint32_t)((NT * 4 + 63) / 64 * 64);   // floats reserved for the taps
     const uint32_t c = blockIdx.x * kWave + lane;
     if (c >= C) return;                                          // no barriers below
+    constexpr int WSLOTS = MIRROR ? 2 * RING : RING;
     float *wring = lds + TAPF;
-    float *wcol = wring + lane;                                  // [RING][64]
-    float *hcol = wring + RING * LP + lane;                      // [64][64]
-    float *ffcol = wring + (RING + kSquelchHist) * LP + lane;    // [DCL][64] (LDS DC path)
+    float *wcol = wring + lane;                                  // [WSLOTS][64]
+    float *hcol = wring + WSLOTS * LP + lane;                    // [64][64]
+    float *ffcol = wring + (WSLOTS + kSquelchHist) * LP + lane;  // [DCL][64] (LDS DC path)
     float *fbcol = ffcol + DCL * LP;
 
     Lane L;
@@ -211,14 +229,22 @@ __global__ __launch_bounds__(kWave) void demod_fast_kernel(Params P, State S, Ou
     }
     // state arrays are [slot][channel]: a wave-uniform row pointer plus the lane's channel
     // index keeps the address arithmetic on the scalar unit
+    // the window ring is re-based: LDS slot j holds the state's slot (j + counter0) mod RING,
+    // so the first sample of this launch lands in slot 0 (see demod_fast)
 #pragma unroll 2
-    for (int i = 0; i < RING; ++i) { const float *row = S.win_ring + (size_t)i * C; wcol[i * LP] = row[c]; }
+    for (int j = 0; j < RING; ++j) {
+        const uint32_t g = (uint32_t)((uint64_t)j + counter0) & (uint32_t)(RING - 1);
+        const float *row = S.win_ring + (size_t)g * C;
+        const float v = row[c];
+        wcol[j * LP] = v;
+        if (MIRROR) wcol[(j + RING) * LP] = v;
+    }
 #pragma unroll 2
     for (int i = 0; i < kSquelchHist; ++i) { const float *row = S.sq_hist + (size_t)i * C; hcol[i * LP] = row[c]; }
 
     // ring positions common to all channels
     uint32_t dpos = (uint32_t)(counter0 % (uint64_t)DCL);
-    uint32_t wpos = (uint32_t)(counter0 & (uint64_t)(RING - 1));
+    uint32_t wpos = 0;                 // LDS ring slot of the block's first sample: a multiple of 16
     float xp[kB], mp[kB];              // DC_REGS: previous block's inputs / first-stage averages
     if (DC_REGS) {
 #pragma unroll
@@ -302,21 +328,23 @@ __global__ __launch_bounds__(kWave) void demod_fast_kernel(Params P, State S, Ou
 
         // ---- AGC rx/agc.rs:72-77 and window push receiver.rs:345-346 -----------------
         const float g0 = L.gain;
+        float *wblk = wcol + wpos * LP;
         const float bw0 = (L.flags & F_AGC_LOCKED) ? 0.0f : P.agc_bw;
 #pragma unroll
         for (int k = 0; k < kB; ++k) {
             float out = agc_step<MED3>(P, ys[k], L.gain, bw0);
-            wcol[((wpos + (uint32_t)k) & (uint32_t)(RING - 1)) * LP] = out;
+            wblk[k * LP] = out;
+            if (MIRROR) wblk[(k + RING) * LP] = out;
         }
 
         // ---- deferred TED instant ----------------------------------------------------
         if (until < kB) {
             const int fk = until;
-            const uint32_t newest = (wpos + (uint32_t)fk) & (uint32_t)(RING - 1);
+            const uint32_t newest = wpos + (uint32_t)fk;
 #if defined(SAME_ABLATE) && SAME_ABLATE == 2
             const float sa_low = wcol[newest * kWave] * 0.01f;   // ablation build: no matched filter
 #else
-            const float sa_low = demod_fast<NT, RING>(tlds, wcol, lane, newest);
+            const float sa_low = demod_fast<NT, RING, MIRROR>(tlds, wring, lane, newest);
 #endif
             const float rem = L.until_next_ted - (float)cstar;          // receiver.rs:352
             const uint32_t locked_before = L.flags & F_AGC_LOCKED;
@@ -332,7 +360,8 @@ __global__ __launch_bounds__(kWave) void demod_fast_kernel(Params P, State S, Ou
 #pragma unroll
                 for (int k = 0; k < kB; ++k) {
                     float out = agc_step<MED3>(P, ys[k], g, (k <= fk) ? bw0 : bw1);
-                    wcol[((wpos + (uint32_t)k) & (uint32_t)(RING - 1)) * LP] = out;
+                    wblk[k * LP] = out;
+                    if (MIRROR) wblk[(k + RING) * LP] = out;
                 }
                 L.gain = g;
             }
@@ -355,7 +384,11 @@ __global__ __launch_bounds__(kWave) void demod_fast_kernel(Params P, State S, Ou
         S.eq_snap_fbc[i * C + c] = X.sfbc[i]; S.eq_snap_fbw[i * C + c] = X.sfbw[i];
     }
 #pragma unroll 2
-    for (int i = 0; i < RING; ++i) { float *row = S.win_ring + (size_t)i * C; row[c] = wcol[i * LP]; }
+    for (int j = 0; j < RING; ++j) {
+        const uint32_t g = (uint32_t)((uint64_t)j + counter0) & (uint32_t)(RING - 1);
+        float *row = S.win_ring + (size_t)g * C;
+        row[c] = wcol[j * LP];
+    }
 #pragma unroll 2
     for (int i = 0; i < kSquelchHist; ++i) { float *row = S.sq_hist + (size_t)i * C; row[c] = hcol[i * LP]; }
     if (DC_REGS) {
@@ -379,12 +412,21 @@ __global__ __launch_bounds__(kWave) void demod_fast_kernel(Params P, State S, Ou
 // ---------------------------------------------------------------------------------
 // dispatch
 // ---------------------------------------------------------------------------------
-template <int NT, int DCL>
+template <int NT, int DCL, bool MIRROR>
 static constexpr size_t fast_lds_bytes()
 {
     constexpr int RING = (NT + kB - 1 <= 64) ? 64 : 128;
     constexpr size_t TAPF = (size_t)((NT * 4 + 63) / 64 * 64);
-    return (TAPF + (size_t)(RING + kSquelchHist + (DCL == kB ? 0 : 2 * DCL)) * kWave) * sizeof(float);
+    return (TAPF + (size_t)((MIRROR ? 2 : 1) * RING + kSquelchHist + (DCL == kB ? 0 : 2 * DCL)) * kWave) * sizeof(float);
+}
+
+// The mirrored window costs 16 KB of LDS per wavefront: 3 wavefronts fit a CU's 160 KB instead
+// of 4, so it is used while the batch needs at most 3 wavefronts per CU (and only for the
+// 42-tap filters, whose ring is 64 slots).
+static bool fast_use_mirror(uint32_t n_channels, uint32_t ntaps)
+{
+    if (const char *e = getenv("SAME_MIRROR")) return atoi(e) != 0 && ntaps == 42u;
+    return ntaps == 42u && (n_channels + kWave - 1) / kWave <= 3u * 256u;
 }
 
 template <int NT, int DCL, typename SampleT>
@@ -392,15 +434,23 @@ static hipError_t launch_fast_cfg(const Params &P, const State &S, const Output 
                                   const SampleT *x, uint32_t n_blocks, uint64_t counter0, hipStream_t stream)
 {
     const uint32_t grid = (P.n_channels + kWave - 1) / kWave;
-    const size_t lds = fast_lds_bytes<NT, DCL>();
+    constexpr bool CAN_MIRROR = (NT == 42);
+    const bool mirror = CAN_MIRROR && fast_use_mirror(P.n_channels, P.ntaps);
+    const size_t lds = mirror ? fast_lds_bytes<NT, DCL, CAN_MIRROR>() : fast_lds_bytes<NT, DCL, false>();
     // v_med3_f32 == f32::clamp unless a bound is -0.0 (or NaN, which the builder rejects)
     const bool med3 = !(P.agc_min == 0.0f && std::signbit(P.agc_min)) && !(P.agc_max == 0.0f && std::signbit(P.agc_max));
-#define SAME_FAST(NFF, NFB, M3)                                                                         \
-    hipLaunchKernelGGL((demod_fast_kernel<NT, DCL, NFF, NFB, M3, SampleT>), dim3(grid), dim3(kWave), lds, \
+#define SAME_FAST_M(NFF, NFB, M3, MI)                                                                       \
+    hipLaunchKernelGGL((demod_fast_kernel<NT, DCL, NFF, NFB, M3, MI, SampleT>), dim3(grid), dim3(kWave), lds, \
                        stream, P, S, O, taps, x, n_blocks, counter0)
+#define SAME_FAST(NFF, NFB, M3)                                                                         \
+    do {                                                                                                \
+        if (mirror) SAME_FAST_M(NFF, NFB, M3, CAN_MIRROR);                                              \
+        else SAME_FAST_M(NFF, NFB, M3, false);                                                          \
+    } while (0)
     if (P.eq_nff == 6u && P.eq_nfb == 4u) { if (med3) SAME_FAST(6, 4, true); else SAME_FAST(6, 4, false); }
     else { if (med3) SAME_FAST(1, 1, true); else SAME_FAST(1, 1, false); }
 #undef SAME_FAST
+#undef SAME_FAST_M
     return hipGetLastError();
 }
 
