@@ -35,7 +35,8 @@ def flags() -> list:
         "-fgpu-rdc" if False else "-fno-gpu-rdc",
         "-Wall", "-Wno-unused-function", "-Wno-unused-variable",
         "-x", "hip",
-    ] + ([f"-DSAME_ABLATE={os.environ['SAME_ABLATE']}"] if os.environ.get("SAME_ABLATE") else [])
+    ] + ([f"-DSAME_ABLATE={os.environ['SAME_ABLATE']}"] if os.environ.get("SAME_ABLATE") else []) \
+      + (["-DSAME_PROFILE=1"] if os.environ.get("SAME_PROFILE") else [])
 
 
 def is_stale() -> bool:

@@ -36,8 +36,32 @@ typedef float float2v __attribute__((ext_vector_type(2)));
 
 constexpr int kB = 16;   // block length of the fast kernel
 
+#ifdef SAME_PROFILE
+// cycle-attribution build (results unchanged, timing perturbed by the probes): shader-clock
+// time per section of the block loop, summed over the blocks of wavefront 0
+__device__ unsigned long long g_same_prof[9];
+#endif
+
 template <int NFF, int NFB>
 struct FastCtx {
+#ifdef SAME_PROFILE
+    // The accumulators live in one LDS location shared by the whole wavefront: a mark inside a
+    // divergent region is executed by the active lanes only, and every one of them reads and
+    // writes the same values, so the totals are per wavefront whichever lanes were active.
+    // pl[0] = time of the previous mark, pl[1 + i] = cycles attributed to section i; section 8
+    // is the cost of a mark itself (two marks back to back).
+    unsigned long long *pl;
+    __device__ __forceinline__ void mark(int i)
+    {
+        const unsigned long long t = clock64();
+        volatile unsigned long long *p = pl;
+        const unsigned long long prev = p[0];
+        p[0] = t;
+        p[1 + i] = p[1 + i] + (t - prev);
+    }
+#else
+    __device__ __forceinline__ void mark(int) {}
+#endif
     float *hist;                       // LDS column of this lane: slot i at hist[i * kWave]
     float ffc[NFF], ffw[NFF], fbc[NFB], fbw[NFB];
     float sffc[NFF], sffw[NFF], sfbc[NFB], sfbw[NFB];   // equalizer at the last completed byte
@@ -203,7 +227,11 @@ __global__ __launch_bounds__(kWave) void demod_fast_kernel(Params P, State S, Ou
     // the tail-wave exit below, so every wavefront has them)
     float4 *tlds = reinterpret_cast<float4 *>(lds);
     for (uint32_t i = lane; i < (uint32_t)NT; i += kWave) tlds[i] = taps[i];
+#ifdef SAME_PROFILE
+    constexpr uint32_t TAPF = (uint32_t)((NT * 4 + 20 + 63) / 64 * 64);   // taps + profile words
+#else
     constexpr uint32_t TAPF = (uint32_t)((NT * 4 + 63) / 64 * 64);   // floats reserved for the taps
+#endif
     const uint32_t c = blockIdx.x * kWave + lane;
     if (c >= C) return;                                          // no barriers below
     constexpr int WSLOTS = MIRROR ? 2 * RING : RING;
@@ -217,6 +245,10 @@ __global__ __launch_bounds__(kWave) void demod_fast_kernel(Params P, State S, Ou
     lane_load(L, S, c);
     FastCtx<NFF, NFB> X;
     X.hist = hcol;
+#ifdef SAME_PROFILE
+    X.pl = reinterpret_cast<unsigned long long *>(lds + NT * 4);
+    for (int i = 0; i < 10; ++i) X.pl[i] = 0;
+#endif
 #pragma unroll
     for (int i = 0; i < NFF; ++i) {
         X.ffc[i] = S.eq_ffc[i * C + c]; X.ffw[i] = S.eq_ffw[i * C + c];
@@ -270,6 +302,9 @@ __global__ __launch_bounds__(kWave) void demod_fast_kernel(Params P, State S, Ou
 #pragma unroll
     for (int k = 0; k < kB; ++k) { const SampleT *row = x + (size_t)k * C; xn[k] = (float)row[c]; }
 
+#ifdef SAME_PROFILE
+    X.pl[0] = clock64();
+#endif
     for (uint32_t blk = 0; blk < n_blocks; ++blk) {
         float xs[kB];
 #pragma unroll
@@ -284,17 +319,28 @@ __global__ __launch_bounds__(kWave) void demod_fast_kernel(Params P, State S, Ou
         float ys[kB];
         if (DC_REGS) {
             float mnew[kB];
+            // two samples per step: only the running sums are serial, the differences and
+            // scalings of samples k and k+1 are independent and ride in packed f32 operations
+            // (per-element IEEE, same roundings as the scalar form)
 #pragma unroll
-            for (int k = 0; k < kB; ++k) {
-                float d0 = xs[k] - xp[k];                    // input - aged
-                L.sum0 += d0;
-                float ma0 = L.sum0 * P.dc_inv_len;
-                float sig = (k + 1 < kB) ? xp[k + 1] : xs[0];   // window.front() after the push
-                float d1 = ma0 - mp[k];
-                L.sum1 += d1;
-                float ma1 = L.sum1 * P.dc_inv_len;
-                ys[k] = sig - ma1;                           // (len > 1) as f32 == 1.0: exact
-                mnew[k] = ma0;
+            for (int k = 0; k < kB; k += 2) {
+                const float2v x2 = {xs[k], xs[k + 1]}, xo = {xp[k], xp[k + 1]};
+                const float2v d0 = x2 - xo;                  // input - aged
+                const float s0a = L.sum0 + d0.x, s0b = s0a + d0.y;
+                L.sum0 = s0b;
+                const float2v s0 = {s0a, s0b}, inv = {P.dc_inv_len, P.dc_inv_len};
+                const float2v ma0 = s0 * inv;
+                // window.front() after the push
+                const float2v sig = {xp[k + 1], (k + 2 < kB) ? xp[k + 2] : xs[0]};
+                const float2v mo = {mp[k], mp[k + 1]};
+                const float2v d1 = ma0 - mo;
+                const float s1a = L.sum1 + d1.x, s1b = s1a + d1.y;
+                L.sum1 = s1b;
+                const float2v s1 = {s1a, s1b};
+                const float2v ma1 = s1 * inv;
+                const float2v y2 = sig - ma1;                // (len > 1) as f32 == 1.0: exact
+                ys[k] = y2.x; ys[k + 1] = y2.y;
+                mnew[k] = ma0.x; mnew[k + 1] = ma0.y;
             }
 #pragma unroll
             for (int k = 0; k < kB; ++k) { xp[k] = xs[k]; mp[k] = mnew[k]; }
@@ -337,6 +383,7 @@ __global__ __launch_bounds__(kWave) void demod_fast_kernel(Params P, State S, Ou
             if (MIRROR) wblk[(k + RING) * LP] = out;
         }
 
+        X.mark(0);
         // ---- deferred TED instant ----------------------------------------------------
         if (until < kB) {
             const int fk = until;
@@ -346,6 +393,7 @@ __global__ __launch_bounds__(kWave) void demod_fast_kernel(Params P, State S, Ou
 #else
             const float sa_low = demod_fast<NT, RING, MIRROR>(tlds, wring, lane, newest);
 #endif
+            X.mark(1);
             const float rem = L.until_next_ted - (float)cstar;          // receiver.rs:352
             const uint32_t locked_before = L.flags & F_AGC_LOCKED;
             ted_instant(P, L, S, O, X, c, sa_low, rem,
@@ -368,7 +416,15 @@ __global__ __launch_bounds__(kWave) void demod_fast_kernel(Params P, State S, Ou
         }
         until -= kB;
         wpos = (wpos + kB) & (uint32_t)(RING - 1);
+        X.mark(7);
+#ifdef SAME_PROFILE
+        X.mark(8);
+#endif
     }
+#ifdef SAME_PROFILE
+    if (blockIdx.x == 0 && lane == 0)
+        for (int i = 0; i < 9; ++i) atomicAdd(&g_same_prof[i], X.pl[1 + i]);
+#endif
 
     // ---- write the state back --------------------------------------------------------
     L.ted_clock = (uint32_t)(cstar - until - 1);
@@ -416,7 +472,11 @@ template <int NT, int DCL, bool MIRROR>
 static constexpr size_t fast_lds_bytes()
 {
     constexpr int RING = (NT + kB - 1 <= 64) ? 64 : 128;
+#ifdef SAME_PROFILE
+    constexpr size_t TAPF = (size_t)((NT * 4 + 20 + 63) / 64 * 64);
+#else
     constexpr size_t TAPF = (size_t)((NT * 4 + 63) / 64 * 64);
+#endif
     return (TAPF + (size_t)((MIRROR ? 2 : 1) * RING + kSquelchHist + (DCL == kB ? 0 : 2 * DCL)) * kWave) * sizeof(float);
 }
 
@@ -482,3 +542,13 @@ hipError_t launch_demod_fast_i16(const Params &P, const State &S, const Output &
 { return launch_fast_t<int16_t>(P, S, O, taps, x, n_blocks, counter0, stream); }
 
 }  // namespace same
+
+#ifdef SAME_PROFILE
+extern "C" int same_debug_profile(unsigned long long *out8, int reset)   // 9 words
+{
+    unsigned long long z[9] = {0};
+    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(same::g_same_prof), sizeof(z)) != hipSuccess) return -1;
+    if (reset && hipMemcpyToSymbol(HIP_SYMBOL(same::g_same_prof), z, sizeof(z)) != hipSuccess) return -1;
+    return 0;
+}
+#endif

@@ -23,3 +23,14 @@ for r in range(reps):
     n = rx._L.same_batch_pending_events(rx._h)
     print(f"rep {r}: kernel {ms:.3f} ms  wall {dt*1e3:.3f} ms  {C*T/ms/1e3:.1f} Msamples/s (kernel)  "
           f"{4*C*T/ms/1e6:.2f} GB/s  events pending {n}  [{rx.kernel_name()}]", flush=True)
+
+if hasattr(rx._L, "same_debug_profile"):
+    import ctypes
+    buf = (ctypes.c_ulonglong * 9)()
+    rx._L.same_debug_profile(buf, 1)
+    names = ["sample phase", "matched filter", "timing loop", "squelch", "equalizer step", "byte/framer", "events+ticks", "post/latch", "(one mark)"]
+    tot = sum(buf)
+    nblk = reps * (T // 16)
+    for n, v in zip(names, buf):
+        print(f"  {n:16s} {v:14d} clk  {100.0*v/max(tot,1):5.1f} %  {v/nblk:8.1f} clk/block")
+    print(f"  total {tot} clk over {nblk} blocks = {tot/nblk:.1f} clk/block (each executed mark costs about the '(one mark)' figure, charged to the section after it)")
