@@ -15,8 +15,10 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libsame_rx.so")
-SOURCES = ["same_kernels.hip", "same_kernels_fast.hip", "same_synth.hip", "same_batch.cpp", "same_config.cpp", "same_transport.cpp"]
-HEADERS = ["same_dev_common.h", "same_device.h", "same_launch.h", "same_config.h", "same_transport.h", "../../include/same_rx.h"]
+SOURCES = ["same_kernels.hip", "same_kernels_fast.hip", "same_synth.hip", "same_batch.cpp", "same_config.cpp", "same_transport.cpp", "same_place.cpp"]
+HEADERS = ["same_dev_common.h", "same_device.h", "same_launch.h", "same_config.h", "same_transport.h", "../../include/same_rx.h",
+           "../../include/same_place.h", "samedec_main.cpp"]
+SAMEDEC = os.path.join(HERE, "samedec_gpu")      # the command-line decoder (host-only program, dlopens LIB)
 ARCH = "gfx950"
 
 
@@ -40,7 +42,7 @@ def flags() -> list:
 
 
 def is_stale() -> bool:
-    if not os.path.exists(LIB):
+    if not os.path.exists(LIB) or not os.path.exists(SAMEDEC):
         return True
     t = os.path.getmtime(LIB)
     for f in SOURCES + HEADERS:
@@ -73,6 +75,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
             print(out.decode(errors="replace"))
     cmd = [cc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB] + objs
     subprocess.run(cmd, check=True)
+    cxx = shutil.which("g++") or cc
+    subprocess.run([cxx, "-O2", "-std=c++17", "-Wall", os.path.join(CSRC, "samedec_main.cpp"), "-o", SAMEDEC, "-ldl"], check=True)
     return LIB
 
 
