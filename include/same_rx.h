@@ -228,6 +228,14 @@ int same_synth_afsk_device(float *d_x, uint32_t n_channels, size_t n_samples,
                            uint32_t flags, int device, void *hip_stream);
 /* the header text the generator transmits on `channel` (host-side mirror) */
 uint32_t same_synth_payload(uint64_t seed, uint32_t channel, uint8_t *out, uint32_t cap);
+/* AWGN Monte-Carlo trials (BASELINE.json configs[4]): channel c of the TIME_MAJOR buffer is
+ * trial first_trial + c: one burst (16 x 0xAB + same_synth_payload(seed, trial)) after a
+ * ~0.1 s lead-in, in white Gaussian noise at Eb/N0 = ebn0_db_lo + (trial % n_grid) *
+ * ebn0_db_step dB.  Noise: Philox4x32-10 keyed by the seed, counter = (sample block, trial),
+ * Box-Muller in f32; sigma = A sqrt(sps / (4 Eb/N0)). */
+int same_synth_trials_device(float *d_x, uint32_t n_trials, uint32_t first_trial, size_t n_samples,
+                             uint32_t input_rate, uint64_t seed, float ebn0_db_lo, float ebn0_db_step,
+                             uint32_t n_grid, int device, void *hip_stream);
 
 #ifdef __cplusplus
 }

@@ -735,4 +735,18 @@ int same_synth_afsk_device(float *d_x, uint32_t n_channels, size_t n_samples, ui
 uint32_t same_synth_payload(uint64_t seed, uint32_t channel, uint8_t *out, uint32_t cap)
 { return same::synth_payload(seed, channel, out, cap); }
 
+int same_synth_trials_device(float *d_x, uint32_t n_trials, uint32_t first_trial, size_t n_samples,
+                             uint32_t input_rate, uint64_t seed, float ebn0_db_lo, float ebn0_db_step,
+                             uint32_t n_grid, int device, void *hip_stream)
+{
+    if (!d_x || !n_trials || !n_grid) return fail(SAME_EINVAL, "null argument");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(SAME_ENODEVICE, "no HIP device visible");
+    HIP_TRY(hipSetDevice(device));
+    same::TrialParams tp{n_trials, first_trial, input_rate, n_grid, seed, ebn0_db_lo, ebn0_db_step};
+    hipError_t e = same::launch_trials(tp, d_x, n_samples, (hipStream_t)hip_stream);
+    if (e != hipSuccess) return fail(SAME_EHIP, "trial generator launch failed: %s", hipGetErrorString(e));
+    return SAME_OK;
+}
+
 }  // extern "C"

@@ -35,6 +35,15 @@ struct SynthParams {
     uint32_t flags;        // bit 0: integer (even) samples per symbol like the reference's test modulator
 };
 hipError_t launch_synth(const SynthParams &sp, float *x, size_t n_samples, hipStream_t stream);
+struct TrialParams {
+    uint32_t n_trials;     // trials in this buffer (one per channel)
+    uint32_t first_trial;  // global id of trial 0 of this buffer
+    uint32_t input_rate;
+    uint32_t n_grid;       // Eb/N0 grid points; trial t uses point t mod n_grid
+    uint64_t seed;
+    float ebn0_db_lo, ebn0_db_step;
+};
+hipError_t launch_trials(const TrialParams &tp, float *x, size_t n_samples, hipStream_t stream);
 // host mirror of the per-channel payload the generator transmits (header text)
 uint32_t synth_payload(uint64_t seed, uint32_t channel, uint8_t *out, uint32_t cap);
 

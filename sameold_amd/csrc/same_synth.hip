@@ -122,6 +122,82 @@ __global__ __launch_bounds__(kWave) void synth_kernel(SynthParams sp, float *__r
     }
 }
 
+// ---------------------------------------------------------------------------------
+// AWGN Monte-Carlo trials (BASELINE.json configs[4], SURVEY.md section 8d "Config 5")
+// ---------------------------------------------------------------------------------
+// Philox4x32-10 (Salmon et al., "Parallel random numbers: as easy as 1, 2, 3", SC'11):
+// counter-based, so sample block b of trial t is a pure function of (seed, t, b).
+__device__ inline void philox4x32_10(uint32_t c[4], uint32_t k0, uint32_t k1)
+{
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c[0], p1 = (uint64_t)0xCD9E8D57u * c[2];
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0, n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1;
+        c[0] = n0; c[1] = (uint32_t)p1; c[2] = n2; c[3] = (uint32_t)p0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+}
+
+// One burst per trial: 0.1 s + U(0, one symbol) of noise-only lead-in, 16 x 0xAB + the header
+// of "channel" t (same_synth_payload(seed, t)), then noise to the end of the buffer.  Trial t
+// runs at Eb/N0 = lo + (t mod n_grid) * step dB.  Eb = A^2/2 * Tb and N0 = 2 sigma^2 / fs for
+// real white noise sampled at fs, so sigma = A * sqrt(sps / (4 * EbN0)).
+__global__ __launch_bounds__(kWave) void trials_kernel(TrialParams tp, float *__restrict__ x, size_t n_samples)
+{
+    const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= tp.n_trials) return;
+    const uint32_t C = tp.n_trials;
+    const uint32_t trial = tp.first_trial + c;
+    uint8_t hdr[128];
+    const uint32_t hlen = build_payload(tp.seed, trial, hdr, sizeof(hdr));
+    uint64_t s = tp.seed ^ (0x2545f4914f6cdd1dull * (uint64_t)(trial + 1));
+    const double fs = (double)tp.input_rate;
+    const float amp = 2000.0f + 28000.0f * (float)(splitmix64(s) % 65536) * (1.0f / 65536.0f);
+    const double skew = ((double)(splitmix64(s) % 2001) - 1000.0) * 2.5e-6;     // +-0.25 %
+    const double sps = fs / (520.83 * (1.0 + skew));
+    const double lead = 0.1 * fs + (double)(splitmix64(s) % 65536) * (1.0 / 65536.0) * sps;
+    const float ebn0_db = tp.ebn0_db_lo + (float)(trial % tp.n_grid) * tp.ebn0_db_step;
+    const float ebn0 = exp10f(0.1f * ebn0_db);
+    const float sigma = amp * sqrtf((float)(fs / 520.83) / (4.0f * ebn0));
+    const uint32_t dphi_mark = (uint32_t)llround(4294967296.0 * 2083.3 / fs);
+    const uint32_t dphi_space = (uint32_t)llround(4294967296.0 * 1562.5 / fs);
+    const double dur = (double)(16 + hlen) * 8.0 * sps;
+    uint32_t phase = 0;
+    float g[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    for (size_t t = 0; t < n_samples; ++t) {
+        float v = 0.0f;
+        const double u = (double)t - lead;
+        if (u >= 0.0 && u < dur) {
+            const uint32_t sym = (uint32_t)floor(u / sps);
+            const uint32_t bi = sym >> 3;
+            const uint8_t byte = bi < 16 ? 0xab : hdr[min(bi - 16, hlen - 1)];
+            phase += ((byte >> (sym & 7u)) & 1u) ? dphi_mark : dphi_space;
+            v = amp * cospif((float)phase * (1.0f / 2147483648.0f));
+        }
+        if ((t & 3) == 0) {
+            uint32_t ctr[4] = {(uint32_t)(t >> 2), (uint32_t)((uint64_t)t >> 34), trial, 0x5a4d4531u};
+            philox4x32_10(ctr, (uint32_t)tp.seed, (uint32_t)(tp.seed >> 32));
+            // Box-Muller in f32: two uniforms -> two normals
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                const float u1 = ((float)(ctr[2 * p] >> 8) + 1.0f) * (1.0f / 16777216.0f);   // (0, 1]
+                const float u2 = (float)(ctr[2 * p + 1] >> 8) * (1.0f / 16777216.0f);        // [0, 1)
+                const float r = sqrtf(-2.0f * logf(u1));
+                g[2 * p] = r * cospif(2.0f * u2);
+                g[2 * p + 1] = r * sinpif(2.0f * u2);
+            }
+        }
+        x[t * C + c] = v + sigma * g[t & 3];
+    }
+}
+
+hipError_t launch_trials(const TrialParams &tp, float *x, size_t n_samples, hipStream_t stream)
+{
+    const uint32_t grid = (tp.n_trials + kWave - 1) / kWave;
+    hipLaunchKernelGGL(trials_kernel, dim3(grid), dim3(kWave), 0, stream, tp, x, n_samples);
+    return hipGetLastError();
+}
+
 hipError_t launch_synth(const SynthParams &sp, float *x, size_t n_samples, hipStream_t stream)
 {
     const uint32_t grid = (sp.n_channels + kWave - 1) / kWave;

@@ -78,3 +78,33 @@ def test_gather_bursts_gloo_world2():
     assert [g for g in got if g[2][:1] == b"A"] == [(0, 0, b"AAAAA"), (1, 1, b"AAAAAA")]
     assert [g[1] for g in got if g[2][:1] == b"B"] == [1000, 1001, 1002, 1003]
     assert len(res[0][3]) == 2   # a rank with nothing to send contributes nothing
+
+
+def test_montecarlo_scoring_bookkeeping():
+    """Host-side scoring of the AWGN sweep (sameold_amd/montecarlo.py): first burst per trial,
+    bit errors over the common bytes, intact = whole header delivered."""
+    import numpy as np
+    from sameold_amd import montecarlo as mc
+    from sameold_amd import receiver as R
+    payloads = [b"ZCZC-AAA-BBB-123456+0015-1231234-STATION -"] * 4
+    ev = np.zeros(5, dtype=R.EVENT_DTYPE)
+
+    def put(i, ch, t, data, kind=R.LINK_BURST):
+        ev[i]["kind"], ev[i]["channel"], ev[i]["sample_counter"], ev[i]["len"] = kind, ch, t, len(data)
+        ev[i]["bytes"][: len(data)] = np.frombuffer(data, dtype=np.uint8)
+
+    put(0, 0, 500, payloads[0] + b"\0\0\0")                    # intact, trailing bytes ignored
+    put(1, 1, 700, b"ZCZC-AAA-BBB-123456+0015-1231234-STATIOO -")   # one byte wrong: 'N'^'O' = 1 bit
+    put(2, 1, 300, payloads[0][:10])                           # earlier burst of trial 1 wins: cut short
+    put(3, 2, 100, b"", kind=R.LINK_SEARCHING)                 # not a burst
+    put(4, 3, 900, payloads[0])
+    tally = mc.new_tally(2)
+    mc.score_bursts(ev, payloads, 10, 4, 2, tally)            # trials 10..13 -> grid points 0,1,0,1
+    assert tally["trials"].tolist() == [2, 2]
+    assert tally["detected"].tolist() == [1, 2]
+    assert tally["intact"].tolist() == [1, 1]
+    assert tally["bits"].tolist() == [8 * len(payloads[0]), 8 * 10 + 8 * len(payloads[0])]
+    assert tally["bit_errors"].tolist() == [0, 0]
+    assert tally["short_bytes"].tolist() == [0, len(payloads[0]) - 10]
+    rows = mc.summarise(tally, 3.0, 2.0)
+    assert rows[1]["ebn0_db"] == 5.0 and rows[0]["burst_detection_rate"] == 0.5 and rows[1]["ber"] == 0.0
