@@ -35,8 +35,8 @@ HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 ac
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--channels", type=int, default=4096, help="channels per GPU")
     ap.add_argument("--rate", type=int, default=22050)
     ap.add_argument("--seconds", type=float, default=10.0, help="audio per channel per step")

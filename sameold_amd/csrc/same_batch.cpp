@@ -302,14 +302,16 @@ int process_time_major(same_batch *rx, const SampleT *d_x, size_t n_samples, hip
         if (rx->timing) HIP_TRY(hipEventRecord(sl.ev_start, stream));
         const SampleT *xp = d_x + done * rx->P.n_channels;
         hipError_t e = hipSuccess;
-        // whole 16-sample blocks go to the latency-optimised kernel when the configuration
-        // has one; the generic kernel takes the remainder (and every other configuration)
-        size_t n_fast = (rx->use_fast && !rx->force_generic) ? (n / 16) * 16 : 0;
+        // whole blocks (16 or 18 samples) go to the latency-optimised kernel when the
+        // configuration has one; the generic kernel takes the remainder (and every other
+        // configuration)
+        const size_t fb = rx->use_fast ? same::fast_block_len(rx->P) : 16;
+        size_t n_fast = (rx->use_fast && !rx->force_generic) ? (n / fb) * fb : 0;
         if (n_fast) {
             if constexpr (sizeof(SampleT) == 4)
-                e = same::launch_demod_fast(rx->P, rx->S, O, rx->d_taps, (const float *)xp, (uint32_t)(n_fast / 16), rx->counter, stream);
+                e = same::launch_demod_fast(rx->P, rx->S, O, rx->d_taps, (const float *)xp, (uint32_t)(n_fast / fb), rx->counter, stream);
             else
-                e = same::launch_demod_fast_i16(rx->P, rx->S, O, rx->d_taps, (const int16_t *)xp, (uint32_t)(n_fast / 16), rx->counter, stream);
+                e = same::launch_demod_fast_i16(rx->P, rx->S, O, rx->d_taps, (const int16_t *)xp, (uint32_t)(n_fast / fb), rx->counter, stream);
             if (e != hipSuccess) return fail(SAME_EHIP, "fast demod kernel launch failed: %s", hipGetErrorString(e));
         }
         if (n_fast < n) {

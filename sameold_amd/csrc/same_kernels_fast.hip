@@ -34,7 +34,18 @@ namespace same {
 
 typedef float float2v __attribute__((ext_vector_type(2)));
 
-constexpr int kB = 16;   // block length of the fast kernel
+// Block length of the fast kernel: 16 samples, or 18 for the mirrored-window variant.  Both
+// are below the shortest interval between two TED instants at the standard rates (see
+// choose_block_len: 18 is the bound at 22.05 kHz), so a block holds at most one instant.
+constexpr int kBlock = 16;
+constexpr int kBlockMirror = 18;
+template <bool MIRROR> struct FastBlock { static constexpr int len = MIRROR ? kBlockMirror : kBlock; };
+// LDS window ring: a whole number of blocks (a block never wraps); a power of two when the
+// per-tap address wraps with a mask, four blocks when the window is mirrored
+template <int NT, bool MIRROR> struct FastRing {
+    static constexpr int B = FastBlock<MIRROR>::len;
+    static constexpr int slots = MIRROR ? 4 * B : ((NT + B - 1 <= 64) ? 64 : 128);
+};
 
 #ifdef SAME_PROFILE
 // cycle-attribution build (results unchanged, timing perturbed by the probes): shader-clock
@@ -215,10 +226,12 @@ __global__ __launch_bounds__(kWave) void demod_fast_kernel(Params P, State S, Ou
                                                            const SampleT *__restrict__ x,
                                                            uint32_t n_blocks, uint64_t counter0)
 {
-    constexpr int RING = (NT + kB - 1 <= 64) ? 64 : 128;
-    constexpr bool DC_REGS = (DCL == kB);
+    constexpr int kB = FastBlock<MIRROR>::len;
+    constexpr int RING = FastRing<NT, MIRROR>::slots;
+    constexpr bool DC_REGS = (DCL <= kB);
     static_assert(DC_REGS || DCL > kB, "LDS DC path needs a window longer than a block");
-    static_assert(NT + kB - 1 <= 128, "window ring too small");
+    static_assert(!DC_REGS || (DCL & (DCL - 1)) == 0, "register DC path indexes the state ring with a mask");
+    static_assert(NT + kB - 1 <= RING && RING % kB == 0, "window ring too small or not a whole number of blocks");
     extern __shared__ float lds[];
     const uint32_t lane = threadIdx.x;
     const uint32_t C = P.n_channels;
@@ -234,12 +247,16 @@ __global__ __launch_bounds__(kWave) void demod_fast_kernel(Params P, State S, Ou
 #endif
     const uint32_t c = blockIdx.x * kWave + lane;
     if (c >= C) return;                                          // no barriers below
-    constexpr int WSLOTS = MIRROR ? 2 * RING : RING;
-    float *wring = lds + TAPF;
-    float *wcol = wring + lane;                                  // [WSLOTS][64]
-    float *hcol = wring + WSLOTS * LP + lane;                    // [64][64]
-    float *ffcol = wring + (WSLOTS + kSquelchHist) * LP + lane;  // [DCL][64] (LDS DC path)
+    // LDS: taps | squelch history [64][64] | DC rings [2*DCL][64] (LDS DC path) | window.
+    // Mirrored window: logical slots 0 .. 2*RING-1, of which the first block (0 .. kB-1) is
+    // never read (the filters reach down to slot RING - NT + 1 at most) and is not stored.
+    constexpr int WSKIP = MIRROR ? kB : 0;
+    static_assert(!MIRROR || kB <= RING - NT + 1, "the first block's low copy would be read");
+    float *hcol = lds + TAPF + lane;                             // [64][64]
+    float *ffcol = hcol + kSquelchHist * LP;                     // [DCL][64] (LDS DC path)
     float *fbcol = ffcol + DCL * LP;
+    float *wring = lds + TAPF + (kSquelchHist + (DC_REGS ? 0 : 2 * DCL) - WSKIP) * LP;   // logical slot 0
+    float *wcol = wring + lane;
 
     Lane L;
     lane_load(L, S, c);
@@ -263,13 +280,16 @@ __global__ __launch_bounds__(kWave) void demod_fast_kernel(Params P, State S, Ou
     // index keeps the address arithmetic on the scalar unit
     // the window ring is re-based: LDS slot j holds the state's slot (j + counter0) mod RING,
     // so the first sample of this launch lands in slot 0 (see demod_fast)
+    // (sample counter0 - m, m = 1.., sits in the state's slot (counter0 - m) mod win_ring and in
+    // LDS slot RING - m; the LDS ring is at least as long as the state's)
+    const uint32_t G = P.win_ring;
 #pragma unroll 2
-    for (int j = 0; j < RING; ++j) {
-        const uint32_t g = (uint32_t)((uint64_t)j + counter0) & (uint32_t)(RING - 1);
+    for (uint32_t m = 1; m <= G; ++m) {
+        const uint32_t g = (uint32_t)(counter0 - (uint64_t)m) & (G - 1u);
         const float *row = S.win_ring + (size_t)g * C;
         const float v = row[c];
-        wcol[j * LP] = v;
-        if (MIRROR) wcol[(j + RING) * LP] = v;
+        if (!MIRROR || (uint32_t)RING - m >= (uint32_t)WSKIP) wcol[((uint32_t)RING - m) * LP] = v;
+        if (MIRROR) wcol[(2u * (uint32_t)RING - m) * LP] = v;
     }
 #pragma unroll 2
     for (int i = 0; i < kSquelchHist; ++i) { const float *row = S.sq_hist + (size_t)i * C; hcol[i * LP] = row[c]; }
@@ -277,11 +297,12 @@ __global__ __launch_bounds__(kWave) void demod_fast_kernel(Params P, State S, Ou
     // ring positions common to all channels
     uint32_t dpos = (uint32_t)(counter0 % (uint64_t)DCL);
     uint32_t wpos = 0;                 // LDS ring slot of the block's first sample: a multiple of 16
-    float xp[kB], mp[kB];              // DC_REGS: previous block's inputs / first-stage averages
-    if (DC_REGS) {
+    constexpr int DCR = DC_REGS ? DCL : 1;
+    float xp[DCR], mp[DCR];            // DC_REGS: the last DCL inputs / first-stage averages, oldest first
+    if constexpr (DC_REGS) {
 #pragma unroll
-        for (int k = 0; k < kB; ++k) {
-            const uint32_t slot = (dpos + (uint32_t)k) & (uint32_t)(kB - 1);
+        for (int k = 0; k < DCR; ++k) {
+            const uint32_t slot = (dpos + (uint32_t)k) & (uint32_t)(DCR - 1);
             const float *r0 = S.dc_ff_ring + (size_t)slot * C, *r1 = S.dc_fb_ring + (size_t)slot * C;
             xp[k] = r0[c];
             mp[k] = r1[c];
@@ -317,22 +338,25 @@ __global__ __launch_bounds__(kWave) void demod_fast_kernel(Params P, State S, Ou
 
         // ---- DC blocker rx/dcblock.rs:45-49, 104-108 --------------------------------
         float ys[kB];
-        if (DC_REGS) {
+        if constexpr (DC_REGS) {
             float mnew[kB];
             // two samples per step: only the running sums are serial, the differences and
             // scalings of samples k and k+1 are independent and ride in packed f32 operations
-            // (per-element IEEE, same roundings as the scalar form)
+            // (per-element IEEE, same roundings as the scalar form).  Entry i of the window as
+            // it stood before this block is xp[i] for i < DCL and this block's xs[i - DCL] after.
+            auto xw = [&](int i) { return i < DCL ? xp[i < DCL ? i : 0] : xs[i >= DCL ? i - DCL : 0]; };
 #pragma unroll
             for (int k = 0; k < kB; k += 2) {
-                const float2v x2 = {xs[k], xs[k + 1]}, xo = {xp[k], xp[k + 1]};
+                const float2v x2 = {xs[k], xs[k + 1]}, xo = {xw(k), xw(k + 1)};
                 const float2v d0 = x2 - xo;                  // input - aged
                 const float s0a = L.sum0 + d0.x, s0b = s0a + d0.y;
                 L.sum0 = s0b;
                 const float2v s0 = {s0a, s0b}, inv = {P.dc_inv_len, P.dc_inv_len};
                 const float2v ma0 = s0 * inv;
                 // window.front() after the push
-                const float2v sig = {xp[k + 1], (k + 2 < kB) ? xp[k + 2] : xs[0]};
-                const float2v mo = {mp[k], mp[k + 1]};
+                const float2v sig = {xw(k + 1), xw(k + 2)};
+                const float2v mo = {k < DCL ? mp[k < DCL ? k : 0] : mnew[k >= DCL ? k - DCL : 0],
+                                    k + 1 < DCL ? mp[k + 1 < DCL ? k + 1 : 0] : mnew[k + 1 >= DCL ? k + 1 - DCL : 0]};
                 const float2v d1 = ma0 - mo;
                 const float s1a = L.sum1 + d1.x, s1b = s1a + d1.y;
                 L.sum1 = s1b;
@@ -343,7 +367,7 @@ __global__ __launch_bounds__(kWave) void demod_fast_kernel(Params P, State S, Ou
                 mnew[k] = ma0.x; mnew[k + 1] = ma0.y;
             }
 #pragma unroll
-            for (int k = 0; k < kB; ++k) { xp[k] = xs[k]; mp[k] = mnew[k]; }
+            for (int k = 0; k < DCR; ++k) { xp[k] = xs[kB - DCR + k]; mp[k] = mnew[kB - DCR + k]; }
         } else {
             float a0[kB + 1], a1[kB];
             uint32_t slots[kB + 1];
@@ -375,11 +399,14 @@ __global__ __launch_bounds__(kWave) void demod_fast_kernel(Params P, State S, Ou
         // ---- AGC rx/agc.rs:72-77 and window push receiver.rs:345-346 -----------------
         const float g0 = L.gain;
         float *wblk = wcol + wpos * LP;
+        // mirrored window: the low copy of the ring's first block is not stored (never read);
+        // its writes are pointed at the high copy instead, which takes the same value twice
+        float *wlow = wcol + ((MIRROR && wpos == 0u) ? (uint32_t)RING : wpos) * LP;
         const float bw0 = (L.flags & F_AGC_LOCKED) ? 0.0f : P.agc_bw;
 #pragma unroll
         for (int k = 0; k < kB; ++k) {
             float out = agc_step<MED3>(P, ys[k], L.gain, bw0);
-            wblk[k * LP] = out;
+            wlow[k * LP] = out;
             if (MIRROR) wblk[(k + RING) * LP] = out;
         }
 
@@ -408,14 +435,15 @@ __global__ __launch_bounds__(kWave) void demod_fast_kernel(Params P, State S, Ou
 #pragma unroll
                 for (int k = 0; k < kB; ++k) {
                     float out = agc_step<MED3>(P, ys[k], g, (k <= fk) ? bw0 : bw1);
-                    wblk[k * LP] = out;
+                    wlow[k * LP] = out;
                     if (MIRROR) wblk[(k + RING) * LP] = out;
                 }
                 L.gain = g;
             }
         }
         until -= kB;
-        wpos = (wpos + kB) & (uint32_t)(RING - 1);
+        wpos += kB;
+        if (wpos == (uint32_t)RING) wpos = 0;
         X.mark(7);
 #ifdef SAME_PROFILE
         X.mark(8);
@@ -439,18 +467,21 @@ __global__ __launch_bounds__(kWave) void demod_fast_kernel(Params P, State S, Ou
         S.eq_fbc[i * C + c] = X.fbc[i]; S.eq_fbw[i * C + c] = X.fbw[i];
         S.eq_snap_fbc[i * C + c] = X.sfbc[i]; S.eq_snap_fbw[i * C + c] = X.sfbw[i];
     }
+    const uint64_t counter1 = counter0 + (uint64_t)n_blocks * kB;
 #pragma unroll 2
-    for (int j = 0; j < RING; ++j) {
-        const uint32_t g = (uint32_t)((uint64_t)j + counter0) & (uint32_t)(RING - 1);
+    for (uint32_t m = 1; m <= G; ++m) {
+        const uint32_t g = (uint32_t)(counter1 - (uint64_t)m) & (G - 1u);
+        const uint32_t j = wpos >= m ? wpos - m : wpos + (uint32_t)RING - m;
         float *row = S.win_ring + (size_t)g * C;
-        row[c] = wcol[j * LP];
+        row[c] = wcol[(MIRROR ? j + (uint32_t)RING : j) * LP];       // the high copy is always there
     }
 #pragma unroll 2
     for (int i = 0; i < kSquelchHist; ++i) { float *row = S.sq_hist + (size_t)i * C; row[c] = hcol[i * LP]; }
-    if (DC_REGS) {
+    if constexpr (DC_REGS) {
+        dpos = (uint32_t)(counter1 % (uint64_t)DCL);
 #pragma unroll
-        for (int k = 0; k < kB; ++k) {
-            const uint32_t slot = (dpos + (uint32_t)k) & (uint32_t)(kB - 1);
+        for (int k = 0; k < DCR; ++k) {
+            const uint32_t slot = (dpos + (uint32_t)k) & (uint32_t)(DCR - 1);
             float *r0 = S.dc_ff_ring + (size_t)slot * C, *r1 = S.dc_fb_ring + (size_t)slot * C;
             r0[c] = xp[k];
             r1[c] = mp[k];
@@ -471,13 +502,14 @@ __global__ __launch_bounds__(kWave) void demod_fast_kernel(Params P, State S, Ou
 template <int NT, int DCL, bool MIRROR>
 static constexpr size_t fast_lds_bytes()
 {
-    constexpr int RING = (NT + kB - 1 <= 64) ? 64 : 128;
+    constexpr int kB = FastBlock<MIRROR>::len;
+    constexpr int RING = FastRing<NT, MIRROR>::slots;
 #ifdef SAME_PROFILE
     constexpr size_t TAPF = (size_t)((NT * 4 + 20 + 63) / 64 * 64);
 #else
     constexpr size_t TAPF = (size_t)((NT * 4 + 63) / 64 * 64);
 #endif
-    return (TAPF + (size_t)((MIRROR ? 2 : 1) * RING + kSquelchHist + (DCL == kB ? 0 : 2 * DCL)) * kWave) * sizeof(float);
+    return (TAPF + (size_t)((MIRROR ? 2 * RING - kB : RING) + kSquelchHist + (DCL <= kB ? 0 : 2 * DCL)) * kWave) * sizeof(float);
 }
 
 // The mirrored window costs 16 KB of LDS per wavefront: 3 wavefronts fit a CU's 160 KB instead
@@ -516,14 +548,18 @@ static hipError_t launch_fast_cfg(const Params &P, const State &S, const Output 
 
 bool fast_kernel_supported(const Params &P)
 {
-    if (P.block_len != (uint32_t)kB || P.win_ring > 128u) return false;
+    if (P.block_len != (uint32_t)kBlock || P.win_ring > 128u) return false;
     const bool eq_ok = (P.eq_nff == 6u && P.eq_nfb == 4u) || (P.eq_nff == 1u && P.eq_nfb == 1u);
     if (!eq_ok) return false;
     return (P.ntaps == 42u && P.dc_len == 16u) || (P.ntaps == 92u && P.dc_len == 35u) ||
            (P.ntaps == 84u && P.dc_len == 32u);
 }
 
-uint32_t fast_win_ring(const Params &P) { return (P.ntaps + kB - 1 <= 64u) ? 64u : 128u; }
+uint32_t fast_win_ring(const Params &P) { return (P.ntaps + kBlock - 1 <= 64u) ? 64u : 128u; }
+
+// samples per block of the variant launch_demod_fast will pick for this batch
+uint32_t fast_block_len(const Params &P)
+{ return (P.ntaps == 42u && fast_use_mirror(P.n_channels, P.ntaps)) ? (uint32_t)kBlockMirror : (uint32_t)kBlock; }
 
 template <typename SampleT>
 static hipError_t launch_fast_t(const Params &P, const State &S, const Output &O, const float4 *taps,

@@ -14,6 +14,7 @@ hipError_t launch_demod_i16(const Params &P, const State &S, const Output &O, co
 size_t demod_lds_bytes(const Params &P);
 // latency-optimised kernel for the standard rates (same_kernels_fast.hip); whole blocks of 16
 bool fast_kernel_supported(const Params &P);
+uint32_t fast_block_len(const Params &P);   // samples per block of the fast kernel variant for this batch
 hipError_t launch_demod_fast(const Params &P, const State &S, const Output &O, const float4 *taps,
                              const float *x, uint32_t n_blocks, uint64_t counter0, hipStream_t stream);
 hipError_t launch_demod_fast_i16(const Params &P, const State &S, const Output &O, const float4 *taps,
