@@ -430,6 +430,10 @@ __device__ __forceinline__ uint32_t rx_symbol(const Params &P, Lane &L, const St
 
     // --- CodeAndPowerSquelch::input rx/codesquelch.rs:228-304
     const uint32_t slot = (uint32_t)(2u * (uint32_t)L.sq_symbols) & 63u;
+    // the symbol the equalizer may step over below (history offset 14/15 from the oldest sample
+    // once this symbol is in): slots slot+16/+17, distinct from the two written here, so the
+    // reads are issued first and their latency hides under the squelch arithmetic
+    const float eq_in0 = X.hist_get((slot + 16u) & 63u), eq_in1 = X.hist_get((slot + 17u) & 63u);
     X.hist_put(slot, zero);
     X.hist_put(slot + 1u, sym);
     const uint32_t fill = min(64u, L.sq_fill + 2u);
@@ -482,7 +486,7 @@ __device__ __forceinline__ uint32_t rx_symbol(const Params &P, Lane &L, const St
     X.mark(3);
     if ((clock_before >= 0) & !adjusted & (ready | reading)) {
         const uint32_t j = (uint32_t)(clock_before + 7) & 7u;   // clock 1..7 -> symbol 0..6, clock 0 -> 7
-        const uint32_t ebit = X.eq_symbol1(P, L, X.hist_get((head + 14u) & 63u), X.hist_get((head + 15u) & 63u));
+        const uint32_t ebit = X.eq_symbol1(P, L, eq_in0, eq_in1);   // history slots head+14, head+15
         uint32_t bits = (j == 0u) ? 0u : ((L.flags & F_EQ_BITS_MASK) >> F_EQ_BITS_SHIFT);
         bits |= ebit << j;
         L.flags = (L.flags & ~F_EQ_BITS_MASK) | (bits << F_EQ_BITS_SHIFT);

@@ -122,6 +122,10 @@ __device__ __forceinline__ int next_fire_count(float s, uint32_t clock)
     float f = floorf(s) - 1.0f;
     int c = (int)clock + 1;
     if (f > (float)c) c = (int)f;
+    // from floor(s) - 1 the test passes within three counts; two select steps cover that
+    // without a divergent loop, and the loop stays as the (never iterating) general case
+    c += ((s - (float)c) < 0.5f) ? 0 : 1;
+    c += ((s - (float)c) < 0.5f) ? 0 : 1;
     while (!((s - (float)c) < 0.5f)) ++c;
     return c;
 }
