@@ -308,10 +308,13 @@ int process_time_major(same_batch *rx, const SampleT *d_x, size_t n_samples, hip
         const size_t fb = rx->use_fast ? same::fast_block_len(rx->P) : 16;
         size_t n_fast = (rx->use_fast && !rx->force_generic) ? (n / fb) * fb : 0;
         if (n_fast) {
+            const bool pipe = same::pipe_kernel_selected(rx->P);
             if constexpr (sizeof(SampleT) == 4)
-                e = same::launch_demod_fast(rx->P, rx->S, O, rx->d_taps, (const float *)xp, (uint32_t)(n_fast / fb), rx->counter, stream);
+                e = pipe ? same::launch_demod_pipe(rx->P, rx->S, O, rx->d_taps, (const float *)xp, (uint32_t)(n_fast / fb), rx->counter, stream)
+                         : same::launch_demod_fast(rx->P, rx->S, O, rx->d_taps, (const float *)xp, (uint32_t)(n_fast / fb), rx->counter, stream);
             else
-                e = same::launch_demod_fast_i16(rx->P, rx->S, O, rx->d_taps, (const int16_t *)xp, (uint32_t)(n_fast / fb), rx->counter, stream);
+                e = pipe ? same::launch_demod_pipe_i16(rx->P, rx->S, O, rx->d_taps, (const int16_t *)xp, (uint32_t)(n_fast / fb), rx->counter, stream)
+                         : same::launch_demod_fast_i16(rx->P, rx->S, O, rx->d_taps, (const int16_t *)xp, (uint32_t)(n_fast / fb), rx->counter, stream);
             if (e != hipSuccess) return fail(SAME_EHIP, "fast demod kernel launch failed: %s", hipGetErrorString(e));
         }
         if (n_fast < n) {
@@ -614,7 +617,7 @@ int same_batch_last_kernel_ms(same_batch *rx, float *ms)
 const char *same_batch_kernel_name(const same_batch *rx)
 {
     if (!rx) return "";
-    if (rx->use_fast && !rx->force_generic) return "demod_fast_kernel";
+    if (rx->use_fast && !rx->force_generic) return same::pipe_kernel_selected(rx->P) ? "demod_pipe_kernel" : "demod_fast_kernel";
     switch (rx->P.block_len) {
     case 16: return "demod_kernel<B=16>";
     case 8: return "demod_kernel<B=8>";
