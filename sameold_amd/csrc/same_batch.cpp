@@ -617,7 +617,11 @@ int same_batch_last_kernel_ms(same_batch *rx, float *ms)
 const char *same_batch_kernel_name(const same_batch *rx)
 {
     if (!rx) return "";
-    if (rx->use_fast && !rx->force_generic) return same::pipe_kernel_selected(rx->P) ? "demod_pipe_kernel" : "demod_fast_kernel";
+    if (rx->use_fast && !rx->force_generic) 
+    {
+        const uint32_t st = same::pipe_kernel_stages(rx->P);
+        return st == 3u ? "demod_pipe3_kernel" : (st == 2u ? "demod_pipe_kernel" : "demod_fast_kernel");
+    }
     switch (rx->P.block_len) {
     case 16: return "demod_kernel<B=16>";
     case 8: return "demod_kernel<B=8>";

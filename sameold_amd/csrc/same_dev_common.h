@@ -65,6 +65,7 @@ struct Lane {
     uint32_t fr_word, fr_count, fr_invalid, fr_len;
     uint32_t flags;
     uint64_t tk_next, tk_last, wake_sample, wake_fired;
+    uint32_t ended;        // set by rx_end(); scratch for the pipelined kernel, never stored
 };
 
 __device__ __forceinline__ void lane_load(Lane &L, const State &S, uint32_t c)
@@ -407,6 +408,7 @@ template <typename Ctx>
 __device__ __forceinline__ void rx_end(const Params &P, Lane &L, Ctx &X)
 {
     L.flags &= ~(F_AGC_LOCKED | F_SQ_LOCK | F_BW_LOCKED | F_TED_PHASE);
+    L.ended = 1u;
     L.sq_clock = -1;                                       // squelch.end() rx/codesquelch.rs:336-339
     X.eq_reset(P);
     // symsync.set_loop_bandwidth(unlocked); symsync.reset() rx/symsync.rs:166-170, 265-271
@@ -621,16 +623,15 @@ __device__ __forceinline__ float demod_now(const Params &P, const float4 *__rest
     return rs_clamp(d, -1.0f, 1.0f);
 }
 
-template <typename Ctx>
-__device__ __forceinline__ void ted_instant(const Params &P, Lane &L, const State &S,
-                                            const Output &O, Ctx &X, uint32_t c, float sa_low,
-                                            float rem, uint64_t counter)
+// The timing half of a TED instant: ZeroCrossingTed + TimingLoop.  Returns true when this
+// instant completes a symbol (receiver.rs:383), with its two samples and the timing error.
+__device__ __forceinline__ bool ted_timing(const Params &P, Lane &L, float sa_low, float rem,
+                                           float *zero_out, float *sym_out, float *terr_out)
 {
     // ZeroCrossingTed::input rx/symsync.rs:278-287
     L.h0 = L.h1; L.h1 = L.h2; L.h2 = sa_low;
     L.flags ^= F_TED_PHASE;
     const bool have = (L.flags & F_TED_PHASE) != 0;
-    const float zero = L.h1, sym = L.h2;
     const float dsg = rs_signum(L.h0) - rs_signum(L.h2);    // zero_crossing_metric :311-322
     const float terr = L.h1 * dsg;
     // TimingLoop::advance_loop rx/symsync.rs:219-244 -- both arms computed, one committed
@@ -651,13 +652,22 @@ __device__ __forceinline__ void ted_instant(const Params &P, Lane &L, const Stat
     L.period_avg = have ? avg1 : L.period_avg;
     L.period_inst = have ? inst1 : inst0;
     L.until_next_ted = L.period_inst;                       // receiver.rs:382
-    if (!have) return;                                      // receiver.rs:383
+    *zero_out = L.h1; *sym_out = L.h2; *terr_out = terr;
+    return have;
+}
 
+// The symbol half: trace, link layer (squelch, equalizer, framer), link events, wake-ups.
+// `until_next_ted` is only recorded in the trace.
+template <typename Ctx>
+__device__ __forceinline__ void ted_symbol(const Params &P, Lane &L, const State &S, const Output &O,
+                                           Ctx &X, uint32_t c, float zero, float sym, float terr,
+                                           float until_next_ted, uint64_t counter)
+{
     if (P.trace_cap) {
         uint32_t n = S.trace_n[c];
         if (n < P.trace_cap) {
             float *t = S.trace + ((size_t)c * P.trace_cap + n) * 4;
-            t[0] = zero; t[1] = sym; t[2] = terr; t[3] = L.until_next_ted;
+            t[0] = zero; t[1] = sym; t[2] = terr; t[3] = until_next_ted;
             S.trace_idx[(size_t)c * P.trace_cap + n] = counter;
         }
         S.trace_n[c] = n + 1;
@@ -687,6 +697,16 @@ __device__ __forceinline__ void ted_instant(const Params &P, Lane &L, const Stat
         }
     }
     X.mark(6);
+}
+
+template <typename Ctx>
+__device__ __forceinline__ void ted_instant(const Params &P, Lane &L, const State &S,
+                                            const Output &O, Ctx &X, uint32_t c, float sa_low,
+                                            float rem, uint64_t counter)
+{
+    float zero, sym, terr;
+    if (!ted_timing(P, L, sa_low, rem, &zero, &sym, &terr)) return;
+    ted_symbol(P, L, S, O, X, c, zero, sym, terr, L.until_next_ted, counter);
 }
 
 

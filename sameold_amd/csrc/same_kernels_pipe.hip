@@ -297,32 +297,395 @@ __global__ __launch_bounds__(2 * kWave) void demod_pipe_kernel(Params P, State S
     }
 }
 
+// =====================================================================================
+// Three stages: sample phase (block s) | matched filters + timing loop (block s-1) | symbol
+// path (block s-2), one wavefront each.
+//
+// Stage 2 hands every completed symbol (its two soft samples, the timing error and the sample
+// index) to stage 3 through an LDS mailbox.  Stage 3's feedback is rare (about three symbols
+// per burst) and goes both ways back: the AGC lock to stage 1, and to stage 2 the loop
+// bandwidth (locked on sync, receiver.rs:432) and the timing-loop reset of end()
+// (receiver.rs:479-490 -> rx/symsync.rs:166-170, 265-271).  Both earlier stages run ahead on
+// their belief.  When a symbol of block b changes any of it, stage 1 replays the lane's AGC
+// from the sample after that instant through blocks b+1 and b+2, and stage 2 -- which keeps a
+// copy of its lane state from before block b+1 -- goes back to it, applies the change and
+// processes block b+1 again over the corrected window, replacing what it had handed on.
+// Every channel therefore sees exactly the sequential order of operations.
+// =====================================================================================
+constexpr uint32_t kP3SymWords = 5u * kWave;              // per parity: header, zero, sym, terr, until
+constexpr uint32_t kP3FbWords = kWave + 32u;              // per parity: one word per lane + the any-flag
+constexpr uint32_t kP3MailWords = 2u * kP3SymWords + 2u * kP3FbWords + kWave;   // + stage 2's final TED phase
+
+// Stage 1 state: DC blocker, AGC, input prefetch, and what a replay needs of its last three blocks
+template <bool MED3, typename SampleT>
+struct SampleStage {
+    static constexpr int NT = kPipeNT, DCL = kPipeDCL, kB = kPipeB, RING = kPipeRing;
+    static constexpr uint32_t LP = kWave;
+    float sum0, sum1, gain;
+    bool locked;                         // this stage's belief of the AGC lock
+    float xp[DCL], mp[DCL];              // the last DCL inputs / first-stage averages, oldest first
+    float xn[kB];                        // prefetched inputs of the next block
+    float ys[3][kB];                     // DC-blocker outputs: [0] newest block ... [2] two blocks back
+    float g0[3];                         // AGC gain each of them started with
+    uint32_t wp[3];                      // their ring positions
+    uint32_t wnext;                      // ring position of the block computed next
+
+    __device__ __forceinline__ void load(const Params &P, const State &S, const SampleT *__restrict__ x,
+                                         uint32_t c, uint32_t C, uint64_t counter0, float *wcol)
+    {
+        const uint32_t G = P.win_ring;
+#pragma unroll 2
+        for (uint32_t m = 1; m <= G; ++m) {
+            const uint32_t g = (uint32_t)(counter0 - (uint64_t)m) & (G - 1u);
+            const float *row = S.win_ring + (size_t)g * C;
+            const float v = row[c];
+            if ((uint32_t)RING - m >= (uint32_t)kB) wcol[((uint32_t)RING - m) * LP] = v;
+            wcol[(2u * (uint32_t)RING - m) * LP] = v;
+        }
+        sum0 = S.dc_sum0[c]; sum1 = S.dc_sum1[c]; gain = S.agc_gain[c];
+        locked = (S.flags[c] & F_AGC_LOCKED) != 0u;
+        const uint32_t dpos = (uint32_t)(counter0 % (uint64_t)DCL);
+#pragma unroll
+        for (int k = 0; k < DCL; ++k) {
+            const uint32_t slot = (dpos + (uint32_t)k) & (uint32_t)(DCL - 1);
+            const float *r0 = S.dc_ff_ring + (size_t)slot * C, *r1 = S.dc_fb_ring + (size_t)slot * C;
+            xp[k] = r0[c];
+            mp[k] = r1[c];
+        }
+#pragma unroll
+        for (int k = 0; k < kB; ++k) { const SampleT *row = x + (size_t)k * C; xn[k] = (float)row[c]; }
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            g0[j] = gain; wp[j] = 0;
+#pragma unroll
+            for (int k = 0; k < kB; ++k) ys[j][k] = 0.0f;
+        }
+        wnext = 0;
+    }
+
+    __device__ __forceinline__ void rotate()
+    {
+#pragma unroll
+        for (int k = 0; k < kB; ++k) { ys[2][k] = ys[1][k]; ys[1][k] = ys[0][k]; }
+        g0[2] = g0[1]; g0[1] = g0[0];
+        wp[2] = wp[1]; wp[1] = wp[0];
+    }
+
+    __device__ __forceinline__ void push_block(const Params &P, float *wcol, int j, float &g, int fk, float bw0, float bw1)
+    {
+        // AGC (rx/agc.rs:72-77) and window push (receiver.rs:345-346) of the block in slot j:
+        // bandwidth bw0 up to sample fk, bw1 after it
+        float *wblk = wcol + wp[j] * LP;
+        float *wlow = wcol + (wp[j] == 0u ? (uint32_t)RING : wp[j]) * LP;
+#pragma unroll
+        for (int k = 0; k < kB; ++k) {
+            const float out = agc_step<MED3>(P, ys[j][k], g, (k <= fk) ? bw0 : bw1);
+            wlow[k * LP] = out;
+            wblk[(k + RING) * LP] = out;
+        }
+    }
+
+    // DC blocker (rx/dcblock.rs:45-49, 104-108), AGC and window push of block `blk` into slot 0
+    __device__ __forceinline__ void block(const Params &P, const SampleT *__restrict__ x, uint32_t blk,
+                                          uint32_t n_blocks, uint32_t c, uint32_t C, float *wcol)
+    {
+        float xs[kB];
+#pragma unroll
+        for (int k = 0; k < kB; ++k) xs[k] = xn[k];
+        if (blk + 1 < n_blocks) {
+            const SampleT *xb = x + ((size_t)(blk + 1) * kB) * C;      // wave-uniform
+#pragma unroll
+            for (int k = 0; k < kB; ++k) { const SampleT *row = xb + (size_t)k * C; xn[k] = (float)row[c]; }
+        }
+        float mnew[kB];
+        auto xw = [&](int i) { return i < DCL ? xp[i < DCL ? i : 0] : xs[i >= DCL ? i - DCL : 0]; };
+#pragma unroll
+        for (int k = 0; k < kB; k += 2) {
+            const float2v x2 = {xs[k], xs[k + 1]}, xo = {xw(k), xw(k + 1)};
+            const float2v d0 = x2 - xo;
+            const float s0a = sum0 + d0.x, s0b = s0a + d0.y;
+            sum0 = s0b;
+            const float2v s0 = {s0a, s0b}, inv = {P.dc_inv_len, P.dc_inv_len};
+            const float2v ma0 = s0 * inv;
+            const float2v sig = {xw(k + 1), xw(k + 2)};
+            const float2v mo = {k < DCL ? mp[k < DCL ? k : 0] : mnew[k >= DCL ? k - DCL : 0],
+                                k + 1 < DCL ? mp[k + 1 < DCL ? k + 1 : 0] : mnew[k + 1 >= DCL ? k + 1 - DCL : 0]};
+            const float2v d1 = ma0 - mo;
+            const float s1a = sum1 + d1.x, s1b = s1a + d1.y;
+            sum1 = s1b;
+            const float2v s1 = {s1a, s1b};
+            const float2v ma1 = s1 * inv;
+            const float2v y2 = sig - ma1;
+            ys[0][k] = y2.x; ys[0][k + 1] = y2.y;
+            mnew[k] = ma0.x; mnew[k + 1] = ma0.y;
+        }
+#pragma unroll
+        for (int k = 0; k < DCL; ++k) { xp[k] = xs[kB - DCL + k]; mp[k] = mnew[kB - DCL + k]; }
+        g0[0] = gain;
+        wp[0] = wnext;
+        const float bw = locked ? 0.0f : P.agc_bw;
+        push_block(P, wcol, 0, gain, kB, bw, bw);
+        wnext += kB;
+        if (wnext == (uint32_t)RING) wnext = 0;
+    }
+
+    // the lock flipped at sample fk of the block in slot 2: redo the AGC from there on
+    __device__ __forceinline__ void replay(const Params &P, float *wcol, int fk, bool new_locked, bool valid1, bool valid0)
+    {
+        const float bw0 = locked ? 0.0f : P.agc_bw;
+        locked = new_locked;
+        const float bw1 = locked ? 0.0f : P.agc_bw;
+        float g = g0[2];
+        push_block(P, wcol, 2, g, fk, bw0, bw1);
+        if (valid1) { g0[1] = g; push_block(P, wcol, 1, g, -1, bw1, bw1); }
+        if (valid0) { g0[0] = g; push_block(P, wcol, 0, g, -1, bw1, bw1); }
+        gain = g;
+    }
+
+    __device__ __forceinline__ void store(const Params &P, const State &S, uint32_t c, uint32_t C, uint64_t counter1,
+                                          const float *wcol)
+    {
+        S.dc_sum0[c] = sum0; S.dc_sum1[c] = sum1; S.agc_gain[c] = gain;
+        const uint32_t dpos = (uint32_t)(counter1 % (uint64_t)DCL);
+#pragma unroll
+        for (int k = 0; k < DCL; ++k) {
+            const uint32_t slot = (dpos + (uint32_t)k) & (uint32_t)(DCL - 1);
+            float *r0 = S.dc_ff_ring + (size_t)slot * C, *r1 = S.dc_fb_ring + (size_t)slot * C;
+            r0[c] = xp[k];
+            r1[c] = mp[k];
+        }
+        const uint32_t G = P.win_ring;
+#pragma unroll 2
+        for (uint32_t m = 1; m <= G; ++m) {
+            const uint32_t g = (uint32_t)(counter1 - (uint64_t)m) & (G - 1u);
+            const uint32_t j = wnext >= m ? wnext - m : wnext + (uint32_t)RING - m;
+            float *row = S.win_ring + (size_t)g * C;
+            row[c] = wcol[(j + (uint32_t)RING) * LP];           // the high copy is always there
+        }
+    }
+};
+
+template <int NFF, int NFB, bool MED3, typename SampleT>
+__global__ __launch_bounds__(3 * kWave) void demod_pipe3_kernel(Params P, State S, Output O,
+                                                                const float4 *__restrict__ taps,
+                                                                const SampleT *__restrict__ x,
+                                                                uint32_t n_blocks, uint64_t counter0)
+{
+    constexpr int NT = kPipeNT, kB = kPipeB, RING = kPipeRing;
+    constexpr uint32_t LP = kWave;
+    extern __shared__ float lds[];
+    const uint32_t lane = threadIdx.x & (kWave - 1u);
+    const uint32_t role = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const uint32_t C = P.n_channels;
+    const uint32_t c = blockIdx.x * kWave + lane;            // C % 64 == 0 (host)
+    // LDS: taps | mailboxes | squelch history [64][64] | window (logical slots kB .. 2*RING-1)
+    float4 *tlds = reinterpret_cast<float4 *>(lds);
+    volatile uint32_t *mail = reinterpret_cast<volatile uint32_t *>(lds + kPipeTapFloats);
+    volatile uint32_t *symbox = mail;                                    // [2][5][64]
+    volatile uint32_t *fbbox = mail + 2u * kP3SymWords;                  // [2][64 + flag]
+    volatile uint32_t *phasebox = fbbox + 2u * kP3FbWords;               // [64]
+    float *hcol = lds + kPipeTapFloats + kP3MailWords + lane;
+    float *wring = lds + kPipeTapFloats + kP3MailWords + (kSquelchHist - kB) * LP;   // logical slot 0
+    float *wcol = wring + lane;
+    const uint64_t counter1 = counter0 + (uint64_t)n_blocks * kB;
+    const uint32_t n_steps = n_blocks + 2u;
+
+    if (role == 0u) {
+        // ------------------------------ stage 1: sample phase, block s -------------------------
+        for (uint32_t i = lane; i < (uint32_t)NT; i += kWave) tlds[i] = taps[i];
+        SampleStage<MED3, SampleT> M;
+        M.load(P, S, x, c, C, counter0, wcol);
+        for (uint32_t s = 0; s < n_steps; ++s) {
+            M.rotate();
+            if (s < n_blocks) M.block(P, x, s, n_blocks, c, C, wcol);
+            __syncthreads();                                             // A
+            if (s >= 2u) {
+                const volatile uint32_t *fb = fbbox + (s & 1u) * kP3FbWords;
+                if (__builtin_amdgcn_readfirstlane((int)fb[kWave])) {
+                    const uint32_t v = fb[lane];
+                    const bool new_locked = (v & 2u) != 0u;
+                    if ((v & 1u) && new_locked != M.locked)
+                        M.replay(P, wcol, (int)(v >> 8), new_locked, s - 1u < n_blocks, s < n_blocks);
+                    __syncthreads();                                     // B: the window is corrected
+                    __syncthreads();                                     // C: stage 2 has redone its block
+                }
+            }
+        }
+        __syncthreads();                                                 // (stage 2 -> 3: final TED phase)
+        M.store(P, S, c, C, counter1, wcol);
+    } else if (role == 1u) {
+        // ------------------------------ stage 2: filters + timing loop, block s-1 --------------
+        Lane L;
+        lane_load(L, S, c);
+        int cstar = next_fire_count(L.until_next_ted, L.ted_clock);
+        int until = cstar - (int)L.ted_clock - 1;      // block-relative index of the firing sample
+        uint32_t wpos = 0;
+        // one block: the instant, if this lane has one in it; hands a completed symbol to stage 3
+        auto do_block = [&](uint32_t blk) {
+            uint32_t hdr = 0;
+            float zero = 0.0f, sym = 0.0f, terr = 0.0f;
+            if (until < kB) {
+                const int fk = until;
+                const float sa_low = demod_fast<NT, RING, true>(tlds, wring, lane, wpos + (uint32_t)fk);
+                const float rem = L.until_next_ted - (float)cstar;          // receiver.rs:352
+                if (ted_timing(P, L, sa_low, rem, &zero, &sym, &terr)) hdr = 1u | ((uint32_t)fk << 8);
+                cstar = next_fire_count(L.until_next_ted, 0u);
+                until = fk + cstar;
+            }
+            until -= kB;
+            volatile uint32_t *sb = symbox + (blk & 1u) * kP3SymWords + lane;
+            sb[0] = hdr;
+            sb[kWave] = __float_as_uint(zero); sb[2 * kWave] = __float_as_uint(sym);
+            sb[3 * kWave] = __float_as_uint(terr); sb[4 * kWave] = __float_as_uint(L.until_next_ted);
+        };
+        for (uint32_t s = 0; s < n_steps; ++s) {
+            // this lane's state before block s-1, in case stage 3 sends it back there
+            const float k_h0 = L.h0, k_h1 = L.h1, k_h2 = L.h2, k_avg = L.period_avg, k_inst = L.period_inst,
+                        k_unt = L.until_next_ted;
+            const uint32_t k_flags = L.flags;
+            const int k_cstar = cstar, k_until = until;
+            const bool active = s >= 1u && s <= n_blocks;
+            if (active) do_block(s - 1u);
+            __syncthreads();                                             // A
+            if (s >= 2u) {
+                const volatile uint32_t *fb = fbbox + (s & 1u) * kP3FbWords;
+                if (__builtin_amdgcn_readfirstlane((int)fb[kWave])) {
+                    const uint32_t v = fb[lane];
+                    if (v & 1u) {
+                        L.h0 = k_h0; L.h1 = k_h1; L.h2 = k_h2; L.period_avg = k_avg; L.period_inst = k_inst;
+                        L.until_next_ted = k_unt; L.flags = k_flags; cstar = k_cstar; until = k_until;
+                        L.flags = (L.flags & ~F_BW_LOCKED) | ((v & 4u) ? F_BW_LOCKED : 0u);
+                        if (v & 8u) {                                    // end(): symsync.reset()
+                            L.flags &= ~F_TED_PHASE;
+                            L.h0 = 0.0f; L.h1 = 0.0f; L.h2 = 0.0f;
+                            L.period_avg = P.samples_per_ted; L.period_inst = P.samples_per_ted;
+                        }
+                    }
+                    __syncthreads();                                     // B: stage 1 has corrected the window
+                    if ((v & 1u) && active) do_block(s - 1u);
+                    __syncthreads();                                     // C
+                }
+            }
+            if (active) { wpos += kB; if (wpos == (uint32_t)RING) wpos = 0; }
+        }
+        phasebox[lane] = L.flags & F_TED_PHASE;
+        __syncthreads();                                                 // stage 3 merges the phase bit
+        L.ted_clock = (uint32_t)(cstar - until - 1);
+        S.until_next_ted[c] = L.until_next_ted; S.ted_clock[c] = L.ted_clock;
+        S.ted_h0[c] = L.h0; S.ted_h1[c] = L.h1; S.ted_h2[c] = L.h2;
+        S.period_avg[c] = L.period_avg; S.period_inst[c] = L.period_inst;
+    } else {
+        // ------------------------------ stage 3: symbol path, block s-2 ------------------------
+        Lane L;
+        lane_load(L, S, c);
+        L.ended = 0u;
+        FastCtx<NFF, NFB> X;
+        X.hist = hcol;
+#ifdef SAME_PROFILE
+        X.pl = reinterpret_cast<unsigned long long *>(lds + NT * 4);   // marks land in spare words; not reported
+#endif
+#pragma unroll
+        for (int i = 0; i < NFF; ++i) {
+            X.ffc[i] = S.eq_ffc[i * C + c]; X.ffw[i] = S.eq_ffw[i * C + c];
+            X.sffc[i] = S.eq_snap_ffc[i * C + c]; X.sffw[i] = S.eq_snap_ffw[i * C + c];
+        }
+#pragma unroll
+        for (int i = 0; i < NFB; ++i) {
+            X.fbc[i] = S.eq_fbc[i * C + c]; X.fbw[i] = S.eq_fbw[i * C + c];
+            X.sfbc[i] = S.eq_snap_fbc[i * C + c]; X.sfbw[i] = S.eq_snap_fbw[i * C + c];
+        }
+#pragma unroll 2
+        for (int i = 0; i < kSquelchHist; ++i) { const float *row = S.sq_hist + (size_t)i * C; hcol[i * LP] = row[c]; }
+        for (uint32_t s = 0; s < n_steps; ++s) {
+            bool any = false;
+            if (s >= 2u) {
+                const uint32_t blk = s - 2u;
+                const volatile uint32_t *sb = symbox + (blk & 1u) * kP3SymWords + lane;
+                const uint32_t hdr = sb[0];
+                uint32_t fbv = 0;
+                if (hdr & 1u) {
+                    const uint32_t fk = hdr >> 8;
+                    const float zero = __uint_as_float(sb[kWave]), sym = __uint_as_float(sb[2 * kWave]);
+                    const float terr = __uint_as_float(sb[3 * kWave]), unt = __uint_as_float(sb[4 * kWave]);
+                    const uint32_t before = L.flags & (F_AGC_LOCKED | F_BW_LOCKED);
+                    L.ended = 0u;
+                    ted_symbol(P, L, S, O, X, c, zero, sym, terr, unt, counter0 + (uint64_t)blk * kB + fk + 1u);
+                    const uint32_t after = L.flags & (F_AGC_LOCKED | F_BW_LOCKED);
+                    if (after != before || L.ended)
+                        fbv = 1u | ((after & F_AGC_LOCKED) ? 2u : 0u) | ((after & F_BW_LOCKED) ? 4u : 0u) |
+                              (L.ended ? 8u : 0u) | (fk << 8);
+                }
+                volatile uint32_t *fb = fbbox + (s & 1u) * kP3FbWords;
+                fb[lane] = fbv;
+                any = __builtin_amdgcn_ballot_w64(fbv != 0u) != 0ull;
+                if (lane == 0u) fb[kWave] = any ? 1u : 0u;
+            }
+            __syncthreads();                                             // A
+            if (any) { __syncthreads(); __syncthreads(); }               // B, C: the earlier stages catch up
+        }
+        __syncthreads();                                                 // stage 2's final TED phase
+        L.flags = (L.flags & ~F_TED_PHASE) | (phasebox[lane] & F_TED_PHASE);
+        S.sq_data[c] = L.sq_data; S.sq_power[c] = L.sq_power; S.sq_phist[c] = L.sq_phist;
+        S.sq_fill[c] = L.sq_fill; S.sq_clock[c] = L.sq_clock; S.sq_symbols[c] = L.sq_symbols;
+        S.eq_word[c] = L.eq_word; S.eq_count[c] = L.eq_count;
+        S.fr_word[c] = L.fr_word; S.fr_count[c] = L.fr_count; S.fr_invalid[c] = L.fr_invalid;
+        S.fr_len[c] = L.fr_len; S.flags[c] = L.flags;
+        S.tk_next[c] = L.tk_next; S.tk_last[c] = L.tk_last; S.wake_fired[c] = L.wake_fired;
+#pragma unroll
+        for (int i = 0; i < NFF; ++i) {
+            S.eq_ffc[i * C + c] = X.ffc[i]; S.eq_ffw[i * C + c] = X.ffw[i];
+            S.eq_snap_ffc[i * C + c] = X.sffc[i]; S.eq_snap_ffw[i * C + c] = X.sffw[i];
+        }
+#pragma unroll
+        for (int i = 0; i < NFB; ++i) {
+            S.eq_fbc[i * C + c] = X.fbc[i]; S.eq_fbw[i * C + c] = X.fbw[i];
+            S.eq_snap_fbc[i * C + c] = X.sfbc[i]; S.eq_snap_fbw[i * C + c] = X.sfbw[i];
+        }
+#pragma unroll 2
+        for (int i = 0; i < kSquelchHist; ++i) { float *row = S.sq_hist + (size_t)i * C; row[c] = hcol[i * LP]; }
+    }
+}
+
 // ---------------------------------------------------------------------------------
 // dispatch
 // ---------------------------------------------------------------------------------
 static size_t pipe_lds_bytes()
 { return ((size_t)kPipeTapFloats + kPipeMailWords + (size_t)(kSquelchHist + 2 * kPipeRing - kPipeB) * kWave) * sizeof(float); }
 
-// The pipeline pays when SIMDs are idle: two wavefronts per 64 channels, 59 KB of LDS per
-// workgroup (two workgroups per CU).  Whole groups of 64 channels only.
-bool pipe_kernel_selected(const Params &P)
+static size_t pipe3_lds_bytes()
+{ return ((size_t)kPipeTapFloats + kP3MailWords + (size_t)(kSquelchHist + 2 * kPipeRing - kPipeB) * kWave) * sizeof(float); }
+
+// The pipelines pay while SIMDs are idle.  Whole groups of 64 channels only.  Three stages:
+// three wavefronts per 64 channels, one workgroup per CU (the register footprint keeps two
+// wavefronts from sharing a SIMD) -> up to 16 384 channels in one round; two stages: two
+// workgroups per CU -> up to 32 768.  Returns 0 (none), 2 or 3.
+uint32_t pipe_kernel_stages(const Params &P)
 {
-    if (P.ntaps != (uint32_t)kPipeNT || P.dc_len != (uint32_t)kPipeDCL || (P.n_channels % kWave) != 0u) return false;
-    if (!((P.eq_nff == 6u && P.eq_nfb == 4u) || (P.eq_nff == 1u && P.eq_nfb == 1u))) return false;
-    if (const char *e = getenv("SAME_PIPE")) return atoi(e) != 0;
-    return P.n_channels <= 16384u;
+    if (P.ntaps != (uint32_t)kPipeNT || P.dc_len != (uint32_t)kPipeDCL || (P.n_channels % kWave) != 0u) return 0;
+    if (!((P.eq_nff == 6u && P.eq_nfb == 4u) || (P.eq_nff == 1u && P.eq_nfb == 1u))) return 0;
+    if (const char *e = getenv("SAME_PIPE")) { const int v = atoi(e); return v == 3 ? 3u : (v ? 2u : 0u); }
+    if (P.n_channels <= 16384u) return 3;
+    return P.n_channels <= 32768u ? 2u : 0u;
 }
+bool pipe_kernel_selected(const Params &P) { return pipe_kernel_stages(P) != 0u; }
 
 template <typename SampleT>
 static hipError_t launch_pipe_t(const Params &P, const State &S, const Output &O, const float4 *taps,
                                 const SampleT *x, uint32_t n_blocks, uint64_t counter0, hipStream_t stream)
 {
     const uint32_t grid = P.n_channels / kWave;
-    const size_t lds = pipe_lds_bytes();
+    const bool three = pipe_kernel_stages(P) == 3u;
+    const size_t lds = three ? pipe3_lds_bytes() : pipe_lds_bytes();
     const bool med3 = !(P.agc_min == 0.0f && std::signbit(P.agc_min)) && !(P.agc_max == 0.0f && std::signbit(P.agc_max));
-#define SAME_PIPE_LAUNCH(NFF, NFB, M3)                                                                     \
-    hipLaunchKernelGGL((demod_pipe_kernel<NFF, NFB, M3, SampleT>), dim3(grid), dim3(2 * kWave), lds, stream, \
-                       P, S, O, taps, x, n_blocks, counter0)
+#define SAME_PIPE_LAUNCH(NFF, NFB, M3)                                                                      \
+    do {                                                                                                    \
+        if (three)                                                                                          \
+            hipLaunchKernelGGL((demod_pipe3_kernel<NFF, NFB, M3, SampleT>), dim3(grid), dim3(3 * kWave), lds, \
+                               stream, P, S, O, taps, x, n_blocks, counter0);                                \
+        else                                                                                                \
+            hipLaunchKernelGGL((demod_pipe_kernel<NFF, NFB, M3, SampleT>), dim3(grid), dim3(2 * kWave), lds, \
+                               stream, P, S, O, taps, x, n_blocks, counter0);                                \
+    } while (0)
     if (P.eq_nff == 6u && P.eq_nfb == 4u) { if (med3) SAME_PIPE_LAUNCH(6, 4, true); else SAME_PIPE_LAUNCH(6, 4, false); }
     else { if (med3) SAME_PIPE_LAUNCH(1, 1, true); else SAME_PIPE_LAUNCH(1, 1, false); }
 #undef SAME_PIPE_LAUNCH

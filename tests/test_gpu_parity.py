@@ -292,14 +292,17 @@ def test_hypot_matches_glibc(sa, ob):
 
 
 # ------------------------------------------------------------------ fast vs generic kernel
-@pytest.mark.parametrize("rate,variant", [(22050, "pipe"), (22050, "fast"), (48000, "fast"), (44100, "fast")])
+PIPE_ENV = {"fast": "0", "pipe": "2", "pipe3": "3"}      # SAME_PIPE: stages of the wavefront pipeline (0 = off)
+
+
+@pytest.mark.parametrize("rate,variant", [(22050, "pipe3"), (22050, "pipe"), (22050, "fast"), (48000, "fast"), (44100, "fast")])
 def test_fast_kernel_equals_generic_kernel(sa, ob, rate, variant, monkeypatch):
     """Standard rates dispatch to the latency-optimised kernels (one wavefront per 64 channels,
-    or the two-stage wavefront pipeline for small 22.05 kHz batches); each must reproduce the
+    or the two- / three-stage wavefront pipelines for small 22.05 kHz batches); each must reproduce the
     any-configuration kernel (and therefore the oracle) bit for bit, including when chunk sizes
     are not whole blocks (remainder handled by the generic kernel)."""
     import torch
-    monkeypatch.setenv("SAME_PIPE", "1" if variant == "pipe" else "0")    # read at every launch
+    monkeypatch.setenv("SAME_PIPE", PIPE_ENV[variant])    # read at every launch
     n_ch, n = 128, rate * 3 + 7
     x = mixed_batch(sa, n_ch, n, seed=rate + 1, rate=rate, noise=0.05)
     xd = torch.from_numpy(x).cuda()
@@ -327,21 +330,22 @@ def test_fast_kernel_equals_generic_kernel(sa, ob, rate, variant, monkeypatch):
 
 
 def test_pipeline_kernel_equals_single_wavefront_kernel(sa, monkeypatch):
-    """The same 12 s batch through both 22.05 kHz variants, many bursts per channel (every AGC
-    lock flip makes the pipeline's first stage replay a lane): identical events."""
+    """The same 12 s batch through all three 22.05 kHz variants, many bursts per channel (every
+    AGC lock flip makes a pipeline's earlier stages replay a lane): identical events."""
     n_ch, n = 256, 22050 * 12
     x = sa.synth_afsk(n_ch, n, 22050, seed=4242, noise_sigma=0.02)
     out = {}
-    for variant in ("pipe", "fast"):
-        monkeypatch.setenv("SAME_PIPE", "1" if variant == "pipe" else "0")
+    for variant in ("pipe3", "pipe", "fast"):
+        monkeypatch.setenv("SAME_PIPE", PIPE_ENV[variant])
         rx = sa.SameReceiverBuilder(22050).build_batch(n_ch)
         assert rx.kernel_name() == f"demod_{variant}_kernel"
         for off in range(0, n, 50000):
             rx.process_tensor(x[off:off + 50000].contiguous())
         rx.sync()
         out[variant] = events_by_channel(rx)
-    assert sum(len(v) for v in out["pipe"].values()) > 4 * n_ch
+    assert sum(len(v) for v in out["fast"].values()) > 4 * n_ch
     assert out["pipe"] == out["fast"]
+    assert out["pipe3"] == out["fast"]
 
 
 def test_negative_zero_agc_bound_uses_exact_clamp(sa, ob):
