@@ -227,7 +227,7 @@ __global__ __launch_bounds__(2 * kWave) void demod_pipe_kernel(Params P, State S
         FastCtx<NFF, NFB> X;
         X.hist = hcol;
 #ifdef SAME_PROFILE
-        X.pl = reinterpret_cast<unsigned long long *>(lds + NT * 4);   // marks land in spare words; not reported
+        X.pl = nullptr;                                    // no per-section marks in the pipelines
 #endif
 #pragma unroll
         for (int i = 0; i < NFF; ++i) {
@@ -312,6 +312,19 @@ __global__ __launch_bounds__(2 * kWave) void demod_pipe_kernel(Params P, State S
 // processes block b+1 again over the corrected window, replacing what it had handed on.
 // Every channel therefore sees exactly the sequential order of operations.
 // =====================================================================================
+#ifdef SAME_PROFILE
+// per stage of workgroup 0: cycles working, waiting at the step barrier, handling feedback
+__device__ unsigned long long g_same_prof_pipe[9];
+#define P3_T0() unsigned long long p3_work = 0, p3_wait = 0, p3_fb = 0, p3_t = clock64()
+#define P3_LAP(acc) do { const unsigned long long t_ = clock64(); acc += t_ - p3_t; p3_t = t_; } while (0)
+#define P3_REPORT(role_) do { if (blockIdx.x == 0 && lane == 0) { g_same_prof_pipe[3 * (role_)] += p3_work; \
+        g_same_prof_pipe[3 * (role_) + 1] += p3_wait; g_same_prof_pipe[3 * (role_) + 2] += p3_fb; } } while (0)
+#else
+#define P3_T0() do {} while (0)
+#define P3_LAP(acc) do {} while (0)
+#define P3_REPORT(role_) do {} while (0)
+#endif
+
 constexpr uint32_t kP3SymWords = 5u * kWave;              // per parity: header, zero, sym, terr, until
 constexpr uint32_t kP3FbWords = kWave + 32u;              // per parity: one word per lane + the any-flag
 constexpr uint32_t kP3MailWords = 2u * kP3SymWords + 2u * kP3FbWords + kWave;   // + stage 2's final TED phase
@@ -495,10 +508,13 @@ __global__ __launch_bounds__(3 * kWave) void demod_pipe3_kernel(Params P, State 
         for (uint32_t i = lane; i < (uint32_t)NT; i += kWave) tlds[i] = taps[i];
         SampleStage<MED3, SampleT> M;
         M.load(P, S, x, c, C, counter0, wcol);
+        P3_T0();
         for (uint32_t s = 0; s < n_steps; ++s) {
             M.rotate();
             if (s < n_blocks) M.block(P, x, s, n_blocks, c, C, wcol);
+            P3_LAP(p3_work);
             __syncthreads();                                             // A
+            P3_LAP(p3_wait);
             if (s >= 2u) {
                 const volatile uint32_t *fb = fbbox + (s & 1u) * kP3FbWords;
                 if (__builtin_amdgcn_readfirstlane((int)fb[kWave])) {
@@ -508,9 +524,11 @@ __global__ __launch_bounds__(3 * kWave) void demod_pipe3_kernel(Params P, State 
                         M.replay(P, wcol, (int)(v >> 8), new_locked, s - 1u < n_blocks, s < n_blocks);
                     __syncthreads();                                     // B: the window is corrected
                     __syncthreads();                                     // C: stage 2 has redone its block
+                    P3_LAP(p3_fb);
                 }
             }
         }
+        P3_REPORT(0);
         __syncthreads();                                                 // (stage 2 -> 3: final TED phase)
         M.store(P, S, c, C, counter1, wcol);
     } else if (role == 1u) {
@@ -538,6 +556,7 @@ __global__ __launch_bounds__(3 * kWave) void demod_pipe3_kernel(Params P, State 
             sb[kWave] = __float_as_uint(zero); sb[2 * kWave] = __float_as_uint(sym);
             sb[3 * kWave] = __float_as_uint(terr); sb[4 * kWave] = __float_as_uint(L.until_next_ted);
         };
+        P3_T0();
         for (uint32_t s = 0; s < n_steps; ++s) {
             // this lane's state before block s-1, in case stage 3 sends it back there
             const float k_h0 = L.h0, k_h1 = L.h1, k_h2 = L.h2, k_avg = L.period_avg, k_inst = L.period_inst,
@@ -546,7 +565,9 @@ __global__ __launch_bounds__(3 * kWave) void demod_pipe3_kernel(Params P, State 
             const int k_cstar = cstar, k_until = until;
             const bool active = s >= 1u && s <= n_blocks;
             if (active) do_block(s - 1u);
+            P3_LAP(p3_work);
             __syncthreads();                                             // A
+            P3_LAP(p3_wait);
             if (s >= 2u) {
                 const volatile uint32_t *fb = fbbox + (s & 1u) * kP3FbWords;
                 if (__builtin_amdgcn_readfirstlane((int)fb[kWave])) {
@@ -564,10 +585,12 @@ __global__ __launch_bounds__(3 * kWave) void demod_pipe3_kernel(Params P, State 
                     __syncthreads();                                     // B: stage 1 has corrected the window
                     if ((v & 1u) && active) do_block(s - 1u);
                     __syncthreads();                                     // C
+                    P3_LAP(p3_fb);
                 }
             }
             if (active) { wpos += kB; if (wpos == (uint32_t)RING) wpos = 0; }
         }
+        P3_REPORT(1);
         phasebox[lane] = L.flags & F_TED_PHASE;
         __syncthreads();                                                 // stage 3 merges the phase bit
         L.ted_clock = (uint32_t)(cstar - until - 1);
@@ -582,7 +605,7 @@ __global__ __launch_bounds__(3 * kWave) void demod_pipe3_kernel(Params P, State 
         FastCtx<NFF, NFB> X;
         X.hist = hcol;
 #ifdef SAME_PROFILE
-        X.pl = reinterpret_cast<unsigned long long *>(lds + NT * 4);   // marks land in spare words; not reported
+        X.pl = nullptr;                                    // no per-section marks in the pipelines
 #endif
 #pragma unroll
         for (int i = 0; i < NFF; ++i) {
@@ -596,6 +619,7 @@ __global__ __launch_bounds__(3 * kWave) void demod_pipe3_kernel(Params P, State 
         }
 #pragma unroll 2
         for (int i = 0; i < kSquelchHist; ++i) { const float *row = S.sq_hist + (size_t)i * C; hcol[i * LP] = row[c]; }
+        P3_T0();
         for (uint32_t s = 0; s < n_steps; ++s) {
             bool any = false;
             if (s >= 2u) {
@@ -620,9 +644,12 @@ __global__ __launch_bounds__(3 * kWave) void demod_pipe3_kernel(Params P, State 
                 any = __builtin_amdgcn_ballot_w64(fbv != 0u) != 0ull;
                 if (lane == 0u) fb[kWave] = any ? 1u : 0u;
             }
+            P3_LAP(p3_work);
             __syncthreads();                                             // A
-            if (any) { __syncthreads(); __syncthreads(); }               // B, C: the earlier stages catch up
+            P3_LAP(p3_wait);
+            if (any) { __syncthreads(); __syncthreads(); P3_LAP(p3_fb); }   // B, C: the earlier stages catch up
         }
+        P3_REPORT(2);
         __syncthreads();                                                 // stage 2's final TED phase
         L.flags = (L.flags & ~F_TED_PHASE) | (phasebox[lane] & F_TED_PHASE);
         S.sq_data[c] = L.sq_data; S.sq_power[c] = L.sq_power; S.sq_phist[c] = L.sq_phist;
@@ -658,14 +685,15 @@ static size_t pipe3_lds_bytes()
 // The pipelines pay while SIMDs are idle.  Whole groups of 64 channels only.  Three stages:
 // three wavefronts per 64 channels, one workgroup per CU (the register footprint keeps two
 // wavefronts from sharing a SIMD) -> up to 16 384 channels in one round; two stages: two
-// workgroups per CU -> up to 32 768.  Returns 0 (none), 2 or 3.
+// workgroups per CU -> up to 32 768.  Measured: three stages win up to 32 768 channels (two
+// workgroups of three wavefronts per CU), the one-wavefront kernel from 49 152 on.  Returns 0
+// (none), 2 or 3.
 uint32_t pipe_kernel_stages(const Params &P)
 {
     if (P.ntaps != (uint32_t)kPipeNT || P.dc_len != (uint32_t)kPipeDCL || (P.n_channels % kWave) != 0u) return 0;
     if (!((P.eq_nff == 6u && P.eq_nfb == 4u) || (P.eq_nff == 1u && P.eq_nfb == 1u))) return 0;
     if (const char *e = getenv("SAME_PIPE")) { const int v = atoi(e); return v == 3 ? 3u : (v ? 2u : 0u); }
-    if (P.n_channels <= 16384u) return 3;
-    return P.n_channels <= 32768u ? 2u : 0u;
+    return P.n_channels <= 32768u ? 3u : 0u;       // (the two-stage kernel: SAME_PIPE=2)
 }
 bool pipe_kernel_selected(const Params &P) { return pipe_kernel_stages(P) != 0u; }
 
@@ -700,3 +728,13 @@ hipError_t launch_demod_pipe_i16(const Params &P, const State &S, const Output &
 { return launch_pipe_t<int16_t>(P, S, O, taps, x, n_blocks, counter0, stream); }
 
 }  // namespace same
+
+#ifdef SAME_PROFILE
+extern "C" int same_debug_profile_pipe(unsigned long long *out9, int reset)
+{
+    unsigned long long z[9] = {0};
+    if (hipMemcpyFromSymbol(out9, HIP_SYMBOL(same::g_same_prof_pipe), sizeof(z)) != hipSuccess) return -1;
+    if (reset && hipMemcpyToSymbol(HIP_SYMBOL(same::g_same_prof_pipe), z, sizeof(z)) != hipSuccess) return -1;
+    return 0;
+}
+#endif

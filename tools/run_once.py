@@ -34,3 +34,12 @@ if hasattr(rx._L, "same_debug_profile"):
     for n, v in zip(names, buf):
         print(f"  {n:16s} {v:14d} clk  {100.0*v/max(tot,1):5.1f} %  {v/nblk:8.1f} clk/block")
     print(f"  total {tot} clk over {nblk} blocks = {tot/nblk:.1f} clk/block (each executed mark costs about the '(one mark)' figure, charged to the section after it)")
+
+if hasattr(rx._L, "same_debug_profile_pipe") and "pipe3" in rx.kernel_name():
+    import ctypes
+    buf = (ctypes.c_ulonglong * 9)()
+    rx._L.same_debug_profile_pipe(buf, 1)
+    nstep = reps * (T // 18 + 2)
+    for r, name in enumerate(["stage 1 (sample phase)", "stage 2 (filters + timing)", "stage 3 (symbol path)"]):
+        w, b, f = buf[3 * r], buf[3 * r + 1], buf[3 * r + 2]
+        print(f"  {name:28s} work {w/nstep:8.1f}  barrier wait {b/nstep:8.1f}  feedback {f/nstep:8.1f}  clk/step (total {(w+b+f)/nstep:8.1f})")
