@@ -15,6 +15,7 @@
 #include <deque>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/same_rx.h"
@@ -210,43 +211,82 @@ int harvest_slot(same_batch *rx, same_batch::Slot &sl)
     if (n_bursts) HIP_TRY(hipMemcpyAsync(bursts.data(), sl.d_bursts, bursts.size(), hipMemcpyDeviceToHost, rx->copy_stream));
     if (n_events || n_bursts) HIP_TRY(hipStreamSynchronize(rx->copy_stream));
     auto t_copied = std::chrono::steady_clock::now();
-    // per channel the device emits in time order; across lanes the atomic cursor interleaves
-    std::stable_sort(evs.begin(), evs.end(), [](const same::DevEvent &a, const same::DevEvent &b) {
-        if (a.channel != b.channel) return a.channel < b.channel;
-        return a.sample_counter < b.sample_counter;
-    });
+    // Per channel the device emits in time order (a lane takes its log slots one after the
+    // other); across lanes the atomic cursor interleaves.  A stable counting sort by channel
+    // therefore yields (channel, time) order in O(n).
+    const uint32_t n_ch = rx->P.n_channels;
+    std::vector<uint32_t> first(n_ch + 1u, 0u);
+    for (const same::DevEvent &d : evs) first[std::min(d.channel, n_ch - 1u) + 1u]++;
+    for (uint32_t c = 0; c < n_ch; ++c) first[c + 1u] += first[c];
+    std::vector<uint32_t> order(n_events);
+    {
+        std::vector<uint32_t> fill(first.begin(), first.end() - 1);
+        for (uint32_t i = 0; i < n_events; ++i) order[fill[std::min(evs[i].channel, n_ch - 1u)]++] = i;
+    }
     const bool link_only = (rx->flags & SAME_BATCH_LINK_ONLY) != 0;
     std::vector<uint32_t> rearm;     // channels whose forced-EOM instant changed
-    rx->queue.reserve(rx->queue.size() + evs.size() + evs.size() / 2);
-    same_rx_event ev;
-    std::memset(&ev, 0, sizeof(ev));
-    for (const same::DevEvent &d : evs) {
-        std::memset(&ev, 0, offsetof(same_rx_event, bytes));
-        ev.kind = d.kind; ev.channel = d.channel; ev.sample_counter = d.sample_counter;
-        ev.symbol_count = d.symbol_count;
-        const uint8_t *bytes = nullptr;
-        if (d.kind == SAME_LINK_BURST) {
-            ev.len = d.burst_len;
-            const uint32_t n = std::min<uint32_t>(d.burst_len, SAME_EVENT_MAX_BYTES);
-            if (d.burst_slot < n_bursts) {
-                bytes = bursts.data() + (size_t)d.burst_slot * same::kBurstCap;
-                std::memcpy(ev.bytes, bytes, n);
-            } else {
-                ev.len = 0;   // pool overflow: the burst bytes were lost (SAME_EOVERFLOW is reported)
+
+    // Channels are independent (one Transport each), so contiguous channel ranges are replayed
+    // on separate host threads; each produces its slice of the output queue, in order.
+    struct Part { std::vector<same_rx_event> out; std::vector<uint32_t> rearm; };
+    auto run_range = [&](uint32_t c0, uint32_t c1, Part &part) {
+        part.out.reserve((size_t)(first[c1] - first[c0]) * 3 / 2 + 4);
+        same_rx_event ev;
+        std::memset(&ev, 0, sizeof(ev));
+        for (uint32_t k = first[c0]; k < first[c1]; ++k) {
+            const same::DevEvent &d = evs[order[k]];
+            std::memset(&ev, 0, offsetof(same_rx_event, bytes));
+            ev.kind = d.kind; ev.channel = d.channel; ev.sample_counter = d.sample_counter;
+            ev.symbol_count = d.symbol_count;
+            if (d.kind == SAME_LINK_BURST) {
+                ev.len = d.burst_len;
+                const uint32_t n = std::min<uint32_t>(d.burst_len, SAME_EVENT_MAX_BYTES);
+                if (d.burst_slot < n_bursts) std::memcpy(ev.bytes, bursts.data() + (size_t)d.burst_slot * same::kBurstCap, n);
+                else ev.len = 0;   // pool overflow: the burst bytes were lost (SAME_EOVERFLOW is reported)
             }
-        }
-        if (d.kind <= SAME_LINK_BURST) rx->queue.push_back(ev);
-        if (!link_only) {
-            same_rx_event tev;
-            if (rx->transport[d.channel].on_link_event(d.kind, d.sample_counter, d.symbol_count,
-                                                       ev.bytes, std::min<uint32_t>(ev.len, SAME_EVENT_MAX_BYTES),
-                                                       rx->P.input_rate, &tev)) {
-                tev.channel = d.channel;
-                rx->queue.push_back(tev);
+            if (d.kind <= SAME_LINK_BURST) part.out.push_back(ev);
+            if (!link_only) {
+                same_rx_event tev;
+                if (rx->transport[d.channel].on_link_event(d.kind, d.sample_counter, d.symbol_count, ev.bytes,
+                                                           std::min<uint32_t>(ev.len, SAME_EVENT_MAX_BYTES),
+                                                           rx->P.input_rate, &tev)) {
+                    tev.channel = d.channel;
+                    part.out.push_back(tev);
+                }
+                if (rx->transport[d.channel].force_eom_dirty()) part.rearm.push_back(d.channel);
             }
-            if (rx->transport[d.channel].force_eom_dirty()) rearm.push_back(d.channel);
+            if (d.kind == SAME_LINK_BURST) std::memset(ev.bytes, 0, sizeof(ev.bytes));   // keep later events clean
         }
-        if (d.kind == SAME_LINK_BURST) std::memset(ev.bytes, 0, sizeof(ev.bytes));   // keep later events clean
+    };
+    uint32_t n_threads = 1;
+    if (n_events >= 16384u && n_ch >= 64u) {
+        const unsigned hw = std::thread::hardware_concurrency();
+        n_threads = std::min<uint32_t>({16u, hw ? hw : 1u, n_ch / 32u});
+        if (const char *e = std::getenv("SAME_HOST_THREADS")) n_threads = std::max(1, std::atoi(e));
+    }
+    std::vector<Part> parts(n_threads);
+    if (n_threads == 1) {
+        run_range(0, n_ch, parts[0]);
+    } else {
+        // split by event count, on channel boundaries
+        std::vector<uint32_t> cut(n_threads + 1u, n_ch);
+        cut[0] = 0;
+        for (uint32_t t = 1; t < n_threads; ++t) {
+            const uint32_t target = (uint32_t)((uint64_t)n_events * t / n_threads);
+            cut[t] = (uint32_t)(std::lower_bound(first.begin(), first.end(), target) - first.begin());
+            cut[t] = std::min(std::max(cut[t], cut[t - 1u]), n_ch);
+        }
+        std::vector<std::thread> pool;
+        for (uint32_t t = 1; t < n_threads; ++t) pool.emplace_back(run_range, cut[t], cut[t + 1u], std::ref(parts[t]));
+        run_range(cut[0], cut[1], parts[0]);
+        for (std::thread &th : pool) th.join();
+    }
+    size_t total = 0;
+    for (const Part &p : parts) total += p.out.size();
+    rx->queue.reserve(rx->queue.size() + total);
+    for (Part &p : parts) {
+        rx->queue.insert(rx->queue.end(), p.out.begin(), p.out.end());
+        rearm.insert(rearm.end(), p.rearm.begin(), p.rearm.end());
     }
     // force_eom_at_sample (receiver.rs:321-328) lives on the host; tell the device when to
     // wake the transport layer for it.  Launches are capped well below the 135 s timeout,
