@@ -216,12 +216,16 @@ int harvest_slot(same_batch *rx, same_batch::Slot &sl)
     // therefore yields (channel, time) order in O(n).
     const uint32_t n_ch = rx->P.n_channels;
     std::vector<uint32_t> first(n_ch + 1u, 0u);
-    for (const same::DevEvent &d : evs) first[std::min(d.channel, n_ch - 1u) + 1u]++;
+    // (slots a wavefront reserved but did not use carry kDevEventNone and are dropped here)
+    for (const same::DevEvent &d : evs)
+        if (d.kind != same::kDevEventNone) first[std::min(d.channel, n_ch - 1u) + 1u]++;
     for (uint32_t c = 0; c < n_ch; ++c) first[c + 1u] += first[c];
-    std::vector<uint32_t> order(n_events);
+    const uint32_t n_real = first[n_ch];
+    std::vector<uint32_t> order(n_real);
     {
         std::vector<uint32_t> fill(first.begin(), first.end() - 1);
-        for (uint32_t i = 0; i < n_events; ++i) order[fill[std::min(evs[i].channel, n_ch - 1u)]++] = i;
+        for (uint32_t i = 0; i < n_events; ++i)
+            if (evs[i].kind != same::kDevEventNone) order[fill[std::min(evs[i].channel, n_ch - 1u)]++] = i;
     }
     const bool link_only = (rx->flags & SAME_BATCH_LINK_ONLY) != 0;
     std::vector<uint32_t> rearm;     // channels whose forced-EOM instant changed
@@ -259,7 +263,7 @@ int harvest_slot(same_batch *rx, same_batch::Slot &sl)
         }
     };
     uint32_t n_threads = 1;
-    if (n_events >= 16384u && n_ch >= 64u) {
+    if (n_real >= 16384u && n_ch >= 64u) {
         const unsigned hw = std::thread::hardware_concurrency();
         n_threads = std::min<uint32_t>({16u, hw ? hw : 1u, n_ch / 32u});
         if (const char *e = std::getenv("SAME_HOST_THREADS")) n_threads = std::max(1, std::atoi(e));
@@ -272,7 +276,7 @@ int harvest_slot(same_batch *rx, same_batch::Slot &sl)
         std::vector<uint32_t> cut(n_threads + 1u, n_ch);
         cut[0] = 0;
         for (uint32_t t = 1; t < n_threads; ++t) {
-            const uint32_t target = (uint32_t)((uint64_t)n_events * t / n_threads);
+            const uint32_t target = (uint32_t)((uint64_t)n_real * t / n_threads);
             cut[t] = (uint32_t)(std::lower_bound(first.begin(), first.end(), target) - first.begin());
             cut[t] = std::min(std::max(cut[t], cut[t - 1u]), n_ch);
         }

@@ -379,6 +379,9 @@ struct GlobalCtx {
     const State &S;
     uint32_t c, C;
     __device__ __forceinline__ void mark(int) const {}      // profiling hook of the fast kernel
+    __device__ __forceinline__ void emit(const Params &P, const State &S, const Output &O, uint32_t c, uint32_t kind,
+                                         uint64_t sample_counter, uint64_t symbols, uint32_t burst_len) const
+    { emit_event(P, S, O, c, kind, sample_counter, symbols, burst_len); }
     __device__ __forceinline__ void hist_put(uint32_t slot, float v) const { S.sq_hist[slot * C + c] = v; }
     __device__ __forceinline__ float hist_get(uint32_t slot) const { return S.sq_hist[slot * C + c]; }
     // run the equalizer over nsym symbols (2 samples each); bit b of the result = symbol b
@@ -576,14 +579,15 @@ __device__ __forceinline__ void tick_on_burst(const Params &P, Lane &L, const St
     L.tk_next = tick_min(L, S, C, c, n);
     L.flags |= F_TICK_AGAIN;
 }
-__device__ __forceinline__ void tick_poll(const Params &P, Lane &L, const State &S, const Output &O,
+template <typename Ctx>
+__device__ __forceinline__ void tick_poll(const Params &P, Lane &L, const State &S, const Output &O, Ctx &X,
                                        uint32_t c, uint64_t counter)
 {
     const uint32_t C = P.n_channels;
     const uint64_t sym = L.sq_symbols;
     const bool expired = sym >= L.tk_next;
     const bool woke = L.wake_sample != 0 && L.wake_sample != L.wake_fired && counter > L.wake_sample;
-    emit_event(P, S, O, c, 8u, counter, sym, 0);
+    X.emit(P, S, O, c, 8u, counter, sym, 0);
     L.flags &= ~F_TICK_AGAIN;
     if (woke) L.wake_fired = L.wake_sample;
     if (expired) {
@@ -685,7 +689,7 @@ __device__ __forceinline__ void ted_symbol(const Params &P, Lane &L, const State
     uint32_t last = (L.flags & F_LINK_MASK) >> F_LINK_SHIFT;
     if (link != last || link == 3u) {
         L.flags = (L.flags & ~F_LINK_MASK) | (link << F_LINK_SHIFT);
-        emit_event(P, S, O, c, link, counter, L.sq_symbols, burst_len);
+        X.emit(P, S, O, c, link, counter, L.sq_symbols, burst_len);
     }
     if (P.ticks) {
         if (link == 3u) {
@@ -693,7 +697,7 @@ __device__ __forceinline__ void ted_symbol(const Params &P, Lane &L, const State
         } else if (link == 0u) {
             if ((L.flags & F_TICK_AGAIN) || L.sq_symbols >= L.tk_next ||
                 (L.wake_sample != 0 && L.wake_sample != L.wake_fired && counter > L.wake_sample))
-                tick_poll(P, L, S, O, c, counter);
+                tick_poll(P, L, S, O, X, c, counter);
         }
     }
     X.mark(6);

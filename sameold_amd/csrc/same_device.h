@@ -116,9 +116,10 @@ struct State {
 };
 
 // One link-layer event as the device records it.  32 bytes.
+constexpr uint32_t kDevEventNone = 0xffffffffu;   // kind of a reserved but unused log slot (skipped by the host)
 struct DevEvent {
     uint32_t channel;
-    uint32_t kind;           // SAME_LINK_*
+    uint32_t kind;           // SAME_LINK_*, 8 = transport wake-up, kDevEventNone = empty slot
     uint64_t sample_counter;
     uint64_t symbol_count;
     uint32_t burst_len;      // true length (may exceed kBurstCap)

@@ -51,6 +51,9 @@ struct FastCtx {
     float *hist;                       // LDS column of this lane: slot i at hist[i * kWave]
     float ffc[NFF], ffw[NFF], fbc[NFB], fbw[NFB];
     float sffc[NFF], sffw[NFF], sfbc[NFB], sfbw[NFB];   // equalizer at the last completed byte
+    __device__ __forceinline__ void emit(const Params &P, const State &S, const Output &O, uint32_t c, uint32_t kind,
+                                         uint64_t sample_counter, uint64_t symbols, uint32_t burst_len)
+    { emit_event(P, S, O, c, kind, sample_counter, symbols, burst_len); }
     __device__ __forceinline__ void eq_snapshot(const Params &)
     {
 #pragma unroll

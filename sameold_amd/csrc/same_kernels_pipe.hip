@@ -327,7 +327,63 @@ __device__ unsigned long long g_same_prof_pipe[9];
 
 constexpr uint32_t kP3SymWords = 5u * kWave;              // per parity: header, zero, sym, terr, until
 constexpr uint32_t kP3FbWords = kWave + 32u;              // per parity: one word per lane + the any-flag
-constexpr uint32_t kP3MailWords = 2u * kP3SymWords + 2u * kP3FbWords + kWave;   // + stage 2's final TED phase
+constexpr uint32_t kP3MailWords = 2u * kP3SymWords + 2u * kP3FbWords + 2u * kWave;   // + stage 2's final TED phase, + the log chunk
+
+// Stage 3's event log access.  emit_event takes a slot with a returning atomic per event --
+// an L2 round trip (~1 us) on the critical path of whichever stage emits.  Here the
+// wavefront reserves runs of 64 slots (one atomic per run) and hands them out with a ballot;
+// slots of a run that stay unused are marked kDevEventNone for the host to skip.
+constexpr uint32_t kEvChunk = 64;
+template <int NFF, int NFB>
+struct PipeCtx : FastCtx<NFF, NFB> {
+    volatile uint32_t *chunk;     // LDS: [0] first slot of the current run, [1] slots of it already handed out
+    __device__ __forceinline__ void emit(const Params &P, const State &S, const Output &O, uint32_t c, uint32_t kind,
+                                         uint64_t sample_counter, uint64_t symbols, uint32_t burst_len)
+    {
+        const uint64_t act = __builtin_amdgcn_ballot_w64(true);          // the lanes emitting right now
+        const uint32_t n = (uint32_t)__popcll(act);
+        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(act >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)act, 0u));
+        uint32_t base = chunk[0], used = chunk[1];
+        if (used + n > kEvChunk) {                                       // wave-uniform
+            for (uint32_t i = used + rank; i < kEvChunk; i += n)
+                if (base + i < O.event_cap) { O.events[base + i].channel = 0; O.events[base + i].kind = kDevEventNone; }
+            uint32_t nb = 0;
+            if (rank == 0u) nb = atomicAdd(O.n_events, kEvChunk);
+            base = (uint32_t)__builtin_amdgcn_readfirstlane((int)nb);    // first active lane = rank 0
+            used = 0;
+        }
+        const uint32_t e = base + used + rank;
+        chunk[0] = base; chunk[1] = used + n;
+        uint32_t slot = 0xffffffffu;
+        if (kind == 3u) {  // SAME_LINK_BURST: copy the framer buffer row into the pool
+            const uint32_t b = atomicAdd(O.n_events + 1, 1u);
+            if (b < O.burst_cap) {
+                slot = b;
+                const uint4 *src = reinterpret_cast<const uint4 *>(S.fr_msg + (size_t)c * kBurstCap);
+                uint4 *dst = reinterpret_cast<uint4 *>(O.bursts + (size_t)b * kBurstCap);
+#pragma unroll
+                for (int i = 0; i < kBurstCap / 16; ++i) dst[i] = src[i];
+            } else {
+                atomicOr(O.n_events + 2, 2u);
+            }
+        }
+        if (e < O.event_cap) {
+            DevEvent ev;
+            ev.channel = c; ev.kind = kind; ev.sample_counter = sample_counter;
+            ev.symbol_count = symbols; ev.burst_len = burst_len; ev.burst_slot = slot;
+            O.events[e] = ev;
+        } else {
+            atomicOr(O.n_events + 2, 1u);
+        }
+    }
+    // end of the launch, all lanes: mark what is left of the current run as empty
+    __device__ __forceinline__ void retire(const Output &O, uint32_t lane)
+    {
+        const uint32_t base = chunk[0], used = chunk[1];
+        for (uint32_t i = used + lane; i < kEvChunk; i += kWave)
+            if (base + i < O.event_cap) { O.events[base + i].channel = 0; O.events[base + i].kind = kDevEventNone; }
+    }
+};
 
 // Stage 1 state: DC blocker, AGC, input prefetch, and what a replay needs of its last three blocks
 template <bool MED3, typename SampleT>
@@ -497,6 +553,7 @@ __global__ __launch_bounds__(3 * kWave) void demod_pipe3_kernel(Params P, State 
     volatile uint32_t *symbox = mail;                                    // [2][5][64]
     volatile uint32_t *fbbox = mail + 2u * kP3SymWords;                  // [2][64 + flag]
     volatile uint32_t *phasebox = fbbox + 2u * kP3FbWords;               // [64]
+    volatile uint32_t *chunkbox = phasebox + kWave;                      // [2]
     float *hcol = lds + kPipeTapFloats + kP3MailWords + lane;
     float *wring = lds + kPipeTapFloats + kP3MailWords + (kSquelchHist - kB) * LP;   // logical slot 0
     float *wcol = wring + lane;
@@ -602,7 +659,9 @@ __global__ __launch_bounds__(3 * kWave) void demod_pipe3_kernel(Params P, State 
         Lane L;
         lane_load(L, S, c);
         L.ended = 0u;
-        FastCtx<NFF, NFB> X;
+        PipeCtx<NFF, NFB> X;
+        X.chunk = chunkbox;
+        chunkbox[0] = 0u; chunkbox[1] = kEvChunk;       // nothing reserved yet
         X.hist = hcol;
 #ifdef SAME_PROFILE
         X.pl = nullptr;                                    // no per-section marks in the pipelines
@@ -650,6 +709,7 @@ __global__ __launch_bounds__(3 * kWave) void demod_pipe3_kernel(Params P, State 
             if (any) { __syncthreads(); __syncthreads(); P3_LAP(p3_fb); }   // B, C: the earlier stages catch up
         }
         P3_REPORT(2);
+        X.retire(O, lane);
         __syncthreads();                                                 // stage 2's final TED phase
         L.flags = (L.flags & ~F_TED_PHASE) | (phasebox[lane] & F_TED_PHASE);
         S.sq_data[c] = L.sq_data; S.sq_power[c] = L.sq_power; S.sq_phist[c] = L.sq_phist;
