@@ -372,12 +372,23 @@ __device__ __forceinline__ void eq_reset(const Params &P, const State &S, uint32
     for (uint32_t i = 0; i < P.eq_nfb; ++i) { S.eq_fbc[i * C + c] = (i == 0) ? 1.0f : 0.0f; S.eq_fbw[i * C + c] = 0.0f; }
 }
 
+// The deadline ring (oldest first) is reached through the kernel's context: tk_count / tk_at /
+// tk_set.  TickRingGlobal keeps it in the HBM state arrays; the pipelined kernel keeps it in
+// registers for the launch.
+struct TickRingGlobal {
+    __device__ __forceinline__ uint32_t tk_count(const State &S, uint32_t c) const { return S.tk_n[c]; }
+    __device__ __forceinline__ void tk_set_count(const State &S, uint32_t c, uint32_t n) const { S.tk_n[c] = n; }
+    __device__ __forceinline__ uint64_t tk_at(const State &S, uint32_t C, uint32_t c, uint32_t i) const { return S.tk_ring[i * C + c]; }
+    __device__ __forceinline__ void tk_set(const State &S, uint32_t C, uint32_t c, uint32_t i, uint64_t v) const { S.tk_ring[i * C + c] = v; }
+};
+
 // Where the symbol-rate state that is too big for registers lives.  GlobalCtx keeps the
 // squelch sample history and the equalizer in the HBM state arrays (any configuration);
 // the fast kernel supplies a context with the history in LDS and the equalizer in VGPRs.
-struct GlobalCtx {
+struct GlobalCtx : TickRingGlobal {
     const State &S;
     uint32_t c, C;
+    __device__ __forceinline__ GlobalCtx(const State &S_, uint32_t c_, uint32_t C_) : S(S_), c(c_), C(C_) {}
     __device__ __forceinline__ void mark(int) const {}      // profiling hook of the fast kernel
     __device__ __forceinline__ void emit(const Params &P, const State &S, const Output &O, uint32_t c, uint32_t kind,
                                          uint64_t sample_counter, uint64_t symbols, uint32_t burst_len) const
@@ -558,25 +569,27 @@ __device__ __forceinline__ uint32_t rx_symbol(const Params &P, Lane &L, const St
 // ---------------------------------------------------------------------------------
 static constexpr uint64_t kNoDeadline = ~0ull;
 
-__device__ __forceinline__ uint64_t tick_min(const Lane &L, const State &S, uint32_t C, uint32_t c, uint32_t n)
+template <typename Ctx>
+__device__ __forceinline__ uint64_t tick_min(const Lane &L, const State &S, const Ctx &X, uint32_t C, uint32_t c, uint32_t n)
 {
     uint64_t m = L.tk_last;
-    if (n) { uint64_t f = S.tk_ring[c]; m = f < m ? f : m; }   // ring is oldest (smallest) first
+    if (n) { uint64_t f = X.tk_at(S, C, c, 0u); m = f < m ? f : m; }   // ring is oldest (smallest) first
     return m;
 }
-__device__ __forceinline__ void tick_on_burst(const Params &P, Lane &L, const State &S, uint32_t c)
+template <typename Ctx>
+__device__ __forceinline__ void tick_on_burst(const Params &P, Lane &L, const State &S, Ctx &X, uint32_t c)
 {
     const uint32_t C = P.n_channels;
-    uint32_t n = S.tk_n[c];
+    uint32_t n = X.tk_count(S, c);
     if (n == (uint32_t)kTickRing) {          // full: drop the oldest deadline
-        for (uint32_t i = 1; i < n; ++i) S.tk_ring[(i - 1) * C + c] = S.tk_ring[i * C + c];
+        for (uint32_t i = 1; i < n; ++i) X.tk_set(S, C, c, i - 1u, X.tk_at(S, C, c, i));
         n -= 1;
     }
-    S.tk_ring[n * C + c] = L.sq_symbols + P.tick_interburst;
+    X.tk_set(S, C, c, n, L.sq_symbols + P.tick_interburst);
     n += 1;
-    S.tk_n[c] = n;
+    X.tk_set_count(S, c, n);
     L.tk_last = L.sq_symbols + P.tick_history;
-    L.tk_next = tick_min(L, S, C, c, n);
+    L.tk_next = tick_min(L, S, X, C, c, n);
     L.flags |= F_TICK_AGAIN;
 }
 template <typename Ctx>
@@ -591,15 +604,15 @@ __device__ __forceinline__ void tick_poll(const Params &P, Lane &L, const State 
     L.flags &= ~F_TICK_AGAIN;
     if (woke) L.wake_fired = L.wake_sample;
     if (expired) {
-        uint32_t n = S.tk_n[c], drop = 0;
-        while (drop < n && S.tk_ring[drop * C + c] <= sym) ++drop;
+        uint32_t n = X.tk_count(S, c), drop = 0;
+        while (drop < n && X.tk_at(S, C, c, drop) <= sym) ++drop;
         if (drop) {
-            for (uint32_t i = drop; i < n; ++i) S.tk_ring[(i - drop) * C + c] = S.tk_ring[i * C + c];
+            for (uint32_t i = drop; i < n; ++i) X.tk_set(S, C, c, i - drop, X.tk_at(S, C, c, i));
             n -= drop;
-            S.tk_n[c] = n;
+            X.tk_set_count(S, c, n);
         }
         if (L.tk_last <= sym) L.tk_last = kNoDeadline;
-        L.tk_next = tick_min(L, S, C, c, n);
+        L.tk_next = tick_min(L, S, X, C, c, n);
     }
     if (expired || woke) L.flags |= F_TICK_AGAIN;
 }
@@ -693,7 +706,7 @@ __device__ __forceinline__ void ted_symbol(const Params &P, Lane &L, const State
     }
     if (P.ticks) {
         if (link == 3u) {
-            tick_on_burst(P, L, S, c);
+            tick_on_burst(P, L, S, X, c);
         } else if (link == 0u) {
             if ((L.flags & F_TICK_AGAIN) || L.sq_symbols >= L.tk_next ||
                 (L.wake_sample != 0 && L.wake_sample != L.wake_fired && counter > L.wake_sample))

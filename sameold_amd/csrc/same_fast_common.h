@@ -28,7 +28,7 @@ template <int NT, bool MIRROR> struct FastRing {
 
 
 template <int NFF, int NFB>
-struct FastCtx {
+struct FastCtx : TickRingGlobal {
 #ifdef SAME_PROFILE
     // The accumulators live in one LDS location shared by the whole wavefront: a mark inside a
     // divergent region is executed by the active lanes only, and every one of them reads and
