@@ -327,7 +327,9 @@ __device__ unsigned long long g_same_prof_pipe[9];
 
 constexpr uint32_t kP3SymWords = 5u * kWave;              // per parity: header, zero, sym, terr, until
 constexpr uint32_t kP3FbWords = kWave + 32u;              // per parity: one word per lane + the any-flag
-constexpr uint32_t kP3MailWords = 2u * kP3SymWords + 2u * kP3FbWords + 2u * kWave;   // + stage 2's final TED phase, + the log chunk
+constexpr uint32_t kP3MailWords = 2u * kP3SymWords + 2u * kP3FbWords + kWave;   // + stage 2's final TED phase
+// (the log-chunk words live in the padding of the first feedback box: 62 208 B of LDS in all,
+// and two workgroups share a CU -- at 62 464 B they no longer do)
 
 // Stage 3's event log access.  emit_event takes a slot with a returning atomic per event --
 // an L2 round trip (~1 us) on the critical path of whichever stage emits.  Here the
@@ -534,8 +536,11 @@ struct SampleStage {
     }
 };
 
-template <int NFF, int NFB, bool MED3, typename SampleT>
-__global__ __launch_bounds__(3 * kWave) void demod_pipe3_kernel(Params P, State S, Output O,
+// SHARE: built for two wavefronts per SIMD (half of the 512-entry register file each, a few
+// spills) -- what lets two workgroups, six wavefronts, share a CU's four SIMDs beyond 16 384
+// channels.  Smaller batches use the unconstrained build (2 % faster).
+template <int NFF, int NFB, bool MED3, bool SHARE, typename SampleT>
+__global__ __launch_bounds__(3 * kWave, SHARE ? 2 : 1) void demod_pipe3_kernel(Params P, State S, Output O,
                                                                 const float4 *__restrict__ taps,
                                                                 const SampleT *__restrict__ x,
                                                                 uint32_t n_blocks, uint64_t counter0)
@@ -553,7 +558,7 @@ __global__ __launch_bounds__(3 * kWave) void demod_pipe3_kernel(Params P, State 
     volatile uint32_t *symbox = mail;                                    // [2][5][64]
     volatile uint32_t *fbbox = mail + 2u * kP3SymWords;                  // [2][64 + flag]
     volatile uint32_t *phasebox = fbbox + 2u * kP3FbWords;               // [64]
-    volatile uint32_t *chunkbox = phasebox + kWave;                      // [2]
+    volatile uint32_t *chunkbox = fbbox + kWave + 2u;                    // [2], in the first box's padding
     float *hcol = lds + kPipeTapFloats + kP3MailWords + lane;
     float *wring = lds + kPipeTapFloats + kP3MailWords + (kSquelchHist - kB) * LP;   // logical slot 0
     float *wcol = wring + lane;
@@ -767,8 +772,11 @@ static hipError_t launch_pipe_t(const Params &P, const State &S, const Output &O
     const bool med3 = !(P.agc_min == 0.0f && std::signbit(P.agc_min)) && !(P.agc_max == 0.0f && std::signbit(P.agc_max));
 #define SAME_PIPE_LAUNCH(NFF, NFB, M3)                                                                      \
     do {                                                                                                    \
-        if (three)                                                                                          \
-            hipLaunchKernelGGL((demod_pipe3_kernel<NFF, NFB, M3, SampleT>), dim3(grid), dim3(3 * kWave), lds, \
+        if (three && P.n_channels > 16384u)                                                                 \
+            hipLaunchKernelGGL((demod_pipe3_kernel<NFF, NFB, M3, true, SampleT>), dim3(grid), dim3(3 * kWave), lds, \
+                               stream, P, S, O, taps, x, n_blocks, counter0);                                \
+        else if (three)                                                                                     \
+            hipLaunchKernelGGL((demod_pipe3_kernel<NFF, NFB, M3, false, SampleT>), dim3(grid), dim3(3 * kWave), lds, \
                                stream, P, S, O, taps, x, n_blocks, counter0);                                \
         else                                                                                                \
             hipLaunchKernelGGL((demod_pipe_kernel<NFF, NFB, M3, SampleT>), dim3(grid), dim3(2 * kWave), lds, \

@@ -329,10 +329,12 @@ def test_fast_kernel_equals_generic_kernel(sa, ob, rate, variant, monkeypatch):
         assert a.get(c, []) == oracle_events(ob, cfg, x[:, c]), f"channel {c}"
 
 
-def test_pipeline_kernel_equals_single_wavefront_kernel(sa, monkeypatch):
-    """The same 12 s batch through all three 22.05 kHz variants, many bursts per channel (every
-    AGC lock flip makes a pipeline's earlier stages replay a lane): identical events."""
-    n_ch, n = 256, 22050 * 12
+@pytest.mark.parametrize("n_ch,seconds", [(256, 12.0), (16448, 1.5)])
+def test_pipeline_kernel_equals_single_wavefront_kernel(sa, monkeypatch, n_ch, seconds):
+    """The same batch through all three 22.05 kHz variants, many bursts per channel (every AGC
+    lock flip makes a pipeline's earlier stages replay a lane): identical events.  Above 16 384
+    channels the three-stage kernel is the build with the halved register budget."""
+    n = int(22050 * seconds)
     x = sa.synth_afsk(n_ch, n, 22050, seed=4242, noise_sigma=0.02)
     out = {}
     for variant in ("pipe3", "pipe", "fast"):
@@ -343,7 +345,7 @@ def test_pipeline_kernel_equals_single_wavefront_kernel(sa, monkeypatch):
             rx.process_tensor(x[off:off + 50000].contiguous())
         rx.sync()
         out[variant] = events_by_channel(rx)
-    assert sum(len(v) for v in out["fast"].values()) > 4 * n_ch
+    assert sum(len(v) for v in out["fast"].values()) > 2 * n_ch
     assert out["pipe"] == out["fast"]
     assert out["pipe3"] == out["fast"]
 
