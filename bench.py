@@ -193,7 +193,7 @@ def main():
             "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
             "kernel_ms": round(k_ms, 4), "algorithmic_bytes_per_launch": 4 * C * T,
-            "note": "latency/issue-bound at 64 wavefronts on 1024 SIMDs (DESIGN.md section 5)",
+            "note": "issue-bound serial streams: 64 workgroups x 3 pipeline-stage wavefronts on 1024 SIMDs (DESIGN.md 4.4, 4.4b)",
         },
     }
 

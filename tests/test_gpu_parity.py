@@ -350,6 +350,19 @@ def test_pipeline_kernel_equals_single_wavefront_kernel(sa, monkeypatch, n_ch, s
     assert out["pipe3"] == out["fast"]
 
 
+def test_i16_input_through_the_pipeline_kernel(sa, ob):
+    """int16 samples cast in stage 1 of the pipelined kernel (64 channels => demod_pipe3_kernel)."""
+    n_ch, n = 64, 22050 * 4
+    x = np.clip(np.rint(mixed_batch(sa, n_ch, n, seed=77)), -32768, 32767).astype(np.int16)
+    rx = sa.SameReceiverBuilder(22050).samedec().build_batch(n_ch)
+    assert rx.kernel_name() == "demod_pipe3_kernel"
+    rx.process_host(x)
+    got = events_by_channel(rx)
+    cfg = ob.samedec_config()
+    for c in range(0, n_ch, 7):
+        assert got.get(c, []) == oracle_events(ob, cfg, x[:, c]), f"channel {c}"
+
+
 def test_negative_zero_agc_bound_uses_exact_clamp(sa, ob):
     """v_med3_f32 is only used when no AGC bound is -0.0; the other path must still match."""
     n_ch, n = 64, 22050 * 2
