@@ -137,12 +137,11 @@ def main():
     stream = 0
 
     def gather(ev):
-        b = ev[ev["kind"] == sa.LINK_BURST]
+        # the step's one collective: every rank's burst records to rank 0 (RCCL; vectorised packing)
+        recs = sd.pack_burst_events(ev, first_ch)
         if not distributed:
-            return len(b)
-        recs = [(int(first_ch + r["channel"]), int(r["sample_counter"]), r["bytes"][: min(int(r["len"]), 288)].tobytes())
-                for r in b]
-        got = sd.gather_bursts(recs, dev)
+            return len(recs)
+        got = sd.gather_records(recs, dev)
         return len(got) if got is not None else 0
 
     def barrier():

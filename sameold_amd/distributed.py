@@ -48,6 +48,44 @@ def unpack_bursts(recs: np.ndarray) -> List[Tuple[int, int, bytes]]:
     return out
 
 
+def pack_burst_events(events: np.ndarray, first_channel: int = 0) -> np.ndarray:
+    """Vectorised pack_bursts for an EVENT_DTYPE array (sameold_amd.receiver): the SAME_LINK_BURST
+    events of one rank -> uint8 [n, RECORD_BYTES] with global channel numbers."""
+    b = events[events["kind"] == 3]                      # SAME_LINK_BURST
+    out = np.zeros((len(b), RECORD_BYTES), dtype=np.uint8)
+    if len(b):
+        out[:, 0:4] = (b["channel"].astype(np.uint32) + np.uint32(first_channel)).view(np.uint8).reshape(-1, 4)
+        out[:, 4:12] = b["sample_counter"].astype(np.uint64).view(np.uint8).reshape(-1, 8)
+        n = np.minimum(b["len"].astype(np.uint32), np.uint32(RECORD_BYTES - _HDR))
+        out[:, 12:16] = n.view(np.uint8).reshape(-1, 4)
+        data = b["bytes"][:, : RECORD_BYTES - _HDR]
+        keep = np.arange(RECORD_BYTES - _HDR, dtype=np.uint32)[None, :] < n[:, None]
+        out[:, _HDR:] = np.where(keep, data, 0)
+    return out
+
+
+def gather_records(recs: np.ndarray, device: torch.device, dst: int = 0) -> Optional[np.ndarray]:
+    """Gather packed records ([n, RECORD_BYTES] uint8 per rank) on rank `dst`: one all_gather of
+    the counts, one gather of the records padded to the largest count.  Returns the
+    concatenation on `dst` (rank order), None elsewhere; the identity without a process group."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return recs
+    world, rank = dist.get_world_size(), dist.get_rank()
+    n = torch.tensor([len(recs)], dtype=torch.int64, device=device)
+    counts = [torch.zeros_like(n) for _ in range(world)]
+    dist.all_gather(counts, n)
+    counts = [int(c.item()) for c in counts]
+    m = max(max(counts), 1)
+    buf = torch.zeros((m, RECORD_BYTES), dtype=torch.uint8, device=device)
+    if len(recs):
+        buf[: len(recs)] = torch.from_numpy(np.ascontiguousarray(recs)).to(device)
+    out = [torch.zeros_like(buf) for _ in range(world)] if rank == dst else None
+    dist.gather(buf, out, dst=dst)
+    if rank != dst:
+        return None
+    return np.concatenate([out[r][: counts[r]].cpu().numpy() for r in range(world)], axis=0)
+
+
 def gather_bursts(bursts: Sequence[Tuple[int, int, bytes]], device: torch.device,
                   dst: int = 0) -> Optional[List[Tuple[int, int, bytes]]]:
     """Gather every rank's bursts on rank `dst` (returns None on the other ranks).

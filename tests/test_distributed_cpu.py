@@ -32,6 +32,12 @@ def _worker(rank, world, port, q):
     mine = [(first + (i % count), 1000 * rank + i, bytes([65 + rank]) * (5 + i)) for i in range((rank + 1) * 2)]
     got = sd.gather_bursts(mine, torch.device("cpu"))
     got2 = sd.gather_bursts(mine if rank == 0 else [], torch.device("cpu"))
+    # the vectorised record path bench.py uses
+    recs = sd.gather_records(sd.pack_bursts(mine), torch.device("cpu"))
+    if recs is not None:
+        assert sd.unpack_bursts(recs) == got
+    else:
+        assert got is None
     dist.barrier()
     q.put((rank, first, count, got, got2))
     dist.destroy_process_group()
@@ -108,3 +114,23 @@ def test_montecarlo_scoring_bookkeeping():
     assert tally["short_bytes"].tolist() == [0, len(payloads[0]) - 10]
     rows = mc.summarise(tally, 3.0, 2.0)
     assert rows[1]["ebn0_db"] == 5.0 and rows[0]["burst_detection_rate"] == 0.5 and rows[1]["ber"] == 0.0
+
+
+def test_vectorised_burst_packing_matches_the_record_layout():
+    """pack_burst_events (what bench.py gathers) == pack_bursts on the same bursts."""
+    import numpy as np
+    from sameold_amd import distributed as sd
+    from sameold_amd import receiver as R
+    ev = np.zeros(4, dtype=R.EVENT_DTYPE)
+    payloads = [b"ZCZC-AAA-BBB-123456+0015-1231234-STATION -", b"NNNN", b"x" * 300, b""]
+    kinds = [R.LINK_BURST, R.LINK_BURST, R.LINK_BURST, R.LINK_SEARCHING]
+    for i, (p, k) in enumerate(zip(payloads, kinds)):
+        ev[i]["kind"], ev[i]["channel"], ev[i]["sample_counter"], ev[i]["len"] = k, 7 + i, 1000 * (i + 1) + (1 << 33), len(p)
+        n = min(len(p), 288)
+        ev[i]["bytes"][:n] = np.frombuffer(p[:n], dtype=np.uint8)
+        ev[i]["bytes"][n:] = 0xEE                       # stale bytes past the burst must not leak
+    got = sd.pack_burst_events(ev, first_channel=4096)
+    want = sd.pack_bursts([(4096 + 7 + i, 1000 * (i + 1) + (1 << 33), payloads[i][:288]) for i in range(3)])
+    assert got.shape == (3, sd.RECORD_BYTES) and np.array_equal(got, want)
+    assert sd.unpack_bursts(got)[1] == (4096 + 8, 2000 + (1 << 33), b"NNNN")
+    assert sd.gather_records(got, None) is got      # no process group: identity
