@@ -14,6 +14,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import sys
 from typing import Iterator, List, Optional, Sequence
 
 import numpy as np
@@ -87,6 +88,28 @@ class SymbolTrace(C.Structure):
 _lib = None
 
 
+def _share_hip_runtime_with_torch() -> None:
+    """PyTorch-ROCm wheels carry their own libamdhip64 (same SONAME as the system one, different
+    file).  If this library is loaded before torch, the process ends up with two HIP runtimes
+    and the one initialised second sees no device.  Loading torch's copy first -- without
+    importing torch -- makes both bind to the same runtime whichever order they arrive in."""
+    import importlib.util
+    if "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return
+    cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        try:
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
 def load_library() -> C.CDLL:
     """Load libsame_rx.so and declare every prototype of include/same_rx.h."""
     global _lib
@@ -95,6 +118,7 @@ def load_library() -> C.CDLL:
     if not os.path.exists(LIB_PATH):
         raise SameError(-5, f"{LIB_PATH} is missing: run `python -m sameold_amd.build` "
                             "(hipcc, gfx950); there is no CPU implementation to fall back to")
+    _share_hip_runtime_with_torch()
     L = C.CDLL(LIB_PATH)
     P, vp, u32, u64, f32 = C.POINTER, C.c_void_p, C.c_uint32, C.c_uint64, C.c_float
 
