@@ -91,7 +91,7 @@ static void cisoid(uint32_t points, float freq_fs, float *re, float *im)
     }
 }
 
-uint32_t choose_block_len(const Params &P)
+uint32_t max_block_len(const Params &P)
 {
     // Shortest period the timing loop can command (rx/symsync.rs:219-244): period_inst =
     // period_avg + alpha*err + offset with period_avg >= period_min, |err| <= 1,
@@ -103,10 +103,16 @@ uint32_t choose_block_len(const Params &P)
     float lb = P.period_min - a - 0.5f;
     if (!(lb > 0.0f)) lb = 0.0f;
     // one more sample of margin for the f32 rounding of (period - clock)
-    float maxb = std::floor(lb - 0.5f);
+    const float maxb = std::floor(lb - 0.5f);
+    return maxb >= 1.0f ? (uint32_t)maxb : 1u;
+}
+
+uint32_t choose_block_len(const Params &P)
+{
+    const uint32_t maxb = max_block_len(P);
     uint32_t B = 1;
     for (uint32_t cand : {16u, 8u, 4u, 2u}) {
-        if ((float)cand <= maxb) { B = cand; break; }
+        if (cand <= maxb) { B = cand; break; }
     }
     return B;
 }

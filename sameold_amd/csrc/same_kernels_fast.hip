@@ -45,7 +45,7 @@ __global__ __launch_bounds__(kWave) void demod_fast_kernel(Params P, State S, Ou
                                                            const SampleT *__restrict__ x,
                                                            uint32_t n_blocks, uint64_t counter0)
 {
-    constexpr int kB = FastBlock<MIRROR>::len;
+    constexpr int kB = FastBlock<NT, MIRROR>::len;
     constexpr int RING = FastRing<NT, MIRROR>::slots;
     constexpr bool DC_REGS = (DCL <= kB);
     static_assert(DC_REGS || DCL > kB, "LDS DC path needs a window longer than a block");
@@ -321,7 +321,7 @@ __global__ __launch_bounds__(kWave) void demod_fast_kernel(Params P, State S, Ou
 template <int NT, int DCL, bool MIRROR>
 static constexpr size_t fast_lds_bytes()
 {
-    constexpr int kB = FastBlock<MIRROR>::len;
+    constexpr int kB = FastBlock<NT, MIRROR>::len;
     constexpr int RING = FastRing<NT, MIRROR>::slots;
 #ifdef SAME_PROFILE
     constexpr size_t TAPF = (size_t)((NT * 4 + 20 + 63) / 64 * 64);
@@ -334,8 +334,9 @@ static constexpr size_t fast_lds_bytes()
 // The mirrored window costs 16 KB of LDS per wavefront: 3 wavefronts fit a CU's 160 KB instead
 // of 4, so it is used while the batch needs at most 3 wavefronts per CU (and only for the
 // 42-tap filters, whose ring is 64 slots).
-static bool fast_use_mirror(uint32_t n_channels, uint32_t ntaps)
+static bool fast_use_mirror(uint32_t n_channels, uint32_t ntaps, uint32_t max_block)
 {
+    if (max_block < (uint32_t)kBlockMirror) return false;     // 18-sample blocks need the timing bound
     if (const char *e = getenv("SAME_MIRROR")) return atoi(e) != 0 && ntaps == 42u;
     return ntaps == 42u && (n_channels + kWave - 1) / kWave <= 3u * 256u;
 }
@@ -346,7 +347,7 @@ static hipError_t launch_fast_cfg(const Params &P, const State &S, const Output 
 {
     const uint32_t grid = (P.n_channels + kWave - 1) / kWave;
     constexpr bool CAN_MIRROR = (NT == 42);
-    const bool mirror = CAN_MIRROR && fast_use_mirror(P.n_channels, P.ntaps);
+    const bool mirror = CAN_MIRROR && fast_use_mirror(P.n_channels, P.ntaps, max_block_len(P));
     const size_t lds = mirror ? fast_lds_bytes<NT, DCL, CAN_MIRROR>() : fast_lds_bytes<NT, DCL, false>();
     // v_med3_f32 == f32::clamp unless a bound is -0.0 (or NaN, which the builder rejects)
     const bool med3 = !(P.agc_min == 0.0f && std::signbit(P.agc_min)) && !(P.agc_max == 0.0f && std::signbit(P.agc_max));
@@ -370,6 +371,7 @@ bool fast_kernel_supported(const Params &P)
     if (P.block_len != (uint32_t)kBlock || P.win_ring > 128u) return false;
     const bool eq_ok = (P.eq_nff == 6u && P.eq_nfb == 4u) || (P.eq_nff == 1u && P.eq_nfb == 1u);
     if (!eq_ok) return false;
+    if (P.ntaps == 92u && max_block_len(P) < (uint32_t)kBlock48k) return false;   // its block is 32 samples
     return (P.ntaps == 42u && P.dc_len == 16u) || (P.ntaps == 92u && P.dc_len == 35u) ||
            (P.ntaps == 84u && P.dc_len == 32u);
 }
@@ -380,7 +382,8 @@ uint32_t fast_win_ring(const Params &P) { return (P.ntaps + kBlock - 1 <= 64u) ?
 uint32_t fast_block_len(const Params &P)
 {
     if (pipe_kernel_selected(P)) return (uint32_t)kBlockMirror;
-    return (P.ntaps == 42u && fast_use_mirror(P.n_channels, P.ntaps)) ? (uint32_t)kBlockMirror : (uint32_t)kBlock;
+    if (P.ntaps == 42u && fast_use_mirror(P.n_channels, P.ntaps, max_block_len(P))) return (uint32_t)kBlockMirror;
+    return P.ntaps == 92u ? (uint32_t)kBlock48k : (uint32_t)kBlock;
 }
 
 template <typename SampleT>

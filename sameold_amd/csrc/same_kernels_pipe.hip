@@ -757,6 +757,7 @@ uint32_t pipe_kernel_stages(const Params &P)
 {
     if (P.ntaps != (uint32_t)kPipeNT || P.dc_len != (uint32_t)kPipeDCL || (P.n_channels % kWave) != 0u) return 0;
     if (!((P.eq_nff == 6u && P.eq_nfb == 4u) || (P.eq_nff == 1u && P.eq_nfb == 1u))) return 0;
+    if (P.block_len != 16u || max_block_len(P) < (uint32_t)kPipeB) return 0;       // 18-sample blocks
     if (const char *e = getenv("SAME_PIPE")) { const int v = atoi(e); return v == 3 ? 3u : (v ? 2u : 0u); }
     return P.n_channels <= 32768u ? 3u : 0u;       // (the two-stage kernel: SAME_PIPE=2)
 }

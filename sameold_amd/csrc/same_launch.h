@@ -13,6 +13,8 @@ hipError_t launch_demod_i16(const Params &P, const State &S, const Output &O, co
                             const int16_t *x, uint32_t n_samples, uint64_t counter0, hipStream_t stream);
 size_t demod_lds_bytes(const Params &P);
 // latency-optimised kernel for the standard rates (same_kernels_fast.hip); whole blocks of 16
+// longest block that can hold at most one TED instant for this configuration (same_config.cpp)
+uint32_t max_block_len(const Params &P);
 bool fast_kernel_supported(const Params &P);
 uint32_t fast_block_len(const Params &P);   // samples per block of the fast kernel variant for this batch
 // two-stage wavefront pipeline (same_kernels_pipe.hip): small batches at 22.05 kHz

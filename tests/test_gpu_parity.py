@@ -249,6 +249,26 @@ def test_builder_variants(sa, ob, variant):
         assert got.get(c, []) == oracle_events(ob, cfg, x[:, c]), f"{variant} channel {c}"
 
 
+@pytest.mark.parametrize("rate,dev,kernel", [(22050, 0.05, "demod_fast_kernel"), (22050, 0.01, "demod_pipe3_kernel"),
+                                             (48000, 0.2, "demod_kernel<B=16>"), (48000, 0.01, "demod_fast_kernel")])
+def test_block_length_follows_the_timing_bound(sa, ob, rate, dev, kernel):
+    """A block may hold at most one TED instant.  The 18-sample (22.05 kHz mirrored / pipelined)
+    and 32-sample (48 kHz) variants are only dispatched when timing_max_deviation leaves room
+    for them; with a wider deviation the dispatcher falls back to shorter blocks, and every
+    choice matches the oracle."""
+    n_ch, n = 64, rate * 3
+    x = mixed_batch(sa, n_ch, n, seed=5, rate=rate, noise=0.05)
+    b = sa.SameReceiverBuilder(rate).with_timing_max_deviation(dev)
+    cfg = ob.default_config(rate)
+    ob.lib().so_config_with_timing_max_deviation(C.byref(cfg), dev)
+    rx = b.build_batch(n_ch)
+    assert rx.kernel_name() == kernel
+    rx.process_host(x)
+    got = events_by_channel(rx)
+    for c in range(0, n_ch, 5):
+        assert got.get(c, []) == oracle_events(ob, cfg, x[:, c]), f"channel {c}"
+
+
 def test_reset(sa, ob):
     pcm = load_pcm("npt").astype(np.float32)
     rx = sa.SameReceiverBuilder(22050).samedec().build_batch(1)
