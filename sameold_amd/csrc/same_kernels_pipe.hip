@@ -1,23 +1,16 @@
-// same_kernels_pipe.hip -- two-stage wavefront pipeline for small batches at 22.05 kHz.
+// same_kernels_pipe.hip -- three-stage wavefront pipeline for small and medium batches at 22.05 kHz.
 //
 // With one wavefront per 64 channels (same_kernels_fast.hip) a launch of 4 096 channels is 64
 // serial instruction streams on a machine with 1 024 SIMDs, and a stream's length per block is
-// what it is whichever lanes are live.  Here a workgroup of TWO wavefronts owns 64 channels and
-// the stream is cut in two stages that run concurrently on different SIMDs of one CU, one
-// block apart, handing data over through LDS:
-//
-//   wavefront 0 ("sample phase"): input prefetch, DC blocker, AGC, window push   -- block i+1
-//   wavefront 1 ("instants"):     matched filters, timing loop, symbol path      -- block i
-//
-// The only feedback from the second stage into the first is the AGC lock (agc.lock(true) on
-// sync, lock(false) in end(): receiver.rs:431, 481) -- about three times per burst.  The sample
-// phase therefore runs ahead on its current belief; when an instant of block i flips a lane's
-// lock, the first wavefront replays that lane's AGC from the sample after the instant through
-// block i+1 (it keeps the DC-blocker outputs of both blocks and the gain block i started with)
-// before the second stage moves on.  The arithmetic per channel and its order are exactly
-// those of the one-wavefront kernels, so results are bit-identical (tests/test_gpu_parity.py
-// runs every case through whichever variant the dispatcher picks, and
-// test_fast_kernel_equals_generic_kernel pits them against each other).
+// what it is whichever lanes are live.  Here a workgroup of THREE wavefronts owns 64 channels:
+// the stream is cut in stages that run concurrently on different SIMDs of one CU, one block
+// apart, handing data over through LDS (see "Three stages" below).  The arithmetic per channel
+// and its order are exactly those of the one-wavefront kernels, so results are bit-identical
+// (tests/test_gpu_parity.py runs every 22.05 kHz case of up to 32 768 channels through this
+// kernel; test_fast_kernel_equals_generic_kernel and
+// test_pipeline_kernel_equals_single_wavefront_kernel pit the variants against each other).
+// A two-stage cut (sample phase | everything else) was measured on the way: 27.8 ms against
+// 35.3 ms (one wavefront) and 20.3 ms (three stages) at 4 096 channels x 10 s.
 //
 // Window ring: 5 blocks of 18 slots, mirrored (see same_fast_common.h): while stage 2 reads the
 // 42 slots ending at an instant of block i, stage 1 writes block i+1, and with five blocks the
@@ -43,259 +36,6 @@ constexpr uint32_t kPipeTapFloats = (uint32_t)((kPipeNT * 4 + 20 + 63) / 64 * 64
 #else
 constexpr uint32_t kPipeTapFloats = (uint32_t)((kPipeNT * 4 + 63) / 64 * 64);
 #endif
-constexpr uint32_t kPipeMailWords = 192;     // two mailboxes of 64 per-lane words + 1 flag, padded
-
-template <int NFF, int NFB, bool MED3, typename SampleT>
-__global__ __launch_bounds__(2 * kWave) void demod_pipe_kernel(Params P, State S, Output O,
-                                                               const float4 *__restrict__ taps,
-                                                               const SampleT *__restrict__ x,
-                                                               uint32_t n_blocks, uint64_t counter0)
-{
-    constexpr int NT = kPipeNT, DCL = kPipeDCL, kB = kPipeB, RING = kPipeRing;
-    constexpr uint32_t LP = kWave;
-    static_assert((DCL & (DCL - 1)) == 0 && DCL <= kB, "register DC path");
-    static_assert(kB <= RING - NT + 1, "the first block's low copy would be read");
-    extern __shared__ float lds[];
-    const uint32_t lane = threadIdx.x & (kWave - 1u);
-    const uint32_t role = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const uint32_t C = P.n_channels;
-    const uint32_t c = blockIdx.x * kWave + lane;            // the host launches this kernel only for C % 64 == 0
-    // LDS: taps | mailboxes | squelch history [64][64] | window (logical slots kB .. 2*RING-1)
-    float4 *tlds = reinterpret_cast<float4 *>(lds);
-    volatile uint32_t *mail = reinterpret_cast<volatile uint32_t *>(lds + kPipeTapFloats);
-    float *hcol = lds + kPipeTapFloats + kPipeMailWords + lane;
-    float *wring = lds + kPipeTapFloats + kPipeMailWords + (kSquelchHist - kB) * LP;   // logical slot 0
-    float *wcol = wring + lane;
-    const uint64_t counter1 = counter0 + (uint64_t)n_blocks * kB;
-    const uint32_t G = P.win_ring;
-
-    if (role == 0u) {
-        // =========================== stage 1: the sample phase ===============================
-        for (uint32_t i = lane; i < (uint32_t)NT; i += kWave) tlds[i] = taps[i];
-        // window ring, re-based so that the launch's first sample lands in slot 0 (same_fast_common.h)
-#pragma unroll 2
-        for (uint32_t m = 1; m <= G; ++m) {
-            const uint32_t g = (uint32_t)(counter0 - (uint64_t)m) & (G - 1u);
-            const float *row = S.win_ring + (size_t)g * C;
-            const float v = row[c];
-            if ((uint32_t)RING - m >= (uint32_t)kB) wcol[((uint32_t)RING - m) * LP] = v;
-            wcol[(2u * (uint32_t)RING - m) * LP] = v;
-        }
-        float sum0 = S.dc_sum0[c], sum1 = S.dc_sum1[c], gain = S.agc_gain[c];
-        bool locked = (S.flags[c] & F_AGC_LOCKED) != 0u;     // this stage's belief
-        uint32_t dpos = (uint32_t)(counter0 % (uint64_t)DCL);
-        float xp[DCL], mp[DCL];                              // the last DCL inputs / first-stage averages
-#pragma unroll
-        for (int k = 0; k < DCL; ++k) {
-            const uint32_t slot = (dpos + (uint32_t)k) & (uint32_t)(DCL - 1);
-            const float *r0 = S.dc_ff_ring + (size_t)slot * C, *r1 = S.dc_fb_ring + (size_t)slot * C;
-            xp[k] = r0[c];
-            mp[k] = r1[c];
-        }
-        float xn[kB];
-#pragma unroll
-        for (int k = 0; k < kB; ++k) { const SampleT *row = x + (size_t)k * C; xn[k] = (float)row[c]; }
-
-        float ys_cur[kB], ys_prev[kB];          // DC-blocker outputs of the newest block and the one before
-        float g0_cur = gain, g0_prev = gain;    // AGC gain each of them started with
-        uint32_t wp_cur = 0, wp_prev = 0;       // their ring positions
-        uint32_t wnext = 0;                     // ring position of the block computed next
-#pragma unroll
-        for (int k = 0; k < kB; ++k) { ys_cur[k] = 0.0f; ys_prev[k] = 0.0f; }
-
-        // one block through DC blocker (rx/dcblock.rs:45-49, 104-108), AGC (rx/agc.rs:72-77) and
-        // window push (receiver.rs:345-346); `blk` is its index
-        auto sample_phase = [&](uint32_t blk) {
-            float xs[kB];
-#pragma unroll
-            for (int k = 0; k < kB; ++k) xs[k] = xn[k];
-            if (blk + 1 < n_blocks) {
-                const SampleT *xb = x + ((size_t)(blk + 1) * kB) * C;      // wave-uniform
-#pragma unroll
-                for (int k = 0; k < kB; ++k) { const SampleT *row = xb + (size_t)k * C; xn[k] = (float)row[c]; }
-            }
-            float mnew[kB];
-            auto xw = [&](int i) { return i < DCL ? xp[i < DCL ? i : 0] : xs[i >= DCL ? i - DCL : 0]; };
-#pragma unroll
-            for (int k = 0; k < kB; k += 2) {
-                const float2v x2 = {xs[k], xs[k + 1]}, xo = {xw(k), xw(k + 1)};
-                const float2v d0 = x2 - xo;
-                const float s0a = sum0 + d0.x, s0b = s0a + d0.y;
-                sum0 = s0b;
-                const float2v s0 = {s0a, s0b}, inv = {P.dc_inv_len, P.dc_inv_len};
-                const float2v ma0 = s0 * inv;
-                const float2v sig = {xw(k + 1), xw(k + 2)};
-                const float2v mo = {k < DCL ? mp[k < DCL ? k : 0] : mnew[k >= DCL ? k - DCL : 0],
-                                    k + 1 < DCL ? mp[k + 1 < DCL ? k + 1 : 0] : mnew[k + 1 >= DCL ? k + 1 - DCL : 0]};
-                const float2v d1 = ma0 - mo;
-                const float s1a = sum1 + d1.x, s1b = s1a + d1.y;
-                sum1 = s1b;
-                const float2v s1 = {s1a, s1b};
-                const float2v ma1 = s1 * inv;
-                const float2v y2 = sig - ma1;
-                ys_cur[k] = y2.x; ys_cur[k + 1] = y2.y;
-                mnew[k] = ma0.x; mnew[k + 1] = ma0.y;
-            }
-#pragma unroll
-            for (int k = 0; k < DCL; ++k) { xp[k] = xs[kB - DCL + k]; mp[k] = mnew[kB - DCL + k]; }
-            g0_cur = gain;
-            wp_cur = wnext;
-            const float bw = locked ? 0.0f : P.agc_bw;
-            float *wblk = wcol + wnext * LP;
-            float *wlow = wcol + (wnext == 0u ? (uint32_t)RING : wnext) * LP;
-#pragma unroll
-            for (int k = 0; k < kB; ++k) {
-                const float out = agc_step<MED3>(P, ys_cur[k], gain, bw);
-                wlow[k * LP] = out;
-                wblk[(k + RING) * LP] = out;
-            }
-            wnext += kB;
-            if (wnext == (uint32_t)RING) wnext = 0;
-        };
-
-        sample_phase(0);
-        __syncthreads();
-        for (uint32_t blk = 0; blk < n_blocks; ++blk) {
-            // stage 2 is on block blk; this stage moves on to block blk + 1
-#pragma unroll
-            for (int k = 0; k < kB; ++k) ys_prev[k] = ys_cur[k];
-            g0_prev = g0_cur;
-            wp_prev = wp_cur;
-            const bool have_next = blk + 1 < n_blocks;
-            if (have_next) sample_phase(blk + 1);
-            __syncthreads();
-            const volatile uint32_t *mb = mail + (blk & 1u) * 96u;
-            const uint32_t any = (uint32_t)__builtin_amdgcn_readfirstlane((int)mb[64]);
-            if (any) {
-                const uint32_t fbv = mb[lane];
-                if (fbv & 1u) {
-                    // this lane's lock flipped at sample fk of block blk: redo its AGC with the
-                    // old lock up to fk and the new one after it, through block blk + 1
-                    const int fk = (int)(fbv >> 8);
-                    const float bw0 = locked ? 0.0f : P.agc_bw;
-                    locked = (fbv & 2u) != 0u;
-                    const float bw1 = locked ? 0.0f : P.agc_bw;
-                    float g = g0_prev;
-                    {
-                        float *wblk = wcol + wp_prev * LP;
-                        float *wlow = wcol + (wp_prev == 0u ? (uint32_t)RING : wp_prev) * LP;
-#pragma unroll
-                        for (int k = 0; k < kB; ++k) {
-                            const float out = agc_step<MED3>(P, ys_prev[k], g, (k <= fk) ? bw0 : bw1);
-                            wlow[k * LP] = out;
-                            wblk[(k + RING) * LP] = out;
-                        }
-                    }
-                    if (have_next) {
-                        g0_cur = g;
-                        float *wblk = wcol + wp_cur * LP;
-                        float *wlow = wcol + (wp_cur == 0u ? (uint32_t)RING : wp_cur) * LP;
-#pragma unroll
-                        for (int k = 0; k < kB; ++k) {
-                            const float out = agc_step<MED3>(P, ys_cur[k], g, bw1);
-                            wlow[k * LP] = out;
-                            wblk[(k + RING) * LP] = out;
-                        }
-                    }
-                    gain = g;
-                }
-                __syncthreads();
-            }
-        }
-
-        // ---- this stage's share of the state ------------------------------------------------
-        S.dc_sum0[c] = sum0; S.dc_sum1[c] = sum1; S.agc_gain[c] = gain;
-        dpos = (uint32_t)(counter1 % (uint64_t)DCL);
-#pragma unroll
-        for (int k = 0; k < DCL; ++k) {
-            const uint32_t slot = (dpos + (uint32_t)k) & (uint32_t)(DCL - 1);
-            float *r0 = S.dc_ff_ring + (size_t)slot * C, *r1 = S.dc_fb_ring + (size_t)slot * C;
-            r0[c] = xp[k];
-            r1[c] = mp[k];
-        }
-#pragma unroll 2
-        for (uint32_t m = 1; m <= G; ++m) {
-            const uint32_t g = (uint32_t)(counter1 - (uint64_t)m) & (G - 1u);
-            const uint32_t j = wnext >= m ? wnext - m : wnext + (uint32_t)RING - m;
-            float *row = S.win_ring + (size_t)g * C;
-            row[c] = wcol[(j + (uint32_t)RING) * LP];           // the high copy is always there
-        }
-    } else {
-        // =========================== stage 2: the instants ====================================
-        Lane L;
-        lane_load(L, S, c);
-        FastCtx<NFF, NFB> X;
-        X.hist = hcol;
-#ifdef SAME_PROFILE
-        X.pl = nullptr;                                    // no per-section marks in the pipelines
-#endif
-#pragma unroll
-        for (int i = 0; i < NFF; ++i) {
-            X.ffc[i] = S.eq_ffc[i * C + c]; X.ffw[i] = S.eq_ffw[i * C + c];
-            X.sffc[i] = S.eq_snap_ffc[i * C + c]; X.sffw[i] = S.eq_snap_ffw[i * C + c];
-        }
-#pragma unroll
-        for (int i = 0; i < NFB; ++i) {
-            X.fbc[i] = S.eq_fbc[i * C + c]; X.fbw[i] = S.eq_fbw[i * C + c];
-            X.sfbc[i] = S.eq_snap_fbc[i * C + c]; X.sfbw[i] = S.eq_snap_fbw[i * C + c];
-        }
-#pragma unroll 2
-        for (int i = 0; i < kSquelchHist; ++i) { const float *row = S.sq_hist + (size_t)i * C; hcol[i * LP] = row[c]; }
-
-        int cstar = next_fire_count(L.until_next_ted, L.ted_clock);
-        int until = cstar - (int)L.ted_clock - 1;      // block-relative index of the firing sample
-        uint32_t wpos = 0;
-        __syncthreads();                               // taps, window and block 0 are in LDS
-        for (uint32_t blk = 0; blk < n_blocks; ++blk) {
-            uint32_t fbv = 0;
-            if (until < kB) {
-                const int fk = until;
-                const uint32_t newest = wpos + (uint32_t)fk;
-                const float sa_low = demod_fast<NT, RING, true>(tlds, wring, lane, newest);
-                const float rem = L.until_next_ted - (float)cstar;          // receiver.rs:352
-                const uint32_t locked_before = L.flags & F_AGC_LOCKED;
-                ted_instant(P, L, S, O, X, c, sa_low, rem, counter0 + (uint64_t)blk * kB + (uint32_t)fk + 1u);
-                cstar = next_fire_count(L.until_next_ted, 0u);
-                until = fk + cstar;
-                const uint32_t locked_after = L.flags & F_AGC_LOCKED;
-                if (locked_after != locked_before) fbv = 1u | (locked_after ? 2u : 0u) | ((uint32_t)fk << 8);
-            }
-            until -= kB;
-            wpos += kB;
-            if (wpos == (uint32_t)RING) wpos = 0;
-            volatile uint32_t *mb = mail + (blk & 1u) * 96u;
-            mb[lane] = fbv;
-            const bool any = __builtin_amdgcn_ballot_w64(fbv != 0u) != 0ull;
-            if (lane == 0u) mb[64] = any ? 1u : 0u;
-            __syncthreads();
-            if (any) __syncthreads();                  // stage 1 replays the affected lanes in between
-        }
-
-        // ---- this stage's share of the state ------------------------------------------------
-        L.ted_clock = (uint32_t)(cstar - until - 1);
-        S.until_next_ted[c] = L.until_next_ted; S.ted_clock[c] = L.ted_clock;
-        S.ted_h0[c] = L.h0; S.ted_h1[c] = L.h1; S.ted_h2[c] = L.h2;
-        S.period_avg[c] = L.period_avg; S.period_inst[c] = L.period_inst;
-        S.sq_data[c] = L.sq_data; S.sq_power[c] = L.sq_power; S.sq_phist[c] = L.sq_phist;
-        S.sq_fill[c] = L.sq_fill; S.sq_clock[c] = L.sq_clock; S.sq_symbols[c] = L.sq_symbols;
-        S.eq_word[c] = L.eq_word; S.eq_count[c] = L.eq_count;
-        S.fr_word[c] = L.fr_word; S.fr_count[c] = L.fr_count; S.fr_invalid[c] = L.fr_invalid;
-        S.fr_len[c] = L.fr_len; S.flags[c] = L.flags;
-        S.tk_next[c] = L.tk_next; S.tk_last[c] = L.tk_last; S.wake_fired[c] = L.wake_fired;
-#pragma unroll
-        for (int i = 0; i < NFF; ++i) {
-            S.eq_ffc[i * C + c] = X.ffc[i]; S.eq_ffw[i * C + c] = X.ffw[i];
-            S.eq_snap_ffc[i * C + c] = X.sffc[i]; S.eq_snap_ffw[i * C + c] = X.sffw[i];
-        }
-#pragma unroll
-        for (int i = 0; i < NFB; ++i) {
-            S.eq_fbc[i * C + c] = X.fbc[i]; S.eq_fbw[i * C + c] = X.fbw[i];
-            S.eq_snap_fbc[i * C + c] = X.sfbc[i]; S.eq_snap_fbw[i * C + c] = X.sfbw[i];
-        }
-#pragma unroll 2
-        for (int i = 0; i < kSquelchHist; ++i) { float *row = S.sq_hist + (size_t)i * C; row[c] = hcol[i * LP]; }
-    }
-}
 
 // =====================================================================================
 // Three stages: sample phase (block s) | matched filters + timing loop (block s-1) | symbol
@@ -741,25 +481,19 @@ __global__ __launch_bounds__(3 * kWave, SHARE ? 2 : 1) void demod_pipe3_kernel(P
 // ---------------------------------------------------------------------------------
 // dispatch
 // ---------------------------------------------------------------------------------
-static size_t pipe_lds_bytes()
-{ return ((size_t)kPipeTapFloats + kPipeMailWords + (size_t)(kSquelchHist + 2 * kPipeRing - kPipeB) * kWave) * sizeof(float); }
-
 static size_t pipe3_lds_bytes()
 { return ((size_t)kPipeTapFloats + kP3MailWords + (size_t)(kSquelchHist + 2 * kPipeRing - kPipeB) * kWave) * sizeof(float); }
 
-// The pipelines pay while SIMDs are idle.  Whole groups of 64 channels only.  Three stages:
-// three wavefronts per 64 channels, one workgroup per CU (the register footprint keeps two
-// wavefronts from sharing a SIMD) -> up to 16 384 channels in one round; two stages: two
-// workgroups per CU -> up to 32 768.  Measured: three stages win up to 32 768 channels (two
-// workgroups of three wavefronts per CU), the one-wavefront kernel from 49 152 on.  Returns 0
-// (none), 2 or 3.
+// The pipeline pays while SIMDs are idle.  Whole groups of 64 channels only.  Measured: it wins
+// up to 32 768 channels (two workgroups of three wavefronts per CU), the one-wavefront kernel
+// from 49 152 on.  Returns the number of stages: 0 (not selected) or 3.
 uint32_t pipe_kernel_stages(const Params &P)
 {
     if (P.ntaps != (uint32_t)kPipeNT || P.dc_len != (uint32_t)kPipeDCL || (P.n_channels % kWave) != 0u) return 0;
     if (!((P.eq_nff == 6u && P.eq_nfb == 4u) || (P.eq_nff == 1u && P.eq_nfb == 1u))) return 0;
     if (P.block_len != 16u || max_block_len(P) < (uint32_t)kPipeB) return 0;       // 18-sample blocks
-    if (const char *e = getenv("SAME_PIPE")) { const int v = atoi(e); return v == 3 ? 3u : (v ? 2u : 0u); }
-    return P.n_channels <= 32768u ? 3u : 0u;       // (the two-stage kernel: SAME_PIPE=2)
+    if (const char *e = getenv("SAME_PIPE")) return atoi(e) ? 3u : 0u;       // 0 = off, anything else = on
+    return P.n_channels <= 32768u ? 3u : 0u;
 }
 bool pipe_kernel_selected(const Params &P) { return pipe_kernel_stages(P) != 0u; }
 
@@ -768,19 +502,16 @@ static hipError_t launch_pipe_t(const Params &P, const State &S, const Output &O
                                 const SampleT *x, uint32_t n_blocks, uint64_t counter0, hipStream_t stream)
 {
     const uint32_t grid = P.n_channels / kWave;
-    const bool three = pipe_kernel_stages(P) == 3u;
-    const size_t lds = three ? pipe3_lds_bytes() : pipe_lds_bytes();
+    const size_t lds = pipe3_lds_bytes();
+    const bool share = P.n_channels > 16384u;       // two workgroups per CU: the register-capped build
     const bool med3 = !(P.agc_min == 0.0f && std::signbit(P.agc_min)) && !(P.agc_max == 0.0f && std::signbit(P.agc_max));
 #define SAME_PIPE_LAUNCH(NFF, NFB, M3)                                                                      \
     do {                                                                                                    \
-        if (three && P.n_channels > 16384u)                                                                 \
+        if (share)                                                                                          \
             hipLaunchKernelGGL((demod_pipe3_kernel<NFF, NFB, M3, true, SampleT>), dim3(grid), dim3(3 * kWave), lds, \
                                stream, P, S, O, taps, x, n_blocks, counter0);                                \
-        else if (three)                                                                                     \
-            hipLaunchKernelGGL((demod_pipe3_kernel<NFF, NFB, M3, false, SampleT>), dim3(grid), dim3(3 * kWave), lds, \
-                               stream, P, S, O, taps, x, n_blocks, counter0);                                \
         else                                                                                                \
-            hipLaunchKernelGGL((demod_pipe_kernel<NFF, NFB, M3, SampleT>), dim3(grid), dim3(2 * kWave), lds, \
+            hipLaunchKernelGGL((demod_pipe3_kernel<NFF, NFB, M3, false, SampleT>), dim3(grid), dim3(3 * kWave), lds, \
                                stream, P, S, O, taps, x, n_blocks, counter0);                                \
     } while (0)
     if (P.eq_nff == 6u && P.eq_nfb == 4u) { if (med3) SAME_PIPE_LAUNCH(6, 4, true); else SAME_PIPE_LAUNCH(6, 4, false); }
