@@ -38,7 +38,8 @@ def flags() -> list:
         "-Wall", "-Wno-unused-function", "-Wno-unused-variable",
         "-x", "hip",
     ] + ([f"-DSAME_ABLATE={os.environ['SAME_ABLATE']}"] if os.environ.get("SAME_ABLATE") else []) \
-      + (["-DSAME_PROFILE=1"] if os.environ.get("SAME_PROFILE") else [])
+      + (["-DSAME_PROFILE=1"] if os.environ.get("SAME_PROFILE") else []) \
+      + (["-DSAME_P3_MARKS=1"] if os.environ.get("SAME_P3_MARKS") else [])
 
 
 def is_stale() -> bool:

@@ -41,9 +41,10 @@ struct FastCtx : TickRingGlobal {
     // pl[0] = time of the previous mark, pl[1 + i] = cycles attributed to section i; section 8
     // is the cost of a mark itself (two marks back to back).
     unsigned long long *pl;
+    bool pon = true;
     __device__ __forceinline__ void mark(int i)
     {
-        if (!pl) return;                                   // (the pipeline kernels time whole stages instead)
+        if (!pon) return;
         const unsigned long long t = clock64();
         volatile unsigned long long *p = pl;
         const unsigned long long prev = p[0];

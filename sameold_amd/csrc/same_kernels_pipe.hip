@@ -30,6 +30,20 @@
 
 namespace same {
 
+// Mailbox words in LDS.  The address space is part of the type: a plain `volatile uint32_t *`
+// derived from the LDS base degrades to a generic pointer, and every access becomes a
+// system-scope FLAT instruction followed by s_waitcnt vmcnt(0).
+typedef volatile __attribute__((address_space(3))) uint32_t lds_u32;
+
+// Workgroup barrier for stages that talk through LDS only.  __syncthreads() also waits for the
+// wavefront's outstanding GLOBAL memory operations (vmcnt(0)): stage 1's input prefetch for the
+// next block and stage 3's framer-byte and event stores would be waited for at every step,
+// although no other wavefront ever reads them.  LDS traffic is ordered by lgkmcnt alone.
+__device__ __forceinline__ void lds_barrier()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 constexpr int kPipeNT = 42, kPipeDCL = 16, kPipeB = kBlockMirror, kPipeRing = 5 * kPipeB;
 #ifdef SAME_PROFILE
 constexpr uint32_t kPipeTapFloats = (uint32_t)((kPipeNT * 4 + 20 + 63) / 64 * 64);
@@ -78,7 +92,7 @@ constexpr uint32_t kP3MailWords = 2u * kP3SymWords + 2u * kP3FbWords + kWave;   
 constexpr uint32_t kEvChunk = 64;
 template <int NFF, int NFB>
 struct PipeCtx : FastCtx<NFF, NFB> {
-    volatile uint32_t *chunk;     // LDS: [0] first slot of the current run, [1] slots of it already handed out
+    lds_u32 *chunk;     // LDS: [0] first slot of the current run, [1] slots of it already handed out
     __device__ __forceinline__ void emit(const Params &P, const State &S, const Output &O, uint32_t c, uint32_t kind,
                                          uint64_t sample_counter, uint64_t symbols, uint32_t burst_len)
     {
@@ -294,11 +308,11 @@ __global__ __launch_bounds__(3 * kWave, SHARE ? 2 : 1) void demod_pipe3_kernel(P
     const uint32_t c = blockIdx.x * kWave + lane;            // C % 64 == 0 (host)
     // LDS: taps | mailboxes | squelch history [64][64] | window (logical slots kB .. 2*RING-1)
     float4 *tlds = reinterpret_cast<float4 *>(lds);
-    volatile uint32_t *mail = reinterpret_cast<volatile uint32_t *>(lds + kPipeTapFloats);
-    volatile uint32_t *symbox = mail;                                    // [2][5][64]
-    volatile uint32_t *fbbox = mail + 2u * kP3SymWords;                  // [2][64 + flag]
-    volatile uint32_t *phasebox = fbbox + 2u * kP3FbWords;               // [64]
-    volatile uint32_t *chunkbox = fbbox + kWave + 2u;                    // [2], in the first box's padding
+    lds_u32 *mail = (lds_u32 *)(lds + kPipeTapFloats);
+    lds_u32 *symbox = mail;                                    // [2][5][64]
+    lds_u32 *fbbox = mail + 2u * kP3SymWords;                  // [2][64 + flag]
+    lds_u32 *phasebox = fbbox + 2u * kP3FbWords;               // [64]
+    lds_u32 *chunkbox = fbbox + kWave + 2u;                    // [2], in the first box's padding
     float *hcol = lds + kPipeTapFloats + kP3MailWords + lane;
     float *wring = lds + kPipeTapFloats + kP3MailWords + (kSquelchHist - kB) * LP;   // logical slot 0
     float *wcol = wring + lane;
@@ -315,23 +329,25 @@ __global__ __launch_bounds__(3 * kWave, SHARE ? 2 : 1) void demod_pipe3_kernel(P
             M.rotate();
             if (s < n_blocks) M.block(P, x, s, n_blocks, c, C, wcol);
             P3_LAP(p3_work);
-            __syncthreads();                                             // A
+            lds_barrier();                                             // A
             P3_LAP(p3_wait);
             if (s >= 2u) {
-                const volatile uint32_t *fb = fbbox + (s & 1u) * kP3FbWords;
+                const lds_u32 *fb = fbbox + (s & 1u) * kP3FbWords;
                 if (__builtin_amdgcn_readfirstlane((int)fb[kWave])) {
                     const uint32_t v = fb[lane];
                     const bool new_locked = (v & 2u) != 0u;
                     if ((v & 1u) && new_locked != M.locked)
                         M.replay(P, wcol, (int)(v >> 8), new_locked, s - 1u < n_blocks, s < n_blocks);
-                    __syncthreads();                                     // B: the window is corrected
-                    __syncthreads();                                     // C: stage 2 has redone its block
+                    lds_barrier();                                     // B: the window is corrected
+                    lds_barrier();                                     // C: stage 2 has redone its block
                     P3_LAP(p3_fb);
                 }
             }
         }
+#ifndef SAME_P3_MARKS
         P3_REPORT(0);
-        __syncthreads();                                                 // (stage 2 -> 3: final TED phase)
+#endif
+        lds_barrier();                                                 // (stage 2 -> 3: final TED phase)
         M.store(P, S, c, C, counter1, wcol);
     } else if (role == 1u) {
         // ------------------------------ stage 2: filters + timing loop, block s-1 --------------
@@ -353,7 +369,7 @@ __global__ __launch_bounds__(3 * kWave, SHARE ? 2 : 1) void demod_pipe3_kernel(P
                 until = fk + cstar;
             }
             until -= kB;
-            volatile uint32_t *sb = symbox + (blk & 1u) * kP3SymWords + lane;
+            lds_u32 *sb = symbox + (blk & 1u) * kP3SymWords + lane;
             sb[0] = hdr;
             sb[kWave] = __float_as_uint(zero); sb[2 * kWave] = __float_as_uint(sym);
             sb[3 * kWave] = __float_as_uint(terr); sb[4 * kWave] = __float_as_uint(L.until_next_ted);
@@ -368,10 +384,10 @@ __global__ __launch_bounds__(3 * kWave, SHARE ? 2 : 1) void demod_pipe3_kernel(P
             const bool active = s >= 1u && s <= n_blocks;
             if (active) do_block(s - 1u);
             P3_LAP(p3_work);
-            __syncthreads();                                             // A
+            lds_barrier();                                             // A
             P3_LAP(p3_wait);
             if (s >= 2u) {
-                const volatile uint32_t *fb = fbbox + (s & 1u) * kP3FbWords;
+                const lds_u32 *fb = fbbox + (s & 1u) * kP3FbWords;
                 if (__builtin_amdgcn_readfirstlane((int)fb[kWave])) {
                     const uint32_t v = fb[lane];
                     if (v & 1u) {
@@ -384,17 +400,19 @@ __global__ __launch_bounds__(3 * kWave, SHARE ? 2 : 1) void demod_pipe3_kernel(P
                             L.period_avg = P.samples_per_ted; L.period_inst = P.samples_per_ted;
                         }
                     }
-                    __syncthreads();                                     // B: stage 1 has corrected the window
+                    lds_barrier();                                     // B: stage 1 has corrected the window
                     if ((v & 1u) && active) do_block(s - 1u);
-                    __syncthreads();                                     // C
+                    lds_barrier();                                     // C
                     P3_LAP(p3_fb);
                 }
             }
             if (active) { wpos += kB; if (wpos == (uint32_t)RING) wpos = 0; }
         }
+#ifndef SAME_P3_MARKS
         P3_REPORT(1);
+#endif
         phasebox[lane] = L.flags & F_TED_PHASE;
-        __syncthreads();                                                 // stage 3 merges the phase bit
+        lds_barrier();                                                 // stage 3 merges the phase bit
         L.ted_clock = (uint32_t)(cstar - until - 1);
         S.until_next_ted[c] = L.until_next_ted; S.ted_clock[c] = L.ted_clock;
         S.ted_h0[c] = L.h0; S.ted_h1[c] = L.h1; S.ted_h2[c] = L.h2;
@@ -409,7 +427,16 @@ __global__ __launch_bounds__(3 * kWave, SHARE ? 2 : 1) void demod_pipe3_kernel(P
         chunkbox[0] = 0u; chunkbox[1] = kEvChunk;       // nothing reserved yet
         X.hist = hcol;
 #ifdef SAME_PROFILE
-        X.pl = nullptr;                                    // no per-section marks in the pipelines
+        // per-section marks of the symbol path (SAME_P3_MARKS build): words behind the taps, reported
+        // through g_same_prof_pipe[0..5] instead of stage 1's and stage 2's timers
+        X.pl = reinterpret_cast<unsigned long long *>(lds + NT * 4);
+#ifdef SAME_P3_MARKS
+        X.pon = true;
+        for (int i = 0; i < 10; ++i) X.pl[i] = 0;
+        X.pl[0] = clock64();
+#else
+        X.pon = false;
+#endif
 #endif
 #pragma unroll
         for (int i = 0; i < NFF; ++i) {
@@ -428,7 +455,7 @@ __global__ __launch_bounds__(3 * kWave, SHARE ? 2 : 1) void demod_pipe3_kernel(P
             bool any = false;
             if (s >= 2u) {
                 const uint32_t blk = s - 2u;
-                const volatile uint32_t *sb = symbox + (blk & 1u) * kP3SymWords + lane;
+                const lds_u32 *sb = symbox + (blk & 1u) * kP3SymWords + lane;
                 const uint32_t hdr = sb[0];
                 uint32_t fbv = 0;
                 if (hdr & 1u) {
@@ -443,19 +470,25 @@ __global__ __launch_bounds__(3 * kWave, SHARE ? 2 : 1) void demod_pipe3_kernel(P
                         fbv = 1u | ((after & F_AGC_LOCKED) ? 2u : 0u) | ((after & F_BW_LOCKED) ? 4u : 0u) |
                               (L.ended ? 8u : 0u) | (fk << 8);
                 }
-                volatile uint32_t *fb = fbbox + (s & 1u) * kP3FbWords;
+                lds_u32 *fb = fbbox + (s & 1u) * kP3FbWords;
                 fb[lane] = fbv;
                 any = __builtin_amdgcn_ballot_w64(fbv != 0u) != 0ull;
                 if (lane == 0u) fb[kWave] = any ? 1u : 0u;
             }
             P3_LAP(p3_work);
-            __syncthreads();                                             // A
+            lds_barrier();                                             // A
             P3_LAP(p3_wait);
-            if (any) { __syncthreads(); __syncthreads(); P3_LAP(p3_fb); }   // B, C: the earlier stages catch up
+            if (any) { lds_barrier(); lds_barrier(); P3_LAP(p3_fb); }   // B, C: the earlier stages catch up
         }
+#ifndef SAME_P3_MARKS
         P3_REPORT(2);
+#endif
+#if defined(SAME_PROFILE) && defined(SAME_P3_MARKS)
+        if (blockIdx.x == 0 && lane == 0)
+            for (int i = 0; i < 6; ++i) atomicAdd(&g_same_prof_pipe[i], X.pl[1 + 2 + i] - (i == 0 ? 0ull : 0ull));
+#endif
         X.retire(O, lane);
-        __syncthreads();                                                 // stage 2's final TED phase
+        lds_barrier();                                                 // stage 2's final TED phase
         L.flags = (L.flags & ~F_TED_PHASE) | (phasebox[lane] & F_TED_PHASE);
         S.sq_data[c] = L.sq_data; S.sq_power[c] = L.sq_power; S.sq_phist[c] = L.sq_phist;
         S.sq_fill[c] = L.sq_fill; S.sq_clock[c] = L.sq_clock; S.sq_symbols[c] = L.sq_symbols;

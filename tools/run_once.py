@@ -40,6 +40,10 @@ if hasattr(rx._L, "same_debug_profile_pipe") and "pipe3" in rx.kernel_name():
     buf = (ctypes.c_ulonglong * 9)()
     rx._L.same_debug_profile_pipe(buf, 1)
     nstep = reps * (T // 18 + 2)
-    for r, name in enumerate(["stage 1 (sample phase)", "stage 2 (filters + timing)", "stage 3 (symbol path)"]):
+    if os.environ.get("SAME_P3_MARKS"):
+        for name, v in zip(["other (mailbox, barrier, idle)", "squelch", "equalizer step", "byte/framer", "events+wake-ups", "-"], buf):
+            print(f"  stage 3 {name:32s} {v/nstep:8.1f} clk/step (each mark costs ~340 clk, charged to the section after it)")
+    else:
+      for r, name in enumerate(["stage 1 (sample phase)", "stage 2 (filters + timing)", "stage 3 (symbol path)"]):
         w, b, f = buf[3 * r], buf[3 * r + 1], buf[3 * r + 2]
         print(f"  {name:28s} work {w/nstep:8.1f}  barrier wait {b/nstep:8.1f}  feedback {f/nstep:8.1f}  clk/step (total {(w+b+f)/nstep:8.1f})")
