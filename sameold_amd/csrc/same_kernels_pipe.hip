@@ -115,10 +115,7 @@ struct PipeCtx : FastCtx<NFF, NFB> {
             const uint32_t b = atomicAdd(O.n_events + 1, 1u);
             if (b < O.burst_cap) {
                 slot = b;
-                const uint4 *src = reinterpret_cast<const uint4 *>(S.fr_msg + (size_t)c * kBurstCap);
-                uint4 *dst = reinterpret_cast<uint4 *>(O.bursts + (size_t)b * kBurstCap);
-#pragma unroll
-                for (int i = 0; i < kBurstCap / 16; ++i) dst[i] = src[i];
+                copy_burst_row(O.bursts + (size_t)b * kBurstCap, S.fr_msg + (size_t)c * kBurstCap);
             } else {
                 atomicOr(O.n_events + 2, 2u);
             }
