@@ -39,7 +39,8 @@ def flags() -> list:
         "-x", "hip",
     ] + ([f"-DSAME_ABLATE={os.environ['SAME_ABLATE']}"] if os.environ.get("SAME_ABLATE") else []) \
       + (["-DSAME_PROFILE=1"] if os.environ.get("SAME_PROFILE") else []) \
-      + (["-DSAME_P3_MARKS=1"] if os.environ.get("SAME_P3_MARKS") else [])
+      + (["-DSAME_P3_MARKS=1"] if os.environ.get("SAME_P3_MARKS") else []) \
+      + (["-DSAME_P1_SPLIT=1"] if os.environ.get("SAME_P1_SPLIT") else [])
 
 
 def is_stale() -> bool:

@@ -207,11 +207,11 @@ struct SampleStage {
         }
     }
 
-    // DC blocker (rx/dcblock.rs:45-49, 104-108), AGC and window push of block `blk` into slot 0
-    __device__ __forceinline__ void block(const Params &P, const SampleT *__restrict__ x, uint32_t blk,
-                                          uint32_t n_blocks, uint32_t c, uint32_t C, float *wcol)
+    float xs[kB];                        // inputs of the block being computed
+    // take the prefetched inputs of block `blk` and start fetching block blk + 1
+    __device__ __forceinline__ void fetch(const SampleT *__restrict__ x, uint32_t blk, uint32_t n_blocks,
+                                          uint32_t c, uint32_t C)
     {
-        float xs[kB];
 #pragma unroll
         for (int k = 0; k < kB; ++k) xs[k] = xn[k];
         if (blk + 1 < n_blocks) {
@@ -219,6 +219,10 @@ struct SampleStage {
 #pragma unroll
             for (int k = 0; k < kB; ++k) { const SampleT *row = xb + (size_t)k * C; xn[k] = (float)row[c]; }
         }
+    }
+    // DC blocker (rx/dcblock.rs:45-49, 104-108), AGC and window push of the fetched block into slot 0
+    __device__ __forceinline__ void block(const Params &P, float *wcol)
+    {
         float mnew[kB];
         auto xw = [&](int i) { return i < DCL ? xp[i < DCL ? i : 0] : xs[i >= DCL ? i - DCL : 0]; };
 #pragma unroll
@@ -324,7 +328,14 @@ __global__ __launch_bounds__(3 * kWave, SHARE ? 2 : 1) void demod_pipe3_kernel(P
         P3_T0();
         for (uint32_t s = 0; s < n_steps; ++s) {
             M.rotate();
-            if (s < n_blocks) M.block(P, x, s, n_blocks, c, C, wcol);
+            if (s < n_blocks) {
+                M.fetch(x, s, n_blocks, c, C);
+#ifdef SAME_P1_SPLIT
+                asm volatile("s_waitcnt vmcnt(18)" ::: "memory");    // profiling: the block's inputs have arrived
+                P3_LAP(p3_fb);                                       // (reported in the "feedback" column)
+#endif
+                M.block(P, wcol);
+            }
             P3_LAP(p3_work);
             lds_barrier();                                             // A
             P3_LAP(p3_wait);
