@@ -71,6 +71,11 @@ struct same_batch {
         uint32_t *h_counters = nullptr;  // pinned, host-mapped
         uint32_t *h_counters_dev = nullptr;  // device view of h_counters
         hipEvent_t ev_start = nullptr, ev_stop = nullptr, ev_done = nullptr;
+        // pinned landing buffers of the read-back, grown on demand.  A copy into pageable memory
+        // is staged by the runtime (blit kernel + host memcpy per chunk) and, queued beside the
+        // next launch, holds that launch up for as long as the host is busy.
+        void *h_events = nullptr; size_t h_events_bytes = 0;
+        void *h_bursts = nullptr; size_t h_bursts_bytes = 0;
         bool in_flight = false;
         uint64_t seq = 0;                // launch order
     } slot[2];
@@ -91,7 +96,7 @@ struct same_batch {
     size_t queue_head = 0;
     // transport layer, one assembler per channel (unless SAME_BATCH_LINK_ONLY)
     std::vector<same::Transport> transport;
-    std::vector<uint64_t> h_wake;    // host mirror of State::wake_sample
+    uint64_t *h_wake = nullptr;      // host mirror of State::wake_sample (pinned, n_channels words, zero = unarmed)
 };
 
 namespace {
@@ -205,10 +210,21 @@ int harvest_slot(same_batch *rx, same_batch::Slot &sl)
                      sl.h_counters[1], sl.event_cap, sl.burst_cap);
     const uint32_t n_bursts = std::min(sl.h_counters[1], sl.burst_cap);
     if (sl.h_counters[2]) rx->overflowed = true;
-    std::vector<same::DevEvent> evs(n_events);
-    std::vector<uint8_t> bursts((size_t)n_bursts * same::kBurstCap);
-    if (n_events) HIP_TRY(hipMemcpyAsync(evs.data(), sl.d_events, (size_t)n_events * sizeof(same::DevEvent), hipMemcpyDeviceToHost, rx->copy_stream));
-    if (n_bursts) HIP_TRY(hipMemcpyAsync(bursts.data(), sl.d_bursts, bursts.size(), hipMemcpyDeviceToHost, rx->copy_stream));
+    const size_t ev_bytes = (size_t)n_events * sizeof(same::DevEvent), bu_bytes = (size_t)n_bursts * same::kBurstCap;
+    auto grow = [](void **p, size_t *have, size_t need) -> hipError_t {
+        if (need <= *have) return hipSuccess;
+        if (*p) { (void)hipHostFree(*p); *p = nullptr; *have = 0; }
+        const size_t want = need + need / 2 + 4096;
+        hipError_t e = hipHostMalloc(p, want, hipHostMallocDefault);
+        if (e == hipSuccess) *have = want;
+        return e;
+    };
+    HIP_TRY(grow(&sl.h_events, &sl.h_events_bytes, ev_bytes));
+    HIP_TRY(grow(&sl.h_bursts, &sl.h_bursts_bytes, bu_bytes));
+    const same::DevEvent *evs = static_cast<const same::DevEvent *>(sl.h_events);
+    const uint8_t *bursts = static_cast<const uint8_t *>(sl.h_bursts);
+    if (n_events) HIP_TRY(hipMemcpyAsync(sl.h_events, sl.d_events, ev_bytes, hipMemcpyDeviceToHost, rx->copy_stream));
+    if (n_bursts) HIP_TRY(hipMemcpyAsync(sl.h_bursts, sl.d_bursts, bu_bytes, hipMemcpyDeviceToHost, rx->copy_stream));
     if (n_events || n_bursts) HIP_TRY(hipStreamSynchronize(rx->copy_stream));
     auto t_copied = std::chrono::steady_clock::now();
     // Per channel the device emits in time order (a lane takes its log slots one after the
@@ -217,8 +233,8 @@ int harvest_slot(same_batch *rx, same_batch::Slot &sl)
     const uint32_t n_ch = rx->P.n_channels;
     std::vector<uint32_t> first(n_ch + 1u, 0u);
     // (slots a wavefront reserved but did not use carry kDevEventNone and are dropped here)
-    for (const same::DevEvent &d : evs)
-        if (d.kind != same::kDevEventNone) first[std::min(d.channel, n_ch - 1u) + 1u]++;
+    for (uint32_t i = 0; i < n_events; ++i)
+        if (evs[i].kind != same::kDevEventNone) first[std::min(evs[i].channel, n_ch - 1u) + 1u]++;
     for (uint32_t c = 0; c < n_ch; ++c) first[c + 1u] += first[c];
     const uint32_t n_real = first[n_ch];
     std::vector<uint32_t> order(n_real);
@@ -245,7 +261,7 @@ int harvest_slot(same_batch *rx, same_batch::Slot &sl)
             if (d.kind == SAME_LINK_BURST) {
                 ev.len = d.burst_len;
                 const uint32_t n = std::min<uint32_t>(d.burst_len, SAME_EVENT_MAX_BYTES);
-                if (d.burst_slot < n_bursts) std::memcpy(ev.bytes, bursts.data() + (size_t)d.burst_slot * same::kBurstCap, n);
+                if (d.burst_slot < n_bursts) std::memcpy(ev.bytes, bursts + (size_t)d.burst_slot * same::kBurstCap, n);
                 else ev.len = 0;   // pool overflow: the burst bytes were lost (SAME_EOVERFLOW is reported)
             }
             if (d.kind <= SAME_LINK_BURST) part.out.push_back(ev);
@@ -298,11 +314,14 @@ int harvest_slot(same_batch *rx, same_batch::Slot &sl)
     if (!rearm.empty()) {
         // one upload of the whole wake table (a device word the kernel already cleared is
         // re-armed at worst to an instant in the past: one harmless extra poll)
-        if (rx->h_wake.size() != rx->P.n_channels) rx->h_wake.assign(rx->P.n_channels, 0);
+        if (!rx->h_wake) {
+            HIP_TRY(hipHostMalloc((void **)&rx->h_wake, (size_t)rx->P.n_channels * sizeof(uint64_t), hipHostMallocDefault));
+            std::memset(rx->h_wake, 0, (size_t)rx->P.n_channels * sizeof(uint64_t));
+        }
         for (uint32_t c : rearm) rx->h_wake[c] = rx->transport[c].force_eom_at();
         // the kernels only read this table (it is host-owned), so it may be updated while a
         // later launch runs; launches are capped at 45 s, two launches < the 135 s timeout
-        HIP_TRY(hipMemcpyAsync(rx->S.wake_sample, rx->h_wake.data(), rx->h_wake.size() * sizeof(uint64_t), hipMemcpyHostToDevice, rx->copy_stream));
+        HIP_TRY(hipMemcpyAsync(rx->S.wake_sample, rx->h_wake, (size_t)rx->P.n_channels * sizeof(uint64_t), hipMemcpyHostToDevice, rx->copy_stream));
         HIP_TRY(hipStreamSynchronize(rx->copy_stream));
     }
     if (dbg) {
@@ -531,11 +550,14 @@ void same_batch_free(same_batch *rx)
         if (sl.d_bursts) (void)hipFree(sl.d_bursts);
         if (sl.d_counters) (void)hipFree(sl.d_counters);
         if (sl.h_counters) (void)hipHostFree(sl.h_counters);
+        if (sl.h_events) (void)hipHostFree(sl.h_events);
+        if (sl.h_bursts) (void)hipHostFree(sl.h_bursts);
         if (sl.ev_start) (void)hipEventDestroy(sl.ev_start);
         if (sl.ev_stop) (void)hipEventDestroy(sl.ev_stop);
         if (sl.ev_done) (void)hipEventDestroy(sl.ev_done);
     }
     if (rx->copy_stream) (void)hipStreamDestroy(rx->copy_stream);
+    if (rx->h_wake) (void)hipHostFree(rx->h_wake);
     if (rx->d_stage) (void)hipFree(rx->d_stage);
     if (rx->d_stage2) (void)hipFree(rx->d_stage2);
     if (rx->own_stream) (void)hipStreamDestroy(rx->own_stream);
@@ -554,7 +576,7 @@ int same_batch_reset(same_batch *rx)
     rx->counter = 0;
     rx->queue.clear(); rx->queue_head = 0;   // event_queue.clear() receiver.rs:194
     for (auto &t : rx->transport) t.reset();
-    rx->h_wake.clear();
+    if (rx->h_wake) std::memset(rx->h_wake, 0, (size_t)rx->P.n_channels * sizeof(uint64_t));
     rx->overflowed = false;
     return SAME_OK;
 }
