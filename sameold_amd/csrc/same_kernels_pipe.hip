@@ -380,7 +380,9 @@ __global__ __launch_bounds__(3 * kWave, SHARE ? 2 : 1) void demod_pipe3_kernel(P
             lds_u32 *sb = symbox + (blk & 1u) * kP3SymWords + lane;
             sb[0] = hdr;
             sb[kWave] = __float_as_uint(zero); sb[2 * kWave] = __float_as_uint(sym);
-            sb[3 * kWave] = __float_as_uint(terr); sb[4 * kWave] = __float_as_uint(L.until_next_ted);
+            if (P.trace_cap) {                         // only the symbol trace records these two
+                sb[3 * kWave] = __float_as_uint(terr); sb[4 * kWave] = __float_as_uint(L.until_next_ted);
+            }
         };
         P3_T0();
         for (uint32_t s = 0; s < n_steps; ++s) {
@@ -469,7 +471,8 @@ __global__ __launch_bounds__(3 * kWave, SHARE ? 2 : 1) void demod_pipe3_kernel(P
                 if (hdr & 1u) {
                     const uint32_t fk = hdr >> 8;
                     const float zero = __uint_as_float(sb[kWave]), sym = __uint_as_float(sb[2 * kWave]);
-                    const float terr = __uint_as_float(sb[3 * kWave]), unt = __uint_as_float(sb[4 * kWave]);
+                    float terr = 0.0f, unt = 0.0f;
+                    if (P.trace_cap) { terr = __uint_as_float(sb[3 * kWave]); unt = __uint_as_float(sb[4 * kWave]); }
                     const uint32_t before = L.flags & (F_AGC_LOCKED | F_BW_LOCKED);
                     L.ended = 0u;
                     ted_symbol(P, L, S, O, X, c, zero, sym, terr, unt, counter0 + (uint64_t)blk * kB + fk + 1u);
