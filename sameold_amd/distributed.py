@@ -64,6 +64,21 @@ def pack_burst_events(events: np.ndarray, first_channel: int = 0) -> np.ndarray:
     return out
 
 
+_pinned = {}
+
+
+def _pinned_bytes(tag: str, n_rows: int) -> torch.Tensor:
+    """A cached pinned host tensor of at least [n_rows, RECORD_BYTES] uint8.  Transfers between
+    the device and pageable host memory are staged by the runtime and can hold up kernels queued
+    beside them; pinned memory moves in one DMA."""
+    t = _pinned.get(tag)
+    if t is None or t.shape[0] < n_rows:
+        rows = max(n_rows + n_rows // 2, 1024)
+        t = torch.empty((rows, RECORD_BYTES), dtype=torch.uint8, pin_memory=True)
+        _pinned[tag] = t
+    return t
+
+
 def gather_records(recs: np.ndarray, device: torch.device, dst: int = 0) -> Optional[np.ndarray]:
     """Gather packed records ([n, RECORD_BYTES] uint8 per rank) on rank `dst`: one all_gather of
     the counts, one gather of the records padded to the largest count.  Returns the
@@ -71,6 +86,7 @@ def gather_records(recs: np.ndarray, device: torch.device, dst: int = 0) -> Opti
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return recs
     world, rank = dist.get_world_size(), dist.get_rank()
+    on_gpu = torch.device(device).type == "cuda"
     n = torch.tensor([len(recs)], dtype=torch.int64, device=device)
     counts = [torch.zeros_like(n) for _ in range(world)]
     dist.all_gather(counts, n)
@@ -78,12 +94,27 @@ def gather_records(recs: np.ndarray, device: torch.device, dst: int = 0) -> Opti
     m = max(max(counts), 1)
     buf = torch.zeros((m, RECORD_BYTES), dtype=torch.uint8, device=device)
     if len(recs):
-        buf[: len(recs)] = torch.from_numpy(np.ascontiguousarray(recs)).to(device)
+        src = torch.from_numpy(np.ascontiguousarray(recs))
+        if on_gpu:
+            stage = _pinned_bytes("send", len(recs))[: len(recs)]
+            stage.copy_(src)
+            buf[: len(recs)].copy_(stage, non_blocking=True)
+        else:
+            buf[: len(recs)] = src
     out = [torch.zeros_like(buf) for _ in range(world)] if rank == dst else None
     dist.gather(buf, out, dst=dst)
     if rank != dst:
         return None
-    return np.concatenate([out[r][: counts[r]].cpu().numpy() for r in range(world)], axis=0)
+    total = sum(counts)
+    if on_gpu:
+        land = _pinned_bytes("recv", total)
+        at = 0
+        for r in range(world):
+            land[at: at + counts[r]].copy_(out[r][: counts[r]], non_blocking=True)
+            at += counts[r]
+        torch.cuda.current_stream(device).synchronize()
+        return land[:total].numpy()            # a view of the cached landing buffer: valid until the next call
+    return np.concatenate([out[r][: counts[r]].numpy() for r in range(world)], axis=0)
 
 
 def gather_bursts(bursts: Sequence[Tuple[int, int, bytes]], device: torch.device,
