@@ -22,6 +22,7 @@
 
 #include <cmath>
 #include <cstdlib>
+#include <type_traits>
 
 #include "same_dev_common.h"
 #include "same_device.h"
@@ -146,14 +147,16 @@ struct SampleStage {
     float sum0, sum1, gain;
     bool locked;                         // this stage's belief of the AGC lock
     float xp[DCL], mp[DCL];              // the last DCL inputs / first-stage averages, oldest first
-    float xn[kB];                        // prefetched inputs of the next block
+    float xn[2][kB];                     // prefetched inputs of the next two blocks: block b waits in xn[b & 1]
+                                         // (a step is shorter than an HBM round trip with a TLB miss, so
+                                         // the prefetch distance is two steps)
     float ys[3][kB];                     // DC-blocker outputs: [0] newest block ... [2] two blocks back
     float g0[3];                         // AGC gain each of them started with
     uint32_t wp[3];                      // their ring positions
     uint32_t wnext;                      // ring position of the block computed next
 
     __device__ __forceinline__ void load(const Params &P, const State &S, const SampleT *__restrict__ x,
-                                         uint32_t c, uint32_t C, uint64_t counter0, float *wcol)
+                                         uint32_t c, uint32_t C, uint64_t counter0, float *wcol, uint32_t n_blocks)
     {
         const uint32_t G = P.win_ring;
 #pragma unroll 2
@@ -175,7 +178,12 @@ struct SampleStage {
             mp[k] = r1[c];
         }
 #pragma unroll
-        for (int k = 0; k < kB; ++k) { const SampleT *row = x + (size_t)k * C; xn[k] = (float)row[c]; }
+        for (int k = 0; k < kB; ++k) { const SampleT *row = x + (size_t)k * C; xn[0][k] = (float)row[c]; }
+        if (n_blocks > 1u) {
+            const SampleT *xb = x + (size_t)kB * C;
+#pragma unroll
+            for (int k = 0; k < kB; ++k) { const SampleT *row = xb + (size_t)k * C; xn[1][k] = (float)row[c]; }
+        }
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
             g0[j] = gain; wp[j] = 0;
@@ -208,16 +216,18 @@ struct SampleStage {
     }
 
     float xs[kB];                        // inputs of the block being computed
-    // take the prefetched inputs of block `blk` and start fetching block blk + 1
+    // take the prefetched inputs of block `blk` (BUF = blk & 1) and start fetching block blk + 2 into
+    // the registers they leave
+    template <int BUF>
     __device__ __forceinline__ void fetch(const SampleT *__restrict__ x, uint32_t blk, uint32_t n_blocks,
                                           uint32_t c, uint32_t C)
     {
 #pragma unroll
-        for (int k = 0; k < kB; ++k) xs[k] = xn[k];
-        if (blk + 1 < n_blocks) {
-            const SampleT *xb = x + ((size_t)(blk + 1) * kB) * C;      // wave-uniform
+        for (int k = 0; k < kB; ++k) xs[k] = xn[BUF][k];
+        if (blk + 2 < n_blocks) {
+            const SampleT *xb = x + ((size_t)(blk + 2) * kB) * C;      // wave-uniform
 #pragma unroll
-            for (int k = 0; k < kB; ++k) { const SampleT *row = xb + (size_t)k * C; xn[k] = (float)row[c]; }
+            for (int k = 0; k < kB; ++k) { const SampleT *row = xb + (size_t)k * C; xn[BUF][k] = (float)row[c]; }
         }
     }
     // DC blocker (rx/dcblock.rs:45-49, 104-108), AGC and window push of the fetched block into slot 0
@@ -324,12 +334,13 @@ __global__ __launch_bounds__(3 * kWave, SHARE ? 2 : 1) void demod_pipe3_kernel(P
         // ------------------------------ stage 1: sample phase, block s -------------------------
         for (uint32_t i = lane; i < (uint32_t)NT; i += kWave) tlds[i] = taps[i];
         SampleStage<MED3, SampleT> M;
-        M.load(P, S, x, c, C, counter0, wcol);
+        M.load(P, S, x, c, C, counter0, wcol, n_blocks);
         P3_T0();
-        for (uint32_t s = 0; s < n_steps; ++s) {
+        // one step; BUF = s & 1 names the prefetch registers statically, so the loop runs two steps a turn
+        auto step = [&](uint32_t s, auto buf) {
             M.rotate();
             if (s < n_blocks) {
-                M.fetch(x, s, n_blocks, c, C);
+                M.template fetch<decltype(buf)::value>(x, s, n_blocks, c, C);
 #ifdef SAME_P1_SPLIT
                 asm volatile("s_waitcnt vmcnt(18)" ::: "memory");    // profiling: the block's inputs have arrived
                 P3_LAP(p3_fb);                                       // (reported in the "feedback" column)
@@ -351,6 +362,10 @@ __global__ __launch_bounds__(3 * kWave, SHARE ? 2 : 1) void demod_pipe3_kernel(P
                     P3_LAP(p3_fb);
                 }
             }
+        };
+        for (uint32_t s = 0; s < n_steps; s += 2u) {
+            step(s, std::integral_constant<int, 0>{});
+            if (s + 1u < n_steps) step(s + 1u, std::integral_constant<int, 1>{});
         }
 #ifndef SAME_P3_MARKS
         P3_REPORT(0);
