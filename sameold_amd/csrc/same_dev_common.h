@@ -689,12 +689,14 @@ __device__ __forceinline__ bool ted_timing(const Params &P, Lane &L, float sa_lo
     return have;
 }
 
-// The symbol half: trace, link layer (squelch, equalizer, framer), link events, wake-ups.
-// `until_next_ted` is only recorded in the trace.
+// The symbol half, in two parts so that a pipelined kernel can run them on different wavefronts.
+// symbol_link: trace and link layer (squelch, equalizer, framer); returns the LinkState kind and
+// whether an event is due (receiver.rs:246-253: report on change; a Burst always differs from its
+// predecessor).  `until_next_ted` is only recorded in the trace.
 template <typename Ctx>
-__device__ __forceinline__ void ted_symbol(const Params &P, Lane &L, const State &S, const Output &O,
-                                           Ctx &X, uint32_t c, float zero, float sym, float terr,
-                                           float until_next_ted, uint64_t counter)
+__device__ __forceinline__ uint32_t symbol_link(const Params &P, Lane &L, const State &S, Ctx &X, uint32_t c,
+                                                float zero, float sym, float terr, float until_next_ted,
+                                                uint64_t counter, uint32_t *burst_len, bool *emit)
 {
     if (P.trace_cap) {
         uint32_t n = S.trace_n[c];
@@ -705,21 +707,26 @@ __device__ __forceinline__ void ted_symbol(const Params &P, Lane &L, const State
         }
         S.trace_n[c] = n + 1;
     }
-
-    uint32_t burst_len = 0;
     X.mark(2);
 #if defined(SAME_ABLATE) && SAME_ABLATE == 1
     uint32_t link = (L.flags & F_LINK_MASK) >> F_LINK_SHIFT; L.sq_symbols += 1; L.sq_power += sym + zero;   // ablation build: no symbol path
 #else
-    uint32_t link = rx_symbol(P, L, S, X, c, zero, sym, &burst_len);
+    uint32_t link = rx_symbol(P, L, S, X, c, zero, sym, burst_len);
 #endif
     X.mark(5);
-    // receiver.rs:246-253: report on change (a Burst always differs from its predecessor)
-    uint32_t last = (L.flags & F_LINK_MASK) >> F_LINK_SHIFT;
-    if (link != last || link == 3u) {
-        L.flags = (L.flags & ~F_LINK_MASK) | (link << F_LINK_SHIFT);
-        X.emit(P, S, O, c, link, counter, L.sq_symbols, burst_len);
-    }
+    const uint32_t last = (L.flags & F_LINK_MASK) >> F_LINK_SHIFT;
+    *emit = link != last || link == 3u;
+    if (*emit) L.flags = (L.flags & ~F_LINK_MASK) | (link << F_LINK_SHIFT);
+    return link;
+}
+
+// symbol_io: the link event and the transport wake-ups of one symbol.  Uses of L: sq_symbols (the
+// count after this symbol), tk_next, tk_last, wake_sample, wake_fired and the F_TICK_AGAIN flag.
+template <typename Ctx>
+__device__ __forceinline__ void symbol_io(const Params &P, Lane &L, const State &S, const Output &O, Ctx &X,
+                                          uint32_t c, uint32_t link, bool emit, uint64_t counter, uint32_t burst_len)
+{
+    if (emit) X.emit(P, S, O, c, link, counter, L.sq_symbols, burst_len);
     if (P.ticks) {
         if (link == 3u) {
             tick_on_burst(P, L, S, X, c);
@@ -730,6 +737,17 @@ __device__ __forceinline__ void ted_symbol(const Params &P, Lane &L, const State
         }
     }
     X.mark(6);
+}
+
+template <typename Ctx>
+__device__ __forceinline__ void ted_symbol(const Params &P, Lane &L, const State &S, const Output &O,
+                                           Ctx &X, uint32_t c, float zero, float sym, float terr,
+                                           float until_next_ted, uint64_t counter)
+{
+    uint32_t burst_len = 0;
+    bool emit = false;
+    const uint32_t link = symbol_link(P, L, S, X, c, zero, sym, terr, until_next_ted, counter, &burst_len, &emit);
+    symbol_io(P, L, S, O, X, c, link, emit, counter, burst_len);
 }
 
 template <typename Ctx>

@@ -53,8 +53,10 @@ constexpr uint32_t kPipeTapFloats = (uint32_t)((kPipeNT * 4 + 63) / 64 * 64);
 #endif
 
 // =====================================================================================
-// Three stages: sample phase (block s) | matched filters + timing loop (block s-1) | symbol
-// path (block s-2), one wavefront each.
+// Four stages, one wavefront each: sample phase (block s) | matched filters + timing loop (block
+// s-1) | symbol path (block s-2) | link events and transport wake-ups (block s-3).  The last one
+// has no feedback into the others: it takes the global-memory round trips (event-log slots, the
+// deadline ring in HBM) off the stage that is critical.
 //
 // Stage 2 hands every completed symbol (its two soft samples, the timing error and the sample
 // index) to stage 3 through an LDS mailbox.  Stage 3's feedback is rare (about three symbols
@@ -82,18 +84,29 @@ __device__ unsigned long long g_same_prof_pipe[9];
 
 constexpr uint32_t kP3SymWords = 5u * kWave;              // per parity: header, zero, sym, terr, until
 constexpr uint32_t kP3FbWords = kWave + 32u;              // per parity: one word per lane + the any-flag
-constexpr uint32_t kP3MailWords = 2u * kP3SymWords + 2u * kP3FbWords + kWave;   // + stage 2's final TED phase
-// (the log-chunk words live in the padding of the first feedback box: 62 208 B of LDS in all,
-// and two workgroups share a CU -- at 62 464 B they no longer do)
+constexpr uint32_t kP3IoWords = 3u * kWave;               // per parity: symbol word, burst-pool slot, burst length
+constexpr uint32_t kP3MailWords = 2u * kP3SymWords + 2u * kP3FbWords + 2u * kP3IoWords +
+                                  2u * kWave;              // + the final TED-phase and wake-up flag bits
+// (the log-chunk words live in the padding of the first feedback box)
 
-// Stage 3's event log access.  emit_event takes a slot with a returning atomic per event --
-// an L2 round trip (~1 us) on the critical path of whichever stage emits.  Here the
-// wavefront reserves runs of 64 slots (one atomic per run) and hands them out with a ballot;
-// slots of a run that stay unused are marked kDevEventNone for the host to skip.
+// Stage 3 keeps the framer rows; a finished burst is copied into the pool here, its slot travels on.
+__device__ __forceinline__ uint32_t burst_to_pool(const State &S, const Output &O, uint32_t c)
+{
+    const uint32_t b = atomicAdd(O.n_events + 1, 1u);
+    if (b >= O.burst_cap) { atomicOr(O.n_events + 2, 2u); return 0xffffffffu; }
+    copy_burst_row(O.bursts + (size_t)b * kBurstCap, S.fr_msg + (size_t)c * kBurstCap);
+    return b;
+}
+
+// Stage 4's context: the event log.  emit_event takes a slot with a returning atomic per event --
+// an L2 round trip on the critical path of whichever stage emits.  Here the wavefront reserves
+// runs of 64 slots (one atomic per run) and hands them out with a ballot; slots of a run that stay
+// unused are marked kDevEventNone for the host to skip.  The deadline ring stays in HBM.
 constexpr uint32_t kEvChunk = 64;
-template <int NFF, int NFB>
-struct PipeCtx : FastCtx<NFF, NFB> {
-    lds_u32 *chunk;     // LDS: [0] first slot of the current run, [1] slots of it already handed out
+struct IoCtx : TickRingGlobal {
+    lds_u32 *chunk;            // LDS: [0] first slot of the current run, [1] slots of it already handed out
+    uint32_t pending_slot;     // burst-pool slot of the Burst event about to be emitted
+    __device__ __forceinline__ void mark(int) const {}
     __device__ __forceinline__ void emit(const Params &P, const State &S, const Output &O, uint32_t c, uint32_t kind,
                                          uint64_t sample_counter, uint64_t symbols, uint32_t burst_len)
     {
@@ -111,20 +124,11 @@ struct PipeCtx : FastCtx<NFF, NFB> {
         }
         const uint32_t e = base + used + rank;
         chunk[0] = base; chunk[1] = used + n;
-        uint32_t slot = 0xffffffffu;
-        if (kind == 3u) {  // SAME_LINK_BURST: copy the framer buffer row into the pool
-            const uint32_t b = atomicAdd(O.n_events + 1, 1u);
-            if (b < O.burst_cap) {
-                slot = b;
-                copy_burst_row(O.bursts + (size_t)b * kBurstCap, S.fr_msg + (size_t)c * kBurstCap);
-            } else {
-                atomicOr(O.n_events + 2, 2u);
-            }
-        }
         if (e < O.event_cap) {
             DevEvent ev;
             ev.channel = c; ev.kind = kind; ev.sample_counter = sample_counter;
-            ev.symbol_count = symbols; ev.burst_len = burst_len; ev.burst_slot = slot;
+            ev.symbol_count = symbols; ev.burst_len = burst_len;
+            ev.burst_slot = kind == 3u ? pending_slot : 0xffffffffu;
             O.events[e] = ev;
         } else {
             atomicOr(O.n_events + 2, 1u);
@@ -305,7 +309,7 @@ struct SampleStage {
 // spills) -- what lets two workgroups, six wavefronts, share a CU's four SIMDs beyond 16 384
 // channels.  Smaller batches use the unconstrained build (2 % faster).
 template <int NFF, int NFB, bool MED3, bool SHARE, typename SampleT>
-__global__ __launch_bounds__(3 * kWave, SHARE ? 2 : 1) void demod_pipe3_kernel(Params P, State S, Output O,
+__global__ __launch_bounds__(4 * kWave, SHARE ? 2 : 1) void demod_pipe3_kernel(Params P, State S, Output O,
                                                                 const float4 *__restrict__ taps,
                                                                 const SampleT *__restrict__ x,
                                                                 uint32_t n_blocks, uint64_t counter0)
@@ -322,13 +326,16 @@ __global__ __launch_bounds__(3 * kWave, SHARE ? 2 : 1) void demod_pipe3_kernel(P
     lds_u32 *mail = (lds_u32 *)(lds + kPipeTapFloats);
     lds_u32 *symbox = mail;                                    // [2][5][64]
     lds_u32 *fbbox = mail + 2u * kP3SymWords;                  // [2][64 + flag]
-    lds_u32 *phasebox = fbbox + 2u * kP3FbWords;               // [64]
+    lds_u32 *iobox = fbbox + 2u * kP3FbWords;                  // [2][3][64]
+    lds_u32 *phasebox = iobox + 2u * kP3IoWords;               // [64] stage 2's final TED phase bit
+    lds_u32 *againbox = phasebox + kWave;                      // [64] stage 4's final F_TICK_AGAIN bit
     lds_u32 *chunkbox = fbbox + kWave + 2u;                    // [2], in the first box's padding
     float *hcol = lds + kPipeTapFloats + kP3MailWords + lane;
     float *wring = lds + kPipeTapFloats + kP3MailWords + (kSquelchHist - kB) * LP;   // logical slot 0
     float *wcol = wring + lane;
     const uint64_t counter1 = counter0 + (uint64_t)n_blocks * kB;
-    const uint32_t n_steps = n_blocks + 2u;
+    const uint32_t n_steps = n_blocks + 3u;
+    const uint32_t last_fb_step = n_blocks + 1u;                // stage 3 runs in steps 2 .. n_blocks + 1
 
     if (role == 0u) {
         // ------------------------------ stage 1: sample phase, block s -------------------------
@@ -350,7 +357,7 @@ __global__ __launch_bounds__(3 * kWave, SHARE ? 2 : 1) void demod_pipe3_kernel(P
             P3_LAP(p3_work);
             lds_barrier();                                             // A
             P3_LAP(p3_wait);
-            if (s >= 2u) {
+            if (s >= 2u && s <= last_fb_step) {
                 const lds_u32 *fb = fbbox + (s & 1u) * kP3FbWords;
                 if (__builtin_amdgcn_readfirstlane((int)fb[kWave])) {
                     const uint32_t v = fb[lane];
@@ -411,7 +418,7 @@ __global__ __launch_bounds__(3 * kWave, SHARE ? 2 : 1) void demod_pipe3_kernel(P
             P3_LAP(p3_work);
             lds_barrier();                                             // A
             P3_LAP(p3_wait);
-            if (s >= 2u) {
+            if (s >= 2u && s <= last_fb_step) {
                 const lds_u32 *fb = fbbox + (s & 1u) * kP3FbWords;
                 if (__builtin_amdgcn_readfirstlane((int)fb[kWave])) {
                     const uint32_t v = fb[lane];
@@ -442,14 +449,12 @@ __global__ __launch_bounds__(3 * kWave, SHARE ? 2 : 1) void demod_pipe3_kernel(P
         S.until_next_ted[c] = L.until_next_ted; S.ted_clock[c] = L.ted_clock;
         S.ted_h0[c] = L.h0; S.ted_h1[c] = L.h1; S.ted_h2[c] = L.h2;
         S.period_avg[c] = L.period_avg; S.period_inst[c] = L.period_inst;
-    } else {
+    } else if (role == 2u) {
         // ------------------------------ stage 3: symbol path, block s-2 ------------------------
         Lane L;
         lane_load(L, S, c);
         L.ended = 0u;
-        PipeCtx<NFF, NFB> X;
-        X.chunk = chunkbox;
-        chunkbox[0] = 0u; chunkbox[1] = kEvChunk;       // nothing reserved yet
+        FastCtx<NFF, NFB> X;
         X.hist = hcol;
 #ifdef SAME_PROFILE
         // per-section marks of the symbol path (SAME_P3_MARKS build): words behind the taps, reported
@@ -478,11 +483,11 @@ __global__ __launch_bounds__(3 * kWave, SHARE ? 2 : 1) void demod_pipe3_kernel(P
         P3_T0();
         for (uint32_t s = 0; s < n_steps; ++s) {
             bool any = false;
-            if (s >= 2u) {
+            if (s >= 2u && s <= last_fb_step) {
                 const uint32_t blk = s - 2u;
                 const lds_u32 *sb = symbox + (blk & 1u) * kP3SymWords + lane;
                 const uint32_t hdr = sb[0];
-                uint32_t fbv = 0;
+                uint32_t fbv = 0, io0 = 0, io1 = 0xffffffffu, io2 = 0;
                 if (hdr & 1u) {
                     const uint32_t fk = hdr >> 8;
                     const float zero = __uint_as_float(sb[kWave]), sym = __uint_as_float(sb[2 * kWave]);
@@ -490,12 +495,21 @@ __global__ __launch_bounds__(3 * kWave, SHARE ? 2 : 1) void demod_pipe3_kernel(P
                     if (P.trace_cap) { terr = __uint_as_float(sb[3 * kWave]); unt = __uint_as_float(sb[4 * kWave]); }
                     const uint32_t before = L.flags & (F_AGC_LOCKED | F_BW_LOCKED);
                     L.ended = 0u;
-                    ted_symbol(P, L, S, O, X, c, zero, sym, terr, unt, counter0 + (uint64_t)blk * kB + fk + 1u);
+                    uint32_t burst_len = 0;
+                    bool emit = false;
+                    const uint32_t link = symbol_link(P, L, S, X, c, zero, sym, terr, unt,
+                                                      counter0 + (uint64_t)blk * kB + fk + 1u, &burst_len, &emit);
+                    if (emit && link == 3u) io1 = burst_to_pool(S, O, c);
+                    io0 = 1u | (link << 1) | (emit ? 8u : 0u) | (fk << 4);
+                    io2 = burst_len;
                     const uint32_t after = L.flags & (F_AGC_LOCKED | F_BW_LOCKED);
                     if (after != before || L.ended)
                         fbv = 1u | ((after & F_AGC_LOCKED) ? 2u : 0u) | ((after & F_BW_LOCKED) ? 4u : 0u) |
                               (L.ended ? 8u : 0u) | (fk << 8);
                 }
+                lds_u32 *io = iobox + (s & 1u) * kP3IoWords + lane;
+                io[0] = io0;
+                if (__builtin_amdgcn_ballot_w64((io0 & 8u) != 0u && ((io0 >> 1) & 3u) == 3u) != 0ull) { io[kWave] = io1; io[2 * kWave] = io2; }
                 lds_u32 *fb = fbbox + (s & 1u) * kP3FbWords;
                 fb[lane] = fbv;
                 any = __builtin_amdgcn_ballot_w64(fbv != 0u) != 0ull;
@@ -513,15 +527,13 @@ __global__ __launch_bounds__(3 * kWave, SHARE ? 2 : 1) void demod_pipe3_kernel(P
         if (blockIdx.x == 0 && lane == 0)
             for (int i = 0; i < 6; ++i) atomicAdd(&g_same_prof_pipe[i], X.pl[1 + 2 + i] - (i == 0 ? 0ull : 0ull));
 #endif
-        X.retire(O, lane);
-        lds_barrier();                                                 // stage 2's final TED phase
-        L.flags = (L.flags & ~F_TED_PHASE) | (phasebox[lane] & F_TED_PHASE);
+        lds_barrier();                                                 // stage 2's TED phase, stage 4's wake-up flag
+        L.flags = (L.flags & ~(F_TED_PHASE | F_TICK_AGAIN)) | (phasebox[lane] & F_TED_PHASE) | (againbox[lane] & F_TICK_AGAIN);
         S.sq_data[c] = L.sq_data; S.sq_power[c] = L.sq_power; S.sq_phist[c] = L.sq_phist;
         S.sq_fill[c] = L.sq_fill; S.sq_clock[c] = L.sq_clock; S.sq_symbols[c] = L.sq_symbols;
         S.eq_word[c] = L.eq_word; S.eq_count[c] = L.eq_count;
         S.fr_word[c] = L.fr_word; S.fr_count[c] = L.fr_count; S.fr_invalid[c] = L.fr_invalid;
         S.fr_len[c] = L.fr_len; S.flags[c] = L.flags;
-        S.tk_next[c] = L.tk_next; S.tk_last[c] = L.tk_last; S.wake_fired[c] = L.wake_fired;
 #pragma unroll
         for (int i = 0; i < NFF; ++i) {
             S.eq_ffc[i * C + c] = X.ffc[i]; S.eq_ffw[i * C + c] = X.ffw[i];
@@ -534,6 +546,38 @@ __global__ __launch_bounds__(3 * kWave, SHARE ? 2 : 1) void demod_pipe3_kernel(P
         }
 #pragma unroll 2
         for (int i = 0; i < kSquelchHist; ++i) { float *row = S.sq_hist + (size_t)i * C; row[c] = hcol[i * LP]; }
+    } else {
+        // ------------------------------ stage 4: link events + wake-ups, block s-3 -------------
+        Lane L;
+        lane_load(L, S, c);                    // uses sq_symbols, tk_next, tk_last, wake_*, F_TICK_AGAIN
+        IoCtx X;
+        X.chunk = chunkbox;
+        chunkbox[0] = 0u; chunkbox[1] = kEvChunk;       // nothing reserved yet
+        X.pending_slot = 0xffffffffu;
+        for (uint32_t s = 0; s < n_steps; ++s) {
+            if (s >= 3u) {
+                const uint32_t blk = s - 3u;
+                const lds_u32 *io = iobox + ((s - 1u) & 1u) * kP3IoWords + lane;   // what stage 3 posted last step
+                const uint32_t io0 = io[0];
+                if (io0 & 1u) {
+                    L.sq_symbols += 1;         // as rx_symbol counted it (rx/codesquelch.rs:232)
+                    const uint32_t link = (io0 >> 1) & 3u, fk = (io0 >> 4) & 31u;
+                    const bool burst = (io0 & 8u) != 0u && link == 3u;
+                    uint32_t burst_len = 0;
+                    if (burst) { X.pending_slot = io[kWave]; burst_len = io[2 * kWave]; }
+                    symbol_io(P, L, S, O, X, c, link, (io0 & 8u) != 0u, counter0 + (uint64_t)blk * kB + fk + 1u, burst_len);
+                }
+            }
+            lds_barrier();                                             // A
+            if (s >= 2u && s <= last_fb_step) {
+                const lds_u32 *fb = fbbox + (s & 1u) * kP3FbWords;
+                if (__builtin_amdgcn_readfirstlane((int)fb[kWave])) { lds_barrier(); lds_barrier(); }   // B, C
+            }
+        }
+        X.retire(O, lane);
+        againbox[lane] = L.flags & F_TICK_AGAIN;
+        lds_barrier();                                                 // stage 3 merges the flag bits
+        S.tk_next[c] = L.tk_next; S.tk_last[c] = L.tk_last; S.wake_fired[c] = L.wake_fired;
     }
 }
 
@@ -567,10 +611,10 @@ static hipError_t launch_pipe_t(const Params &P, const State &S, const Output &O
 #define SAME_PIPE_LAUNCH(NFF, NFB, M3)                                                                      \
     do {                                                                                                    \
         if (share)                                                                                          \
-            hipLaunchKernelGGL((demod_pipe3_kernel<NFF, NFB, M3, true, SampleT>), dim3(grid), dim3(3 * kWave), lds, \
+            hipLaunchKernelGGL((demod_pipe3_kernel<NFF, NFB, M3, true, SampleT>), dim3(grid), dim3(4 * kWave), lds, \
                                stream, P, S, O, taps, x, n_blocks, counter0);                                \
         else                                                                                                \
-            hipLaunchKernelGGL((demod_pipe3_kernel<NFF, NFB, M3, false, SampleT>), dim3(grid), dim3(3 * kWave), lds, \
+            hipLaunchKernelGGL((demod_pipe3_kernel<NFF, NFB, M3, false, SampleT>), dim3(grid), dim3(4 * kWave), lds, \
                                stream, P, S, O, taps, x, n_blocks, counter0);                                \
     } while (0)
     if (P.eq_nff == 6u && P.eq_nfb == 4u) { if (med3) SAME_PIPE_LAUNCH(6, 4, true); else SAME_PIPE_LAUNCH(6, 4, false); }
