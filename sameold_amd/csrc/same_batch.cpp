@@ -686,7 +686,7 @@ const char *same_batch_kernel_name(const same_batch *rx)
     if (rx->use_fast && !rx->force_generic) 
     {
         const uint32_t st = same::pipe_kernel_stages(rx->P);
-        return st == 3u ? "demod_pipe3_kernel" : "demod_fast_kernel";
+        return st != 0u ? "demod_pipe_kernel" : "demod_fast_kernel";
     }
     switch (rx->P.block_len) {
     case 16: return "demod_kernel<B=16>";

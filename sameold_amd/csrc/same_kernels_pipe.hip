@@ -1,16 +1,16 @@
-// same_kernels_pipe.hip -- three-stage wavefront pipeline for small and medium batches at 22.05 kHz.
+// same_kernels_pipe.hip -- four-stage wavefront pipeline for small and medium batches at 22.05 kHz.
 //
 // With one wavefront per 64 channels (same_kernels_fast.hip) a launch of 4 096 channels is 64
 // serial instruction streams on a machine with 1 024 SIMDs, and a stream's length per block is
-// what it is whichever lanes are live.  Here a workgroup of THREE wavefronts owns 64 channels:
+// what it is whichever lanes are live.  Here a workgroup of FOUR wavefronts owns 64 channels:
 // the stream is cut in stages that run concurrently on different SIMDs of one CU, one block
-// apart, handing data over through LDS (see "Three stages" below).  The arithmetic per channel
+// apart, handing data over through LDS (see "Four stages" below).  The arithmetic per channel
 // and its order are exactly those of the one-wavefront kernels, so results are bit-identical
 // (tests/test_gpu_parity.py runs every 22.05 kHz case of up to 32 768 channels through this
 // kernel; test_fast_kernel_equals_generic_kernel and
 // test_pipeline_kernel_equals_single_wavefront_kernel pit the variants against each other).
 // A two-stage cut (sample phase | everything else) was measured on the way: 27.8 ms against
-// 35.3 ms (one wavefront) and 20.3 ms (three stages) at 4 096 channels x 10 s.
+// 35.3 ms (one wavefront), 19.2 ms (three stages) and 17.3 ms (four) at 4 096 channels x 10 s.
 //
 // Window ring: 5 blocks of 18 slots, mirrored (see same_fast_common.h): while stage 2 reads the
 // 42 slots ending at an instant of block i, stage 1 writes block i+1, and with five blocks the
@@ -309,7 +309,7 @@ struct SampleStage {
 // spills) -- what lets two workgroups, six wavefronts, share a CU's four SIMDs beyond 16 384
 // channels.  Smaller batches use the unconstrained build (2 % faster).
 template <int NFF, int NFB, bool MED3, bool SHARE, typename SampleT>
-__global__ __launch_bounds__(4 * kWave, SHARE ? 2 : 1) void demod_pipe3_kernel(Params P, State S, Output O,
+__global__ __launch_bounds__(4 * kWave, SHARE ? 2 : 1) void demod_pipe_kernel(Params P, State S, Output O,
                                                                 const float4 *__restrict__ taps,
                                                                 const SampleT *__restrict__ x,
                                                                 uint32_t n_blocks, uint64_t counter0)
@@ -584,19 +584,19 @@ __global__ __launch_bounds__(4 * kWave, SHARE ? 2 : 1) void demod_pipe3_kernel(P
 // ---------------------------------------------------------------------------------
 // dispatch
 // ---------------------------------------------------------------------------------
-static size_t pipe3_lds_bytes()
+static size_t pipe_lds_bytes()
 { return ((size_t)kPipeTapFloats + kP3MailWords + (size_t)(kSquelchHist + 2 * kPipeRing - kPipeB) * kWave) * sizeof(float); }
 
 // The pipeline pays while SIMDs are idle.  Whole groups of 64 channels only.  Measured: it wins
-// up to 32 768 channels (two workgroups of three wavefronts per CU), the one-wavefront kernel
-// from 49 152 on.  Returns the number of stages: 0 (not selected) or 3.
+// up to 32 768 channels (two workgroups of four wavefronts per CU), the one-wavefront kernel
+// from 49 152 on.  Returns 0 (not selected) or non-zero.
 uint32_t pipe_kernel_stages(const Params &P)
 {
     if (P.ntaps != (uint32_t)kPipeNT || P.dc_len != (uint32_t)kPipeDCL || (P.n_channels % kWave) != 0u) return 0;
     if (!((P.eq_nff == 6u && P.eq_nfb == 4u) || (P.eq_nff == 1u && P.eq_nfb == 1u))) return 0;
     if (P.block_len != 16u || max_block_len(P) < (uint32_t)kPipeB) return 0;       // 18-sample blocks
-    if (const char *e = getenv("SAME_PIPE")) return atoi(e) ? 3u : 0u;       // 0 = off, anything else = on
-    return P.n_channels <= 32768u ? 3u : 0u;
+    if (const char *e = getenv("SAME_PIPE")) return atoi(e) ? 4u : 0u;       // 0 = off, anything else = on
+    return P.n_channels <= 32768u ? 4u : 0u;
 }
 bool pipe_kernel_selected(const Params &P) { return pipe_kernel_stages(P) != 0u; }
 
@@ -605,16 +605,16 @@ static hipError_t launch_pipe_t(const Params &P, const State &S, const Output &O
                                 const SampleT *x, uint32_t n_blocks, uint64_t counter0, hipStream_t stream)
 {
     const uint32_t grid = P.n_channels / kWave;
-    const size_t lds = pipe3_lds_bytes();
+    const size_t lds = pipe_lds_bytes();
     const bool share = P.n_channels > 16384u;       // two workgroups per CU: the register-capped build
     const bool med3 = !(P.agc_min == 0.0f && std::signbit(P.agc_min)) && !(P.agc_max == 0.0f && std::signbit(P.agc_max));
 #define SAME_PIPE_LAUNCH(NFF, NFB, M3)                                                                      \
     do {                                                                                                    \
         if (share)                                                                                          \
-            hipLaunchKernelGGL((demod_pipe3_kernel<NFF, NFB, M3, true, SampleT>), dim3(grid), dim3(4 * kWave), lds, \
+            hipLaunchKernelGGL((demod_pipe_kernel<NFF, NFB, M3, true, SampleT>), dim3(grid), dim3(4 * kWave), lds, \
                                stream, P, S, O, taps, x, n_blocks, counter0);                                \
         else                                                                                                \
-            hipLaunchKernelGGL((demod_pipe3_kernel<NFF, NFB, M3, false, SampleT>), dim3(grid), dim3(4 * kWave), lds, \
+            hipLaunchKernelGGL((demod_pipe_kernel<NFF, NFB, M3, false, SampleT>), dim3(grid), dim3(4 * kWave), lds, \
                                stream, P, S, O, taps, x, n_blocks, counter0);                                \
     } while (0)
     if (P.eq_nff == 6u && P.eq_nfb == 4u) { if (med3) SAME_PIPE_LAUNCH(6, 4, true); else SAME_PIPE_LAUNCH(6, 4, false); }

@@ -249,7 +249,7 @@ def test_builder_variants(sa, ob, variant):
         assert got.get(c, []) == oracle_events(ob, cfg, x[:, c]), f"{variant} channel {c}"
 
 
-@pytest.mark.parametrize("rate,dev,kernel", [(22050, 0.05, "demod_fast_kernel"), (22050, 0.01, "demod_pipe3_kernel"),
+@pytest.mark.parametrize("rate,dev,kernel", [(22050, 0.05, "demod_fast_kernel"), (22050, 0.01, "demod_pipe_kernel"),
                                              (48000, 0.2, "demod_kernel<B=16>"), (48000, 0.01, "demod_fast_kernel")])
 def test_block_length_follows_the_timing_bound(sa, ob, rate, dev, kernel):
     """A block may hold at most one TED instant.  The 18-sample (22.05 kHz mirrored / pipelined)
@@ -312,13 +312,13 @@ def test_hypot_matches_glibc(sa, ob):
 
 
 # ------------------------------------------------------------------ fast vs generic kernel
-PIPE_ENV = {"fast": "0", "pipe3": "1"}      # SAME_PIPE: wavefront pipeline off / on (read at every launch)
+PIPE_ENV = {"fast": "0", "pipe": "1"}      # SAME_PIPE: wavefront pipeline off / on (read at every launch)
 
 
-@pytest.mark.parametrize("rate,variant", [(22050, "pipe3"), (22050, "fast"), (48000, "fast"), (44100, "fast")])
+@pytest.mark.parametrize("rate,variant", [(22050, "pipe"), (22050, "fast"), (48000, "fast"), (44100, "fast")])
 def test_fast_kernel_equals_generic_kernel(sa, ob, rate, variant, monkeypatch):
     """Standard rates dispatch to the latency-optimised kernels (one wavefront per 64 channels,
-    or the three-stage wavefront pipeline for 22.05 kHz batches of up to 32 768 channels); each must reproduce the
+    or the wavefront pipeline for 22.05 kHz batches of up to 32 768 channels); each must reproduce the
     any-configuration kernel (and therefore the oracle) bit for bit, including when chunk sizes
     are not whole blocks (remainder handled by the generic kernel)."""
     import torch
@@ -353,11 +353,11 @@ def test_fast_kernel_equals_generic_kernel(sa, ob, rate, variant, monkeypatch):
 def test_pipeline_kernel_equals_single_wavefront_kernel(sa, monkeypatch, n_ch, seconds):
     """The same batch through both 22.05 kHz variants, many bursts per channel (every AGC lock
     flip makes the pipeline's earlier stages replay a lane): identical events.  Above 16 384
-    channels the three-stage kernel is the build with the halved register budget."""
+    channels the pipeline kernel is the build with the halved register budget."""
     n = int(22050 * seconds)
     x = sa.synth_afsk(n_ch, n, 22050, seed=4242, noise_sigma=0.02)
     out = {}
-    for variant in ("pipe3", "fast"):
+    for variant in ("pipe", "fast"):
         monkeypatch.setenv("SAME_PIPE", PIPE_ENV[variant])
         rx = sa.SameReceiverBuilder(22050).build_batch(n_ch)
         assert rx.kernel_name() == f"demod_{variant}_kernel"
@@ -366,15 +366,15 @@ def test_pipeline_kernel_equals_single_wavefront_kernel(sa, monkeypatch, n_ch, s
         rx.sync()
         out[variant] = events_by_channel(rx)
     assert sum(len(v) for v in out["fast"].values()) > 2 * n_ch
-    assert out["pipe3"] == out["fast"]
+    assert out["pipe"] == out["fast"]
 
 
 def test_i16_input_through_the_pipeline_kernel(sa, ob):
-    """int16 samples cast in stage 1 of the pipelined kernel (64 channels => demod_pipe3_kernel)."""
+    """int16 samples cast in stage 1 of the pipelined kernel (64 channels => demod_pipe_kernel)."""
     n_ch, n = 64, 22050 * 4
     x = np.clip(np.rint(mixed_batch(sa, n_ch, n, seed=77)), -32768, 32767).astype(np.int16)
     rx = sa.SameReceiverBuilder(22050).samedec().build_batch(n_ch)
-    assert rx.kernel_name() == "demod_pipe3_kernel"
+    assert rx.kernel_name() == "demod_pipe_kernel"
     rx.process_host(x)
     got = events_by_channel(rx)
     cfg = ob.samedec_config()

@@ -35,7 +35,7 @@ if hasattr(rx._L, "same_debug_profile"):
         print(f"  {n:16s} {v:14d} clk  {100.0*v/max(tot,1):5.1f} %  {v/nblk:8.1f} clk/block")
     print(f"  total {tot} clk over {nblk} blocks = {tot/nblk:.1f} clk/block (each executed mark costs about the '(one mark)' figure, charged to the section after it)")
 
-if hasattr(rx._L, "same_debug_profile_pipe") and "pipe3" in rx.kernel_name():
+if hasattr(rx._L, "same_debug_profile_pipe") and "pipe" in rx.kernel_name():
     import ctypes
     buf = (ctypes.c_ulonglong * 9)()
     rx._L.same_debug_profile_pipe(buf, 1)
