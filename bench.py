@@ -138,7 +138,7 @@ def main():
 
     def gather(ev):
         # the step's one collective: every rank's burst records to rank 0 (RCCL; vectorised packing)
-        recs = sd.pack_burst_events(ev, first_ch)
+        recs = sd.pack_burst_events(ev, first_ch, zero_padded=True)
         if not distributed:
             return len(recs)
         got = sd.gather_records(recs, dev)

@@ -48,19 +48,34 @@ def unpack_bursts(recs: np.ndarray) -> List[Tuple[int, int, bytes]]:
     return out
 
 
-def pack_burst_events(events: np.ndarray, first_channel: int = 0) -> np.ndarray:
+def pack_burst_events(events: np.ndarray, first_channel: int = 0, zero_padded: bool = False) -> np.ndarray:
     """Vectorised pack_bursts for an EVENT_DTYPE array (sameold_amd.receiver): the SAME_LINK_BURST
-    events of one rank -> uint8 [n, RECORD_BYTES] with global channel numbers."""
-    b = events[events["kind"] == 3]                      # SAME_LINK_BURST
-    out = np.zeros((len(b), RECORD_BYTES), dtype=np.uint8)
-    if len(b):
-        out[:, 0:4] = (b["channel"].astype(np.uint32) + np.uint32(first_channel)).view(np.uint8).reshape(-1, 4)
-        out[:, 4:12] = b["sample_counter"].astype(np.uint64).view(np.uint8).reshape(-1, 8)
-        n = np.minimum(b["len"].astype(np.uint32), np.uint32(RECORD_BYTES - _HDR))
+    events of one rank -> uint8 [n, RECORD_BYTES] with global channel numbers.  `zero_padded`:
+    the caller vouches that event bytes past `len` are zero (true for events polled from the
+    library), which saves masking them."""
+    # work on the raw bytes: fancy indexing of a structured array with a 288-byte sub-array field
+    # goes element by element, a row take of a uint8 matrix is one memcpy per row
+    dt = events.dtype
+    raw = np.ascontiguousarray(events).view(np.uint8).reshape(-1, dt.itemsize)
+    off = {name: dt.fields[name][1] for name in ("kind", "channel", "sample_counter", "len", "bytes")}
+    kind = raw[:, off["kind"]: off["kind"] + 4].view(np.uint32).ravel()
+    rows = raw[np.flatnonzero(kind == 3)]                # SAME_LINK_BURST
+    out = np.empty((len(rows), RECORD_BYTES), dtype=np.uint8)
+    if len(rows):
+        ch = np.ascontiguousarray(rows[:, off["channel"]: off["channel"] + 4]).view(np.uint32).ravel()
+        out[:, 0:4] = (ch + np.uint32(first_channel)).view(np.uint8).reshape(-1, 4)
+        out[:, 4:12] = rows[:, off["sample_counter"]: off["sample_counter"] + 8]
+        n = np.minimum(np.ascontiguousarray(rows[:, off["len"]: off["len"] + 4]).view(np.uint32).ravel(),
+                       np.uint32(RECORD_BYTES - _HDR))
         out[:, 12:16] = n.view(np.uint8).reshape(-1, 4)
-        data = b["bytes"][:, : RECORD_BYTES - _HDR]
-        keep = np.arange(RECORD_BYTES - _HDR, dtype=np.uint32)[None, :] < n[:, None]
-        out[:, _HDR:] = np.where(keep, data, 0)
+        out[:, _HDR:] = rows[:, off["bytes"]: off["bytes"] + RECORD_BYTES - _HDR]
+        if not zero_padded:
+            short = np.flatnonzero(n < RECORD_BYTES - _HDR)
+            if len(short):
+                cols = np.arange(RECORD_BYTES - _HDR, dtype=np.uint32)[None, :]
+                body = out[short, _HDR:]
+                body[cols >= n[short, None]] = 0
+                out[short, _HDR:] = body
     return out
 
 
