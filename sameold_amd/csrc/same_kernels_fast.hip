@@ -2,22 +2,26 @@
 // rates (22.05 / 44.1 / 48 kHz with the reference's default DC-blocker length).
 //
 // Same arithmetic contract and the same "deferred TED" schedule as demod_kernel in
-// same_kernels.hip (one lane = one channel, blocks of 16 samples, at most one TED
-// instant per lane per block), so results are bit-identical; what changes is where state
-// lives and how memory latency is taken off the critical path:
+// same_kernels.hip (one lane = one channel, blocks of 16 / 18 / 32 samples -- see
+// same_fast_common.h -- with at most one TED instant per lane per block), so results are
+// bit-identical; what changes is where state lives and how memory latency is taken off the
+// critical path.  One wavefront owns 64 channels for the whole launch; it is the variant for
+// batches that fill the machine (from 49 152 channels at 22.05 kHz) and for 44.1 / 48 kHz.
+// Smaller 22.05 kHz batches go to the wavefront pipeline of same_kernels_pipe.hip.
 //
-//   * DC blocker (22.05 kHz: window length 16 = block length): both moving-average
-//     windows are the previous block's 16 inputs / 16 averages, held in VGPRs with static
-//     indices -- no LDS traffic at all.  Other rates read all of a block's aged-off ring
-//     entries from LDS up front (they cannot alias this block's writes because the window
-//     is longer than a block).
-//   * the next block's 16 input samples are fetched while the current block is computed;
+//   * DC blocker (22.05 kHz: window length 16 <= block length): both moving-average
+//     windows are the last 16 inputs / 16 averages, held in VGPRs with static indices -- no
+//     LDS traffic at all.  Other rates read all of a block's aged-off ring entries from LDS
+//     up front (they cannot alias this block's writes because the window is longer than a
+//     block).
+//   * the next block's input samples are fetched while the current block is computed;
 //   * the TED instant of a lane is known in advance (the sample clock is a counter
 //     against a fixed period), so the per-sample clock test collapses to one compare per
 //     block;
-//   * matched filters: window samples are pulled from the LDS ring in batches and the
-//     four accumulation chains run as two v_pk_mul_f32 / v_pk_add_f32 pairs per tap
-//     (per-element IEEE, identical rounding to the scalar form);
+//   * matched filters: window samples and taps are pulled from LDS in batches (the window
+//     mirrored for 42 taps, so no per-tap address arithmetic) and the four accumulation
+//     chains run as two v_pk_mul_f32 / v_pk_add_f32 pairs per tap (per-element IEEE,
+//     identical rounding to the scalar form);
 //   * squelch sample history lives in LDS, the equalizer's 20 floats in VGPRs.
 //
 // Citations: file:line under /root/reference/crates/sameold/src/ ("rx/" = receiver/).

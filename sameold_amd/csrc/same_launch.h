@@ -12,7 +12,8 @@ hipError_t launch_demod(const Params &P, const State &S, const Output &O, const 
 hipError_t launch_demod_i16(const Params &P, const State &S, const Output &O, const float4 *taps,
                             const int16_t *x, uint32_t n_samples, uint64_t counter0, hipStream_t stream);
 size_t demod_lds_bytes(const Params &P);
-// latency-optimised kernel for the standard rates (same_kernels_fast.hip); whole blocks of 16
+// latency-optimised kernel for the standard rates (same_kernels_fast.hip); whole blocks of
+// fast_block_len() samples, the generic kernel takes the rest of a call
 // longest block that can hold at most one TED instant for this configuration (same_config.cpp)
 uint32_t max_block_len(const Params &P);
 bool fast_kernel_supported(const Params &P);
