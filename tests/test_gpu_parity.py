@@ -180,6 +180,30 @@ def test_chunked_processing_equals_one_shot(sa, ob):
     assert chunked.input_sample_counter() == n
 
 
+def test_tiny_chunks_through_the_pipeline(sa, ob):
+    """Calls of one, two and three blocks (and fractions of a block) exercise the pipeline's fill and
+    drain: 64 channels at 22.05 kHz run demod_pipe_kernel for every whole 18-sample block."""
+    n_ch, n = 64, 22050 * 2
+    x = mixed_batch(sa, n_ch, n, seed=21)
+    import torch
+    xd = torch.from_numpy(x).cuda()
+    one = sa.SameReceiverBuilder(22050).build_batch(n_ch)
+    assert one.kernel_name() == "demod_pipe_kernel"
+    one.process_tensor(xd); one.sync()
+    a = events_by_channel(one)
+    chunked = sa.SameReceiverBuilder(22050).build_batch(n_ch)
+    sizes = [1, 17, 18, 19, 35, 36, 37, 54, 5, 72, 90, 2000]
+    off = i = 0
+    while off < n:
+        k = sizes[i % len(sizes)] if off < 12000 else 7000
+        chunked.process_tensor(xd[off:off + k].contiguous())
+        off += k; i += 1
+    chunked.sync()
+    assert events_by_channel(chunked) == a
+    for c in (0, 31, 63):
+        assert a.get(c, []) == oracle_events(ob, ob.default_config(22050), x[:, c])
+
+
 def test_channel_major_layout(sa, ob):
     n_ch, n = 70, 22050 * 3
     x = mixed_batch(sa, n_ch, n, seed=9)
