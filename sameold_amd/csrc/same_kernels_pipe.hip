@@ -306,7 +306,7 @@ struct SampleStage {
 };
 
 // SHARE: built for two wavefronts per SIMD (half of the 512-entry register file each, a few
-// spills) -- what lets two workgroups, six wavefronts, share a CU's four SIMDs beyond 16 384
+// spills) -- what lets two workgroups, eight wavefronts, share a CU's four SIMDs beyond 16 384
 // channels.  Smaller batches use the unconstrained build (2 % faster).
 template <int NFF, int NFB, bool MED3, bool SHARE, typename SampleT>
 __global__ __launch_bounds__(4 * kWave, SHARE ? 2 : 1) void demod_pipe_kernel(Params P, State S, Output O,
