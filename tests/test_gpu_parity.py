@@ -535,3 +535,62 @@ def test_awgn_trials_bit_exact_and_scored(sa, ob):
     assert min(r["burst_detection_rate"] for r in hi) >= 0.8
     assert max(r["burst_detection_rate"] for r in lo) <= 0.2 and all(r["intact_header_rate"] == 0.0 for r in lo)
     assert sum(r["intact_header_rate"] for r in hi) > 2.0
+
+
+# ------------------------------------------------------------------ full size (BASELINE.json configs[1])
+def test_full_size_round_trip_4096_channels_10s(sa, ob):
+    """configs[1] at full size (4 096 channels x 220 500 samples, the bench workload): every channel's
+    decoded header equals the header it was sent (modulate -> demodulate round trip), the link
+    layer delivered three bursts of it, and 48 channels spread over the batch match the oracle
+    event for event."""
+    import torch
+    n_ch, n, seed = 4096, 220500, 20260000
+    x = sa.synth_afsk(n_ch, n, 22050, seed=seed)
+    rx = sa.SameReceiverBuilder(22050).build_batch(n_ch)
+    assert rx.kernel_name() == "demod_pipe_kernel"
+    rx.process_tensor(x)
+    rx.sync()
+    ev = rx.poll_events_np()
+    starts = ev[ev["kind"] == sa.TRANSPORT_MSG_START]
+    assert len(np.unique(starts["channel"])) == n_ch
+    first = {}
+    for r in starts:
+        first.setdefault(int(r["channel"]), r["bytes"][: int(r["len"])].tobytes())
+    bursts = ev[ev["kind"] == sa.LINK_BURST]
+    n_bursts = np.bincount(bursts["channel"], minlength=n_ch)
+    for c in range(n_ch):
+        want = sa.synth_payload(seed, c)
+        assert first[c] == want, f"channel {c}"
+        assert n_bursts[c] >= 3
+    cfg = ob.default_config(22050)
+    for c in range(0, n_ch, 86):
+        mine = ev[ev["channel"] == c]
+        got = [(int(r["kind"]), int(r["sample_counter"]), r["bytes"][: min(int(r["len"]), 288)].tobytes()) for r in mine]
+        xc = x[:, c].contiguous().cpu().numpy()
+        assert got == oracle_events(ob, cfg, xc), f"channel {c}"
+
+
+@pytest.mark.parametrize("n_ch,rate,seconds", [(32768, 22050, 2.6), (16384, 48000, 2.6)])
+def test_full_width_batches_deliver_what_was_sent(sa, ob, n_ch, rate, seconds):
+    """The per-GPU shard of configs[3] (32 768 channels) and configs[2] (16 384 channels at 48 kHz)
+    at full width: every burst a channel delivers begins with the header it was sent, nearly all
+    channels deliver one within the first 2.6 s, and channels spread over the batch match the oracle."""
+    n, seed = int(rate * seconds), 31337
+    x = sa.synth_afsk(n_ch, n, rate, seed=seed)
+    rx = sa.SameReceiverBuilder(rate).build_batch(n_ch, link_only=True)
+    rx.process_tensor(x)
+    rx.sync()
+    ev = rx.poll_events_np()
+    bursts = ev[ev["kind"] == sa.LINK_BURST]
+    assert len(np.unique(bursts["channel"])) > 0.95 * n_ch
+    payload = {}
+    for r in bursts:
+        c = int(r["channel"])
+        want = payload.setdefault(c, sa.synth_payload(seed, c))
+        assert r["bytes"][: len(want)].tobytes() == want, f"channel {c}"
+    cfg = ob.default_config(rate)
+    for c in range(0, n_ch, n_ch // 24):
+        mine = ev[ev["channel"] == c]
+        got = [(int(r["kind"]), int(r["sample_counter"]), r["bytes"][: min(int(r["len"]), 288)].tobytes()) for r in mine]
+        xc = x[:, c].contiguous().cpu().numpy()
+        assert got == oracle_events(ob, cfg, xc, link_only=True), f"channel {c}"
