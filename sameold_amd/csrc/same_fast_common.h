@@ -18,11 +18,12 @@ typedef float float2v __attribute__((ext_vector_type(2)));
 // choose_block_len: 18 is the bound at 22.05 kHz), so a block holds at most one instant.
 constexpr int kBlock = 16;
 constexpr int kBlockMirror = 18;
-// 48 kHz (92 taps): instants are 46 samples apart and the bound is 43, so the block is 32 --
-// the block-rate passes (92-tap filters, timing loop, symbol path) serve twice the samples.
+// 48 kHz (92 taps) and 44.1 kHz (84 taps): instants are 46 / 42 samples apart and the bound is
+// 43 / 39, so the block is 32 -- the block-rate passes (the long filters, timing loop, symbol
+// path) serve twice the samples.
 constexpr int kBlock48k = 32;
 template <int NT, bool MIRROR> struct FastBlock {
-    static constexpr int len = MIRROR ? kBlockMirror : (NT == 92 ? kBlock48k : kBlock);
+    static constexpr int len = MIRROR ? kBlockMirror : (NT >= 84 ? kBlock48k : kBlock);
 };
 // LDS window ring: a whole number of blocks (a block never wraps); a power of two when the
 // per-tap address wraps with a mask, four blocks when the window is mirrored

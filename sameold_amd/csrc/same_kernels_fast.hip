@@ -51,8 +51,8 @@ __global__ __launch_bounds__(kWave) void demod_fast_kernel(Params P, State S, Ou
 {
     constexpr int kB = FastBlock<NT, MIRROR>::len;
     constexpr int RING = FastRing<NT, MIRROR>::slots;
-    constexpr bool DC_REGS = (DCL <= kB);
-    static_assert(DC_REGS || DCL > kB, "LDS DC path needs a window longer than a block");
+    constexpr bool DC_REGS = (DCL <= kB) && DCL <= 16;      // the windows in registers: short ones only
+    static_assert(DC_REGS || DCL >= kB, "LDS DC path needs a window at least as long as a block");
     static_assert(!DC_REGS || (DCL & (DCL - 1)) == 0, "register DC path indexes the state ring with a mask");
     static_assert(NT + kB - 1 <= RING && RING % kB == 0, "window ring too small or not a whole number of blocks");
     extern __shared__ float lds[];
@@ -201,6 +201,9 @@ __global__ __launch_bounds__(kWave) void demod_fast_kernel(Params P, State S, Ou
             }
 #pragma unroll
             for (int k = 0; k <= kB; ++k) a0[k] = ffcol[slots[k] * LP];
+            // window exactly one block long: the entry aged at the next block's first step is this
+            // block's first input, which is not in the ring yet
+            if (DCL == kB) a0[kB] = xs[0];
 #pragma unroll
             for (int k = 0; k < kB; ++k) a1[k] = fbcol[slots[k] * LP];
 #pragma unroll
@@ -208,7 +211,7 @@ __global__ __launch_bounds__(kWave) void demod_fast_kernel(Params P, State S, Ou
                 float d0 = xs[k] - a0[k];
                 L.sum0 += d0;
                 float ma0 = L.sum0 * P.dc_inv_len;
-                float sig = a0[k + 1];                       // not yet overwritten: DCL > block
+                float sig = a0[k + 1];                       // read before this block's writes
                 float d1 = ma0 - a1[k];
                 L.sum1 += d1;
                 float ma1 = L.sum1 * P.dc_inv_len;
@@ -332,7 +335,7 @@ static constexpr size_t fast_lds_bytes()
 #else
     constexpr size_t TAPF = (size_t)((NT * 4 + 63) / 64 * 64);
 #endif
-    return (TAPF + (size_t)((MIRROR ? 2 * RING - kB : RING) + kSquelchHist + (DCL <= kB ? 0 : 2 * DCL)) * kWave) * sizeof(float);
+    return (TAPF + (size_t)((MIRROR ? 2 * RING - kB : RING) + kSquelchHist + ((DCL <= kB && DCL <= 16) ? 0 : 2 * DCL)) * kWave) * sizeof(float);
 }
 
 // The mirrored window costs 16 KB of LDS per wavefront: 3 wavefronts fit a CU's 160 KB instead
@@ -375,7 +378,7 @@ bool fast_kernel_supported(const Params &P)
     if (P.block_len != (uint32_t)kBlock || P.win_ring > 128u) return false;
     const bool eq_ok = (P.eq_nff == 6u && P.eq_nfb == 4u) || (P.eq_nff == 1u && P.eq_nfb == 1u);
     if (!eq_ok) return false;
-    if (P.ntaps == 92u && max_block_len(P) < (uint32_t)kBlock48k) return false;   // its block is 32 samples
+    if (P.ntaps >= 84u && max_block_len(P) < (uint32_t)kBlock48k) return false;   // their block is 32 samples
     return (P.ntaps == 42u && P.dc_len == 16u) || (P.ntaps == 92u && P.dc_len == 35u) ||
            (P.ntaps == 84u && P.dc_len == 32u);
 }
@@ -387,7 +390,7 @@ uint32_t fast_block_len(const Params &P)
 {
     if (pipe_kernel_selected(P)) return (uint32_t)kBlockMirror;
     if (P.ntaps == 42u && fast_use_mirror(P.n_channels, P.ntaps, max_block_len(P))) return (uint32_t)kBlockMirror;
-    return P.ntaps == 92u ? (uint32_t)kBlock48k : (uint32_t)kBlock;
+    return P.ntaps >= 84u ? (uint32_t)kBlock48k : (uint32_t)kBlock;
 }
 
 template <typename SampleT>

@@ -274,10 +274,11 @@ def test_builder_variants(sa, ob, variant):
 
 
 @pytest.mark.parametrize("rate,dev,kernel", [(22050, 0.05, "demod_fast_kernel"), (22050, 0.01, "demod_pipe_kernel"),
-                                             (48000, 0.2, "demod_kernel<B=16>"), (48000, 0.01, "demod_fast_kernel")])
+                                             (48000, 0.2, "demod_kernel<B=16>"), (48000, 0.01, "demod_fast_kernel"),
+                                             (44100, 0.15, "demod_kernel<B=16>"), (44100, 0.01, "demod_fast_kernel")])
 def test_block_length_follows_the_timing_bound(sa, ob, rate, dev, kernel):
     """A block may hold at most one TED instant.  The 18-sample (22.05 kHz mirrored / pipelined)
-    and 32-sample (48 kHz) variants are only dispatched when timing_max_deviation leaves room
+    and 32-sample (48 / 44.1 kHz) variants are only dispatched when timing_max_deviation leaves room
     for them; with a wider deviation the dispatcher falls back to shorter blocks, and every
     choice matches the oracle."""
     n_ch, n = 64, rate * 3
