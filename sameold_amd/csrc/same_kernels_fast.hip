@@ -388,7 +388,7 @@ uint32_t fast_win_ring(const Params &P) { return (P.ntaps + kBlock - 1 <= 64u) ?
 // samples per block of the variant launch_demod_fast will pick for this batch
 uint32_t fast_block_len(const Params &P)
 {
-    if (pipe_kernel_selected(P)) return (uint32_t)kBlockMirror;
+    if (pipe_kernel_selected(P)) return pipe_block_len(P);
     if (P.ntaps == 42u && fast_use_mirror(P.n_channels, P.ntaps, max_block_len(P))) return (uint32_t)kBlockMirror;
     return P.ntaps >= 84u ? (uint32_t)kBlock48k : (uint32_t)kBlock;
 }

@@ -1,4 +1,5 @@
-// same_kernels_pipe.hip -- four-stage wavefront pipeline for small and medium batches at 22.05 kHz.
+// same_kernels_pipe.hip -- four-stage wavefront pipeline for small and medium batches at the
+// standard rates (22.05 / 44.1 / 48 kHz).
 //
 // With one wavefront per 64 channels (same_kernels_fast.hip) a launch of 4 096 channels is 64
 // serial instruction streams on a machine with 1 024 SIMDs, and a stream's length per block is
@@ -12,7 +13,7 @@
 // A two-stage cut (sample phase | everything else) was measured on the way: 27.8 ms against
 // 35.3 ms (one wavefront), 19.2 ms (three stages) and 17.3 ms (four) at 4 096 channels x 10 s.
 //
-// Window ring: 5 blocks of 18 slots, mirrored (see same_fast_common.h): while stage 2 reads the
+// Window ring: 5 blocks (of 18 slots at 22.05 kHz, 32 at 44.1 / 48 kHz), mirrored (see same_fast_common.h): while stage 2 reads the
 // 42 slots ending at an instant of block i, stage 1 writes block i+1, and with five blocks the
 // two never touch the same slot (four would: an instant early in block i still needs the tail
 // of block i-3, which block i+1 overwrites).
@@ -45,12 +46,22 @@ __device__ __forceinline__ void lds_barrier()
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
-constexpr int kPipeNT = 42, kPipeDCL = 16, kPipeB = kBlockMirror, kPipeRing = 5 * kPipeB;
+// Geometry per sample rate (filter length NT): DC-blocker window, samples per block, window ring.
+// The ring is five blocks at every rate: NT - 1 samples back from an instant early in block s-1
+// reach into block s-4 (41 = 2*18 + 5, 91 = 2*32 + 27, 83 = 2*32 + 19) while stage 1 writes block s.
+template <int NT> struct PipeGeom;
+template <> struct PipeGeom<42> { static constexpr int DCL = 16, B = kBlockMirror; };   // 22.05 kHz
+template <> struct PipeGeom<92> { static constexpr int DCL = 35, B = kBlock48k; };      // 48 kHz
+template <> struct PipeGeom<84> { static constexpr int DCL = 32, B = kBlock48k; };      // 44.1 kHz
+template <int NT> struct PipeLayout {
+    static constexpr int B = PipeGeom<NT>::B, RING = 5 * B;
 #ifdef SAME_PROFILE
-constexpr uint32_t kPipeTapFloats = (uint32_t)((kPipeNT * 4 + 20 + 63) / 64 * 64);
+    static constexpr uint32_t tap_floats = (uint32_t)((NT * 4 + 20 + 63) / 64 * 64);
 #else
-constexpr uint32_t kPipeTapFloats = (uint32_t)((kPipeNT * 4 + 63) / 64 * 64);
+    static constexpr uint32_t tap_floats = (uint32_t)((NT * 4 + 63) / 64 * 64);
 #endif
+    static_assert(B <= RING - NT + 1, "the first block's low copy would be read");
+};
 
 // =====================================================================================
 // Four stages, one wavefront each: sample phase (block s) | matched filters + timing loop (block
@@ -144,9 +155,9 @@ struct IoCtx : TickRingGlobal {
 };
 
 // Stage 1 state: DC blocker, AGC, input prefetch, and what a replay needs of its last three blocks
-template <bool MED3, typename SampleT>
+template <int NT_, bool MED3, typename SampleT>
 struct SampleStage {
-    static constexpr int NT = kPipeNT, DCL = kPipeDCL, kB = kPipeB, RING = kPipeRing;
+    static constexpr int NT = NT_, DCL = PipeGeom<NT_>::DCL, kB = PipeLayout<NT_>::B, RING = PipeLayout<NT_>::RING;
     static constexpr uint32_t LP = kWave;
     float sum0, sum1, gain;
     bool locked;                         // this stage's belief of the AGC lock
@@ -176,7 +187,8 @@ struct SampleStage {
         const uint32_t dpos = (uint32_t)(counter0 % (uint64_t)DCL);
 #pragma unroll
         for (int k = 0; k < DCL; ++k) {
-            const uint32_t slot = (dpos + (uint32_t)k) & (uint32_t)(DCL - 1);
+            uint32_t slot = dpos + (uint32_t)k;
+            if (slot >= (uint32_t)DCL) slot -= (uint32_t)DCL;
             const float *r0 = S.dc_ff_ring + (size_t)slot * C, *r1 = S.dc_fb_ring + (size_t)slot * C;
             xp[k] = r0[c];
             mp[k] = r1[c];
@@ -259,8 +271,12 @@ struct SampleStage {
             ys[0][k] = y2.x; ys[0][k + 1] = y2.y;
             mnew[k] = ma0.x; mnew[k + 1] = ma0.y;
         }
+        // the windows move on by one block (ascending: entry k only takes from entries above it)
 #pragma unroll
-        for (int k = 0; k < DCL; ++k) { xp[k] = xs[kB - DCL + k]; mp[k] = mnew[kB - DCL + k]; }
+        for (int k = 0; k < DCL; ++k) {
+            xp[k] = kB + k < DCL ? xp[kB + k < DCL ? kB + k : 0] : xs[kB + k >= DCL ? kB + k - DCL : 0];
+            mp[k] = kB + k < DCL ? mp[kB + k < DCL ? kB + k : 0] : mnew[kB + k >= DCL ? kB + k - DCL : 0];
+        }
         g0[0] = gain;
         wp[0] = wnext;
         const float bw = locked ? 0.0f : P.agc_bw;
@@ -289,7 +305,8 @@ struct SampleStage {
         const uint32_t dpos = (uint32_t)(counter1 % (uint64_t)DCL);
 #pragma unroll
         for (int k = 0; k < DCL; ++k) {
-            const uint32_t slot = (dpos + (uint32_t)k) & (uint32_t)(DCL - 1);
+            uint32_t slot = dpos + (uint32_t)k;
+            if (slot >= (uint32_t)DCL) slot -= (uint32_t)DCL;
             float *r0 = S.dc_ff_ring + (size_t)slot * C, *r1 = S.dc_fb_ring + (size_t)slot * C;
             r0[c] = xp[k];
             r1[c] = mp[k];
@@ -308,14 +325,15 @@ struct SampleStage {
 // SHARE: built for two wavefronts per SIMD (half of the 512-entry register file each, a few
 // spills) -- what lets two workgroups, eight wavefronts, share a CU's four SIMDs beyond 16 384
 // channels.  Smaller batches use the unconstrained build (2 % faster).
-template <int NFF, int NFB, bool MED3, bool SHARE, typename SampleT>
+template <int NT, int NFF, int NFB, bool MED3, bool SHARE, typename SampleT>
 __global__ __launch_bounds__(4 * kWave, SHARE ? 2 : 1) void demod_pipe_kernel(Params P, State S, Output O,
                                                                 const float4 *__restrict__ taps,
                                                                 const SampleT *__restrict__ x,
                                                                 uint32_t n_blocks, uint64_t counter0)
 {
-    constexpr int NT = kPipeNT, kB = kPipeB, RING = kPipeRing;
-    constexpr uint32_t LP = kWave;
+    constexpr int kB = PipeLayout<NT>::B, RING = PipeLayout<NT>::RING;
+    constexpr uint32_t LP = kWave, kPipeTapFloats = PipeLayout<NT>::tap_floats;
+    static_assert(kB <= 32, "the sample index travels in five bits of the stage 3 -> 4 word");
     extern __shared__ float lds[];
     const uint32_t lane = threadIdx.x & (kWave - 1u);
     const uint32_t role = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -340,7 +358,7 @@ __global__ __launch_bounds__(4 * kWave, SHARE ? 2 : 1) void demod_pipe_kernel(Pa
     if (role == 0u) {
         // ------------------------------ stage 1: sample phase, block s -------------------------
         for (uint32_t i = lane; i < (uint32_t)NT; i += kWave) tlds[i] = taps[i];
-        SampleStage<MED3, SampleT> M;
+        SampleStage<NT, MED3, SampleT> M;
         M.load(P, S, x, c, C, counter0, wcol, n_blocks);
         P3_T0();
         // one step; BUF = s & 1 names the prefetch registers statically, so the loop runs two steps a turn
@@ -349,7 +367,7 @@ __global__ __launch_bounds__(4 * kWave, SHARE ? 2 : 1) void demod_pipe_kernel(Pa
             if (s < n_blocks) {
                 M.template fetch<decltype(buf)::value>(x, s, n_blocks, c, C);
 #ifdef SAME_P1_SPLIT
-                asm volatile("s_waitcnt vmcnt(18)" ::: "memory");    // profiling: the block's inputs have arrived
+                asm volatile("s_waitcnt vmcnt(%0)" :: "n"(kB) : "memory");    // profiling: the block's inputs have arrived
                 P3_LAP(p3_fb);                                       // (reported in the "feedback" column)
 #endif
                 M.block(P, wcol);
@@ -584,43 +602,77 @@ __global__ __launch_bounds__(4 * kWave, SHARE ? 2 : 1) void demod_pipe_kernel(Pa
 // ---------------------------------------------------------------------------------
 // dispatch
 // ---------------------------------------------------------------------------------
-static size_t pipe_lds_bytes()
-{ return ((size_t)kPipeTapFloats + kP3MailWords + (size_t)(kSquelchHist + 2 * kPipeRing - kPipeB) * kWave) * sizeof(float); }
+template <int NT>
+static constexpr size_t pipe_lds_bytes()
+{
+    return ((size_t)PipeLayout<NT>::tap_floats + kP3MailWords +
+            (size_t)(kSquelchHist + 2 * PipeLayout<NT>::RING - PipeLayout<NT>::B) * kWave) * sizeof(float);
+}
 
-// The pipeline pays while SIMDs are idle.  Whole groups of 64 channels only.  Measured: it wins
-// up to 32 768 channels (two workgroups of four wavefronts per CU), the one-wavefront kernel
-// from 49 152 on.  Returns 0 (not selected) or non-zero.
+// The pipeline pays while SIMDs are idle.  Whole groups of 64 channels only.  Measured at
+// 22.05 kHz: it wins up to 32 768 channels (two workgroups of four wavefronts per CU), the
+// one-wavefront kernel from 49 152 on.  At 44.1 / 48 kHz a workgroup's window ring is 72 KB of
+// the CU's 160 KB of LDS, so one workgroup per CU and 16 384 channels at a time; two rounds of
+// them (32 768 channels: 13.1 ms for 2 s at 48 kHz) still beat one wavefront per 64 channels
+// (16.0 ms), three do not.  Returns 0 (not selected) or non-zero.
 uint32_t pipe_kernel_stages(const Params &P)
 {
-    if (P.ntaps != (uint32_t)kPipeNT || P.dc_len != (uint32_t)kPipeDCL || (P.n_channels % kWave) != 0u) return 0;
+    const bool r22 = P.ntaps == 42u && P.dc_len == 16u, r48 = P.ntaps == 92u && P.dc_len == 35u,
+               r44 = P.ntaps == 84u && P.dc_len == 32u;
+    if (!(r22 || r48 || r44) || (P.n_channels % kWave) != 0u) return 0;
     if (!((P.eq_nff == 6u && P.eq_nfb == 4u) || (P.eq_nff == 1u && P.eq_nfb == 1u))) return 0;
-    if (P.block_len != 16u || max_block_len(P) < (uint32_t)kPipeB) return 0;       // 18-sample blocks
+    if (P.block_len != 16u || max_block_len(P) < (r22 ? (uint32_t)kBlockMirror : (uint32_t)kBlock48k)) return 0;
     if (const char *e = getenv("SAME_PIPE")) return atoi(e) ? 4u : 0u;       // 0 = off, anything else = on
     return P.n_channels <= 32768u ? 4u : 0u;
 }
 bool pipe_kernel_selected(const Params &P) { return pipe_kernel_stages(P) != 0u; }
+uint32_t pipe_block_len(const Params &P) { return P.ntaps == 42u ? (uint32_t)kBlockMirror : (uint32_t)kBlock48k; }
+
+template <int NT, int NFF, int NFB, bool M3, bool SHARE, typename SampleT>
+static hipError_t launch_pipe_one(const Params &P, const State &S, const Output &O, const float4 *taps,
+                                  const SampleT *x, uint32_t n_blocks, uint64_t counter0, hipStream_t stream)
+{
+    constexpr size_t lds = pipe_lds_bytes<NT>();
+    auto *kernel = demod_pipe_kernel<NT, NFF, NFB, M3, SHARE, SampleT>;
+    if (lds > 64u * 1024u) {
+        // more than the default 64 KB of dynamic LDS per workgroup: opt in, once per kernel and device
+        static bool opted_in[64] = {};
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
+        if (!opted_in[dev]) {
+            const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return e;
+            opted_in[dev] = true;
+        }
+    }
+    hipLaunchKernelGGL(kernel, dim3(P.n_channels / kWave), dim3(4 * kWave), lds, stream, P, S, O, taps, x, n_blocks, counter0);
+    return hipGetLastError();
+}
+
+template <int NT, typename SampleT>
+static hipError_t launch_pipe_cfg(const Params &P, const State &S, const Output &O, const float4 *taps,
+                                  const SampleT *x, uint32_t n_blocks, uint64_t counter0, hipStream_t stream)
+{
+    // two workgroups per CU (22.05 kHz only, where their LDS allows it): the register-capped build
+    constexpr bool CAN_SHARE = (NT == 42);
+    const bool share = CAN_SHARE && P.n_channels > 16384u;
+    const bool med3 = !(P.agc_min == 0.0f && std::signbit(P.agc_min)) && !(P.agc_max == 0.0f && std::signbit(P.agc_max));
+#define SAME_PIPE_LAUNCH(NFF, NFB, M3)                                                                              \
+    (share ? launch_pipe_one<NT, NFF, NFB, M3, CAN_SHARE, SampleT>(P, S, O, taps, x, n_blocks, counter0, stream)    \
+           : launch_pipe_one<NT, NFF, NFB, M3, false, SampleT>(P, S, O, taps, x, n_blocks, counter0, stream))
+    if (P.eq_nff == 6u && P.eq_nfb == 4u) return med3 ? SAME_PIPE_LAUNCH(6, 4, true) : SAME_PIPE_LAUNCH(6, 4, false);
+    return med3 ? SAME_PIPE_LAUNCH(1, 1, true) : SAME_PIPE_LAUNCH(1, 1, false);
+#undef SAME_PIPE_LAUNCH
+}
 
 template <typename SampleT>
 static hipError_t launch_pipe_t(const Params &P, const State &S, const Output &O, const float4 *taps,
                                 const SampleT *x, uint32_t n_blocks, uint64_t counter0, hipStream_t stream)
 {
-    const uint32_t grid = P.n_channels / kWave;
-    const size_t lds = pipe_lds_bytes();
-    const bool share = P.n_channels > 16384u;       // two workgroups per CU: the register-capped build
-    const bool med3 = !(P.agc_min == 0.0f && std::signbit(P.agc_min)) && !(P.agc_max == 0.0f && std::signbit(P.agc_max));
-#define SAME_PIPE_LAUNCH(NFF, NFB, M3)                                                                      \
-    do {                                                                                                    \
-        if (share)                                                                                          \
-            hipLaunchKernelGGL((demod_pipe_kernel<NFF, NFB, M3, true, SampleT>), dim3(grid), dim3(4 * kWave), lds, \
-                               stream, P, S, O, taps, x, n_blocks, counter0);                                \
-        else                                                                                                \
-            hipLaunchKernelGGL((demod_pipe_kernel<NFF, NFB, M3, false, SampleT>), dim3(grid), dim3(4 * kWave), lds, \
-                               stream, P, S, O, taps, x, n_blocks, counter0);                                \
-    } while (0)
-    if (P.eq_nff == 6u && P.eq_nfb == 4u) { if (med3) SAME_PIPE_LAUNCH(6, 4, true); else SAME_PIPE_LAUNCH(6, 4, false); }
-    else { if (med3) SAME_PIPE_LAUNCH(1, 1, true); else SAME_PIPE_LAUNCH(1, 1, false); }
-#undef SAME_PIPE_LAUNCH
-    return hipGetLastError();
+    if (P.ntaps == 42u) return launch_pipe_cfg<42, SampleT>(P, S, O, taps, x, n_blocks, counter0, stream);
+    if (P.ntaps == 92u) return launch_pipe_cfg<92, SampleT>(P, S, O, taps, x, n_blocks, counter0, stream);
+    return launch_pipe_cfg<84, SampleT>(P, S, O, taps, x, n_blocks, counter0, stream);
 }
 
 hipError_t launch_demod_pipe(const Params &P, const State &S, const Output &O, const float4 *taps,

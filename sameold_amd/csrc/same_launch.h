@@ -21,6 +21,7 @@ uint32_t fast_block_len(const Params &P);   // samples per block of the fast ker
 // four-stage wavefront pipeline (same_kernels_pipe.hip): up to 32 768 channels at 22.05 kHz
 bool pipe_kernel_selected(const Params &P);
 uint32_t pipe_kernel_stages(const Params &P);     // 0 (not selected) or non-zero
+uint32_t pipe_block_len(const Params &P);         // samples per block of the pipeline at this rate
 hipError_t launch_demod_pipe(const Params &P, const State &S, const Output &O, const float4 *taps,
                              const float *x, uint32_t n_blocks, uint64_t counter0, hipStream_t stream);
 hipError_t launch_demod_pipe_i16(const Params &P, const State &S, const Output &O, const float4 *taps,

@@ -274,8 +274,8 @@ def test_builder_variants(sa, ob, variant):
 
 
 @pytest.mark.parametrize("rate,dev,kernel", [(22050, 0.05, "demod_fast_kernel"), (22050, 0.01, "demod_pipe_kernel"),
-                                             (48000, 0.2, "demod_kernel<B=16>"), (48000, 0.01, "demod_fast_kernel"),
-                                             (44100, 0.15, "demod_kernel<B=16>"), (44100, 0.01, "demod_fast_kernel")])
+                                             (48000, 0.2, "demod_kernel<B=16>"), (48000, 0.01, "demod_pipe_kernel"),
+                                             (44100, 0.15, "demod_kernel<B=16>"), (44100, 0.01, "demod_pipe_kernel")])
 def test_block_length_follows_the_timing_bound(sa, ob, rate, dev, kernel):
     """A block may hold at most one TED instant.  The 18-sample (22.05 kHz mirrored / pipelined)
     and 32-sample (48 / 44.1 kHz) variants are only dispatched when timing_max_deviation leaves room
@@ -340,10 +340,11 @@ def test_hypot_matches_glibc(sa, ob):
 PIPE_ENV = {"fast": "0", "pipe": "1"}      # SAME_PIPE: wavefront pipeline off / on (read at every launch)
 
 
-@pytest.mark.parametrize("rate,variant", [(22050, "pipe"), (22050, "fast"), (48000, "fast"), (44100, "fast")])
+@pytest.mark.parametrize("rate,variant", [(22050, "pipe"), (22050, "fast"), (48000, "pipe"), (48000, "fast"),
+                                          (44100, "pipe"), (44100, "fast")])
 def test_fast_kernel_equals_generic_kernel(sa, ob, rate, variant, monkeypatch):
     """Standard rates dispatch to the latency-optimised kernels (one wavefront per 64 channels,
-    or the wavefront pipeline for 22.05 kHz batches of up to 32 768 channels); each must reproduce the
+    or the wavefront pipeline for small and medium batches); each must reproduce the
     any-configuration kernel (and therefore the oracle) bit for bit, including when chunk sizes
     are not whole blocks (remainder handled by the generic kernel)."""
     import torch
@@ -374,17 +375,18 @@ def test_fast_kernel_equals_generic_kernel(sa, ob, rate, variant, monkeypatch):
         assert a.get(c, []) == oracle_events(ob, cfg, x[:, c]), f"channel {c}"
 
 
-@pytest.mark.parametrize("n_ch,seconds", [(256, 12.0), (16448, 1.5)])
-def test_pipeline_kernel_equals_single_wavefront_kernel(sa, monkeypatch, n_ch, seconds):
-    """The same batch through both 22.05 kHz variants, many bursts per channel (every AGC lock
+@pytest.mark.parametrize("rate,n_ch,seconds", [(22050, 256, 12.0), (22050, 16448, 1.5), (48000, 256, 8.0),
+                                               (44100, 192, 8.0)])
+def test_pipeline_kernel_equals_single_wavefront_kernel(sa, monkeypatch, rate, n_ch, seconds):
+    """The same batch through both variants of a rate, many bursts per channel (every AGC lock
     flip makes the pipeline's earlier stages replay a lane): identical events.  Above 16 384
-    channels the pipeline kernel is the build with the halved register budget."""
-    n = int(22050 * seconds)
-    x = sa.synth_afsk(n_ch, n, 22050, seed=4242, noise_sigma=0.02)
+    channels the 22.05 kHz pipeline kernel is the build with the halved register budget."""
+    n = int(rate * seconds)
+    x = sa.synth_afsk(n_ch, n, rate, seed=4242, noise_sigma=0.02)
     out = {}
     for variant in ("pipe", "fast"):
         monkeypatch.setenv("SAME_PIPE", PIPE_ENV[variant])
-        rx = sa.SameReceiverBuilder(22050).build_batch(n_ch)
+        rx = sa.SameReceiverBuilder(rate).build_batch(n_ch)
         assert rx.kernel_name() == f"demod_{variant}_kernel"
         for off in range(0, n, 50000):
             rx.process_tensor(x[off:off + 50000].contiguous())
