@@ -192,7 +192,7 @@ def main():
             "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
             "kernel_ms": round(k_ms, 4), "algorithmic_bytes_per_launch": 4 * C * T,
-            "note": "issue-bound serial streams: 64 workgroups x 4 pipeline-stage wavefronts on 1024 SIMDs (DESIGN.md 4.4, 4.4b)",
+            "note": "issue-bound serial streams: 256 workgroups (16 channels each) x 4 pipeline-stage wavefronts, one per SIMD (DESIGN.md 4.4, 4.4b)",
         },
     }
 

@@ -146,10 +146,10 @@ struct IoCtx : TickRingGlobal {
         }
     }
     // end of the launch, all lanes: mark what is left of the current run as empty
-    __device__ __forceinline__ void retire(const Output &O, uint32_t lane)
+    __device__ __forceinline__ void retire(const Output &O, uint32_t lane, uint32_t lanes)
     {
         const uint32_t base = chunk[0], used = chunk[1];
-        for (uint32_t i = used + lane; i < kEvChunk; i += kWave)
+        for (uint32_t i = used + lane; i < kEvChunk; i += lanes)
             if (base + i < O.event_cap) { O.events[base + i].channel = 0; O.events[base + i].kind = kDevEventNone; }
     }
 };
@@ -325,7 +325,13 @@ struct SampleStage {
 // SHARE: built for two wavefronts per SIMD (half of the 512-entry register file each, a few
 // spills) -- what lets two workgroups, eight wavefronts, share a CU's four SIMDs beyond 16 384
 // channels.  Smaller batches use the unconstrained build (2 % faster).
-template <int NT, int NFF, int NFB, bool MED3, bool SHARE, typename SampleT>
+//
+// LANES: channels per workgroup.  A wavefront's time per step does not depend on how many of its
+// lanes are live, but it does depend on which paths ANY live lane takes: with 64 channels nearly
+// every step has a lane with a byte due, a lane whose symbol changes the AGC lock, ...; with 16
+// most steps skip those sections.  Small batches (which leave CUs idle anyway) therefore spread
+// over more workgroups of fewer channels; lanes >= LANES retire at once.
+template <int NT, int NFF, int NFB, bool MED3, bool SHARE, int LANES, typename SampleT>
 __global__ __launch_bounds__(4 * kWave, SHARE ? 2 : 1) void demod_pipe_kernel(Params P, State S, Output O,
                                                                 const float4 *__restrict__ taps,
                                                                 const SampleT *__restrict__ x,
@@ -338,7 +344,7 @@ __global__ __launch_bounds__(4 * kWave, SHARE ? 2 : 1) void demod_pipe_kernel(Pa
     const uint32_t lane = threadIdx.x & (kWave - 1u);
     const uint32_t role = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const uint32_t C = P.n_channels;
-    const uint32_t c = blockIdx.x * kWave + lane;            // C % 64 == 0 (host)
+    const uint32_t c = blockIdx.x * (uint32_t)LANES + lane;  // C % LANES == 0 (host)
     // LDS: taps | mailboxes | squelch history [64][64] | window (logical slots kB .. 2*RING-1)
     float4 *tlds = reinterpret_cast<float4 *>(lds);
     lds_u32 *mail = (lds_u32 *)(lds + kPipeTapFloats);
@@ -358,6 +364,7 @@ __global__ __launch_bounds__(4 * kWave, SHARE ? 2 : 1) void demod_pipe_kernel(Pa
     if (role == 0u) {
         // ------------------------------ stage 1: sample phase, block s -------------------------
         for (uint32_t i = lane; i < (uint32_t)NT; i += kWave) tlds[i] = taps[i];
+        if (LANES < (int)kWave && lane >= (uint32_t)LANES) return;      // (the wavefront goes on without them)
         SampleStage<NT, MED3, SampleT> M;
         M.load(P, S, x, c, C, counter0, wcol, n_blocks);
         P3_T0();
@@ -399,6 +406,7 @@ __global__ __launch_bounds__(4 * kWave, SHARE ? 2 : 1) void demod_pipe_kernel(Pa
         M.store(P, S, c, C, counter1, wcol);
     } else if (role == 1u) {
         // ------------------------------ stage 2: filters + timing loop, block s-1 --------------
+        if (LANES < (int)kWave && lane >= (uint32_t)LANES) return;
         Lane L;
         lane_load(L, S, c);
         int cstar = next_fire_count(L.until_next_ted, L.ted_clock);
@@ -469,6 +477,7 @@ __global__ __launch_bounds__(4 * kWave, SHARE ? 2 : 1) void demod_pipe_kernel(Pa
         S.period_avg[c] = L.period_avg; S.period_inst[c] = L.period_inst;
     } else if (role == 2u) {
         // ------------------------------ stage 3: symbol path, block s-2 ------------------------
+        if (LANES < (int)kWave && lane >= (uint32_t)LANES) return;
         Lane L;
         lane_load(L, S, c);
         L.ended = 0u;
@@ -566,6 +575,7 @@ __global__ __launch_bounds__(4 * kWave, SHARE ? 2 : 1) void demod_pipe_kernel(Pa
         for (int i = 0; i < kSquelchHist; ++i) { float *row = S.sq_hist + (size_t)i * C; row[c] = hcol[i * LP]; }
     } else {
         // ------------------------------ stage 4: link events + wake-ups, block s-3 -------------
+        if (LANES < (int)kWave && lane >= (uint32_t)LANES) return;
         Lane L;
         lane_load(L, S, c);                    // uses sq_symbols, tk_next, tk_last, wake_*, F_TICK_AGAIN
         IoCtx X;
@@ -592,7 +602,7 @@ __global__ __launch_bounds__(4 * kWave, SHARE ? 2 : 1) void demod_pipe_kernel(Pa
                 if (__builtin_amdgcn_readfirstlane((int)fb[kWave])) { lds_barrier(); lds_barrier(); }   // B, C
             }
         }
-        X.retire(O, lane);
+        X.retire(O, lane, (uint32_t)LANES);
         againbox[lane] = L.flags & F_TICK_AGAIN;
         lds_barrier();                                                 // stage 3 merges the flag bits
         S.tk_next[c] = L.tk_next; S.tk_last[c] = L.tk_last; S.wake_fired[c] = L.wake_fired;
@@ -615,11 +625,26 @@ static constexpr size_t pipe_lds_bytes()
 // the CU's 160 KB of LDS, so one workgroup per CU and 16 384 channels at a time; two rounds of
 // them (32 768 channels: 13.1 ms for 2 s at 48 kHz) still beat one wavefront per 64 channels
 // (16.0 ms), three do not.  Returns 0 (not selected) or non-zero.
+// v_med3_f32 == f32::clamp unless a bound is -0.0 (or NaN, which the builder rejects)
+static bool agc_clamp_is_med3(const Params &P)
+{ return !(P.agc_min == 0.0f && std::signbit(P.agc_min)) && !(P.agc_max == 0.0f && std::signbit(P.agc_max)); }
+
+// channels per workgroup: 16 while that still leaves the batch within one workgroup per CU
+// (default equalizer only: fewer kernels to build), else 64
+static uint32_t pipe_lanes(const Params &P)
+{
+    if (!(P.eq_nff == 6u && P.eq_nfb == 4u) || !agc_clamp_is_med3(P)) return kWave;
+    if (const char *e = getenv("SAME_PIPE_LANES")) { const int v = atoi(e); if (v == 16 || v == 32 || v == 64) return (uint32_t)v; }
+    if (P.n_channels <= 16u * 256u && P.n_channels % 16u == 0u) return 16u;
+    if (P.n_channels <= 32u * 256u && P.n_channels % 32u == 0u) return 32u;
+    return kWave;
+}
+
 uint32_t pipe_kernel_stages(const Params &P)
 {
     const bool r22 = P.ntaps == 42u && P.dc_len == 16u, r48 = P.ntaps == 92u && P.dc_len == 35u,
                r44 = P.ntaps == 84u && P.dc_len == 32u;
-    if (!(r22 || r48 || r44) || (P.n_channels % kWave) != 0u) return 0;
+    if (!(r22 || r48 || r44) || (P.n_channels % pipe_lanes(P)) != 0u) return 0;
     if (!((P.eq_nff == 6u && P.eq_nfb == 4u) || (P.eq_nff == 1u && P.eq_nfb == 1u))) return 0;
     if (P.block_len != 16u || max_block_len(P) < (r22 ? (uint32_t)kBlockMirror : (uint32_t)kBlock48k)) return 0;
     if (const char *e = getenv("SAME_PIPE")) return atoi(e) ? 4u : 0u;       // 0 = off, anything else = on
@@ -628,12 +653,12 @@ uint32_t pipe_kernel_stages(const Params &P)
 bool pipe_kernel_selected(const Params &P) { return pipe_kernel_stages(P) != 0u; }
 uint32_t pipe_block_len(const Params &P) { return P.ntaps == 42u ? (uint32_t)kBlockMirror : (uint32_t)kBlock48k; }
 
-template <int NT, int NFF, int NFB, bool M3, bool SHARE, typename SampleT>
+template <int NT, int NFF, int NFB, bool M3, bool SHARE, int LANES, typename SampleT>
 static hipError_t launch_pipe_one(const Params &P, const State &S, const Output &O, const float4 *taps,
                                   const SampleT *x, uint32_t n_blocks, uint64_t counter0, hipStream_t stream)
 {
     constexpr size_t lds = pipe_lds_bytes<NT>();
-    auto *kernel = demod_pipe_kernel<NT, NFF, NFB, M3, SHARE, SampleT>;
+    auto *kernel = demod_pipe_kernel<NT, NFF, NFB, M3, SHARE, LANES, SampleT>;
     if (lds > 64u * 1024u) {
         // more than the default 64 KB of dynamic LDS per workgroup: opt in, once per kernel and device
         static bool opted_in[64] = {};
@@ -646,7 +671,7 @@ static hipError_t launch_pipe_one(const Params &P, const State &S, const Output 
             opted_in[dev] = true;
         }
     }
-    hipLaunchKernelGGL(kernel, dim3(P.n_channels / kWave), dim3(4 * kWave), lds, stream, P, S, O, taps, x, n_blocks, counter0);
+    hipLaunchKernelGGL(kernel, dim3(P.n_channels / (uint32_t)LANES), dim3(4 * kWave), lds, stream, P, S, O, taps, x, n_blocks, counter0);
     return hipGetLastError();
 }
 
@@ -657,10 +682,15 @@ static hipError_t launch_pipe_cfg(const Params &P, const State &S, const Output 
     // two workgroups per CU (22.05 kHz only, where their LDS allows it): the register-capped build
     constexpr bool CAN_SHARE = (NT == 42);
     const bool share = CAN_SHARE && P.n_channels > 16384u;
-    const bool med3 = !(P.agc_min == 0.0f && std::signbit(P.agc_min)) && !(P.agc_max == 0.0f && std::signbit(P.agc_max));
-#define SAME_PIPE_LAUNCH(NFF, NFB, M3)                                                                              \
-    (share ? launch_pipe_one<NT, NFF, NFB, M3, CAN_SHARE, SampleT>(P, S, O, taps, x, n_blocks, counter0, stream)    \
-           : launch_pipe_one<NT, NFF, NFB, M3, false, SampleT>(P, S, O, taps, x, n_blocks, counter0, stream))
+    const bool med3 = agc_clamp_is_med3(P);
+#define SAME_PIPE_LAUNCH(NFF, NFB, M3)                                                                                  \
+    (share ? launch_pipe_one<NT, NFF, NFB, M3, CAN_SHARE, 64, SampleT>(P, S, O, taps, x, n_blocks, counter0, stream)    \
+           : launch_pipe_one<NT, NFF, NFB, M3, false, 64, SampleT>(P, S, O, taps, x, n_blocks, counter0, stream))
+    const uint32_t lanes = pipe_lanes(P);
+    if (lanes != kWave) {                      // (default equalizer, med3: see pipe_lanes)
+        if (lanes == 16u) return launch_pipe_one<NT, 6, 4, true, false, 16, SampleT>(P, S, O, taps, x, n_blocks, counter0, stream);
+        return launch_pipe_one<NT, 6, 4, true, false, 32, SampleT>(P, S, O, taps, x, n_blocks, counter0, stream);
+    }
     if (P.eq_nff == 6u && P.eq_nfb == 4u) return med3 ? SAME_PIPE_LAUNCH(6, 4, true) : SAME_PIPE_LAUNCH(6, 4, false);
     return med3 ? SAME_PIPE_LAUNCH(1, 1, true) : SAME_PIPE_LAUNCH(1, 1, false);
 #undef SAME_PIPE_LAUNCH

@@ -396,6 +396,26 @@ def test_pipeline_kernel_equals_single_wavefront_kernel(sa, monkeypatch, rate, n
     assert out["pipe"] == out["fast"]
 
 
+@pytest.mark.parametrize("rate", [22050, 48000])
+def test_pipeline_workgroup_widths(sa, ob, monkeypatch, rate):
+    """Small batches spread over workgroups of 16 or 32 channels instead of 64 (more CUs, fewer
+    divergent paths per wavefront).  Which channels share a wavefront must not matter."""
+    n_ch, n = 192, rate * 5
+    x = mixed_batch(sa, n_ch, n, seed=31 + rate, rate=rate, noise=0.05)
+    out = {}
+    for lanes in ("16", "32", "64"):
+        monkeypatch.setenv("SAME_PIPE_LANES", lanes)         # read at every launch
+        rx = sa.SameReceiverBuilder(rate).build_batch(n_ch)
+        assert rx.kernel_name() == "demod_pipe_kernel"
+        for off in range(0, n, 30001):
+            rx.process_host(x[off:off + 30001])
+        out[lanes] = events_by_channel(rx)
+    assert out["16"] == out["64"] and out["32"] == out["64"]
+    cfg = ob.default_config(rate)
+    for c in range(0, n_ch, 23):
+        assert out["16"].get(c, []) == oracle_events(ob, cfg, x[:, c]), f"channel {c}"
+
+
 def test_i16_input_through_the_pipeline_kernel(sa, ob):
     """int16 samples cast in stage 1 of the pipelined kernel (64 channels => demod_pipe_kernel)."""
     n_ch, n = 64, 22050 * 4
