@@ -83,6 +83,10 @@ template <int NT> struct PipeLayout {
 #ifdef SAME_PROFILE
 // per stage of workgroup 0: cycles working, waiting at the step barrier, handling feedback
 __device__ unsigned long long g_same_prof_pipe[9];
+// [role] = HW_ID of workgroup 0's wavefront in that role (SIMD = bits 5:4); [5] cycles stage 2 polled
+// its helper, [6] cycles the helper worked
+__device__ unsigned long long g_same_prof_hw[8];
+#define P3_HWID(role_) do { if (blockIdx.x == 0 && lane == 0) g_same_prof_hw[role_] = __builtin_amdgcn_s_getreg((31 << 11) | 4); } while (0)
 #define P3_T0() unsigned long long p3_work = 0, p3_wait = 0, p3_fb = 0, p3_t = clock64()
 #define P3_LAP(acc) do { const unsigned long long t_ = clock64(); acc += t_ - p3_t; p3_t = t_; } while (0)
 #define P3_REPORT(role_) do { if (blockIdx.x == 0 && lane == 0) { g_same_prof_pipe[3 * (role_)] += p3_work; \
@@ -91,14 +95,54 @@ __device__ unsigned long long g_same_prof_pipe[9];
 #define P3_T0() do {} while (0)
 #define P3_LAP(acc) do {} while (0)
 #define P3_REPORT(role_) do {} while (0)
+#define P3_HWID(role_) do {} while (0)
 #endif
 
 constexpr uint32_t kP3SymWords = 5u * kWave;              // per parity: header, zero, sym, terr, until
 constexpr uint32_t kP3FbWords = kWave + 32u;              // per parity: one word per lane + the any-flag
 constexpr uint32_t kP3IoWords = 3u * kWave;               // per parity: symbol word, burst-pool slot, burst length
 constexpr uint32_t kP3MailWords = 2u * kP3SymWords + 2u * kP3FbWords + 2u * kP3IoWords +
-                                  2u * kWave;              // + the final TED-phase and wake-up flag bits
-// (the log-chunk words live in the padding of the first feedback box)
+                                  2u * kWave +             // + the final TED-phase and wake-up flag bits
+                                  3u * kWave;              // + SPLIT: instant positions [2][64], space magnitudes [64]
+// (the log-chunk words and SPLIT's sequence word live in the padding of the first feedback box)
+
+// One of the two matched filters (WHICH 0: mark, 1: space) over the mirrored window: the half of
+// demod_fast that one wavefront of the split stage 2 computes.  Same products, same order of
+// accumulation, same hypot -- the two magnitudes are subtracted and clamped by the caller.
+template <int NT, int RING, int WHICH>
+__device__ __forceinline__ float demod_half(const float4 *tlds, const float *wring, uint32_t lane, uint32_t newest)
+{
+    constexpr int CH = 14;
+    float2v acc = {0.0f, 0.0f};
+    const float *wm = wring + ((int)newest + RING - (CH - 1)) * (int)kWave + (int)lane;
+    const float2v *t2 = reinterpret_cast<const float2v *>(tlds) + WHICH;      // tap i: t2[2 * i]
+#pragma unroll 1
+    for (int base = 0; base + CH <= NT; base += CH) {
+        float w[CH];
+        float2v h[CH];
+#pragma unroll
+        for (int j = 0; j < CH; ++j) w[j] = wm[(CH - 1 - j) * (int)kWave];
+        wm -= CH * (int)kWave;
+#pragma unroll
+        for (int j = 0; j < CH; ++j) h[j] = t2[2 * (base + j)];
+#pragma unroll
+        for (int j = 0; j < CH; ++j) { const float2v x2 = {w[j], w[j]}; const float2v pr = x2 * h[j]; acc += pr; }
+    }
+    constexpr int REM = NT % CH;
+    if (REM) {
+        float w[REM ? REM : 1];
+#pragma unroll
+        for (int j = 0; j < REM; ++j) w[j] = wm[(CH - 1 - j) * (int)kWave];
+#pragma unroll
+        for (int j = 0; j < REM; ++j) {
+            const float2v t = t2[2 * (NT - REM + j)];
+            const float2v x2 = {w[j], w[j]};
+            const float2v pr = x2 * t;
+            acc += pr;
+        }
+    }
+    return rs_hypot(acc.x, acc.y);
+}
 
 // Stage 3 keeps the framer rows; a finished burst is copied into the pool here, its slot travels on.
 __device__ __forceinline__ uint32_t burst_to_pool(const State &S, const Output &O, uint32_t c)
@@ -331,8 +375,14 @@ struct SampleStage {
 // every step has a lane with a byte due, a lane whose symbol changes the AGC lock, ...; with 16
 // most steps skip those sections.  Small batches (which leave CUs idle anyway) therefore spread
 // over more workgroups of fewer channels; lanes >= LANES retire at once.
-template <int NT, int NFF, int NFB, bool MED3, bool SHARE, int LANES, typename SampleT>
-__global__ __launch_bounds__(4 * kWave, SHARE ? 2 : 1) void demod_pipe_kernel(Params P, State S, Output O,
+//
+// SPLIT: a fifth wavefront takes the space filter off stage 2 (which keeps the mark filter and the
+// timing loop).  Both need only the position of the block's instant, known a block ahead; stage 2
+// posts it, its helper posts the space magnitude and bumps a sequence word that stage 2 polls
+// before it combines the two -- a hand-over inside the step, no extra block of latency.  The
+// helper shares a SIMD with stage 4, the lightest (wavefronts 0 and 4 of the workgroup).
+template <int NT, int NFF, int NFB, bool MED3, bool SHARE, int LANES, bool SPLIT, typename SampleT>
+__global__ __launch_bounds__((SPLIT ? 5 : 4) * kWave, SHARE ? 2 : 1) void demod_pipe_kernel(Params P, State S, Output O,
                                                                 const float4 *__restrict__ taps,
                                                                 const SampleT *__restrict__ x,
                                                                 uint32_t n_blocks, uint64_t counter0)
@@ -342,7 +392,9 @@ __global__ __launch_bounds__(4 * kWave, SHARE ? 2 : 1) void demod_pipe_kernel(Pa
     static_assert(kB <= 32, "the sample index travels in five bits of the stage 3 -> 4 word");
     extern __shared__ float lds[];
     const uint32_t lane = threadIdx.x & (kWave - 1u);
-    const uint32_t role = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    // role 0..3 = stage 1..4, role 4 = stage 2's space-filter helper
+    const uint32_t role = !SPLIT ? wave : (wave == 0u ? 3u : (wave == 4u ? 4u : wave - 1u));
     const uint32_t C = P.n_channels;
     const uint32_t c = blockIdx.x * (uint32_t)LANES + lane;  // C % LANES == 0 (host)
     // LDS: taps | mailboxes | squelch history [64][64] | window (logical slots kB .. 2*RING-1)
@@ -354,6 +406,9 @@ __global__ __launch_bounds__(4 * kWave, SHARE ? 2 : 1) void demod_pipe_kernel(Pa
     lds_u32 *phasebox = iobox + 2u * kP3IoWords;               // [64] stage 2's final TED phase bit
     lds_u32 *againbox = phasebox + kWave;                      // [64] stage 4's final F_TICK_AGAIN bit
     lds_u32 *chunkbox = fbbox + kWave + 2u;                    // [2], in the first box's padding
+    lds_u32 *seqbox = fbbox + kWave + 4u;                      // SPLIT: the helper's progress, 2 * step + pass
+    lds_u32 *posbox = againbox + kWave;                        // SPLIT: [2][64] sample index of block b's instant
+    lds_u32 *spacebox = posbox + 2u * kWave;                   // SPLIT: [64] space-filter magnitude
     float *hcol = lds + kPipeTapFloats + kP3MailWords + lane;
     float *wring = lds + kPipeTapFloats + kP3MailWords + (kSquelchHist - kB) * LP;   // logical slot 0
     float *wcol = wring + lane;
@@ -365,6 +420,7 @@ __global__ __launch_bounds__(4 * kWave, SHARE ? 2 : 1) void demod_pipe_kernel(Pa
         // ------------------------------ stage 1: sample phase, block s -------------------------
         for (uint32_t i = lane; i < (uint32_t)NT; i += kWave) tlds[i] = taps[i];
         if (LANES < (int)kWave && lane >= (uint32_t)LANES) return;      // (the wavefront goes on without them)
+        P3_HWID(0);
         SampleStage<NT, MED3, SampleT> M;
         M.load(P, S, x, c, C, counter0, wcol, n_blocks);
         P3_T0();
@@ -407,24 +463,41 @@ __global__ __launch_bounds__(4 * kWave, SHARE ? 2 : 1) void demod_pipe_kernel(Pa
     } else if (role == 1u) {
         // ------------------------------ stage 2: filters + timing loop, block s-1 --------------
         if (LANES < (int)kWave && lane >= (uint32_t)LANES) return;
+        P3_HWID(1);
         Lane L;
         lane_load(L, S, c);
         int cstar = next_fire_count(L.until_next_ted, L.ted_clock);
         int until = cstar - (int)L.ted_clock - 1;      // block-relative index of the firing sample
         uint32_t wpos = 0;
         // one block: the instant, if this lane has one in it; hands a completed symbol to stage 3
-        auto do_block = [&](uint32_t blk) {
+        auto do_block = [&](uint32_t blk, uint32_t seq) {
             uint32_t hdr = 0;
             float zero = 0.0f, sym = 0.0f, terr = 0.0f;
             if (until < kB) {
                 const int fk = until;
-                const float sa_low = demod_fast<NT, RING, true>(tlds, wring, lane, wpos + (uint32_t)fk);
+                float sa_low;
+                if constexpr (SPLIT) {
+                    const float hm = demod_half<NT, RING, 0>(tlds, wring, lane, wpos + (uint32_t)fk);
+#ifdef SAME_PROFILE
+                    const unsigned long long spin_t0 = clock64();
+#endif
+                    while ((int32_t)(seqbox[0] - seq) < 0) {}          // the helper has posted this pass
+#ifdef SAME_PROFILE
+                    if (blockIdx.x == 0 && lane == (uint32_t)__builtin_amdgcn_readfirstlane((int)lane))
+                        g_same_prof_hw[5] += clock64() - spin_t0;
+#endif
+                    const float hs = __uint_as_float(spacebox[lane]);
+                    sa_low = rs_clamp(hm - hs, -1.0f, 1.0f);
+                } else {
+                    sa_low = demod_fast<NT, RING, true>(tlds, wring, lane, wpos + (uint32_t)fk);
+                }
                 const float rem = L.until_next_ted - (float)cstar;          // receiver.rs:352
                 if (ted_timing(P, L, sa_low, rem, &zero, &sym, &terr)) hdr = 1u | ((uint32_t)fk << 8);
                 cstar = next_fire_count(L.until_next_ted, 0u);
                 until = fk + cstar;
             }
             until -= kB;
+            if constexpr (SPLIT) posbox[((blk + 1u) & 1u) * kWave + lane] = (uint32_t)until;   // block blk + 1's instant
             lds_u32 *sb = symbox + (blk & 1u) * kP3SymWords + lane;
             sb[0] = hdr;
             sb[kWave] = __float_as_uint(zero); sb[2 * kWave] = __float_as_uint(sym);
@@ -440,7 +513,8 @@ __global__ __launch_bounds__(4 * kWave, SHARE ? 2 : 1) void demod_pipe_kernel(Pa
             const uint32_t k_flags = L.flags;
             const int k_cstar = cstar, k_until = until;
             const bool active = s >= 1u && s <= n_blocks;
-            if (active) do_block(s - 1u);
+            if (active) do_block(s - 1u, 2u * s + 1u);
+            else if (SPLIT && s == 0u) posbox[lane] = (uint32_t)until;       // block 0's instant
             P3_LAP(p3_work);
             lds_barrier();                                             // A
             P3_LAP(p3_wait);
@@ -459,7 +533,7 @@ __global__ __launch_bounds__(4 * kWave, SHARE ? 2 : 1) void demod_pipe_kernel(Pa
                         }
                     }
                     lds_barrier();                                     // B: stage 1 has corrected the window
-                    if ((v & 1u) && active) do_block(s - 1u);
+                    if ((v & 1u) && active) do_block(s - 1u, 2u * s + 2u);
                     lds_barrier();                                     // C
                     P3_LAP(p3_fb);
                 }
@@ -478,6 +552,7 @@ __global__ __launch_bounds__(4 * kWave, SHARE ? 2 : 1) void demod_pipe_kernel(Pa
     } else if (role == 2u) {
         // ------------------------------ stage 3: symbol path, block s-2 ------------------------
         if (LANES < (int)kWave && lane >= (uint32_t)LANES) return;
+        P3_HWID(2);
         Lane L;
         lane_load(L, S, c);
         L.ended = 0u;
@@ -573,11 +648,48 @@ __global__ __launch_bounds__(4 * kWave, SHARE ? 2 : 1) void demod_pipe_kernel(Pa
         }
 #pragma unroll 2
         for (int i = 0; i < kSquelchHist; ++i) { float *row = S.sq_hist + (size_t)i * C; row[c] = hcol[i * LP]; }
+    } else if (SPLIT && role == 4u) {
+        // ------------------------------ stage 2's helper: space filter, block s-1 ---------------
+        if (LANES < (int)kWave && lane >= (uint32_t)LANES) return;
+        uint32_t wpos = 0;
+        if (lane == 0u) seqbox[0] = 0u;
+        P3_HWID(4);
+        for (uint32_t s = 0; s < n_steps; ++s) {
+            const bool active = s >= 1u && s <= n_blocks;
+            uint32_t pos = 0xffffffffu;
+#ifdef SAME_PROFILE
+            const unsigned long long help_t0 = clock64();
+#endif
+            if (active) {
+                pos = posbox[((s - 1u) & 1u) * kWave + lane];          // posted by stage 2 during the last step
+                if (pos < (uint32_t)kB)
+                    spacebox[lane] = __float_as_uint(demod_half<NT, RING, 1>(tlds, wring, lane, wpos + pos));
+                if (lane == 0u) seqbox[0] = 2u * s + 1u;                // (LDS operations of a wavefront stay in order)
+            }
+#ifdef SAME_PROFILE
+            if (blockIdx.x == 0 && lane == 0) g_same_prof_hw[6] += clock64() - help_t0;
+#endif
+            lds_barrier();                                             // A
+            if (s >= 2u && s <= last_fb_step) {
+                const lds_u32 *fb = fbbox + (s & 1u) * kP3FbWords;
+                if (__builtin_amdgcn_readfirstlane((int)fb[kWave])) {
+                    const uint32_t v = fb[lane];
+                    lds_barrier();                                     // B: stage 1 has corrected the window
+                    if ((v & 1u) && active && pos < (uint32_t)kB)
+                        spacebox[lane] = __float_as_uint(demod_half<NT, RING, 1>(tlds, wring, lane, wpos + pos));
+                    if (lane == 0u) seqbox[0] = 2u * s + 2u;
+                    lds_barrier();                                     // C
+                }
+            }
+            if (active) { wpos += kB; if (wpos == (uint32_t)RING) wpos = 0; }
+        }
+        lds_barrier();                                                 // (the final exchange of the other stages)
     } else {
         // ------------------------------ stage 4: link events + wake-ups, block s-3 -------------
         if (LANES < (int)kWave && lane >= (uint32_t)LANES) return;
         Lane L;
         lane_load(L, S, c);                    // uses sq_symbols, tk_next, tk_last, wake_*, F_TICK_AGAIN
+        P3_HWID(3);
         IoCtx X;
         X.chunk = chunkbox;
         chunkbox[0] = 0u; chunkbox[1] = kEvChunk;       // nothing reserved yet
@@ -653,12 +765,12 @@ uint32_t pipe_kernel_stages(const Params &P)
 bool pipe_kernel_selected(const Params &P) { return pipe_kernel_stages(P) != 0u; }
 uint32_t pipe_block_len(const Params &P) { return P.ntaps == 42u ? (uint32_t)kBlockMirror : (uint32_t)kBlock48k; }
 
-template <int NT, int NFF, int NFB, bool M3, bool SHARE, int LANES, typename SampleT>
+template <int NT, int NFF, int NFB, bool M3, bool SHARE, int LANES, bool SPLIT, typename SampleT>
 static hipError_t launch_pipe_one(const Params &P, const State &S, const Output &O, const float4 *taps,
                                   const SampleT *x, uint32_t n_blocks, uint64_t counter0, hipStream_t stream)
 {
     constexpr size_t lds = pipe_lds_bytes<NT>();
-    auto *kernel = demod_pipe_kernel<NT, NFF, NFB, M3, SHARE, LANES, SampleT>;
+    auto *kernel = demod_pipe_kernel<NT, NFF, NFB, M3, SHARE, LANES, SPLIT, SampleT>;
     if (lds > 64u * 1024u) {
         // more than the default 64 KB of dynamic LDS per workgroup: opt in, once per kernel and device
         static bool opted_in[64] = {};
@@ -671,7 +783,7 @@ static hipError_t launch_pipe_one(const Params &P, const State &S, const Output 
             opted_in[dev] = true;
         }
     }
-    hipLaunchKernelGGL(kernel, dim3(P.n_channels / (uint32_t)LANES), dim3(4 * kWave), lds, stream, P, S, O, taps, x, n_blocks, counter0);
+    hipLaunchKernelGGL(kernel, dim3(P.n_channels / (uint32_t)LANES), dim3((SPLIT ? 5 : 4) * kWave), lds, stream, P, S, O, taps, x, n_blocks, counter0);
     return hipGetLastError();
 }
 
@@ -684,12 +796,21 @@ static hipError_t launch_pipe_cfg(const Params &P, const State &S, const Output 
     const bool share = CAN_SHARE && P.n_channels > 16384u;
     const bool med3 = agc_clamp_is_med3(P);
 #define SAME_PIPE_LAUNCH(NFF, NFB, M3)                                                                                  \
-    (share ? launch_pipe_one<NT, NFF, NFB, M3, CAN_SHARE, 64, SampleT>(P, S, O, taps, x, n_blocks, counter0, stream)    \
-           : launch_pipe_one<NT, NFF, NFB, M3, false, 64, SampleT>(P, S, O, taps, x, n_blocks, counter0, stream))
+    (share ? launch_pipe_one<NT, NFF, NFB, M3, CAN_SHARE, 64, false, SampleT>(P, S, O, taps, x, n_blocks, counter0, stream)    \
+           : launch_pipe_one<NT, NFF, NFB, M3, false, 64, false, SampleT>(P, S, O, taps, x, n_blocks, counter0, stream))
     const uint32_t lanes = pipe_lanes(P);
     if (lanes != kWave) {                      // (default equalizer, med3: see pipe_lanes)
-        if (lanes == 16u) return launch_pipe_one<NT, 6, 4, true, false, 16, SampleT>(P, S, O, taps, x, n_blocks, counter0, stream);
-        return launch_pipe_one<NT, 6, 4, true, false, 32, SampleT>(P, S, O, taps, x, n_blocks, counter0, stream);
+        // the fifth wavefront halves every wavefront's register budget (two on one SIMD): at 44.1 / 48 kHz
+        // stage 1 (32-sample blocks, longer DC windows) would spill, so only 22.05 kHz splits stage 2
+        constexpr bool CAN_SPLIT = (NT == 42);
+        const char *e = getenv("SAME_PIPE_SPLIT");
+        const bool split = CAN_SPLIT && (e ? atoi(e) != 0 : true);
+        if (lanes == 16u) {
+            if (split) return launch_pipe_one<NT, 6, 4, true, false, 16, CAN_SPLIT, SampleT>(P, S, O, taps, x, n_blocks, counter0, stream);
+            return launch_pipe_one<NT, 6, 4, true, false, 16, false, SampleT>(P, S, O, taps, x, n_blocks, counter0, stream);
+        }
+        if (split) return launch_pipe_one<NT, 6, 4, true, false, 32, CAN_SPLIT, SampleT>(P, S, O, taps, x, n_blocks, counter0, stream);
+        return launch_pipe_one<NT, 6, 4, true, false, 32, false, SampleT>(P, S, O, taps, x, n_blocks, counter0, stream);
     }
     if (P.eq_nff == 6u && P.eq_nfb == 4u) return med3 ? SAME_PIPE_LAUNCH(6, 4, true) : SAME_PIPE_LAUNCH(6, 4, false);
     return med3 ? SAME_PIPE_LAUNCH(1, 1, true) : SAME_PIPE_LAUNCH(1, 1, false);
@@ -715,6 +836,13 @@ hipError_t launch_demod_pipe_i16(const Params &P, const State &S, const Output &
 }  // namespace same
 
 #ifdef SAME_PROFILE
+extern "C" int same_debug_profile_hw(unsigned long long *out8, int reset)
+{
+    unsigned long long z[8] = {0};
+    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(same::g_same_prof_hw), sizeof(z)) != hipSuccess) return -1;
+    if (reset && hipMemcpyToSymbol(HIP_SYMBOL(same::g_same_prof_hw), z, sizeof(z)) != hipSuccess) return -1;
+    return 0;
+}
 extern "C" int same_debug_profile_pipe(unsigned long long *out9, int reset)
 {
     unsigned long long z[9] = {0};

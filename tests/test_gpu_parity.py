@@ -411,6 +411,11 @@ def test_pipeline_workgroup_widths(sa, ob, monkeypatch, rate):
             rx.process_host(x[off:off + 30001])
         out[lanes] = events_by_channel(rx)
     assert out["16"] == out["64"] and out["32"] == out["64"]
+    # 22.05 kHz: the narrow workgroups also split stage 2 over two wavefronts (mark / space filter)
+    monkeypatch.setenv("SAME_PIPE_LANES", "16"); monkeypatch.setenv("SAME_PIPE_SPLIT", "0")
+    rx = sa.SameReceiverBuilder(rate).build_batch(n_ch)
+    rx.process_host(x)
+    assert events_by_channel(rx) == out["64"]
     cfg = ob.default_config(rate)
     for c in range(0, n_ch, 23):
         assert out["16"].get(c, []) == oracle_events(ob, cfg, x[:, c]), f"channel {c}"

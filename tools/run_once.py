@@ -47,3 +47,9 @@ if hasattr(rx._L, "same_debug_profile_pipe") and "pipe" in rx.kernel_name():
       for r, name in enumerate(["stage 1 (sample phase)", "stage 2 (filters + timing)", "stage 3 (symbol path)"]):
         w, b, f = buf[3 * r], buf[3 * r + 1], buf[3 * r + 2]
         print(f"  {name:28s} work {w/nstep:8.1f}  barrier wait {b/nstep:8.1f}  feedback {f/nstep:8.1f}  clk/step (total {(w+b+f)/nstep:8.1f})")
+    if hasattr(rx._L, "same_debug_profile_hw"):
+        hw = (ctypes.c_ulonglong * 8)()
+        rx._L.same_debug_profile_hw(hw, 1)
+        print("  HW_ID (SIMD) per role [stage1, stage2, stage3, stage4, helper]:",
+              [f"{int(v) & 0xffffffff:#x} (simd {(int(v) >> 4) & 3})" for v in hw[:5]])
+        print(f"  stage 2 polled its helper {hw[5]/nstep:8.1f} clk/step; helper worked {hw[6]/nstep:8.1f} clk/step")
