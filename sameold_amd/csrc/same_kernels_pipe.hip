@@ -55,6 +55,11 @@ template <> struct PipeGeom<92> { static constexpr int DCL = 35, B = kBlock48k; 
 template <> struct PipeGeom<84> { static constexpr int DCL = 32, B = kBlock48k; };      // 44.1 kHz
 template <int NT> struct PipeLayout {
     static constexpr int B = PipeGeom<NT>::B, RING = 5 * B;
+    // stage 1 keeps the DC-blocker outputs of its last three blocks for a replay: in registers
+    // (3 x 18) at 22.05 kHz, in an LDS ring of three blocks at 44.1 / 48 kHz, where 3 x 32 more
+    // registers per lane would spill and the CU's LDS has room
+    static constexpr bool YLDS = B > kBlockMirror;
+    static constexpr uint32_t yring_floats = YLDS ? 3u * (uint32_t)B * kWave : 0u;
 #ifdef SAME_PROFILE
     static constexpr uint32_t tap_floats = (uint32_t)((NT * 4 + 20 + 63) / 64 * 64);
 #else
@@ -203,13 +208,16 @@ template <int NT_, bool MED3, typename SampleT>
 struct SampleStage {
     static constexpr int NT = NT_, DCL = PipeGeom<NT_>::DCL, kB = PipeLayout<NT_>::B, RING = PipeLayout<NT_>::RING;
     static constexpr uint32_t LP = kWave;
+    static constexpr bool YLDS = PipeLayout<NT_>::YLDS;
+    float *ycol;                         // YLDS: this lane's column of the ring [3][kB][64]
+    uint32_t ycur;                       // YLDS: ring block of the newest block (slot j back: (ycur + 3 - j) % 3)
     float sum0, sum1, gain;
     bool locked;                         // this stage's belief of the AGC lock
     float xp[DCL], mp[DCL];              // the last DCL inputs / first-stage averages, oldest first
     float xn[2][kB];                     // prefetched inputs of the next two blocks: block b waits in xn[b & 1]
                                          // (a step is shorter than an HBM round trip with a TLB miss, so
                                          // the prefetch distance is two steps)
-    float ys[3][kB];                     // DC-blocker outputs: [0] newest block ... [2] two blocks back
+    float ys[YLDS ? 1 : 3][kB];          // DC-blocker outputs: [0] newest block ... [2] two blocks back
     float g0[3];                         // AGC gain each of them started with
     uint32_t wp[3];                      // their ring positions
     uint32_t wnext;                      // ring position of the block computed next
@@ -247,29 +255,55 @@ struct SampleStage {
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
             g0[j] = gain; wp[j] = 0;
+            if (!YLDS || j == 0) {
 #pragma unroll
-            for (int k = 0; k < kB; ++k) ys[j][k] = 0.0f;
+                for (int k = 0; k < kB; ++k) ys[YLDS ? 0 : j][k] = 0.0f;
+            }
         }
+        ycur = 0;
         wnext = 0;
     }
 
     __device__ __forceinline__ void rotate()
     {
+        if constexpr (YLDS) {
+            ycur = ycur == 2u ? 0u : ycur + 1u;          // every step, like the register rotation
+        } else {
 #pragma unroll
-        for (int k = 0; k < kB; ++k) { ys[2][k] = ys[1][k]; ys[1][k] = ys[0][k]; }
+            for (int k = 0; k < kB; ++k) { ys[2][k] = ys[1][k]; ys[1][k] = ys[0][k]; }
+        }
         g0[2] = g0[1]; g0[1] = g0[0];
         wp[2] = wp[1]; wp[1] = wp[0];
     }
 
     __device__ __forceinline__ void push_block(const Params &P, float *wcol, int j, float &g, int fk, float bw0, float bw1)
     {
+        if constexpr (YLDS) {
+            if (j != 0) {                  // (only a replay gets here: the block's outputs come back from the ring)
+                const uint32_t yb = ycur + 3u - (uint32_t)j;
+                const float *y = ycol + ((yb >= 3u ? yb - 3u : yb) * (uint32_t)kB) * LP;
+                float yv[kB];
+#pragma unroll
+                for (int k = 0; k < kB; ++k) yv[k] = y[k * LP];
+                float *wblk = wcol + wp[j] * LP;
+                float *wlow = wcol + (wp[j] == 0u ? (uint32_t)RING : wp[j]) * LP;
+#pragma unroll
+                for (int k = 0; k < kB; ++k) {
+                    const float out = agc_step<MED3>(P, yv[k], g, (k <= fk) ? bw0 : bw1);
+                    wlow[k * LP] = out;
+                    wblk[(k + RING) * LP] = out;
+                }
+                return;
+            }
+        }
+        const int jj = YLDS ? 0 : j;
         // AGC (rx/agc.rs:72-77) and window push (receiver.rs:345-346) of the block in slot j:
         // bandwidth bw0 up to sample fk, bw1 after it
         float *wblk = wcol + wp[j] * LP;
         float *wlow = wcol + (wp[j] == 0u ? (uint32_t)RING : wp[j]) * LP;
 #pragma unroll
         for (int k = 0; k < kB; ++k) {
-            const float out = agc_step<MED3>(P, ys[j][k], g, (k <= fk) ? bw0 : bw1);
+            const float out = agc_step<MED3>(P, ys[jj][k], g, (k <= fk) ? bw0 : bw1);
             wlow[k * LP] = out;
             wblk[(k + RING) * LP] = out;
         }
@@ -320,6 +354,11 @@ struct SampleStage {
         for (int k = 0; k < DCL; ++k) {
             xp[k] = kB + k < DCL ? xp[kB + k < DCL ? kB + k : 0] : xs[kB + k >= DCL ? kB + k - DCL : 0];
             mp[k] = kB + k < DCL ? mp[kB + k < DCL ? kB + k : 0] : mnew[kB + k >= DCL ? kB + k - DCL : 0];
+        }
+        if constexpr (YLDS) {
+            float *y = ycol + (ycur * (uint32_t)kB) * LP;
+#pragma unroll
+            for (int k = 0; k < kB; ++k) y[k * LP] = ys[0][k];
         }
         g0[0] = gain;
         wp[0] = wnext;
@@ -397,7 +436,7 @@ __global__ __launch_bounds__((SPLIT ? 5 : 4) * kWave, SHARE ? 2 : 1) void demod_
     const uint32_t role = !SPLIT ? wave : (wave == 0u ? 3u : (wave == 4u ? 4u : wave - 1u));
     const uint32_t C = P.n_channels;
     const uint32_t c = blockIdx.x * (uint32_t)LANES + lane;  // C % LANES == 0 (host)
-    // LDS: taps | mailboxes | squelch history [64][64] | window (logical slots kB .. 2*RING-1)
+    // LDS: taps | mailboxes | squelch history [64][64] | window (logical slots kB .. 2*RING-1) | stage 1's ring (YLDS)
     float4 *tlds = reinterpret_cast<float4 *>(lds);
     lds_u32 *mail = (lds_u32 *)(lds + kPipeTapFloats);
     lds_u32 *symbox = mail;                                    // [2][5][64]
@@ -422,6 +461,7 @@ __global__ __launch_bounds__((SPLIT ? 5 : 4) * kWave, SHARE ? 2 : 1) void demod_
         if (LANES < (int)kWave && lane >= (uint32_t)LANES) return;      // (the wavefront goes on without them)
         P3_HWID(0);
         SampleStage<NT, MED3, SampleT> M;
+        M.ycol = wring + (2u * (uint32_t)RING) * LP + lane;           // behind the window
         M.load(P, S, x, c, C, counter0, wcol, n_blocks);
         P3_T0();
         // one step; BUF = s & 1 names the prefetch registers statically, so the loop runs two steps a turn
@@ -727,7 +767,7 @@ __global__ __launch_bounds__((SPLIT ? 5 : 4) * kWave, SHARE ? 2 : 1) void demod_
 template <int NT>
 static constexpr size_t pipe_lds_bytes()
 {
-    return ((size_t)PipeLayout<NT>::tap_floats + kP3MailWords +
+    return ((size_t)PipeLayout<NT>::tap_floats + kP3MailWords + PipeLayout<NT>::yring_floats +
             (size_t)(kSquelchHist + 2 * PipeLayout<NT>::RING - PipeLayout<NT>::B) * kWave) * sizeof(float);
 }
 
