@@ -1,11 +1,17 @@
-// Calibration of rocprofv3 FETCH_SIZE for this project's access pattern: every lane reads one
-// dword per time step from a time-major array x[t][channel] (256 contiguous bytes per
-// wavefront-instruction), exactly like the demodulation kernel.  Known byte count: T*C*4.
+// Calibration of rocprofv3 FETCH_SIZE for this project's access pattern: every live lane reads one
+// dword per time step from a time-major array x[t][channel], exactly like the demodulation
+// kernels.  Two launches shapes, three launches each, known byte count T*C*4 for both:
+//   read_time_major<64>: 64 channels per wavefront (256 contiguous bytes per wavefront-instruction),
+//                        the one-wavefront kernels and the 64-channel pipeline workgroups;
+//   read_time_major<16>: 16 channels per wavefront (64 contiguous bytes), the narrow pipeline
+//                        workgroups small batches use.
 #include <hip/hip_runtime.h>
 #include <cstdio>
+template <int LANES>
 __global__ void read_time_major(const float *x, float *out, unsigned C, unsigned T)
 {
-    unsigned c = blockIdx.x * 64 + threadIdx.x;
+    if (threadIdx.x >= LANES) return;
+    unsigned c = blockIdx.x * LANES + threadIdx.x;
     if (c >= C) return;
     float acc = 0.f;
     for (unsigned t = 0; t < T; t += 16) {
@@ -23,7 +29,8 @@ int main()
     float *x, *out;
     hipMalloc(&x, (size_t)C * T * 4); hipMalloc(&out, C * 4);
     hipMemset(x, 0, (size_t)C * T * 4);
-    for (int r = 0; r < 3; ++r) hipLaunchKernelGGL(read_time_major, dim3(C / 64), dim3(64), 0, 0, x, out, C, T);
+    for (int r = 0; r < 3; ++r) hipLaunchKernelGGL(read_time_major<64>, dim3(C / 64), dim3(64), 0, 0, x, out, C, T);
+    for (int r = 0; r < 3; ++r) hipLaunchKernelGGL(read_time_major<16>, dim3(C / 16), dim3(64), 0, 0, x, out, C, T);
     hipDeviceSynchronize();
     printf("known bytes read per launch: %zu\n", (size_t)C * T * 4);
     return 0;
