@@ -415,13 +415,13 @@ struct SampleStage {
 // most steps skip those sections.  Small batches (which leave CUs idle anyway) therefore spread
 // over more workgroups of fewer channels; lanes >= LANES retire at once.
 //
-// SPLIT: a fifth wavefront takes the space filter off stage 2 (which keeps the mark filter and the
-// timing loop).  Both need only the position of the block's instant, known a block ahead; stage 2
-// posts it, its helper posts the space magnitude and bumps a sequence word that stage 2 polls
-// before it combines the two -- a hand-over inside the step, no extra block of latency.  The
-// helper shares a SIMD with stage 4, the lightest (wavefronts 0 and 4 of the workgroup).
+// SPLIT: stage 4's wavefront, the lightest, takes the space filter off stage 2 (which keeps the
+// mark filter and the timing loop).  Both filters need only the position of the block's instant,
+// known a block ahead; stage 2 posts it, stage 4 computes the space magnitude first thing in its
+// step, posts it and bumps a sequence word that stage 2 polls before it combines the two -- a
+// hand-over inside the step, no extra block of latency.
 template <int NT, int NFF, int NFB, bool MED3, bool SHARE, int LANES, bool SPLIT, typename SampleT>
-__global__ __launch_bounds__((SPLIT ? 5 : 4) * kWave, SHARE ? 2 : 1) void demod_pipe_kernel(Params P, State S, Output O,
+__global__ __launch_bounds__(4 * kWave, SHARE ? 2 : 1) void demod_pipe_kernel(Params P, State S, Output O,
                                                                 const float4 *__restrict__ taps,
                                                                 const SampleT *__restrict__ x,
                                                                 uint32_t n_blocks, uint64_t counter0)
@@ -431,9 +431,7 @@ __global__ __launch_bounds__((SPLIT ? 5 : 4) * kWave, SHARE ? 2 : 1) void demod_
     static_assert(kB <= 32, "the sample index travels in five bits of the stage 3 -> 4 word");
     extern __shared__ float lds[];
     const uint32_t lane = threadIdx.x & (kWave - 1u);
-    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    // role 0..3 = stage 1..4, role 4 = stage 2's space-filter helper
-    const uint32_t role = !SPLIT ? wave : (wave == 0u ? 3u : (wave == 4u ? 4u : wave - 1u));
+    const uint32_t role = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // 0..3 = stage 1..4
     const uint32_t C = P.n_channels;
     const uint32_t c = blockIdx.x * (uint32_t)LANES + lane;  // C % LANES == 0 (host)
     // LDS: taps | mailboxes | squelch history [64][64] | window (logical slots kB .. 2*RING-1) | stage 1's ring (YLDS)
@@ -688,42 +686,6 @@ __global__ __launch_bounds__((SPLIT ? 5 : 4) * kWave, SHARE ? 2 : 1) void demod_
         }
 #pragma unroll 2
         for (int i = 0; i < kSquelchHist; ++i) { float *row = S.sq_hist + (size_t)i * C; row[c] = hcol[i * LP]; }
-    } else if (SPLIT && role == 4u) {
-        // ------------------------------ stage 2's helper: space filter, block s-1 ---------------
-        if (LANES < (int)kWave && lane >= (uint32_t)LANES) return;
-        uint32_t wpos = 0;
-        if (lane == 0u) seqbox[0] = 0u;
-        P3_HWID(4);
-        for (uint32_t s = 0; s < n_steps; ++s) {
-            const bool active = s >= 1u && s <= n_blocks;
-            uint32_t pos = 0xffffffffu;
-#ifdef SAME_PROFILE
-            const unsigned long long help_t0 = clock64();
-#endif
-            if (active) {
-                pos = posbox[((s - 1u) & 1u) * kWave + lane];          // posted by stage 2 during the last step
-                if (pos < (uint32_t)kB)
-                    spacebox[lane] = __float_as_uint(demod_half<NT, RING, 1>(tlds, wring, lane, wpos + pos));
-                if (lane == 0u) seqbox[0] = 2u * s + 1u;                // (LDS operations of a wavefront stay in order)
-            }
-#ifdef SAME_PROFILE
-            if (blockIdx.x == 0 && lane == 0) g_same_prof_hw[6] += clock64() - help_t0;
-#endif
-            lds_barrier();                                             // A
-            if (s >= 2u && s <= last_fb_step) {
-                const lds_u32 *fb = fbbox + (s & 1u) * kP3FbWords;
-                if (__builtin_amdgcn_readfirstlane((int)fb[kWave])) {
-                    const uint32_t v = fb[lane];
-                    lds_barrier();                                     // B: stage 1 has corrected the window
-                    if ((v & 1u) && active && pos < (uint32_t)kB)
-                        spacebox[lane] = __float_as_uint(demod_half<NT, RING, 1>(tlds, wring, lane, wpos + pos));
-                    if (lane == 0u) seqbox[0] = 2u * s + 2u;
-                    lds_barrier();                                     // C
-                }
-            }
-            if (active) { wpos += kB; if (wpos == (uint32_t)RING) wpos = 0; }
-        }
-        lds_barrier();                                                 // (the final exchange of the other stages)
     } else {
         // ------------------------------ stage 4: link events + wake-ups, block s-3 -------------
         if (LANES < (int)kWave && lane >= (uint32_t)LANES) return;
@@ -734,7 +696,24 @@ __global__ __launch_bounds__((SPLIT ? 5 : 4) * kWave, SHARE ? 2 : 1) void demod_
         X.chunk = chunkbox;
         chunkbox[0] = 0u; chunkbox[1] = kEvChunk;       // nothing reserved yet
         X.pending_slot = 0xffffffffu;
+        uint32_t wpos = 0;                     // SPLIT: ring slot of block s-1's first sample
+        if (SPLIT && lane == 0u) seqbox[0] = 0u;
         for (uint32_t s = 0; s < n_steps; ++s) {
+            // SPLIT: first the space filter of block s-1 for stage 2, which waits for it
+            const bool active = SPLIT && s >= 1u && s <= n_blocks;
+            uint32_t pos = 0xffffffffu;
+#ifdef SAME_PROFILE
+            const unsigned long long help_t0 = clock64();
+#endif
+            if (active) {
+                pos = posbox[((s - 1u) & 1u) * kWave + lane];              // posted by stage 2 during the last step
+                if (pos < (uint32_t)kB)
+                    spacebox[lane] = __float_as_uint(demod_half<NT, RING, 1>(tlds, wring, lane, wpos + pos));
+                if (lane == 0u) seqbox[0] = 2u * s + 1u;                    // (LDS operations of a wavefront stay in order)
+            }
+#ifdef SAME_PROFILE
+            if (SPLIT && blockIdx.x == 0 && lane == 0) g_same_prof_hw[6] += clock64() - help_t0;
+#endif
             if (s >= 3u) {
                 const uint32_t blk = s - 3u;
                 const lds_u32 *io = iobox + ((s - 1u) & 1u) * kP3IoWords + lane;   // what stage 3 posted last step
@@ -751,8 +730,18 @@ __global__ __launch_bounds__((SPLIT ? 5 : 4) * kWave, SHARE ? 2 : 1) void demod_
             lds_barrier();                                             // A
             if (s >= 2u && s <= last_fb_step) {
                 const lds_u32 *fb = fbbox + (s & 1u) * kP3FbWords;
-                if (__builtin_amdgcn_readfirstlane((int)fb[kWave])) { lds_barrier(); lds_barrier(); }   // B, C
+                if (__builtin_amdgcn_readfirstlane((int)fb[kWave])) {
+                    const uint32_t v = SPLIT ? fb[lane] : 0u;
+                    lds_barrier();                                     // B: stage 1 has corrected the window
+                    if (SPLIT) {
+                        if ((v & 1u) && active && pos < (uint32_t)kB)
+                            spacebox[lane] = __float_as_uint(demod_half<NT, RING, 1>(tlds, wring, lane, wpos + pos));
+                        if (lane == 0u) seqbox[0] = 2u * s + 2u;
+                    }
+                    lds_barrier();                                     // C
+                }
             }
+            if (active) { wpos += kB; if (wpos == (uint32_t)RING) wpos = 0; }
         }
         X.retire(O, lane, (uint32_t)LANES);
         againbox[lane] = L.flags & F_TICK_AGAIN;
@@ -823,7 +812,7 @@ static hipError_t launch_pipe_one(const Params &P, const State &S, const Output 
             opted_in[dev] = true;
         }
     }
-    hipLaunchKernelGGL(kernel, dim3(P.n_channels / (uint32_t)LANES), dim3((SPLIT ? 5 : 4) * kWave), lds, stream, P, S, O, taps, x, n_blocks, counter0);
+    hipLaunchKernelGGL(kernel, dim3(P.n_channels / (uint32_t)LANES), dim3(4 * kWave), lds, stream, P, S, O, taps, x, n_blocks, counter0);
     return hipGetLastError();
 }
 
@@ -839,18 +828,19 @@ static hipError_t launch_pipe_cfg(const Params &P, const State &S, const Output 
     (share ? launch_pipe_one<NT, NFF, NFB, M3, CAN_SHARE, 64, false, SampleT>(P, S, O, taps, x, n_blocks, counter0, stream)    \
            : launch_pipe_one<NT, NFF, NFB, M3, false, 64, false, SampleT>(P, S, O, taps, x, n_blocks, counter0, stream))
     const uint32_t lanes = pipe_lanes(P);
-    if (lanes != kWave) {                      // (default equalizer, med3: see pipe_lanes)
-        // the fifth wavefront halves every wavefront's register budget (two on one SIMD): at 44.1 / 48 kHz
-        // stage 1 (32-sample blocks, longer DC windows) would spill, so only 22.05 kHz splits stage 2
-        constexpr bool CAN_SPLIT = (NT == 42);
+    if (P.eq_nff == 6u && P.eq_nfb == 4u && med3 && !share) {
+        // the default configuration: narrow workgroups for small batches, and stage 2 split with stage 4's
+        // wavefront wherever stage 2 is (one of) the longest -- everywhere except 64-channel workgroups at
+        // 22.05 kHz, whose symbol stage is longer still
         const char *e = getenv("SAME_PIPE_SPLIT");
-        const bool split = CAN_SPLIT && (e ? atoi(e) != 0 : true);
-        if (lanes == 16u) {
-            if (split) return launch_pipe_one<NT, 6, 4, true, false, 16, CAN_SPLIT, SampleT>(P, S, O, taps, x, n_blocks, counter0, stream);
-            return launch_pipe_one<NT, 6, 4, true, false, 16, false, SampleT>(P, S, O, taps, x, n_blocks, counter0, stream);
-        }
-        if (split) return launch_pipe_one<NT, 6, 4, true, false, 32, CAN_SPLIT, SampleT>(P, S, O, taps, x, n_blocks, counter0, stream);
-        return launch_pipe_one<NT, 6, 4, true, false, 32, false, SampleT>(P, S, O, taps, x, n_blocks, counter0, stream);
+        const bool split = e ? atoi(e) != 0 : (NT != 42 || lanes != kWave);
+#define SAME_PIPE_LANES_LAUNCH(LN)                                                                                          \
+        (split ? launch_pipe_one<NT, 6, 4, true, false, LN, true, SampleT>(P, S, O, taps, x, n_blocks, counter0, stream)    \
+               : launch_pipe_one<NT, 6, 4, true, false, LN, false, SampleT>(P, S, O, taps, x, n_blocks, counter0, stream))
+        if (lanes == 16u) return SAME_PIPE_LANES_LAUNCH(16);
+        if (lanes == 32u) return SAME_PIPE_LANES_LAUNCH(32);
+        return SAME_PIPE_LANES_LAUNCH(64);
+#undef SAME_PIPE_LANES_LAUNCH
     }
     if (P.eq_nff == 6u && P.eq_nfb == 4u) return med3 ? SAME_PIPE_LAUNCH(6, 4, true) : SAME_PIPE_LAUNCH(6, 4, false);
     return med3 ? SAME_PIPE_LAUNCH(1, 1, true) : SAME_PIPE_LAUNCH(1, 1, false);
