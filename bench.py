@@ -63,12 +63,13 @@ def run_steps(sa, rx, x, T, stream, steps, warmup, gather, barrier):
     last_bursts = [0]
 
     def consume():
-        ev = rx.poll_events_np()           # non-blocking: what the host already has
+        ev = rx.peek_events_np()           # non-blocking: what the host already has, viewed in place
         if len(ev):
             kernel_ms.append(rx.last_kernel_ms())
             if keep_first[0]:
-                first.append(ev)
-            last_bursts[0] = gather(ev)
+                first.append(ev.copy())
+            last_bursts[0] = gather(ev)    # (copies the burst records out)
+            rx.drop_events(len(ev))
 
     def one_pass():
         rx.process_device_ptr(x.data_ptr(), T, sa.LAYOUT_TIME_MAJOR, stream)
@@ -87,12 +88,17 @@ def run_steps(sa, rx, x, T, stream, steps, warmup, gather, barrier):
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    marks = []
     for _ in range(steps):
         one_pass()
+        marks.append(time.perf_counter())
     drain()
+    marks.append(time.perf_counter())
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
+    if os.environ.get("SAME_BENCH_DEBUG"):
+        sys.stderr.write("per-pass wall ms (last = drain): " + " ".join(f"{1e3 * (b - a):.2f}" for a, b in zip([t0] + marks[:-1], marks)) + "\n")
     first_ev = np.concatenate(first) if first else np.zeros(0, dtype=sa.receiver.EVENT_DTYPE)
     first_ev = first_ev[first_ev["sample_counter"] <= T]     # the very first pass only
     return elapsed, sum(kernel_ms) / max(len(kernel_ms), 1), first_ev, last_bursts[0]

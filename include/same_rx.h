@@ -183,6 +183,12 @@ int same_batch_sync(same_batch *rx);
 int same_batch_poll_events(same_batch *rx, same_rx_event *out, size_t cap, size_t *n_out,
                            size_t *n_left);
 size_t same_batch_pending_events(same_batch *rx);
+/* The same queue without the copy: *events points at *n queued events inside the handle, valid
+ * until the next call on this handle other than same_batch_pending_events; same_batch_drop_events
+ * then removes the first n of them (n <= *n of the last peek).  For consumers that scan the queue
+ * once and keep only the few events they care about (the bursts, say). */
+int same_batch_peek_events(same_batch *rx, const same_rx_event **events, size_t *n);
+int same_batch_drop_events(same_batch *rx, size_t n);
 
 /* soft-symbol trace (SAME_BATCH_TRACE_SYMBOLS): SymbolEstimate stream of one channel
  * (rx/symsync.rs:52-71) with the input sample counter of each TED instant */

@@ -644,6 +644,23 @@ int same_batch_poll_events(same_batch *rx, same_rx_event *out, size_t cap, size_
     return SAME_OK;
 }
 
+int same_batch_peek_events(same_batch *rx, const same_rx_event **events, size_t *n)
+{
+    if (!rx || !events || !n) return fail(SAME_EINVAL, "null argument");
+    *n = rx->queue.size() - rx->queue_head;
+    *events = *n ? rx->queue.data() + rx->queue_head : nullptr;
+    return SAME_OK;
+}
+
+int same_batch_drop_events(same_batch *rx, size_t n)
+{
+    if (!rx) return fail(SAME_EINVAL, "null argument");
+    if (n > rx->queue.size() - rx->queue_head) return fail(SAME_EINVAL, "more events than are queued");
+    rx->queue_head += n;
+    if (rx->queue_head == rx->queue.size()) { rx->queue.clear(); rx->queue_head = 0; }
+    return SAME_OK;
+}
+
 int same_batch_read_trace(same_batch *rx, uint32_t channel, same_symbol_trace *out, size_t cap, size_t *n_out)
 {
     if (!rx || !n_out) return fail(SAME_EINVAL, "null argument");

@@ -248,7 +248,7 @@ bool Transport::on_link_event(uint32_t kind, uint64_t sample_counter, uint64_t s
     if (same) return false;
     state_kind_ = st;
     if (is_msg) state_msg_ = msg; else clear_result(&state_msg_);
-    std::memset(out, 0, offsetof(same_rx_event, bytes));
+    std::memset(out, 0, sizeof(*out));          // payload bytes past `len` are zero, never stack contents
     out->kind = st;
     out->sample_counter = sample_counter;
     out->symbol_count = symbol_count;

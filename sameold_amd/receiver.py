@@ -173,6 +173,8 @@ def load_library() -> C.CDLL:
     sig("same_batch_sync", C.c_int, vp)
     sig("same_batch_poll_events", C.c_int, vp, P(Event), C.c_size_t, P(C.c_size_t), P(C.c_size_t))
     sig("same_batch_pending_events", C.c_size_t, vp)
+    sig("same_batch_peek_events", C.c_int, vp, P(P(Event)), P(C.c_size_t))
+    sig("same_batch_drop_events", C.c_int, vp, C.c_size_t)
     sig("same_batch_read_trace", C.c_int, vp, u32, P(SymbolTrace), C.c_size_t, P(C.c_size_t))
     sig("same_batch_last_kernel_ms", C.c_int, vp, P(f32))
     sig("same_batch_set_kernel_timing", None, vp, C.c_int)
@@ -417,6 +419,22 @@ class SameBatchReceiver:
                                                   C.byref(n), C.byref(left)))
             out = out[: n.value]
         return out
+
+    def peek_events_np(self) -> np.ndarray:
+        """The queued events as a read-only numpy view INTO the handle (same_batch_peek_events):
+        no copy.  Valid until the next call on this receiver other than `drop_events`; copy what
+        you keep, then `drop_events(len(view))`."""
+        ptr, n = C.POINTER(Event)(), C.c_size_t()
+        _check(self._L.same_batch_peek_events(self._h, C.byref(ptr), C.byref(n)))
+        if not n.value:
+            return np.zeros(0, dtype=EVENT_DTYPE)
+        buf = (C.c_char * (n.value * C.sizeof(Event))).from_address(C.addressof(ptr.contents))
+        out = np.frombuffer(buf, dtype=EVENT_DTYPE, count=n.value)
+        out.flags.writeable = False
+        return out
+
+    def drop_events(self, n: int) -> None:
+        _check(self._L.same_batch_drop_events(self._h, n))
 
     def read_trace(self, channel: int, cap: int = 4096) -> np.ndarray:
         buf = (SymbolTrace * cap)()

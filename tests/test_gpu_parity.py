@@ -421,6 +421,28 @@ def test_pipeline_workgroup_widths(sa, ob, monkeypatch, rate):
         assert out["16"].get(c, []) == oracle_events(ob, cfg, x[:, c]), f"channel {c}"
 
 
+def test_peek_and_drop_events_equal_poll(sa):
+    """same_batch_peek_events / same_batch_drop_events: the queue viewed in place, then released."""
+    n_ch, n = 64, 22050 * 4
+    x = mixed_batch(sa, n_ch, n, seed=12)
+    a = sa.SameReceiverBuilder(22050).build_batch(n_ch)
+    b = sa.SameReceiverBuilder(22050).build_batch(n_ch)
+    a.process_host(x); b.process_host(x)
+    a.sync(); b.sync()
+    want = a.poll_events_np()
+    view = b.peek_events_np()
+    assert len(view) == len(want) > 0 and not view.flags.writeable
+    assert view.tobytes() == want.tobytes()
+    half = len(view) // 2
+    b.drop_events(half)
+    rest = b.peek_events_np()
+    assert rest.tobytes() == want[half:].tobytes()
+    with pytest.raises(sa.SameError):
+        b.drop_events(len(rest) + 1)
+    b.drop_events(len(rest))
+    assert len(b.peek_events_np()) == 0 and len(b.poll_events_np()) == 0
+
+
 def test_i16_input_through_the_pipeline_kernel(sa, ob):
     """int16 samples cast in stage 1 of the pipelined kernel (64 channels => demod_pipe_kernel)."""
     n_ch, n = 64, 22050 * 4
