@@ -180,28 +180,47 @@ def test_chunked_processing_equals_one_shot(sa, ob):
     assert chunked.input_sample_counter() == n
 
 
-def test_tiny_chunks_through_the_pipeline(sa, ob):
+@pytest.mark.parametrize("rate", [22050, 48000])
+def test_tiny_chunks_through_the_pipeline(sa, ob, rate):
     """Calls of one, two and three blocks (and fractions of a block) exercise the pipeline's fill and
-    drain: 64 channels at 22.05 kHz run demod_pipe_kernel for every whole 18-sample block."""
-    n_ch, n = 64, 22050 * 2
-    x = mixed_batch(sa, n_ch, n, seed=21)
+    drain: 64 channels at a standard rate run demod_pipe_kernel for every whole block (18 samples at
+    22.05 kHz, 32 at 48 kHz, where stage 1's replay history also lives in a three-block LDS ring)."""
+    n_ch, n = 64, rate * 2
+    blk = 18 if rate == 22050 else 32
+    x = mixed_batch(sa, n_ch, n, seed=21, rate=rate)
     import torch
     xd = torch.from_numpy(x).cuda()
-    one = sa.SameReceiverBuilder(22050).build_batch(n_ch)
+    one = sa.SameReceiverBuilder(rate).build_batch(n_ch)
     assert one.kernel_name() == "demod_pipe_kernel"
     one.process_tensor(xd); one.sync()
     a = events_by_channel(one)
-    chunked = sa.SameReceiverBuilder(22050).build_batch(n_ch)
-    sizes = [1, 17, 18, 19, 35, 36, 37, 54, 5, 72, 90, 2000]
+    chunked = sa.SameReceiverBuilder(rate).build_batch(n_ch)
+    sizes = [1, blk - 1, blk, blk + 1, 2 * blk - 1, 2 * blk, 2 * blk + 1, 3 * blk, 5, 4 * blk, 5 * blk, 2000]
     off = i = 0
     while off < n:
-        k = sizes[i % len(sizes)] if off < 12000 else 7000
+        k = sizes[i % len(sizes)] if off < 12000 * blk // 18 else 7000
         chunked.process_tensor(xd[off:off + k].contiguous())
         off += k; i += 1
     chunked.sync()
     assert events_by_channel(chunked) == a
     for c in (0, 31, 63):
-        assert a.get(c, []) == oracle_events(ob, ob.default_config(22050), x[:, c])
+        assert a.get(c, []) == oracle_events(ob, ob.default_config(rate), x[:, c])
+
+
+def test_empty_input_is_a_no_op(sa):
+    """process() of no samples (the reference's iterator simply ends): no launch, no events, no state change."""
+    import torch
+    n_ch = 64
+    rx = sa.SameReceiverBuilder(22050).build_batch(n_ch)
+    rx.process_host(np.zeros((0, n_ch), dtype=np.float32))
+    rx.process_tensor(torch.zeros((0, n_ch), dtype=torch.float32, device="cuda"))
+    rx.sync()
+    assert rx.input_sample_counter() == 0 and len(rx.poll_events_np()) == 0
+    x = mixed_batch(sa, n_ch, 22050, seed=3)
+    rx.process_host(x); rx.process_host(x[:0]); rx.sync()
+    ref = sa.SameReceiverBuilder(22050).build_batch(n_ch)
+    ref.process_host(x); ref.sync()
+    assert rx.input_sample_counter() == 22050 and events_by_channel(rx) == events_by_channel(ref)
 
 
 def test_channel_major_layout(sa, ob):
