@@ -3,20 +3,22 @@
 //
 // With one wavefront per 64 channels (same_kernels_fast.hip) a launch of 4 096 channels is 64
 // serial instruction streams on a machine with 1 024 SIMDs, and a stream's length per block is
-// what it is whichever lanes are live.  Here a workgroup of FOUR wavefronts owns 64 channels:
-// the stream is cut in stages that run concurrently on different SIMDs of one CU, one block
-// apart, handing data over through LDS (see "Four stages" below).  The arithmetic per channel
-// and its order are exactly those of the one-wavefront kernels, so results are bit-identical
-// (tests/test_gpu_parity.py runs every 22.05 kHz case of up to 32 768 channels through this
-// kernel; test_fast_kernel_equals_generic_kernel and
-// test_pipeline_kernel_equals_single_wavefront_kernel pit the variants against each other).
-// A two-stage cut (sample phase | everything else) was measured on the way: 27.8 ms against
-// 35.3 ms (one wavefront), 19.2 ms (three stages) and 17.3 ms (four) at 4 096 channels x 10 s.
+// what it is whichever lanes are live.  Here a workgroup of FOUR wavefronts owns up to 64
+// channels: the stream is cut in stages that run concurrently on different SIMDs of one CU, one
+// block apart, handing data over through LDS (see "Four stages" below).  The arithmetic per
+// channel and its order are exactly those of the one-wavefront kernels, so results are
+// bit-identical (tests/test_gpu_parity.py runs every standard-rate case of up to 32 768 channels
+// through this kernel; test_fast_kernel_equals_generic_kernel,
+// test_pipeline_kernel_equals_single_wavefront_kernel and test_pipeline_workgroup_widths pit the
+// variants against each other).  At 4 096 channels x 10 s, 22.05 kHz: 35.3 ms (one wavefront per
+// 64 channels) -> 27.8 ms (two stages: sample phase | everything else) -> 19.2 ms (three) ->
+// 17.3 ms (four) -> 15.1 ms (16 channels per workgroup, LANES) -> 13.9 ms (stage 2's space
+// filter on stage 4's wavefront, SPLIT).
 //
-// Window ring: 5 blocks (of 18 slots at 22.05 kHz, 32 at 44.1 / 48 kHz), mirrored (see same_fast_common.h): while stage 2 reads the
-// 42 slots ending at an instant of block i, stage 1 writes block i+1, and with five blocks the
-// two never touch the same slot (four would: an instant early in block i still needs the tail
-// of block i-3, which block i+1 overwrites).
+// Window ring: 5 blocks (of 18 slots at 22.05 kHz, 32 at 44.1 / 48 kHz), mirrored (see
+// same_fast_common.h): while stage 2 reads the NT slots ending at an instant of block i, stage 1
+// writes block i+1, and with five blocks the two never touch the same slot (four would: an
+// instant early in block i still needs the tail of block i-3, which block i+1 overwrites).
 //
 // Citations: file:line under /root/reference/crates/sameold/src/ ("rx/" = receiver/).
 #include <hip/hip_runtime.h>
