@@ -16,7 +16,8 @@ R = sys.argv[1] if len(sys.argv) > 1 else "r01"
 
 
 def one(pattern):
-    return glob.glob(os.path.join(P, pattern))[0]
+    # gpurun merges new files into gpurun_out/ without removing those of earlier calls: take the newest
+    return max(glob.glob(os.path.join(P, pattern)), key=os.path.getmtime)
 
 
 def demod_rows(d):
