@@ -50,6 +50,35 @@ int fail(int code, const char *fmt, ...)
 }  // namespace
 
 // ------------------------------------------------------------------------------------
+// The host event queue: a plain growable array of PODs.  (std::vector would zero-fill 328 bytes per
+// event on resize and can only be appended to from one thread; a harvest appends ~35 MB.)
+struct EventQueue {
+    same_rx_event *buf = nullptr;
+    size_t n = 0, cap = 0;
+    ~EventQueue() { std::free(buf); }
+    EventQueue() = default;
+    EventQueue(const EventQueue &) = delete;
+    EventQueue &operator=(const EventQueue &) = delete;
+    size_t size() const { return n; }
+    same_rx_event *data() { return buf; }
+    void clear() { n = 0; }
+    // room for `extra` more events; returns where they go, or nullptr when out of memory
+    same_rx_event *grow(size_t extra)
+    {
+        if (n + extra > cap) {
+            const size_t want = (n + extra) + (n + extra) / 2 + 64;
+            void *p = std::realloc(buf, want * sizeof(same_rx_event));
+            if (!p) return nullptr;
+            buf = static_cast<same_rx_event *>(p);
+            cap = want;
+        }
+        same_rx_event *at = buf + n;
+        n += extra;
+        return at;
+    }
+};
+struct HarvestPart { std::vector<same_rx_event> out; std::vector<uint32_t> rearm; };
+
 struct same_batch {
     same_rx_builder builder{};
     same::Params P{};
@@ -92,8 +121,9 @@ struct same_batch {
     bool timing = false;
     bool have_timing = false;
     // ordered host-side event queue
-    std::vector<same_rx_event> queue;   // events not yet polled: [queue_head, size)
+    EventQueue queue;                   // events not yet polled: [queue_head, size)
     size_t queue_head = 0;
+    std::vector<HarvestPart> parts;     // per host thread, kept between harvests for their capacity
     // transport layer, one assembler per channel (unless SAME_BATCH_LINK_ONLY)
     std::vector<same::Transport> transport;
     uint64_t *h_wake = nullptr;      // host mirror of State::wake_sample (pinned, n_channels words, zero = unarmed)
@@ -248,8 +278,9 @@ int harvest_slot(same_batch *rx, same_batch::Slot &sl)
 
     // Channels are independent (one Transport each), so contiguous channel ranges are replayed
     // on separate host threads; each produces its slice of the output queue, in order.
-    struct Part { std::vector<same_rx_event> out; std::vector<uint32_t> rearm; };
+    using Part = HarvestPart;
     auto run_range = [&](uint32_t c0, uint32_t c1, Part &part) {
+        part.out.clear(); part.rearm.clear();
         part.out.reserve((size_t)(first[c1] - first[c0]) * 3 / 2 + 4);
         same_rx_event ev;
         std::memset(&ev, 0, sizeof(ev));
@@ -284,7 +315,9 @@ int harvest_slot(same_batch *rx, same_batch::Slot &sl)
         n_threads = std::min<uint32_t>({16u, hw ? hw : 1u, n_ch / 32u});
         if (const char *e = std::getenv("SAME_HOST_THREADS")) n_threads = std::max(1, std::atoi(e));
     }
-    std::vector<Part> parts(n_threads);
+    if (rx->parts.size() < n_threads) rx->parts.resize(n_threads);
+    std::vector<Part> &parts = rx->parts;
+    for (Part &p : parts) { p.out.clear(); p.rearm.clear(); }
     if (n_threads == 1) {
         run_range(0, n_ch, parts[0]);
     } else {
@@ -303,11 +336,23 @@ int harvest_slot(same_batch *rx, same_batch::Slot &sl)
     }
     size_t total = 0;
     for (const Part &p : parts) total += p.out.size();
-    rx->queue.reserve(rx->queue.size() + total);
-    for (Part &p : parts) {
-        rx->queue.insert(rx->queue.end(), p.out.begin(), p.out.end());
-        rearm.insert(rearm.end(), p.rearm.begin(), p.rearm.end());
+    same_rx_event *dst = rx->queue.grow(total);
+    if (total && !dst) return fail(SAME_ENOMEM, "event queue");
+    {
+        // every thread's slice lands at its prefix offset; the copies run side by side
+        std::vector<std::thread> pool;
+        size_t at = 0;
+        for (size_t t = 0; t < parts.size(); ++t) {
+            const Part &p = parts[t];
+            if (p.out.empty()) continue;
+            same_rx_event *to = dst + at;
+            at += p.out.size();
+            auto copy = [to, &p]() { std::memcpy(to, p.out.data(), p.out.size() * sizeof(same_rx_event)); };
+            if (n_threads > 1 && at < total) pool.emplace_back(copy); else copy();
+        }
+        for (std::thread &th : pool) th.join();
     }
+    for (Part &p : parts) rearm.insert(rearm.end(), p.rearm.begin(), p.rearm.end());
     // force_eom_at_sample (receiver.rs:321-328) lives on the host; tell the device when to
     // wake the transport layer for it.  Launches are capped well below the 135 s timeout,
     // so the instant is always armed before the device reaches it.
