@@ -440,6 +440,22 @@ def test_pipeline_workgroup_widths(sa, ob, monkeypatch, rate):
         assert out["16"].get(c, []) == oracle_events(ob, cfg, x[:, c]), f"channel {c}"
 
 
+@pytest.mark.parametrize("n_ch,kernel", [(16, "demod_pipe_kernel"), (48, "demod_pipe_kernel"), (80, "demod_pipe_kernel"),
+                                         (70, "demod_fast_kernel"), (4128, "demod_pipe_kernel"), (4112, "demod_fast_kernel")])
+def test_channel_counts_around_the_workgroup_widths(sa, n_ch, kernel):
+    """Batches that are whole 16- or 32-channel workgroups run the pipeline, others one wavefront per 64
+    channels with a ragged tail; either way every channel equals the any-configuration kernel."""
+    n = 22050 * 2
+    x = sa.synth_afsk(n_ch, n, 22050, seed=77, noise_sigma=0.02)
+    rx = sa.SameReceiverBuilder(22050).build_batch(n_ch)
+    assert rx.kernel_name() == kernel
+    gen = sa.SameReceiverBuilder(22050).build_batch(n_ch, generic_kernel=True)
+    rx.process_tensor(x); gen.process_tensor(x)
+    rx.sync(); gen.sync()
+    a, b = events_by_channel(rx), events_by_channel(gen)
+    assert sum(len(v) for v in b.values()) >= n_ch and a == b
+
+
 def test_peek_and_drop_events_equal_poll(sa):
     """same_batch_peek_events / same_batch_drop_events: the queue viewed in place, then released."""
     n_ch, n = 64, 22050 * 4
