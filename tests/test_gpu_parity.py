@@ -478,15 +478,16 @@ def test_peek_and_drop_events_equal_poll(sa):
     assert len(b.peek_events_np()) == 0 and len(b.poll_events_np()) == 0
 
 
-def test_i16_input_through_the_pipeline_kernel(sa, ob):
+@pytest.mark.parametrize("rate", [22050, 48000])
+def test_i16_input_through_the_pipeline_kernel(sa, ob, rate):
     """int16 samples cast in stage 1 of the pipelined kernel (64 channels => demod_pipe_kernel)."""
-    n_ch, n = 64, 22050 * 4
-    x = np.clip(np.rint(mixed_batch(sa, n_ch, n, seed=77)), -32768, 32767).astype(np.int16)
-    rx = sa.SameReceiverBuilder(22050).samedec().build_batch(n_ch)
+    n_ch, n = 64, rate * 4
+    x = np.clip(np.rint(mixed_batch(sa, n_ch, n, seed=77, rate=rate)), -32768, 32767).astype(np.int16)
+    rx = sa.SameReceiverBuilder(rate).samedec().build_batch(n_ch)
     assert rx.kernel_name() == "demod_pipe_kernel"
     rx.process_host(x)
     got = events_by_channel(rx)
-    cfg = ob.samedec_config()
+    cfg = ob.samedec_config(rate)
     for c in range(0, n_ch, 7):
         assert got.get(c, []) == oracle_events(ob, cfg, x[:, c]), f"channel {c}"
 
