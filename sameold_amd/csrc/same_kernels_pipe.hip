@@ -91,7 +91,7 @@ template <int NT> struct PipeLayout {
 // per stage of workgroup 0: cycles working, waiting at the step barrier, handling feedback
 __device__ unsigned long long g_same_prof_pipe[9];
 // [role] = HW_ID of workgroup 0's wavefront in that role (SIMD = bits 5:4); [5] cycles stage 2 polled
-// its helper, [6] cycles the helper worked
+// stage 4 for the space magnitude, [6] cycles stage 4 spent on the space filter
 __device__ unsigned long long g_same_prof_hw[8];
 #define P3_HWID(role_) do { if (blockIdx.x == 0 && lane == 0) g_same_prof_hw[role_] = __builtin_amdgcn_s_getreg((31 << 11) | 4); } while (0)
 #define P3_T0() unsigned long long p3_work = 0, p3_wait = 0, p3_fb = 0, p3_t = clock64()
@@ -445,7 +445,7 @@ __global__ __launch_bounds__(4 * kWave, SHARE ? 2 : 1) void demod_pipe_kernel(Pa
     lds_u32 *phasebox = iobox + 2u * kP3IoWords;               // [64] stage 2's final TED phase bit
     lds_u32 *againbox = phasebox + kWave;                      // [64] stage 4's final F_TICK_AGAIN bit
     lds_u32 *chunkbox = fbbox + kWave + 2u;                    // [2], in the first box's padding
-    lds_u32 *seqbox = fbbox + kWave + 4u;                      // SPLIT: the helper's progress, 2 * step + pass
+    lds_u32 *seqbox = fbbox + kWave + 4u;                      // SPLIT: stage 4's progress with the space filter, 2 * step + pass
     lds_u32 *posbox = againbox + kWave;                        // SPLIT: [2][64] sample index of block b's instant
     lds_u32 *spacebox = posbox + 2u * kWave;                   // SPLIT: [64] space-filter magnitude
     float *hcol = lds + kPipeTapFloats + kP3MailWords + lane;
@@ -521,7 +521,7 @@ __global__ __launch_bounds__(4 * kWave, SHARE ? 2 : 1) void demod_pipe_kernel(Pa
 #ifdef SAME_PROFILE
                     const unsigned long long spin_t0 = clock64();
 #endif
-                    while ((int32_t)(seqbox[0] - seq) < 0) {}          // the helper has posted this pass
+                    while ((int32_t)(seqbox[0] - seq) < 0) {}          // stage 4 has posted this pass
 #ifdef SAME_PROFILE
                     if (blockIdx.x == 0 && lane == (uint32_t)__builtin_amdgcn_readfirstlane((int)lane))
                         g_same_prof_hw[5] += clock64() - spin_t0;

@@ -50,6 +50,6 @@ if hasattr(rx._L, "same_debug_profile_pipe") and "pipe" in rx.kernel_name():
     if hasattr(rx._L, "same_debug_profile_hw"):
         hw = (ctypes.c_ulonglong * 8)()
         rx._L.same_debug_profile_hw(hw, 1)
-        print("  HW_ID (SIMD) per role [stage1, stage2, stage3, stage4, helper]:",
-              [f"{int(v) & 0xffffffff:#x} (simd {(int(v) >> 4) & 3})" for v in hw[:5]])
-        print(f"  stage 2 polled its helper {hw[5]/nstep:8.1f} clk/step; helper worked {hw[6]/nstep:8.1f} clk/step")
+        print("  HW_ID (SIMD) per role [stage1, stage2, stage3, stage4]:",
+              [f"{int(v) & 0xffffffff:#x} (simd {(int(v) >> 4) & 3})" for v in hw[:4]])
+        print(f"  stage 2 polled stage 4 for the space magnitude {hw[5]/nstep:8.1f} clk/step; stage 4's space filter took {hw[6]/nstep:8.1f} clk/step")
