@@ -822,12 +822,19 @@ template <int NT, typename SampleT>
 static hipError_t launch_pipe_cfg(const Params &P, const State &S, const Output &O, const float4 *taps,
                                   const SampleT *x, uint32_t n_blocks, uint64_t counter0, hipStream_t stream)
 {
-    // two workgroups per CU (22.05 kHz only, where their LDS allows it): the register-capped build
+    // two workgroups per CU (22.05 kHz only, where their LDS allows it): the register-capped build, with
+    // stage 2 split (same box, 32 768 channels x 2 s: 4.27-4.29 ms unsplit, 4.18-4.24 ms split).  Which stages
+    // of the two workgroups meet on a SIMD makes no measurable difference there (dealt by SIMD id: like + like
+    // 4.14 ms, stage 1 + 2 and 3 + 4 4.19 ms, 1 + 4 and 2 + 3 4.20 ms, by wavefront number 4.20 ms, one box),
+    // so they are left where they fall.
     constexpr bool CAN_SHARE = (NT == 42);
     const bool share = CAN_SHARE && P.n_channels > 16384u;
     const bool med3 = agc_clamp_is_med3(P);
+    const char *split_env = getenv("SAME_PIPE_SPLIT");
+    const bool share_split = split_env ? atoi(split_env) != 0 : true;
 #define SAME_PIPE_LAUNCH(NFF, NFB, M3)                                                                                  \
-    (share ? launch_pipe_one<NT, NFF, NFB, M3, CAN_SHARE, 64, false, SampleT>(P, S, O, taps, x, n_blocks, counter0, stream)    \
+    (share ? (share_split ? launch_pipe_one<NT, NFF, NFB, M3, CAN_SHARE, 64, CAN_SHARE, SampleT>(P, S, O, taps, x, n_blocks, counter0, stream)    \
+                          : launch_pipe_one<NT, NFF, NFB, M3, CAN_SHARE, 64, false, SampleT>(P, S, O, taps, x, n_blocks, counter0, stream))     \
            : launch_pipe_one<NT, NFF, NFB, M3, false, 64, false, SampleT>(P, S, O, taps, x, n_blocks, counter0, stream))
     const uint32_t lanes = pipe_lanes(P);
     if (P.eq_nff == 6u && P.eq_nfb == 4u && med3 && !share) {
