@@ -292,6 +292,48 @@ def test_builder_variants(sa, ob, variant):
         assert got.get(c, []) == oracle_events(ob, cfg, x[:, c]), f"{variant} channel {c}"
 
 
+@pytest.mark.parametrize("seed", range(10))
+def test_random_builder_configurations(sa, ob, seed):
+    """Every builder setter at once, drawn at random (including rates no specialised kernel exists
+    for): whatever kernel the dispatcher picks, every checked channel equals the oracle given the
+    same calls."""
+    rng = np.random.default_rng(1000 + seed)
+    rate = int(rng.choice([22050, 22050, 48000, 44100, 16000, 32000, 11025]))
+    b = sa.SameReceiverBuilder(rate)
+    cfg = ob.default_config(rate)
+    L = ob.lib()
+    f32 = lambda v: float(np.float32(v))
+
+    def both(name, *args):
+        getattr(b, name)(*args)
+        getattr(L, "so_config_" + name)(C.byref(cfg), *args)
+
+    if rng.random() < 0.5: both("with_dc_blocker_length", f32(rng.uniform(0.05, 1.2)))
+    if rng.random() < 0.5: both("with_agc_bandwidth", f32(rng.uniform(0.002, 0.05)))
+    if rng.random() < 0.5: both("with_agc_gain_limits", f32(10 ** rng.uniform(-6, -4)), f32(10 ** rng.uniform(-3, 0)))
+    if rng.random() < 0.5:
+        u = f32(rng.uniform(0.05, 0.4)); both("with_timing_bandwidth", u, f32(u * rng.uniform(0.2, 1.5)))
+    if rng.random() < 0.5: both("with_timing_max_deviation", f32(rng.choice([0.0, 0.005, 0.01, 0.03, 0.1, 0.25])))
+    if rng.random() < 0.5:
+        o = f32(rng.uniform(0.0, 0.6)); both("with_squelch_power", o, f32(o * rng.uniform(0.3, 1.3)))
+    if rng.random() < 0.5: both("with_squelch_bandwidth", f32(rng.uniform(0.02, 0.3)))
+    if rng.random() < 0.5: both("with_preamble_max_errors", int(rng.integers(0, 6)))
+    r = rng.random()
+    if r < 0.25: both("without_adaptive_equalizer")
+    elif r < 0.6: both("with_adaptive_equalizer", int(rng.integers(1, 12)), int(rng.integers(1, 8)),
+                       f32(rng.uniform(0.01, 0.3)), f32(10 ** rng.uniform(-7, -4)))
+    if rng.random() < 0.5: both("with_frame_prefix_max_errors", int(rng.integers(0, 5)))
+    if rng.random() < 0.5: both("with_frame_max_invalid", int(rng.integers(0, 6)))
+    n_ch, n = 64, rate * 3
+    x = mixed_batch(sa, n_ch, n, seed=500 + seed, rate=rate, noise=float(rng.choice([0.0, 0.05, 0.2])))
+    rx = b.build_batch(n_ch)
+    for off in range(0, n, 25013):
+        rx.process_host(x[off:off + 25013])
+    got = events_by_channel(rx)
+    for c in range(0, n_ch, 6):
+        assert got.get(c, []) == oracle_events(ob, cfg, x[:, c]), f"seed {seed} rate {rate} kernel {rx.kernel_name()} channel {c}"
+
+
 @pytest.mark.parametrize("rate,dev,kernel", [(22050, 0.05, "demod_fast_kernel"), (22050, 0.01, "demod_pipe_kernel"),
                                              (48000, 0.2, "demod_kernel<B=16>"), (48000, 0.01, "demod_pipe_kernel"),
                                              (44100, 0.15, "demod_kernel<B=16>"), (44100, 0.01, "demod_pipe_kernel")])
