@@ -275,6 +275,7 @@ int harvest_slot(same_batch *rx, same_batch::Slot &sl)
     }
     const bool link_only = (rx->flags & SAME_BATCH_LINK_ONLY) != 0;
     std::vector<uint32_t> rearm;     // channels whose forced-EOM instant changed
+    auto t_sorted = std::chrono::steady_clock::now();
 
     // Channels are independent (one Transport each), so contiguous channel ranges are replayed
     // on separate host threads; each produces its slice of the output queue, in order.
@@ -334,6 +335,7 @@ int harvest_slot(same_batch *rx, same_batch::Slot &sl)
         run_range(cut[0], cut[1], parts[0]);
         for (std::thread &th : pool) th.join();
     }
+    auto t_replayed = std::chrono::steady_clock::now();
     size_t total = 0;
     for (const Part &p : parts) total += p.out.size();
     same_rx_event *dst = rx->queue.grow(total);
@@ -372,8 +374,10 @@ int harvest_slot(same_batch *rx, same_batch::Slot &sl)
     if (dbg) {
         auto t_end = std::chrono::steady_clock::now();
         auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
-        std::fprintf(stderr, "[same] harvest timing: wait %.2f ms, copy %.2f ms, order+transport %.2f ms\n",
-                     ms(t_begin, t_waited), ms(t_waited, t_copied), ms(t_copied, t_end));
+        std::fprintf(stderr, "[same] harvest timing: wait %.2f ms, copy %.2f ms, sort %.2f ms, replay on %u threads %.2f ms, "
+                             "queue %.2f ms\n",
+                     ms(t_begin, t_waited), ms(t_waited, t_copied), ms(t_copied, t_sorted), n_threads,
+                     ms(t_sorted, t_replayed), ms(t_replayed, t_end));
     }
     return SAME_OK;
 }
