@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
-"""Compare GPU events with the oracle on the bench workload and print the first differences."""
+"""Compare GPU events with the oracle on the bench workload and print the first differences.
+(Test tooling: it lives under tests/ because it runs the oracle.)"""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 import sameold_amd as sa
 from oracle import binding as ob
