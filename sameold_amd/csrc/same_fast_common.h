@@ -18,6 +18,12 @@ typedef float float2v __attribute__((ext_vector_type(2)));
 // choose_block_len: 18 is the bound at 22.05 kHz), so a block holds at most one instant.
 constexpr int kBlock = 16;
 constexpr int kBlockMirror = 18;
+// The 22.05 kHz wavefront pipeline runs 20-sample blocks: instants are at least 19.45 samples apart
+// there (the bound above), so a block can hold a SECOND instant when the timing loop runs at its
+// fastest -- never a third -- and stage 2 handles that rare one on the spot (same_kernels_pipe.hip).
+// Of the two, exactly one completes a symbol (the TED alternates), so everything downstream still
+// sees at most one symbol per block.
+constexpr int kBlockPipe22 = 20;
 // 48 kHz (92 taps) and 44.1 kHz (84 taps): instants are 46 / 42 samples apart and the bound is
 // 43 / 39, so the block is 32 -- the block-rate passes (the long filters, timing loop, symbol
 // path) serve twice the samples.

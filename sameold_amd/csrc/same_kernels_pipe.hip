@@ -52,7 +52,7 @@ __device__ __forceinline__ void lds_barrier()
 // The ring is five blocks at every rate: NT - 1 samples back from an instant early in block s-1
 // reach into block s-4 (41 = 2*18 + 5, 91 = 2*32 + 27, 83 = 2*32 + 19) while stage 1 writes block s.
 template <int NT> struct PipeGeom;
-template <> struct PipeGeom<42> { static constexpr int DCL = 16, B = kBlockMirror; };   // 22.05 kHz
+template <> struct PipeGeom<42> { static constexpr int DCL = 16, B = kBlockPipe22; };   // 22.05 kHz
 template <> struct PipeGeom<92> { static constexpr int DCL = 35, B = kBlock48k; };      // 48 kHz
 template <> struct PipeGeom<84> { static constexpr int DCL = 32, B = kBlock48k; };      // 44.1 kHz
 template <int NT> struct PipeLayout {
@@ -60,7 +60,7 @@ template <int NT> struct PipeLayout {
     // stage 1 keeps the DC-blocker outputs of its last three blocks for a replay: in registers
     // (3 x 18) at 22.05 kHz, in an LDS ring of three blocks at 44.1 / 48 kHz, where 3 x 32 more
     // registers per lane would spill and the CU's LDS has room
-    static constexpr bool YLDS = B > kBlockMirror;
+    static constexpr bool YLDS = B >= kBlock48k;
     static constexpr uint32_t yring_floats = YLDS ? 3u * (uint32_t)B * kWave : 0u;
 #ifdef SAME_PROFILE
     static constexpr uint32_t tap_floats = (uint32_t)((NT * 4 + 20 + 63) / 64 * 64);
@@ -512,7 +512,7 @@ __global__ __launch_bounds__(4 * kWave, SHARE ? 2 : 1) void demod_pipe_kernel(Pa
         // one block: the instant, if this lane has one in it; hands a completed symbol to stage 3
         auto do_block = [&](uint32_t blk, uint32_t seq) {
             uint32_t hdr = 0;
-            float zero = 0.0f, sym = 0.0f, terr = 0.0f;
+            float zero = 0.0f, sym = 0.0f, terr = 0.0f, next = 0.0f;
             if (until < kB) {
                 const int fk = until;
                 float sa_low;
@@ -532,9 +532,23 @@ __global__ __launch_bounds__(4 * kWave, SHARE ? 2 : 1) void demod_pipe_kernel(Pa
                     sa_low = demod_fast<NT, RING, true>(tlds, wring, lane, wpos + (uint32_t)fk);
                 }
                 const float rem = L.until_next_ted - (float)cstar;          // receiver.rs:352
-                if (ted_timing(P, L, sa_low, rem, &zero, &sym, &terr)) hdr = 1u | ((uint32_t)fk << 8);
+                if (ted_timing(P, L, sa_low, rem, &zero, &sym, &terr)) { hdr = 1u | ((uint32_t)fk << 8); next = L.until_next_ted; }
                 cstar = next_fire_count(L.until_next_ted, 0u);
                 until = fk + cstar;
+                if (until < kB) {
+                    // A second instant in the same block (20-sample blocks at 22.05 kHz, the loop at its
+                    // fastest): rare, so this wavefront computes both filters itself.  Exactly one of the
+                    // two instants completes a symbol.
+                    const int fk2 = until;
+                    const float sa2 = demod_fast<NT, RING, true>(tlds, wring, lane, wpos + (uint32_t)fk2);
+                    const float rem2 = L.until_next_ted - (float)cstar;
+                    float z2 = 0.0f, s2 = 0.0f, e2 = 0.0f;
+                    if (ted_timing(P, L, sa2, rem2, &z2, &s2, &e2)) {
+                        hdr = 1u | ((uint32_t)fk2 << 8); zero = z2; sym = s2; terr = e2; next = L.until_next_ted;
+                    }
+                    cstar = next_fire_count(L.until_next_ted, 0u);
+                    until = fk2 + cstar;
+                }
             }
             until -= kB;
             if constexpr (SPLIT) posbox[((blk + 1u) & 1u) * kWave + lane] = (uint32_t)until;   // block blk + 1's instant
@@ -542,7 +556,7 @@ __global__ __launch_bounds__(4 * kWave, SHARE ? 2 : 1) void demod_pipe_kernel(Pa
             sb[0] = hdr;
             sb[kWave] = __float_as_uint(zero); sb[2 * kWave] = __float_as_uint(sym);
             if (P.trace_cap) {                         // only the symbol trace records these two
-                sb[3 * kWave] = __float_as_uint(terr); sb[4 * kWave] = __float_as_uint(L.until_next_ted);
+                sb[3 * kWave] = __float_as_uint(terr); sb[4 * kWave] = __float_as_uint(next);
             }
         };
         P3_T0();
@@ -794,7 +808,7 @@ uint32_t pipe_kernel_stages(const Params &P)
     return P.n_channels <= 32768u ? 4u : 0u;
 }
 bool pipe_kernel_selected(const Params &P) { return pipe_kernel_stages(P) != 0u; }
-uint32_t pipe_block_len(const Params &P) { return P.ntaps == 42u ? (uint32_t)kBlockMirror : (uint32_t)kBlock48k; }
+uint32_t pipe_block_len(const Params &P) { return P.ntaps == 42u ? (uint32_t)kBlockPipe22 : (uint32_t)kBlock48k; }
 
 template <int NT, int NFF, int NFB, bool M3, bool SHARE, int LANES, bool SPLIT, typename SampleT>
 static hipError_t launch_pipe_one(const Params &P, const State &S, const Output &O, const float4 *taps,

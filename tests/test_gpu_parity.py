@@ -183,10 +183,10 @@ def test_chunked_processing_equals_one_shot(sa, ob):
 @pytest.mark.parametrize("rate", [22050, 48000])
 def test_tiny_chunks_through_the_pipeline(sa, ob, rate):
     """Calls of one, two and three blocks (and fractions of a block) exercise the pipeline's fill and
-    drain: 64 channels at a standard rate run demod_pipe_kernel for every whole block (18 samples at
+    drain: 64 channels at a standard rate run demod_pipe_kernel for every whole block (20 samples at
     22.05 kHz, 32 at 48 kHz, where stage 1's replay history also lives in a three-block LDS ring)."""
     n_ch, n = 64, rate * 2
-    blk = 18 if rate == 22050 else 32
+    blk = 20 if rate == 22050 else 32
     x = mixed_batch(sa, n_ch, n, seed=21, rate=rate)
     import torch
     xd = torch.from_numpy(x).cuda()
@@ -496,6 +496,43 @@ def test_channel_counts_around_the_workgroup_widths(sa, n_ch, kernel):
     rx.sync(); gen.sync()
     a, b = events_by_channel(rx), events_by_channel(gen)
     assert sum(len(v) for v in b.values()) >= n_ch and a == b
+
+
+@pytest.mark.parametrize("amp", [300.0, 6000.0])
+def test_two_instants_in_one_block(sa, ob, amp):
+    """The 22.05 kHz pipeline's blocks are 20 samples, instants at least 19.45 apart: when the timing loop runs
+    at its fastest a block holds two.  Noise drives the loop to both ends of its range all the time (the
+    soft-symbol trace shows instants 19 and 20 samples apart), and every instant, symbol and event still
+    equals the one-wavefront kernel's and the oracle's."""
+    import torch
+    n_ch, n = 64, 22050 * 3
+    rng = np.random.default_rng(int(amp))
+    x = (rng.standard_normal((n, n_ch)) * amp).astype(np.float32)
+    x[:, ::2] += mixed_batch(sa, n_ch, n, seed=91)[:, ::2]          # every other channel also carries bursts
+    xd = torch.from_numpy(x).cuda()
+    out = {}
+    for variant in ("pipe", "fast"):
+        os.environ["SAME_PIPE"] = PIPE_ENV[variant]
+        try:
+            rx = sa.SameReceiverBuilder(22050).build_batch(n_ch, trace_symbols=True)
+            assert rx.kernel_name() == f"demod_{variant}_kernel"
+            for off in range(0, n, 9973):
+                rx.process_tensor(xd[off:off + 9973].contiguous())
+            rx.sync()
+            out[variant] = (events_by_channel(rx), [rx.read_trace(c, cap=8192) for c in (1, 2, 33)])
+        finally:
+            os.environ.pop("SAME_PIPE", None)
+    assert out["pipe"][0] == out["fast"][0]
+    close = 0
+    for tp, tf in zip(out["pipe"][1], out["fast"][1]):
+        assert np.array_equal(tp["sample_counter"], tf["sample_counter"])
+        for f in ("zero", "sym", "err", "next"):
+            assert np.array_equal(tp[f].view(np.uint32), tf[f].view(np.uint32)), f
+        close += int(np.sum(np.diff(tp["sample_counter"].astype(np.int64)) < 41))    # two instants < 20.5 apart
+    assert close > 0, "the input never made the loop run fast enough to test anything"
+    cfg = ob.default_config(22050)
+    for c in (1, 2, 40):
+        assert out["pipe"][0].get(c, []) == oracle_events(ob, cfg, x[:, c]), f"channel {c}"
 
 
 def test_peek_and_drop_events_equal_poll(sa):
