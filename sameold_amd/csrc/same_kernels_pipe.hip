@@ -13,9 +13,10 @@
 // variants against each other).  At 4 096 channels x 10 s, 22.05 kHz: 35.3 ms (one wavefront per
 // 64 channels) -> 27.8 ms (two stages: sample phase | everything else) -> 19.2 ms (three) ->
 // 17.3 ms (four) -> 15.1 ms (16 channels per workgroup, LANES) -> 13.9 ms (stage 2's space
-// filter on stage 4's wavefront, SPLIT).
+// filter on stage 4's wavefront, SPLIT) -> 13.2 ms (20-sample blocks with the rare second instant
+// of a block handled in stage 2, same_fast_common.h).
 //
-// Window ring: 5 blocks (of 18 slots at 22.05 kHz, 32 at 44.1 / 48 kHz), mirrored (see
+// Window ring: 5 blocks (of 20 slots at 22.05 kHz, 32 at 44.1 / 48 kHz), mirrored (see
 // same_fast_common.h): while stage 2 reads the NT slots ending at an instant of block i, stage 1
 // writes block i+1, and with five blocks the two never touch the same slot (four would: an
 // instant early in block i still needs the tail of block i-3, which block i+1 overwrites).
@@ -50,7 +51,7 @@ __device__ __forceinline__ void lds_barrier()
 
 // Geometry per sample rate (filter length NT): DC-blocker window, samples per block, window ring.
 // The ring is five blocks at every rate: NT - 1 samples back from an instant early in block s-1
-// reach into block s-4 (41 = 2*18 + 5, 91 = 2*32 + 27, 83 = 2*32 + 19) while stage 1 writes block s.
+// reach into block s-4 (41 = 2*20 + 1, 91 = 2*32 + 27, 83 = 2*32 + 19) while stage 1 writes block s.
 template <int NT> struct PipeGeom;
 template <> struct PipeGeom<42> { static constexpr int DCL = 16, B = kBlockPipe22; };   // 22.05 kHz
 template <> struct PipeGeom<92> { static constexpr int DCL = 35, B = kBlock48k; };      // 48 kHz
@@ -58,7 +59,7 @@ template <> struct PipeGeom<84> { static constexpr int DCL = 32, B = kBlock48k; 
 template <int NT> struct PipeLayout {
     static constexpr int B = PipeGeom<NT>::B, RING = 5 * B;
     // stage 1 keeps the DC-blocker outputs of its last three blocks for a replay: in registers
-    // (3 x 18) at 22.05 kHz, in an LDS ring of three blocks at 44.1 / 48 kHz, where 3 x 32 more
+    // (3 x 20) at 22.05 kHz, in an LDS ring of three blocks at 44.1 / 48 kHz, where 3 x 32 more
     // registers per lane would spill and the CU's LDS has room
     static constexpr bool YLDS = B >= kBlock48k;
     static constexpr uint32_t yring_floats = YLDS ? 3u * (uint32_t)B * kWave : 0u;

@@ -338,7 +338,7 @@ def test_random_builder_configurations(sa, ob, seed):
                                              (48000, 0.2, "demod_kernel<B=16>"), (48000, 0.01, "demod_pipe_kernel"),
                                              (44100, 0.15, "demod_kernel<B=16>"), (44100, 0.01, "demod_pipe_kernel")])
 def test_block_length_follows_the_timing_bound(sa, ob, rate, dev, kernel):
-    """A block may hold at most one TED instant.  The 18-sample (22.05 kHz mirrored / pipelined)
+    """A block may hold at most one TED instant (the 22.05 kHz pipeline: two).  The 18-sample (22.05 kHz mirrored), 20-sample (pipelined)
     and 32-sample (48 / 44.1 kHz) variants are only dispatched when timing_max_deviation leaves room
     for them; with a wider deviation the dispatcher falls back to shorter blocks, and every
     choice matches the oracle."""
