@@ -52,10 +52,17 @@ __device__ __forceinline__ void lds_barrier()
 // Geometry per sample rate (filter length NT): DC-blocker window, samples per block, window ring.
 // The ring is five blocks at every rate: NT - 1 samples back from an instant early in block s-1
 // reach into block s-4 (41 = 2*20 + 1, 91 = 2*32 + 27, 83 = 2*32 + 19) while stage 1 writes block s.
+// Samples per block at 48 / 44.1 kHz (bounds 43 / 39, one instant per block).  Measured at 16 384
+// channels x 2 s: 48 kHz 6.03 ms with 32, 6.75 with 36, 6.48 with 40 (stage 1's registers);
+// 44.1 kHz 5.35 ms with 32, 5.20 with 36.
+#ifndef SAME_B48
+#define SAME_B48 32
+#define SAME_B44 36
+#endif
 template <int NT> struct PipeGeom;
 template <> struct PipeGeom<42> { static constexpr int DCL = 16, B = kBlockPipe22; };   // 22.05 kHz
-template <> struct PipeGeom<92> { static constexpr int DCL = 35, B = kBlock48k; };      // 48 kHz
-template <> struct PipeGeom<84> { static constexpr int DCL = 32, B = kBlock48k; };      // 44.1 kHz
+template <> struct PipeGeom<92> { static constexpr int DCL = 35, B = SAME_B48; };       // 48 kHz
+template <> struct PipeGeom<84> { static constexpr int DCL = 32, B = SAME_B44; };       // 44.1 kHz
 template <int NT> struct PipeLayout {
     static constexpr int B = PipeGeom<NT>::B, RING = 5 * B;
     // stage 1 keeps the DC-blocker outputs of its last three blocks for a replay: in registers
@@ -431,7 +438,7 @@ __global__ __launch_bounds__(4 * kWave, SHARE ? 2 : 1) void demod_pipe_kernel(Pa
 {
     constexpr int kB = PipeLayout<NT>::B, RING = PipeLayout<NT>::RING;
     constexpr uint32_t LP = kWave, kPipeTapFloats = PipeLayout<NT>::tap_floats;
-    static_assert(kB <= 32, "the sample index travels in five bits of the stage 3 -> 4 word");
+    static_assert(kB <= 64, "the sample index travels in six bits of the stage 3 -> 4 word");
     extern __shared__ float lds[];
     const uint32_t lane = threadIdx.x & (kWave - 1u);
     const uint32_t role = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // 0..3 = stage 1..4
@@ -737,7 +744,7 @@ __global__ __launch_bounds__(4 * kWave, SHARE ? 2 : 1) void demod_pipe_kernel(Pa
                 const uint32_t io0 = io[0];
                 if (io0 & 1u) {
                     L.sq_symbols += 1;         // as rx_symbol counted it (rx/codesquelch.rs:232)
-                    const uint32_t link = (io0 >> 1) & 3u, fk = (io0 >> 4) & 31u;
+                    const uint32_t link = (io0 >> 1) & 3u, fk = (io0 >> 4) & 63u;
                     const bool burst = (io0 & 8u) != 0u && link == 3u;
                     uint32_t burst_len = 0;
                     if (burst) { X.pending_slot = io[kWave]; burst_len = io[2 * kWave]; }
@@ -804,12 +811,13 @@ uint32_t pipe_kernel_stages(const Params &P)
                r44 = P.ntaps == 84u && P.dc_len == 32u;
     if (!(r22 || r48 || r44) || (P.n_channels % pipe_lanes(P)) != 0u) return 0;
     if (!((P.eq_nff == 6u && P.eq_nfb == 4u) || (P.eq_nff == 1u && P.eq_nfb == 1u))) return 0;
-    if (P.block_len != 16u || max_block_len(P) < (r22 ? (uint32_t)kBlockMirror : (uint32_t)kBlock48k)) return 0;
+    if (P.block_len != 16u || max_block_len(P) < (r22 ? (uint32_t)kBlockMirror : pipe_block_len(P))) return 0;
     if (const char *e = getenv("SAME_PIPE")) return atoi(e) ? 4u : 0u;       // 0 = off, anything else = on
     return P.n_channels <= 32768u ? 4u : 0u;
 }
 bool pipe_kernel_selected(const Params &P) { return pipe_kernel_stages(P) != 0u; }
-uint32_t pipe_block_len(const Params &P) { return P.ntaps == 42u ? (uint32_t)kBlockPipe22 : (uint32_t)kBlock48k; }
+uint32_t pipe_block_len(const Params &P)
+{ return P.ntaps == 42u ? (uint32_t)kBlockPipe22 : (P.ntaps == 92u ? (uint32_t)PipeGeom<92>::B : (uint32_t)PipeGeom<84>::B); }
 
 template <int NT, int NFF, int NFB, bool M3, bool SHARE, int LANES, bool SPLIT, typename SampleT>
 static hipError_t launch_pipe_one(const Params &P, const State &S, const Output &O, const float4 *taps,

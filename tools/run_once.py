@@ -39,7 +39,7 @@ if hasattr(rx._L, "same_debug_profile_pipe") and "pipe" in rx.kernel_name():
     import ctypes
     buf = (ctypes.c_ulonglong * 9)()
     rx._L.same_debug_profile_pipe(buf, 1)
-    nstep = reps * (T // (20 if rate == 22050 else 32) + 3)
+    nstep = reps * (T // {22050: 20, 48000: 32, 44100: 36}.get(rate, 32) + 3)
     if os.environ.get("SAME_P3_MARKS"):
         for name, v in zip(["other (mailbox, barrier, idle)", "squelch", "equalizer step", "byte/framer", "events+wake-ups", "-"], buf):
             print(f"  stage 3 {name:32s} {v/nstep:8.1f} clk/step (each mark costs ~340 clk, charged to the section after it)")
