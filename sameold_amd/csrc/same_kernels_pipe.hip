@@ -99,7 +99,7 @@ template <int NT> struct PipeLayout {
 // per stage of workgroup 0: cycles working, waiting at the step barrier, handling feedback
 __device__ unsigned long long g_same_prof_pipe[9];
 // [role] = HW_ID of workgroup 0's wavefront in that role (SIMD = bits 5:4); [5] cycles stage 2 polled
-// stage 4 for the space magnitude, [6] cycles stage 4 spent on the space filter
+// stage 4 for the space magnitude, [6] cycles stage 4 spent on the space filter, [7] second instants of a block
 __device__ unsigned long long g_same_prof_hw[8];
 #define P3_HWID(role_) do { if (blockIdx.x == 0 && lane == 0) g_same_prof_hw[role_] = __builtin_amdgcn_s_getreg((31 << 11) | 4); } while (0)
 #define P3_T0() unsigned long long p3_work = 0, p3_wait = 0, p3_fb = 0, p3_t = clock64()
@@ -548,6 +548,9 @@ __global__ __launch_bounds__(4 * kWave, SHARE ? 2 : 1) void demod_pipe_kernel(Pa
                     // fastest): rare, so this wavefront computes both filters itself.  Exactly one of the
                     // two instants completes a symbol.
                     const int fk2 = until;
+#ifdef SAME_PROFILE
+                    atomicAdd(&g_same_prof_hw[7], 1ull);          // lanes that took this path (any workgroup)
+#endif
                     const float sa2 = demod_fast<NT, RING, true>(tlds, wring, lane, wpos + (uint32_t)fk2);
                     const float rem2 = L.until_next_ted - (float)cstar;
                     float z2 = 0.0f, s2 = 0.0f, e2 = 0.0f;

@@ -10,7 +10,7 @@ secs = float(sys.argv[2]) if len(sys.argv) > 2 else 2.0
 reps = int(sys.argv[3]) if len(sys.argv) > 3 else 3
 rate = int(sys.argv[4]) if len(sys.argv) > 4 else 22050
 T = int(rate * secs)
-x = sa.synth_afsk(C, T, rate, seed=1)
+x = sa.synth_afsk(C, T, rate, seed=1, noise_sigma=float(os.environ.get('SAME_NOISE', '0')))
 torch.cuda.synchronize()
 rx = sa.SameReceiverBuilder(rate).build_batch(C, link_only=not os.environ.get('SAME_TRANSPORT'))
 rx.set_kernel_timing(True)
@@ -53,3 +53,4 @@ if hasattr(rx._L, "same_debug_profile_pipe") and "pipe" in rx.kernel_name():
         print("  HW_ID (SIMD) per role [stage1, stage2, stage3, stage4]:",
               [f"{int(v) & 0xffffffff:#x} (simd {(int(v) >> 4) & 3})" for v in hw[:4]])
         print(f"  stage 2 polled stage 4 for the space magnitude {hw[5]/nstep:8.1f} clk/step; stage 4's space filter took {hw[6]/nstep:8.1f} clk/step")
+        print(f"  second TED instants inside one block (all workgroups): {int(hw[7])}")
