@@ -101,6 +101,10 @@ __device__ unsigned long long g_same_prof_pipe[9];
 // [role] = HW_ID of workgroup 0's wavefront in that role (SIMD = bits 5:4); [5] cycles stage 2 polled
 // stage 4 for the space magnitude, [6] cycles stage 4 spent on the space filter, [7] second instants of a block
 __device__ unsigned long long g_same_prof_hw[8];
+// stage 2 of workgroup 0, cycles per section of a block: [0] mark filter + hypot, [1] polling stage 4,
+// [2] combine + timing loop + next instant, [3] posting (mailboxes), [4] checkpoint + loop + barrier entry
+__device__ unsigned long long g_same_prof_s2[8];
+#define S2_LAP(i) do { const unsigned long long t_ = clock64(); s2_acc[i] += t_ - s2_t; s2_t = t_; } while (0)
 #define P3_HWID(role_) do { if (blockIdx.x == 0 && lane == 0) g_same_prof_hw[role_] = __builtin_amdgcn_s_getreg((31 << 11) | 4); } while (0)
 #define P3_T0() unsigned long long p3_work = 0, p3_wait = 0, p3_fb = 0, p3_t = clock64()
 #define P3_LAP(acc) do { const unsigned long long t_ = clock64(); acc += t_ - p3_t; p3_t = t_; } while (0)
@@ -111,6 +115,7 @@ __device__ unsigned long long g_same_prof_hw[8];
 #define P3_LAP(acc) do {} while (0)
 #define P3_REPORT(role_) do {} while (0)
 #define P3_HWID(role_) do {} while (0)
+#define S2_LAP(i) do {} while (0)
 #endif
 
 constexpr uint32_t kP3SymWords = 5u * kWave;              // per parity: header, zero, sym, terr, until
@@ -518,7 +523,11 @@ __global__ __launch_bounds__(4 * kWave, SHARE ? 2 : 1) void demod_pipe_kernel(Pa
         int until = cstar - (int)L.ted_clock - 1;      // block-relative index of the firing sample
         uint32_t wpos = 0;
         // one block: the instant, if this lane has one in it; hands a completed symbol to stage 3
+#ifdef SAME_PROFILE
+        unsigned long long s2_acc[5] = {0, 0, 0, 0, 0}, s2_t = clock64();
+#endif
         auto do_block = [&](uint32_t blk, uint32_t seq) {
+            S2_LAP(4);
             uint32_t hdr = 0;
             float zero = 0.0f, sym = 0.0f, terr = 0.0f, next = 0.0f;
             if (until < kB) {
@@ -526,6 +535,7 @@ __global__ __launch_bounds__(4 * kWave, SHARE ? 2 : 1) void demod_pipe_kernel(Pa
                 float sa_low;
                 if constexpr (SPLIT) {
                     const float hm = demod_half<NT, RING, 0>(tlds, wring, lane, wpos + (uint32_t)fk);
+                    S2_LAP(0);
 #ifdef SAME_PROFILE
                     const unsigned long long spin_t0 = clock64();
 #endif
@@ -535,6 +545,7 @@ __global__ __launch_bounds__(4 * kWave, SHARE ? 2 : 1) void demod_pipe_kernel(Pa
                         g_same_prof_hw[5] += clock64() - spin_t0;
 #endif
                     const float hs = __uint_as_float(spacebox[lane]);
+                    S2_LAP(1);
                     sa_low = rs_clamp(hm - hs, -1.0f, 1.0f);
                 } else {
                     sa_low = demod_fast<NT, RING, true>(tlds, wring, lane, wpos + (uint32_t)fk);
@@ -562,6 +573,7 @@ __global__ __launch_bounds__(4 * kWave, SHARE ? 2 : 1) void demod_pipe_kernel(Pa
                 }
             }
             until -= kB;
+            S2_LAP(2);
             if constexpr (SPLIT) posbox[((blk + 1u) & 1u) * kWave + lane] = (uint32_t)until;   // block blk + 1's instant
             lds_u32 *sb = symbox + (blk & 1u) * kP3SymWords + lane;
             sb[0] = hdr;
@@ -569,6 +581,7 @@ __global__ __launch_bounds__(4 * kWave, SHARE ? 2 : 1) void demod_pipe_kernel(Pa
             if (P.trace_cap) {                         // only the symbol trace records these two
                 sb[3 * kWave] = __float_as_uint(terr); sb[4 * kWave] = __float_as_uint(next);
             }
+            S2_LAP(3);
         };
         P3_T0();
         for (uint32_t s = 0; s < n_steps; ++s) {
@@ -607,6 +620,9 @@ __global__ __launch_bounds__(4 * kWave, SHARE ? 2 : 1) void demod_pipe_kernel(Pa
         }
 #ifndef SAME_P3_MARKS
         P3_REPORT(1);
+#endif
+#ifdef SAME_PROFILE
+        if (blockIdx.x == 0 && lane == 0) for (int i = 0; i < 5; ++i) g_same_prof_s2[i] += s2_acc[i];
 #endif
         phasebox[lane] = L.flags & F_TED_PHASE;
         lds_barrier();                                                 // stage 3 merges the phase bit
@@ -901,6 +917,13 @@ hipError_t launch_demod_pipe_i16(const Params &P, const State &S, const Output &
 }  // namespace same
 
 #ifdef SAME_PROFILE
+extern "C" int same_debug_profile_s2(unsigned long long *out8, int reset)
+{
+    unsigned long long z[8] = {0};
+    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(same::g_same_prof_s2), sizeof(z)) != hipSuccess) return -1;
+    if (reset && hipMemcpyToSymbol(HIP_SYMBOL(same::g_same_prof_s2), z, sizeof(z)) != hipSuccess) return -1;
+    return 0;
+}
 extern "C" int same_debug_profile_hw(unsigned long long *out8, int reset)
 {
     unsigned long long z[8] = {0};

@@ -54,3 +54,9 @@ if hasattr(rx._L, "same_debug_profile_pipe") and "pipe" in rx.kernel_name():
               [f"{int(v) & 0xffffffff:#x} (simd {(int(v) >> 4) & 3})" for v in hw[:4]])
         print(f"  stage 2 polled stage 4 for the space magnitude {hw[5]/nstep:8.1f} clk/step; stage 4's space filter took {hw[6]/nstep:8.1f} clk/step")
         print(f"  second TED instants inside one block (all workgroups): {int(hw[7])}")
+
+    if hasattr(rx._L, "same_debug_profile_s2"):
+        s2 = (ctypes.c_ulonglong * 8)()
+        rx._L.same_debug_profile_s2(s2, 1)
+        names = ["mark filter + hypot", "polling stage 4", "combine + timing loop + next instant", "posting", "checkpoint + loop + barrier entry"]
+        print("  stage 2 sections (clk/step): " + ", ".join(f"{n} {s2[i]/nstep:.0f}" for i, n in enumerate(names)))
