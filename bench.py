@@ -69,7 +69,7 @@ def run_steps(sa, rx, x, T, stream, steps, warmup, gather, barrier):
             kernel_ms.append(rx.last_kernel_ms())
             if keep_first[0]:
                 first.append(ev.copy())
-            last_bursts[0] = gather(ev)    # (copies the burst records out)
+            last_bursts[0] = gather(rx)    # (copies the burst records out of the queue)
             rx.drop_events(len(ev))
 
     def one_pass():
@@ -143,9 +143,9 @@ def main():
     # running kernel until the next API call, which would serialise launch k+1 with harvest k.)
     stream = 0
 
-    def gather(ev):
-        # the step's one collective: every rank's burst records to rank 0 (RCCL; vectorised packing)
-        recs = sd.pack_burst_events(ev, first_ch, zero_padded=True)
+    def gather(rx_):
+        # the step's one collective: every rank's burst records to rank 0 (RCCL; packed by the library)
+        recs = rx_.pack_bursts_np(first_ch)
         if not distributed:
             return len(recs)
         got = sd.gather_records(recs, dev)
@@ -244,7 +244,7 @@ def main():
             x2 = sa.synth_afsk(Cs, Ts, args.rate, seed=777, device=local_rank)
             rx2 = sa.SameReceiverBuilder(args.rate).build_batch(Cs, device=local_rank)
             rx2.set_kernel_timing(True)
-            e2, k2, _, _ = run_steps(sa, rx2, x2, Ts, stream, 3, 1, lambda ev: len(ev), lambda: None)
+            e2, k2, _, _ = run_steps(sa, rx2, x2, Ts, stream, 3, 1, lambda r: len(r.pack_bursts_np(0)), lambda: None)
             a2 = 4.0 * Cs * Ts / (k2 * 1e-3) / 1e9
             out["scaled"] = {
                 "workload": f"{Cs} channels x {Ts} samples per step (per-GPU shard of BASELINE.json configs[3])",
@@ -260,7 +260,7 @@ def main():
             x3 = sa.synth_afsk(C3, T3, R3, seed=778, device=local_rank)
             rx3 = sa.SameReceiverBuilder(R3).build_batch(C3, device=local_rank)
             rx3.set_kernel_timing(True)
-            e3, k3, _, _ = run_steps(sa, rx3, x3, T3, stream, 3, 1, lambda ev: len(ev), lambda: None)
+            e3, k3, _, _ = run_steps(sa, rx3, x3, T3, stream, 3, 1, lambda r: len(r.pack_bursts_np(0)), lambda: None)
             a3 = 4.0 * C3 * T3 / (k3 * 1e-3) / 1e9
             out["configs2_48k"] = {
                 "workload": f"{C3} channels x {T3} samples per step at {R3} Hz (BASELINE.json configs[2], 2 s of its 10 s)",

@@ -189,6 +189,12 @@ size_t same_batch_pending_events(same_batch *rx);
  * once and keep only the few events they care about (the bursts, say). */
 int same_batch_peek_events(same_batch *rx, const same_rx_event **events, size_t *n);
 int same_batch_drop_events(same_batch *rx, size_t n);
+/* The queued SAME_LINK_BURST events as fixed 304-byte records, in queue order: u32 channel +
+ * first_channel, u64 sample_counter, u32 length (<= 288), 288 payload bytes zero-padded (the record
+ * the multi-GPU gather moves, sameold_amd/distributed.py).  out == NULL: only counts.  Writes at most
+ * `cap` records; *n_records = bursts queued.  The queue is left as it is. */
+#define SAME_BURST_RECORD_BYTES 304
+int same_batch_pack_bursts(same_batch *rx, uint32_t first_channel, uint8_t *out, size_t cap, size_t *n_records);
 
 /* soft-symbol trace (SAME_BATCH_TRACE_SYMBOLS): SymbolEstimate stream of one channel
  * (rx/symsync.rs:52-71) with the input sample counter of each TED instant */

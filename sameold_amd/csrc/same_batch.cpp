@@ -16,6 +16,7 @@
 #include <new>
 #include <string>
 #include <thread>
+#include <utility>
 #include <vector>
 
 #include "../../include/same_rx.h"
@@ -707,6 +708,46 @@ int same_batch_drop_events(same_batch *rx, size_t n)
     if (n > rx->queue.size() - rx->queue_head) return fail(SAME_EINVAL, "more events than are queued");
     rx->queue_head += n;
     if (rx->queue_head == rx->queue.size()) { rx->queue.clear(); rx->queue_head = 0; }
+    return SAME_OK;
+}
+
+int same_batch_pack_bursts(same_batch *rx, uint32_t first_channel, uint8_t *out, size_t cap, size_t *n_records)
+{
+    if (!rx || !n_records) return fail(SAME_EINVAL, "null argument");
+    static_assert(SAME_BURST_RECORD_BYTES == 16 + SAME_EVENT_MAX_BYTES, "record layout");
+    const same_rx_event *ev = rx->queue.data() + rx->queue_head;
+    const size_t n_ev = rx->queue.size() - rx->queue_head;
+    // where each thread's bursts go: count per slice, then copy side by side
+    const unsigned hw = std::thread::hardware_concurrency();
+    const size_t n_threads = (out && n_ev >= 32768) ? std::min<size_t>({8u, hw ? hw : 1u}) : 1u;
+    std::vector<size_t> count(n_threads + 1, 0);
+    auto slice = [&](size_t t) { return std::pair<size_t, size_t>(n_ev * t / n_threads, n_ev * (t + 1) / n_threads); };
+    auto count_slice = [&](size_t t) {
+        size_t c = 0;
+        for (size_t i = slice(t).first; i < slice(t).second; ++i) c += ev[i].kind == SAME_LINK_BURST;
+        count[t + 1] = c;
+    };
+    auto copy_slice = [&](size_t t) {
+        size_t at = count[t];
+        for (size_t i = slice(t).first; i < slice(t).second && at < cap; ++i) {
+            if (ev[i].kind != SAME_LINK_BURST) continue;
+            uint8_t *r = out + at++ * SAME_BURST_RECORD_BYTES;
+            const uint32_t ch = ev[i].channel + first_channel, len = std::min<uint32_t>(ev[i].len, SAME_EVENT_MAX_BYTES);
+            std::memcpy(r, &ch, 4); std::memcpy(r + 4, &ev[i].sample_counter, 8); std::memcpy(r + 12, &len, 4);
+            std::memcpy(r + 16, ev[i].bytes, len);
+            std::memset(r + 16 + len, 0, SAME_EVENT_MAX_BYTES - len);
+        }
+    };
+    auto run = [&](auto fn) {
+        std::vector<std::thread> pool;
+        for (size_t t = 1; t < n_threads; ++t) pool.emplace_back(fn, t);
+        fn(0);
+        for (std::thread &th : pool) th.join();
+    };
+    run(count_slice);
+    for (size_t t = 0; t < n_threads; ++t) count[t + 1] += count[t];
+    *n_records = count[n_threads];
+    if (out && cap) run(copy_slice);
     return SAME_OK;
 }
 

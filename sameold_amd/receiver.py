@@ -175,6 +175,7 @@ def load_library() -> C.CDLL:
     sig("same_batch_pending_events", C.c_size_t, vp)
     sig("same_batch_peek_events", C.c_int, vp, P(P(Event)), P(C.c_size_t))
     sig("same_batch_drop_events", C.c_int, vp, C.c_size_t)
+    sig("same_batch_pack_bursts", C.c_int, vp, u32, vp, C.c_size_t, P(C.c_size_t))
     sig("same_batch_read_trace", C.c_int, vp, u32, P(SymbolTrace), C.c_size_t, P(C.c_size_t))
     sig("same_batch_last_kernel_ms", C.c_int, vp, P(f32))
     sig("same_batch_set_kernel_timing", None, vp, C.c_int)
@@ -431,6 +432,16 @@ class SameBatchReceiver:
         buf = (C.c_char * (n.value * C.sizeof(Event))).from_address(C.addressof(ptr.contents))
         out = np.frombuffer(buf, dtype=EVENT_DTYPE, count=n.value)
         out.flags.writeable = False
+        return out
+
+    def pack_bursts_np(self, first_channel: int = 0) -> np.ndarray:
+        """The queued bursts as uint8 [n, 304] records with global channel numbers (same_batch_pack_bursts;
+        the layout of sameold_amd.distributed).  The queue is left as it is."""
+        n = C.c_size_t()
+        _check(self._L.same_batch_pack_bursts(self._h, first_channel, None, 0, C.byref(n)))
+        out = np.empty((n.value, 304), dtype=np.uint8)
+        if n.value:
+            _check(self._L.same_batch_pack_bursts(self._h, first_channel, C.c_void_p(out.ctypes.data), n.value, C.byref(n)))
         return out
 
     def drop_events(self, n: int) -> None:

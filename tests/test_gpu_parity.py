@@ -537,6 +537,22 @@ def test_two_instants_in_one_block(sa, ob, amp):
         assert out["pipe"][0].get(c, []) == oracle_events(ob, cfg, x[:, c]), f"channel {c}"
 
 
+def test_pack_bursts_matches_the_python_packer(sa):
+    """same_batch_pack_bursts (what bench.py gathers across ranks) == distributed.pack_burst_events on the
+    same queue, single- and multi-threaded (the library splits queues of 32 768 events and more)."""
+    from sameold_amd import distributed as sd
+    for n_ch, secs in ((64, 4), (4096, 6)):
+        x = sa.synth_afsk(n_ch, 22050 * secs, 22050, seed=5)
+        rx = sa.SameReceiverBuilder(22050).build_batch(n_ch)
+        rx.process_tensor(x); rx.sync()
+        ev = rx.peek_events_np()
+        want = sd.pack_burst_events(ev, first_channel=1000)
+        got = rx.pack_bursts_np(first_channel=1000)
+        assert len(ev) > (32768 if n_ch > 64 else 0) and got.shape == want.shape and len(got) > n_ch
+        assert np.array_equal(got, want)
+        assert len(rx.peek_events_np()) == len(ev)          # the queue is untouched
+
+
 def test_peek_and_drop_events_equal_poll(sa):
     """same_batch_peek_events / same_batch_drop_events: the queue viewed in place, then released."""
     n_ch, n = 64, 22050 * 4
