@@ -47,7 +47,70 @@ def parse():
     ap.add_argument("--scaled-channels", type=int, default=32768)
     ap.add_argument("--check", type=int, default=16, help="channels of rank 0 verified against the oracle")
     ap.add_argument("--traffic", type=float, default=None, help="HBM bytes/launch from a PMC pass (profiles/)")
+    ap.add_argument("--cpu-seconds", type=float, default=3.0, help="minimum wall time of the CPU baseline run")
+    ap.add_argument("--plumbing", action="store_true",
+                    help="CPU-only check of the N-rank path (gloo, fabricated burst records, no kernel)")
+    ap.add_argument("--master-port", type=int, default=0, help="rendezvous port when bench.py starts the ranks itself")
     return ap.parse_args()
+
+
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start N ranks of this script under
+    torch.distributed.run as a CHILD process and pass its output and exit code on.  Decided before
+    anything touches torch.cuda (a process that has initialised the GPU must never exec or be
+    replaced; this one never initialises it at all)."""
+    import socket
+    import subprocess
+    port = args.master_port
+    if not port:
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
+
+
+def plumbing(args):
+    """The N-rank path without a GPU: gloo process group, every rank fabricates the burst records of
+    its own channel shard, one gather per step to rank 0, max-over-ranks timing, rank 0 prints the
+    JSON line.  No demodulation happens (value 0); tests/test_distributed_cpu.py runs this."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from sameold_amd import distributed as sd
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo")
+    C = args.channels
+    first_ch = rank * C
+    per_rank = 3 + rank
+    recs = sd.pack_bursts([(first_ch + i, 1000 * rank + i, b"ZCZC-PLUMBING-%d-" % rank) for i in range(per_rank)])
+    got = 0
+    t0 = time.perf_counter()
+    for _ in range(args.warmup + args.steps):
+        r = sd.gather_records(recs, torch.device("cpu"))
+        got = len(r) if r is not None else 0
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if rank == 0:
+        print(json.dumps({"metric": "plumbing (no demodulation)", "value": 0.0, "unit": "Msamples/s", "n_gpus": world,
+                          "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / max(args.steps, 1) * 1e3, 3),
+                          "scaling": "weak", "data": "fabricated burst records",
+                          "config": {"workload": "plumbing", "channels_per_gpu": C,
+                                     "bursts_gathered_last_step": int(got),
+                                     "first_channels": [r * C for r in range(world)]}}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
 
 
 def run_steps(sa, rx, x, T, stream, steps, warmup, gather, barrier):
@@ -107,6 +170,10 @@ def run_steps(sa, rx, x, T, stream, steps, warmup, gather, barrier):
 
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(spawn_ranks(args))
+    if args.plumbing:
+        return plumbing(args)
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -115,6 +182,9 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     distributed = world > 1
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; start it as `python bench.py --gpus N` "
+                         "(it launches the ranks itself) or under torch.distributed.run with a matching --nproc-per-node")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
     torch.cuda.set_device(local_rank)
@@ -221,20 +291,31 @@ def main():
             if not ok:
                 out["config"]["parity"] = "MISMATCH"
         if not args.no_cpu_baseline:
+            # One SameReceiver per channel over a CONTIGUOUS stream (the sample is transposed to
+            # channel-major on the host first), one worker pinned per physical core, repeated until the
+            # run is long enough to time arithmetic rather than thread start-up.
             cc = min(args.cpu_channels, C)
             if xs is None or xs.shape[1] < cc:
                 xs = x[:, :cc].contiguous().cpu().numpy()
-            xs = np.ascontiguousarray(xs[:, :cc])
-            cores = len(os.sched_getaffinity(0))
+            xc = np.ascontiguousarray(xs[:, :cc].T)          # [channel][time]
+            cores = ob.physical_cores()
+            logical = len(os.sched_getaffinity(0))
             t1 = time.perf_counter()
-            ob.batch_run_time_major(cfg, xs, cores)
+            ob.batch_run_channel_major(cfg, xc, cpus=cores, reps=1)
+            probe = time.perf_counter() - t1
+            reps = max(1, int(np.ceil(args.cpu_seconds / max(probe, 1e-3))))
+            t1 = time.perf_counter()
+            ob.batch_run_channel_major(cfg, xc, cpus=cores, reps=reps)
             dt = time.perf_counter() - t1
+            rate = cc * T * reps / dt / 1e6
             out["cpu_baseline"] = {
-                "value": round(cc * T / dt / 1e6, 2), "unit": "Msamples/s", "cores": cores, "kind": "port",
-                "sample": f"first {cc} channels x {T} samples of the same synthetic input, link layer only, "
-                          f"{dt:.2f} s wall on {cores} threads (scalar C restatement of sameold 0.6.0; "
-                          "the Rust reference cannot be built in this image)",
+                "value": round(rate, 2), "unit": "Msamples/s", "cores": len(cores), "kind": "port",
+                "per_core": round(rate / len(cores), 2), "logical_cpus": logical,
+                "sample": f"first {cc} channels x {T} samples of the same synthetic input, channel-major on the host, "
+                          f"{reps} repetition(s), link layer only, {dt:.2f} s wall on {len(cores)} threads pinned one per "
+                          f"physical core (scalar C restatement of sameold 0.6.0; the Rust reference cannot be built in this image)",
             }
+            del xc
         del xs
         if not args.no_scaled:
             # same kernel, the per-GPU shard of configs[3]: 32768 channels (2 s per step to bound memory)

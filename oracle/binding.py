@@ -179,6 +179,8 @@ def lib() -> C.CDLL:
     sig("so_rx_trace_count", C.c_size_t, vp)
     sig("so_rx_set_link_only", None, vp, C.c_int)
     sig("so_batch_run_time_major", C.c_size_t, P(Config), vp, C.c_size_t, C.c_size_t, C.c_int, P(Event), C.c_size_t)
+    sig("so_batch_run_channel_major", C.c_size_t, P(Config), vp, C.c_size_t, C.c_size_t, C.c_int, P(C.c_int), C.c_int,
+        P(Event), C.c_size_t)
 
     sig("so_derive", None, P(Config), P(Derived))
     sig("so_matched_filter_taps", None, C.c_uint32, f32p, P(C.c_uint32))
@@ -408,4 +410,53 @@ def batch_run_time_major(cfg: Config, x: np.ndarray, nthreads: int, cap: int = 1
     T, Cn = x.shape
     evs = (Event * cap)()
     n = lib().so_batch_run_time_major(C.byref(cfg), C.c_void_p(x.ctypes.data), Cn, T, nthreads, evs, cap)
+    return n, evs
+
+
+_EVENT_NP = np.dtype([("kind", "<u4"), ("len", "<u4"), ("sample_counter", "<u8"), ("symbol_count", "<u8"),
+                      ("aux", "<u4"), ("aux2", "<u4"), ("bytes", "u1", (EVENT_MAX_BYTES,))])
+assert _EVENT_NP.itemsize == C.sizeof(Event)
+
+
+def events_by_channel(n: int, evs, n_channels: int):
+    """Link events of a batch run (aux = channel) -> per channel list of (kind, sample_counter, bytes),
+    in time order.  Workers append under a mutex, so events of one channel are already in order."""
+    a = np.frombuffer(evs, dtype=_EVENT_NP, count=min(n, len(evs)))
+    out = [[] for _ in range(n_channels)]
+    order = np.argsort(a["aux"], kind="stable")
+    for i in order:
+        r = a[i]
+        out[int(r["aux"])].append((int(r["kind"]), int(r["sample_counter"]),
+                                   r["bytes"][: min(int(r["len"]), EVENT_MAX_BYTES)].tobytes()))
+    return out
+
+
+def physical_cores() -> List[int]:
+    """One allowed logical CPU per physical core (the first sibling of each core this process may run on)."""
+    allowed = sorted(os.sched_getaffinity(0))
+    seen, out = set(), []
+    for cpu in allowed:
+        try:
+            with open(f"/sys/devices/system/cpu/cpu{cpu}/topology/thread_siblings_list") as f:
+                key = f.read().strip()
+        except OSError:
+            key = str(cpu)
+        if key not in seen:
+            seen.add(key)
+            out.append(cpu)
+    return out
+
+
+def batch_run_channel_major(cfg: Config, x: np.ndarray, cpus: Optional[List[int]] = None, nthreads: Optional[int] = None,
+                            reps: int = 1, cap: int = 1 << 16):
+    """CPU baseline proper: x is [C, T] float32, every channel contiguous; one worker per entry of
+    `cpus` (pinned) or `nthreads` unpinned workers.  Returns (n_events of the first repetition, events)."""
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    Cn, T = x.shape
+    evs = (Event * cap)()
+    if cpus:
+        arr = (C.c_int * len(cpus))(*cpus)
+        n = lib().so_batch_run_channel_major(C.byref(cfg), C.c_void_p(x.ctypes.data), Cn, T, len(cpus), arr, reps, evs, cap)
+    else:
+        n = lib().so_batch_run_channel_major(C.byref(cfg), C.c_void_p(x.ctypes.data), Cn, T, nthreads or 1, None, reps, evs, cap)
     return n, evs

@@ -15,6 +15,7 @@
 
 #include <math.h>
 #include <pthread.h>
+#include <sched.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -1540,6 +1541,68 @@ size_t so_batch_run_time_major(const so_config *cfg, const float *x, size_t C, s
         jobs[i] = (batch_job){ cfg, x, C, T, C * (size_t)i / (size_t)nthreads,
                                C * (size_t)(i + 1) / (size_t)nthreads, ev, cap, &count, &mu };
         pthread_create(&th[i], NULL, batch_worker, &jobs[i]);
+    }
+    for (int i = 0; i < nthreads; ++i) pthread_join(th[i], NULL);
+    free(th); free(jobs);
+    return count;
+}
+
+/* Channel-major variant for an honest CPU baseline (bench.py): x is [C][T], every channel a
+ * contiguous stream (what a host application feeding one SameReceiver per channel has), each
+ * worker owns a contiguous channel range, optionally pinned to cpus[i] (one logical CPU per
+ * physical core, chosen by the caller), and runs its range `reps` times with fresh receivers so
+ * that the timed region is long enough to measure arithmetic rather than thread start-up.
+ * Events of the first repetition are returned (aux = channel). */
+typedef struct cm_job {
+    const so_config *cfg; const float *x; size_t C, T, c0, c1; int reps; int cpu;
+    so_event *ev; size_t cap; size_t *count; pthread_mutex_t *mu;
+} cm_job;
+
+static void *cm_worker(void *p)
+{
+    cm_job *j = (cm_job *)p;
+    if (j->cpu >= 0) {
+        cpu_set_t set; CPU_ZERO(&set); CPU_SET(j->cpu, &set);
+        (void)pthread_setaffinity_np(pthread_self(), sizeof(set), &set);
+    }
+    for (int r = 0; r < j->reps; ++r) {
+        for (size_t c = j->c0; c < j->c1; ++c) {
+            so_rx *rx = NULL;
+            if (so_rx_new(j->cfg, &rx)) continue;
+            so_rx_set_link_only(rx, 1);
+            const float *xs = j->x + c * j->T;
+            size_t off = 0; so_event tmp;
+            for (;;) {
+                size_t used = 0;
+                int got = so_rx_process(rx, xs + off, j->T - off, &used, &tmp);
+                off += used;
+                if (!got) break;
+                if (r != 0) continue;
+                tmp.aux = (uint32_t)c;
+                pthread_mutex_lock(j->mu);
+                if (*j->count < j->cap) j->ev[*j->count] = tmp;
+                (*j->count)++;
+                pthread_mutex_unlock(j->mu);
+            }
+            so_rx_free(rx);
+        }
+    }
+    return NULL;
+}
+size_t so_batch_run_channel_major(const so_config *cfg, const float *x, size_t C, size_t T, int nthreads,
+                                  const int *cpus, int reps, so_event *ev, size_t cap)
+{
+    if (nthreads < 1) nthreads = 1;
+    if ((size_t)nthreads > C) nthreads = (int)(C ? C : 1);
+    if (reps < 1) reps = 1;
+    pthread_t *th = (pthread_t *)malloc(sizeof(pthread_t) * (size_t)nthreads);
+    cm_job *jobs = (cm_job *)malloc(sizeof(cm_job) * (size_t)nthreads);
+    pthread_mutex_t mu = PTHREAD_MUTEX_INITIALIZER;
+    size_t count = 0;
+    for (int i = 0; i < nthreads; ++i) {
+        jobs[i] = (cm_job){ cfg, x, C, T, C * (size_t)i / (size_t)nthreads, C * (size_t)(i + 1) / (size_t)nthreads,
+                            reps, cpus ? cpus[i] : -1, ev, cap, &count, &mu };
+        pthread_create(&th[i], NULL, cm_worker, &jobs[i]);
     }
     for (int i = 0; i < nthreads; ++i) pthread_join(th[i], NULL);
     free(th); free(jobs);

@@ -134,6 +134,9 @@ void so_rx_set_link_only(so_rx *rx, int link_only);
  * link-only, returns total number of link events; nthreads >= 1 */
 size_t so_batch_run_time_major(const so_config *cfg, const float *x, size_t n_channels,
                                size_t n_samples, int nthreads, so_event *ev, size_t cap);
+/* x is [C][T] channel-major; workers optionally pinned to cpus[i]; the range is run `reps` times */
+size_t so_batch_run_channel_major(const so_config *cfg, const float *x, size_t n_channels, size_t n_samples,
+                                  int nthreads, const int *cpus, int reps, so_event *ev, size_t cap);
 
 /* ---- derived constants, exposed for tests / cross-checks ---- */
 typedef struct so_derived {

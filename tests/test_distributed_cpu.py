@@ -134,3 +134,31 @@ def test_vectorised_burst_packing_matches_the_record_layout():
     assert got.shape == (3, sd.RECORD_BYTES) and np.array_equal(got, want)
     assert sd.unpack_bursts(got)[1] == (4096 + 8, 2000 + (1 << 33), b"NNNN")
     assert sd.gather_records(got, None) is got      # no process group: identity
+
+
+def test_bench_gpus_2_starts_two_ranks_itself():
+    """`python bench.py --gpus 2` must launch the ranks itself (round-1 finding: --gpus was parsed and
+    ignored).  Plumbing mode: gloo, fabricated burst records, no kernel -- checks the world size rank 0
+    reports and that the gathered burst count comes from both ranks (3 + 4)."""
+    import json
+    import subprocess
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--plumbing", "--steps", "2",
+                        "--warmup", "1", "--channels", "16"], capture_output=True, text=True, timeout=300, env=env)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 2 and out["warmup"] == 1
+    assert out["config"]["bursts_gathered_last_step"] == 7
+    assert out["config"]["first_channels"] == [0, 16]
+
+
+def test_bench_refuses_a_world_size_that_contradicts_gpus():
+    import subprocess
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert p.returncode != 0 and "WORLD_SIZE" in (p.stderr + p.stdout)
