@@ -208,10 +208,11 @@ def main():
     torch.cuda.synchronize()
     rx = sa.SameReceiverBuilder(args.rate).build_batch(C, device=local_rank)
     rx.set_kernel_timing(True)
-    # 0 = the library's own non-blocking stream.  (The input was produced on torch's stream and
-    # synchronised above.  On the legacy null stream the runtime holds a launch enqueued behind a
-    # running kernel until the next API call, which would serialise launch k+1 with harvest k.)
-    stream = 0
+    # None = the library's own non-blocking stream.  (The input was produced on torch's stream and
+    # synchronised above; x stays alive for the whole run.  On the legacy null stream the runtime holds
+    # a launch enqueued behind a running kernel until the next API call, which would serialise launch
+    # k+1 with harvest k.)
+    stream = None
 
     def gather(rx_):
         # the step's one collective: every rank's burst records to rank 0 (RCCL; packed by the library)

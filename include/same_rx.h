@@ -45,6 +45,9 @@ enum {
 };
 const char *same_last_error(void);
 uint32_t same_rx_abi_version(void);
+/* "SAME_SOURCE_HASH=<sha256>" of the sources the library was built from (sameold_amd/build.py
+ * rebuilds when it differs from the tree's) */
+const char *same_rx_source_hash(void);
 
 /* ------------------------------------------------------------------ builder
  * Mirrors `SameReceiverBuilder` (rx/builder.rs:22-37): a plain copyable value with the
@@ -154,13 +157,27 @@ uint32_t same_batch_n_channels(const same_batch *rx);
 uint64_t same_batch_input_sample_counter(const same_batch *rx); /* input_sample_counter() :175-177 */
 int same_batch_device(const same_batch *rx);
 
-/* The hot path.  `d_x` is a DEVICE pointer to n_samples * n_channels floats that stays
- * valid until the stream reaches the end of this call's work; `hip_stream` is a
- * hipStream_t (NULL = the library's own stream).  Asynchronous: events become visible
- * to same_batch_poll_events after same_batch_sync.  Replaces the sample loop of
- * SameReceiver::process (receiver.rs:243-270) for every channel. */
+/* The hot path.  `d_x` is a DEVICE pointer to n_samples * n_channels floats; `hip_stream`
+ * is the hipStream_t the kernels are launched on.  Asynchronous: events become visible to
+ * same_batch_poll_events after same_batch_sync.  Replaces the sample loop of
+ * SameReceiver::process (receiver.rs:243-270) for every channel.
+ *
+ * Stream contract.  Every value of `hip_stream` other than SAME_STREAM_OWN is a real stream
+ * handle -- NULL is HIP's legacy default stream, exactly as in hipLaunchKernelGGL -- and the
+ * launch is ordered on it like any other work of the caller.  SAME_STREAM_OWN selects the
+ * library's private non-blocking stream, which is NOT ordered after anything the caller has
+ * queued elsewhere: whoever produced `d_x` on another stream calls same_batch_order_after(rx,
+ * producer_stream) first (one event record + one stream wait, no host blocking).  In both
+ * cases `d_x` must stay valid, and unmodified, until the launch has finished: until
+ * same_batch_sync returns, or until the second-next process call on this handle returns
+ * (at most two launches are in flight; a process call collects the launch before the
+ * previous one).  A caching allocator must not be allowed to reuse the buffer earlier. */
+#define SAME_STREAM_OWN ((void *)(intptr_t)-1)
 int same_batch_process_device(same_batch *rx, const float *d_x, size_t n_samples,
                               uint32_t layout, void *hip_stream);
+/* make the library's own stream wait for everything queued on `producer_stream` so far
+ * (a hipStream_t; NULL = the legacy default stream) */
+int same_batch_order_after(same_batch *rx, void *producer_stream);
 /* int16 PCM on the device, cast to f32 without scaling in the kernel
  * (crates/samedec/src/app.rs:112); 2 bytes/sample of HBM traffic */
 int same_batch_process_device_i16(same_batch *rx, const int16_t *d_x, size_t n_samples,
@@ -221,6 +238,15 @@ const char *same_batch_kernel_name(const same_batch *rx);
  * as the Rust iterator leaves its source.  (The device runs ahead over the whole slice;
  * samples past *consumed must therefore be re-presented unchanged, which any iterator
  * adaptor does.) */
+/* same_rx_flush mirrors flush() (receiver.rs:216-224): it feeds 4 s of zeros and returns at the
+ * first Message.  The reference's iterator stops consuming zeros there; the device has already run
+ * over all of them.  Further flushes are unaffected (they present zeros again, which is what the
+ * device saw), and that is how samedec drains a file (crates/samedec/src/app.rs:118).  Real samples
+ * are not: while the device is ahead over flush zeros, same_rx_process returns SAME_EINVAL instead
+ * of silently skipping that many samples of the caller's audio; same_rx_reset (or flushing until
+ * the zeros are used up) makes the handle usable again.  The same contract covers a caller that
+ * abandons same_rx_process mid-slice: samples between *consumed and n must be re-presented
+ * unchanged. */
 typedef struct same_rx same_rx;
 int same_rx_build(const same_rx_builder *b, int device, same_rx **out);  /* build() */
 void same_rx_free(same_rx *rx);

@@ -7,7 +7,9 @@ reproduce the reference's one-rounding-per-operation f32 arithmetic bit for bit.
 """
 from __future__ import annotations
 
+import hashlib
 import os
+import re
 import shutil
 import subprocess
 import sys
@@ -43,27 +45,50 @@ def flags() -> list:
       + (["-DSAME_P1_SPLIT=1"] if os.environ.get("SAME_P1_SPLIT") else [])
 
 
+def source_hash() -> str:
+    """sha256 over everything the library is made of: sources, headers, this script's flags."""
+    h = hashlib.sha256()
+    for f in sorted(SOURCES + HEADERS):
+        with open(os.path.join(CSRC, f), "rb") as fh:
+            h.update(f.encode() + b"\0" + fh.read() + b"\0")
+    h.update(" ".join(flags()).encode())
+    return h.hexdigest()
+
+
+_MARK = re.compile(rb"SAME_SOURCE_HASH=([0-9a-f]{64})")
+
+
+def built_hash(path: str = LIB):
+    """The source hash compiled into an existing library (same_rx_source_hash()), read from the file
+    itself so that nothing has to be loaded; None when the file is missing or predates the scheme."""
+    try:
+        with open(path, "rb") as fh:
+            m = _MARK.search(fh.read())
+    except OSError:
+        return None
+    return m.group(1).decode() if m else None
+
+
 def is_stale() -> bool:
+    """The shipped binary must be the one HEAD's sources build: compare hashes, not mtimes (the .so
+    travels to the GPU box with fresh mtimes and is git-ignored)."""
     if not os.path.exists(LIB) or not os.path.exists(SAMEDEC):
         return True
-    t = os.path.getmtime(LIB)
-    for f in SOURCES + HEADERS:
-        if os.path.getmtime(os.path.join(CSRC, f)) > t:
-            return True
-    return os.path.getmtime(__file__) > t
+    return built_hash() != source_hash()
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
     if not force and not is_stale():
         return LIB
     objs = []
+    digest = source_hash()
     cc = hipcc()
     bdir = os.path.join(HERE, "build")
     os.makedirs(bdir, exist_ok=True)
     procs = []
     for src in SOURCES:
         obj = os.path.join(bdir, os.path.splitext(src)[0] + ".o")
-        cmd = [cc] + flags() + ["-c", os.path.join(CSRC, src), "-o", obj]
+        cmd = [cc] + flags() + [f'-DSAME_SOURCE_HASH="{digest}"', "-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd))
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))

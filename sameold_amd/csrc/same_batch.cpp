@@ -63,6 +63,14 @@ struct EventQueue {
     size_t size() const { return n; }
     same_rx_event *data() { return buf; }
     void clear() { n = 0; }
+    // drop the first `head` (already polled) events by moving the rest to the front; returns the new head (0)
+    size_t compact(size_t head)
+    {
+        if (head == 0) return 0;
+        if (head < n) std::memmove(buf, buf + head, (n - head) * sizeof(same_rx_event));
+        n -= head;
+        return 0;
+    }
     // room for `extra` more events; returns where they go, or nullptr when out of memory
     same_rx_event *grow(size_t extra)
     {
@@ -115,9 +123,14 @@ struct same_batch {
     bool overflowed = false;
     bool use_fast = false;           // configuration has a latency-optimised kernel
     bool force_generic = false;      // SAME_BATCH_GENERIC_KERNEL (tests compare both kernels)
+    bool debug = false;              // SAME_DEBUG: harvest statistics on stderr
+    int host_threads = 0;            // SAME_HOST_THREADS: harvest threads (0 = choose)
     // staging for host / channel-major inputs
     void *d_stage = nullptr; size_t stage_bytes = 0;
     void *d_stage2 = nullptr; size_t stage2_bytes = 0;
+    void *d_upload = nullptr; size_t upload_bytes = 0;      // host-buffer entry points: grow-only upload slab
+    void *d_zero = nullptr; size_t zero_bytes = 0;          // flush: grow-only slab of zeros
+    hipEvent_t ev_order = nullptr;                          // same_batch_order_after
     // kernel timing
     bool timing = false;
     bool have_timing = false;
@@ -181,6 +194,19 @@ size_t carve_state(const same::Params &P, char *base, same::State &S)
     return (cv.off + 255) & ~size_t(255);
 }
 
+// every environment knob of the library, read once per batch
+void read_knobs(same_batch *rx)
+{
+    auto num = [](const char *name, int unset) { const char *e = std::getenv(name); return e ? std::atoi(e) : unset; };
+    auto tri = [](const char *name) { const char *e = std::getenv(name); return e ? (std::atoi(e) ? 1 : -1) : 0; };
+    rx->P.knob_pipe = tri("SAME_PIPE");
+    rx->P.knob_pipe_lanes = num("SAME_PIPE_LANES", 0);
+    rx->P.knob_pipe_split = tri("SAME_PIPE_SPLIT");
+    rx->P.knob_mirror = tri("SAME_MIRROR");
+    rx->debug = std::getenv("SAME_DEBUG") != nullptr;
+    rx->host_threads = std::max(0, num("SAME_HOST_THREADS", 0));
+}
+
 int ensure_output(same_batch *rx, same_batch::Slot &sl, size_t n_samples, same::Output &O)
 {
     // Worst case per channel: an acquisition attempt (Searching ... NoCarrier) needs a
@@ -224,7 +250,7 @@ int ensure_stage(void **p, size_t *have, size_t need)
 int harvest_slot(same_batch *rx, same_batch::Slot &sl)
 {
     if (!sl.in_flight) return SAME_OK;
-    const bool dbg = std::getenv("SAME_DEBUG") != nullptr;
+    const bool dbg = rx->debug;
     auto t_begin = std::chrono::steady_clock::now();
     // wait for THIS launch only (its cursors have landed in pinned memory); a later launch
     // may still be running on the compute stream
@@ -315,7 +341,7 @@ int harvest_slot(same_batch *rx, same_batch::Slot &sl)
     if (n_real >= 16384u && n_ch >= 64u) {
         const unsigned hw = std::thread::hardware_concurrency();
         n_threads = std::min<uint32_t>({16u, hw ? hw : 1u, n_ch / 32u});
-        if (const char *e = std::getenv("SAME_HOST_THREADS")) n_threads = std::max(1, std::atoi(e));
+        if (rx->host_threads > 0) n_threads = (uint32_t)rx->host_threads;
     }
     if (rx->parts.size() < n_threads) rx->parts.resize(n_threads);
     std::vector<Part> &parts = rx->parts;
@@ -339,6 +365,10 @@ int harvest_slot(same_batch *rx, same_batch::Slot &sl)
     auto t_replayed = std::chrono::steady_clock::now();
     size_t total = 0;
     for (const Part &p : parts) total += p.out.size();
+    // a consumer that always polls less than is pending never drains the queue: reclaim the polled
+    // prefix once it is at least as large as what is still waiting (amortised O(1) per event)
+    if (rx->queue_head && rx->queue_head >= rx->queue.size() - rx->queue_head)
+        rx->queue_head = rx->queue.compact(rx->queue_head);
     same_rx_event *dst = rx->queue.grow(total);
     if (total && !dst) return fail(SAME_ENOMEM, "event queue");
     {
@@ -459,7 +489,8 @@ int process_device_any(same_batch *rx, const SampleT *d_x, size_t n_samples, uin
     if (!rx || (!d_x && n_samples)) return fail(SAME_EINVAL, "null argument");
     if (n_samples == 0) return SAME_OK;
     HIP_TRY(hipSetDevice(rx->device));
-    hipStream_t stream = hip_stream ? (hipStream_t)hip_stream : rx->own_stream;
+    // SAME_STREAM_OWN: the library's private stream; anything else (NULL included) is the caller's stream
+    hipStream_t stream = hip_stream == SAME_STREAM_OWN ? rx->own_stream : (hipStream_t)hip_stream;
     if (layout == SAME_LAYOUT_TIME_MAJOR) return process_time_major(rx, d_x, n_samples, stream);
     if (layout != SAME_LAYOUT_CHANNEL_MAJOR) return fail(SAME_EINVAL, "unknown layout %u", layout);
     // channel-major: transpose slabs of time through a staging buffer
@@ -498,12 +529,13 @@ int process_host_any(same_batch *rx, const SampleT *h_x, size_t n_samples, uint3
     // upload in slabs so arbitrarily long host streams need bounded device memory
     const size_t C = rx->P.n_channels;
     const size_t slab = std::max<size_t>(1, std::min<size_t>(n_samples, ((size_t)256 << 20) / (C * sizeof(SampleT))));
-    void *d_in = nullptr;
-    HIP_TRY(hipMalloc(&d_in, slab * C * sizeof(SampleT)));
-    int rc = SAME_OK;
+    int rc = ensure_stage(&rx->d_upload, &rx->upload_bytes, slab * C * sizeof(SampleT));
+    if (rc) return rc;
+    void *d_in = rx->d_upload;
     for (size_t t0 = 0; t0 < n_samples && rc == SAME_OK; t0 += slab) {
         const size_t n = std::min(slab, n_samples - t0);
         hipError_t e;
+        // (the previous slab's launch was collected below, so the buffer is free again)
         if (layout == SAME_LAYOUT_TIME_MAJOR) {
             e = hipMemcpy(d_in, h_x + t0 * C, n * C * sizeof(SampleT), hipMemcpyHostToDevice);
         } else {
@@ -511,10 +543,9 @@ int process_host_any(same_batch *rx, const SampleT *h_x, size_t n_samples, uint3
                             n * sizeof(SampleT), C, hipMemcpyHostToDevice);
         }
         if (e != hipSuccess) { rc = fail(SAME_EHIP, "upload failed: %s", hipGetErrorString(e)); break; }
-        rc = process_device_any(rx, (const SampleT *)d_in, n, layout, nullptr);
+        rc = process_device_any(rx, (const SampleT *)d_in, n, layout, SAME_STREAM_OWN);
         if (rc == SAME_OK) rc = harvest(rx);
     }
-    (void)hipFree(d_in);
     if (rc == SAME_OK && rx->overflowed) return fail(SAME_EOVERFLOW, "event/burst pool overflow");
     return rc;
 }
@@ -525,6 +556,12 @@ int process_host_any(same_batch *rx, const SampleT *h_x, size_t n_samples, uint3
 extern "C" {
 
 const char *same_last_error(void) { return g_last_error.c_str(); }
+
+#ifndef SAME_SOURCE_HASH
+#define SAME_SOURCE_HASH "unknown"
+#endif
+// sha256 of the sources this binary was built from (sameold_amd/build.py compares it with the tree)
+const char *same_rx_source_hash(void) { return "SAME_SOURCE_HASH=" SAME_SOURCE_HASH; }
 
 int same_batch_new(const same_rx_builder *b, uint32_t n_channels, int device, uint32_t flags,
                    same_batch **out)
@@ -543,6 +580,7 @@ int same_batch_new(const same_rx_builder *b, uint32_t n_channels, int device, ui
     std::vector<float> taps;
     int rc = same::derive_params(*b, n_channels, rx->P, taps);
     if (rc) { delete rx; return fail(rc, "builder rejected (code %d)", rc); }
+    read_knobs(rx);
     rx->P.trace_cap = (flags & SAME_BATCH_TRACE_SYMBOLS) ? 4096u : 0u;
     rx->P.ticks = (flags & SAME_BATCH_LINK_ONLY) ? 0u : 1u;
     rx->P.tick_interburst = (uint32_t)same::max_interburst_symbols();
@@ -566,6 +604,7 @@ int same_batch_new(const same_rx_builder *b, uint32_t n_channels, int device, ui
         return cleanup(fail(SAME_EINVAL, "configuration needs %zu bytes of LDS per wavefront (limit 160 KiB)", same::demod_lds_bytes(rx->P)));
     TRY_OR_CLEAN(hipStreamCreateWithFlags(&rx->own_stream, hipStreamNonBlocking));
     TRY_OR_CLEAN(hipStreamCreateWithFlags(&rx->copy_stream, hipStreamNonBlocking));
+    TRY_OR_CLEAN(hipEventCreateWithFlags(&rx->ev_order, hipEventDisableTiming));
     for (auto &sl : rx->slot) {
         TRY_OR_CLEAN(hipEventCreate(&sl.ev_start));
         TRY_OR_CLEAN(hipEventCreate(&sl.ev_stop));
@@ -610,6 +649,9 @@ void same_batch_free(same_batch *rx)
     if (rx->h_wake) (void)hipHostFree(rx->h_wake);
     if (rx->d_stage) (void)hipFree(rx->d_stage);
     if (rx->d_stage2) (void)hipFree(rx->d_stage2);
+    if (rx->d_upload) (void)hipFree(rx->d_upload);
+    if (rx->d_zero) (void)hipFree(rx->d_zero);
+    if (rx->ev_order) (void)hipEventDestroy(rx->ev_order);
     if (rx->own_stream) (void)hipStreamDestroy(rx->own_stream);
     delete rx;
 }
@@ -652,16 +694,27 @@ int same_batch_flush(same_batch *rx)
     // four seconds of zeros per channel (receiver.rs:216-224), generated on the device
     const size_t n = (size_t)rx->P.input_rate * 4;
     const size_t slab = std::max<size_t>(1, std::min<size_t>(n, ((size_t)256 << 20) / ((size_t)rx->P.n_channels * sizeof(float))));
-    void *d_zero = nullptr;
-    HIP_TRY(hipMalloc(&d_zero, slab * rx->P.n_channels * sizeof(float)));
-    hipError_t e = hipMemset(d_zero, 0, slab * rx->P.n_channels * sizeof(float));
-    int rc = e == hipSuccess ? SAME_OK : fail(SAME_EHIP, "memset failed: %s", hipGetErrorString(e));
+    if (slab * rx->P.n_channels * sizeof(float) > rx->zero_bytes) {
+        int rc0 = ensure_stage(&rx->d_zero, &rx->zero_bytes, slab * rx->P.n_channels * sizeof(float));
+        if (rc0) return rc0;
+        HIP_TRY(hipMemset(rx->d_zero, 0, rx->zero_bytes));       // once per growth: the kernels only read it
+    }
+    int rc = SAME_OK;
     for (size_t t0 = 0; t0 < n && rc == SAME_OK; t0 += slab) {
-        rc = process_device_any<float>(rx, (const float *)d_zero, std::min(slab, n - t0), SAME_LAYOUT_TIME_MAJOR, nullptr);
+        rc = process_device_any<float>(rx, (const float *)rx->d_zero, std::min(slab, n - t0), SAME_LAYOUT_TIME_MAJOR, SAME_STREAM_OWN);
         if (rc == SAME_OK) rc = harvest(rx);
     }
-    (void)hipFree(d_zero);
     return rc;
+}
+
+int same_batch_order_after(same_batch *rx, void *producer_stream)
+{
+    if (!rx) return fail(SAME_EINVAL, "null handle");
+    if (producer_stream == SAME_STREAM_OWN) return SAME_OK;
+    HIP_TRY(hipSetDevice(rx->device));
+    HIP_TRY(hipEventRecord(rx->ev_order, (hipStream_t)producer_stream));
+    HIP_TRY(hipStreamWaitEvent(rx->own_stream, rx->ev_order, 0));
+    return SAME_OK;
 }
 
 int same_batch_sync(same_batch *rx)
@@ -812,6 +865,7 @@ const char *same_batch_kernel_name(const same_batch *rx)
 struct same_rx {
     same_batch *batch = nullptr;
     uint64_t reported = 0;           // samples the caller has logically consumed
+    uint64_t zeros_until = 0;        // the device ran over flush zeros up to this sample (0 = no such run-ahead)
     std::deque<same_rx_event> events;
 };
 
@@ -842,9 +896,21 @@ int same_rx_build(const same_rx_builder *b, int device, same_rx **out)
 }
 void same_rx_free(same_rx *rx) { if (rx) { same_batch_free(rx->batch); delete rx; } }
 
+static int rx_process(same_rx *rx, const float *x, size_t n, size_t *consumed, same_rx_event *ev);
+
 int same_rx_process(same_rx *rx, const float *x, size_t n, size_t *consumed, same_rx_event *ev)
 {
     if (!rx || !consumed || !ev || (!x && n)) return fail(SAME_EINVAL, "null argument");
+    *consumed = 0;
+    if (rx->zeros_until > rx->reported && n)
+        return fail(SAME_EINVAL, "a flush returned at its first message with the device %llu zero samples ahead; "
+                                 "reset the receiver (or flush again) before presenting audio",
+                    (unsigned long long)(rx->zeros_until - rx->reported));
+    return rx_process(rx, x, n, consumed, ev);
+}
+
+static int rx_process(same_rx *rx, const float *x, size_t n, size_t *consumed, same_rx_event *ev)
+{
     *consumed = 0;
     // x[0] sits at absolute sample `reported`; the device may already be past it
     const uint64_t device_at = same_batch_input_sample_counter(rx->batch);
@@ -880,12 +946,14 @@ int same_rx_flush(same_rx *rx, same_rx_event *msg)
     while (off < n) {
         size_t used = 0;
         same_rx_event ev;
-        int got = same_rx_process(rx, zeros.data() + off, n - off, &used, &ev);
+        int got = rx_process(rx, zeros.data() + off, n - off, &used, &ev);
         if (got < 0) return got;
         off += used;
         if (!got) break;
         if (ev.kind == SAME_TRANSPORT_MSG_START || ev.kind == SAME_TRANSPORT_MSG_END) {
             if (msg) *msg = ev;
+            // the device has consumed all n zeros, the caller only those up to this event
+            rx->zeros_until = same_batch_input_sample_counter(rx->batch);
             return 1;
         }
     }
@@ -897,6 +965,7 @@ int same_rx_reset(same_rx *rx)
     if (!rx) return fail(SAME_EINVAL, "null handle");
     rx->events.clear();
     rx->reported = 0;
+    rx->zeros_until = 0;
     return same_batch_reset(rx->batch);
 }
 uint32_t same_rx_input_rate(const same_rx *rx) { return rx ? same_batch_input_rate(rx->batch) : 0; }

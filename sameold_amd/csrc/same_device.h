@@ -48,6 +48,13 @@ struct Params {
     uint32_t ticks;
     uint32_t tick_interburst; // MAX_INTERBURST_SYMBOLS  (rx/assembler.rs:85)
     uint32_t tick_history;    // MAX_HISTORY_DURATION    (rx/assembler.rs:92-93)
+    // Test / profiling overrides of the kernel dispatch.  Read from the environment ONCE, when the
+    // batch is created (same_batch.cpp: read_knobs); nothing on the launch path calls getenv.
+    // Tri-state knobs: 0 = unset (a zero-initialised Params behaves like the defaults), +1 = on, -1 = off.
+    int32_t knob_pipe;        // SAME_PIPE=0 -> -1 never the wavefront pipeline, SAME_PIPE=1 -> +1 whenever it applies
+    int32_t knob_pipe_lanes;  // SAME_PIPE_LANES: 0 unset, else 16 / 32 / 64 channels per workgroup
+    int32_t knob_pipe_split;  // SAME_PIPE_SPLIT
+    int32_t knob_mirror;      // SAME_MIRROR (one-wavefront kernel's mirrored window)
 };
 
 // flag bits of State::flags

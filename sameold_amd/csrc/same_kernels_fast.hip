@@ -341,11 +341,11 @@ static constexpr size_t fast_lds_bytes()
 // The mirrored window costs 16 KB of LDS per wavefront: 3 wavefronts fit a CU's 160 KB instead
 // of 4, so it is used while the batch needs at most 3 wavefronts per CU (and only for the
 // 42-tap filters, whose ring is 64 slots).
-static bool fast_use_mirror(uint32_t n_channels, uint32_t ntaps, uint32_t max_block)
+static bool fast_use_mirror(const Params &P, uint32_t max_block)
 {
     if (max_block < (uint32_t)kBlockMirror) return false;     // 18-sample blocks need the timing bound
-    if (const char *e = getenv("SAME_MIRROR")) return atoi(e) != 0 && ntaps == 42u;
-    return ntaps == 42u && (n_channels + kWave - 1) / kWave <= 3u * 256u;
+    if (P.knob_mirror != 0) return P.knob_mirror > 0 && P.ntaps == 42u;
+    return P.ntaps == 42u && (P.n_channels + kWave - 1) / kWave <= 3u * 256u;
 }
 
 template <int NT, int DCL, typename SampleT>
@@ -354,7 +354,7 @@ static hipError_t launch_fast_cfg(const Params &P, const State &S, const Output 
 {
     const uint32_t grid = (P.n_channels + kWave - 1) / kWave;
     constexpr bool CAN_MIRROR = (NT == 42);
-    const bool mirror = CAN_MIRROR && fast_use_mirror(P.n_channels, P.ntaps, max_block_len(P));
+    const bool mirror = CAN_MIRROR && fast_use_mirror(P, max_block_len(P));
     const size_t lds = mirror ? fast_lds_bytes<NT, DCL, CAN_MIRROR>() : fast_lds_bytes<NT, DCL, false>();
     // v_med3_f32 == f32::clamp unless a bound is -0.0 (or NaN, which the builder rejects)
     const bool med3 = !(P.agc_min == 0.0f && std::signbit(P.agc_min)) && !(P.agc_max == 0.0f && std::signbit(P.agc_max));
@@ -389,7 +389,7 @@ uint32_t fast_win_ring(const Params &P) { return (P.ntaps + kBlock - 1 <= 64u) ?
 uint32_t fast_block_len(const Params &P)
 {
     if (pipe_kernel_selected(P)) return pipe_block_len(P);
-    if (P.ntaps == 42u && fast_use_mirror(P.n_channels, P.ntaps, max_block_len(P))) return (uint32_t)kBlockMirror;
+    if (P.ntaps == 42u && fast_use_mirror(P, max_block_len(P))) return (uint32_t)kBlockMirror;
     return P.ntaps >= 84u ? (uint32_t)kBlock48k : (uint32_t)kBlock;
 }
 

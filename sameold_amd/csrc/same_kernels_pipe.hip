@@ -818,7 +818,7 @@ static bool agc_clamp_is_med3(const Params &P)
 static uint32_t pipe_lanes(const Params &P)
 {
     if (!(P.eq_nff == 6u && P.eq_nfb == 4u) || !agc_clamp_is_med3(P)) return kWave;
-    if (const char *e = getenv("SAME_PIPE_LANES")) { const int v = atoi(e); if (v == 16 || v == 32 || v == 64) return (uint32_t)v; }
+    if (P.knob_pipe_lanes == 16 || P.knob_pipe_lanes == 32 || P.knob_pipe_lanes == 64) return (uint32_t)P.knob_pipe_lanes;
     if (P.n_channels <= 16u * 256u && P.n_channels % 16u == 0u) return 16u;
     if (P.n_channels <= 32u * 256u && P.n_channels % 32u == 0u) return 32u;
     return kWave;
@@ -831,7 +831,7 @@ uint32_t pipe_kernel_stages(const Params &P)
     if (!(r22 || r48 || r44) || (P.n_channels % pipe_lanes(P)) != 0u) return 0;
     if (!((P.eq_nff == 6u && P.eq_nfb == 4u) || (P.eq_nff == 1u && P.eq_nfb == 1u))) return 0;
     if (P.block_len != 16u || max_block_len(P) < (r22 ? (uint32_t)kBlockMirror : pipe_block_len(P))) return 0;
-    if (const char *e = getenv("SAME_PIPE")) return atoi(e) ? 4u : 0u;       // 0 = off, anything else = on
+    if (P.knob_pipe != 0) return P.knob_pipe > 0 ? 4u : 0u;
     return P.n_channels <= 32768u ? 4u : 0u;
 }
 bool pipe_kernel_selected(const Params &P) { return pipe_kernel_stages(P) != 0u; }
@@ -872,8 +872,7 @@ static hipError_t launch_pipe_cfg(const Params &P, const State &S, const Output 
     constexpr bool CAN_SHARE = (NT == 42);
     const bool share = CAN_SHARE && P.n_channels > 16384u;
     const bool med3 = agc_clamp_is_med3(P);
-    const char *split_env = getenv("SAME_PIPE_SPLIT");
-    const bool share_split = split_env ? atoi(split_env) != 0 : true;
+    const bool share_split = P.knob_pipe_split != 0 ? P.knob_pipe_split > 0 : true;
 #define SAME_PIPE_LAUNCH(NFF, NFB, M3)                                                                                  \
     (share ? (share_split ? launch_pipe_one<NT, NFF, NFB, M3, CAN_SHARE, 64, CAN_SHARE, SampleT>(P, S, O, taps, x, n_blocks, counter0, stream)    \
                           : launch_pipe_one<NT, NFF, NFB, M3, CAN_SHARE, 64, false, SampleT>(P, S, O, taps, x, n_blocks, counter0, stream))     \
@@ -883,8 +882,7 @@ static hipError_t launch_pipe_cfg(const Params &P, const State &S, const Output 
         // the default configuration: narrow workgroups for small batches, and stage 2 split with stage 4's
         // wavefront wherever stage 2 is (one of) the longest -- everywhere except 64-channel workgroups at
         // 22.05 kHz, whose symbol stage is longer still
-        const char *e = getenv("SAME_PIPE_SPLIT");
-        const bool split = e ? atoi(e) != 0 : (NT != 42 || lanes != kWave);
+        const bool split = P.knob_pipe_split != 0 ? P.knob_pipe_split > 0 : (NT != 42 || lanes != kWave);
 #define SAME_PIPE_LANES_LAUNCH(LN)                                                                                          \
         (split ? launch_pipe_one<NT, 6, 4, true, false, LN, true, SampleT>(P, S, O, taps, x, n_blocks, counter0, stream)    \
                : launch_pipe_one<NT, 6, 4, true, false, LN, false, SampleT>(P, S, O, taps, x, n_blocks, counter0, stream))

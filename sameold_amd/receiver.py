@@ -26,6 +26,7 @@ LINK_NO_CARRIER, LINK_SEARCHING, LINK_READING, LINK_BURST = 0, 1, 2, 3
 TRANSPORT_IDLE, TRANSPORT_ASSEMBLING, TRANSPORT_MSG_START, TRANSPORT_MSG_END, TRANSPORT_MSG_ERR = 16, 17, 18, 19, 20
 LAYOUT_TIME_MAJOR, LAYOUT_CHANNEL_MAJOR = 0, 1
 BATCH_LINK_ONLY, BATCH_TRACE_SYMBOLS, BATCH_GENERIC_KERNEL = 1, 2, 4
+STREAM_OWN = (1 << 64) - 1          # SAME_STREAM_OWN: (void *)-1, the library's own stream
 EVENT_MAX_BYTES = 288
 
 ERRORS = {-1: "EINVAL", -2: "EDCLEN", -3: "EAGCLIMITS", -4: "EEQORDER", -5: "ENODEVICE",
@@ -166,6 +167,7 @@ def load_library() -> C.CDLL:
     sig("same_batch_input_sample_counter", u64, vp)
     sig("same_batch_device", C.c_int, vp)
     sig("same_batch_process_device", C.c_int, vp, vp, C.c_size_t, u32, vp)
+    sig("same_batch_order_after", C.c_int, vp, vp)
     sig("same_batch_process_device_i16", C.c_int, vp, vp, C.c_size_t, u32, vp)
     sig("same_batch_process_host", C.c_int, vp, vp, C.c_size_t, u32)
     sig("same_batch_process_host_i16", C.c_int, vp, vp, C.c_size_t, u32)
@@ -320,6 +322,7 @@ class SameBatchReceiver:
                  | (BATCH_GENERIC_KERNEL if generic_kernel else 0))
         _check(self._L.same_batch_new(builder._h, n_channels, device, flags, C.byref(h)))
         self._h = h
+        self._inflight = []          # input tensors of launches that may still be running (process_tensor)
 
     def __del__(self):
         if getattr(self, "_h", None):
@@ -343,14 +346,28 @@ class SameBatchReceiver:
         _check(self._L.same_batch_reset(self._h))
 
     def process_device_ptr(self, ptr: int, n_samples: int, layout: int = LAYOUT_TIME_MAJOR,
-                           stream: int = 0, i16: bool = False):
-        """Hot path: `ptr` is a device pointer (e.g. torch_tensor.data_ptr()), `stream` a
-        hipStream_t handle (e.g. torch.cuda.current_stream().cuda_stream) or 0."""
+                           stream: Optional[int] = None, i16: bool = False):
+        """Hot path: `ptr` is a device pointer (e.g. torch_tensor.data_ptr()).  `stream`: None = the
+        library's own non-blocking stream (SAME_STREAM_OWN), otherwise a hipStream_t handle -- 0 is the
+        legacy default stream, like any HIP API.  The caller keeps the buffer alive and unmodified until
+        `sync()` or until the second-next process call returns, and orders the library's own stream after
+        whatever produced the buffer (`order_after`); `process_tensor` does both."""
         fn = self._L.same_batch_process_device_i16 if i16 else self._L.same_batch_process_device
-        _check(fn(self._h, C.c_void_p(ptr), n_samples, layout, C.c_void_p(stream)))
+        _check(fn(self._h, C.c_void_p(ptr), n_samples, layout, C.c_void_p(STREAM_OWN if stream is None else stream)))
 
-    def process_tensor(self, x, layout: int = LAYOUT_TIME_MAJOR, stream: int = 0):
-        """x: torch CUDA tensor, float32 or int16, [T, C] (time-major) or [C, T]."""
+    def order_after(self, producer_stream: int):
+        """Make the library's own stream wait for the work queued so far on `producer_stream`
+        (a hipStream_t handle, 0 = the legacy default stream)."""
+        _check(self._L.same_batch_order_after(self._h, C.c_void_p(producer_stream)))
+
+    def process_tensor(self, x, layout: int = LAYOUT_TIME_MAJOR, stream: Optional[int] = None):
+        """x: torch CUDA tensor, float32 or int16, [T, C] (time-major) or [C, T].
+
+        stream None: runs on the library's own stream, ordered after the work already queued on
+        torch's current stream of x's device (whatever produced x: a generator kernel, a cast, a
+        `.contiguous()` copy).  A reference to x is held until its launch can no longer be running
+        (two process calls later, or `sync()`), so torch's caching allocator cannot hand the memory
+        to someone else while the kernel still reads it."""
         import torch
         assert x.is_cuda and x.is_contiguous()
         if layout == LAYOUT_TIME_MAJOR:
@@ -358,12 +375,14 @@ class SameBatchReceiver:
         else:
             ch, n = x.shape
         assert ch == self.n_channels
-        if x.dtype == torch.float32:
-            self.process_device_ptr(x.data_ptr(), n, layout, stream, False)
-        elif x.dtype == torch.int16:
-            self.process_device_ptr(x.data_ptr(), n, layout, stream, True)
-        else:
+        if x.dtype not in (torch.float32, torch.int16):
             raise TypeError("float32 or int16 input")
+        if stream is None:
+            self.order_after(torch.cuda.current_stream(x.device).cuda_stream)
+        self._inflight.append(x)
+        if len(self._inflight) > 2:
+            del self._inflight[0]
+        self.process_device_ptr(x.data_ptr(), n, layout, stream, x.dtype == torch.int16)
 
     def process_host(self, x: np.ndarray, layout: int = LAYOUT_TIME_MAJOR):
         """x: numpy float32/int16 array, [T, C] (time-major) or [C, T]."""
@@ -383,6 +402,7 @@ class SameBatchReceiver:
 
     def sync(self):
         _check(self._L.same_batch_sync(self._h))
+        self._inflight.clear()
 
     def set_kernel_timing(self, enable: bool):
         self._L.same_batch_set_kernel_timing(self._h, int(enable))

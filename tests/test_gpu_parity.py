@@ -52,6 +52,41 @@ def oracle_events(ob, cfg, x, link_only=False):
     return [e.as_tuple() for e in ob.Receiver(cfg, link_only=link_only).run(np.ascontiguousarray(x))]
 
 
+def assert_every_channel_matches_oracle(ob, cfg, x, ev, slab=2048):
+    """Link events (kind, input sample counter, burst bytes) of EVERY channel of a device batch against
+    the oracle, which runs the same samples on all host cores (ob.batch_run_time_major, link layer
+    only).  `x` is the device tensor [T, C]; `ev` the polled events (numpy, ordered by channel then
+    time); transport events in `ev` are ignored.  Channels go to the host in slabs to bound memory."""
+    n_ch = x.shape[1]
+    link = ev[ev["kind"] <= 3]
+    threads = len(os.sched_getaffinity(0))
+    first = np.searchsorted(link["channel"], np.arange(n_ch + 1))
+    assert np.all(np.diff(link["channel"].astype(np.int64)) >= 0), "events must be ordered by channel"
+    for c0 in range(0, n_ch, slab):
+        c1 = min(n_ch, c0 + slab)
+        xs = x[:, c0:c1].contiguous().cpu().numpy()
+        cap = 1 << 16
+        while True:
+            n, evs = ob.batch_run_time_major(cfg, xs, threads, cap=cap)
+            if n <= cap:
+                break
+            cap = int(n) + 1024
+        ref = np.frombuffer(evs, dtype=ob._EVENT_NP, count=n)
+        ref = ref[np.argsort(ref["aux"], kind="stable")]          # workers append in time order per channel
+        mine = link[first[c0]:first[c1]]
+        assert len(mine) == len(ref), f"channels {c0}..{c1}: {len(mine)} device events, oracle {len(ref)}"
+        bad = np.flatnonzero((mine["channel"] - c0 != ref["aux"]) | (mine["kind"] != ref["kind"])
+                             | (mine["sample_counter"] != ref["sample_counter"]) | (mine["len"] != ref["len"]))
+        assert len(bad) == 0, f"first mismatch at channel {int(mine['channel'][bad[0]])}: {mine[bad[0]]} vs {ref[bad[0]]}"
+        b = np.flatnonzero(mine["kind"] == 3)
+        if len(b):
+            ln = np.minimum(mine["len"][b], 288)[:, None]
+            cols = np.arange(288)[None, :]
+            diff = (mine["bytes"][b] != ref["bytes"][b]) & (cols < ln)
+            assert not diff.any(), f"burst bytes differ on channel {int(mine['channel'][b[np.flatnonzero(diff.any(axis=1))[0]]])}"
+    return len(link)
+
+
 # ------------------------------------------------------------------ golden recordings
 @pytest.mark.parametrize("name", ["npt", "two_and_two", "long_message"])
 def test_sample_recordings_match_oracle_and_text(sa, ob, name):
@@ -398,7 +433,7 @@ def test_hypot_matches_glibc(sa, ob):
 
 
 # ------------------------------------------------------------------ fast vs generic kernel
-PIPE_ENV = {"fast": "0", "pipe": "1"}      # SAME_PIPE: wavefront pipeline off / on (read at every launch)
+PIPE_ENV = {"fast": "0", "pipe": "1"}      # SAME_PIPE: wavefront pipeline off / on (read when the batch is created)
 
 
 @pytest.mark.parametrize("rate,variant", [(22050, "pipe"), (22050, "fast"), (48000, "pipe"), (48000, "fast"),
@@ -409,7 +444,7 @@ def test_fast_kernel_equals_generic_kernel(sa, ob, rate, variant, monkeypatch):
     any-configuration kernel (and therefore the oracle) bit for bit, including when chunk sizes
     are not whole blocks (remainder handled by the generic kernel)."""
     import torch
-    monkeypatch.setenv("SAME_PIPE", PIPE_ENV[variant])    # read at every launch
+    monkeypatch.setenv("SAME_PIPE", PIPE_ENV[variant])    # read when the batch is created
     n_ch, n = 128, rate * 3 + 7
     x = mixed_batch(sa, n_ch, n, seed=rate + 1, rate=rate, noise=0.05)
     xd = torch.from_numpy(x).cuda()
@@ -465,7 +500,7 @@ def test_pipeline_workgroup_widths(sa, ob, monkeypatch, rate):
     x = mixed_batch(sa, n_ch, n, seed=31 + rate, rate=rate, noise=0.05)
     out = {}
     for lanes in ("16", "32", "64"):
-        monkeypatch.setenv("SAME_PIPE_LANES", lanes)         # read at every launch
+        monkeypatch.setenv("SAME_PIPE_LANES", lanes)         # read when the batch is created
         rx = sa.SameReceiverBuilder(rate).build_batch(n_ch)
         assert rx.kernel_name() == "demod_pipe_kernel"
         for off in range(0, n, 30001):
@@ -724,8 +759,8 @@ def test_awgn_trials_bit_exact_and_scored(sa, ob):
 def test_full_size_round_trip_4096_channels_10s(sa, ob):
     """configs[1] at full size (4 096 channels x 220 500 samples, the bench workload): every channel's
     decoded header equals the header it was sent (modulate -> demodulate round trip), the link
-    layer delivered three bursts of it, and 48 channels spread over the batch match the oracle
-    event for event."""
+    layer delivered three bursts of it, and EVERY channel's link events (kind, sample counter, burst
+    bytes) equal the oracle's."""
     import torch
     n_ch, n, seed = 4096, 220500, 20260000
     x = sa.synth_afsk(n_ch, n, 22050, seed=seed)
@@ -745,19 +780,14 @@ def test_full_size_round_trip_4096_channels_10s(sa, ob):
         want = sa.synth_payload(seed, c)
         assert first[c] == want, f"channel {c}"
         assert n_bursts[c] >= 3
-    cfg = ob.default_config(22050)
-    for c in range(0, n_ch, 86):
-        mine = ev[ev["channel"] == c]
-        got = [(int(r["kind"]), int(r["sample_counter"]), r["bytes"][: min(int(r["len"]), 288)].tobytes()) for r in mine]
-        xc = x[:, c].contiguous().cpu().numpy()
-        assert got == oracle_events(ob, cfg, xc), f"channel {c}"
+    assert_every_channel_matches_oracle(ob, ob.default_config(22050), x, ev)
 
 
 @pytest.mark.parametrize("n_ch,rate,seconds", [(32768, 22050, 2.6), (16384, 48000, 2.6)])
 def test_full_width_batches_deliver_what_was_sent(sa, ob, n_ch, rate, seconds):
     """The per-GPU shard of configs[3] (32 768 channels) and configs[2] (16 384 channels at 48 kHz)
     at full width: every burst a channel delivers begins with the header it was sent, nearly all
-    channels deliver one within the first 2.6 s, and channels spread over the batch match the oracle."""
+    channels deliver one within the first 2.6 s, and every channel matches the oracle event for event."""
     n, seed = int(rate * seconds), 31337
     x = sa.synth_afsk(n_ch, n, rate, seed=seed)
     rx = sa.SameReceiverBuilder(rate).build_batch(n_ch, link_only=True)
@@ -771,9 +801,95 @@ def test_full_width_batches_deliver_what_was_sent(sa, ob, n_ch, rate, seconds):
         c = int(r["channel"])
         want = payload.setdefault(c, sa.synth_payload(seed, c))
         assert r["bytes"][: len(want)].tobytes() == want, f"channel {c}"
-    cfg = ob.default_config(rate)
-    for c in range(0, n_ch, n_ch // 24):
-        mine = ev[ev["channel"] == c]
-        got = [(int(r["kind"]), int(r["sample_counter"]), r["bytes"][: min(int(r["len"]), 288)].tobytes()) for r in mine]
-        xc = x[:, c].contiguous().cpu().numpy()
-        assert got == oracle_events(ob, cfg, xc, link_only=True), f"channel {c}"
+    assert_every_channel_matches_oracle(ob, ob.default_config(rate), x, ev)
+
+
+def test_configs2_full_length_16384_channels_48k_10s(sa, ob):
+    """BASELINE.json configs[2] as stated: 16 384 channels at 48 kHz, 10 s (480 000 samples per channel,
+    31 GB resident), every channel against the oracle."""
+    n_ch, rate, seed = 16384, 48000, 4242
+    n = rate * 10
+    x = sa.synth_afsk(n_ch, n, rate, seed=seed)
+    rx = sa.SameReceiverBuilder(rate).build_batch(n_ch, link_only=True)
+    assert rx.kernel_name() == "demod_pipe_kernel"
+    rx.process_tensor(x)
+    rx.sync()
+    ev = rx.poll_events_np()
+    bursts = ev[ev["kind"] == sa.LINK_BURST]
+    assert len(np.unique(bursts["channel"])) == n_ch
+    assert assert_every_channel_matches_oracle(ob, ob.default_config(rate), x, ev) > 20 * n_ch
+
+
+# ------------------------------------------------------------------ stream contract, flush run-ahead, small polls
+def test_process_tensor_is_ordered_after_the_producer_stream(sa, ob):
+    """The library's own stream must wait for whatever produced the input on torch's stream (round-1
+    advisor finding): the input here is the last link of a chain of asynchronous torch kernels on a
+    side stream, handed over without a synchronise, and the temporaries are dropped at once."""
+    import torch
+    n_ch, n = 64, 22050 * 5
+    base = sa.synth_afsk(n_ch, n, 22050, seed=77)
+    want = base.cpu().numpy()
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    rx = sa.SameReceiverBuilder(22050).build_batch(n_ch, link_only=True)
+    with torch.cuda.stream(side):
+        junk = torch.empty((8192, 8192), device="cuda")
+        for _ in range(6):
+            junk = junk @ junk.T * 0.0                   # keeps the side stream busy for a while
+        y = base.double()
+        for _ in range(4):
+            y = y * 1.0 + junk[0, 0].double() * 0.0
+        xd = y.float().contiguous()                       # produced behind all of the above
+        rx.process_tensor(xd)                            # no synchronise in between
+        del xd, y, junk                                  # the allocator may want the memory back right away
+        scratch = torch.full((n, n_ch), 1.0e9, device="cuda")   # ... and would scribble over it if it got it
+    rx.sync()
+    del scratch
+    got = events_by_channel(rx)
+    cfg = ob.default_config(22050)
+    for c in range(n_ch):
+        assert got.get(c, []) == oracle_events(ob, cfg, want[:, c], link_only=True), f"channel {c}"
+
+
+def test_audio_after_an_early_flush_is_refused_until_reset(sa):
+    """flush() returns at its first message while the device has run over all 4 s of zeros; real audio
+    presented next must not be silently skipped (round-1 advisor finding)."""
+    pcm = load_pcm("long_message").astype(np.float32)
+    rx = sa.SameReceiverBuilder(22050).samedec().build()
+    assert list(rx.iter_messages(pcm)) == []
+    assert rx.flush() == TEST_MESSAGE                      # returned early: zeros left over on the device
+    with pytest.raises(sa.receiver.SameError):
+        next(rx.iter_events(load_pcm("npt").astype(np.float32)), None)
+    assert rx.flush() is None                             # flushing on is fine (zeros again) and uses them up
+    rx.reset()
+    assert list(rx.iter_messages(load_pcm("npt").astype(np.float32))) == ["ZCZC-PEP-NPT-000000+0030-2771820-TEST    -"]
+
+
+def test_polling_less_than_is_pending_still_delivers_everything_in_order(sa, ob):
+    """A consumer that never drains the queue (cap < pending on every poll) while launches keep
+    appending: nothing lost, nothing reordered (the polled prefix is reclaimed inside the handle)."""
+    import torch
+    n_ch, n = 64, 22050 * 8
+    x = sa.synth_afsk(n_ch, n, 22050, seed=5150)
+    ref = sa.SameReceiverBuilder(22050).build_batch(n_ch)
+    ref.process_tensor(x); ref.sync()
+    want = [e.as_tuple() + (e.channel,) for e in ref.poll_events()]
+    rx = sa.SameReceiverBuilder(22050).build_batch(n_ch)
+    got = []
+    step = 22050
+    for off in range(0, n, step):
+        rx.process_tensor(x[off:off + step].contiguous())
+        got += [e.as_tuple() + (e.channel,) for e in rx.poll_events(max_events=7)]
+    rx.sync()
+    while True:
+        more = rx.poll_events(max_events=5)
+        if not more:
+            break
+        got += [e.as_tuple() + (e.channel,) for e in more]
+    # the reference handle saw one call, this one eight: per channel the streams are identical
+    def by_channel(evs):
+        out = {}
+        for t in evs:
+            out.setdefault(t[3], []).append(t[:3])
+        return out
+    assert by_channel(got) == by_channel(want)

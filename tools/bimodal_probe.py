@@ -16,7 +16,7 @@ rx.set_kernel_timing(True)
 L = rx._L
 ms = []
 for k in range(steps):
-    rx.process_device_ptr(x.data_ptr(), T, sa.LAYOUT_TIME_MAJOR, 0)
+    rx.process_device_ptr(x.data_ptr(), T, sa.LAYOUT_TIME_MAJOR, None)
     ev = rx.poll_events_np()
     if len(ev):
         ms.append(rx.last_kernel_ms())

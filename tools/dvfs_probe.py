@@ -15,7 +15,7 @@ rx.set_kernel_timing(True)
 ms = []
 t0 = time.perf_counter()
 for k in range(14):
-    rx.process_device_ptr(x.data_ptr(), T, sa.LAYOUT_TIME_MAJOR, 0)   # harvests launch k-1 (waits for it) after enqueueing k
+    rx.process_device_ptr(x.data_ptr(), T, sa.LAYOUT_TIME_MAJOR, None)   # harvests launch k-1 (waits for it) after enqueueing k
     if k: ms.append(rx.last_kernel_ms())
     rx.poll_events_np()
     if gap: rx.sync(); time.sleep(gap * 1e-3)

@@ -25,7 +25,7 @@ for t in ths: t.start()
 time.sleep(0.3)
 ms = []
 for k in range(8):
-    rx.process_device_ptr(x.data_ptr(), T, sa.LAYOUT_TIME_MAJOR, 0)
+    rx.process_device_ptr(x.data_ptr(), T, sa.LAYOUT_TIME_MAJOR, None)
     rx.sync()
     ms.append(rx.last_kernel_ms())
     rx.poll_events_np()

@@ -16,7 +16,7 @@ for mode in "ABC":
     for k in range(15):
         if k == 3:
             rx.sync(); torch.cuda.synchronize(); t_start = time.perf_counter()
-        t0 = time.perf_counter(); rx.process_device_ptr(x.data_ptr(), T, sa.LAYOUT_TIME_MAJOR, 0)
+        t0 = time.perf_counter(); rx.process_device_ptr(x.data_ptr(), T, sa.LAYOUT_TIME_MAJOR, None)
         t1 = time.perf_counter()
         ev = rx.poll_events_np() if mode in "BC" else None
         t2 = time.perf_counter()
