@@ -1,0 +1,91 @@
+#!/usr/bin/env python3
+"""BASELINE.json configs[4], "BER curve bit-matched to CPU reference": one batch of AWGN trials
+(default 65 536: one burst each, Eb/N0 0..14 dB) demodulated on the GPU and by the oracle on all host
+cores over the IDENTICAL noisy samples.  Asserts that every trial's link events are equal and that the
+two BER tallies (detection, intact headers, bits compared, bit errors per grid point) are equal row
+for row, then writes the rows.
+
+    python tests/helpers/ber_vs_oracle.py --trials 65536 --out profiles/r02_ber_vs_oracle.json
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.dirname(HERE))
+
+
+def run(trials=65536, rate=22050, seconds=2.0, seed=2026, grid=15, first_trial=0, slab=4096):
+    import torch
+    import sameold_amd as sa
+    from sameold_amd import montecarlo as mc
+    from sameold_amd import receiver as R
+    from oracle import binding as ob
+    from helpers.oracle_compare import assert_every_channel_matches_oracle
+
+    n_samples = int(round(rate * seconds))
+    n_samples -= n_samples % 16
+    t0 = time.perf_counter()
+    x = mc.synth_trials(trials, first_trial, n_samples, rate, seed, 0.0, 1.0, grid)
+    rx = sa.SameReceiverBuilder(rate).build_batch(trials, link_only=True)
+    rx.set_kernel_timing(True)
+    rx.process_tensor(x)
+    rx.sync()
+    ev = rx.poll_events_np()
+    t_gpu = time.perf_counter() - t0
+    kernel_ms = rx.last_kernel_ms()
+    payloads = [R.synth_payload(seed, first_trial + c) for c in range(trials)]
+    gpu_tally = mc.new_tally(grid)
+    mc.score_bursts(ev, payloads, first_trial, trials, grid, gpu_tally)
+
+    t0 = time.perf_counter()
+    slabs = []
+    n_link = assert_every_channel_matches_oracle(ob, ob.default_config(rate), x, ev, slab=slab, collect=slabs)
+    t_cpu = time.perf_counter() - t0
+    # the oracle's events in the device's record layout, scored by the same code
+    total = sum(len(r) for _, r in slabs)
+    oev = np.zeros(total, dtype=R.EVENT_DTYPE)
+    at = 0
+    for c0, ref in slabs:
+        seg = oev[at:at + len(ref)]
+        seg["kind"] = ref["kind"]; seg["channel"] = ref["aux"] + c0; seg["sample_counter"] = ref["sample_counter"]
+        seg["len"] = ref["len"]; seg["bytes"] = ref["bytes"]
+        at += len(ref)
+    cpu_tally = mc.new_tally(grid)
+    mc.score_bursts(oev, payloads, first_trial, trials, grid, cpu_tally)
+    for k in gpu_tally:
+        assert np.array_equal(gpu_tally[k], cpu_tally[k]), f"tally column {k} differs: {gpu_tally[k]} vs {cpu_tally[k]}"
+    return {
+        "workload": f"{trials} AWGN trials (trial ids {first_trial}..{first_trial + trials - 1}), one burst each, {rate} Hz, "
+                    f"{n_samples} samples per trial, Eb/N0 0..{grid - 1} dB, seed {seed}",
+        "link_events_compared": int(n_link), "events_equal": True, "tally_rows_equal": True,
+        "rows_gpu": mc.summarise(gpu_tally, 0.0, 1.0), "rows_oracle": mc.summarise(cpu_tally, 0.0, 1.0),
+        "gpu_seconds_incl_generation": round(t_gpu, 3), "gpu_kernel_ms": round(kernel_ms, 3),
+        "oracle_seconds_incl_readback": round(t_cpu, 3), "host_threads": len(os.sched_getaffinity(0)),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--trials", type=int, default=65536)
+    ap.add_argument("--first-trial", type=int, default=0)
+    ap.add_argument("--seed", type=int, default=2026)
+    ap.add_argument("--out", default=None)
+    a = ap.parse_args()
+    from sameold_amd import build as b
+    b.build()
+    res = run(a.trials, seed=a.seed, first_trial=a.first_trial)
+    print(json.dumps({k: v for k, v in res.items() if not k.startswith("rows")}))
+    if a.out:
+        with open(a.out, "w") as f:
+            json.dump(res, f, indent=1)
+
+
+if __name__ == "__main__":
+    main()

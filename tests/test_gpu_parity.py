@@ -12,6 +12,7 @@ import numpy as np
 import pytest
 
 from conftest import GOLDEN, TEST_MESSAGE
+from helpers.oracle_compare import assert_every_channel_matches_oracle
 
 pytestmark = pytest.mark.gpu
 
@@ -51,40 +52,6 @@ def events_by_channel(rx):
 def oracle_events(ob, cfg, x, link_only=False):
     return [e.as_tuple() for e in ob.Receiver(cfg, link_only=link_only).run(np.ascontiguousarray(x))]
 
-
-def assert_every_channel_matches_oracle(ob, cfg, x, ev, slab=2048):
-    """Link events (kind, input sample counter, burst bytes) of EVERY channel of a device batch against
-    the oracle, which runs the same samples on all host cores (ob.batch_run_time_major, link layer
-    only).  `x` is the device tensor [T, C]; `ev` the polled events (numpy, ordered by channel then
-    time); transport events in `ev` are ignored.  Channels go to the host in slabs to bound memory."""
-    n_ch = x.shape[1]
-    link = ev[ev["kind"] <= 3]
-    threads = len(os.sched_getaffinity(0))
-    first = np.searchsorted(link["channel"], np.arange(n_ch + 1))
-    assert np.all(np.diff(link["channel"].astype(np.int64)) >= 0), "events must be ordered by channel"
-    for c0 in range(0, n_ch, slab):
-        c1 = min(n_ch, c0 + slab)
-        xs = x[:, c0:c1].contiguous().cpu().numpy()
-        cap = 1 << 16
-        while True:
-            n, evs = ob.batch_run_time_major(cfg, xs, threads, cap=cap)
-            if n <= cap:
-                break
-            cap = int(n) + 1024
-        ref = np.frombuffer(evs, dtype=ob._EVENT_NP, count=n)
-        ref = ref[np.argsort(ref["aux"], kind="stable")]          # workers append in time order per channel
-        mine = link[first[c0]:first[c1]]
-        assert len(mine) == len(ref), f"channels {c0}..{c1}: {len(mine)} device events, oracle {len(ref)}"
-        bad = np.flatnonzero((mine["channel"] - c0 != ref["aux"]) | (mine["kind"] != ref["kind"])
-                             | (mine["sample_counter"] != ref["sample_counter"]) | (mine["len"] != ref["len"]))
-        assert len(bad) == 0, f"first mismatch at channel {int(mine['channel'][bad[0]])}: {mine[bad[0]]} vs {ref[bad[0]]}"
-        b = np.flatnonzero(mine["kind"] == 3)
-        if len(b):
-            ln = np.minimum(mine["len"][b], 288)[:, None]
-            cols = np.arange(288)[None, :]
-            diff = (mine["bytes"][b] != ref["bytes"][b]) & (cols < ln)
-            assert not diff.any(), f"burst bytes differ on channel {int(mine['channel'][b[np.flatnonzero(diff.any(axis=1))[0]]])}"
-    return len(link)
 
 
 # ------------------------------------------------------------------ golden recordings
@@ -893,3 +860,14 @@ def test_polling_less_than_is_pending_still_delivers_everything_in_order(sa, ob)
             out.setdefault(t[3], []).append(t[:3])
         return out
     assert by_channel(got) == by_channel(want)
+
+
+def test_awgn_batch_tally_equals_the_oracles(sa, ob):
+    """configs[4]: the BER tally of a whole batch of AWGN trials equals the oracle's row for row, and every
+    trial's events are equal (tests/helpers/ber_vs_oracle.py runs the same check on a 65 536-trial batch
+    and files the rows under profiles/)."""
+    from helpers import ber_vs_oracle
+    res = ber_vs_oracle.run(trials=8192, seed=424242, first_trial=12345)
+    assert res["events_equal"] and res["tally_rows_equal"]
+    assert res["rows_gpu"] == res["rows_oracle"]
+    assert sum(r["trials"] for r in res["rows_gpu"]) == 8192
