@@ -142,8 +142,25 @@ enum { SAME_LAYOUT_TIME_MAJOR = 0, SAME_LAYOUT_CHANNEL_MAJOR = 1 };
 enum {
     SAME_BATCH_LINK_ONLY = 1u << 0,   /* report link events only; skip the transport layer */
     SAME_BATCH_TRACE_SYMBOLS = 1u << 1,/* record every soft symbol (debug / parity tests) */
-    SAME_BATCH_GENERIC_KERNEL = 1u << 2 /* always use the any-configuration kernel (tests) */
+    SAME_BATCH_GENERIC_KERNEL = 1u << 2,/* always use the any-configuration kernel (tests) */
+    /* Time-parallel ("fast") mode.  A long call on few channels is a few serial instruction streams on a
+     * machine with a thousand SIMDs; with this flag a call is cut into K time chunks per channel that
+     * run side by side (K * n_channels <= 32 768 state columns through the wavefront pipeline).  Chunk 0
+     * continues from the channel's state; every other chunk starts from a freshly built receiver a
+     * warm-up (64 symbols by default) before the samples it owns, and a chunk keeps running past its
+     * end until its channel has been seen idle (LinkState::NoCarrier), where the next chunk takes over.
+     * The arithmetic of every chunk is the strict, bit-exact arithmetic; what is approximated is the
+     * state a chunk starts from.  Contract (tests/test_time_parallel.py): burst bytes, their order and
+     * the transport messages equal the reference's; link events are the same sequence with sample
+     * counters within SAME_TP_EVENT_TOLERANCE_SYMBOLS symbols (Searching: anywhere inside the preamble);
+     * soft symbols of an open squelch within 0.05 with equal sign; transport events are stamped from a
+     * host-side symbol clock (within a few symbols of the reference's).  Calls too short to be cut, other
+     * sample rates than 22.05 / 44.1 / 48 kHz, non-default equalizer orders and channel counts that are
+     * not a multiple of 16 run as ordinary strict launches.  Not combinable with
+     * SAME_BATCH_TRACE_SYMBOLS. */
+    SAME_BATCH_TIME_PARALLEL = 1u << 3
 };
+#define SAME_TP_EVENT_TOLERANCE_SYMBOLS 2
 
 typedef struct same_batch same_batch;
 
@@ -212,6 +229,14 @@ int same_batch_drop_events(same_batch *rx, size_t n);
  * `cap` records; *n_records = bursts queued.  The queue is left as it is. */
 #define SAME_BURST_RECORD_BYTES 304
 int same_batch_pack_bursts(same_batch *rx, uint32_t first_channel, uint8_t *out, size_t cap, size_t *n_records);
+
+/* Time-parallel mode tuning (0 = keep the default): most chunks per channel (default: as many as fit
+ * 32 768 state columns), fewest samples a chunk may own (default 4 x warm-up), warm-up samples
+ * (default 64 symbols).  Takes effect from the next process call. */
+int same_batch_time_parallel_config(same_batch *rx, uint32_t max_chunks, uint32_t min_own_samples,
+                                    uint32_t warmup_samples);
+/* chunks per channel the most recent process call was cut into (1 = it ran as one strict launch) */
+uint32_t same_batch_time_parallel_chunks(const same_batch *rx);
 
 /* soft-symbol trace (SAME_BATCH_TRACE_SYMBOLS): SymbolEstimate stream of one channel
  * (rx/symsync.rs:52-71) with the input sample counter of each TED instant */

@@ -88,6 +88,58 @@ struct EventQueue {
 };
 struct HarvestPart { std::vector<same_rx_event> out; std::vector<uint32_t> rearm; };
 
+// Time-parallel mode: the transport layer's poll instants, synthesised on the host.  The reference polls
+// its assembler on every symbol whose link state is NoCarrier or Burst (receiver.rs:292-315); the answer
+// can only change at a burst, at the first poll on or after a deadline a burst armed (burst + 682
+// symbols, burst + 5 652 symbols: rx/assembler.rs:85, 92-93, 294-299), after the forced-EOM instant
+// (receiver.rs:300-309), or at the poll following one of those.  In strict mode the device reports
+// exactly those instants (SAME_DEV_TICK); chunks that start from a fresh receiver cannot know the
+// deadlines earlier chunks armed, so here the host keeps them per channel, on the (rebased) symbol
+// clock of the stitched event stream, and interpolates the sample counter of a poll from the last event.
+struct TickSynth {
+    uint32_t link = 0;                 // LinkState kind after the last event
+    uint64_t a_sym = 0, a_t = 0;       // last event: symbol count (rebased) and input sample counter
+    uint64_t dl[12];                   // pending symbol deadlines, ascending
+    uint32_t n = 0;
+    bool again = false;                // a deadline passed while the link was busy: poll once more after the next idle event
+    void reset() { link = 0; a_sym = 0; a_t = 0; n = 0; again = false; }
+    void add(uint64_t d)
+    {
+        if (n == 12) { for (uint32_t i = 1; i < n; ++i) dl[i - 1] = dl[i]; --n; }
+        uint32_t i = n++;
+        while (i > 0 && dl[i - 1] > d) { dl[i] = dl[i - 1]; --i; }
+        dl[i] = d;
+    }
+    // polls for every deadline before symbol `sym_limit` (an event at sym_limit polls by itself)
+    template <typename Poll> void run_until(uint64_t sym_limit, uint64_t t_limit, double sps, uint64_t force_eom_at, Poll &&poll)
+    {
+        auto at = [&](uint64_t sym) {
+            const uint64_t t = a_t + (uint64_t)((double)(sym - a_sym) * sps);
+            return t < t_limit ? t : (t_limit ? t_limit - 1 : 0);
+        };
+        if (force_eom_at && link == 0 && a_t <= force_eom_at && force_eom_at + 1 < t_limit) {
+            const uint64_t sym = a_sym + (uint64_t)((double)(force_eom_at + 1 - a_t) / sps) + 1u;
+            if (sym < sym_limit) add(sym);
+        }
+        while (n && dl[0] < sym_limit) {
+            uint64_t d = dl[0];
+            for (uint32_t i = 1; i < n; ++i) dl[i - 1] = dl[i];
+            --n;
+            if (link != 0) { again = true; continue; }       // busy: the next NoCarrier / Burst event is that poll
+            if (d <= a_sym) d = a_sym + 1u;
+            if (d >= sym_limit) { again = true; continue; }
+            poll(d, at(d));
+            if (d + 1u < sym_limit && !(n && dl[0] == d + 1u)) poll(d + 1u, at(d + 1u));
+        }
+    }
+    void after_event(uint32_t kind, uint64_t sym, uint64_t t, uint64_t interburst, uint64_t history)
+    {
+        link = kind; a_sym = sym; a_t = t;
+        if (kind == SAME_LINK_BURST) { add(sym + interburst); add(sym + history); again = true; }
+        else if (kind == SAME_LINK_NO_CARRIER && again) { add(sym + 1u); again = false; }
+    }
+};
+
 struct same_batch {
     same_rx_builder builder{};
     same::Params P{};
@@ -116,7 +168,30 @@ struct same_batch {
         void *h_bursts = nullptr; size_t h_bursts_bytes = 0;
         bool in_flight = false;
         uint64_t seq = 0;                // launch order
+        uint64_t end_counter = 0;        // input sample counter after this launch
+        // time-parallel launch: geometry, the end of its last whole block, the hand-over instants
+        bool chunked = false;
+        same::ChunkGeom geom{};
+        uint64_t end_blocks = 0;
+        uint64_t *d_handover = nullptr, *h_handover = nullptr;
+        size_t handover_cap = 0;
     } slot[2];
+    // time-parallel mode (SAME_BATCH_TIME_PARALLEL)
+    struct TimePar {
+        bool enabled = false;
+        uint32_t max_chunks = 0, min_own = 0, warmup = 0;     // same_batch_time_parallel_config (0 = default)
+        uint32_t cap_columns = 0;                             // columns the wide state blob holds
+        uint32_t carved_columns = 0;                          // columns Pv / Sv / the descriptor tables are laid out for
+        same::Params Pv{};
+        same::State Sv{};
+        void *blob = nullptr;
+        same::StateArrayDesc *d_desc_in = nullptr, *d_desc_out = nullptr;   // real -> wide, wide -> real
+        uint32_t n_desc = 0;
+        uint32_t *d_final_col = nullptr;
+        uint32_t last_chunks = 1;
+        std::vector<int64_t> sym_off;        // per channel: reported symbol count - the device's
+        std::vector<TickSynth> synth;
+    } tp;
     uint64_t launch_seq = 0;
     hipStream_t copy_stream = nullptr;   // read-back of finished launches, beside the compute stream
     float last_ms = 0.0f;
@@ -156,6 +231,27 @@ struct Carver {
     }
 };
 
+// every State array that is laid out [rows][channel]: field, element type, rows
+#define SAME_STATE_ARRAYS(X, P)                                                                            \
+    X(dc_ff_ring, float, (P).dc_len) X(dc_fb_ring, float, (P).dc_len)                                        \
+    X(dc_sum0, float, 1) X(dc_sum1, float, 1) X(agc_gain, float, 1)                                          \
+    X(win_ring, float, (P).win_ring)                                                                         \
+    X(ted_clock, uint32_t, 1) X(until_next_ted, float, 1)                                                    \
+    X(ted_h0, float, 1) X(ted_h1, float, 1) X(ted_h2, float, 1)                                              \
+    X(period_avg, float, 1) X(period_inst, float, 1)                                                         \
+    X(sq_data, uint32_t, 1) X(sq_power, float, 1) X(sq_phist, uint32_t, 1)                                   \
+    X(sq_fill, uint32_t, 1) X(sq_clock, int32_t, 1) X(sq_symbols, uint64_t, 1)                               \
+    X(sq_hist, float, same::kSquelchHist)                                                                    \
+    X(eq_ffc, float, (P).eq_nff) X(eq_fbc, float, (P).eq_nfb)                                                \
+    X(eq_ffw, float, (P).eq_nff) X(eq_fbw, float, (P).eq_nfb)                                                \
+    X(eq_word, uint32_t, 1) X(eq_count, uint32_t, 1)                                                         \
+    X(eq_snap_ffc, float, (P).eq_nff) X(eq_snap_fbc, float, (P).eq_nfb)                                      \
+    X(eq_snap_ffw, float, (P).eq_nff) X(eq_snap_fbw, float, (P).eq_nfb)                                      \
+    X(fr_word, uint32_t, 1) X(fr_count, uint32_t, 1) X(fr_invalid, uint32_t, 1) X(fr_len, uint32_t, 1)       \
+    X(flags, uint32_t, 1)                                                                                    \
+    X(tk_next, uint64_t, 1) X(tk_last, uint64_t, 1) X(tk_ring, uint64_t, same::kTickRing)                    \
+    X(tk_n, uint32_t, 1) X(wake_sample, uint64_t, 1) X(wake_fired, uint64_t, 1)
+
 // lays out every State array inside one blob; with base == nullptr only sizes it
 size_t carve_state(const same::Params &P, char *base, same::State &S)
 {
@@ -163,28 +259,10 @@ size_t carve_state(const same::Params &P, char *base, same::State &S)
     Carver cv;
 #define CARVE(field, type, count) \
     do { size_t o = cv.take<type>(count); if (base) S.field = reinterpret_cast<type *>(base + o); } while (0)
-    CARVE(dc_ff_ring, float, (size_t)P.dc_len * C);
-    CARVE(dc_fb_ring, float, (size_t)P.dc_len * C);
-    CARVE(dc_sum0, float, C); CARVE(dc_sum1, float, C); CARVE(agc_gain, float, C);
-    CARVE(win_ring, float, (size_t)P.win_ring * C);
-    CARVE(ted_clock, uint32_t, C); CARVE(until_next_ted, float, C);
-    CARVE(ted_h0, float, C); CARVE(ted_h1, float, C); CARVE(ted_h2, float, C);
-    CARVE(period_avg, float, C); CARVE(period_inst, float, C);
-    CARVE(sq_data, uint32_t, C); CARVE(sq_power, float, C); CARVE(sq_phist, uint32_t, C);
-    CARVE(sq_fill, uint32_t, C); CARVE(sq_clock, int32_t, C); CARVE(sq_symbols, uint64_t, C);
-    CARVE(sq_hist, float, (size_t)same::kSquelchHist * C);
-    CARVE(eq_ffc, float, (size_t)P.eq_nff * C); CARVE(eq_fbc, float, (size_t)P.eq_nfb * C);
-    CARVE(eq_ffw, float, (size_t)P.eq_nff * C); CARVE(eq_fbw, float, (size_t)P.eq_nfb * C);
-    CARVE(eq_word, uint32_t, C); CARVE(eq_count, uint32_t, C);
-    CARVE(eq_snap_ffc, float, (size_t)P.eq_nff * C); CARVE(eq_snap_fbc, float, (size_t)P.eq_nfb * C);
-    CARVE(eq_snap_ffw, float, (size_t)P.eq_nff * C); CARVE(eq_snap_fbw, float, (size_t)P.eq_nfb * C);
-    CARVE(fr_word, uint32_t, C); CARVE(fr_count, uint32_t, C); CARVE(fr_invalid, uint32_t, C);
-    CARVE(fr_len, uint32_t, C);
-    CARVE(fr_msg, uint8_t, (size_t)same::kBurstCap * C);
-    CARVE(flags, uint32_t, C);
-    CARVE(tk_next, uint64_t, C); CARVE(tk_last, uint64_t, C);
-    CARVE(tk_ring, uint64_t, (size_t)same::kTickRing * C);
-    CARVE(tk_n, uint32_t, C); CARVE(wake_sample, uint64_t, C); CARVE(wake_fired, uint64_t, C);
+#define CARVE_ROWS(field, type, rows) CARVE(field, type, (size_t)(rows) * C);
+    SAME_STATE_ARRAYS(CARVE_ROWS, P)
+#undef CARVE_ROWS
+    CARVE(fr_msg, uint8_t, (size_t)same::kBurstCap * C);      // [channel][kBurstCap]
     if (P.trace_cap) {
         CARVE(trace_n, uint32_t, C);
         CARVE(trace, float, (size_t)P.trace_cap * 4 * C);
@@ -192,6 +270,22 @@ size_t carve_state(const same::Params &P, char *base, same::State &S)
     }
 #undef CARVE
     return (cv.off + 255) & ~size_t(255);
+}
+
+// the same arrays as (source, destination) pairs for launch_copy_state_columns (no trace arrays: the
+// time-parallel mode does not record one)
+void list_state_arrays(const same::Params &P, const same::State &src, const same::State &dst,
+                       std::vector<same::StateArrayDesc> &out)
+{
+    out.clear();
+#define DESC_ROWS(field, type, rows)                                                                     \
+    out.push_back(same::StateArrayDesc{reinterpret_cast<char *>(src.field), reinterpret_cast<char *>(dst.field), \
+                                       (uint32_t)(rows), (uint32_t)(sizeof(type) / 4)});
+    SAME_STATE_ARRAYS(DESC_ROWS, P)
+#undef DESC_ROWS
+    static_assert(same::kBurstCap % 4 == 0, "framer rows are copied in words");
+    out.push_back(same::StateArrayDesc{reinterpret_cast<char *>(src.fr_msg), reinterpret_cast<char *>(dst.fr_msg), 1u,
+                                       (uint32_t)(same::kBurstCap / 4)});
 }
 
 // every environment knob of the library, read once per batch
@@ -207,16 +301,17 @@ void read_knobs(same_batch *rx)
     rx->host_threads = std::max(0, num("SAME_HOST_THREADS", 0));
 }
 
-int ensure_output(same_batch *rx, same_batch::Slot &sl, size_t n_samples, same::Output &O)
+int ensure_output(same_batch *rx, same_batch::Slot &sl, size_t n_samples, same::Output &O, size_t n_columns = 0)
 {
+    const size_t n_ch = n_columns ? n_columns : rx->P.n_channels;
     // Worst case per channel: an acquisition attempt (Searching ... NoCarrier) needs a
     // fresh byte sync, i.e. at least 32 symbols, so < 2 link events per 32 symbols; bursts
     // are rarer still.  Size generously: 4 events per 32 symbols + slack.
     const double symbols = (double)n_samples * 520.83 / (double)rx->P.input_rate;
     const size_t per_chan_events = (size_t)(symbols / 8.0) + 16;
     const size_t per_chan_bursts = (size_t)(symbols / 160.0) + 4;   // a burst is >= 20 bytes
-    size_t ecap = std::min<size_t>(per_chan_events * rx->P.n_channels, 0x7fffffffu / sizeof(same::DevEvent));
-    size_t bcap = std::min<size_t>(per_chan_bursts * rx->P.n_channels, 0x7fffffffu / same::kBurstCap);
+    size_t ecap = std::min<size_t>(per_chan_events * n_ch, 0x7fffffffu / sizeof(same::DevEvent));
+    size_t bcap = std::min<size_t>(per_chan_bursts * n_ch, 0x7fffffffu / same::kBurstCap);
     if (ecap > sl.event_cap) {
         if (sl.d_events) HIP_TRY(hipFree(sl.d_events));
         sl.d_events = nullptr; sl.event_cap = 0;
@@ -282,59 +377,162 @@ int harvest_slot(same_batch *rx, same_batch::Slot &sl)
     const uint8_t *bursts = static_cast<const uint8_t *>(sl.h_bursts);
     if (n_events) HIP_TRY(hipMemcpyAsync(sl.h_events, sl.d_events, ev_bytes, hipMemcpyDeviceToHost, rx->copy_stream));
     if (n_bursts) HIP_TRY(hipMemcpyAsync(sl.h_bursts, sl.d_bursts, bu_bytes, hipMemcpyDeviceToHost, rx->copy_stream));
-    if (n_events || n_bursts) HIP_TRY(hipStreamSynchronize(rx->copy_stream));
-    auto t_copied = std::chrono::steady_clock::now();
-    // Per channel the device emits in time order (a lane takes its log slots one after the
-    // other); across lanes the atomic cursor interleaves.  A stable counting sort by channel
-    // therefore yields (channel, time) order in O(n).
     const uint32_t n_ch = rx->P.n_channels;
-    std::vector<uint32_t> first(n_ch + 1u, 0u);
+    const uint32_t n_bins = sl.chunked ? sl.geom.n_chunks * n_ch : n_ch;     // state columns of the launch
+    if (sl.chunked)
+        HIP_TRY(hipMemcpyAsync(sl.h_handover, sl.d_handover, (size_t)n_bins * sizeof(uint64_t), hipMemcpyDeviceToHost, rx->copy_stream));
+    if (n_events || n_bursts || sl.chunked) HIP_TRY(hipStreamSynchronize(rx->copy_stream));
+    auto t_copied = std::chrono::steady_clock::now();
+    // Per column the device emits in time order (a lane takes its log slots one after the
+    // other); across lanes the atomic cursor interleaves.  A stable counting sort by column
+    // therefore yields (column, time) order in O(n).
+    std::vector<uint32_t> first(n_bins + 1u, 0u);
     // (slots a wavefront reserved but did not use carry kDevEventNone and are dropped here)
     for (uint32_t i = 0; i < n_events; ++i)
-        if (evs[i].kind != same::kDevEventNone) first[std::min(evs[i].channel, n_ch - 1u) + 1u]++;
-    for (uint32_t c = 0; c < n_ch; ++c) first[c + 1u] += first[c];
-    const uint32_t n_real = first[n_ch];
+        if (evs[i].kind != same::kDevEventNone) first[std::min(evs[i].channel, n_bins - 1u) + 1u]++;
+    for (uint32_t c = 0; c < n_bins; ++c) first[c + 1u] += first[c];
+    const uint32_t n_real = first[n_bins];
     std::vector<uint32_t> order(n_real);
     {
         std::vector<uint32_t> fill(first.begin(), first.end() - 1);
         for (uint32_t i = 0; i < n_events; ++i)
-            if (evs[i].kind != same::kDevEventNone) order[fill[std::min(evs[i].channel, n_ch - 1u)]++] = i;
+            if (evs[i].kind != same::kDevEventNone) order[fill[std::min(evs[i].channel, n_bins - 1u)]++] = i;
     }
+    // events per real channel, cumulative (a chunked launch spreads a channel over n_chunks columns)
+    std::vector<uint32_t> chan_first;
+    if (sl.chunked) {
+        chan_first.assign(n_ch + 1u, 0u);
+        for (uint32_t k = 0; k < sl.geom.n_chunks; ++k)
+            for (uint32_t c = 0; c < n_ch; ++c) chan_first[c + 1u] += first[k * n_ch + c + 1u] - first[k * n_ch + c];
+        for (uint32_t c = 0; c < n_ch; ++c) chan_first[c + 1u] += chan_first[c];
+    }
+    const std::vector<uint32_t> &cfirst = sl.chunked ? chan_first : first;
     const bool link_only = (rx->flags & SAME_BATCH_LINK_ONLY) != 0;
+    const bool tp = rx->tp.enabled;
     std::vector<uint32_t> rearm;     // channels whose forced-EOM instant changed
     auto t_sorted = std::chrono::steady_clock::now();
 
     // Channels are independent (one Transport each), so contiguous channel ranges are replayed
     // on separate host threads; each produces its slice of the output queue, in order.
     using Part = HarvestPart;
+    const double sps = (double)rx->P.input_rate / 520.83;
+    const uint64_t interburst = same::max_interburst_symbols(), history = same::max_history_duration();
+    // one device event -> the link event of channel c (+ the transport event it causes).  `off`: what
+    // the time-parallel mode adds to the device's symbol count (0 otherwise).
+    auto feed = [&](Part &part, same_rx_event &ev, const same::DevEvent &d, uint32_t c, int64_t off) {
+        const uint64_t sym = (uint64_t)((int64_t)d.symbol_count + off);
+        auto poll = [&](uint64_t psym, uint64_t pt) {
+            same_rx_event tev;
+            if (rx->transport[c].on_link_event(same::kDevTick, pt, psym, nullptr, 0, rx->P.input_rate, &tev)) {
+                tev.channel = c;
+                part.out.push_back(tev);
+            }
+        };
+        if (tp && !link_only)
+            rx->tp.synth[c].run_until(sym, d.sample_counter, sps, rx->transport[c].force_eom_at(), poll);
+        std::memset(&ev, 0, offsetof(same_rx_event, bytes));
+        ev.kind = d.kind; ev.channel = c; ev.sample_counter = d.sample_counter;
+        ev.symbol_count = sym;
+        if (d.kind == SAME_LINK_BURST) {
+            ev.len = d.burst_len;
+            const uint32_t n = std::min<uint32_t>(d.burst_len, SAME_EVENT_MAX_BYTES);
+            if (d.burst_slot < n_bursts) std::memcpy(ev.bytes, bursts + (size_t)d.burst_slot * same::kBurstCap, n);
+            else ev.len = 0;   // pool overflow: the burst bytes were lost (SAME_EOVERFLOW is reported)
+        }
+        if (d.kind <= SAME_LINK_BURST) part.out.push_back(ev);
+        if (!link_only) {
+            same_rx_event tev;
+            if (rx->transport[c].on_link_event(d.kind, d.sample_counter, sym, ev.bytes,
+                                               std::min<uint32_t>(ev.len, SAME_EVENT_MAX_BYTES),
+                                               rx->P.input_rate, &tev)) {
+                tev.channel = c;
+                part.out.push_back(tev);
+            }
+            if (!tp && rx->transport[c].force_eom_dirty()) part.rearm.push_back(c);
+        }
+        if (tp && d.kind <= SAME_LINK_BURST) rx->tp.synth[c].after_event(d.kind, sym, d.sample_counter, interburst, history);
+        if (d.kind == SAME_LINK_BURST) std::memset(ev.bytes, 0, sizeof(ev.bytes));   // keep later events clean
+    };
+    // Time-parallel launch: the events of channel c, stitched from its chunks.  Chunk `cur` is kept up to
+    // its hand-over instant h (the end of the first block at or after its nominal end in which the
+    // device saw it idle), then the chunk that owns h takes over -- from h if it is idle there too,
+    // otherwise from its own next NoCarrier on (it was still busy with the tail of a burst it joined in
+    // the middle, or with a duplicate of the burst the previous chunk has just delivered).
+    auto stitch = [&](Part &part, same_rx_event &ev, uint32_t c) {
+        const same::ChunkGeom &g = sl.geom;
+        const uint64_t *hand = sl.h_handover;
+        TickSynth &ts = rx->tp.synth[c];
+        int64_t off = rx->tp.sym_off[c];
+        uint32_t cur = 0;
+        uint64_t keep_after = 0;
+        for (;;) {
+            const uint32_t col = cur * n_ch + c;
+            const uint64_t h = hand[col];
+            const uint64_t upto = std::min(h, sl.end_blocks);
+            bool rebased = cur == 0;
+            for (uint32_t i = first[col]; i < first[col + 1u]; ++i) {
+                const same::DevEvent &d = evs[order[i]];
+                if (d.sample_counter <= keep_after) continue;
+                if (d.sample_counter > upto) break;
+                if (!rebased) {
+                    // continue the channel's symbol clock: the last reported event plus the nominal symbol rate
+                    const int64_t est = (int64_t)ts.a_sym + (int64_t)((double)(d.sample_counter - ts.a_t) / sps + 0.5);
+                    off = est - (int64_t)d.symbol_count;
+                    rebased = true;
+                }
+                feed(part, ev, d, c, off);
+            }
+            if (!rebased) {
+                // nothing reported from this chunk: its counter started at 0 at its first row
+                const uint64_t row0 = g.counter0 + (uint64_t)cur * g.stride_blocks * g.block_len;
+                const int64_t est_end = (int64_t)ts.a_sym + (int64_t)((double)(sl.end_blocks - ts.a_t) / sps + 0.5);
+                off = est_end - (int64_t)((double)(sl.end_blocks - row0) / sps + 0.5);
+            }
+            if (h == same::kNoHandover) break;
+            const uint32_t nxt = g.owner_of(h);
+            if (nxt <= cur) break;
+            // the next chunk's link state at h, and where it is first idle from there on
+            const uint32_t ncol = nxt * n_ch + c;
+            uint32_t st = 0, j = first[ncol];
+            for (; j < first[ncol + 1u] && evs[order[j]].sample_counter <= h; ++j)
+                if (evs[order[j]].kind <= SAME_LINK_BURST) st = evs[order[j]].kind;
+            keep_after = h;
+            if (st != SAME_LINK_NO_CARRIER)
+                for (; j < first[ncol + 1u]; ++j)
+                    if (evs[order[j]].kind == SAME_LINK_NO_CARRIER) { keep_after = evs[order[j]].sample_counter; break; }
+            cur = nxt;
+        }
+        // the remainder of the call (less than a block), demodulated on the channel's real state afterwards,
+        // logs under column c like chunk 0
+        for (uint32_t i = first[c]; i < first[c + 1u]; ++i)
+            if (evs[order[i]].sample_counter > sl.end_blocks) feed(part, ev, evs[order[i]], c, off);
+        rx->tp.sym_off[c] = off;
+    };
     auto run_range = [&](uint32_t c0, uint32_t c1, Part &part) {
         part.out.clear(); part.rearm.clear();
-        part.out.reserve((size_t)(first[c1] - first[c0]) * 3 / 2 + 4);
+        part.out.reserve((size_t)(cfirst[c1] - cfirst[c0]) * 3 / 2 + 4);
         same_rx_event ev;
         std::memset(&ev, 0, sizeof(ev));
-        for (uint32_t k = first[c0]; k < first[c1]; ++k) {
-            const same::DevEvent &d = evs[order[k]];
-            std::memset(&ev, 0, offsetof(same_rx_event, bytes));
-            ev.kind = d.kind; ev.channel = d.channel; ev.sample_counter = d.sample_counter;
-            ev.symbol_count = d.symbol_count;
-            if (d.kind == SAME_LINK_BURST) {
-                ev.len = d.burst_len;
-                const uint32_t n = std::min<uint32_t>(d.burst_len, SAME_EVENT_MAX_BYTES);
-                if (d.burst_slot < n_bursts) std::memcpy(ev.bytes, bursts + (size_t)d.burst_slot * same::kBurstCap, n);
-                else ev.len = 0;   // pool overflow: the burst bytes were lost (SAME_EOVERFLOW is reported)
-            }
-            if (d.kind <= SAME_LINK_BURST) part.out.push_back(ev);
-            if (!link_only) {
-                same_rx_event tev;
-                if (rx->transport[d.channel].on_link_event(d.kind, d.sample_counter, d.symbol_count, ev.bytes,
-                                                           std::min<uint32_t>(ev.len, SAME_EVENT_MAX_BYTES),
-                                                           rx->P.input_rate, &tev)) {
-                    tev.channel = d.channel;
-                    part.out.push_back(tev);
+        for (uint32_t c = c0; c < c1; ++c) {
+            if (sl.chunked) stitch(part, ev, c);
+            else
+                for (uint32_t k = first[c]; k < first[c + 1u]; ++k)
+                    feed(part, ev, evs[order[k]], c, tp ? rx->tp.sym_off[c] : 0);
+            if (tp && !link_only) {
+                // polls due before the end of this launch (the next launch's events start after it)
+                TickSynth &ts = rx->tp.synth[c];
+                if (ts.link == SAME_LINK_NO_CARRIER && sl.end_counter > ts.a_t) {
+                    const uint64_t sym_end = ts.a_sym + (uint64_t)((double)(sl.end_counter - ts.a_t) / sps);
+                    auto poll = [&](uint64_t psym, uint64_t pt) {
+                        same_rx_event tev;
+                        if (rx->transport[c].on_link_event(same::kDevTick, pt, psym, nullptr, 0, rx->P.input_rate, &tev)) {
+                            tev.channel = c;
+                            part.out.push_back(tev);
+                        }
+                    };
+                    ts.run_until(sym_end + 1u, sl.end_counter + 1u, sps, rx->transport[c].force_eom_at(), poll);
                 }
-                if (rx->transport[d.channel].force_eom_dirty()) part.rearm.push_back(d.channel);
             }
-            if (d.kind == SAME_LINK_BURST) std::memset(ev.bytes, 0, sizeof(ev.bytes));   // keep later events clean
         }
     };
     uint32_t n_threads = 1;
@@ -354,7 +552,7 @@ int harvest_slot(same_batch *rx, same_batch::Slot &sl)
         cut[0] = 0;
         for (uint32_t t = 1; t < n_threads; ++t) {
             const uint32_t target = (uint32_t)((uint64_t)n_real * t / n_threads);
-            cut[t] = (uint32_t)(std::lower_bound(first.begin(), first.end(), target) - first.begin());
+            cut[t] = (uint32_t)(std::lower_bound(cfirst.begin(), cfirst.end(), target) - cfirst.begin());
             cut[t] = std::min(std::max(cut[t], cut[t - 1u]), n_ch);
         }
         std::vector<std::thread> pool;
@@ -425,6 +623,78 @@ int harvest(same_batch *rx)
     return SAME_OK;
 }
 
+int harvest(same_batch *rx);
+inline const same::Params &tp_params(const same_batch *rx) { return rx->P; }
+
+// How a call of n samples is cut into time-parallel chunks: fills geom / pc and returns the number of
+// chunks, or 1 when the call runs as one strict launch (mode off, configuration without a pipeline kernel,
+// call too short).
+uint32_t plan_chunks(same_batch *rx, size_t n, same::ChunkGeom &geom, same::PipeChunks &pc)
+{
+    same_batch::TimePar &tp = rx->tp;
+    if (!tp.enabled || !rx->use_fast || rx->force_generic) return 1;
+    const uint32_t C = rx->P.n_channels;
+    if (C % 16u != 0u || C > 16384u) return 1;
+    same::Params Pv = rx->P;
+    Pv.ticks = 0; Pv.trace_cap = 0;
+    const double sps = (double)rx->P.input_rate / 520.83;
+    const uint32_t k_cap = 32768u / C;
+    uint32_t k_max = tp.max_chunks ? std::min(tp.max_chunks, k_cap) : k_cap;
+    for (uint32_t K = k_max; K >= 2u; --K) {
+        Pv.n_channels = K * C;
+        if (!same::pipe_kernel_selected(Pv) || C % same::pipe_workgroup_channels(Pv) != 0u) continue;
+        const uint32_t fb = same::pipe_block_len(Pv);
+        const uint32_t warm = tp.warmup ? tp.warmup : (uint32_t)(64.0 * sps + 0.5);
+        const uint32_t WB = (warm + fb - 1u) / fb;
+        const uint64_t TB = n / fb;
+        if (TB <= WB) return 1;
+        const uint64_t SB = (TB - WB) / K;
+        const uint64_t min_own = tp.min_own ? tp.min_own : 4ull * WB * fb;
+        if (SB == 0 || SB * fb < min_own) continue;
+        geom.counter0 = rx->counter;
+        geom.n_chunks = K; geom.block_len = fb; geom.stride_blocks = (uint32_t)SB; geom.warmup_blocks = WB;
+        pc.n_chunks = K; pc.in_channels = C; pc.stride_blocks = (uint32_t)SB; pc.nominal_blocks = (uint32_t)SB + WB;
+        pc.handover = nullptr;
+        return K;
+    }
+    return 1;
+}
+
+// the wide state blob: `columns` state columns laid out like the channel state, plus the copy tables
+int ensure_wide_state(same_batch *rx, uint32_t columns)
+{
+    same_batch::TimePar &tp = rx->tp;
+    if (tp.carved_columns == columns) return SAME_OK;
+    int rc = harvest(rx);                    // nothing in flight may still use the old layout
+    if (rc) return rc;
+    HIP_TRY(hipDeviceSynchronize());
+    tp.Pv = rx->P;
+    tp.Pv.n_channels = columns;
+    tp.Pv.ticks = 0; tp.Pv.trace_cap = 0;
+    if (columns > tp.cap_columns) {
+        if (tp.blob) HIP_TRY(hipFree(tp.blob));
+        tp.blob = nullptr; tp.cap_columns = 0;
+        const size_t bytes = carve_state(tp.Pv, nullptr, tp.Sv);
+        HIP_TRY(hipMalloc(&tp.blob, bytes));
+        HIP_TRY(hipMemset(tp.blob, 0, bytes));
+        tp.cap_columns = columns;
+    }
+    carve_state(tp.Pv, (char *)tp.blob, tp.Sv);
+    std::vector<same::StateArrayDesc> in, out;
+    list_state_arrays(rx->P, rx->S, tp.Sv, in);
+    list_state_arrays(rx->P, tp.Sv, rx->S, out);
+    tp.n_desc = (uint32_t)in.size();
+    if (!tp.d_desc_in) {
+        HIP_TRY(hipMalloc((void **)&tp.d_desc_in, in.size() * sizeof(same::StateArrayDesc)));
+        HIP_TRY(hipMalloc((void **)&tp.d_desc_out, out.size() * sizeof(same::StateArrayDesc)));
+        HIP_TRY(hipMalloc((void **)&tp.d_final_col, (size_t)rx->P.n_channels * sizeof(uint32_t)));
+    }
+    HIP_TRY(hipMemcpy(tp.d_desc_in, in.data(), in.size() * sizeof(same::StateArrayDesc), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(tp.d_desc_out, out.data(), out.size() * sizeof(same::StateArrayDesc), hipMemcpyHostToDevice));
+    tp.carved_columns = columns;
+    return SAME_OK;
+}
+
 template <typename SampleT>
 int process_time_major(same_batch *rx, const SampleT *d_x, size_t n_samples, hipStream_t stream)
 {
@@ -438,7 +708,62 @@ int process_time_major(same_batch *rx, const SampleT *d_x, size_t n_samples, hip
         same_batch::Slot &prev = rx->slot[(rx->launch_seq & 1) ^ 1];
         int rc = harvest_slot(rx, sl);          // its buffers are about to be reused
         if (rc) return rc;
+        same::ChunkGeom geom{};
+        same::PipeChunks pc{};
+        const uint32_t n_chunks = plan_chunks(rx, n, geom, pc);
+        rx->tp.last_chunks = n_chunks;
         same::Output O{};
+        if (n_chunks > 1u) {
+            // Time-parallel launch: every channel as n_chunks state columns side by side.
+            const uint32_t C = rx->P.n_channels, columns = n_chunks * C;
+            rc = ensure_wide_state(rx, columns);
+            if (rc) return rc;
+            const size_t fbk = geom.block_len;
+            const size_t per_column = std::min<size_t>(n, 3 * (size_t)pc.nominal_blocks * fbk + 65536);
+            rc = ensure_output(rx, sl, per_column, O, columns);
+            if (rc) return rc;
+            if (sl.handover_cap < columns) {
+                if (sl.d_handover) HIP_TRY(hipFree(sl.d_handover));
+                if (sl.h_handover) HIP_TRY(hipHostFree(sl.h_handover));
+                sl.d_handover = nullptr; sl.h_handover = nullptr; sl.handover_cap = 0;
+                HIP_TRY(hipMalloc((void **)&sl.d_handover, (size_t)columns * sizeof(uint64_t)));
+                HIP_TRY(hipHostMalloc((void **)&sl.h_handover, (size_t)columns * sizeof(uint64_t), hipHostMallocDefault));
+                sl.handover_cap = columns;
+            }
+            pc.handover = sl.d_handover;
+            same_batch::TimePar &tp = rx->tp;
+            HIP_TRY(same::launch_counters(sl.d_counters, sl.h_counters_dev, 0, stream));
+            if (rx->timing) HIP_TRY(hipEventRecord(sl.ev_start, stream));
+            // fresh receivers in every column, the channels' own state into chunk 0's columns
+            HIP_TRY(same::launch_init_state(tp.Pv, tp.Sv, 0, stream));
+            HIP_TRY(same::launch_copy_state_columns(tp.d_desc_in, tp.n_desc, C, columns, nullptr, C, stream));
+            HIP_TRY(same::launch_fill_u64(sl.d_handover, columns, same::kNoHandover, stream));
+            const SampleT *xp = d_x + done * C;
+            const uint32_t total_blocks = (uint32_t)(n / fbk);
+            hipError_t e;
+            if constexpr (sizeof(SampleT) == 4)
+                e = same::launch_demod_pipe(tp.Pv, tp.Sv, O, rx->d_taps, (const float *)xp, total_blocks, rx->counter, stream, pc);
+            else
+                e = same::launch_demod_pipe_i16(tp.Pv, tp.Sv, O, rx->d_taps, (const int16_t *)xp, total_blocks, rx->counter, stream, pc);
+            if (e != hipSuccess) return fail(SAME_EHIP, "time-parallel demod kernel launch failed: %s", hipGetErrorString(e));
+            // the channel's state afterwards is that of the chunk which ran to the end of the input
+            HIP_TRY(same::launch_chunk_final_column(sl.d_handover, C, geom, tp.d_final_col, stream));
+            HIP_TRY(same::launch_copy_state_columns(tp.d_desc_out, tp.n_desc, columns, C, tp.d_final_col, C, stream));
+            const size_t n_whole = (size_t)total_blocks * fbk;
+            if (n_whole < n) {
+                // less than a block is left: the any-configuration kernel, on the channels' own state
+                const SampleT *xr = xp + n_whole * C;
+                if constexpr (sizeof(SampleT) == 4)
+                    e = same::launch_demod(tp_params(rx), rx->S, O, rx->d_taps, (const float *)xr, (uint32_t)(n - n_whole), rx->counter + n_whole, stream);
+                else
+                    e = same::launch_demod_i16(tp_params(rx), rx->S, O, rx->d_taps, (const int16_t *)xr, (uint32_t)(n - n_whole), rx->counter + n_whole, stream);
+                if (e != hipSuccess) return fail(SAME_EHIP, "demod kernel launch failed: %s", hipGetErrorString(e));
+            }
+            sl.chunked = true;
+            sl.geom = geom;
+            sl.end_blocks = rx->counter + n_whole;
+        } else {
+        sl.chunked = false;
         rc = ensure_output(rx, sl, n, O);
         if (rc) return rc;
         HIP_TRY(same::launch_counters(sl.d_counters, sl.h_counters_dev, 0, stream));
@@ -468,6 +793,7 @@ int process_time_major(same_batch *rx, const SampleT *d_x, size_t n_samples, hip
                 e = same::launch_demod_i16(rx->P, rx->S, O, rx->d_taps, (const int16_t *)xr, (uint32_t)(n - n_fast), rx->counter + n_fast, stream);
             if (e != hipSuccess) return fail(SAME_EHIP, "demod kernel launch failed: %s", hipGetErrorString(e));
         }
+        }
         if (rx->timing) HIP_TRY(hipEventRecord(sl.ev_stop, stream));
         HIP_TRY(same::launch_counters(sl.d_counters, sl.h_counters_dev, 1, stream));
         HIP_TRY(hipEventRecord(sl.ev_done, stream));
@@ -475,6 +801,7 @@ int process_time_major(same_batch *rx, const SampleT *d_x, size_t n_samples, hip
         sl.seq = ++rx->launch_seq;
         rx->last_stream = stream;
         rx->counter += n;
+        sl.end_counter = rx->counter;
         done += n;
         // while this launch runs, bring in the previous one
         rc = harvest_slot(rx, prev);
@@ -582,7 +909,13 @@ int same_batch_new(const same_rx_builder *b, uint32_t n_channels, int device, ui
     if (rc) { delete rx; return fail(rc, "builder rejected (code %d)", rc); }
     read_knobs(rx);
     rx->P.trace_cap = (flags & SAME_BATCH_TRACE_SYMBOLS) ? 4096u : 0u;
-    rx->P.ticks = (flags & SAME_BATCH_LINK_ONLY) ? 0u : 1u;
+    if ((flags & SAME_BATCH_TIME_PARALLEL) && (flags & SAME_BATCH_TRACE_SYMBOLS)) {
+        delete rx;
+        return fail(SAME_EINVAL, "SAME_BATCH_TIME_PARALLEL cannot record a symbol trace");
+    }
+    rx->tp.enabled = (flags & SAME_BATCH_TIME_PARALLEL) != 0;
+    // transport wake-ups come from the device in strict mode, from the host's symbol clock in time-parallel mode
+    rx->P.ticks = ((flags & SAME_BATCH_LINK_ONLY) || rx->tp.enabled) ? 0u : 1u;
     rx->P.tick_interburst = (uint32_t)same::max_interburst_symbols();
     rx->P.tick_history = (uint32_t)same::max_history_duration();
 
@@ -623,6 +956,7 @@ int same_batch_new(const same_rx_builder *b, uint32_t n_channels, int device, ui
     TRY_OR_CLEAN(hipStreamSynchronize(rx->own_stream));
 #undef TRY_OR_CLEAN
     if (!(flags & SAME_BATCH_LINK_ONLY)) rx->transport.resize(n_channels);
+    if (rx->tp.enabled) { rx->tp.sym_off.assign(n_channels, 0); rx->tp.synth.assign(n_channels, TickSynth{}); }
     *out = rx;
     return SAME_OK;
 }
@@ -644,7 +978,13 @@ void same_batch_free(same_batch *rx)
         if (sl.ev_start) (void)hipEventDestroy(sl.ev_start);
         if (sl.ev_stop) (void)hipEventDestroy(sl.ev_stop);
         if (sl.ev_done) (void)hipEventDestroy(sl.ev_done);
+        if (sl.d_handover) (void)hipFree(sl.d_handover);
+        if (sl.h_handover) (void)hipHostFree(sl.h_handover);
     }
+    if (rx->tp.blob) (void)hipFree(rx->tp.blob);
+    if (rx->tp.d_desc_in) (void)hipFree(rx->tp.d_desc_in);
+    if (rx->tp.d_desc_out) (void)hipFree(rx->tp.d_desc_out);
+    if (rx->tp.d_final_col) (void)hipFree(rx->tp.d_final_col);
     if (rx->copy_stream) (void)hipStreamDestroy(rx->copy_stream);
     if (rx->h_wake) (void)hipHostFree(rx->h_wake);
     if (rx->d_stage) (void)hipFree(rx->d_stage);
@@ -668,6 +1008,8 @@ int same_batch_reset(same_batch *rx)
     rx->counter = 0;
     rx->queue.clear(); rx->queue_head = 0;   // event_queue.clear() receiver.rs:194
     for (auto &t : rx->transport) t.reset();
+    for (auto &o : rx->tp.sym_off) o = 0;
+    for (auto &t : rx->tp.synth) t.reset();
     if (rx->h_wake) std::memset(rx->h_wake, 0, (size_t)rx->P.n_channels * sizeof(uint64_t));
     rx->overflowed = false;
     return SAME_OK;
@@ -840,6 +1182,15 @@ int same_batch_last_kernel_ms(same_batch *rx, float *ms)
     *ms = rx->last_ms;
     return SAME_OK;
 }
+int same_batch_time_parallel_config(same_batch *rx, uint32_t max_chunks, uint32_t min_own_samples, uint32_t warmup_samples)
+{
+    if (!rx) return fail(SAME_EINVAL, "null handle");
+    if (!rx->tp.enabled) return fail(SAME_EINVAL, "batch was not created with SAME_BATCH_TIME_PARALLEL");
+    rx->tp.max_chunks = max_chunks; rx->tp.min_own = min_own_samples; rx->tp.warmup = warmup_samples;
+    return SAME_OK;
+}
+uint32_t same_batch_time_parallel_chunks(const same_batch *rx) { return rx ? rx->tp.last_chunks : 0; }
+
 const char *same_batch_kernel_name(const same_batch *rx)
 {
     if (!rx) return "";

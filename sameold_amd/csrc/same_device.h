@@ -122,6 +122,49 @@ struct State {
     uint64_t *trace_idx;   // [C][trace_cap]
 };
 
+// Time-parallel chunks (same_kernels_pipe.hip).  A launch over n_chunks * in_channels
+// state columns: column chunk * in_channels + cin demodulates input column cin from block
+// chunk * stride_blocks of the call on.  Chunk 0 starts from the channel's real state, the others from
+// a reset receiver `warm-up` samples before the range they own; every chunk but the last runs
+// nominal_blocks blocks and then on until each of its lanes has been seen idle (NoCarrier), records
+// that instant in handover[column] and leaves; the last one runs to the end of the input.
+// n_chunks <= 1: an ordinary launch (all other fields ignored).
+struct PipeChunks {
+    uint32_t n_chunks;
+    uint32_t in_channels;      // channels of the input rows (multiple of the workgroup width)
+    uint32_t stride_blocks;    // blocks between the first rows of consecutive chunks
+    uint32_t nominal_blocks;   // warm-up + own range, in blocks, of every chunk but the last
+    uint64_t *handover;        // [n_chunks * in_channels] input sample counter of the hand-over, ~0 = never
+};
+
+// Geometry of one time-parallel call, shared by the device (which chunk's final state becomes the
+// channel's state) and the host (which chunk's events are kept when): chunk k >= 1 owns the samples
+// from own_start(k) on, and a chunk that hands over at input sample counter h is followed by the chunk
+// that owns h.
+struct ChunkGeom {
+    uint64_t counter0;       // input sample counter of the call's first sample
+    uint32_t n_chunks, block_len, stride_blocks, warmup_blocks;
+#if defined(__HIPCC__)
+    __host__ __device__
+#endif
+    uint32_t owner_of(uint64_t h) const
+    {
+        const uint64_t blocks = (h - counter0) / block_len;
+        if (blocks < warmup_blocks) return 0u;
+        const uint64_t k = (blocks - warmup_blocks) / stride_blocks;
+        return k >= n_chunks ? n_chunks - 1u : (uint32_t)k;
+    }
+#if defined(__HIPCC__)
+    __host__ __device__
+#endif
+    uint64_t own_start(uint32_t k) const
+    { return k == 0u ? counter0 : counter0 + ((uint64_t)k * stride_blocks + warmup_blocks) * block_len; }
+};
+constexpr uint64_t kNoHandover = ~0ull;
+
+// one State array for the column copies between the real and the time-parallel state blobs
+struct StateArrayDesc { char *src; char *dst; uint32_t rows; uint32_t elem_words; };
+
 // One link-layer event as the device records it.  32 bytes.
 constexpr uint32_t kDevEventNone = 0xffffffffu;   // kind of a reserved but unused log slot (skipped by the host)
 struct DevEvent {

@@ -269,6 +269,63 @@ hipError_t launch_init_state(const Params &P, const State &S, int is_reset, hipS
     return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------------
+// time-parallel chunks: state columns in and out of the wide state blob
+// ---------------------------------------------------------------------------------
+__global__ void copy_state_columns_kernel(const StateArrayDesc *desc, uint32_t Csrc, uint32_t Cdst,
+                                          const uint32_t *src_col, uint32_t n_cols)
+{
+    const uint32_t col = blockIdx.x * blockDim.x + threadIdx.x;
+    if (col >= n_cols) return;
+    const StateArrayDesc d = desc[blockIdx.y];
+    const uint32_t sc = src_col ? src_col[col] : col;
+    const uint32_t w = d.elem_words;
+    const uint32_t *src = reinterpret_cast<const uint32_t *>(d.src);
+    uint32_t *dst = reinterpret_cast<uint32_t *>(d.dst);
+    for (uint32_t r = 0; r < d.rows; ++r) {
+        const uint32_t *s = src + ((size_t)r * Csrc + sc) * w;
+        uint32_t *t = dst + ((size_t)r * Cdst + col) * w;
+        for (uint32_t i = 0; i < w; ++i) t[i] = s[i];
+    }
+}
+hipError_t launch_copy_state_columns(const StateArrayDesc *desc, uint32_t n_desc, uint32_t src_channels,
+                                     uint32_t dst_channels, const uint32_t *src_col, uint32_t n_cols, hipStream_t stream)
+{
+    hipLaunchKernelGGL(copy_state_columns_kernel, dim3((n_cols + 255) / 256, n_desc), dim3(256), 0, stream, desc,
+                       src_channels, dst_channels, src_col, n_cols);
+    return hipGetLastError();
+}
+__global__ void chunk_final_column_kernel(const uint64_t *handover, uint32_t C, ChunkGeom g, uint32_t *final_col)
+{
+    const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    uint32_t cur = 0;
+    for (;;) {
+        const uint64_t h = handover[(size_t)cur * C + c];
+        if (h == kNoHandover) break;
+        const uint32_t nxt = g.owner_of(h);
+        if (nxt <= cur) break;                   // (cannot happen: a hand-over lies in a later chunk's range)
+        cur = nxt;
+    }
+    final_col[c] = cur * C + c;
+}
+hipError_t launch_chunk_final_column(const uint64_t *handover, uint32_t in_channels, ChunkGeom g, uint32_t *final_col,
+                                     hipStream_t stream)
+{
+    hipLaunchKernelGGL(chunk_final_column_kernel, dim3((in_channels + 255) / 256), dim3(256), 0, stream, handover, in_channels, g, final_col);
+    return hipGetLastError();
+}
+__global__ void fill_u64_kernel(uint64_t *p, size_t n, uint64_t v)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+hipError_t launch_fill_u64(uint64_t *p, size_t n, uint64_t v, hipStream_t stream)
+{
+    hipLaunchKernelGGL(fill_u64_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, p, n, v);
+    return hipGetLastError();
+}
+
 hipError_t launch_transpose_f32(const float *in, float *out, uint32_t n_channels, uint32_t n_samples,
                                 hipStream_t stream)
 {

@@ -237,8 +237,11 @@ struct SampleStage {
     uint32_t wp[3];                      // their ring positions
     uint32_t wnext;                      // ring position of the block computed next
 
+    // c / C index the state arrays, cin / Cin the input (they differ for time-parallel chunks, where
+    // several state columns read the same input column at different rows)
     __device__ __forceinline__ void load(const Params &P, const State &S, const SampleT *__restrict__ x,
-                                         uint32_t c, uint32_t C, uint64_t counter0, float *wcol, uint32_t n_blocks)
+                                         uint32_t c, uint32_t C, uint32_t cin, uint32_t Cin, uint64_t counter0,
+                                         float *wcol, uint32_t n_blocks)
     {
         const uint32_t G = P.win_ring;
 #pragma unroll 2
@@ -261,11 +264,11 @@ struct SampleStage {
             mp[k] = r1[c];
         }
 #pragma unroll
-        for (int k = 0; k < kB; ++k) { const SampleT *row = x + (size_t)k * C; xn[0][k] = (float)row[c]; }
+        for (int k = 0; k < kB; ++k) { const SampleT *row = x + (size_t)k * Cin; xn[0][k] = (float)row[cin]; }
         if (n_blocks > 1u) {
-            const SampleT *xb = x + (size_t)kB * C;
+            const SampleT *xb = x + (size_t)kB * Cin;
 #pragma unroll
-            for (int k = 0; k < kB; ++k) { const SampleT *row = xb + (size_t)k * C; xn[1][k] = (float)row[c]; }
+            for (int k = 0; k < kB; ++k) { const SampleT *row = xb + (size_t)k * Cin; xn[1][k] = (float)row[cin]; }
         }
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
@@ -329,14 +332,14 @@ struct SampleStage {
     // the registers they leave
     template <int BUF>
     __device__ __forceinline__ void fetch(const SampleT *__restrict__ x, uint32_t blk, uint32_t n_blocks,
-                                          uint32_t c, uint32_t C)
+                                          uint32_t cin, uint32_t Cin)
     {
 #pragma unroll
         for (int k = 0; k < kB; ++k) xs[k] = xn[BUF][k];
         if (blk + 2 < n_blocks) {
-            const SampleT *xb = x + ((size_t)(blk + 2) * kB) * C;      // wave-uniform
+            const SampleT *xb = x + ((size_t)(blk + 2) * kB) * Cin;      // wave-uniform
 #pragma unroll
-            for (int k = 0; k < kB; ++k) { const SampleT *row = xb + (size_t)k * C; xn[BUF][k] = (float)row[c]; }
+            for (int k = 0; k < kB; ++k) { const SampleT *row = xb + (size_t)k * Cin; xn[BUF][k] = (float)row[cin]; }
         }
     }
     // DC blocker (rx/dcblock.rs:45-49, 104-108), AGC and window push of the fetched block into slot 0
@@ -439,7 +442,7 @@ template <int NT, int NFF, int NFB, bool MED3, bool SHARE, int LANES, bool SPLIT
 __global__ __launch_bounds__(4 * kWave, SHARE ? 2 : 1) void demod_pipe_kernel(Params P, State S, Output O,
                                                                 const float4 *__restrict__ taps,
                                                                 const SampleT *__restrict__ x,
-                                                                uint32_t n_blocks, uint64_t counter0)
+                                                                uint32_t n_blocks, uint64_t counter0, PipeChunks K)
 {
     constexpr int kB = PipeLayout<NT>::B, RING = PipeLayout<NT>::RING;
     constexpr uint32_t LP = kWave, kPipeTapFloats = PipeLayout<NT>::tap_floats;
@@ -449,6 +452,22 @@ __global__ __launch_bounds__(4 * kWave, SHARE ? 2 : 1) void demod_pipe_kernel(Pa
     const uint32_t role = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // 0..3 = stage 1..4
     const uint32_t C = P.n_channels;
     const uint32_t c = blockIdx.x * (uint32_t)LANES + lane;  // C % LANES == 0 (host)
+    // Time-parallel chunks: state column c = chunk * Cin + cin reads input column cin
+    // from the chunk's first row on; a workgroup never straddles chunks (Cin % LANES == 0, host).
+    uint32_t cin = c, Cin = C, n_nominal = n_blocks;
+    bool may_leave = false;                                  // chunk that hands over: leave once every lane is idle
+    if (K.n_chunks > 1u) {
+        const uint32_t wgs = K.in_channels / (uint32_t)LANES;
+        const uint32_t chunk = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x / wgs));
+        cin = (blockIdx.x - chunk * wgs) * (uint32_t)LANES + lane;
+        Cin = K.in_channels;
+        const uint32_t first_block = chunk * K.stride_blocks;
+        x += (size_t)first_block * kB * Cin;
+        counter0 += (uint64_t)first_block * kB;
+        n_blocks -= first_block;                             // everything up to the end of the input is available
+        may_leave = chunk + 1u < K.n_chunks;
+        n_nominal = may_leave ? K.nominal_blocks : n_blocks;
+    }
     // LDS: taps | mailboxes | squelch history [64][64] | window (logical slots kB .. 2*RING-1) | stage 1's ring (YLDS)
     float4 *tlds = reinterpret_cast<float4 *>(lds);
     lds_u32 *mail = (lds_u32 *)(lds + kPipeTapFloats);
@@ -475,13 +494,14 @@ __global__ __launch_bounds__(4 * kWave, SHARE ? 2 : 1) void demod_pipe_kernel(Pa
         P3_HWID(0);
         SampleStage<NT, MED3, SampleT> M;
         M.ycol = wring + (2u * (uint32_t)RING) * LP + lane;           // behind the window
-        M.load(P, S, x, c, C, counter0, wcol, n_blocks);
+        M.load(P, S, x, c, C, cin, Cin, counter0, wcol, n_blocks);
         P3_T0();
         // one step; BUF = s & 1 names the prefetch registers statically, so the loop runs two steps a turn
-        auto step = [&](uint32_t s, auto buf) {
+        uint32_t stop_at = 0xffffffffu;                                // time-parallel chunk: leave after this step
+        auto step = [&](uint32_t s, auto buf) -> bool {
             M.rotate();
             if (s < n_blocks) {
-                M.template fetch<decltype(buf)::value>(x, s, n_blocks, c, C);
+                M.template fetch<decltype(buf)::value>(x, s, n_blocks, cin, Cin);
 #ifdef SAME_P1_SPLIT
                 asm volatile("s_waitcnt vmcnt(%0)" :: "n"(kB) : "memory");    // profiling: the block's inputs have arrived
                 P3_LAP(p3_fb);                                       // (reported in the "feedback" column)
@@ -493,7 +513,9 @@ __global__ __launch_bounds__(4 * kWave, SHARE ? 2 : 1) void demod_pipe_kernel(Pa
             P3_LAP(p3_wait);
             if (s >= 2u && s <= last_fb_step) {
                 const lds_u32 *fb = fbbox + (s & 1u) * kP3FbWords;
-                if (__builtin_amdgcn_readfirstlane((int)fb[kWave])) {
+                const uint32_t fbw = (uint32_t)__builtin_amdgcn_readfirstlane((int)fb[kWave]);
+                if (fbw & 2u) stop_at = s + 1u;
+                if (fbw & 1u) {
                     const uint32_t v = fb[lane];
                     const bool new_locked = (v & 2u) != 0u;
                     if ((v & 1u) && new_locked != M.locked)
@@ -503,14 +525,17 @@ __global__ __launch_bounds__(4 * kWave, SHARE ? 2 : 1) void demod_pipe_kernel(Pa
                     P3_LAP(p3_fb);
                 }
             }
+            return s == stop_at;
         };
-        for (uint32_t s = 0; s < n_steps; s += 2u) {
-            step(s, std::integral_constant<int, 0>{});
-            if (s + 1u < n_steps) step(s + 1u, std::integral_constant<int, 1>{});
+        bool left = false;
+        for (uint32_t s = 0; s < n_steps && !left; s += 2u) {
+            left = step(s, std::integral_constant<int, 0>{});
+            if (!left && s + 1u < n_steps) left = step(s + 1u, std::integral_constant<int, 1>{});
         }
 #ifndef SAME_P3_MARKS
         P3_REPORT(0);
 #endif
+        if (left) return;                                              // handed over: this chunk's state is not needed
         lds_barrier();                                                 // (stage 2 -> 3: final TED phase)
         M.store(P, S, c, C, counter1, wcol);
     } else if (role == 1u) {
@@ -584,6 +609,8 @@ __global__ __launch_bounds__(4 * kWave, SHARE ? 2 : 1) void demod_pipe_kernel(Pa
             S2_LAP(3);
         };
         P3_T0();
+        uint32_t stop_at = 0xffffffffu;
+        bool left = false;
         for (uint32_t s = 0; s < n_steps; ++s) {
             // this lane's state before block s-1, in case stage 3 sends it back there
             const float k_h0 = L.h0, k_h1 = L.h1, k_h2 = L.h2, k_avg = L.period_avg, k_inst = L.period_inst,
@@ -598,7 +625,9 @@ __global__ __launch_bounds__(4 * kWave, SHARE ? 2 : 1) void demod_pipe_kernel(Pa
             P3_LAP(p3_wait);
             if (s >= 2u && s <= last_fb_step) {
                 const lds_u32 *fb = fbbox + (s & 1u) * kP3FbWords;
-                if (__builtin_amdgcn_readfirstlane((int)fb[kWave])) {
+                const uint32_t fbw = (uint32_t)__builtin_amdgcn_readfirstlane((int)fb[kWave]);
+                if (fbw & 2u) stop_at = s + 1u;
+                if (fbw & 1u) {
                     const uint32_t v = fb[lane];
                     if (v & 1u) {
                         L.h0 = k_h0; L.h1 = k_h1; L.h2 = k_h2; L.period_avg = k_avg; L.period_inst = k_inst;
@@ -617,6 +646,7 @@ __global__ __launch_bounds__(4 * kWave, SHARE ? 2 : 1) void demod_pipe_kernel(Pa
                 }
             }
             if (active) { wpos += kB; if (wpos == (uint32_t)RING) wpos = 0; }
+            if (s == stop_at) { left = true; break; }
         }
 #ifndef SAME_P3_MARKS
         P3_REPORT(1);
@@ -624,6 +654,7 @@ __global__ __launch_bounds__(4 * kWave, SHARE ? 2 : 1) void demod_pipe_kernel(Pa
 #ifdef SAME_PROFILE
         if (blockIdx.x == 0 && lane == 0) for (int i = 0; i < 5; ++i) g_same_prof_s2[i] += s2_acc[i];
 #endif
+        if (left) return;
         phasebox[lane] = L.flags & F_TED_PHASE;
         lds_barrier();                                                 // stage 3 merges the phase bit
         L.ted_clock = (uint32_t)(cstar - until - 1);
@@ -664,6 +695,8 @@ __global__ __launch_bounds__(4 * kWave, SHARE ? 2 : 1) void demod_pipe_kernel(Pa
 #pragma unroll 2
         for (int i = 0; i < kSquelchHist; ++i) { const float *row = S.sq_hist + (size_t)i * C; hcol[i * LP] = row[c]; }
         P3_T0();
+        uint32_t stop_at = 0xffffffffu;
+        bool left = false, lane_done = false, leave_posted = false;
         for (uint32_t s = 0; s < n_steps; ++s) {
             bool any = false;
             if (s >= 2u && s <= last_fb_step) {
@@ -696,12 +729,25 @@ __global__ __launch_bounds__(4 * kWave, SHARE ? 2 : 1) void demod_pipe_kernel(Pa
                 lds_u32 *fb = fbbox + (s & 1u) * kP3FbWords;
                 fb[lane] = fbv;
                 any = __builtin_amdgcn_ballot_w64(fbv != 0u) != 0ull;
-                if (lane == 0u) fb[kWave] = any ? 1u : 0u;
+                // Time-parallel chunk that hands over: from its nominal end on, a lane's
+                // hand-over instant is the end of the first block after which its link state is NoCarrier;
+                // once every lane has one the workgroup leaves (one more step: stage 4 still has to log
+                // this block's events).
+                uint32_t leave = 0u;
+                if (may_leave && !leave_posted && blk + 1u >= n_nominal) {
+                    if (!lane_done && (L.flags & F_LINK_MASK) == 0u) {
+                        lane_done = true;
+                        K.handover[c] = counter0 + (uint64_t)(blk + 1u) * kB;
+                    }
+                    if (__builtin_amdgcn_ballot_w64(!lane_done) == 0ull) { leave = 2u; leave_posted = true; stop_at = s + 1u; }
+                }
+                if (lane == 0u) fb[kWave] = (any ? 1u : 0u) | leave;
             }
             P3_LAP(p3_work);
             lds_barrier();                                             // A
             P3_LAP(p3_wait);
             if (any) { lds_barrier(); lds_barrier(); P3_LAP(p3_fb); }   // B, C: the earlier stages catch up
+            if (s == stop_at) { left = true; break; }
         }
 #ifndef SAME_P3_MARKS
         P3_REPORT(2);
@@ -710,6 +756,7 @@ __global__ __launch_bounds__(4 * kWave, SHARE ? 2 : 1) void demod_pipe_kernel(Pa
         if (blockIdx.x == 0 && lane == 0)
             for (int i = 0; i < 6; ++i) atomicAdd(&g_same_prof_pipe[i], X.pl[1 + 2 + i] - (i == 0 ? 0ull : 0ull));
 #endif
+        if (left) return;
         lds_barrier();                                                 // stage 2's TED phase, stage 4's wake-up flag
         L.flags = (L.flags & ~(F_TED_PHASE | F_TICK_AGAIN)) | (phasebox[lane] & F_TED_PHASE) | (againbox[lane] & F_TICK_AGAIN);
         S.sq_data[c] = L.sq_data; S.sq_power[c] = L.sq_power; S.sq_phist[c] = L.sq_phist;
@@ -741,6 +788,8 @@ __global__ __launch_bounds__(4 * kWave, SHARE ? 2 : 1) void demod_pipe_kernel(Pa
         X.pending_slot = 0xffffffffu;
         uint32_t wpos = 0;                     // SPLIT: ring slot of block s-1's first sample
         if (SPLIT && lane == 0u) seqbox[0] = 0u;
+        uint32_t stop_at = 0xffffffffu;
+        bool left = false;
         for (uint32_t s = 0; s < n_steps; ++s) {
             // SPLIT: first the space filter of block s-1 for stage 2, which waits for it
             const bool active = SPLIT && s >= 1u && s <= n_blocks;
@@ -773,7 +822,9 @@ __global__ __launch_bounds__(4 * kWave, SHARE ? 2 : 1) void demod_pipe_kernel(Pa
             lds_barrier();                                             // A
             if (s >= 2u && s <= last_fb_step) {
                 const lds_u32 *fb = fbbox + (s & 1u) * kP3FbWords;
-                if (__builtin_amdgcn_readfirstlane((int)fb[kWave])) {
+                const uint32_t fbw = (uint32_t)__builtin_amdgcn_readfirstlane((int)fb[kWave]);
+                if (fbw & 2u) stop_at = s + 1u;
+                if (fbw & 1u) {
                     const uint32_t v = SPLIT ? fb[lane] : 0u;
                     lds_barrier();                                     // B: stage 1 has corrected the window
                     if (SPLIT) {
@@ -785,8 +836,10 @@ __global__ __launch_bounds__(4 * kWave, SHARE ? 2 : 1) void demod_pipe_kernel(Pa
                 }
             }
             if (active) { wpos += kB; if (wpos == (uint32_t)RING) wpos = 0; }
+            if (s == stop_at) { left = true; break; }
         }
         X.retire(O, lane, (uint32_t)LANES);
+        if (left) return;
         againbox[lane] = L.flags & F_TICK_AGAIN;
         lds_barrier();                                                 // stage 3 merges the flag bits
         S.tk_next[c] = L.tk_next; S.tk_last[c] = L.tk_last; S.wake_fired[c] = L.wake_fired;
@@ -840,7 +893,8 @@ uint32_t pipe_block_len(const Params &P)
 
 template <int NT, int NFF, int NFB, bool M3, bool SHARE, int LANES, bool SPLIT, typename SampleT>
 static hipError_t launch_pipe_one(const Params &P, const State &S, const Output &O, const float4 *taps,
-                                  const SampleT *x, uint32_t n_blocks, uint64_t counter0, hipStream_t stream)
+                                  const SampleT *x, uint32_t n_blocks, uint64_t counter0, hipStream_t stream,
+                                  const PipeChunks &K)
 {
     constexpr size_t lds = pipe_lds_bytes<NT>();
     auto *kernel = demod_pipe_kernel<NT, NFF, NFB, M3, SHARE, LANES, SPLIT, SampleT>;
@@ -856,13 +910,15 @@ static hipError_t launch_pipe_one(const Params &P, const State &S, const Output 
             opted_in[dev] = true;
         }
     }
-    hipLaunchKernelGGL(kernel, dim3(P.n_channels / (uint32_t)LANES), dim3(4 * kWave), lds, stream, P, S, O, taps, x, n_blocks, counter0);
+    if (K.n_chunks > 1u && (K.in_channels % (uint32_t)LANES) != 0u) return hipErrorInvalidValue;   // a workgroup would straddle chunks
+    hipLaunchKernelGGL(kernel, dim3(P.n_channels / (uint32_t)LANES), dim3(4 * kWave), lds, stream, P, S, O, taps, x, n_blocks, counter0, K);
     return hipGetLastError();
 }
 
 template <int NT, typename SampleT>
 static hipError_t launch_pipe_cfg(const Params &P, const State &S, const Output &O, const float4 *taps,
-                                  const SampleT *x, uint32_t n_blocks, uint64_t counter0, hipStream_t stream)
+                                  const SampleT *x, uint32_t n_blocks, uint64_t counter0, hipStream_t stream,
+                                  const PipeChunks &K)
 {
     // two workgroups per CU (22.05 kHz only, where their LDS allows it): the register-capped build, with
     // stage 2 split (same box, 32 768 channels x 2 s: 4.27-4.29 ms unsplit, 4.18-4.24 ms split).  Which stages
@@ -874,9 +930,9 @@ static hipError_t launch_pipe_cfg(const Params &P, const State &S, const Output 
     const bool med3 = agc_clamp_is_med3(P);
     const bool share_split = P.knob_pipe_split != 0 ? P.knob_pipe_split > 0 : true;
 #define SAME_PIPE_LAUNCH(NFF, NFB, M3)                                                                                  \
-    (share ? (share_split ? launch_pipe_one<NT, NFF, NFB, M3, CAN_SHARE, 64, CAN_SHARE, SampleT>(P, S, O, taps, x, n_blocks, counter0, stream)    \
-                          : launch_pipe_one<NT, NFF, NFB, M3, CAN_SHARE, 64, false, SampleT>(P, S, O, taps, x, n_blocks, counter0, stream))     \
-           : launch_pipe_one<NT, NFF, NFB, M3, false, 64, false, SampleT>(P, S, O, taps, x, n_blocks, counter0, stream))
+    (share ? (share_split ? launch_pipe_one<NT, NFF, NFB, M3, CAN_SHARE, 64, CAN_SHARE, SampleT>(P, S, O, taps, x, n_blocks, counter0, stream, K)    \
+                          : launch_pipe_one<NT, NFF, NFB, M3, CAN_SHARE, 64, false, SampleT>(P, S, O, taps, x, n_blocks, counter0, stream, K))     \
+           : launch_pipe_one<NT, NFF, NFB, M3, false, 64, false, SampleT>(P, S, O, taps, x, n_blocks, counter0, stream, K))
     const uint32_t lanes = pipe_lanes(P);
     if (P.eq_nff == 6u && P.eq_nfb == 4u && med3 && !share) {
         // the default configuration: narrow workgroups for small batches, and stage 2 split with stage 4's
@@ -884,8 +940,8 @@ static hipError_t launch_pipe_cfg(const Params &P, const State &S, const Output 
         // 22.05 kHz, whose symbol stage is longer still
         const bool split = P.knob_pipe_split != 0 ? P.knob_pipe_split > 0 : (NT != 42 || lanes != kWave);
 #define SAME_PIPE_LANES_LAUNCH(LN)                                                                                          \
-        (split ? launch_pipe_one<NT, 6, 4, true, false, LN, true, SampleT>(P, S, O, taps, x, n_blocks, counter0, stream)    \
-               : launch_pipe_one<NT, 6, 4, true, false, LN, false, SampleT>(P, S, O, taps, x, n_blocks, counter0, stream))
+        (split ? launch_pipe_one<NT, 6, 4, true, false, LN, true, SampleT>(P, S, O, taps, x, n_blocks, counter0, stream, K)    \
+               : launch_pipe_one<NT, 6, 4, true, false, LN, false, SampleT>(P, S, O, taps, x, n_blocks, counter0, stream, K))
         if (lanes == 16u) return SAME_PIPE_LANES_LAUNCH(16);
         if (lanes == 32u) return SAME_PIPE_LANES_LAUNCH(32);
         return SAME_PIPE_LANES_LAUNCH(64);
@@ -898,19 +954,21 @@ static hipError_t launch_pipe_cfg(const Params &P, const State &S, const Output 
 
 template <typename SampleT>
 static hipError_t launch_pipe_t(const Params &P, const State &S, const Output &O, const float4 *taps,
-                                const SampleT *x, uint32_t n_blocks, uint64_t counter0, hipStream_t stream)
+                                const SampleT *x, uint32_t n_blocks, uint64_t counter0, hipStream_t stream,
+                                const PipeChunks &K)
 {
-    if (P.ntaps == 42u) return launch_pipe_cfg<42, SampleT>(P, S, O, taps, x, n_blocks, counter0, stream);
-    if (P.ntaps == 92u) return launch_pipe_cfg<92, SampleT>(P, S, O, taps, x, n_blocks, counter0, stream);
-    return launch_pipe_cfg<84, SampleT>(P, S, O, taps, x, n_blocks, counter0, stream);
+    if (P.ntaps == 42u) return launch_pipe_cfg<42, SampleT>(P, S, O, taps, x, n_blocks, counter0, stream, K);
+    if (P.ntaps == 92u) return launch_pipe_cfg<92, SampleT>(P, S, O, taps, x, n_blocks, counter0, stream, K);
+    return launch_pipe_cfg<84, SampleT>(P, S, O, taps, x, n_blocks, counter0, stream, K);
 }
 
 hipError_t launch_demod_pipe(const Params &P, const State &S, const Output &O, const float4 *taps,
-                             const float *x, uint32_t n_blocks, uint64_t counter0, hipStream_t stream)
-{ return launch_pipe_t<float>(P, S, O, taps, x, n_blocks, counter0, stream); }
+                             const float *x, uint32_t n_blocks, uint64_t counter0, hipStream_t stream, const PipeChunks &K)
+{ return launch_pipe_t<float>(P, S, O, taps, x, n_blocks, counter0, stream, K); }
 hipError_t launch_demod_pipe_i16(const Params &P, const State &S, const Output &O, const float4 *taps,
-                                 const int16_t *x, uint32_t n_blocks, uint64_t counter0, hipStream_t stream)
-{ return launch_pipe_t<int16_t>(P, S, O, taps, x, n_blocks, counter0, stream); }
+                                 const int16_t *x, uint32_t n_blocks, uint64_t counter0, hipStream_t stream, const PipeChunks &K)
+{ return launch_pipe_t<int16_t>(P, S, O, taps, x, n_blocks, counter0, stream, K); }
+uint32_t pipe_workgroup_channels(const Params &P) { return pipe_lanes(P); }
 
 }  // namespace same
 

@@ -23,9 +23,12 @@ bool pipe_kernel_selected(const Params &P);
 uint32_t pipe_kernel_stages(const Params &P);     // 0 (not selected) or non-zero
 uint32_t pipe_block_len(const Params &P);         // samples per block of the pipeline at this rate
 hipError_t launch_demod_pipe(const Params &P, const State &S, const Output &O, const float4 *taps,
-                             const float *x, uint32_t n_blocks, uint64_t counter0, hipStream_t stream);
+                             const float *x, uint32_t n_blocks, uint64_t counter0, hipStream_t stream,
+                             const PipeChunks &chunks = PipeChunks{});
 hipError_t launch_demod_pipe_i16(const Params &P, const State &S, const Output &O, const float4 *taps,
-                                 const int16_t *x, uint32_t n_blocks, uint64_t counter0, hipStream_t stream);
+                                 const int16_t *x, uint32_t n_blocks, uint64_t counter0, hipStream_t stream,
+                                 const PipeChunks &chunks = PipeChunks{});
+uint32_t pipe_workgroup_channels(const Params &P);   // channels per workgroup the pipeline would use for this batch
 hipError_t launch_demod_fast(const Params &P, const State &S, const Output &O, const float4 *taps,
                              const float *x, uint32_t n_blocks, uint64_t counter0, hipStream_t stream);
 hipError_t launch_demod_fast_i16(const Params &P, const State &S, const Output &O, const float4 *taps,
@@ -33,6 +36,14 @@ hipError_t launch_demod_fast_i16(const Params &P, const State &S, const Output &
 // zero the launch cursors (publish = 0) or copy them to host-mapped memory (publish = 1)
 hipError_t launch_counters(uint32_t *dev, uint32_t *host_mapped, int publish, hipStream_t stream);
 hipError_t launch_init_state(const Params &P, const State &S, int is_reset, hipStream_t stream);
+// Column copies between state blobs of different widths: for every array of `desc` (device memory,
+// n_desc entries) and every column col < n_cols, dst[row][col] = src[row][src_col ? src_col[col] : col].
+hipError_t launch_copy_state_columns(const StateArrayDesc *desc, uint32_t n_desc, uint32_t src_channels,
+                                     uint32_t dst_channels, const uint32_t *src_col, uint32_t n_cols, hipStream_t stream);
+// final_col[c] = the state column (chunk * in_channels + c) whose chunk ran to the end of the input
+hipError_t launch_chunk_final_column(const uint64_t *handover, uint32_t in_channels, ChunkGeom g, uint32_t *final_col,
+                                     hipStream_t stream);
+hipError_t launch_fill_u64(uint64_t *p, size_t n, uint64_t v, hipStream_t stream);
 hipError_t launch_transpose_f32(const float *in, float *out, uint32_t n_channels, uint32_t n_samples,
                                 hipStream_t stream);
 hipError_t launch_transpose_i16(const int16_t *in, int16_t *out, uint32_t n_channels, uint32_t n_samples,

@@ -25,7 +25,8 @@ LIB_PATH = os.path.join(_HERE, "libsame_rx.so")
 LINK_NO_CARRIER, LINK_SEARCHING, LINK_READING, LINK_BURST = 0, 1, 2, 3
 TRANSPORT_IDLE, TRANSPORT_ASSEMBLING, TRANSPORT_MSG_START, TRANSPORT_MSG_END, TRANSPORT_MSG_ERR = 16, 17, 18, 19, 20
 LAYOUT_TIME_MAJOR, LAYOUT_CHANNEL_MAJOR = 0, 1
-BATCH_LINK_ONLY, BATCH_TRACE_SYMBOLS, BATCH_GENERIC_KERNEL = 1, 2, 4
+BATCH_LINK_ONLY, BATCH_TRACE_SYMBOLS, BATCH_GENERIC_KERNEL, BATCH_TIME_PARALLEL = 1, 2, 4, 8
+TP_EVENT_TOLERANCE_SYMBOLS = 2      # SAME_TP_EVENT_TOLERANCE_SYMBOLS
 STREAM_OWN = (1 << 64) - 1          # SAME_STREAM_OWN: (void *)-1, the library's own stream
 EVENT_MAX_BYTES = 288
 
@@ -168,6 +169,9 @@ def load_library() -> C.CDLL:
     sig("same_batch_device", C.c_int, vp)
     sig("same_batch_process_device", C.c_int, vp, vp, C.c_size_t, u32, vp)
     sig("same_batch_order_after", C.c_int, vp, vp)
+    sig("same_batch_time_parallel_config", C.c_int, vp, u32, u32, u32)
+    sig("same_batch_time_parallel_chunks", u32, vp)
+    sig("same_rx_source_hash", C.c_char_p)
     sig("same_batch_process_device_i16", C.c_int, vp, vp, C.c_size_t, u32, vp)
     sig("same_batch_process_host", C.c_int, vp, vp, C.c_size_t, u32)
     sig("same_batch_process_host_i16", C.c_int, vp, vp, C.c_size_t, u32)
@@ -307,19 +311,21 @@ class SameReceiverBuilder:
         return SameReceiver(self, device)
 
     def build_batch(self, n_channels: int, device: int = 0, link_only: bool = False,
-                    trace_symbols: bool = False, generic_kernel: bool = False) -> "SameBatchReceiver":
-        return SameBatchReceiver(self, n_channels, device, link_only, trace_symbols, generic_kernel)
+                    trace_symbols: bool = False, generic_kernel: bool = False,
+                    time_parallel: bool = False) -> "SameBatchReceiver":
+        return SameBatchReceiver(self, n_channels, device, link_only, trace_symbols, generic_kernel, time_parallel)
 
 
 class SameBatchReceiver:
     """n independent `SameReceiver`s advancing in lockstep on one MI355X."""
 
     def __init__(self, builder: SameReceiverBuilder, n_channels: int, device: int = 0,
-                 link_only: bool = False, trace_symbols: bool = False, generic_kernel: bool = False):
+                 link_only: bool = False, trace_symbols: bool = False, generic_kernel: bool = False,
+                 time_parallel: bool = False):
         self._L = load_library()
         h = C.c_void_p()
         flags = ((BATCH_LINK_ONLY if link_only else 0) | (BATCH_TRACE_SYMBOLS if trace_symbols else 0)
-                 | (BATCH_GENERIC_KERNEL if generic_kernel else 0))
+                 | (BATCH_GENERIC_KERNEL if generic_kernel else 0) | (BATCH_TIME_PARALLEL if time_parallel else 0))
         _check(self._L.same_batch_new(builder._h, n_channels, device, flags, C.byref(h)))
         self._h = h
         self._inflight = []          # input tensors of launches that may still be running (process_tensor)
@@ -344,6 +350,14 @@ class SameBatchReceiver:
 
     def reset(self):
         _check(self._L.same_batch_reset(self._h))
+
+    def time_parallel_config(self, max_chunks: int = 0, min_own_samples: int = 0, warmup_samples: int = 0):
+        """SAME_BATCH_TIME_PARALLEL tuning (0 = default), see include/same_rx.h."""
+        _check(self._L.same_batch_time_parallel_config(self._h, max_chunks, min_own_samples, warmup_samples))
+
+    def time_parallel_chunks(self) -> int:
+        """Chunks per channel of the most recent process call (1 = one strict launch)."""
+        return self._L.same_batch_time_parallel_chunks(self._h)
 
     def process_device_ptr(self, ptr: int, n_samples: int, layout: int = LAYOUT_TIME_MAJOR,
                            stream: Optional[int] = None, i16: bool = False):
