@@ -497,9 +497,20 @@ int harvest_slot(same_batch *rx, same_batch::Slot &sl)
             for (; j < first[ncol + 1u] && evs[order[j]].sample_counter <= h; ++j)
                 if (evs[order[j]].kind <= SAME_LINK_BURST) st = evs[order[j]].kind;
             keep_after = h;
-            if (st != SAME_LINK_NO_CARRIER)
+            if (st == SAME_LINK_READING || st == SAME_LINK_BURST) {
+                // busy with a burst the previous chunk has already delivered (or with the garbage a chunk that
+                // joined in the middle of one makes of it): its events count from its next NoCarrier on
                 for (; j < first[ncol + 1u]; ++j)
                     if (evs[order[j]].kind == SAME_LINK_NO_CARRIER) { keep_after = evs[order[j]].sample_counter; break; }
+            } else if (st == SAME_LINK_SEARCHING && ts.link == SAME_LINK_NO_CARRIER) {
+                // it has byte sync where the previous chunk has none yet (the two acquire a preamble some
+                // symbols apart): what follows -- Reading, Burst -- is real, so the channel is Searching from here
+                same::DevEvent inj{};
+                inj.channel = ncol; inj.kind = SAME_LINK_SEARCHING; inj.sample_counter = h;
+                inj.symbol_count = ts.a_sym + (uint64_t)((double)(h > ts.a_t ? h - ts.a_t : 0) / sps + 0.5);
+                inj.burst_slot = 0xffffffffu;
+                feed(part, ev, inj, c, 0);
+            }
             cur = nxt;
         }
         // the remainder of the call (less than a block), demodulated on the channel's real state afterwards,

@@ -1,0 +1,300 @@
+"""Time-parallel ("fast") mode, SAME_BATCH_TIME_PARALLEL: the parity contract of include/same_rx.h.
+
+Every chunk's arithmetic is the strict, bit-exact one; what the mode approximates is the state a chunk
+starts from (a freshly built receiver one warm-up before the samples it owns).  Against the oracle on
+the same samples:
+  * bursts: their number and order per channel and every transmitted byte (the header, or NNNN): EQUAL.
+    The up to frame_max_invalid + 1 bytes a burst carries after them are decoded from the silence that
+    follows the carrier and depend on the symbol clock's phase to the sample; they are not compared
+    (the transport layer never votes on them either: rx/combiner.rs truncates at the header's end);
+  * transport messages (header text, end-of-message), their number and order: EQUAL;
+  * link events of every delivered burst -- Reading, Burst, the NoCarrier after it -- within
+    TP_EVENT_TOLERANCE_SYMBOLS symbols of the reference's sample counter, its Searching anywhere inside
+    the preamble.  Acquisitions that never reach Reading (a Searching / NoCarrier pair) may differ;
+  * soft symbols of an open squelch: instants within SOFT_INSTANT_TOLERANCE samples, values within
+    SOFT_SYMBOL_TOLERANCE with equal sign;
+  * noisy input, where the reference itself drops a burst now and then and which one is chaotic: bursts
+    both deliver are equal as above, the number of unmatched bursts is bounded, BER tallies are
+    statistically equal.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+
+SOFT_SYMBOL_TOLERANCE = 0.05
+SOFT_INSTANT_TOLERANCE = 4       # samples (a tenth of a symbol at 22.05 kHz)
+
+
+@pytest.fixture(scope="module")
+def sa():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from sameold_amd import build as sbuild
+    sbuild.build()
+    import sameold_amd
+    sameold_amd.load_library()
+    return sameold_amd
+
+
+@pytest.fixture(scope="module")
+def ob():
+    from oracle import binding
+    binding.lib()
+    return binding
+
+
+def split(ev, n_ch):
+    first = np.searchsorted(ev["channel"], np.arange(n_ch + 1))
+    return [ev[first[c]:first[c + 1]] for c in range(n_ch)]
+
+
+def burst_list(e):
+    b = e[e["kind"] == 3]
+    return [r["bytes"][: min(int(r["len"]), 288)].tobytes() for r in b]
+
+
+def message_list(e):
+    m = e[e["kind"] >= 18]
+    return [(int(r["kind"]), r["bytes"][: min(int(r["len"]), 288)].tobytes()) for r in m]
+
+
+def burst_records(e):
+    """Per delivered burst: (t_searching, t_reading, t_burst, t_no_carrier_after, bytes) -- the acquisition
+    that led to it (last Searching before its Reading), leaving failed acquisitions out."""
+    out, t_s, t_r = [], None, None
+    link = e[e["kind"] <= 3]
+    for i, r in enumerate(link):
+        k, t = int(r["kind"]), int(r["sample_counter"])
+        if k == 1:
+            t_s = t
+        elif k == 2:
+            t_r = t
+        elif k == 3:
+            t_n = int(link[i + 1]["sample_counter"]) if i + 1 < len(link) and link[i + 1]["kind"] == 0 else None
+            out.append((t_s, t_r, t, t_n, r["bytes"][: min(int(r["len"]), 288)].tobytes()))
+            t_s = t_r = None
+    return out
+
+
+def payload_len(burst, payload):
+    """Bytes of a burst that were transmitted: the header (or NNNN).  What follows is decoded from the
+    silence after the carrier stops -- up to frame_max_invalid + 1 bytes -- and depends on the symbol
+    clock's phase to the sample."""
+    return len(payload) if burst[:4] == payload[:4] else 4
+
+
+def assert_contract(sa, got, ref, rate, n_ch, payload_of, exact_bursts=True, what=""):
+    """got / ref: event arrays (kind, channel, sample_counter, len, bytes) ordered by channel then time;
+    ref from the oracle or from a strict batch.  payload_of(c) = what channel c transmits."""
+    sps = rate / 520.83
+    tol = sa.receiver.TP_EVENT_TOLERANCE_SYMBOLS * sps
+    g, r = split(got, n_ch), split(ref, n_ch)
+    worst = {"reading": 0, "burst": 0, "no_carrier": 0, "searching": 0}
+    n_bursts = n_missing = 0
+    for c in range(n_ch):
+        pay = payload_of(c)
+        bg, br = burst_records(g[c]), burst_records(r[c])
+        n_bursts += len(br)
+        if exact_bursts:
+            assert len(bg) == len(br), f"{what} channel {c}: {len(bg)} bursts, reference {len(br)}"
+            assert message_list(g[c]) == message_list(r[c]), f"{what} channel {c}: transport messages differ"
+            pairs = list(zip(bg, br))
+        else:
+            # noisy input: the reference itself misses a burst now and then (an early false sync inside the
+            # preamble), and which ones is chaotic; match bursts by time and count the unmatched
+            pairs, j = [], 0
+            for x in br:
+                while j < len(bg) and bg[j][2] < x[2] - 4 * sps:
+                    j += 1; n_missing += 1
+                if j < len(bg) and abs(bg[j][2] - x[2]) <= 4 * sps:
+                    pairs.append((bg[j], x)); j += 1
+                else:
+                    n_missing += 1
+            n_missing += len(bg) - j
+        for x, y in pairs:
+            n = payload_len(y[4], pay)
+            assert x[4][:n] == y[4][:n], f"{what} channel {c}: burst payload differs: {x[4]!r} vs {y[4]!r}"
+            for name, i in (("reading", 1), ("burst", 2), ("no_carrier", 3)):
+                if x[i] is not None and y[i] is not None:
+                    d = abs(x[i] - y[i])
+                    worst[name] = max(worst[name], d)
+                    assert d <= tol, f"{what} channel {c}: {name} {d} samples off (tolerance {tol:.0f})"
+            if x[0] is not None and y[0] is not None:
+                d = abs(x[0] - y[0])
+                worst["searching"] = max(worst["searching"], d)
+                assert d <= 16 * 8 * sps, f"{what} channel {c}: Searching outside the preamble"
+    if not exact_bursts:
+        assert n_missing <= max(4, n_bursts // 25), f"{what}: {n_missing} of {n_bursts} bursts unmatched"
+    return worst
+
+
+def strict_events(sa, x, rate, builder=None, link_only=False):
+    n_ch = x.shape[1]
+    rx = (builder or sa.SameReceiverBuilder(rate)).build_batch(n_ch, link_only=link_only)
+    rx.process_tensor(x)
+    rx.sync()
+    return rx.poll_events_np()
+
+
+@pytest.mark.parametrize("n_ch,seconds,chunks,noise,rate", [(256, 10.0, 8, 0.0, 22050), (512, 8.0, 4, 0.05, 22050),
+                                                            (192, 12.0, 6, 0.0, 22050), (256, 6.0, 4, 0.02, 48000),
+                                                            (128, 6.0, 3, 0.0, 44100)])
+def test_time_parallel_meets_the_contract(sa, ob, n_ch, seconds, chunks, noise, rate):
+    from helpers.oracle_compare import assert_every_channel_matches_oracle
+    n = int(rate * seconds)
+    x = sa.synth_afsk(n_ch, n, rate, seed=1000 + n_ch, noise_sigma=noise)
+    ref = strict_events(sa, x, rate)
+    assert_every_channel_matches_oracle(ob, ob.default_config(rate), x, ref)      # the yardstick itself
+    rx = sa.SameReceiverBuilder(rate).build_batch(n_ch, time_parallel=True)
+    rx.time_parallel_config(max_chunks=chunks)
+    rx.process_tensor(x)
+    rx.sync()
+    assert rx.time_parallel_chunks() == chunks
+    got = rx.poll_events_np()
+    assert len(got[got["kind"] == 3]) >= 2 * n_ch
+    assert_contract(sa, got, ref, rate, n_ch, lambda c: sa.synth_payload(1000 + n_ch, c), exact_bursts=(noise == 0.0))
+
+
+def test_time_parallel_streaming_calls_continue_the_channel_state(sa):
+    """Three chunked calls back to back: chunk 0 of a call continues from the state the previous call's
+    last chunk left, bursts that straddle a call boundary included."""
+    rate, n_ch, n = 22050, 128, 22050 * 15
+    x = sa.synth_afsk(n_ch, n, rate, seed=808)
+    ref = strict_events(sa, x, rate)
+    rx = sa.SameReceiverBuilder(rate).build_batch(n_ch, time_parallel=True)
+    rx.time_parallel_config(max_chunks=4)
+    parts = []
+    for off in range(0, n, 22050 * 5):
+        rx.process_tensor(x[off:off + 22050 * 5].contiguous())
+        assert rx.time_parallel_chunks() == 4
+    rx.sync()
+    got = rx.poll_events_np()
+    # events come per call; bring them into (channel, time) order over the whole stream
+    got = got[np.lexsort((np.arange(len(got)), got["channel"]))]
+    assert_contract(sa, got, ref, rate, n_ch, lambda c: sa.synth_payload(808, c))
+
+
+@pytest.mark.parametrize("name", ["npt", "two_and_two", "long_message"])
+def test_time_parallel_golden_recordings(sa, ob, name):
+    """The reference's recordings cut into chunks (64 copies of the recording with different lead-ins, so
+    chunk boundaries fall at 64 different places of the transmission): the decoded text equals the .txt."""
+    import torch
+    pcm = np.fromfile(os.path.join(GOLDEN, f"{name}.22050.s16le.bin"), dtype="<i2").astype(np.float32)
+    n_ch = 64
+    lead = [317 * c for c in range(n_ch)]
+    n = len(pcm) + max(lead) + 4 * 22050           # + what samedec's end-of-file flush appends
+    x = np.zeros((n, n_ch), np.float32)
+    for c in range(n_ch):
+        x[lead[c]:lead[c] + len(pcm), c] = pcm
+    exp = [ln for ln in open(os.path.join(GOLDEN, f"{name}.22050.s16le.txt")).read().splitlines() if ln != "+OK"]
+    for chunks in (3, 5):
+        rx = sa.SameReceiverBuilder(22050).samedec().build_batch(n_ch, time_parallel=True)
+        rx.time_parallel_config(max_chunks=chunks)
+        rx.process_tensor(torch.from_numpy(x).cuda())
+        rx.sync()
+        assert rx.time_parallel_chunks() == chunks
+        ev = split(rx.poll_events_np(), n_ch)
+        for c in range(n_ch):
+            lines = [r["bytes"][: int(r["len"])].tobytes().decode() if r["kind"] == sa.TRANSPORT_MSG_START else "NNNN"
+                     for r in ev[c] if r["kind"] in (sa.TRANSPORT_MSG_START, sa.TRANSPORT_MSG_END)]
+            assert lines == exp, f"{chunks} chunks, lead-in {lead[c]}: {lines}"
+
+
+def test_short_calls_and_odd_batches_run_strict(sa, ob):
+    """Calls too short to cut, and channel counts the pipeline cannot take, run as one strict launch and
+    are then bit-exact."""
+    rate = 22050
+    for n_ch, n in ((64, 22050), (70, 22050 * 6)):
+        x = sa.synth_afsk(n_ch, n, rate, seed=5)
+        rx = sa.SameReceiverBuilder(rate).build_batch(n_ch, time_parallel=True)
+        rx.process_tensor(x)
+        rx.sync()
+        assert rx.time_parallel_chunks() == 1
+        got = rx.poll_events_np()
+        ref = strict_events(sa, x, rate)
+        lg, lr = got[got["kind"] <= 3], ref[ref["kind"] <= 3]
+        assert np.array_equal(lg["kind"], lr["kind"]) and np.array_equal(lg["sample_counter"], lr["sample_counter"])
+        assert np.array_equal(lg["bytes"], lr["bytes"])
+        assert [m for c in split(got, n_ch) for m in message_list(c)] == [m for c in split(ref, n_ch) for m in message_list(c)]
+
+
+def test_soft_symbols_of_a_chunk_that_starts_fresh(sa, ob):
+    """What a chunk does, on one channel with the symbol trace on (strict API): a freshly built receiver
+    started one warm-up before a burst's preamble produces, while the squelch is open (Reading ... Burst),
+    symbols at instants within SOFT_INSTANT_TOLERANCE samples of the continuous receiver's, with equal
+    sign and values within SOFT_SYMBOL_TOLERANCE."""
+    rate, n = 22050, 22050 * 10
+    warm = int(64 * rate / 520.83)
+    x = sa.synth_afsk(64, n, rate, seed=99)
+    full = sa.SameReceiverBuilder(rate).build_batch(64, trace_symbols=True, link_only=True)
+    full.process_tensor(x); full.sync()
+    ev = split(full.poll_events_np(), 64)
+    checked, all_dt, all_err, sign_flips = 0, [], [], 0
+    for c in range(0, 64, 5):
+        reading = ev[c][ev[c]["kind"] == 2]["sample_counter"]
+        bursts = ev[c][ev[c]["kind"] == 3]["sample_counter"]
+        if len(reading) < 2 or len(bursts) < 2:
+            continue
+        t_read, t_burst = int(reading[1]), int(bursts[1])          # the channel's second burst
+        start = t_read - 16 * 8 * 43 - warm                        # one warm-up before its preamble
+        start -= start % 20
+        if start < 0:
+            continue
+        part = sa.SameReceiverBuilder(rate).build_batch(64, trace_symbols=True, link_only=True)
+        part.process_tensor(x[start:].contiguous()); part.sync()
+        ta, tb = full.read_trace(c, cap=4096), part.read_trace(c, cap=4096)
+        tb = tb.copy(); tb["sample_counter"] += start
+        # transmitted symbols only: the burst event comes (max_invalid + 1) bytes after the carrier stopped
+        a = ta[(ta["sample_counter"] > t_read) & (ta["sample_counter"] < t_burst - 5 * 8 * 43)]
+        b = tb[(tb["sample_counter"] > t_read - 64) & (tb["sample_counter"] < t_burst + 64)]
+        assert len(a) > 200
+        idx = np.clip(np.searchsorted(b["sample_counter"], a["sample_counter"]), 1, len(b) - 1)
+        ta_ = a["sample_counter"].astype(np.int64)
+        near = np.where(np.abs(b["sample_counter"][idx].astype(np.int64) - ta_)
+                        < np.abs(b["sample_counter"][idx - 1].astype(np.int64) - ta_), idx, idx - 1)
+        all_dt.append(np.abs(b["sample_counter"][near].astype(np.int64) - ta_))
+        all_err.append(np.abs(b["sym"][near] - a["sym"]))
+        sign_flips += int(np.sum(np.sign(b["sym"][near]) != np.sign(a["sym"])))
+        checked += 1
+    assert checked >= 5
+    dt, err = np.concatenate(all_dt), np.concatenate(all_err)
+    stats = (f"{len(dt)} symbols of {checked} bursts: instants max {dt.max()} samples apart (mean {dt.mean():.2f}); "
+             f"soft symbols max |diff| {err.max():.4f}, {np.mean(err <= SOFT_SYMBOL_TOLERANCE):.5f} within {SOFT_SYMBOL_TOLERANCE}, "
+             f"{sign_flips} sign differences")
+    print(stats)
+    assert sign_flips == 0, stats
+    assert dt.max() <= SOFT_INSTANT_TOLERANCE, stats
+    assert err.max() <= SOFT_SYMBOL_TOLERANCE, stats
+
+
+def test_awgn_tally_statistically_equal(sa):
+    """configs[4] through the time-parallel mode: every 2 s trial cut in two (the boundary falls inside the
+    burst, so the first chunk runs on and the second joins mid-burst).  Burst lists must agree with strict
+    mode on all but a handful of marginal trials, and the tallies must be statistically equal."""
+    from sameold_amd import montecarlo as mc
+    n, grid, rate, seed = 4096, 15, 22050, 31
+    T = 2 * rate - (2 * rate) % 20
+    x = mc.synth_trials(n, 0, T, rate, seed, 0.0, 1.0, grid)
+    ref = strict_events(sa, x, rate, link_only=True)
+    rx = sa.SameReceiverBuilder(rate).build_batch(n, link_only=True, time_parallel=True)
+    rx.time_parallel_config(max_chunks=2, min_own_samples=8000)
+    rx.process_tensor(x); rx.sync()
+    assert rx.time_parallel_chunks() == 2
+    got = rx.poll_events_np()
+    payloads = [sa.synth_payload(seed, c) for c in range(n)]
+    ta, tb = mc.new_tally(grid), mc.new_tally(grid)
+    mc.score_bursts(ref, payloads, 0, n, grid, ta)
+    mc.score_bursts(got, payloads, 0, n, grid, tb)
+    g, r = split(got, n), split(ref, n)
+    differ = sum(burst_list(g[c]) != burst_list(r[c]) for c in range(n))
+    assert differ <= n // 100, f"{differ} of {n} trials decode differently"
+    for k in ("detected", "intact"):
+        # binomial: |difference| within 4 sigma of the strict count per grid point
+        sig = np.sqrt(np.maximum(ta[k] * (1 - ta[k] / np.maximum(ta["trials"], 1)), 1.0))
+        assert np.all(np.abs(ta[k] - tb[k]) <= 4 * sig + 2), (k, ta[k], tb[k])

@@ -69,11 +69,36 @@ def main():
             d = lb["sample_counter"].astype(np.int64) - la["sample_counter"].astype(np.int64)
             for k in (0, 1, 2, 3):
                 dt[k] += list(d[la["kind"] == k])
-        if bad and shown < 6:
+        if len(ba) != len(bb) or ma != mb:
+            print(f"=== channel {c}: {len(ba)} vs {len(bb)} bursts, messages {'==' if ma == mb else '!='}")
+            print("  strict:", [(int(r['kind']), int(r['sample_counter']), r['bytes'][:min(int(r['len']), 12)].tobytes()) for r in sa_])
+            print("  tp    :", [(int(r['kind']), int(r['sample_counter']), r['bytes'][:min(int(r['len']), 12)].tobytes()) for r in sb_])
+        if (ma != mb or list(la["kind"]) != list(lb["kind"])) and shown < 3:
             shown += 1
             print(f"--- channel {c}: bursts {'==' if ba == bb else '!='}, messages {'==' if ma == mb else '!='}")
             print("  strict:", [(int(r['kind']), int(r['sample_counter'])) for r in sa_][:40])
             print("  tp    :", [(int(r['kind']), int(r['sample_counter'])) for r in sb_][:40])
+    # what differs inside bursts: only bytes after the transmitted payload (decoded from the silence that
+    # follows the carrier), or payload bytes too?
+    tail_only = payload_bad = count_bad = 0
+    for c in range(C):
+        la, lb = a[c][a[c]["kind"] == 3], b[c][b[c]["kind"] == 3]
+        if len(la) != len(lb):
+            count_bad += 1
+            continue
+        pay = sa.synth_payload(20260000, c)
+        for ra, rb in zip(la, lb):
+            xa, xb = ra["bytes"][: int(ra["len"])].tobytes(), rb["bytes"][: int(rb["len"])].tobytes()
+            if xa == xb:
+                continue
+            n = len(pay) if xa.startswith(pay[:4]) else 4      # header burst or NNNN burst
+            if xa[:n] == xb[:n]:
+                tail_only += 1
+            else:
+                payload_bad += 1
+                if payload_bad <= 5:
+                    print(f"   payload differs, channel {c} @ {int(ra['sample_counter'])}/{int(rb['sample_counter'])}: {xa!r} vs {xb!r}")
+    print(f"burst differences: {tail_only} only after the payload, {payload_bad} inside it, {count_bad} channels with a different number of bursts")
     print(f"channels {C}: burst lists differ on {n_burst_bad}, message lists on {n_msg_bad}, link kind sequences on {n_seq_bad}")
     for k, name in ((1, "searching"), (2, "reading"), (3, "burst"), (0, "no_carrier")):
         d = np.array(dt[k])
