@@ -549,7 +549,8 @@ int harvest_slot(same_batch *rx, same_batch::Slot &sl)
     uint32_t n_threads = 1;
     if (n_real >= 16384u && n_ch >= 64u) {
         const unsigned hw = std::thread::hardware_concurrency();
-        n_threads = std::min<uint32_t>({16u, hw ? hw : 1u, n_ch / 32u});
+        // up to 32 replay threads, at most an eighth of the host's hardware threads (eight ranks share a node)
+        n_threads = std::min<uint32_t>({32u, std::max(16u, hw / 8u), hw ? hw : 1u, n_ch / 32u});
         if (rx->host_threads > 0) n_threads = (uint32_t)rx->host_threads;
     }
     if (rx->parts.size() < n_threads) rx->parts.resize(n_threads);
