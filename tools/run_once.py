@@ -12,7 +12,8 @@ rate = int(sys.argv[4]) if len(sys.argv) > 4 else 22050
 T = int(rate * secs)
 x = sa.synth_afsk(C, T, rate, seed=1, noise_sigma=float(os.environ.get('SAME_NOISE', '0')))
 torch.cuda.synchronize()
-rx = sa.SameReceiverBuilder(rate).build_batch(C, link_only=not os.environ.get('SAME_TRANSPORT'))
+rx = sa.SameReceiverBuilder(rate).build_batch(C, link_only=not os.environ.get('SAME_TRANSPORT'),
+                                             time_parallel=bool(os.environ.get('SAME_TP')))
 rx.set_kernel_timing(True)
 for r in range(reps):
     t0 = time.perf_counter()
@@ -20,6 +21,8 @@ for r in range(reps):
     rx.sync()
     dt = time.perf_counter() - t0
     ms = rx.last_kernel_ms()
+    if r + 1 < reps and os.environ.get('SAME_TP'):
+        rx.drop_events(len(rx.peek_events_np())); rx.reset()
     n = rx._L.same_batch_pending_events(rx._h)
     print(f"rep {r}: kernel {ms:.3f} ms  wall {dt*1e3:.3f} ms  {C*T/ms/1e3:.1f} Msamples/s (kernel)  "
           f"{4*C*T/ms/1e6:.2f} GB/s  events pending {n}  [{rx.kernel_name()}]", flush=True)
