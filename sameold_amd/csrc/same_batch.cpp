@@ -650,7 +650,9 @@ uint32_t plan_chunks(same_batch *rx, size_t n, same::ChunkGeom &geom, same::Pipe
     same::Params Pv = rx->P;
     Pv.ticks = 0; Pv.trace_cap = 0;
     const double sps = (double)rx->P.input_rate / 520.83;
-    const uint32_t k_cap = 32768u / C;
+    // state columns the pipeline takes at full speed: 32 768 at 22.05 kHz (two workgroups per CU), 16 384 at
+    // 44.1 / 48 kHz (their window ring leaves room for one)
+    const uint32_t k_cap = (rx->P.ntaps == 42u ? 32768u : 16384u) / C;
     uint32_t k_max = tp.max_chunks ? std::min(tp.max_chunks, k_cap) : k_cap;
     for (uint32_t K = k_max; K >= 2u; --K) {
         Pv.n_channels = K * C;

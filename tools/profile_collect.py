@@ -1,18 +1,18 @@
 #!/usr/bin/env python3
 """Turn gpurun_out/prof (written by tools/profile_round.sh on the GPU box) into the files under profiles/:
-bench line, rocprofv3 kernel/domain stats, per-launch durations of the demod kernel, the two PMC
-passes restricted to the demod kernel, and r01_traffic.json (what bench.py reports as roofline.traffic).
+bench line, rocprofv3 kernel/domain stats, per-launch durations of every demod kernel variant the bench
+runs, the PMC passes restricted to them, and rNN_traffic.json (what bench.py reports as roofline.traffic).
 
-    python tools/profile_collect.py [round-prefix, default r01]
+    python tools/profile_collect.py [round-prefix, default r02]
 
-FETCH_SIZE correction: 1.0 for the 16-channel workgroup shape, 2.0 for 64 channels per wavefront
-(profiles/r01_fetch_calibration.txt); picked from the kernel's template arguments."""
-import csv, glob, json, os, re, shutil, sys
+FETCH_SIZE correction: 1.0 for the 16-channel workgroup shape (64-byte rows per wavefront load), 2.0 for
+64 channels per wavefront (profiles/r01_fetch_calibration.txt); picked from the kernel's template arguments."""
+import collections, csv, glob, json, os, re, shutil, sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 P = os.path.join(ROOT, "gpurun_out", "prof")
 OUT = os.path.join(ROOT, "profiles")
-R = sys.argv[1] if len(sys.argv) > 1 else "r01"
+R = sys.argv[1] if len(sys.argv) > 1 else "r02"
 
 
 def one(pattern):
@@ -20,47 +20,88 @@ def one(pattern):
     return max(glob.glob(os.path.join(P, pattern)), key=os.path.getmtime)
 
 
-def demod_rows(d):
-    rows = list(csv.reader(open(one(f"{d}/*/*_counter_collection.csv"))))
-    return [rows[0]] + [r for r in rows[1:] if "demod" in r[8]]
+def short(name):
+    return name.split("(")[0].replace("void same::", "")
 
 
+def variant(name):
+    """Which block of the bench line a demod kernel instance belongs to, from its template arguments
+    <NT, NFF, NFB, MED3, SHARE, LANES, SPLIT, SampleT>."""
+    m = re.search(r"demod_pipe_kernel<(\d+), \d+, \d+, \w+, (\w+), (\d+)", name)
+    if not m:
+        return None
+    nt, share, lanes = int(m.group(1)), m.group(2) in ("true", "1"), int(m.group(3))
+    if nt == 92:
+        return "configs2_48k"
+    if lanes == 16:
+        return "strict"
+    return "share64"          # time-parallel configs[1] (8 x 4096 columns) and the 32 768-channel block: told apart by grid size / order
+
+
+bench = json.loads(open(os.path.join(P, "bench.json")).read().strip().splitlines()[-1])
 shutil.copy(os.path.join(P, "bench.json"), os.path.join(OUT, f"{R}_bench_4096ch_10s.json"))
 shutil.copy(one("trace/*/*_kernel_stats.csv"), os.path.join(OUT, f"{R}_rocprofv3_kernel_stats.csv"))
 shutil.copy(one("trace/*/*_domain_stats.csv"), os.path.join(OUT, f"{R}_rocprofv3_domain_stats.csv"))
-per = {}
-for d, name in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
-    rows = demod_rows(d)
-    with open(os.path.join(OUT, f"{R}_pmc_{name}.csv"), "w", newline="") as f:
-        csv.writer(f, quoting=csv.QUOTE_NONNUMERIC).writerows(rows)
-    vals = [float(r[16]) for r in rows[1:]]
-    per[name] = (sum(vals) / len(vals), len(vals), rows[1][8])
-kernel = per["FETCH_SIZE"][2].split("(")[0].replace("void same::", "")
-m = re.search(r"demod_pipe_kernel<\d+, \d+, \d+, \w+, \w+, (\d+)", kernel)
-corr = 1.0 if (m and m.group(1) == "16") else 2.0
-bench = json.loads(open(os.path.join(P, "bench.json")).read().strip().splitlines()[-1])
 C, T = bench["config"]["channels_per_gpu"], bench["config"]["samples_per_channel"]
-traffic = int(round(per["FETCH_SIZE"][0] * 1024 * corr + per["WRITE_SIZE"][0] * 1024))
-json.dump({"workload": f"{C} ch x {T} samples", "hbm_bytes_per_launch": traffic,
-           "fetch_size_kb": round(per["FETCH_SIZE"][0], 1), "write_size_kb": round(per["WRITE_SIZE"][0], 1),
-           "fetch_correction": corr,
-           "source": f"profiles/{R}_pmc_FETCH_SIZE.csv, {R}_pmc_WRITE_SIZE.csv ({per['FETCH_SIZE'][1]} launches each of {kernel}); "
-                     f"FETCH_SIZE counts this kernel's wavefront loads x{corr:g}: r01_fetch_calibration.txt"},
-          open(os.path.join(OUT, f"{R}_traffic.json"), "w"), indent=1)
-d = sorted((int(r["Start_Timestamp"]), (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6)
-           for r in csv.DictReader(open(one("trace/*/*_kernel_trace.csv"))) if "demod_pipe_kernel" in r["Kernel_Name"] or "demod_fast_kernel" in r["Kernel_Name"])
+
+# ---- per-launch durations, in launch order, per block
+rows = [r for r in csv.DictReader(open(one("trace/*/*_kernel_trace.csv"))) if "demod_pipe_kernel" in r["Kernel_Name"] or "demod_fast_kernel" in r["Kernel_Name"]]
+rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+blocks = collections.OrderedDict()
+for r in rows:
+    v = variant(r["Kernel_Name"]) or short(r["Kernel_Name"])
+    grid = int(r.get("Grid_Size_X", r.get("Grid_Size", "0")) or 0)
+    if v == "share64":
+        v = "time_parallel" if not any(k == "scaled" for k in blocks) and grid <= 8 * C // 64 * 256 and len(blocks.get("time_parallel", [])) < bench["steps"] + bench["warmup"] else "scaled"
+    blocks.setdefault(v, []).append(((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6, short(r["Kernel_Name"]), grid))
 log = open(os.path.join(P, "trace_bench.log")).read()
-live = re.search(r'"kernel_ms": ([0-9.]+)', log)
-warm = len(d) - bench["steps"]
 with open(os.path.join(OUT, f"{R}_rocprofv3_kernel_trace_demod.txt"), "w") as o:
-    o.write(f"{kernel} launches of\n`rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --no-cpu-baseline --no-scaled --check 0`\n"
-            f"(tools/profile_round.sh; {warm} warm-up + {bench['steps']} timed; durations in ms, in launch order):\n")
-    o.write(" ".join(f"{x[1]:.3f}" for x in d) + "\n")
-    o.write(f"average of the {bench['steps']} timed launches: {sum(x[1] for x in d[warm:]) / bench['steps']:.3f} ms   "
-            f"(bench.py's HIP-event figure for the same launches, printed by that run: {live.group(1) if live else '?'} ms)\n")
-    o.write(f"average of all {len(d)} (what *_kernel_stats.csv reports): {sum(x[1] for x in d) / len(d):.3f} ms\n")
-    o.write(f"An unprofiled `python bench.py` on the same box reported kernel_ms {bench['roofline']['kernel_ms']} ({R}_bench_4096ch_10s.json).\n")
+    o.write("demodulation kernel launches of\n`rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --no-cpu-baseline --check 0`\n"
+            "(tools/profile_round.sh), durations in ms in launch order, per block of the bench line:\n")
+    for v, lst in blocks.items():
+        n_timed = bench["steps"] if v in ("strict", "time_parallel") else 3
+        d = [x[0] for x in lst]
+        o.write(f"\n[{v}] {lst[0][1]}  grid {lst[0][2]}  ({len(d)} launches)\n  " + " ".join(f"{x:.3f}" for x in d) + "\n")
+        o.write(f"  average of the last {min(n_timed, len(d))} (the timed ones): {sum(d[-n_timed:]) / min(n_timed, len(d)):.3f} ms; of all: {sum(d) / len(d):.3f} ms\n")
+    m = re.findall(r'"kernel_ms": ([0-9.]+)', log)
+    o.write(f"\nbench.py's own HIP-event figures printed by that profiled run (kernel_ms, in the order of the JSON line): {' '.join(m)}\n")
+    o.write(f"An unprofiled `python bench.py` on the same box: {R}_bench_4096ch_10s.json.\n")
+
+# ---- PMC: FETCH_SIZE / WRITE_SIZE per block
+def counters(d):
+    rows = list(csv.DictReader(open(one(f"{d}/*/*_counter_collection.csv"))))
+    return [r for r in rows if "demod" in r["Kernel_Name"]]
+
+traffic = []
+per = collections.defaultdict(dict)
+for d, name in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
+    rows = counters(d)
+    with open(os.path.join(OUT, f"{R}_pmc_{name}.csv"), "w", newline="") as f:
+        w = csv.DictWriter(f, fieldnames=list(rows[0].keys()))
+        w.writeheader(); w.writerows(rows)
+    seen = collections.defaultdict(list)
+    order = []
+    for r in sorted(rows, key=lambda r: int(r["Dispatch_Id"])):
+        v = variant(r["Kernel_Name"]) or short(r["Kernel_Name"])
+        if v == "share64":
+            v = "time_parallel" if len(seen["time_parallel"]) < 3 else "scaled"      # --steps 2 --warmup 1 per block
+        seen[v].append(float(r["Counter_Value"]))
+    for v, vals in seen.items():
+        per[v][name] = (sum(vals) / len(vals), len(vals))
+sizes = {"strict": (C, T), "time_parallel": (C, T), "scaled": (32768, 44100), "configs2_48k": (16384, 96000)}
+for v, d in per.items():
+    if "FETCH_SIZE" not in d or "WRITE_SIZE" not in d or v not in sizes:
+        continue
+    corr = 1.0 if v == "strict" else 2.0
+    cc, tt = sizes[v]
+    hbm = int(round(d["FETCH_SIZE"][0] * 1024 * corr + d["WRITE_SIZE"][0] * 1024))
+    traffic.append({"mode": v if v in ("strict", "time_parallel") else "strict", "block": v, "workload": f"{cc} ch x {tt} samples",
+                    "hbm_bytes_per_launch": hbm, "algorithmic_bytes_per_launch": 4 * cc * tt, "ratio": round(hbm / (4.0 * cc * tt), 4),
+                    "fetch_size_kb": round(d["FETCH_SIZE"][0], 1), "write_size_kb": round(d["WRITE_SIZE"][0], 1), "fetch_correction": corr,
+                    "launches": d["FETCH_SIZE"][1],
+                    "source": f"profiles/{R}_pmc_FETCH_SIZE.csv, {R}_pmc_WRITE_SIZE.csv; FETCH_SIZE counts this kernel shape's wavefront loads x{corr:g}: r01_fetch_calibration.txt"})
+json.dump(traffic, open(os.path.join(OUT, f"{R}_traffic.json"), "w"), indent=1)
+shutil.copy(os.path.join(P, "pmc_summary.txt"), os.path.join(OUT, f"{R}_pmc_summary.txt"))
 print(open(os.path.join(OUT, f"{R}_rocprofv3_kernel_trace_demod.txt")).read())
-print(json.dumps(json.load(open(os.path.join(OUT, f"{R}_traffic.json"))), indent=1))
-print("algorithmic", 4 * C * T, "ratio", traffic / (4.0 * C * T))
-print("bench value", bench["value"], "ms_per_step", bench["ms_per_step"], "frac", bench["roofline"]["frac"])
+print(json.dumps(traffic, indent=1))
+print("bench value", bench["value"], "ms_per_step", bench["ms_per_step"], "frac", bench["roofline"]["frac"], "mode", bench["config"].get("mode"))
