@@ -689,6 +689,69 @@ __device__ __forceinline__ bool ted_timing(const Params &P, Lane &L, float sa_lo
     return have;
 }
 
+// ted_timing in two halves, for a stage that waits for the instant's soft sample (the matched filters run on
+// other wavefronts).  Of the new sample the timing loop uses one bit: terr = h1 * (signum(h0) - signum(h2))
+// (rx/symsync.rs:311-322) with h2 the new sample, and on the instants that complete no symbol not even that
+// (period_inst += offset, rx/symsync.rs:236-241).  ted_ahead evaluates everything ted_timing would for both
+// signs of the sample that is still on its way -- the same operations on the same operands in the same
+// order, so whichever half is committed is bit-identical to ted_timing's result -- including the sample
+// count of the next instant (next_fire_count); ted_commit, once the sample is there, selects by its sign bit.
+struct TedAhead {
+    float zero;              // h1 after the shift: the symbol estimate's first sample (and the TED's middle tap)
+    float terr[2];           // [0]: the new sample is >= +0.0, [1]: it carries a sign bit
+    float avg[2], inst[2];   // period_avg / period_inst after the instant
+    int cstar[2];            // next_fire_count(period_inst, 0)
+    uint32_t flags;          // with the TED phase toggled
+    bool have;
+};
+__device__ __forceinline__ int next_fire_count(float s, uint32_t clock);   // same_fast_common.h
+__device__ __forceinline__ TedAhead ted_ahead(const Params &P, const Lane &L, float rem)
+{
+    TedAhead A;
+    const float h0 = L.h1, h1 = L.h2;                       // ZeroCrossingTed::input rx/symsync.rs:278-287
+    A.zero = h1;
+    A.flags = L.flags ^ F_TED_PHASE;
+    A.have = (A.flags & F_TED_PHASE) != 0;
+    const float offset = rs_clamp(rem, -0.5f, 0.5f);        // TimingLoop::advance_loop rx/symsync.rs:219-244
+    const float q = offset / P.samples_per_ted;
+    const bool bw_locked = (L.flags & F_BW_LOCKED) != 0;
+    const float alpha = bw_locked ? P.alpha_locked : P.alpha_unlocked;
+    const float beta = bw_locked ? P.beta_locked : P.beta_unlocked;
+    const float inst0 = L.period_inst + offset;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const float sg2 = k ? -1.0f : 1.0f;                 // rs_signum(h2)
+        const float dsg = rs_signum(h0) - sg2;
+        const float terr = h1 * dsg;
+        const float e0 = terr - q;
+        const float e = rs_clamp(e0, -1.0f, 1.0f);
+        const float bi = beta * e;
+        const float avg1 = rs_clamp(L.period_avg + bi, P.period_min, P.period_max);
+        const float ai = alpha * e;
+        const float t = avg1 + ai;
+        float inst1 = t + offset;
+        inst1 = (inst1 < 0.0f) ? avg1 : inst1;
+        A.terr[k] = terr;
+        A.avg[k] = A.have ? avg1 : L.period_avg;
+        A.inst[k] = A.have ? inst1 : inst0;
+        A.cstar[k] = next_fire_count(A.inst[k], 0u);
+    }
+    return A;
+}
+__device__ __forceinline__ bool ted_commit(Lane &L, const TedAhead &A, float sa_low, float *zero_out, float *sym_out,
+                                           float *terr_out, int *cstar_out)
+{
+    const int k = (int)(__float_as_uint(sa_low) >> 31);     // the sign bit, as rs_signum reads it
+    L.h0 = L.h1; L.h1 = L.h2; L.h2 = sa_low;
+    L.flags = A.flags;
+    L.period_avg = A.avg[k];
+    L.period_inst = A.inst[k];
+    L.until_next_ted = L.period_inst;                       // receiver.rs:382
+    *zero_out = A.zero; *sym_out = sa_low; *terr_out = A.terr[k];
+    *cstar_out = A.cstar[k];
+    return A.have;
+}
+
 // The symbol half, in two parts so that a pipelined kernel can run them on different wavefronts.
 // symbol_link: trace and link layer (squelch, equalizer, framer); returns the LinkState kind and
 // whether an event is due (receiver.rs:246-253: report on change; a Burst always differs from its

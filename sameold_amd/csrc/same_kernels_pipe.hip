@@ -123,7 +123,7 @@ constexpr uint32_t kP3FbWords = kWave + 32u;              // per parity: one wor
 constexpr uint32_t kP3IoWords = 3u * kWave;               // per parity: symbol word, burst-pool slot, burst length
 constexpr uint32_t kP3MailWords = 2u * kP3SymWords + 2u * kP3FbWords + 2u * kP3IoWords +
                                   2u * kWave +             // + the final TED-phase and wake-up flag bits
-                                  3u * kWave;              // + SPLIT: instant positions [2][64], space magnitudes [64]
+                                  4u * kWave;              // + SPLIT: instant positions [2][64], space and mark magnitudes [64] each
 // (the log-chunk words and SPLIT's sequence word live in the padding of the first feedback box)
 
 // One of the two matched filters (WHICH 0: mark, 1: space) over the mirrored window: the half of
@@ -136,6 +136,45 @@ __device__ __forceinline__ float demod_half(const float4 *tlds, const float *wri
     float2v acc = {0.0f, 0.0f};
     const float *wm = wring + ((int)newest + RING - (CH - 1)) * (int)kWave + (int)lane;
     const float2v *t2 = reinterpret_cast<const float2v *>(tlds) + WHICH;      // tap i: t2[2 * i]
+#pragma unroll 1
+    for (int base = 0; base + CH <= NT; base += CH) {
+        float w[CH];
+        float2v h[CH];
+#pragma unroll
+        for (int j = 0; j < CH; ++j) w[j] = wm[(CH - 1 - j) * (int)kWave];
+        wm -= CH * (int)kWave;
+#pragma unroll
+        for (int j = 0; j < CH; ++j) h[j] = t2[2 * (base + j)];
+#pragma unroll
+        for (int j = 0; j < CH; ++j) { const float2v x2 = {w[j], w[j]}; const float2v pr = x2 * h[j]; acc += pr; }
+    }
+    constexpr int REM = NT % CH;
+    if (REM) {
+        float w[REM ? REM : 1];
+#pragma unroll
+        for (int j = 0; j < REM; ++j) w[j] = wm[(CH - 1 - j) * (int)kWave];
+#pragma unroll
+        for (int j = 0; j < REM; ++j) {
+            const float2v t = t2[2 * (NT - REM + j)];
+            const float2v x2 = {w[j], w[j]};
+            const float2v pr = x2 * t;
+            acc += pr;
+        }
+    }
+    return rs_hypot(acc.x, acc.y);
+}
+
+// The same with the filter chosen per lane (which 0: mark, 1: space): narrow workgroups (16 or 32 channels)
+// leave half of the helper wavefront's lanes idle, so lanes 0 .. LANES-1 take the mark filter of channel
+// `ch` and lanes LANES .. 2*LANES-1 its space filter -- both filters in the time of one.  The taps are then
+// read with two addresses per wavefront instead of one (still conflict-free: adjacent 8-byte words).
+template <int NT, int RING>
+__device__ __forceinline__ float demod_half_dyn(const float4 *tlds, const float *wring, uint32_t ch, uint32_t newest, uint32_t which)
+{
+    constexpr int CH = 14;
+    float2v acc = {0.0f, 0.0f};
+    const float *wm = wring + ((int)newest + RING - (CH - 1)) * (int)kWave + (int)ch;
+    const float2v *t2 = reinterpret_cast<const float2v *>(tlds) + which;      // tap i: t2[2 * i]
 #pragma unroll 1
     for (int base = 0; base + CH <= NT; base += CH) {
         float w[CH];
@@ -446,6 +485,9 @@ __global__ __launch_bounds__(4 * kWave, SHARE ? 2 : 1) void demod_pipe_kernel(Pa
 {
     constexpr int kB = PipeLayout<NT>::B, RING = PipeLayout<NT>::RING;
     constexpr uint32_t LP = kWave, kPipeTapFloats = PipeLayout<NT>::tap_floats;
+    // PACKED: workgroups of 16 or 32 channels -- the helper wavefront computes BOTH matched filters (mark on its
+    // lanes 0 .. LANES-1, space on LANES .. 2*LANES-1) and stage 2 keeps only the timing loop
+    constexpr bool PACKED = SPLIT && LANES <= 32;
     static_assert(kB <= 64, "the sample index travels in six bits of the stage 3 -> 4 word");
     extern __shared__ float lds[];
     const uint32_t lane = threadIdx.x & (kWave - 1u);
@@ -480,6 +522,7 @@ __global__ __launch_bounds__(4 * kWave, SHARE ? 2 : 1) void demod_pipe_kernel(Pa
     lds_u32 *seqbox = fbbox + kWave + 4u;                      // SPLIT: stage 4's progress with the space filter, 2 * step + pass
     lds_u32 *posbox = againbox + kWave;                        // SPLIT: [2][64] sample index of block b's instant
     lds_u32 *spacebox = posbox + 2u * kWave;                   // SPLIT: [64] space-filter magnitude
+    lds_u32 *markbox = spacebox + kWave;                       // PACKED: [64] mark-filter magnitude
     float *hcol = lds + kPipeTapFloats + kP3MailWords + lane;
     float *wring = lds + kPipeTapFloats + kP3MailWords + (kSquelchHist - kB) * LP;   // logical slot 0
     float *wcol = wring + lane;
@@ -558,9 +601,14 @@ __global__ __launch_bounds__(4 * kWave, SHARE ? 2 : 1) void demod_pipe_kernel(Pa
             if (until < kB) {
                 const int fk = until;
                 float sa_low;
+                const float rem = L.until_next_ted - (float)cstar;          // receiver.rs:352
                 if constexpr (SPLIT) {
-                    const float hm = demod_half<NT, RING, 0>(tlds, wring, lane, wpos + (uint32_t)fk);
+                    float hm = 0.0f;
+                    if constexpr (!PACKED) hm = demod_half<NT, RING, 0>(tlds, wring, lane, wpos + (uint32_t)fk);
                     S2_LAP(0);
+                    // while the helper wavefront is still filtering: the timing loop for both signs of the soft
+                    // sample it will deliver (same_dev_common.h: ted_ahead / ted_commit)
+                    const TedAhead A = ted_ahead(P, L, rem);
 #ifdef SAME_PROFILE
                     const unsigned long long spin_t0 = clock64();
 #endif
@@ -569,15 +617,18 @@ __global__ __launch_bounds__(4 * kWave, SHARE ? 2 : 1) void demod_pipe_kernel(Pa
                     if (blockIdx.x == 0 && lane == (uint32_t)__builtin_amdgcn_readfirstlane((int)lane))
                         g_same_prof_hw[5] += clock64() - spin_t0;
 #endif
+                    if constexpr (PACKED) hm = __uint_as_float(markbox[lane]);
                     const float hs = __uint_as_float(spacebox[lane]);
                     S2_LAP(1);
                     sa_low = rs_clamp(hm - hs, -1.0f, 1.0f);
+                    int cs;
+                    if (ted_commit(L, A, sa_low, &zero, &sym, &terr, &cs)) { hdr = 1u | ((uint32_t)fk << 8); next = L.until_next_ted; }
+                    cstar = cs;
                 } else {
                     sa_low = demod_fast<NT, RING, true>(tlds, wring, lane, wpos + (uint32_t)fk);
+                    if (ted_timing(P, L, sa_low, rem, &zero, &sym, &terr)) { hdr = 1u | ((uint32_t)fk << 8); next = L.until_next_ted; }
+                    cstar = next_fire_count(L.until_next_ted, 0u);
                 }
-                const float rem = L.until_next_ted - (float)cstar;          // receiver.rs:352
-                if (ted_timing(P, L, sa_low, rem, &zero, &sym, &terr)) { hdr = 1u | ((uint32_t)fk << 8); next = L.until_next_ted; }
-                cstar = next_fire_count(L.until_next_ted, 0u);
                 until = fk + cstar;
                 if (until < kB) {
                     // A second instant in the same block (20-sample blocks at 22.05 kHz, the loop at its
@@ -778,9 +829,14 @@ __global__ __launch_bounds__(4 * kWave, SHARE ? 2 : 1) void demod_pipe_kernel(Pa
         for (int i = 0; i < kSquelchHist; ++i) { float *row = S.sq_hist + (size_t)i * C; row[c] = hcol[i * LP]; }
     } else {
         // ------------------------------ stage 4: link events + wake-ups, block s-3 -------------
-        if (LANES < (int)kWave && lane >= (uint32_t)LANES) return;
+        // PACKED: lanes LANES .. 2*LANES-1 stay for the filter half of every step (the space filter of channel
+        // lane - LANES, while lanes 0 .. LANES-1 compute the mark filter) and sit the event half out.
+        const bool evt_lane = lane < (uint32_t)LANES;
+        if (LANES < (int)kWave && lane >= (uint32_t)(PACKED ? 2 * LANES : LANES)) return;
+        const uint32_t fch = PACKED ? (lane & (uint32_t)(LANES - 1)) : lane;      // the channel this lane filters for
+        const uint32_t which = PACKED ? (lane >= (uint32_t)LANES ? 1u : 0u) : 1u;   // 0 mark, 1 space
         Lane L;
-        lane_load(L, S, c);                    // uses sq_symbols, tk_next, tk_last, wake_*, F_TICK_AGAIN
+        if (evt_lane) lane_load(L, S, c);      // uses sq_symbols, tk_next, tk_last, wake_*, F_TICK_AGAIN
         P3_HWID(3);
         IoCtx X;
         X.chunk = chunkbox;
@@ -790,23 +846,30 @@ __global__ __launch_bounds__(4 * kWave, SHARE ? 2 : 1) void demod_pipe_kernel(Pa
         if (SPLIT && lane == 0u) seqbox[0] = 0u;
         uint32_t stop_at = 0xffffffffu;
         bool left = false;
+        auto filter = [&](uint32_t pos) {
+            if constexpr (PACKED) {
+                const float mag = demod_half_dyn<NT, RING>(tlds, wring, fch, wpos + pos, which);
+                (which ? spacebox : markbox)[fch] = __float_as_uint(mag);
+            } else {
+                spacebox[lane] = __float_as_uint(demod_half<NT, RING, 1>(tlds, wring, lane, wpos + pos));
+            }
+        };
         for (uint32_t s = 0; s < n_steps; ++s) {
-            // SPLIT: first the space filter of block s-1 for stage 2, which waits for it
+            // SPLIT: first the matched filter(s) of block s-1 for stage 2, which waits for them
             const bool active = SPLIT && s >= 1u && s <= n_blocks;
             uint32_t pos = 0xffffffffu;
 #ifdef SAME_PROFILE
             const unsigned long long help_t0 = clock64();
 #endif
             if (active) {
-                pos = posbox[((s - 1u) & 1u) * kWave + lane];              // posted by stage 2 during the last step
-                if (pos < (uint32_t)kB)
-                    spacebox[lane] = __float_as_uint(demod_half<NT, RING, 1>(tlds, wring, lane, wpos + pos));
+                pos = posbox[((s - 1u) & 1u) * kWave + fch];               // posted by stage 2 during the last step
+                if (pos < (uint32_t)kB) filter(pos);
                 if (lane == 0u) seqbox[0] = 2u * s + 1u;                    // (LDS operations of a wavefront stay in order)
             }
 #ifdef SAME_PROFILE
             if (SPLIT && blockIdx.x == 0 && lane == 0) g_same_prof_hw[6] += clock64() - help_t0;
 #endif
-            if (s >= 3u) {
+            if (s >= 3u && evt_lane) {
                 const uint32_t blk = s - 3u;
                 const lds_u32 *io = iobox + ((s - 1u) & 1u) * kP3IoWords + lane;   // what stage 3 posted last step
                 const uint32_t io0 = io[0];
@@ -825,11 +888,10 @@ __global__ __launch_bounds__(4 * kWave, SHARE ? 2 : 1) void demod_pipe_kernel(Pa
                 const uint32_t fbw = (uint32_t)__builtin_amdgcn_readfirstlane((int)fb[kWave]);
                 if (fbw & 2u) stop_at = s + 1u;
                 if (fbw & 1u) {
-                    const uint32_t v = SPLIT ? fb[lane] : 0u;
+                    const uint32_t v = SPLIT ? fb[fch] : 0u;
                     lds_barrier();                                     // B: stage 1 has corrected the window
                     if (SPLIT) {
-                        if ((v & 1u) && active && pos < (uint32_t)kB)
-                            spacebox[lane] = __float_as_uint(demod_half<NT, RING, 1>(tlds, wring, lane, wpos + pos));
+                        if ((v & 1u) && active && pos < (uint32_t)kB) filter(pos);
                         if (lane == 0u) seqbox[0] = 2u * s + 2u;
                     }
                     lds_barrier();                                     // C
@@ -838,11 +900,11 @@ __global__ __launch_bounds__(4 * kWave, SHARE ? 2 : 1) void demod_pipe_kernel(Pa
             if (active) { wpos += kB; if (wpos == (uint32_t)RING) wpos = 0; }
             if (s == stop_at) { left = true; break; }
         }
-        X.retire(O, lane, (uint32_t)LANES);
+        if (evt_lane) X.retire(O, lane, (uint32_t)LANES);
         if (left) return;
-        againbox[lane] = L.flags & F_TICK_AGAIN;
+        if (evt_lane) againbox[lane] = L.flags & F_TICK_AGAIN;
         lds_barrier();                                                 // stage 3 merges the flag bits
-        S.tk_next[c] = L.tk_next; S.tk_last[c] = L.tk_last; S.wake_fired[c] = L.wake_fired;
+        if (evt_lane) { S.tk_next[c] = L.tk_next; S.tk_last[c] = L.tk_last; S.wake_fired[c] = L.wake_fired; }
     }
 }
 
