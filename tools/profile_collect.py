@@ -59,7 +59,7 @@ with open(os.path.join(OUT, f"{R}_rocprofv3_kernel_trace_demod.txt"), "w") as o:
     o.write("demodulation kernel launches of\n`rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --no-cpu-baseline --check 0`\n"
             "(tools/profile_round.sh), durations in ms in launch order, per block of the bench line:\n")
     for v, lst in blocks.items():
-        n_timed = bench["steps"] if v in ("strict", "time_parallel") else 3
+        n_timed = bench["steps"] if v in ("strict", "time_parallel") else max(bench["steps"], 10)
         d = [x[0] for x in lst]
         o.write(f"\n[{v}] {lst[0][1]}  grid {lst[0][2]}  ({len(d)} launches)\n  " + " ".join(f"{x:.3f}" for x in d) + "\n")
         o.write(f"  average of the last {min(n_timed, len(d))} (the timed ones): {sum(d[-n_timed:]) / min(n_timed, len(d)):.3f} ms; of all: {sum(d) / len(d):.3f} ms\n")
@@ -84,7 +84,7 @@ for d, name in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
     for r in sorted(rows, key=lambda r: int(r["Dispatch_Id"])):
         v = variant(r["Kernel_Name"]) or short(r["Kernel_Name"])
         if v == "share64":
-            v = "time_parallel" if len(seen["time_parallel"]) < 3 else "scaled"      # --steps 2 --warmup 1 per block
+            v = "time_parallel" if len(seen["time_parallel"]) < 3 else "scaled"      # --steps 2 --warmup 1: three configs[1] launches, then the 32 768-channel block
         seen[v].append(float(r["Counter_Value"]))
     for v, vals in seen.items():
         per[v][name] = (sum(vals) / len(vals), len(vals))
