@@ -105,4 +105,58 @@ private:
     uint64_t last_polled_symbol_ = 0;
 };
 
+
+// Time-parallel mode: the transport layer's poll instants, synthesised on the host.  The reference polls
+// its assembler on every symbol whose link state is NoCarrier or Burst (receiver.rs:292-315); the answer
+// can only change at a burst, at the first poll on or after a deadline a burst armed (burst + 682
+// symbols, burst + 5 652 symbols: rx/assembler.rs:85, 92-93, 294-299), after the forced-EOM instant
+// (receiver.rs:300-309), or at the poll following one of those.  In strict mode the device reports
+// exactly those instants (SAME_DEV_TICK); chunks that start from a fresh receiver cannot know the
+// deadlines earlier chunks armed, so here the host keeps them per channel, on the (rebased) symbol
+// clock of the stitched event stream, and interpolates the sample counter of a poll from the last event.
+struct TickSynth {
+    uint32_t link = 0;                 // LinkState kind after the last event
+    uint64_t a_sym = 0, a_t = 0;       // last event: symbol count (rebased) and input sample counter
+    uint64_t dl[12];                   // pending symbol deadlines, ascending
+    uint32_t n = 0;
+    bool again = false;                // a deadline passed while the link was busy: poll once more after the next idle event
+    void reset() { link = 0; a_sym = 0; a_t = 0; n = 0; again = false; }
+    void add(uint64_t d)
+    {
+        if (n == 12) { for (uint32_t i = 1; i < n; ++i) dl[i - 1] = dl[i]; --n; }
+        uint32_t i = n++;
+        while (i > 0 && dl[i - 1] > d) { dl[i] = dl[i - 1]; --i; }
+        dl[i] = d;
+    }
+    // polls for every deadline before symbol `sym_limit` (an event at sym_limit polls by itself)
+    template <typename Poll> void run_until(uint64_t sym_limit, uint64_t t_limit, double sps, uint64_t force_eom_at, Poll &&poll)
+    {
+        auto at = [&](uint64_t sym) {
+            const uint64_t t = a_t + (uint64_t)((double)(sym - a_sym) * sps);
+            return t < t_limit ? t : (t_limit ? t_limit - 1 : 0);
+        };
+        if (force_eom_at && link == 0 && a_t <= force_eom_at && force_eom_at + 1 < t_limit) {
+            const uint64_t sym = a_sym + (uint64_t)((double)(force_eom_at + 1 - a_t) / sps) + 1u;
+            if (sym < sym_limit) add(sym);
+        }
+        while (n && dl[0] < sym_limit) {
+            uint64_t d = dl[0];
+            for (uint32_t i = 1; i < n; ++i) dl[i - 1] = dl[i];
+            --n;
+            if (link != 0) { again = true; continue; }       // busy: the next NoCarrier / Burst event is that poll
+            if (d <= a_sym) d = a_sym + 1u;
+            if (d >= sym_limit) { again = true; continue; }
+            poll(d, at(d));
+            if (d + 1u < sym_limit && !(n && dl[0] == d + 1u)) poll(d + 1u, at(d + 1u));
+        }
+    }
+    void after_event(uint32_t kind, uint64_t sym, uint64_t t, uint64_t interburst, uint64_t history)
+    {
+        link = kind; a_sym = sym; a_t = t;
+        if (kind == SAME_LINK_BURST) { add(sym + interburst); add(sym + history); again = true; }
+        else if (kind == SAME_LINK_NO_CARRIER && again) { add(sym + 1u); again = false; }
+    }
+};
+
+
 }  // namespace same

@@ -92,12 +92,35 @@ int main(int argc, char **argv)
         if (!f) { std::perror(argv[1]); return 2; }
         same::Transport tr;
         tr.reset();
+        // argv[2] == "synth": the time-parallel mode's way -- only link events come from the device, the poll
+        // instants of the transport layer are synthesised on the host (same::TickSynth), exactly as
+        // same_batch.cpp's harvest does; argv[3] = sample counter at the end of the input
+        const bool synth = argc > 2 && std::strcmp(argv[2], "synth") == 0;
+        same::TickSynth ts;
+        ts.reset();
+        const double sps = 22050.0 / 520.83;
+        auto print = [](const same_rx_event &ev) {
+            std::printf("%u %" PRIu64 " %u ", ev.kind, ev.sample_counter, ev.len);
+            std::fwrite(ev.bytes, 1, ev.len < SAME_EVENT_MAX_BYTES ? ev.len : SAME_EVENT_MAX_BYTES, stdout);
+            std::printf("\n");
+        };
+        auto poll = [&](uint64_t psym, uint64_t pt) {
+            same_rx_event tev;
+            if (tr.on_link_event(same::kDevTick, pt, psym, nullptr, 0, 22050, &tev)) print(tev);
+        };
         char hex[1024];
         unsigned kind; unsigned long long sc, sym;
         while (std::fscanf(f, "%u %llu %llu %1023s", &kind, &sc, &sym, hex) == 4) {
             std::vector<uint8_t> bytes;
             if (hex[0] != '-') for (size_t i = 0; hex[i] && hex[i + 1]; i += 2) bytes.push_back((uint8_t)(hexval(hex[i]) * 16 + hexval(hex[i + 1])));
             same_rx_event ev;
+            if (synth) {
+                if (kind >= 8) continue;                      // no device ticks in this mode
+                ts.run_until(sym, sc, sps, tr.force_eom_at(), poll);
+                if (tr.on_link_event(kind, sc, sym, bytes.data(), (uint32_t)bytes.size(), 22050, &ev)) print(ev);
+                ts.after_event(kind, sym, sc, same::max_interburst_symbols(), same::max_history_duration());
+                continue;
+            }
             if (tr.on_link_event(kind, sc, sym, bytes.data(), (uint32_t)bytes.size(), 22050, &ev)) {
                 std::printf("%u %" PRIu64 " %u ", ev.kind, ev.sample_counter, ev.len);
                 std::fwrite(ev.bytes, 1, ev.len < SAME_EVENT_MAX_BYTES ? ev.len : SAME_EVENT_MAX_BYTES, stdout);
@@ -106,6 +129,13 @@ int main(int argc, char **argv)
             (void)tr.force_eom_at(); (void)tr.force_eom_dirty();
         }
         std::fclose(f);
+        if (synth && argc > 3) {
+            const uint64_t t_end = std::strtoull(argv[3], nullptr, 10);
+            if (ts.link == SAME_LINK_NO_CARRIER && t_end > ts.a_t) {
+                const uint64_t sym_end = ts.a_sym + (uint64_t)((double)(t_end - ts.a_t) / sps);
+                ts.run_until(sym_end + 1u, t_end + 1u, sps, tr.force_eom_at(), poll);
+            }
+        }
     }
     if (fails) return 1;
     std::printf("OK\n");

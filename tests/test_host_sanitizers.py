@@ -35,9 +35,9 @@ def driver(tmp_path_factory):
     return out
 
 
-def run(driver, path=None):
+def run(driver, path=None, *more):
     env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1")
-    r = subprocess.run([driver] + ([path] if path else []), capture_output=True, env=env, timeout=120)
+    r = subprocess.run([driver] + ([path] if path else []) + list(more), capture_output=True, env=env, timeout=120)
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
     assert b"runtime error" not in r.stderr and b"AddressSanitizer" not in r.stderr, r.stderr[-4000:]
     lines = r.stdout.split(b"\n")
@@ -70,3 +70,28 @@ def test_transport_replay_under_sanitizers(driver, tmp_path, name):
     # (long_message's header is only delivered by the end-of-file flush, past these events)
     headers = [t for t in gold["lines"] if t.startswith("ZCZC")]
     assert len(texts) == sum(1 for k, _ in want if k == 18) and all(t in headers for t in texts)
+
+
+@pytest.mark.parametrize("name", ["npt", "two_and_two", "long_message"])
+def test_synthesised_transport_polls_reproduce_the_golden_transport_events(driver, tmp_path, name):
+    """Time-parallel mode keeps the transport layer's poll instants on the host (same::TickSynth) instead of
+    taking them from the device.  Fed the golden LINK events only, it must reproduce the golden TRANSPORT
+    events of the reference's recordings: same kinds and header texts in the same order, sample counters
+    within 6 symbols (the synthesised polls are interpolated from the last link event at the nominal
+    symbol rate; the reference's free-running timing loop drifts by up to ~0.5 % between bursts, 3.3 symbols
+    over the 682-symbol message hold of the npt recording)."""
+    with open(os.path.join(GOLDEN, "link_events.json")) as f:
+        gold = json.load(f)[name]
+    feed = [f"{k} {t} {sym} {hx or '-'}" for k, t, sym, hx in gold["events"] if k < 16]
+    want = [(k, t, bytes.fromhex(hx).decode() if hx else "") for k, t, sym, hx in gold["events"] if k >= 16]
+    p = tmp_path / "events.txt"
+    p.write_text("\n".join(feed) + "\n")
+    t_end = max(t for _, t, _, _ in gold["events"]) + 2000
+    out = run(driver, str(p), "synth", str(t_end))
+    got = []
+    for ln in out:
+        kind, t, n, text = ln.split(b" ", 3)
+        got.append((int(kind), int(t), text.decode() if int(kind) == 18 else ""))
+    assert [(k, x) for k, _, x in got] == [(k, x) for k, _, x in want]
+    tol = 6 * 22050 / 520.83
+    assert all(abs(a[1] - b[1]) <= tol for a, b in zip(got, want)), [(a[1], b[1]) for a, b in zip(got, want)]
