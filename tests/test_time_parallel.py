@@ -298,3 +298,52 @@ def test_awgn_tally_statistically_equal(sa):
         # binomial: |difference| within 4 sigma of the strict count per grid point
         sig = np.sqrt(np.maximum(ta[k] * (1 - ta[k] / np.maximum(ta["trials"], 1)), 1.0))
         assert np.all(np.abs(ta[k] - tb[k]) <= 4 * sig + 2), (k, ta[k], tb[k])
+
+
+def test_time_parallel_i16_and_channel_major_inputs(sa):
+    """The other two input forms of the boundary run through the same chunked launch: int16 PCM (cast in the
+    kernel) and a channel-major buffer (transposed on the device slab by slab, every slab cut on its own).
+    Integer-valued samples make all three inputs the same signal."""
+    import torch
+    rate, n_ch, n = 22050, 64, 22050 * 8
+    x = torch.round(sa.synth_afsk(n_ch, n, rate, seed=4711)).contiguous()
+    ref = strict_events(sa, x, rate)
+    pay = lambda c: sa.synth_payload(4711, c)
+    for form in ("f32", "i16", "channel_major"):
+        rx = sa.SameReceiverBuilder(rate).build_batch(n_ch, time_parallel=True)
+        rx.time_parallel_config(max_chunks=4, min_own_samples=6000)
+        if form == "f32":
+            rx.process_tensor(x)
+        elif form == "i16":
+            rx.process_tensor(x.to(torch.int16))
+        else:
+            rx.process_tensor(x.t().contiguous(), layout=sa.LAYOUT_CHANNEL_MAJOR)
+        rx.sync()
+        assert rx.time_parallel_chunks() > 1, form
+        got = rx.poll_events_np()
+        got = got[np.lexsort((np.arange(len(got)), got["channel"]))]
+        assert_contract(sa, got, ref, rate, n_ch, pay, what=form)
+
+
+def test_flush_and_reset_in_time_parallel_mode(sa):
+    """flush() (4 s of zeros) and reset() on a time-parallel batch: the long_message recording's header only
+    comes out during the flush (crates/samedec/src/app.rs:118), whichever way the calls are cut."""
+    import torch
+    pcm = np.fromfile(os.path.join(GOLDEN, "long_message.22050.s16le.bin"), dtype="<i2").astype(np.float32)
+    exp = open(os.path.join(GOLDEN, "long_message.22050.s16le.txt")).read().splitlines()[0]
+    n_ch = 32
+    x = torch.from_numpy(np.repeat(pcm[:, None], n_ch, axis=1)).cuda()
+    rx = sa.SameReceiverBuilder(22050).samedec().build_batch(n_ch, time_parallel=True)
+    rx.time_parallel_config(max_chunks=4)
+    for rep in range(2):
+        rx.process_tensor(x)
+        rx.sync()
+        assert rx.time_parallel_chunks() == 4
+        before = [m for c in split(rx.poll_events_np(), n_ch) for m in message_list(c)]
+        assert before == []
+        rx.flush()
+        rx.sync()
+        after = split(rx.poll_events_np(), n_ch)
+        for c in range(n_ch):
+            assert message_list(after[c])[:1] == [(sa.TRANSPORT_MSG_START, exp.encode())], f"rep {rep} channel {c}"
+        rx.reset()
