@@ -247,6 +247,7 @@ void read_knobs(same_batch *rx)
     rx->P.knob_pipe_lanes = num("SAME_PIPE_LANES", 0);
     rx->P.knob_pipe_split = tri("SAME_PIPE_SPLIT");
     rx->P.knob_mirror = tri("SAME_MIRROR");
+    rx->P.knob_prio = num("SAME_PIPE_PRIO", 0);
     rx->debug = std::getenv("SAME_DEBUG") != nullptr;
     rx->host_threads = std::max(0, num("SAME_HOST_THREADS", 0));
 }

@@ -585,6 +585,7 @@ __global__ __launch_bounds__(4 * kWave, SHARE ? 2 : 1) void demod_pipe_kernel(Pa
         // ------------------------------ stage 2: filters + timing loop, block s-1 --------------
         if (LANES < (int)kWave && lane >= (uint32_t)LANES) return;
         P3_HWID(1);
+        if (P.knob_prio & 1) __builtin_amdgcn_s_setprio(2);
         Lane L;
         lane_load(L, S, c);
         int cstar = next_fire_count(L.until_next_ted, L.ted_clock);
@@ -612,7 +613,8 @@ __global__ __launch_bounds__(4 * kWave, SHARE ? 2 : 1) void demod_pipe_kernel(Pa
 #ifdef SAME_PROFILE
                     const unsigned long long spin_t0 = clock64();
 #endif
-                    while ((int32_t)(seqbox[0] - seq) < 0) {}          // stage 4 has posted this pass
+                    if (P.knob_prio & 2) { while ((int32_t)(seqbox[0] - seq) < 0) __builtin_amdgcn_s_sleep(2); }
+                    else { while ((int32_t)(seqbox[0] - seq) < 0) {} }   // stage 4 has posted this pass
 #ifdef SAME_PROFILE
                     if (blockIdx.x == 0 && lane == (uint32_t)__builtin_amdgcn_readfirstlane((int)lane))
                         g_same_prof_hw[5] += clock64() - spin_t0;
@@ -863,8 +865,10 @@ __global__ __launch_bounds__(4 * kWave, SHARE ? 2 : 1) void demod_pipe_kernel(Pa
 #endif
             if (active) {
                 pos = posbox[((s - 1u) & 1u) * kWave + fch];               // posted by stage 2 during the last step
+                if (P.knob_prio & 1) __builtin_amdgcn_s_setprio(3);
                 if (pos < (uint32_t)kB) filter(pos);
                 if (lane == 0u) seqbox[0] = 2u * s + 1u;                    // (LDS operations of a wavefront stay in order)
+                if (P.knob_prio & 1) __builtin_amdgcn_s_setprio(0);
             }
 #ifdef SAME_PROFILE
             if (SPLIT && blockIdx.x == 0 && lane == 0) g_same_prof_hw[6] += clock64() - help_t0;
