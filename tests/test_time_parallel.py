@@ -193,9 +193,11 @@ def test_time_parallel_golden_recordings(sa, ob, name):
     for c in range(n_ch):
         x[lead[c]:lead[c] + len(pcm), c] = pcm
     exp = [ln for ln in open(os.path.join(GOLDEN, f"{name}.22050.s16le.txt")).read().splitlines() if ln != "+OK"]
-    for chunks in (3, 5):
+    # 3 and 5 chunks, and 12 chunks of ~1.5 s with a 0.4 s minimum: shorter than long_message's 2.2 s bursts, so a
+    # chunk's run-on passes over the whole range of the next one and the hand-over skips it
+    for chunks in (3, 5, 12):
         rx = sa.SameReceiverBuilder(22050).samedec().build_batch(n_ch, time_parallel=True)
-        rx.time_parallel_config(max_chunks=chunks)
+        rx.time_parallel_config(max_chunks=chunks, min_own_samples=9000)
         rx.process_tensor(torch.from_numpy(x).cuda())
         rx.sync()
         assert rx.time_parallel_chunks() == chunks
