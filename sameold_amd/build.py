@@ -18,7 +18,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libsame_rx.so")
 SOURCES = ["same_kernels.hip", "same_kernels_fast.hip", "same_kernels_pipe.hip", "same_synth.hip", "same_batch.cpp", "same_config.cpp", "same_transport.cpp", "same_place.cpp"]
-HEADERS = ["same_dev_common.h", "same_fast_common.h", "same_device.h", "same_launch.h", "same_config.h", "same_transport.h", "../../include/same_rx.h",
+HEADERS = ["same_dev_common.h", "same_fast_common.h", "same_profile.h", "same_device.h", "same_launch.h", "same_config.h", "same_transport.h", "../../include/same_rx.h",
            "../../include/same_place.h", "samedec_main.cpp"]
 SAMEDEC = os.path.join(HERE, "samedec_gpu")      # the command-line decoder (host-only program, dlopens LIB)
 ARCH = "gfx950"
@@ -39,8 +39,7 @@ def flags() -> list:
         "-fgpu-rdc" if False else "-fno-gpu-rdc",
         "-Wall", "-Wno-unused-function", "-Wno-unused-variable",
         "-x", "hip",
-    ] + ([f"-DSAME_ABLATE={os.environ['SAME_ABLATE']}"] if os.environ.get("SAME_ABLATE") else []) \
-      + (["-DSAME_PROFILE=1"] if os.environ.get("SAME_PROFILE") else []) \
+    ] + (["-DSAME_PROFILE=1"] if os.environ.get("SAME_PROFILE") else []) \
       + (["-DSAME_P3_MARKS=1"] if os.environ.get("SAME_P3_MARKS") else []) \
       + (["-DSAME_P1_SPLIT=1"] if os.environ.get("SAME_P1_SPLIT") else [])
 

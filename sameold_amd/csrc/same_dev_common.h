@@ -771,11 +771,7 @@ __device__ __forceinline__ uint32_t symbol_link(const Params &P, Lane &L, const 
         S.trace_n[c] = n + 1;
     }
     X.mark(2);
-#if defined(SAME_ABLATE) && SAME_ABLATE == 1
-    uint32_t link = (L.flags & F_LINK_MASK) >> F_LINK_SHIFT; L.sq_symbols += 1; L.sq_power += sym + zero;   // ablation build: no symbol path
-#else
     uint32_t link = rx_symbol(P, L, S, X, c, zero, sym, burst_len);
-#endif
     X.mark(5);
     const uint32_t last = (L.flags & F_LINK_MASK) >> F_LINK_SHIFT;
     *emit = link != last || link == 3u;

@@ -8,6 +8,7 @@
 
 #include "same_dev_common.h"
 #include "same_device.h"
+#include "same_profile.h"
 
 namespace same {
 
@@ -40,27 +41,7 @@ template <int NT, bool MIRROR> struct FastRing {
 
 
 template <int NFF, int NFB>
-struct FastCtx : TickRingGlobal {
-#ifdef SAME_PROFILE
-    // The accumulators live in one LDS location shared by the whole wavefront: a mark inside a
-    // divergent region is executed by the active lanes only, and every one of them reads and
-    // writes the same values, so the totals are per wavefront whichever lanes were active.
-    // pl[0] = time of the previous mark, pl[1 + i] = cycles attributed to section i; section 8
-    // is the cost of a mark itself (two marks back to back).
-    unsigned long long *pl;
-    bool pon = true;
-    __device__ __forceinline__ void mark(int i)
-    {
-        if (!pon) return;
-        const unsigned long long t = clock64();
-        volatile unsigned long long *p = pl;
-        const unsigned long long prev = p[0];
-        p[0] = t;
-        p[1 + i] = p[1 + i] + (t - prev);
-    }
-#else
-    __device__ __forceinline__ void mark(int) {}
-#endif
+struct FastCtx : TickRingGlobal, ProfMarks {
     float *hist;                       // LDS column of this lane: slot i at hist[i * kWave]
     float ffc[NFF], ffw[NFF], fbc[NFB], fbw[NFB];
     float sffc[NFF], sffw[NFF], sfbc[NFB], sfbw[NFB];   // equalizer at the last completed byte

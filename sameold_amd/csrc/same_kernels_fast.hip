@@ -37,11 +37,6 @@
 
 namespace same {
 
-#ifdef SAME_PROFILE
-// cycle-attribution build (results unchanged, timing perturbed by the probes): shader-clock
-// time per section of the block loop, summed over the blocks of wavefront 0
-__device__ unsigned long long g_same_prof[9];
-#endif
 
 template <int NT, int DCL, int NFF, int NFB, bool MED3, bool MIRROR, typename SampleT>
 __global__ __launch_bounds__(kWave) void demod_fast_kernel(Params P, State S, Output O,
@@ -63,11 +58,7 @@ __global__ __launch_bounds__(kWave) void demod_fast_kernel(Params P, State S, Ou
     // the tail-wave exit below, so every wavefront has them)
     float4 *tlds = reinterpret_cast<float4 *>(lds);
     for (uint32_t i = lane; i < (uint32_t)NT; i += kWave) tlds[i] = taps[i];
-#ifdef SAME_PROFILE
-    constexpr uint32_t TAPF = (uint32_t)((NT * 4 + 20 + 63) / 64 * 64);   // taps + profile words
-#else
-    constexpr uint32_t TAPF = (uint32_t)((NT * 4 + 63) / 64 * 64);   // floats reserved for the taps
-#endif
+    constexpr uint32_t TAPF = (uint32_t)((NT * 4 + PIPE_PROF_TAP_PAD + 63) / 64 * 64);   // floats reserved for the taps
     const uint32_t c = blockIdx.x * kWave + lane;
     if (c >= C) return;                                          // no barriers below
     // LDS: taps | squelch history [64][64] | DC rings [2*DCL][64] (LDS DC path) | window.
@@ -85,10 +76,7 @@ __global__ __launch_bounds__(kWave) void demod_fast_kernel(Params P, State S, Ou
     lane_load(L, S, c);
     FastCtx<NFF, NFB> X;
     X.hist = hcol;
-#ifdef SAME_PROFILE
-    X.pl = reinterpret_cast<unsigned long long *>(lds + NT * 4);
-    for (int i = 0; i < 10; ++i) X.pl[i] = 0;
-#endif
+    FAST_MARKS_BEGIN(X, lds, NT);
 #pragma unroll
     for (int i = 0; i < NFF; ++i) {
         X.ffc[i] = S.eq_ffc[i * C + c]; X.ffw[i] = S.eq_ffw[i * C + c];
@@ -146,9 +134,7 @@ __global__ __launch_bounds__(kWave) void demod_fast_kernel(Params P, State S, Ou
 #pragma unroll
     for (int k = 0; k < kB; ++k) { const SampleT *row = x + (size_t)k * C; xn[k] = (float)row[c]; }
 
-#ifdef SAME_PROFILE
-    X.pl[0] = clock64();
-#endif
+    FAST_MARKS_START(X);
     for (uint32_t blk = 0; blk < n_blocks; ++blk) {
         float xs[kB];
 #pragma unroll
@@ -241,11 +227,7 @@ __global__ __launch_bounds__(kWave) void demod_fast_kernel(Params P, State S, Ou
         if (until < kB) {
             const int fk = until;
             const uint32_t newest = wpos + (uint32_t)fk;
-#if defined(SAME_ABLATE) && SAME_ABLATE == 2
-            const float sa_low = wcol[newest * kWave] * 0.01f;   // ablation build: no matched filter
-#else
             const float sa_low = demod_fast<NT, RING, MIRROR>(tlds, wring, lane, newest);
-#endif
             X.mark(1);
             const float rem = L.until_next_ted - (float)cstar;          // receiver.rs:352
             const uint32_t locked_before = L.flags & F_AGC_LOCKED;
@@ -271,14 +253,9 @@ __global__ __launch_bounds__(kWave) void demod_fast_kernel(Params P, State S, Ou
         wpos += kB;
         if (wpos == (uint32_t)RING) wpos = 0;
         X.mark(7);
-#ifdef SAME_PROFILE
-        X.mark(8);
-#endif
+        X.mark(8);                     // (two marks back to back: what a mark itself costs)
     }
-#ifdef SAME_PROFILE
-    if (blockIdx.x == 0 && lane == 0)
-        for (int i = 0; i < 9; ++i) atomicAdd(&g_same_prof[i], X.pl[1 + i]);
-#endif
+    FAST_MARKS_REPORT(X);
 
     // ---- write the state back --------------------------------------------------------
     L.ted_clock = (uint32_t)(cstar - until - 1);
@@ -330,11 +307,7 @@ static constexpr size_t fast_lds_bytes()
 {
     constexpr int kB = FastBlock<NT, MIRROR>::len;
     constexpr int RING = FastRing<NT, MIRROR>::slots;
-#ifdef SAME_PROFILE
-    constexpr size_t TAPF = (size_t)((NT * 4 + 20 + 63) / 64 * 64);
-#else
-    constexpr size_t TAPF = (size_t)((NT * 4 + 63) / 64 * 64);
-#endif
+    constexpr size_t TAPF = (size_t)((NT * 4 + PIPE_PROF_TAP_PAD + 63) / 64 * 64);
     return (TAPF + (size_t)((MIRROR ? 2 * RING - kB : RING) + kSquelchHist + ((DCL <= kB && DCL <= 16) ? 0 : 2 * DCL)) * kWave) * sizeof(float);
 }
 
@@ -411,12 +384,4 @@ hipError_t launch_demod_fast_i16(const Params &P, const State &S, const Output &
 
 }  // namespace same
 
-#ifdef SAME_PROFILE
-extern "C" int same_debug_profile(unsigned long long *out8, int reset)   // 9 words
-{
-    unsigned long long z[9] = {0};
-    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(same::g_same_prof), sizeof(z)) != hipSuccess) return -1;
-    if (reset && hipMemcpyToSymbol(HIP_SYMBOL(same::g_same_prof), z, sizeof(z)) != hipSuccess) return -1;
-    return 0;
-}
-#endif
+FAST_PROFILE_EXPORTS()

@@ -32,6 +32,7 @@
 #include "same_device.h"
 #include "same_fast_common.h"
 #include "same_launch.h"
+#include "same_profile.h"
 
 namespace same {
 
@@ -55,10 +56,7 @@ __device__ __forceinline__ void lds_barrier()
 // Samples per block at 48 / 44.1 kHz (bounds 43 / 39, one instant per block).  Measured at 16 384
 // channels x 2 s: 48 kHz 6.03 ms with 32, 6.75 with 36, 6.48 with 40 (stage 1's registers);
 // 44.1 kHz 5.35 ms with 32, 5.20 with 36.
-#ifndef SAME_B48
-#define SAME_B48 32
-#define SAME_B44 36
-#endif
+constexpr int kBlockPipe48 = 32, kBlockPipe44 = 36;
 template <int NT> struct PipeGeom;
 template <> struct PipeGeom<42> { static constexpr int DCL = 16, B = kBlockPipe22; };   // 22.05 kHz
 template <> struct PipeGeom<92> { static constexpr int DCL = 35, B = SAME_B48; };       // 48 kHz
@@ -70,11 +68,7 @@ template <int NT> struct PipeLayout {
     // registers per lane would spill and the CU's LDS has room
     static constexpr bool YLDS = B >= kBlock48k;
     static constexpr uint32_t yring_floats = YLDS ? 3u * (uint32_t)B * kWave : 0u;
-#ifdef SAME_PROFILE
-    static constexpr uint32_t tap_floats = (uint32_t)((NT * 4 + 20 + 63) / 64 * 64);
-#else
-    static constexpr uint32_t tap_floats = (uint32_t)((NT * 4 + 63) / 64 * 64);
-#endif
+    static constexpr uint32_t tap_floats = (uint32_t)((NT * 4 + PIPE_PROF_TAP_PAD + 63) / 64 * 64);
     static_assert(B <= RING - NT + 1, "the first block's low copy would be read");
 };
 
@@ -95,29 +89,6 @@ template <int NT> struct PipeLayout {
 // processes block b+1 again over the corrected window, replacing what it had handed on.
 // Every channel therefore sees exactly the sequential order of operations.
 // =====================================================================================
-#ifdef SAME_PROFILE
-// per stage of workgroup 0: cycles working, waiting at the step barrier, handling feedback
-__device__ unsigned long long g_same_prof_pipe[9];
-// [role] = HW_ID of workgroup 0's wavefront in that role (SIMD = bits 5:4); [5] cycles stage 2 polled
-// stage 4 for the space magnitude, [6] cycles stage 4 spent on the space filter, [7] second instants of a block
-__device__ unsigned long long g_same_prof_hw[8];
-// stage 2 of workgroup 0, cycles per section of a block: [0] mark filter + hypot, [1] polling stage 4,
-// [2] combine + timing loop + next instant, [3] posting (mailboxes), [4] checkpoint + loop + barrier entry
-__device__ unsigned long long g_same_prof_s2[8];
-#define S2_LAP(i) do { const unsigned long long t_ = clock64(); s2_acc[i] += t_ - s2_t; s2_t = t_; } while (0)
-#define P3_HWID(role_) do { if (blockIdx.x == 0 && lane == 0) g_same_prof_hw[role_] = __builtin_amdgcn_s_getreg((31 << 11) | 4); } while (0)
-#define P3_T0() unsigned long long p3_work = 0, p3_wait = 0, p3_fb = 0, p3_t = clock64()
-#define P3_LAP(acc) do { const unsigned long long t_ = clock64(); acc += t_ - p3_t; p3_t = t_; } while (0)
-#define P3_REPORT(role_) do { if (blockIdx.x == 0 && lane == 0) { g_same_prof_pipe[3 * (role_)] += p3_work; \
-        g_same_prof_pipe[3 * (role_) + 1] += p3_wait; g_same_prof_pipe[3 * (role_) + 2] += p3_fb; } } while (0)
-#else
-#define P3_T0() do {} while (0)
-#define P3_LAP(acc) do {} while (0)
-#define P3_REPORT(role_) do {} while (0)
-#define P3_HWID(role_) do {} while (0)
-#define S2_LAP(i) do {} while (0)
-#endif
-
 constexpr uint32_t kP3SymWords = 5u * kWave;              // per parity: header, zero, sym, terr, until
 constexpr uint32_t kP3FbWords = kWave + 32u;              // per parity: one word per lane + the any-flag
 constexpr uint32_t kP3IoWords = 3u * kWave;               // per parity: symbol word, burst-pool slot, burst length
@@ -545,10 +516,7 @@ __global__ __launch_bounds__(4 * kWave, SHARE ? 2 : 1) void demod_pipe_kernel(Pa
             M.rotate();
             if (s < n_blocks) {
                 M.template fetch<decltype(buf)::value>(x, s, n_blocks, cin, Cin);
-#ifdef SAME_P1_SPLIT
-                asm volatile("s_waitcnt vmcnt(%0)" :: "n"(kB) : "memory");    // profiling: the block's inputs have arrived
-                P3_LAP(p3_fb);                                       // (reported in the "feedback" column)
-#endif
+                P1_INPUTS_ARRIVED(kB);
                 M.block(P, wcol);
             }
             P3_LAP(p3_work);
@@ -575,9 +543,7 @@ __global__ __launch_bounds__(4 * kWave, SHARE ? 2 : 1) void demod_pipe_kernel(Pa
             left = step(s, std::integral_constant<int, 0>{});
             if (!left && s + 1u < n_steps) left = step(s + 1u, std::integral_constant<int, 1>{});
         }
-#ifndef SAME_P3_MARKS
         P3_REPORT(0);
-#endif
         if (left) return;                                              // handed over: this chunk's state is not needed
         lds_barrier();                                                 // (stage 2 -> 3: final TED phase)
         M.store(P, S, c, C, counter1, wcol);
@@ -592,9 +558,7 @@ __global__ __launch_bounds__(4 * kWave, SHARE ? 2 : 1) void demod_pipe_kernel(Pa
         int until = cstar - (int)L.ted_clock - 1;      // block-relative index of the firing sample
         uint32_t wpos = 0;
         // one block: the instant, if this lane has one in it; hands a completed symbol to stage 3
-#ifdef SAME_PROFILE
-        unsigned long long s2_acc[5] = {0, 0, 0, 0, 0}, s2_t = clock64();
-#endif
+        S2_BEGIN();
         auto do_block = [&](uint32_t blk, uint32_t seq) {
             S2_LAP(4);
             uint32_t hdr = 0;
@@ -610,15 +574,10 @@ __global__ __launch_bounds__(4 * kWave, SHARE ? 2 : 1) void demod_pipe_kernel(Pa
                     // while the helper wavefront is still filtering: the timing loop for both signs of the soft
                     // sample it will deliver (same_dev_common.h: ted_ahead / ted_commit)
                     const TedAhead A = ted_ahead(P, L, rem);
-#ifdef SAME_PROFILE
-                    const unsigned long long spin_t0 = clock64();
-#endif
+                    SPIN_BEGIN();
                     if (P.knob_prio & 2) { while ((int32_t)(seqbox[0] - seq) < 0) __builtin_amdgcn_s_sleep(2); }
                     else { while ((int32_t)(seqbox[0] - seq) < 0) {} }   // stage 4 has posted this pass
-#ifdef SAME_PROFILE
-                    if (blockIdx.x == 0 && lane == (uint32_t)__builtin_amdgcn_readfirstlane((int)lane))
-                        g_same_prof_hw[5] += clock64() - spin_t0;
-#endif
+                    SPIN_END();
                     if constexpr (PACKED) hm = __uint_as_float(markbox[lane]);
                     const float hs = __uint_as_float(spacebox[lane]);
                     S2_LAP(1);
@@ -637,9 +596,7 @@ __global__ __launch_bounds__(4 * kWave, SHARE ? 2 : 1) void demod_pipe_kernel(Pa
                     // fastest): rare, so this wavefront computes both filters itself.  Exactly one of the
                     // two instants completes a symbol.
                     const int fk2 = until;
-#ifdef SAME_PROFILE
-                    atomicAdd(&g_same_prof_hw[7], 1ull);          // lanes that took this path (any workgroup)
-#endif
+                    COUNT_SECOND_INSTANT();
                     const float sa2 = demod_fast<NT, RING, true>(tlds, wring, lane, wpos + (uint32_t)fk2);
                     const float rem2 = L.until_next_ted - (float)cstar;
                     float z2 = 0.0f, s2 = 0.0f, e2 = 0.0f;
@@ -701,12 +658,8 @@ __global__ __launch_bounds__(4 * kWave, SHARE ? 2 : 1) void demod_pipe_kernel(Pa
             if (active) { wpos += kB; if (wpos == (uint32_t)RING) wpos = 0; }
             if (s == stop_at) { left = true; break; }
         }
-#ifndef SAME_P3_MARKS
         P3_REPORT(1);
-#endif
-#ifdef SAME_PROFILE
-        if (blockIdx.x == 0 && lane == 0) for (int i = 0; i < 5; ++i) g_same_prof_s2[i] += s2_acc[i];
-#endif
+        S2_REPORT();
         if (left) return;
         phasebox[lane] = L.flags & F_TED_PHASE;
         lds_barrier();                                                 // stage 3 merges the phase bit
@@ -723,18 +676,7 @@ __global__ __launch_bounds__(4 * kWave, SHARE ? 2 : 1) void demod_pipe_kernel(Pa
         L.ended = 0u;
         FastCtx<NFF, NFB> X;
         X.hist = hcol;
-#ifdef SAME_PROFILE
-        // per-section marks of the symbol path (SAME_P3_MARKS build): words behind the taps, reported
-        // through g_same_prof_pipe[0..5] instead of stage 1's and stage 2's timers
-        X.pl = reinterpret_cast<unsigned long long *>(lds + NT * 4);
-#ifdef SAME_P3_MARKS
-        X.pon = true;
-        for (int i = 0; i < 10; ++i) X.pl[i] = 0;
-        X.pl[0] = clock64();
-#else
-        X.pon = false;
-#endif
-#endif
+        P3_MARKS_BEGIN(X, lds, NT);       // (profile builds: per-section marks of the symbol path)
 #pragma unroll
         for (int i = 0; i < NFF; ++i) {
             X.ffc[i] = S.eq_ffc[i * C + c]; X.ffw[i] = S.eq_ffw[i * C + c];
@@ -802,13 +744,8 @@ __global__ __launch_bounds__(4 * kWave, SHARE ? 2 : 1) void demod_pipe_kernel(Pa
             if (any) { lds_barrier(); lds_barrier(); P3_LAP(p3_fb); }   // B, C: the earlier stages catch up
             if (s == stop_at) { left = true; break; }
         }
-#ifndef SAME_P3_MARKS
         P3_REPORT(2);
-#endif
-#if defined(SAME_PROFILE) && defined(SAME_P3_MARKS)
-        if (blockIdx.x == 0 && lane == 0)
-            for (int i = 0; i < 6; ++i) atomicAdd(&g_same_prof_pipe[i], X.pl[1 + 2 + i] - (i == 0 ? 0ull : 0ull));
-#endif
+        P3_MARKS_REPORT(X);
         if (left) return;
         lds_barrier();                                                 // stage 2's TED phase, stage 4's wake-up flag
         L.flags = (L.flags & ~(F_TED_PHASE | F_TICK_AGAIN)) | (phasebox[lane] & F_TED_PHASE) | (againbox[lane] & F_TICK_AGAIN);
@@ -860,9 +797,7 @@ __global__ __launch_bounds__(4 * kWave, SHARE ? 2 : 1) void demod_pipe_kernel(Pa
             // SPLIT: first the matched filter(s) of block s-1 for stage 2, which waits for them
             const bool active = SPLIT && s >= 1u && s <= n_blocks;
             uint32_t pos = 0xffffffffu;
-#ifdef SAME_PROFILE
-            const unsigned long long help_t0 = clock64();
-#endif
+            HELP_BEGIN();
             if (active) {
                 pos = posbox[((s - 1u) & 1u) * kWave + fch];               // posted by stage 2 during the last step
                 if (P.knob_prio & 1) __builtin_amdgcn_s_setprio(3);
@@ -870,9 +805,7 @@ __global__ __launch_bounds__(4 * kWave, SHARE ? 2 : 1) void demod_pipe_kernel(Pa
                 if (lane == 0u) seqbox[0] = 2u * s + 1u;                    // (LDS operations of a wavefront stay in order)
                 if (P.knob_prio & 1) __builtin_amdgcn_s_setprio(0);
             }
-#ifdef SAME_PROFILE
-            if (SPLIT && blockIdx.x == 0 && lane == 0) g_same_prof_hw[6] += clock64() - help_t0;
-#endif
+            HELP_END(SPLIT);
             if (s >= 3u && evt_lane) {
                 const uint32_t blk = s - 3u;
                 const lds_u32 *io = iobox + ((s - 1u) & 1u) * kP3IoWords + lane;   // what stage 3 posted last step
@@ -1038,26 +971,4 @@ uint32_t pipe_workgroup_channels(const Params &P) { return pipe_lanes(P); }
 
 }  // namespace same
 
-#ifdef SAME_PROFILE
-extern "C" int same_debug_profile_s2(unsigned long long *out8, int reset)
-{
-    unsigned long long z[8] = {0};
-    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(same::g_same_prof_s2), sizeof(z)) != hipSuccess) return -1;
-    if (reset && hipMemcpyToSymbol(HIP_SYMBOL(same::g_same_prof_s2), z, sizeof(z)) != hipSuccess) return -1;
-    return 0;
-}
-extern "C" int same_debug_profile_hw(unsigned long long *out8, int reset)
-{
-    unsigned long long z[8] = {0};
-    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(same::g_same_prof_hw), sizeof(z)) != hipSuccess) return -1;
-    if (reset && hipMemcpyToSymbol(HIP_SYMBOL(same::g_same_prof_hw), z, sizeof(z)) != hipSuccess) return -1;
-    return 0;
-}
-extern "C" int same_debug_profile_pipe(unsigned long long *out9, int reset)
-{
-    unsigned long long z[9] = {0};
-    if (hipMemcpyFromSymbol(out9, HIP_SYMBOL(same::g_same_prof_pipe), sizeof(z)) != hipSuccess) return -1;
-    if (reset && hipMemcpyToSymbol(HIP_SYMBOL(same::g_same_prof_pipe), z, sizeof(z)) != hipSuccess) return -1;
-    return 0;
-}
-#endif
+PIPE_PROFILE_EXPORTS()
