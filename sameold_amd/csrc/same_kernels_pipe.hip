@@ -59,8 +59,8 @@ __device__ __forceinline__ void lds_barrier()
 constexpr int kBlockPipe48 = 32, kBlockPipe44 = 36;
 template <int NT> struct PipeGeom;
 template <> struct PipeGeom<42> { static constexpr int DCL = 16, B = kBlockPipe22; };   // 22.05 kHz
-template <> struct PipeGeom<92> { static constexpr int DCL = 35, B = SAME_B48; };       // 48 kHz
-template <> struct PipeGeom<84> { static constexpr int DCL = 32, B = SAME_B44; };       // 44.1 kHz
+template <> struct PipeGeom<92> { static constexpr int DCL = 35, B = kBlockPipe48; };       // 48 kHz
+template <> struct PipeGeom<84> { static constexpr int DCL = 32, B = kBlockPipe44; };       // 44.1 kHz
 template <int NT> struct PipeLayout {
     static constexpr int B = PipeGeom<NT>::B, RING = 5 * B;
     // stage 1 keeps the DC-blocker outputs of its last three blocks for a replay: in registers
