@@ -139,9 +139,6 @@ struct same_batch {
         uint32_t n_desc = 0;
         uint32_t *d_final_col = nullptr;
         uint32_t last_chunks = 1;
-        // longest run-on seen so far, in samples (0 = none yet: 1.25 s is assumed).  The last chunk of a call never
-        // runs on, so it is given that much more to own: all chunks then finish at about the same time.
-        uint64_t runon_samples = 0;
         std::vector<int64_t> sym_off;        // per channel: reported symbol count - the device's
         std::vector<TickSynth> synth;
     } tp;
@@ -351,19 +348,6 @@ int harvest_slot(same_batch *rx, same_batch::Slot &sl)
         std::vector<uint32_t> fill(first.begin(), first.end() - 1);
         for (uint32_t i = 0; i < n_events; ++i)
             if (evs[i].kind != same::kDevEventNone) order[fill[std::min(evs[i].channel, n_bins - 1u)]++] = i;
-    }
-    if (sl.chunked) {
-        // the longest run-on of this launch: how much later than its nominal end a chunk handed over
-        uint64_t worst = 0;
-        const same::ChunkGeom &g = sl.geom;
-        for (uint32_t k = 0; k + 1u < g.n_chunks; ++k) {
-            const uint64_t nominal_end = g.own_start(k + 1u);
-            for (uint32_t c = 0; c < n_ch; ++c) {
-                const uint64_t h = sl.h_handover[(size_t)k * n_ch + c];
-                if (h != same::kNoHandover && h > nominal_end) worst = std::max(worst, h - nominal_end);
-            }
-        }
-        rx->tp.runon_samples = std::max(worst, rx->tp.runon_samples - rx->tp.runon_samples / 8);   // follow increases at once, decay slowly
     }
     // events per real channel, cumulative (a chunked launch spreads a channel over n_chunks columns)
     std::vector<uint32_t> chan_first;
@@ -629,13 +613,7 @@ uint32_t plan_chunks(same_batch *rx, size_t n, same::ChunkGeom &geom, same::Pipe
         const uint32_t WB = (warm + fb - 1u) / fb;
         const uint64_t TB = n / fb;
         if (TB <= WB) return 1;
-        // every chunk but the last runs on past its end until its lanes are idle; the last one stops at the end of
-        // the input.  Balance them: the last chunk owns the expected run-on more than the others (at most half of
-        // what an even split would give the others).
-        const uint64_t even = (TB - WB) / K;
-        const uint64_t runon = tp.runon_samples ? tp.runon_samples : (uint64_t)(1.25 * rx->P.input_rate);
-        const uint64_t RB = std::min<uint64_t>(runon / fb, even / 2);
-        const uint64_t SB = (TB - WB - RB) / K;
+        const uint64_t SB = (TB - WB) / K;
         const uint64_t min_own = tp.min_own ? tp.min_own : 4ull * WB * fb;
         if (SB == 0 || SB * fb < min_own) continue;
         geom.counter0 = rx->counter;
