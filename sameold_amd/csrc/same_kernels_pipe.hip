@@ -68,6 +68,9 @@ template <int NT> struct PipeLayout {
     // registers per lane would spill and the CU's LDS has room
     static constexpr bool YLDS = B >= kBlock48k;
     static constexpr uint32_t yring_floats = YLDS ? 3u * (uint32_t)B * kWave : 0u;
+    // DCW builds (a fifth wavefront runs the DC blocker a block ahead, see DcStage): its outputs of four
+    // blocks -- the one being written, the one stage 1 consumes, two more for a replay
+    static constexpr uint32_t dcw_ring_floats = 4u * (uint32_t)B * kWave;
     static constexpr uint32_t tap_floats = (uint32_t)((NT * 4 + PIPE_PROF_TAP_PAD + 63) / 64 * 64);
     static_assert(B <= RING - NT + 1, "the first block's low copy would be read");
 };
@@ -433,6 +436,180 @@ struct SampleStage {
     }
 };
 
+// ---- stage 1 cut in two (DCW builds: 16- and 32-channel workgroups at 22.05 kHz) ------------------------
+// The DC blocker takes no feedback from anything downstream (rx/dcblock.rs:45-49), so a fifth wavefront runs
+// it one block AHEAD of the AGC and hands its outputs over through a four-block LDS ring; what is left of
+// stage 1 -- AGC, window push, the replay of an AGC lock flip -- reads them from there.  Same operations in
+// the same order per channel; only the wavefront that executes them changes.
+template <int NT_, typename SampleT>
+struct DcStage {
+    static constexpr int DCL = PipeGeom<NT_>::DCL, kB = PipeLayout<NT_>::B;
+    static constexpr uint32_t LP = kWave;
+    float sum0, sum1;
+    float xp[DCL], mp[DCL];              // the last DCL inputs / first-stage averages, oldest first
+    float xn[2][kB];                     // prefetched inputs of the next two blocks: block b waits in xn[b & 1]
+    float xs[kB];
+    __device__ __forceinline__ void load(const Params &P, const State &S, const SampleT *__restrict__ x, uint32_t c, uint32_t C,
+                                         uint32_t cin, uint32_t Cin, uint64_t counter0, uint32_t n_blocks)
+    {
+        sum0 = S.dc_sum0[c]; sum1 = S.dc_sum1[c];
+        const uint32_t dpos = (uint32_t)(counter0 % (uint64_t)DCL);
+#pragma unroll
+        for (int k = 0; k < DCL; ++k) {
+            uint32_t slot = dpos + (uint32_t)k;
+            if (slot >= (uint32_t)DCL) slot -= (uint32_t)DCL;
+            const float *r0 = S.dc_ff_ring + (size_t)slot * C, *r1 = S.dc_fb_ring + (size_t)slot * C;
+            xp[k] = r0[c];
+            mp[k] = r1[c];
+        }
+#pragma unroll
+        for (int k = 0; k < kB; ++k) { const SampleT *row = x + (size_t)k * Cin; xn[0][k] = (float)row[cin]; }
+        if (n_blocks > 1u) {
+            const SampleT *xb = x + (size_t)kB * Cin;
+#pragma unroll
+            for (int k = 0; k < kB; ++k) { const SampleT *row = xb + (size_t)k * Cin; xn[1][k] = (float)row[cin]; }
+        }
+    }
+    template <int BUF>
+    __device__ __forceinline__ void fetch(const SampleT *__restrict__ x, uint32_t blk, uint32_t n_blocks, uint32_t cin, uint32_t Cin)
+    {
+#pragma unroll
+        for (int k = 0; k < kB; ++k) xs[k] = xn[BUF][k];
+        if (blk + 2 < n_blocks) {
+            const SampleT *xb = x + ((size_t)(blk + 2) * kB) * Cin;      // wave-uniform
+#pragma unroll
+            for (int k = 0; k < kB; ++k) { const SampleT *row = xb + (size_t)k * Cin; xn[BUF][k] = (float)row[cin]; }
+        }
+    }
+    // DC blocker (rx/dcblock.rs:45-49, 104-108) of the fetched block; outputs to y[k * LP]
+    __device__ __forceinline__ void block(const Params &P, float *y)
+    {
+        float mnew[kB];
+        auto xw = [&](int i) { return i < DCL ? xp[i < DCL ? i : 0] : xs[i >= DCL ? i - DCL : 0]; };
+#pragma unroll
+        for (int k = 0; k < kB; k += 2) {
+            const float2v x2 = {xs[k], xs[k + 1]}, xo = {xw(k), xw(k + 1)};
+            const float2v d0 = x2 - xo;
+            const float s0a = sum0 + d0.x, s0b = s0a + d0.y;
+            sum0 = s0b;
+            const float2v s0 = {s0a, s0b}, inv = {P.dc_inv_len, P.dc_inv_len};
+            const float2v ma0 = s0 * inv;
+            const float2v sig = {xw(k + 1), xw(k + 2)};
+            const float2v mo = {k < DCL ? mp[k < DCL ? k : 0] : mnew[k >= DCL ? k - DCL : 0],
+                                k + 1 < DCL ? mp[k + 1 < DCL ? k + 1 : 0] : mnew[k + 1 >= DCL ? k + 1 - DCL : 0]};
+            const float2v d1 = ma0 - mo;
+            const float s1a = sum1 + d1.x, s1b = s1a + d1.y;
+            sum1 = s1b;
+            const float2v s1 = {s1a, s1b};
+            const float2v ma1 = s1 * inv;
+            const float2v y2 = sig - ma1;
+            y[k * LP] = y2.x; y[(k + 1) * LP] = y2.y;
+            mnew[k] = ma0.x; mnew[k + 1] = ma0.y;
+        }
+#pragma unroll
+        for (int k = 0; k < DCL; ++k) {
+            xp[k] = kB + k < DCL ? xp[kB + k < DCL ? kB + k : 0] : xs[kB + k >= DCL ? kB + k - DCL : 0];
+            mp[k] = kB + k < DCL ? mp[kB + k < DCL ? kB + k : 0] : mnew[kB + k >= DCL ? kB + k - DCL : 0];
+        }
+    }
+    __device__ __forceinline__ void store(const State &S, uint32_t c, uint32_t C, uint64_t counter1)
+    {
+        S.dc_sum0[c] = sum0; S.dc_sum1[c] = sum1;
+        const uint32_t dpos = (uint32_t)(counter1 % (uint64_t)DCL);
+#pragma unroll
+        for (int k = 0; k < DCL; ++k) {
+            uint32_t slot = dpos + (uint32_t)k;
+            if (slot >= (uint32_t)DCL) slot -= (uint32_t)DCL;
+            float *r0 = S.dc_ff_ring + (size_t)slot * C, *r1 = S.dc_fb_ring + (size_t)slot * C;
+            r0[c] = xp[k];
+            r1[c] = mp[k];
+        }
+    }
+};
+
+template <int NT_, bool MED3>
+struct AgcStage {
+    static constexpr int kB = PipeLayout<NT_>::B, RING = PipeLayout<NT_>::RING;
+    static constexpr uint32_t LP = kWave;
+    const float *ycol;                   // this lane's column of the DC wave's ring [4][kB][64]; block b in slot b & 3
+    float gain;
+    bool locked;                         // this stage's belief of the AGC lock
+    float g0[3];                         // AGC gain the last three blocks started with ([0] newest)
+    uint32_t wp[3];                      // their window-ring positions
+    uint32_t wnext;
+    __device__ __forceinline__ void load(const Params &P, const State &S, uint32_t c, uint32_t C, uint64_t counter0, float *wcol)
+    {
+        const uint32_t G = P.win_ring;
+#pragma unroll 2
+        for (uint32_t m = 1; m <= G; ++m) {
+            const uint32_t g = (uint32_t)(counter0 - (uint64_t)m) & (G - 1u);
+            const float *row = S.win_ring + (size_t)g * C;
+            const float v = row[c];
+            if ((uint32_t)RING - m >= (uint32_t)kB) wcol[((uint32_t)RING - m) * LP] = v;
+            wcol[(2u * (uint32_t)RING - m) * LP] = v;
+        }
+        gain = S.agc_gain[c];
+        locked = (S.flags[c] & F_AGC_LOCKED) != 0u;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) { g0[j] = gain; wp[j] = 0; }
+        wnext = 0;
+    }
+    __device__ __forceinline__ void rotate() { g0[2] = g0[1]; g0[1] = g0[0]; wp[2] = wp[1]; wp[1] = wp[0]; }
+    // AGC (rx/agc.rs:72-77) and window push (receiver.rs:345-346) of block `blk` (history slot j): bandwidth bw0
+    // up to sample fk, bw1 after it
+    __device__ __forceinline__ void push(const Params &P, float *wcol, int j, uint32_t blk, float &g, int fk, float bw0, float bw1)
+    {
+        const float *y = ycol + ((blk & 3u) * (uint32_t)kB) * LP;
+        float yv[kB];
+#pragma unroll
+        for (int k = 0; k < kB; ++k) yv[k] = y[k * LP];
+        float *wblk = wcol + wp[j] * LP;
+        float *wlow = wcol + (wp[j] == 0u ? (uint32_t)RING : wp[j]) * LP;
+#pragma unroll
+        for (int k = 0; k < kB; ++k) {
+            const float out = agc_step<MED3>(P, yv[k], g, (k <= fk) ? bw0 : bw1);
+            wlow[k * LP] = out;
+            wblk[(k + RING) * LP] = out;
+        }
+    }
+    __device__ __forceinline__ void block(const Params &P, float *wcol, uint32_t blk)
+    {
+        g0[0] = gain;
+        wp[0] = wnext;
+        const float bw = locked ? 0.0f : P.agc_bw;
+        push(P, wcol, 0, blk, gain, kB, bw, bw);
+        wnext += kB;
+        if (wnext == (uint32_t)RING) wnext = 0;
+    }
+    // the lock flipped at sample fk of block s - 2 (history slot 2): redo the AGC from there on
+    __device__ __forceinline__ void replay(const Params &P, float *wcol, uint32_t s, int fk, bool new_locked, bool valid1, bool valid0)
+    {
+        const float bw0 = locked ? 0.0f : P.agc_bw;
+        locked = new_locked;
+        const float bw1 = locked ? 0.0f : P.agc_bw;
+        float g = g0[2];
+        push(P, wcol, 2, s - 2u, g, fk, bw0, bw1);
+        if (valid1) { g0[1] = g; push(P, wcol, 1, s - 1u, g, -1, bw1, bw1); }
+        if (valid0) { g0[0] = g; push(P, wcol, 0, s, g, -1, bw1, bw1); }
+        gain = g;
+    }
+    __device__ __forceinline__ void store(const Params &P, const State &S, uint32_t c, uint32_t C, uint64_t counter1, const float *wcol)
+    {
+        S.agc_gain[c] = gain;
+        const uint32_t G = P.win_ring;
+#pragma unroll 2
+        for (uint32_t m = 1; m <= G; ++m) {
+            const uint32_t g = (uint32_t)(counter1 - (uint64_t)m) & (G - 1u);
+            const uint32_t j = wnext >= m ? wnext - m : wnext + (uint32_t)RING - m;
+            float *row = S.win_ring + (size_t)g * C;
+            row[c] = wcol[(j + (uint32_t)RING) * LP];           // the high copy is always there
+        }
+    }
+};
+
+// wavefronts per workgroup: five in DCW builds
+template <int NT, int LANES, bool SPLIT> constexpr bool pipe_dcw() { return NT == 42 && LANES <= 32 && SPLIT; }
+
 // SHARE: built for two wavefronts per SIMD (half of the 512-entry register file each, a few
 // spills) -- what lets two workgroups, eight wavefronts, share a CU's four SIMDs beyond 16 384
 // channels.  Smaller batches use the unconstrained build (2 % faster).
@@ -449,7 +626,7 @@ struct SampleStage {
 // step, posts it and bumps a sequence word that stage 2 polls before it combines the two -- a
 // hand-over inside the step, no extra block of latency.
 template <int NT, int NFF, int NFB, bool MED3, bool SHARE, int LANES, bool SPLIT, typename SampleT>
-__global__ __launch_bounds__(4 * kWave, SHARE ? 2 : 1) void demod_pipe_kernel(Params P, State S, Output O,
+__global__ __launch_bounds__((pipe_dcw<NT, LANES, SPLIT>() ? 5 : 4) * kWave, SHARE ? 2 : 1) void demod_pipe_kernel(Params P, State S, Output O,
                                                                 const float4 *__restrict__ taps,
                                                                 const SampleT *__restrict__ x,
                                                                 uint32_t n_blocks, uint64_t counter0, PipeChunks K)
@@ -459,10 +636,12 @@ __global__ __launch_bounds__(4 * kWave, SHARE ? 2 : 1) void demod_pipe_kernel(Pa
     // PACKED: workgroups of 16 or 32 channels -- the helper wavefront computes BOTH matched filters (mark on its
     // lanes 0 .. LANES-1, space on LANES .. 2*LANES-1) and stage 2 keeps only the timing loop
     constexpr bool PACKED = SPLIT && LANES <= 32;
+    // DCW: a fifth wavefront runs the DC blocker one block ahead (DcStage / AgcStage above)
+    constexpr bool DCW = pipe_dcw<NT, LANES, SPLIT>();
     static_assert(kB <= 64, "the sample index travels in six bits of the stage 3 -> 4 word");
     extern __shared__ float lds[];
     const uint32_t lane = threadIdx.x & (kWave - 1u);
-    const uint32_t role = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // 0..3 = stage 1..4
+    const uint32_t role = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // 0..3 = stage 1..4, 4 = DC wave
     const uint32_t C = P.n_channels;
     const uint32_t c = blockIdx.x * (uint32_t)LANES + lane;  // C % LANES == 0 (host)
     // Time-parallel chunks: state column c = chunk * Cin + cin reads input column cin
@@ -501,7 +680,79 @@ __global__ __launch_bounds__(4 * kWave, SHARE ? 2 : 1) void demod_pipe_kernel(Pa
     const uint32_t n_steps = n_blocks + 3u;
     const uint32_t last_fb_step = n_blocks + 1u;                // stage 3 runs in steps 2 .. n_blocks + 1
 
-    if (role == 0u) {
+    float *dcw_ring = wring + (2u * (uint32_t)RING) * LP;             // DCW: [4][kB][64] behind the window
+    if (DCW && role == 4u) {
+        // ------------------------------ DC wave: DC blocker of block s + 1 ------------------------
+        if (LANES < (int)kWave && lane >= (uint32_t)LANES) return;
+        DcStage<NT, SampleT> D;
+        D.load(P, S, x, c, C, cin, Cin, counter0, n_blocks);
+        float *ycol = dcw_ring + lane;
+        D.template fetch<0>(x, 0u, n_blocks, cin, Cin);               // block 0 before anyone starts
+        D.block(P, ycol);
+        lds_barrier();                                                 // prologue (every role of a DCW build has one)
+        uint32_t stop_at = 0xffffffffu;
+        auto step = [&](uint32_t s, auto buf) -> bool {
+            const uint32_t blk = s + 1u;                               // BUF = blk & 1
+            if (blk < n_blocks) {
+                D.template fetch<decltype(buf)::value>(x, blk, n_blocks, cin, Cin);
+                D.block(P, ycol + ((blk & 3u) * (uint32_t)kB) * LP);
+            }
+            lds_barrier();                                             // A
+            if (s >= 2u && s <= last_fb_step) {
+                const lds_u32 *fb = fbbox + (s & 1u) * kP3FbWords;
+                const uint32_t fbw = (uint32_t)__builtin_amdgcn_readfirstlane((int)fb[kWave]);
+                if (fbw & 2u) stop_at = s + 1u;
+                if (fbw & 1u) { lds_barrier(); lds_barrier(); }        // B, C: the others replay (the DC blocker never does)
+            }
+            return s == stop_at;
+        };
+        bool left = false;
+        for (uint32_t s = 0; s < n_steps && !left; s += 2u) {
+            left = step(s, std::integral_constant<int, 1>{});          // block s + 1 is odd when s is even
+            if (!left && s + 1u < n_steps) left = step(s + 1u, std::integral_constant<int, 0>{});
+        }
+        if (left) return;
+        lds_barrier();                                                 // (the final hand-shake of the other roles)
+        D.store(S, c, C, counter1);
+    } else if (DCW && role == 0u) {
+        // ------------------------------ stage 1 (DCW): AGC + window push, block s ------------------
+        for (uint32_t i = lane; i < (uint32_t)NT; i += kWave) tlds[i] = taps[i];
+        if (LANES < (int)kWave && lane >= (uint32_t)LANES) return;
+        P3_HWID(0);
+        AgcStage<NT, MED3> M;
+        M.ycol = dcw_ring + lane;
+        M.load(P, S, c, C, counter0, wcol);
+        lds_barrier();                                                 // prologue: block 0's DC outputs are in the ring
+        P3_T0();
+        uint32_t stop_at = 0xffffffffu;
+        bool left = false;
+        for (uint32_t s = 0; s < n_steps; ++s) {
+            M.rotate();
+            if (s < n_blocks) M.block(P, wcol, s);
+            P3_LAP(p3_work);
+            lds_barrier();                                             // A
+            P3_LAP(p3_wait);
+            if (s >= 2u && s <= last_fb_step) {
+                const lds_u32 *fb = fbbox + (s & 1u) * kP3FbWords;
+                const uint32_t fbw = (uint32_t)__builtin_amdgcn_readfirstlane((int)fb[kWave]);
+                if (fbw & 2u) stop_at = s + 1u;
+                if (fbw & 1u) {
+                    const uint32_t v = fb[lane];
+                    const bool new_locked = (v & 2u) != 0u;
+                    if ((v & 1u) && new_locked != M.locked)
+                        M.replay(P, wcol, s, (int)(v >> 8), new_locked, s - 1u < n_blocks, s < n_blocks);
+                    lds_barrier();                                     // B: the window is corrected
+                    lds_barrier();                                     // C: stage 2 has redone its block
+                    P3_LAP(p3_fb);
+                }
+            }
+            if (s == stop_at) { left = true; break; }
+        }
+        P3_REPORT(0);
+        if (left) return;
+        lds_barrier();                                                 // (stage 2 -> 3: final TED phase)
+        M.store(P, S, c, C, counter1, wcol);
+    } else if (role == 0u) {
         // ------------------------------ stage 1: sample phase, block s -------------------------
         for (uint32_t i = lane; i < (uint32_t)NT; i += kWave) tlds[i] = taps[i];
         if (LANES < (int)kWave && lane >= (uint32_t)LANES) return;      // (the wavefront goes on without them)
@@ -551,6 +802,7 @@ __global__ __launch_bounds__(4 * kWave, SHARE ? 2 : 1) void demod_pipe_kernel(Pa
         // ------------------------------ stage 2: filters + timing loop, block s-1 --------------
         if (LANES < (int)kWave && lane >= (uint32_t)LANES) return;
         P3_HWID(1);
+        if constexpr (DCW) lds_barrier();                              // prologue
         if (P.knob_prio & 1) __builtin_amdgcn_s_setprio(2);
         Lane L;
         lane_load(L, S, c);
@@ -671,6 +923,7 @@ __global__ __launch_bounds__(4 * kWave, SHARE ? 2 : 1) void demod_pipe_kernel(Pa
         // ------------------------------ stage 3: symbol path, block s-2 ------------------------
         if (LANES < (int)kWave && lane >= (uint32_t)LANES) return;
         P3_HWID(2);
+        if constexpr (DCW) lds_barrier();                              // prologue
         Lane L;
         lane_load(L, S, c);
         L.ended = 0u;
@@ -772,6 +1025,7 @@ __global__ __launch_bounds__(4 * kWave, SHARE ? 2 : 1) void demod_pipe_kernel(Pa
         // lane - LANES, while lanes 0 .. LANES-1 compute the mark filter) and sit the event half out.
         const bool evt_lane = lane < (uint32_t)LANES;
         if (LANES < (int)kWave && lane >= (uint32_t)(PACKED ? 2 * LANES : LANES)) return;
+        if constexpr (DCW) lds_barrier();                              // prologue
         const uint32_t fch = PACKED ? (lane & (uint32_t)(LANES - 1)) : lane;      // the channel this lane filters for
         const uint32_t which = PACKED ? (lane >= (uint32_t)LANES ? 1u : 0u) : 1u;   // 0 mark, 1 space
         Lane L;
@@ -848,10 +1102,10 @@ __global__ __launch_bounds__(4 * kWave, SHARE ? 2 : 1) void demod_pipe_kernel(Pa
 // ---------------------------------------------------------------------------------
 // dispatch
 // ---------------------------------------------------------------------------------
-template <int NT>
+template <int NT, bool DCW = false>
 static constexpr size_t pipe_lds_bytes()
 {
-    return ((size_t)PipeLayout<NT>::tap_floats + kP3MailWords + PipeLayout<NT>::yring_floats +
+    return ((size_t)PipeLayout<NT>::tap_floats + kP3MailWords + (DCW ? PipeLayout<NT>::dcw_ring_floats : PipeLayout<NT>::yring_floats) +
             (size_t)(kSquelchHist + 2 * PipeLayout<NT>::RING - PipeLayout<NT>::B) * kWave) * sizeof(float);
 }
 
@@ -895,7 +1149,8 @@ static hipError_t launch_pipe_one(const Params &P, const State &S, const Output 
                                   const SampleT *x, uint32_t n_blocks, uint64_t counter0, hipStream_t stream,
                                   const PipeChunks &K)
 {
-    constexpr size_t lds = pipe_lds_bytes<NT>();
+    constexpr bool DCW = pipe_dcw<NT, LANES, SPLIT>();
+    constexpr size_t lds = pipe_lds_bytes<NT, DCW>();
     auto *kernel = demod_pipe_kernel<NT, NFF, NFB, M3, SHARE, LANES, SPLIT, SampleT>;
     if (lds > 64u * 1024u) {
         // more than the default 64 KB of dynamic LDS per workgroup: opt in, once per kernel and device
@@ -910,7 +1165,7 @@ static hipError_t launch_pipe_one(const Params &P, const State &S, const Output 
         }
     }
     if (K.n_chunks > 1u && (K.in_channels % (uint32_t)LANES) != 0u) return hipErrorInvalidValue;   // a workgroup would straddle chunks
-    hipLaunchKernelGGL(kernel, dim3(P.n_channels / (uint32_t)LANES), dim3(4 * kWave), lds, stream, P, S, O, taps, x, n_blocks, counter0, K);
+    hipLaunchKernelGGL(kernel, dim3(P.n_channels / (uint32_t)LANES), dim3((DCW ? 5 : 4) * kWave), lds, stream, P, S, O, taps, x, n_blocks, counter0, K);
     return hipGetLastError();
 }
 
