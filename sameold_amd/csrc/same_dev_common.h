@@ -244,9 +244,15 @@ __device__ __forceinline__ uint32_t eq_symbol_core(const Params &P, Lane &L, flo
     float ff = 0.0f;
 #pragma unroll
     for (int i = 0; i < NFF; ++i) { float p = ffw[NFF - 1 - i] * ffc[i]; ff += p; }
+    // Feedback window: push(&[decision, 0.0]) (rx/equalize.rs:304) puts an exact +0.0 at every other slot --
+    // indices NFB-1, NFB-3, ... -- from the reset on (the window starts as zeros).  A tap that meets one of them
+    // contributes fbc * 0 = +-0 to a sum that is +0.0 or non-zero (x + (+-0) == x, +0 + (-0) == +0), is updated
+    // by ge * 0 = +-0 (same argument: coefficients start at 1.0 / +0.0), and adds 0 * 0 to the sum of squares:
+    // all three are skipped, bit for bit the same result.
+    constexpr auto fb_zero = [](int widx) { return ((NFB - 1 - widx) & 1) == 0; };
     float fb = 0.0f;
 #pragma unroll
-    for (int i = 0; i < NFB; ++i) { float p = fbw[NFB - 1 - i] * fbc[i]; fb += p; }
+    for (int i = 0; i < NFB; ++i) { if (fb_zero(NFB - 1 - i)) continue; float p = fbw[NFB - 1 - i] * fbc[i]; fb += p; }
     float sym_val = ff - fb;
     float sym_est, err;
     bool evolve = true;
@@ -276,11 +282,11 @@ __device__ __forceinline__ uint32_t eq_symbol_core(const Params &P, Lane &L, flo
         float nerr = -err;
         sumsq = 0.0f;
 #pragma unroll
-        for (int i = 0; i < NFB; ++i) { float q = fbw[i] * fbw[i]; sumsq += q; }
+        for (int i = 0; i < NFB; ++i) { if (fb_zero(i)) continue; float q = fbw[i] * fbw[i]; sumsq += q; }
         gain = P.eq_relaxation / (P.eq_regularization + sumsq);
         ge = gain * nerr;
 #pragma unroll
-        for (int i = 0; i < NFB; ++i) { float p = ge * fbw[NFB - 1 - i]; fbc[i] += p; }
+        for (int i = 0; i < NFB; ++i) { if (fb_zero(NFB - 1 - i)) continue; float p = ge * fbw[NFB - 1 - i]; fbc[i] += p; }
     }
     // feedback_wind.push(&[out.0, 0.0]) :304
     if (NFB >= 2) {
