@@ -237,6 +237,11 @@ int same_batch_time_parallel_config(same_batch *rx, uint32_t max_chunks, uint32_
                                     uint32_t warmup_samples);
 /* chunks per channel the most recent process call was cut into (1 = it ran as one strict launch) */
 uint32_t same_batch_time_parallel_chunks(const same_batch *rx);
+/* 1 when that call's chunk boundaries were chosen per channel at idle instants: a channel-major f32 input of
+ * whole blocks (n_samples a multiple of the kernel's block length and of 4) on a batch whose state columns fill
+ * 64-channel workgroups.  Such a call reads the input where it lies (no transposition pass); its chunks seldom
+ * run on, so it is the faster form of the mode. */
+int same_batch_time_parallel_per_channel(const same_batch *rx);
 
 /* soft-symbol trace (SAME_BATCH_TRACE_SYMBOLS): SymbolEstimate stream of one channel
  * (rx/symsync.rs:52-71) with the input sample counter of each TED instant */

@@ -125,6 +125,11 @@ struct same_batch {
         uint64_t end_blocks = 0;
         uint64_t *d_handover = nullptr, *h_handover = nullptr;
         size_t handover_cap = 0;
+        // per-channel chunk boundaries (channel-major input): device arrays of the launch, host copies for the stitch
+        bool per_channel = false;
+        uint32_t *d_geom = nullptr;      // [own_start | row0 | nominal] x columns, then wg_blocks
+        uint32_t *h_geom = nullptr;      // pinned: own_start | row0
+        size_t geom_cap = 0;
     } slot[2];
     // time-parallel mode (SAME_BATCH_TIME_PARALLEL)
     struct TimePar {
@@ -138,7 +143,9 @@ struct same_batch {
         same::StateArrayDesc *d_desc_in = nullptr, *d_desc_out = nullptr;   // real -> wide, wide -> real
         uint32_t n_desc = 0;
         uint32_t *d_final_col = nullptr;
+        float *d_energy = nullptr; size_t energy_cap = 0;   // scout scratch
         uint32_t last_chunks = 1;
+        bool last_per_channel = false;
         std::vector<int64_t> sym_off;        // per channel: reported symbol count - the device's
         std::vector<TickSynth> synth;
     } tp;
@@ -330,8 +337,11 @@ int harvest_slot(same_batch *rx, same_batch::Slot &sl)
     if (n_bursts) HIP_TRY(hipMemcpyAsync(sl.h_bursts, sl.d_bursts, bu_bytes, hipMemcpyDeviceToHost, rx->copy_stream));
     const uint32_t n_ch = rx->P.n_channels;
     const uint32_t n_bins = sl.chunked ? sl.geom.n_chunks * n_ch : n_ch;     // state columns of the launch
-    if (sl.chunked)
+    if (sl.chunked) {
         HIP_TRY(hipMemcpyAsync(sl.h_handover, sl.d_handover, (size_t)n_bins * sizeof(uint64_t), hipMemcpyDeviceToHost, rx->copy_stream));
+        if (sl.per_channel)
+            HIP_TRY(hipMemcpyAsync(sl.h_geom, sl.d_geom, (size_t)2 * n_bins * sizeof(uint32_t), hipMemcpyDeviceToHost, rx->copy_stream));
+    }
     if (n_events || n_bursts || sl.chunked) HIP_TRY(hipStreamSynchronize(rx->copy_stream));
     auto t_copied = std::chrono::steady_clock::now();
     // Per column the device emits in time order (a lane takes its log slots one after the
@@ -412,6 +422,14 @@ int harvest_slot(same_batch *rx, same_batch::Slot &sl)
     auto stitch = [&](Part &part, same_rx_event &ev, uint32_t c) {
         const same::ChunkGeom &g = sl.geom;
         const uint64_t *hand = sl.h_handover;
+        // per-channel boundaries: own_start[k][c] and row0[k][c] as the device planned them
+        const uint32_t *own = sl.per_channel ? sl.h_geom : nullptr, *rows = sl.per_channel ? sl.h_geom + n_bins : nullptr;
+        auto owner_of = [&](uint64_t h) -> uint32_t {
+            if (!own) return g.owner_of(h);
+            uint32_t k = 0;
+            while (k + 1u < g.n_chunks && g.counter0 + own[(size_t)(k + 1u) * n_ch + c] <= h) ++k;
+            return k;
+        };
         TickSynth &ts = rx->tp.synth[c];
         int64_t off = rx->tp.sym_off[c];
         uint32_t cur = 0;
@@ -435,12 +453,12 @@ int harvest_slot(same_batch *rx, same_batch::Slot &sl)
             }
             if (!rebased) {
                 // nothing reported from this chunk: its counter started at 0 at its first row
-                const uint64_t row0 = g.counter0 + (uint64_t)cur * g.stride_blocks * g.block_len;
+                const uint64_t row0 = rows ? g.counter0 + rows[col] : g.counter0 + (uint64_t)cur * g.stride_blocks * g.block_len;
                 const int64_t est_end = (int64_t)ts.a_sym + (int64_t)((double)(sl.end_blocks - ts.a_t) / sps + 0.5);
                 off = est_end - (int64_t)((double)(sl.end_blocks - row0) / sps + 0.5);
             }
             if (h == same::kNoHandover) break;
-            const uint32_t nxt = g.owner_of(h);
+            const uint32_t nxt = owner_of(h);
             if (nxt <= cur) break;
             // the next chunk's link state at h, and where it is first idle from there on
             const uint32_t ncol = nxt * n_ch + c;
@@ -724,11 +742,12 @@ int process_time_major(same_batch *rx, const SampleT *d_x, size_t n_samples, hip
                     e = same::launch_demod_i16(tp_params(rx), rx->S, O, rx->d_taps, (const int16_t *)xr, (uint32_t)(n - n_whole), rx->counter + n_whole, stream);
                 if (e != hipSuccess) return fail(SAME_EHIP, "demod kernel launch failed: %s", hipGetErrorString(e));
             }
-            sl.chunked = true;
+            sl.chunked = true; sl.per_channel = false;
             sl.geom = geom;
             sl.end_blocks = rx->counter + n_whole;
+            rx->tp.last_per_channel = false;
         } else {
-        sl.chunked = false;
+        sl.chunked = false; sl.per_channel = false;
         rc = ensure_output(rx, sl, n, O);
         if (rc) return rc;
         HIP_TRY(same::launch_counters(sl.d_counters, sl.h_counters_dev, 0, stream));
@@ -775,6 +794,90 @@ int process_time_major(same_batch *rx, const SampleT *d_x, size_t n_samples, hip
     return SAME_OK;
 }
 
+// Time-parallel launch over a CHANNEL-MAJOR input with chunk boundaries chosen per channel at idle instants
+// (DESIGN.md 4.6): an energy scout and the boundary planner run on the device ahead of the demodulation kernel, every
+// state column then reads its own contiguous stream from its own first row.  Returns 1 when the call was handled, 0
+// when it does not qualify (the caller then takes the transposing path), < 0 on error.
+int process_channel_major_native(same_batch *rx, const float *d_x, size_t n, hipStream_t stream)
+{
+    same_batch::TimePar &tp = rx->tp;
+    if (!tp.enabled || n > ((size_t)1 << 22)) return 0;
+    same::ChunkGeom geom{};
+    same::PipeChunks pc{};
+    const uint32_t n_chunks = plan_chunks(rx, n, geom, pc);
+    if (n_chunks < 2u) return 0;
+    const uint32_t C = rx->P.n_channels, columns = n_chunks * C, fb = geom.block_len;
+    same::Params Pv = rx->P;
+    Pv.n_channels = columns; Pv.ticks = 0; Pv.trace_cap = 0;
+    // 16-byte loads from every lane's stream, whole blocks only, full 64-column workgroups
+    if (n % fb != 0 || n % 4 != 0 || fb % 4 != 0 || n < 16u * 256u || same::pipe_workgroup_channels(Pv) != (uint32_t)same::kWave ||
+        C % same::kWave != 0u) return 0;
+    same_batch::Slot &sl = rx->slot[rx->launch_seq & 1];
+    same_batch::Slot &prev = rx->slot[(rx->launch_seq & 1) ^ 1];
+    int rc = harvest_slot(rx, sl);
+    if (rc) return rc;
+    rc = ensure_wide_state(rx, columns);
+    if (rc) return rc;
+    same::Output O{};
+    rc = ensure_output(rx, sl, std::min<size_t>(n, 3 * (size_t)pc.nominal_blocks * fb + 65536), O, columns);
+    if (rc) return rc;
+    if (sl.handover_cap < columns) {
+        if (sl.d_handover) HIP_TRY(hipFree(sl.d_handover));
+        if (sl.h_handover) HIP_TRY(hipHostFree(sl.h_handover));
+        sl.d_handover = nullptr; sl.h_handover = nullptr; sl.handover_cap = 0;
+        HIP_TRY(hipMalloc((void **)&sl.d_handover, (size_t)columns * sizeof(uint64_t)));
+        HIP_TRY(hipHostMalloc((void **)&sl.h_handover, (size_t)columns * sizeof(uint64_t), hipHostMallocDefault));
+        sl.handover_cap = columns;
+    }
+    if (sl.geom_cap < columns) {
+        if (sl.d_geom) HIP_TRY(hipFree(sl.d_geom));
+        if (sl.h_geom) HIP_TRY(hipHostFree(sl.h_geom));
+        sl.d_geom = nullptr; sl.h_geom = nullptr; sl.geom_cap = 0;
+        HIP_TRY(hipMalloc((void **)&sl.d_geom, ((size_t)3 * columns + columns / same::kWave) * sizeof(uint32_t)));
+        HIP_TRY(hipHostMalloc((void **)&sl.h_geom, (size_t)2 * columns * sizeof(uint32_t), hipHostMallocDefault));
+        sl.geom_cap = columns;
+    }
+    same::TpPlan plan{};
+    plan.channels = C; plan.n_chunks = n_chunks; plan.block_len = fb;
+    plan.warmup_samples = geom.warmup_blocks * fb; plan.whole_samples = (uint32_t)n; plan.in_samples = n;
+    plan.scout_blocks = (uint32_t)(n / 256);
+    const size_t e_need = (size_t)C * plan.scout_blocks;
+    if (tp.energy_cap < e_need) {
+        if (tp.d_energy) HIP_TRY(hipFree(tp.d_energy));
+        tp.d_energy = nullptr; tp.energy_cap = 0;
+        HIP_TRY(hipMalloc((void **)&tp.d_energy, e_need * sizeof(float)));
+        tp.energy_cap = e_need;
+    }
+    uint32_t *d_own = sl.d_geom, *d_row0 = sl.d_geom + columns, *d_nom = sl.d_geom + 2 * (size_t)columns, *d_wg = sl.d_geom + 3 * (size_t)columns;
+    HIP_TRY(same::launch_counters(sl.d_counters, sl.h_counters_dev, 0, stream));
+    if (rx->timing) HIP_TRY(hipEventRecord(sl.ev_start, stream));
+    HIP_TRY(same::launch_tp_plan(d_x, plan, tp.d_energy, d_own, d_row0, d_nom, d_wg, stream));
+    HIP_TRY(same::launch_init_state(tp.Pv, tp.Sv, 0, stream));
+    HIP_TRY(same::launch_copy_state_columns(tp.d_desc_in, tp.n_desc, C, columns, nullptr, C, stream));
+    HIP_TRY(same::launch_fill_u64(sl.d_handover, columns, same::kNoHandover, stream));
+    pc.handover = sl.d_handover;
+    pc.col_row0 = d_row0; pc.col_nominal = d_nom; pc.wg_blocks = d_wg;
+    pc.in_samples = n; pc.whole_samples = (uint32_t)n;
+    hipError_t e = same::launch_demod_pipe(tp.Pv, tp.Sv, O, rx->d_taps, d_x, (uint32_t)(n / fb), rx->counter, stream, pc);
+    if (e != hipSuccess) return fail(SAME_EHIP, "time-parallel demod kernel launch failed: %s", hipGetErrorString(e));
+    // the channels' state afterwards: the last chunk's columns (they end with the input)
+    HIP_TRY(same::launch_copy_state_columns(tp.d_desc_out, tp.n_desc, columns, C, nullptr, C, stream, (n_chunks - 1u) * C));
+    sl.chunked = true; sl.per_channel = true;
+    sl.geom = geom;
+    sl.end_blocks = rx->counter + n;
+    if (rx->timing) HIP_TRY(hipEventRecord(sl.ev_stop, stream));
+    HIP_TRY(same::launch_counters(sl.d_counters, sl.h_counters_dev, 1, stream));
+    HIP_TRY(hipEventRecord(sl.ev_done, stream));
+    sl.in_flight = true;
+    sl.seq = ++rx->launch_seq;
+    rx->last_stream = stream;
+    rx->counter += n;
+    sl.end_counter = rx->counter;
+    tp.last_chunks = n_chunks; tp.last_per_channel = true;
+    rc = harvest_slot(rx, prev);          // while this launch runs, bring in the previous one
+    return rc ? rc : 1;
+}
+
 template <typename SampleT>
 int process_device_any(same_batch *rx, const SampleT *d_x, size_t n_samples, uint32_t layout, void *hip_stream)
 {
@@ -785,6 +888,10 @@ int process_device_any(same_batch *rx, const SampleT *d_x, size_t n_samples, uin
     hipStream_t stream = hip_stream == SAME_STREAM_OWN ? rx->own_stream : (hipStream_t)hip_stream;
     if (layout == SAME_LAYOUT_TIME_MAJOR) return process_time_major(rx, d_x, n_samples, stream);
     if (layout != SAME_LAYOUT_CHANNEL_MAJOR) return fail(SAME_EINVAL, "unknown layout %u", layout);
+    if constexpr (sizeof(SampleT) == 4) {
+        const int done = process_channel_major_native(rx, (const float *)d_x, n_samples, stream);
+        if (done) return done < 0 ? done : SAME_OK;
+    }
     // channel-major: transpose slabs of time through a staging buffer
     const size_t slab = std::min<size_t>(n_samples, (size_t)1 << 16);
     int rc = ensure_stage(&rx->d_stage2, &rx->stage2_bytes, slab * rx->P.n_channels * sizeof(SampleT));
@@ -945,11 +1052,14 @@ void same_batch_free(same_batch *rx)
         if (sl.ev_done) (void)hipEventDestroy(sl.ev_done);
         if (sl.d_handover) (void)hipFree(sl.d_handover);
         if (sl.h_handover) (void)hipHostFree(sl.h_handover);
+        if (sl.d_geom) (void)hipFree(sl.d_geom);
+        if (sl.h_geom) (void)hipHostFree(sl.h_geom);
     }
     if (rx->tp.blob) (void)hipFree(rx->tp.blob);
     if (rx->tp.d_desc_in) (void)hipFree(rx->tp.d_desc_in);
     if (rx->tp.d_desc_out) (void)hipFree(rx->tp.d_desc_out);
     if (rx->tp.d_final_col) (void)hipFree(rx->tp.d_final_col);
+    if (rx->tp.d_energy) (void)hipFree(rx->tp.d_energy);
     if (rx->copy_stream) (void)hipStreamDestroy(rx->copy_stream);
     if (rx->h_wake) (void)hipHostFree(rx->h_wake);
     if (rx->d_stage) (void)hipFree(rx->d_stage);
@@ -1155,6 +1265,7 @@ int same_batch_time_parallel_config(same_batch *rx, uint32_t max_chunks, uint32_
     return SAME_OK;
 }
 uint32_t same_batch_time_parallel_chunks(const same_batch *rx) { return rx ? rx->tp.last_chunks : 0; }
+int same_batch_time_parallel_per_channel(const same_batch *rx) { return rx && rx->tp.last_chunks > 1u && rx->tp.last_per_channel ? 1 : 0; }
 
 const char *same_batch_kernel_name(const same_batch *rx)
 {

@@ -137,6 +137,15 @@ struct PipeChunks {
     uint32_t stride_blocks;    // blocks between the first rows of consecutive chunks
     uint32_t nominal_blocks;   // warm-up + own range, in blocks, of every chunk but the last
     uint64_t *handover;        // [n_chunks * in_channels] input sample counter of the hand-over, ~0 = never
+    // Per-column geometry (channel-major input, boundaries chosen per channel at idle instants; null = the
+    // uniform geometry above).  Column v reads its channel's samples from col_row0[v] on and may hand over
+    // after col_nominal[v] blocks; a workgroup runs wg_blocks[workgroup] blocks at most.  Columns of chunk 0 and
+    // of the last chunk share their row within a workgroup (they load / store real state).
+    const uint32_t *col_row0;      // [n_chunks * in_channels] first sample, relative to the call's first; multiple of 4
+    const uint32_t *col_nominal;   // [n_chunks * in_channels] blocks before a hand-over is allowed
+    const uint32_t *wg_blocks;     // [workgroups]
+    uint64_t in_samples;           // channel-major input: samples per channel (the pitch of a channel)
+    uint32_t whole_samples;        // samples of the call that are whole blocks
 };
 
 // Geometry of one time-parallel call, shared by the device (which chunk's final state becomes the

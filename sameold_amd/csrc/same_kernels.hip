@@ -273,12 +273,12 @@ hipError_t launch_init_state(const Params &P, const State &S, int is_reset, hipS
 // time-parallel chunks: state columns in and out of the wide state blob
 // ---------------------------------------------------------------------------------
 __global__ void copy_state_columns_kernel(const StateArrayDesc *desc, uint32_t Csrc, uint32_t Cdst,
-                                          const uint32_t *src_col, uint32_t n_cols)
+                                          const uint32_t *src_col, uint32_t n_cols, uint32_t src_base)
 {
     const uint32_t col = blockIdx.x * blockDim.x + threadIdx.x;
     if (col >= n_cols) return;
     const StateArrayDesc d = desc[blockIdx.y];
-    const uint32_t sc = src_col ? src_col[col] : col;
+    const uint32_t sc = src_col ? src_col[col] : col + src_base;
     const uint32_t w = d.elem_words;
     const uint32_t *src = reinterpret_cast<const uint32_t *>(d.src);
     uint32_t *dst = reinterpret_cast<uint32_t *>(d.dst);
@@ -289,10 +289,11 @@ __global__ void copy_state_columns_kernel(const StateArrayDesc *desc, uint32_t C
     }
 }
 hipError_t launch_copy_state_columns(const StateArrayDesc *desc, uint32_t n_desc, uint32_t src_channels,
-                                     uint32_t dst_channels, const uint32_t *src_col, uint32_t n_cols, hipStream_t stream)
+                                     uint32_t dst_channels, const uint32_t *src_col, uint32_t n_cols, hipStream_t stream,
+                                     uint32_t src_base)
 {
     hipLaunchKernelGGL(copy_state_columns_kernel, dim3((n_cols + 255) / 256, n_desc), dim3(256), 0, stream, desc,
-                       src_channels, dst_channels, src_col, n_cols);
+                       src_channels, dst_channels, src_col, n_cols, src_base);
     return hipGetLastError();
 }
 __global__ void chunk_final_column_kernel(const uint64_t *handover, uint32_t C, ChunkGeom g, uint32_t *final_col)
@@ -315,6 +316,88 @@ hipError_t launch_chunk_final_column(const uint64_t *handover, uint32_t in_chann
     hipLaunchKernelGGL(chunk_final_column_kernel, dim3((in_channels + 255) / 256), dim3(256), 0, stream, handover, in_channels, g, final_col);
     return hipGetLastError();
 }
+// ---- per-channel chunk boundaries (channel-major input) ----------------------------------------------------------
+constexpr uint32_t kScoutBlock = 256;        // samples per energy reading (one 64-byte sector of them is read)
+__global__ void tp_scout_kernel(const float *__restrict__ x, TpPlan g, float *__restrict__ energy)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)g.channels * g.scout_blocks) return;
+    const uint32_t c = (uint32_t)(i / g.scout_blocks), j = (uint32_t)(i % g.scout_blocks);
+    const float4 *p = reinterpret_cast<const float4 *>(x + (size_t)c * g.in_samples + (size_t)j * kScoutBlock);
+    float e = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { const float4 v = p[k]; e += fabsf(v.x) + fabsf(v.y) + fabsf(v.z) + fabsf(v.w); }
+    energy[i] = e;
+}
+// One thread per channel.  A boundary may sit at a scout block j when the channel has been quiet from kQuietBefore
+// blocks before it (the carrier stopped >= 2 048 samples ago: the link layer is back to NoCarrier, 32 symbols after
+// the last one above the squelch) to one block after it; the candidate nearest to the nominal boundary k * T / K
+// wins, and where there is none within half a chunk the nominal boundary itself (the chunk before it then runs on
+// until idle, as with uniform boundaries).  "Quiet": below 8 % of the channel's loudest reading.
+__global__ void tp_boundaries_kernel(const float *__restrict__ energy, TpPlan g, uint32_t *__restrict__ own_start,
+                                     uint32_t *__restrict__ row0, uint32_t *__restrict__ nominal)
+{
+    const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= g.channels) return;
+    const float *e = energy + (size_t)c * g.scout_blocks;
+    const int NB = (int)g.scout_blocks, K = (int)g.n_chunks;
+    constexpr int kQuietBefore = 8, kQuietAfter = 1;
+    float emax = 0.0f;
+    for (int j = 0; j < NB; ++j) emax = fmaxf(emax, e[j]);
+    const float thr = 0.08f * emax;
+    auto quiet_run = [&](int j) {
+        if (j - kQuietBefore < 0 || j + kQuietAfter >= NB) return false;
+        for (int q = j - kQuietBefore; q <= j + kQuietAfter; ++q) if (e[q] > thr) return false;
+        return true;
+    };
+    const uint32_t kB = g.block_len;
+    const uint32_t min_own = 2u * g.warmup_samples;
+    uint32_t prev = 0;
+    own_start[c] = 0;
+    for (int k = 1; k < K; ++k) {
+        const int jt = (int)(((int64_t)k * NB) / K), dmax = NB / (2 * K);
+        int best = -1;
+        for (int d = 0; d <= dmax && best < 0; ++d) {
+            if (quiet_run(jt + d) && (uint32_t)(jt + d) * kScoutBlock >= prev + min_own) best = jt + d;
+            else if (d && quiet_run(jt - d) && (uint32_t)(jt - d) * kScoutBlock >= prev + min_own) best = jt - d;
+        }
+        uint32_t p = (uint32_t)(best >= 0 ? best : jt) * kScoutBlock;
+        p -= p % kB;
+        if (p < prev + min_own) p = prev + min_own - (prev + min_own) % kB + kB;
+        if (p + min_own > g.whole_samples) p = g.whole_samples - min_own - (g.whole_samples - min_own) % kB;
+        own_start[(size_t)k * g.channels + c] = p;
+        prev = p;
+    }
+    for (int k = 0; k < K; ++k) {
+        const uint32_t p = own_start[(size_t)k * g.channels + c];
+        const uint32_t r = (k == 0 || p < g.warmup_samples) ? 0u : p - g.warmup_samples;     // multiples of the block length
+        const size_t v = (size_t)k * g.channels + c;
+        row0[v] = r;
+        nominal[v] = k + 1 < K ? (own_start[(size_t)(k + 1) * g.channels + c] - r + kB - 1u) / kB : 0xffffffffu;
+    }
+}
+// One wavefront per workgroup of the demodulation launch (64 columns): how many blocks it runs at most, and -- last
+// chunk -- one common first row for its lanes, so that they all end with the input (they store the channels' state).
+__global__ void tp_align_kernel(TpPlan g, uint32_t *__restrict__ row0, uint32_t *__restrict__ wg_blocks)
+{
+    const uint32_t v = blockIdx.x * kWave + threadIdx.x;
+    const uint32_t chunk = v / g.channels;
+    uint32_t avail = (g.whole_samples - row0[v]) / g.block_len;
+    uint32_t m = avail;
+    for (int off = 32; off > 0; off >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, off));
+    if (chunk + 1u == g.n_chunks) row0[v] = g.whole_samples - m * g.block_len;
+    if (threadIdx.x == 0) wg_blocks[blockIdx.x] = m;
+}
+hipError_t launch_tp_plan(const float *x, const TpPlan &g, float *energy, uint32_t *own_start, uint32_t *row0,
+                          uint32_t *nominal, uint32_t *wg_blocks, hipStream_t stream)
+{
+    const size_t n = (size_t)g.channels * g.scout_blocks;
+    hipLaunchKernelGGL(tp_scout_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, x, g, energy);
+    hipLaunchKernelGGL(tp_boundaries_kernel, dim3((g.channels + 63) / 64), dim3(64), 0, stream, energy, g, own_start, row0, nominal);
+    hipLaunchKernelGGL(tp_align_kernel, dim3(g.n_chunks * g.channels / kWave), dim3(kWave), 0, stream, g, row0, wg_blocks);
+    return hipGetLastError();
+}
+
 __global__ void fill_u64_kernel(uint64_t *p, size_t n, uint64_t v)
 {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;

@@ -252,6 +252,18 @@ struct SampleStage {
 
     // c / C index the state arrays, cin / Cin the input (they differ for time-parallel chunks, where
     // several state columns read the same input column at different rows)
+    // xl != nullptr: channel-major input, this lane's own contiguous stream (16-byte loads: four lanes' worth of a
+    // 64-byte sector per step and lane, the rest of the sector in the next three); avail = blocks it may read
+    const SampleT *xl = nullptr;
+    uint32_t avail = 0;
+    __device__ __forceinline__ void load_block_cm(float *dst, uint32_t blk) const
+    {
+        if constexpr (std::is_same<SampleT, float>::value) {
+            const float4 *p4 = reinterpret_cast<const float4 *>(xl + (size_t)blk * kB);
+#pragma unroll
+            for (int j = 0; j < kB / 4; ++j) { const float4 v = p4[j]; dst[4 * j] = v.x; dst[4 * j + 1] = v.y; dst[4 * j + 2] = v.z; dst[4 * j + 3] = v.w; }
+        }
+    }
     __device__ __forceinline__ void load(const Params &P, const State &S, const SampleT *__restrict__ x,
                                          uint32_t c, uint32_t C, uint32_t cin, uint32_t Cin, uint64_t counter0,
                                          float *wcol, uint32_t n_blocks)
@@ -276,12 +288,19 @@ struct SampleStage {
             xp[k] = r0[c];
             mp[k] = r1[c];
         }
+        if (xl) {
+#pragma unroll
+            for (int k = 0; k < kB; ++k) { xn[0][k] = 0.0f; xn[1][k] = 0.0f; }
+            if (avail > 0u) load_block_cm(xn[0], 0u);
+            if (avail > 1u) load_block_cm(xn[1], 1u);
+        } else {
 #pragma unroll
         for (int k = 0; k < kB; ++k) { const SampleT *row = x + (size_t)k * Cin; xn[0][k] = (float)row[cin]; }
         if (n_blocks > 1u) {
             const SampleT *xb = x + (size_t)kB * Cin;
 #pragma unroll
             for (int k = 0; k < kB; ++k) { const SampleT *row = xb + (size_t)k * Cin; xn[1][k] = (float)row[cin]; }
+        }
         }
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
@@ -349,7 +368,9 @@ struct SampleStage {
     {
 #pragma unroll
         for (int k = 0; k < kB; ++k) xs[k] = xn[BUF][k];
-        if (blk + 2 < n_blocks) {
+        if (xl) {
+            if (blk + 2 < avail) load_block_cm(xn[BUF], blk + 2u);       // per lane: its stream ends where the input does
+        } else if (blk + 2 < n_blocks) {
             const SampleT *xb = x + ((size_t)(blk + 2) * kB) * Cin;      // wave-uniform
 #pragma unroll
             for (int k = 0; k < kB; ++k) { const SampleT *row = xb + (size_t)k * Cin; xn[BUF][k] = (float)row[cin]; }
@@ -648,17 +669,33 @@ __global__ __launch_bounds__((pipe_dcw<NT, LANES, SPLIT>() ? 5 : 4) * kWave, SHA
     // from the chunk's first row on; a workgroup never straddles chunks (Cin % LANES == 0, host).
     uint32_t cin = c, Cin = C, n_nominal = n_blocks;
     bool may_leave = false;                                  // chunk that hands over: leave once every lane is idle
+    int32_t row_l = 0;                                       // per-column geometry: this lane's first sample, relative to the workgroup's first lane's
+    const SampleT *xl = nullptr;                             // ... and its own stream in a channel-major input
+    uint32_t avail_l = 0;
     if (K.n_chunks > 1u) {
         const uint32_t wgs = K.in_channels / (uint32_t)LANES;
         const uint32_t chunk = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x / wgs));
         cin = (blockIdx.x - chunk * wgs) * (uint32_t)LANES + lane;
         Cin = K.in_channels;
-        const uint32_t first_block = chunk * K.stride_blocks;
-        x += (size_t)first_block * kB * Cin;
-        counter0 += (uint64_t)first_block * kB;
-        n_blocks -= first_block;                             // everything up to the end of the input is available
         may_leave = chunk + 1u < K.n_chunks;
-        n_nominal = may_leave ? K.nominal_blocks : n_blocks;
+        if (K.col_row0) {
+            const uint32_t row_abs = K.col_row0[c];
+            xl = x + (size_t)cin * K.in_samples + row_abs;
+            avail_l = (K.whole_samples - row_abs) / (uint32_t)kB;
+            n_blocks = K.wg_blocks[blockIdx.x];
+            n_nominal = may_leave ? K.col_nominal[c] : n_blocks;      // (per lane)
+            // counter0 stays wave-uniform: the first lane's row (state is loaded / stored by chunk 0 and by the last
+            // chunk only, whose lanes share their row); what a lane's row differs by goes into its event stamps
+            const uint32_t row_first = (uint32_t)__builtin_amdgcn_readfirstlane((int)row_abs);
+            counter0 += (uint64_t)row_first;
+            row_l = (int32_t)(row_abs - row_first);
+        } else {
+            const uint32_t first_block = chunk * K.stride_blocks;
+            x += (size_t)first_block * kB * Cin;
+            counter0 += (uint64_t)first_block * kB;
+            n_blocks -= first_block;                             // everything up to the end of the input is available
+            n_nominal = may_leave ? K.nominal_blocks : n_blocks;
+        }
     }
     // LDS: taps | mailboxes | squelch history [64][64] | window (logical slots kB .. 2*RING-1) | stage 1's ring (YLDS)
     float4 *tlds = reinterpret_cast<float4 *>(lds);
@@ -759,6 +796,7 @@ __global__ __launch_bounds__((pipe_dcw<NT, LANES, SPLIT>() ? 5 : 4) * kWave, SHA
         P3_HWID(0);
         SampleStage<NT, MED3, SampleT> M;
         M.ycol = wring + (2u * (uint32_t)RING) * LP + lane;           // behind the window
+        M.xl = xl; M.avail = avail_l;
         M.load(P, S, x, c, C, cin, Cin, counter0, wcol, n_blocks);
         P3_T0();
         // one step; BUF = s & 1 names the prefetch registers statically, so the loop runs two steps a turn
@@ -962,7 +1000,7 @@ __global__ __launch_bounds__((pipe_dcw<NT, LANES, SPLIT>() ? 5 : 4) * kWave, SHA
                     uint32_t burst_len = 0;
                     bool emit = false;
                     const uint32_t link = symbol_link(P, L, S, X, c, zero, sym, terr, unt,
-                                                      counter0 + (uint64_t)blk * kB + fk + 1u, &burst_len, &emit);
+                                                      counter0 + (int64_t)row_l + (uint64_t)blk * kB + fk + 1u, &burst_len, &emit);
                     if (emit && link == 3u) io1 = burst_to_pool(S, O, c);
                     io0 = 1u | (link << 1) | (emit ? 8u : 0u) | (fk << 4);
                     io2 = burst_len;
@@ -982,10 +1020,11 @@ __global__ __launch_bounds__((pipe_dcw<NT, LANES, SPLIT>() ? 5 : 4) * kWave, SHA
                 // once every lane has one the workgroup leaves (one more step: stage 4 still has to log
                 // this block's events).
                 uint32_t leave = 0u;
-                if (may_leave && !leave_posted && blk + 1u >= n_nominal) {
-                    if (!lane_done && (L.flags & F_LINK_MASK) == 0u) {
+                if (may_leave && !leave_posted) {
+                    // (n_nominal is per lane when the chunk boundaries are per channel)
+                    if (!lane_done && blk + 1u >= n_nominal && (L.flags & F_LINK_MASK) == 0u && (xl == nullptr || blk < avail_l)) {
                         lane_done = true;
-                        K.handover[c] = counter0 + (uint64_t)(blk + 1u) * kB;
+                        K.handover[c] = counter0 + (int64_t)row_l + (uint64_t)(blk + 1u) * kB;
                     }
                     if (__builtin_amdgcn_ballot_w64(!lane_done) == 0ull) { leave = 2u; leave_posted = true; stop_at = s + 1u; }
                 }
@@ -1070,7 +1109,7 @@ __global__ __launch_bounds__((pipe_dcw<NT, LANES, SPLIT>() ? 5 : 4) * kWave, SHA
                     const bool burst = (io0 & 8u) != 0u && link == 3u;
                     uint32_t burst_len = 0;
                     if (burst) { X.pending_slot = io[kWave]; burst_len = io[2 * kWave]; }
-                    symbol_io(P, L, S, O, X, c, link, (io0 & 8u) != 0u, counter0 + (uint64_t)blk * kB + fk + 1u, burst_len);
+                    symbol_io(P, L, S, O, X, c, link, (io0 & 8u) != 0u, counter0 + (int64_t)row_l + (uint64_t)blk * kB + fk + 1u, burst_len);
                 }
             }
             lds_barrier();                                             // A

@@ -37,13 +37,25 @@ hipError_t launch_demod_fast_i16(const Params &P, const State &S, const Output &
 hipError_t launch_counters(uint32_t *dev, uint32_t *host_mapped, int publish, hipStream_t stream);
 hipError_t launch_init_state(const Params &P, const State &S, int is_reset, hipStream_t stream);
 // Column copies between state blobs of different widths: for every array of `desc` (device memory,
-// n_desc entries) and every column col < n_cols, dst[row][col] = src[row][src_col ? src_col[col] : col].
+// n_desc entries) and every column col < n_cols, dst[row][col] = src[row][src_col ? src_col[col] : col + src_base].
 hipError_t launch_copy_state_columns(const StateArrayDesc *desc, uint32_t n_desc, uint32_t src_channels,
-                                     uint32_t dst_channels, const uint32_t *src_col, uint32_t n_cols, hipStream_t stream);
+                                     uint32_t dst_channels, const uint32_t *src_col, uint32_t n_cols, hipStream_t stream,
+                                     uint32_t src_base = 0);   // src_col == nullptr: source column = col + src_base
 // final_col[c] = the state column (chunk * in_channels + c) whose chunk ran to the end of the input
 hipError_t launch_chunk_final_column(const uint64_t *handover, uint32_t in_channels, ChunkGeom g, uint32_t *final_col,
                                      hipStream_t stream);
 hipError_t launch_fill_u64(uint64_t *p, size_t n, uint64_t v, hipStream_t stream);
+// Per-channel chunk boundaries for a channel-major input (time-parallel mode): an energy scout over
+// one 64-byte sector per 256-sample block, then per channel the idle instant nearest to every nominal boundary.
+struct TpPlan {
+    uint32_t channels, n_chunks, block_len, warmup_samples, whole_samples;
+    uint64_t in_samples;      // pitch of a channel in the input
+    uint32_t scout_blocks;    // whole_samples / 256
+};
+// energy [channels][scout_blocks] (scratch), own_start [n_chunks][channels], row0 / nominal [n_chunks * channels],
+// wg_blocks [n_chunks * channels / 64]
+hipError_t launch_tp_plan(const float *x, const TpPlan &g, float *energy, uint32_t *own_start, uint32_t *row0,
+                          uint32_t *nominal, uint32_t *wg_blocks, hipStream_t stream);
 hipError_t launch_transpose_f32(const float *in, float *out, uint32_t n_channels, uint32_t n_samples,
                                 hipStream_t stream);
 hipError_t launch_transpose_i16(const int16_t *in, int16_t *out, uint32_t n_channels, uint32_t n_samples,

@@ -171,6 +171,7 @@ def load_library() -> C.CDLL:
     sig("same_batch_order_after", C.c_int, vp, vp)
     sig("same_batch_time_parallel_config", C.c_int, vp, u32, u32, u32)
     sig("same_batch_time_parallel_chunks", u32, vp)
+    sig("same_batch_time_parallel_per_channel", C.c_int, vp)
     sig("same_rx_source_hash", C.c_char_p)
     sig("same_batch_process_device_i16", C.c_int, vp, vp, C.c_size_t, u32, vp)
     sig("same_batch_process_host", C.c_int, vp, vp, C.c_size_t, u32)
@@ -358,6 +359,10 @@ class SameBatchReceiver:
     def time_parallel_chunks(self) -> int:
         """Chunks per channel of the most recent process call (1 = one strict launch)."""
         return self._L.same_batch_time_parallel_chunks(self._h)
+
+    def time_parallel_per_channel(self) -> bool:
+        """Whether that call's chunk boundaries were chosen per channel (channel-major input, see same_rx.h)."""
+        return bool(self._L.same_batch_time_parallel_per_channel(self._h))
 
     def process_device_ptr(self, ptr: int, n_samples: int, layout: int = LAYOUT_TIME_MAJOR,
                            stream: Optional[int] = None, i16: bool = False):

@@ -28,6 +28,8 @@ def main():
     x = sa.synth_afsk(C, T, rate, seed=20260000, noise_sigma=noise)
     torch.cuda.synchronize()
     res = {}
+    cm = bool(os.environ.get("TP_CM"))          # feed the time-parallel batch a channel-major copy of the input
+    xc = x.t().contiguous() if cm else None
     for mode in ("strict", "tp"):
         rx = sa.SameReceiverBuilder(rate).build_batch(C, time_parallel=(mode == "tp"))
         if mode == "tp" and K:
@@ -38,13 +40,16 @@ def main():
             if rep:
                 rx.reset()
             t0 = time.perf_counter()
-            rx.process_tensor(x)
+            if mode == "tp" and cm:
+                rx.process_tensor(xc, layout=sa.LAYOUT_CHANNEL_MAJOR)
+            else:
+                rx.process_tensor(x)
             rx.sync()
             wall = time.perf_counter() - t0
             ev = rx.poll_events_np()
             ms.append((rx.last_kernel_ms(), wall * 1e3))
         res[mode] = ev
-        print(f"{mode}: chunks {rx.time_parallel_chunks() if mode == 'tp' else 1}  kernel ms / wall ms per rep: "
+        print(f"{mode}: chunks {rx.time_parallel_chunks() if mode == 'tp' else 1}{' per-channel boundaries' if mode == 'tp' and rx.time_parallel_per_channel() else ''}  kernel ms / wall ms per rep: "
               + "  ".join(f"{a:.2f}/{b:.1f}" for a, b in ms) + f"  events {len(ev)}  [{rx.kernel_name()}]", flush=True)
     a, b = by_channel(res["strict"], C), by_channel(res["tp"], C)
     sps = rate / 520.83
