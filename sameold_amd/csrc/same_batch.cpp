@@ -359,6 +359,25 @@ int harvest_slot(same_batch *rx, same_batch::Slot &sl)
         for (uint32_t i = 0; i < n_events; ++i)
             if (evs[i].kind != same::kDevEventNone) order[fill[std::min(evs[i].channel, n_bins - 1u)]++] = i;
     }
+    if (dbg && sl.chunked && sl.per_channel) {
+        // how the per-channel boundaries came out: chunk lengths (own range + warm-up) and run-ons, in samples
+        const same::ChunkGeom &g = sl.geom;
+        const uint32_t *own = sl.h_geom, *rows = sl.h_geom + n_bins;
+        double len_sum = 0, run_sum = 0; uint64_t len_max = 0, run_max = 0, n_len = 0, n_run = 0, n_inf = 0, n_late = 0;
+        for (uint32_t k = 0; k + 1u < g.n_chunks; ++k)
+            for (uint32_t c = 0; c < n_ch; ++c) {
+                const uint64_t end = own[(size_t)(k + 1u) * n_ch + c], len = end - rows[(size_t)k * n_ch + c];
+                len_sum += (double)len; len_max = std::max(len_max, len); ++n_len;
+                const uint64_t h = sl.h_handover[(size_t)k * n_ch + c];
+                if (h == same::kNoHandover) { ++n_inf; continue; }
+                const uint64_t run = h - g.counter0 > end ? h - g.counter0 - end : 0;
+                run_sum += (double)run; run_max = std::max(run_max, run); ++n_run; n_late += run > 2u * g.block_len;
+            }
+        std::fprintf(stderr, "[same] per-channel chunks: length mean %.0f max %llu samples; run-on mean %.0f max %llu, %llu of %llu columns ran on "
+                             "more than two blocks, %llu never handed over\n", len_sum / std::max<uint64_t>(n_len, 1), (unsigned long long)len_max,
+                     run_sum / std::max<uint64_t>(n_run, 1), (unsigned long long)run_max, (unsigned long long)n_late, (unsigned long long)n_run,
+                     (unsigned long long)n_inf);
+    }
     // events per real channel, cumulative (a chunked launch spreads a channel over n_chunks columns)
     std::vector<uint32_t> chan_first;
     if (sl.chunked) {

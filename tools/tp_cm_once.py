@@ -1,0 +1,23 @@
+#!/usr/bin/env python3
+"""One time-parallel pass over a channel-major input (per-channel chunk boundaries); SAME_DEBUG=1 prints how the
+boundaries came out.   python tools/tp_cm_once.py CHANNELS SECONDS [REPS]"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import sameold_amd as sa
+C = int(sys.argv[1]); secs = float(sys.argv[2]); reps = int(sys.argv[3]) if len(sys.argv) > 3 else 3
+T = int(22050 * secs)
+x = sa.synth_afsk(C, T, 22050, seed=20260000)
+xc = x.t().contiguous()
+del x
+torch.cuda.synchronize()
+rx = sa.SameReceiverBuilder(22050).build_batch(C, link_only=True, time_parallel=True)
+rx.set_kernel_timing(True)
+for r in range(reps):
+    if r:
+        rx.reset()
+    t0 = time.perf_counter()
+    rx.process_tensor(xc, layout=sa.LAYOUT_CHANNEL_MAJOR)
+    rx.sync()
+    print(f"rep {r}: kernel {rx.last_kernel_ms():.3f} ms  wall {(time.perf_counter() - t0) * 1e3:.1f} ms  chunks {rx.time_parallel_chunks()} "
+          f"per-channel {rx.time_parallel_per_channel()}  events {len(rx.poll_events_np())}", flush=True)
