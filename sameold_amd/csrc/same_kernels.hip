@@ -330,43 +330,62 @@ __global__ void tp_scout_kernel(const float *__restrict__ x, TpPlan g, float *__
     energy[i] = e;
 }
 // One thread per channel.  A boundary may sit at a scout block j when the channel has been quiet from kQuietBefore
-// blocks before it (the carrier stopped >= 2 048 samples ago: the link layer is back to NoCarrier, 32 symbols after
-// the last one above the squelch) to one block after it; the candidate nearest to the nominal boundary k * T / K
-// wins, and where there is none within half a chunk the nominal boundary itself (the chunk before it then runs on
-// until idle, as with uniform boundaries).  "Quiet": below 8 % of the channel's loudest reading.
+// blocks before it (the carrier stopped >= 3 072 samples ago: the link layer is back to NoCarrier -- 32 symbols of
+// squelch history plus the framer's invalid bytes after the last symbol above the squelch) to one block after it.
+// "Quiet": below 8 % of the channel's loudest reading.  Among all ways to cut the call at such instants into at most
+// n_chunks pieces the planner takes one that minimises the LONGEST piece (a workgroup runs as long as its longest
+// lane): bisection on that length, each trial a greedy scan that always cuts at the latest allowed instant.  Chunks
+// that are left over own nothing (they warm up and hand over at once).  Where a stretch has no quiet instant at all
+// the cut falls where the length limit puts it and the chunk before it runs on until idle, as with uniform boundaries.
 __global__ void tp_boundaries_kernel(const float *__restrict__ energy, TpPlan g, uint32_t *__restrict__ own_start,
-                                     uint32_t *__restrict__ row0, uint32_t *__restrict__ nominal)
+                                     uint32_t *__restrict__ row0, uint32_t *__restrict__ nominal, int16_t *__restrict__ lastq_all)
 {
     const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= g.channels) return;
     const float *e = energy + (size_t)c * g.scout_blocks;
+    int16_t *lastq = lastq_all + (size_t)c * g.scout_blocks;       // latest quiet instant at or before block j (-1: none)
     const int NB = (int)g.scout_blocks, K = (int)g.n_chunks;
-    constexpr int kQuietBefore = 8, kQuietAfter = 1;
+    constexpr int kQuietBefore = 12, kQuietAfter = 1;
     float emax = 0.0f;
     for (int j = 0; j < NB; ++j) emax = fmaxf(emax, e[j]);
     const float thr = 0.08f * emax;
-    auto quiet_run = [&](int j) {
-        if (j - kQuietBefore < 0 || j + kQuietAfter >= NB) return false;
-        for (int q = j - kQuietBefore; q <= j + kQuietAfter; ++q) if (e[q] > thr) return false;
-        return true;
-    };
+    {
+        int lastv = -1;
+        for (int j = 0; j < NB; ++j) {
+            bool ok = j - kQuietBefore >= 0 && j + kQuietAfter < NB;
+            if (ok) for (int t = j - kQuietBefore; t <= j + kQuietAfter; ++t) if (e[t] > thr) { ok = false; break; }
+            if (ok) lastv = j;
+            lastq[j] = (int16_t)lastv;
+        }
+    }
     const uint32_t kB = g.block_len;
-    const uint32_t min_own = 2u * g.warmup_samples;
-    uint32_t prev = 0;
+    const int min_blocks = (int)((2u * g.warmup_samples + kScoutBlock - 1u) / kScoutBlock);      // shortest own range, in scout blocks
+    // greedy cut for a given limit L (scout blocks per chunk); returns the number of chunks, cuts in cut[1..]
+    int cut[64];
+    auto plan = [&](int L, bool store) {
+        int pos = 0, n = 1;
+        while (NB - pos > L) {
+            int q = lastq[min(pos + L, NB - 1)];
+            if (q < pos + min_blocks) q = pos + L;               // no quiet instant in reach: cut at the limit
+            if (q > NB - min_blocks) q = NB - min_blocks;
+            if (q <= pos) return 1 << 20;
+            if (n < 64 && store) cut[n] = q;
+            pos = q; ++n;
+            if (n > K) return n;
+        }
+        return n;
+    };
+    int lo = (NB + K - 1) / K, hi = NB;
+    while (lo < hi) { const int mid = (lo + hi) / 2; if (plan(mid, false) <= K) hi = mid; else lo = mid + 1; }
+    const int used = plan(lo, true);
+    // `used` pieces: cuts 1 .. used-1.  Chunks that are left over sit, empty, at the last cut: the piece after it is
+    // the last chunk (K-1), which ends with the input and leaves the channel's state.
     own_start[c] = 0;
     for (int k = 1; k < K; ++k) {
-        const int jt = (int)(((int64_t)k * NB) / K), dmax = NB / (2 * K);
-        int best = -1;
-        for (int d = 0; d <= dmax && best < 0; ++d) {
-            if (quiet_run(jt + d) && (uint32_t)(jt + d) * kScoutBlock >= prev + min_own) best = jt + d;
-            else if (d && quiet_run(jt - d) && (uint32_t)(jt - d) * kScoutBlock >= prev + min_own) best = jt - d;
-        }
-        uint32_t p = (uint32_t)(best >= 0 ? best : jt) * kScoutBlock;
+        const int i = k < used ? k : used - 1;
+        uint32_t p = i >= 1 ? (uint32_t)cut[i] * kScoutBlock : 0u;
         p -= p % kB;
-        if (p < prev + min_own) p = prev + min_own - (prev + min_own) % kB + kB;
-        if (p + min_own > g.whole_samples) p = g.whole_samples - min_own - (g.whole_samples - min_own) % kB;
         own_start[(size_t)k * g.channels + c] = p;
-        prev = p;
     }
     for (int k = 0; k < K; ++k) {
         const uint32_t p = own_start[(size_t)k * g.channels + c];
@@ -391,9 +410,11 @@ __global__ void tp_align_kernel(TpPlan g, uint32_t *__restrict__ row0, uint32_t 
 hipError_t launch_tp_plan(const float *x, const TpPlan &g, float *energy, uint32_t *own_start, uint32_t *row0,
                           uint32_t *nominal, uint32_t *wg_blocks, hipStream_t stream)
 {
+    // energy: channels * scout_blocks floats, followed by as many int16 of planner scratch (the caller sizes it 1.5 x)
     const size_t n = (size_t)g.channels * g.scout_blocks;
     hipLaunchKernelGGL(tp_scout_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, x, g, energy);
-    hipLaunchKernelGGL(tp_boundaries_kernel, dim3((g.channels + 63) / 64), dim3(64), 0, stream, energy, g, own_start, row0, nominal);
+    hipLaunchKernelGGL(tp_boundaries_kernel, dim3((g.channels + 63) / 64), dim3(64), 0, stream, energy, g, own_start, row0, nominal,
+                       reinterpret_cast<int16_t *>(energy + n));
     hipLaunchKernelGGL(tp_align_kernel, dim3(g.n_chunks * g.channels / kWave), dim3(kWave), 0, stream, g, row0, wg_blocks);
     return hipGetLastError();
 }
