@@ -21,3 +21,12 @@ for r in range(reps):
     rx.sync()
     print(f"rep {r}: kernel {rx.last_kernel_ms():.3f} ms  wall {(time.perf_counter() - t0) * 1e3:.1f} ms  chunks {rx.time_parallel_chunks()} "
           f"per-channel {rx.time_parallel_per_channel()}  events {len(rx.poll_events_np())}", flush=True)
+
+if hasattr(rx._L, "same_debug_profile_pipe"):
+    import ctypes
+    buf = (ctypes.c_ulonglong * 9)()
+    rx._L.same_debug_profile_pipe(buf, 1)
+    names = ["stage 1", "stage 2", "stage 3"]
+    tot = [buf[3 * r] + buf[3 * r + 1] + buf[3 * r + 2] for r in range(3)]
+    for r in range(3):
+        print(f"  {names[r]}: work {buf[3 * r] / max(tot[r], 1):.3f}  barrier wait {buf[3 * r + 1] / max(tot[r], 1):.3f}  feedback {buf[3 * r + 2] / max(tot[r], 1):.3f}  (fractions of workgroup 0's time; total {tot[r]} clk)")
