@@ -362,11 +362,13 @@ __global__ void tp_boundaries_kernel(const float *__restrict__ energy, TpPlan g,
     const int min_blocks = (int)((2u * g.warmup_samples + kScoutBlock - 1u) / kScoutBlock);      // shortest own range, in scout blocks
     // greedy cut for a given limit L (scout blocks per chunk); returns the number of chunks, cuts in cut[1..]
     int cut[64];
-    auto plan = [&](int L, bool store) {
+    // (forced: where no quiet instant is in reach, cut at the limit -- the chunk before it then runs on until idle;
+    // only allowed when no plan without such cuts exists)
+    auto plan = [&](int L, bool store, bool forced) {
         int pos = 0, n = 1;
         while (NB - pos > L) {
             int q = lastq[min(pos + L, NB - 1)];
-            if (q < pos + min_blocks) q = pos + L;               // no quiet instant in reach: cut at the limit
+            if (q < pos + min_blocks) { if (!forced) return 1 << 20; q = pos + L; }
             if (q > NB - min_blocks) q = NB - min_blocks;
             if (q <= pos) return 1 << 20;
             if (n < 64 && store) cut[n] = q;
@@ -375,9 +377,11 @@ __global__ void tp_boundaries_kernel(const float *__restrict__ energy, TpPlan g,
         }
         return n;
     };
+    bool forced = false;
     int lo = (NB + K - 1) / K, hi = NB;
-    while (lo < hi) { const int mid = (lo + hi) / 2; if (plan(mid, false) <= K) hi = mid; else lo = mid + 1; }
-    const int used = plan(lo, true);
+    if (plan(NB - 1, false, false) > K) forced = true;          // not even the loosest limit works with clean cuts only
+    while (lo < hi) { const int mid = (lo + hi) / 2; if (plan(mid, false, forced) <= K) hi = mid; else lo = mid + 1; }
+    const int used = plan(lo, true, forced);
     // `used` pieces: cuts 1 .. used-1.  Chunks that are left over sit, empty, at the last cut: the piece after it is
     // the last chunk (K-1), which ends with the input and leaves the channel's state.
     own_start[c] = 0;
