@@ -829,7 +829,7 @@ int process_channel_major_native(same_batch *rx, const float *d_x, size_t n, hip
     same::Params Pv = rx->P;
     Pv.n_channels = columns; Pv.ticks = 0; Pv.trace_cap = 0;
     // 16-byte loads from every lane's stream, whole blocks only, full 64-column workgroups
-    if (n % fb != 0 || n % 4 != 0 || fb % 4 != 0 || n < 64u * 256u || n / 256 > 32000u || n_chunks > 63u || same::pipe_workgroup_channels(Pv) != (uint32_t)same::kWave ||
+    if (n % fb != 0 || n % 4 != 0 || fb % 4 != 0 || n < 64u * 256u || n / 256 > 7000u || n_chunks > 63u || same::pipe_workgroup_channels(Pv) != (uint32_t)same::kWave ||
         C % same::kWave != 0u) return 0;
     same_batch::Slot &sl = rx->slot[rx->launch_seq & 1];
     same_batch::Slot &prev = rx->slot[(rx->launch_seq & 1) ^ 1];
@@ -860,7 +860,7 @@ int process_channel_major_native(same_batch *rx, const float *d_x, size_t n, hip
     plan.channels = C; plan.n_chunks = n_chunks; plan.block_len = fb;
     plan.warmup_samples = geom.warmup_blocks * fb; plan.whole_samples = (uint32_t)n; plan.in_samples = n;
     plan.scout_blocks = (uint32_t)(n / 256);
-    const size_t e_need = (size_t)C * plan.scout_blocks * 3 / 2 + 64;      // energies + the planner's int16 table
+    const size_t e_need = (size_t)C * plan.scout_blocks;
     if (tp.energy_cap < e_need) {
         if (tp.d_energy) HIP_TRY(hipFree(tp.d_energy));
         tp.d_energy = nullptr; tp.energy_cap = 0;

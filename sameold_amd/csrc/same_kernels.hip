@@ -329,7 +329,7 @@ __global__ void tp_scout_kernel(const float *__restrict__ x, TpPlan g, float *__
     for (int k = 0; k < 4; ++k) { const float4 v = p[k]; e += fabsf(v.x) + fabsf(v.y) + fabsf(v.z) + fabsf(v.w); }
     energy[i] = e;
 }
-// One thread per channel.  A boundary may sit at a scout block j when the channel has been quiet from kQuietBefore
+// A boundary may sit at a scout block j when the channel has been quiet from kQuietBefore
 // blocks before it (the carrier stopped >= 3 072 samples ago: the link layer is back to NoCarrier -- 32 symbols of
 // squelch history plus the framer's invalid bytes after the last symbol above the squelch) to one block after it.
 // "Quiet": below 8 % of the channel's loudest reading.  Among all ways to cut the call at such instants into at most
@@ -337,33 +337,38 @@ __global__ void tp_scout_kernel(const float *__restrict__ x, TpPlan g, float *__
 // lane): bisection on that length, each trial a greedy scan that always cuts at the latest allowed instant.  Chunks
 // that are left over own nothing (they warm up and hand over at once).  Where a stretch has no quiet instant at all
 // the cut falls where the length limit puts it and the chunk before it runs on until idle, as with uniform boundaries.
-__global__ void tp_boundaries_kernel(const float *__restrict__ energy, TpPlan g, uint32_t *__restrict__ own_start,
-                                     uint32_t *__restrict__ row0, uint32_t *__restrict__ nominal, int16_t *__restrict__ lastq_all)
+__global__ __launch_bounds__(256) void tp_boundaries_kernel(const float *__restrict__ energy, TpPlan g, uint32_t *__restrict__ own_start,
+                                                             uint32_t *__restrict__ row0, uint32_t *__restrict__ nominal)
 {
-    const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= g.channels) return;
-    const float *e = energy + (size_t)c * g.scout_blocks;
-    int16_t *lastq = lastq_all + (size_t)c * g.scout_blocks;       // latest quiet instant at or before block j (-1: none)
+    // one workgroup per channel: the readings and the "latest quiet instant" table live in LDS, the 256 threads fill
+    // them together, thread 0 runs the (short) bisection
+    extern __shared__ float tp_lds[];
+    const uint32_t c = blockIdx.x, tid = threadIdx.x;
     const int NB = (int)g.scout_blocks, K = (int)g.n_chunks;
+    float *e = tp_lds;                                             // [NB]
+    int *lastq = reinterpret_cast<int *>(tp_lds + NB);             // [NB] latest allowed instant at or before block j (-1: none)
+    __shared__ float red[256];
     constexpr int kQuietBefore = 12, kQuietAfter = 1;
-    float emax = 0.0f;
-    for (int j = 0; j < NB; ++j) emax = fmaxf(emax, e[j]);
-    const float thr = 0.08f * emax;
-    {
-        int lastv = -1;
-        for (int j = 0; j < NB; ++j) {
-            bool ok = j - kQuietBefore >= 0 && j + kQuietAfter < NB;
-            if (ok) for (int t = j - kQuietBefore; t <= j + kQuietAfter; ++t) if (e[t] > thr) { ok = false; break; }
-            if (ok) lastv = j;
-            lastq[j] = (int16_t)lastv;
-        }
+    float m = 0.0f;
+    for (int j = (int)tid; j < NB; j += 256) { const float v = energy[(size_t)c * NB + j]; e[j] = v; m = fmaxf(m, v); }
+    red[tid] = m;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) { if ((int)tid < off) red[tid] = fmaxf(red[tid], red[tid + off]); __syncthreads(); }
+    const float thr = 0.08f * red[0];
+    for (int j = (int)tid; j < NB; j += 256) {
+        bool ok = j - kQuietBefore >= 0 && j + kQuietAfter < NB;
+        if (ok) for (int t = j - kQuietBefore; t <= j + kQuietAfter; ++t) if (e[t] > thr) { ok = false; break; }
+        lastq[j] = ok ? j : -1;
     }
+    __syncthreads();
+    if (tid != 0) return;
+    for (int j = 1; j < NB; ++j) if (lastq[j] < 0) lastq[j] = lastq[j - 1];      // running "latest allowed"
     const uint32_t kB = g.block_len;
     const int min_blocks = (int)((2u * g.warmup_samples + kScoutBlock - 1u) / kScoutBlock);      // shortest own range, in scout blocks
-    // greedy cut for a given limit L (scout blocks per chunk); returns the number of chunks, cuts in cut[1..]
+    // greedy cut for a given limit L (scout blocks per chunk): always at the latest allowed instant in reach; returns
+    // the number of pieces, cuts in cut[1..].  forced: where no allowed instant is in reach, cut at the limit -- the
+    // chunk before it then runs on until idle; only used when no plan without such cuts exists
     int cut[64];
-    // (forced: where no quiet instant is in reach, cut at the limit -- the chunk before it then runs on until idle;
-    // only allowed when no plan without such cuts exists)
     auto plan = [&](int L, bool store, bool forced) {
         int pos = 0, n = 1;
         while (NB - pos > L) {
@@ -414,11 +419,9 @@ __global__ void tp_align_kernel(TpPlan g, uint32_t *__restrict__ row0, uint32_t 
 hipError_t launch_tp_plan(const float *x, const TpPlan &g, float *energy, uint32_t *own_start, uint32_t *row0,
                           uint32_t *nominal, uint32_t *wg_blocks, hipStream_t stream)
 {
-    // energy: channels * scout_blocks floats, followed by as many int16 of planner scratch (the caller sizes it 1.5 x)
     const size_t n = (size_t)g.channels * g.scout_blocks;
     hipLaunchKernelGGL(tp_scout_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, x, g, energy);
-    hipLaunchKernelGGL(tp_boundaries_kernel, dim3((g.channels + 63) / 64), dim3(64), 0, stream, energy, g, own_start, row0, nominal,
-                       reinterpret_cast<int16_t *>(energy + n));
+    hipLaunchKernelGGL(tp_boundaries_kernel, dim3(g.channels), dim3(256), (size_t)g.scout_blocks * 8, stream, energy, g, own_start, row0, nominal);
     hipLaunchKernelGGL(tp_align_kernel, dim3(g.n_chunks * g.channels / kWave), dim3(kWave), 0, stream, g, row0, wg_blocks);
     return hipGetLastError();
 }
