@@ -349,3 +349,57 @@ def test_flush_and_reset_in_time_parallel_mode(sa):
         for c in range(n_ch):
             assert message_list(after[c])[:1] == [(sa.TRANSPORT_MSG_START, exp.encode())], f"rep {rep} channel {c}"
         rx.reset()
+
+
+@pytest.mark.parametrize("n_ch,seconds,chunks,noise", [(256, 10.0, 8, 0.0), (128, 12.0, 5, 0.0), (192, 9.0, 8, 0.05)])
+def test_per_channel_boundaries_on_channel_major_input(sa, ob, monkeypatch, n_ch, seconds, chunks, noise):
+    """A channel-major f32 input of whole blocks is read where it lies: an energy scout and a planner on the device
+    put every chunk boundary of every channel at an idle instant (no run-on), each state column streams its own
+    contiguous samples.  Same contract as the uniform cut."""
+    monkeypatch.setenv("SAME_PIPE_LANES", "64")      # (small test batches would otherwise get 16-channel workgroups)
+    rate = 22050
+    n = int(rate * seconds)
+    n -= n % 20
+    x = sa.synth_afsk(n_ch, n, rate, seed=3000 + n_ch, noise_sigma=noise)
+    ref = strict_events(sa, x, rate)
+    xc = x.t().contiguous()
+    rx = sa.SameReceiverBuilder(rate).build_batch(n_ch, time_parallel=True)
+    rx.time_parallel_config(max_chunks=chunks)
+    rx.process_tensor(xc, layout=sa.LAYOUT_CHANNEL_MAJOR)
+    rx.sync()
+    assert rx.time_parallel_chunks() == chunks and rx.time_parallel_per_channel()
+    got = rx.poll_events_np()
+    assert_contract(sa, got, ref, rate, n_ch, lambda c: sa.synth_payload(3000 + n_ch, c), exact_bursts=(noise == 0.0))
+    # and a second call continues from the state the last chunks left
+    rx.process_tensor(xc, layout=sa.LAYOUT_CHANNEL_MAJOR)
+    rx.sync()
+    again = rx.poll_events_np()
+    assert len(again[again["kind"] == 3]) >= len(got[got["kind"] == 3]) - n_ch // 8
+
+
+def test_per_channel_boundaries_fall_back_when_there_is_no_quiet_instant(sa, monkeypatch):
+    """Channels that are never quiet (noise as loud as the bursts) leave the planner no allowed instant: it cuts at the
+    length limit and the chunks run on until idle, as with uniform boundaries.  Whatever the two modes decode there
+    is noise-driven; the call must complete and the clean channels beside them still meet the contract."""
+    import torch
+    monkeypatch.setenv("SAME_PIPE_LANES", "64")
+    rate, n_ch, n = 22050, 128, 22050 * 8
+    n -= n % 20
+    x = sa.synth_afsk(n_ch, n, rate, seed=77)
+    gen = torch.Generator(device="cuda"); gen.manual_seed(5)
+    x[:, ::4] += torch.randn((n, n_ch // 4), device="cuda", generator=gen) * 3000.0      # every fourth channel drowned in noise
+    ref = strict_events(sa, x, rate)
+    rx = sa.SameReceiverBuilder(rate).build_batch(n_ch, time_parallel=True)
+    rx.time_parallel_config(max_chunks=6)
+    rx.process_tensor(x.t().contiguous(), layout=sa.LAYOUT_CHANNEL_MAJOR)
+    rx.sync()
+    assert rx.time_parallel_per_channel()
+    got = rx.poll_events_np()
+    clean = np.array([c for c in range(n_ch) if c % 4], dtype=np.uint32)
+    remap = {int(c): i for i, c in enumerate(clean)}
+
+    def only_clean(ev):
+        e = ev[np.isin(ev["channel"], clean)].copy()
+        e["channel"] = np.array([remap[int(c)] for c in e["channel"]], dtype=np.uint32)
+        return e
+    assert_contract(sa, only_clean(got), only_clean(ref), rate, len(clean), lambda i: sa.synth_payload(77, int(clean[i])))
