@@ -48,7 +48,7 @@ def parse():
     ap.add_argument("--check", type=int, default=16, help="channels of rank 0 verified against the oracle")
     ap.add_argument("--traffic", type=float, default=None, help="HBM bytes/launch from a PMC pass (profiles/)")
     ap.add_argument("--cpu-seconds", type=float, default=3.0, help="minimum wall time of the CPU baseline run")
-    ap.add_argument("--mode", choices=["auto", "strict", "time_parallel"], default="auto",
+    ap.add_argument("--mode", choices=["auto", "strict", "time_parallel", "time_parallel_time_major"], default="auto",
                     help="which mode the headline value reports: auto = time-parallel when its parity contract holds on this "
                          "run's own first pass (payload bytes of every burst and every transport message equal to strict "
                          "mode's on every channel), strict otherwise; both are always measured and reported")
@@ -117,7 +117,7 @@ def plumbing(args):
         dist.destroy_process_group()
 
 
-def run_steps(sa, rx, x, T, stream, steps, warmup, gather, barrier):
+def run_steps(sa, rx, x, T, stream, steps, warmup, gather, barrier, layout=0):
     """W untimed + K timed passes.  Each pass launches one batch; the library collects the
     previous batch's event log (copy back, ordering, transport layer) while the new launch
     runs, so a pass consumes the events of the batch before it and the last batch is
@@ -140,7 +140,7 @@ def run_steps(sa, rx, x, T, stream, steps, warmup, gather, barrier):
             rx.drop_events(len(ev))
 
     def one_pass():
-        rx.process_device_ptr(x.data_ptr(), T, sa.LAYOUT_TIME_MAJOR, stream)
+        rx.process_device_ptr(x.data_ptr(), T, layout, stream)
         consume()
 
     def drain():
@@ -278,16 +278,31 @@ def main():
     # strict mode (bit-exact), then the time-parallel mode on the same input with a second receiver
     elapsed, k_ms, first, n_bursts = run_steps(sa, rx, x, T, stream, args.steps, args.warmup, gather, barrier)
     elapsed = max_over_ranks(elapsed)
+    # ... (a) on the same time-major buffer: one row offset per workgroup, uniform chunk boundaries, chunks run on until idle
     rx_tp = sa.SameReceiverBuilder(args.rate).build_batch(C, device=local_rank, time_parallel=True)
     rx_tp.set_kernel_timing(True)
     elapsed_tp, k_ms_tp, first_tp, n_bursts_tp = run_steps(sa, rx_tp, x, T, stream, args.steps, args.warmup, gather, barrier)
     elapsed_tp = max_over_ranks(elapsed_tp)
     tp_chunks = rx_tp.time_parallel_chunks()
     tp_ok, tp_note = tp_contract(sa, first, first_tp, C, 20260000 + rank)
+    del rx_tp
+    # ... (b) on a channel-major copy of it (every channel a contiguous stream, what a capture front end that delivers
+    # per-channel buffers hands over): chunk boundaries per channel at idle instants, no run-on
+    xc = x.t().contiguous()
+    torch.cuda.synchronize()
+    rx_cm = sa.SameReceiverBuilder(args.rate).build_batch(C, device=local_rank, time_parallel=True)
+    rx_cm.set_kernel_timing(True)
+    elapsed_cm, k_ms_cm, first_cm, n_bursts_cm = run_steps(sa, rx_cm, xc, T, stream, args.steps, args.warmup, gather, barrier,
+                                                           layout=sa.LAYOUT_CHANNEL_MAJOR)
+    elapsed_cm = max_over_ranks(elapsed_cm)
+    cm_chunks, cm_per_channel = rx_cm.time_parallel_chunks(), rx_cm.time_parallel_per_channel()
+    cm_ok, cm_note = tp_contract(sa, first, first_cm, C, 20260000 + rank)
+    del rx_cm, xc
+    torch.cuda.empty_cache()
     if distributed:
-        t = torch.tensor([1.0 if tp_ok else 0.0], dtype=torch.float64, device=dev)
+        t = torch.tensor([1.0 if tp_ok else 0.0, 1.0 if cm_ok else 0.0], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MIN)
-        tp_ok = bool(t.item() > 0.5)
+        tp_ok, cm_ok = bool(t[0].item() > 0.5), bool(t[1].item() > 0.5)
 
     # HBM bytes per launch from the committed PMC passes (FETCH_SIZE x2 on gfx950 + WRITE_SIZE,
     # profiles/r01_fetch_calibration.txt); only valid for the workload it was collected on
@@ -317,16 +332,25 @@ def main():
 
     modes = {
         "strict": mode_block("strict", elapsed, k_ms, n_bursts,
-                             "bit-exact; latency-bound serial streams: 256 workgroups (16 channels each) x 4 pipeline-stage "
-                             "wavefronts, one per SIMD (DESIGN.md 4.4, 4.4b)"),
-        "time_parallel": mode_block("time_parallel", elapsed_tp, k_ms_tp, n_bursts_tp,
-                                    f"{tp_chunks} time chunks per channel = {tp_chunks * C} state columns through the same pipeline kernel "
-                                    "(strict arithmetic per chunk, chunks start from a fresh receiver one warm-up early and run on until "
-                                    "idle; DESIGN.md 4.6); kernel_ms includes the state column copies"),
+                             "bit-exact; latency-bound serial streams: 256 workgroups (16 channels each) x 5 pipeline-stage "
+                             "wavefronts (DESIGN.md 4.4, 4.4b)"),
+        "time_parallel": mode_block("time_parallel", elapsed_cm, k_ms_cm, n_bursts_cm,
+                                    f"channel-major input x[channel][t]; {cm_chunks} time chunks per channel = {cm_chunks * C} state columns through the "
+                                    "same pipeline kernel, chunk boundaries per channel at idle instants (device-side energy scout + planner, "
+                                    "inside kernel_ms), strict arithmetic per chunk (DESIGN.md 4.6)"),
+        "time_parallel_time_major": mode_block("time_parallel_time_major", elapsed_tp, k_ms_tp, n_bursts_tp,
+                                               f"time-major input; {tp_chunks} chunks per channel with uniform boundaries (one row offset per workgroup keeps "
+                                               "the loads coalesced), chunks run on until idle (DESIGN.md 4.6); kernel_ms includes the state column copies"),
     }
-    modes["time_parallel"]["chunks"] = int(tp_chunks)
-    modes["time_parallel"]["contract"] = tp_note
-    headline = args.mode if args.mode != "auto" else ("time_parallel" if tp_ok and tp_chunks > 1 else "strict")
+    modes["time_parallel"].update(chunks=int(cm_chunks), per_channel_boundaries=bool(cm_per_channel), contract=cm_note,
+                                  layout="channel-major x[channel][t]")
+    modes["time_parallel_time_major"].update(chunks=int(tp_chunks), contract=tp_note, layout="time-major x[t][channel]")
+    modes["strict"]["layout"] = "time-major x[t][channel]"
+    if args.mode != "auto":
+        headline = args.mode
+    else:
+        ok = [m for m, good, k in (("time_parallel", cm_ok, cm_chunks), ("time_parallel_time_major", tp_ok, tp_chunks)) if good and k > 1]
+        headline = max(ok, key=lambda m: modes[m]["value"]) if ok else "strict"
     hb = modes[headline]
     out = {
         "metric": "Msamples/s demodulated (batched 22.05 kHz channels) + % HBM roofline, 1/8 GPU",
@@ -345,11 +369,11 @@ def main():
             "workload": f"{C} synthetic {args.rate / 1000:g} kHz AFSK channels per GPU, f32, "
                         f"{args.seconds:g} s ({T} samples) per channel per step (BASELINE.json configs[1])",
             "channels_per_gpu": C, "samples_per_channel": T, "input_rate": args.rate,
-            "layout": "time-major x[t][channel]", "kernel": rx.kernel_name(),
+            "layout": modes[headline]["layout"], "kernel": rx.kernel_name(),
             "mode": headline,
             "parity": ("time-parallel: every burst's transmitted bytes and every transport message equal to strict mode's "
                        "(include/same_rx.h, tests/test_time_parallel.py); strict mode is bit-exact to the oracle"
-                       if headline == "time_parallel" else "bit-exact (strict op order)"),
+                       if headline != "strict" else "bit-exact (strict op order)"),
             "bursts_gathered_last_step": hb["bursts_gathered_last_step"], "events_first_step_rank0": int(len(first)),
         },
         "roofline": hb["roofline"],

@@ -52,14 +52,18 @@ for r in rows:
     v = variant(r["Kernel_Name"]) or short(r["Kernel_Name"])
     grid = int(r.get("Grid_Size_X", r.get("Grid_Size", "0")) or 0)
     if v == "share64":
-        v = "time_parallel" if not any(k == "scaled" for k in blocks) and grid <= 8 * C // 64 * 256 and len(blocks.get("time_parallel", [])) < bench["steps"] + bench["warmup"] else "scaled"
+        # launch order of bench.py: configs[1] time-parallel on the time-major buffer, then on the channel-major copy
+        # (steps + warm-up launches each), then the 32 768-channel block
+        n1 = bench["steps"] + bench["warmup"]
+        done = len(blocks.get("time_parallel_time_major", [])) + len(blocks.get("time_parallel", []))
+        v = "time_parallel_time_major" if done < n1 else ("time_parallel" if done < 2 * n1 else "scaled")
     blocks.setdefault(v, []).append(((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6, short(r["Kernel_Name"]), grid))
 log = open(os.path.join(P, "trace_bench.log")).read()
 with open(os.path.join(OUT, f"{R}_rocprofv3_kernel_trace_demod.txt"), "w") as o:
     o.write("demodulation kernel launches of\n`rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --no-cpu-baseline --check 0`\n"
             "(tools/profile_round.sh), durations in ms in launch order, per block of the bench line:\n")
     for v, lst in blocks.items():
-        n_timed = bench["steps"] if v in ("strict", "time_parallel") else max(bench["steps"], 10)
+        n_timed = bench["steps"] if v in ("strict", "time_parallel", "time_parallel_time_major") else max(bench["steps"], 10)
         d = [x[0] for x in lst]
         o.write(f"\n[{v}] {lst[0][1]}  grid {lst[0][2]}  ({len(d)} launches)\n  " + " ".join(f"{x:.3f}" for x in d) + "\n")
         o.write(f"  average of the last {min(n_timed, len(d))} (the timed ones): {sum(d[-n_timed:]) / min(n_timed, len(d)):.3f} ms; of all: {sum(d) / len(d):.3f} ms\n")
@@ -83,19 +87,21 @@ for d, name in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
     order = []
     for r in sorted(rows, key=lambda r: int(r["Dispatch_Id"])):
         v = variant(r["Kernel_Name"]) or short(r["Kernel_Name"])
-        if v == "share64":
-            v = "time_parallel" if len(seen["time_parallel"]) < 3 else "scaled"      # --steps 2 --warmup 1: three configs[1] launches, then the 32 768-channel block
+        if v == "share64":      # --steps 2 --warmup 1: three launches per configs[1] block, in bench.py's order
+            v = "time_parallel_time_major" if len(seen["time_parallel_time_major"]) < 3 else ("time_parallel" if len(seen["time_parallel"]) < 3 else "scaled")
         seen[v].append(float(r["Counter_Value"]))
     for v, vals in seen.items():
         per[v][name] = (sum(vals) / len(vals), len(vals))
-sizes = {"strict": (C, T), "time_parallel": (C, T), "scaled": (32768, 44100), "configs2_48k": (16384, 96000)}
+sizes = {"strict": (C, T), "time_parallel": (C, T), "time_parallel_time_major": (C, T), "scaled": (32768, 44100), "configs2_48k": (16384, 96000)}
 for v, d in per.items():
     if "FETCH_SIZE" not in d or "WRITE_SIZE" not in d or v not in sizes:
         continue
-    corr = 1.0 if v == "strict" else 2.0
+    # per-lane 16-byte loads (channel-major time-parallel launch) are tallied like the 64-byte rows of the 16-channel
+    # workgroups: exactly (r01_fetch_calibration.txt calibrates dword-per-lane streams at one half; a lane's 16 bytes are a full request)
+    corr = 1.0 if v in ("strict", "time_parallel") else 2.0
     cc, tt = sizes[v]
     hbm = int(round(d["FETCH_SIZE"][0] * 1024 * corr + d["WRITE_SIZE"][0] * 1024))
-    traffic.append({"mode": v if v in ("strict", "time_parallel") else "strict", "block": v, "workload": f"{cc} ch x {tt} samples",
+    traffic.append({"mode": v if v in ("strict", "time_parallel", "time_parallel_time_major") else "strict", "block": v, "workload": f"{cc} ch x {tt} samples",
                     "hbm_bytes_per_launch": hbm, "algorithmic_bytes_per_launch": 4 * cc * tt, "ratio": round(hbm / (4.0 * cc * tt), 4),
                     "fetch_size_kb": round(d["FETCH_SIZE"][0], 1), "write_size_kb": round(d["WRITE_SIZE"][0], 1), "fetch_correction": corr,
                     "launches": d["FETCH_SIZE"][1],
