@@ -96,9 +96,10 @@ sizes = {"strict": (C, T), "time_parallel": (C, T), "time_parallel_time_major": 
 for v, d in per.items():
     if "FETCH_SIZE" not in d or "WRITE_SIZE" not in d or v not in sizes:
         continue
-    # per-lane 16-byte loads (channel-major time-parallel launch) are tallied like the 64-byte rows of the 16-channel
-    # workgroups: exactly (r01_fetch_calibration.txt calibrates dword-per-lane streams at one half; a lane's 16 bytes are a full request)
-    corr = 1.0 if v in ("strict", "time_parallel") else 2.0
+    # 1.0 for the 64-byte rows of the 16-channel workgroups, 2.0 for 256-byte rows and for the per-lane 16-byte streams
+    # of the channel-major time-parallel launch (128-byte requests counted as 64: profiles/r01_fetch_calibration.txt,
+    # profiles/r02_fetch_calibration.txt)
+    corr = 1.0 if v == "strict" else 2.0
     cc, tt = sizes[v]
     hbm = int(round(d["FETCH_SIZE"][0] * 1024 * corr + d["WRITE_SIZE"][0] * 1024))
     traffic.append({"mode": v if v in ("strict", "time_parallel", "time_parallel_time_major") else "strict", "block": v, "workload": f"{cc} ch x {tt} samples",
