@@ -624,7 +624,6 @@ int harvest(same_batch *rx)
 }
 
 int harvest(same_batch *rx);
-inline const same::Params &tp_params(const same_batch *rx) { return rx->P; }
 
 // How a call of n samples is cut into time-parallel chunks: fills geom / pc and returns the number of
 // chunks, or 1 when the call runs as one strict launch (mode off, configuration without a pipeline kernel,
@@ -660,6 +659,19 @@ uint32_t plan_chunks(same_batch *rx, size_t n, same::ChunkGeom &geom, same::Pipe
         return K;
     }
     return 1;
+}
+
+// the hand-over records of a time-parallel launch: one per state column, device + pinned host copy
+int ensure_handover(same_batch::Slot &sl, uint32_t columns)
+{
+    if (sl.handover_cap >= columns) return SAME_OK;
+    if (sl.d_handover) HIP_TRY(hipFree(sl.d_handover));
+    if (sl.h_handover) HIP_TRY(hipHostFree(sl.h_handover));
+    sl.d_handover = nullptr; sl.h_handover = nullptr; sl.handover_cap = 0;
+    HIP_TRY(hipMalloc((void **)&sl.d_handover, (size_t)columns * sizeof(uint64_t)));
+    HIP_TRY(hipHostMalloc((void **)&sl.h_handover, (size_t)columns * sizeof(uint64_t), hipHostMallocDefault));
+    sl.handover_cap = columns;
+    return SAME_OK;
 }
 
 // the wide state blob: `columns` state columns laid out like the channel state, plus the copy tables
@@ -724,14 +736,8 @@ int process_time_major(same_batch *rx, const SampleT *d_x, size_t n_samples, hip
             const size_t per_column = std::min<size_t>(n, 3 * (size_t)pc.nominal_blocks * fbk + 65536);
             rc = ensure_output(rx, sl, per_column, O, columns);
             if (rc) return rc;
-            if (sl.handover_cap < columns) {
-                if (sl.d_handover) HIP_TRY(hipFree(sl.d_handover));
-                if (sl.h_handover) HIP_TRY(hipHostFree(sl.h_handover));
-                sl.d_handover = nullptr; sl.h_handover = nullptr; sl.handover_cap = 0;
-                HIP_TRY(hipMalloc((void **)&sl.d_handover, (size_t)columns * sizeof(uint64_t)));
-                HIP_TRY(hipHostMalloc((void **)&sl.h_handover, (size_t)columns * sizeof(uint64_t), hipHostMallocDefault));
-                sl.handover_cap = columns;
-            }
+            rc = ensure_handover(sl, columns);
+            if (rc) return rc;
             pc.handover = sl.d_handover;
             same_batch::TimePar &tp = rx->tp;
             HIP_TRY(same::launch_counters(sl.d_counters, sl.h_counters_dev, 0, stream));
@@ -756,9 +762,9 @@ int process_time_major(same_batch *rx, const SampleT *d_x, size_t n_samples, hip
                 // less than a block is left: the any-configuration kernel, on the channels' own state
                 const SampleT *xr = xp + n_whole * C;
                 if constexpr (sizeof(SampleT) == 4)
-                    e = same::launch_demod(tp_params(rx), rx->S, O, rx->d_taps, (const float *)xr, (uint32_t)(n - n_whole), rx->counter + n_whole, stream);
+                    e = same::launch_demod(rx->P, rx->S, O, rx->d_taps, (const float *)xr, (uint32_t)(n - n_whole), rx->counter + n_whole, stream);
                 else
-                    e = same::launch_demod_i16(tp_params(rx), rx->S, O, rx->d_taps, (const int16_t *)xr, (uint32_t)(n - n_whole), rx->counter + n_whole, stream);
+                    e = same::launch_demod_i16(rx->P, rx->S, O, rx->d_taps, (const int16_t *)xr, (uint32_t)(n - n_whole), rx->counter + n_whole, stream);
                 if (e != hipSuccess) return fail(SAME_EHIP, "demod kernel launch failed: %s", hipGetErrorString(e));
             }
             sl.chunked = true; sl.per_channel = false;
@@ -840,14 +846,8 @@ int process_channel_major_native(same_batch *rx, const float *d_x, size_t n, hip
     same::Output O{};
     rc = ensure_output(rx, sl, std::min<size_t>(n, 3 * (size_t)pc.nominal_blocks * fb + 65536), O, columns);
     if (rc) return rc;
-    if (sl.handover_cap < columns) {
-        if (sl.d_handover) HIP_TRY(hipFree(sl.d_handover));
-        if (sl.h_handover) HIP_TRY(hipHostFree(sl.h_handover));
-        sl.d_handover = nullptr; sl.h_handover = nullptr; sl.handover_cap = 0;
-        HIP_TRY(hipMalloc((void **)&sl.d_handover, (size_t)columns * sizeof(uint64_t)));
-        HIP_TRY(hipHostMalloc((void **)&sl.h_handover, (size_t)columns * sizeof(uint64_t), hipHostMallocDefault));
-        sl.handover_cap = columns;
-    }
+    rc = ensure_handover(sl, columns);
+    if (rc) return rc;
     if (sl.geom_cap < columns) {
         if (sl.d_geom) HIP_TRY(hipFree(sl.d_geom));
         if (sl.h_geom) HIP_TRY(hipHostFree(sl.h_geom));
