@@ -60,15 +60,18 @@ struct EventQueue {
     EventQueue() = default;
     EventQueue(const EventQueue &) = delete;
     EventQueue &operator=(const EventQueue &) = delete;
+    size_t base = 0;                 // how many events have left the front of the buffer since the handle was made:
+                                     // buf[i] is event number base + i (what the burst index below refers to)
     size_t size() const { return n; }
     same_rx_event *data() { return buf; }
-    void clear() { n = 0; }
+    void clear() { base += n; n = 0; }
     // drop the first `head` (already polled) events by moving the rest to the front; returns the new head (0)
     size_t compact(size_t head)
     {
         if (head == 0) return 0;
         if (head < n) std::memmove(buf, buf + head, (n - head) * sizeof(same_rx_event));
         n -= head;
+        base += head;
         return 0;
     }
     // room for `extra` more events; returns where they go, or nullptr when out of memory
@@ -86,7 +89,7 @@ struct EventQueue {
         return at;
     }
 };
-struct HarvestPart { std::vector<same_rx_event> out; std::vector<uint32_t> rearm; };
+struct HarvestPart { std::vector<same_rx_event> out; std::vector<uint32_t> rearm; std::vector<uint32_t> bursts; /* indices into out */ };
 
 using same::TickSynth;
 
@@ -169,6 +172,8 @@ struct same_batch {
     // ordered host-side event queue
     EventQueue queue;                   // events not yet polled: [queue_head, size)
     size_t queue_head = 0;
+    std::vector<size_t> burst_seq;      // event numbers (EventQueue::base + index) of the queued SAME_LINK_BURST events, ascending
+    size_t burst_seq_head = 0;          // entries before this one have been polled or dropped
     std::vector<HarvestPart> parts;     // per host thread, kept between harvests for their capacity
     // transport layer, one assembler per channel (unless SAME_BATCH_LINK_ONLY)
     std::vector<same::Transport> transport;
@@ -419,6 +424,7 @@ int harvest_slot(same_batch *rx, same_batch::Slot &sl)
             if (d.burst_slot < n_bursts) std::memcpy(ev.bytes, bursts + (size_t)d.burst_slot * same::kBurstCap, n);
             else ev.len = 0;   // pool overflow: the burst bytes were lost (SAME_EOVERFLOW is reported)
         }
+        if (d.kind == SAME_LINK_BURST) part.bursts.push_back((uint32_t)part.out.size());
         if (d.kind <= SAME_LINK_BURST) part.out.push_back(ev);
         if (!link_only) {
             same_rx_event tev;
@@ -508,7 +514,7 @@ int harvest_slot(same_batch *rx, same_batch::Slot &sl)
         rx->tp.sym_off[c] = off;
     };
     auto run_range = [&](uint32_t c0, uint32_t c1, Part &part) {
-        part.out.clear(); part.rearm.clear();
+        part.out.clear(); part.rearm.clear(); part.bursts.clear();
         part.out.reserve((size_t)(cfirst[c1] - cfirst[c0]) * 3 / 2 + 4);
         same_rx_event ev;
         std::memset(&ev, 0, sizeof(ev));
@@ -543,7 +549,7 @@ int harvest_slot(same_batch *rx, same_batch::Slot &sl)
     }
     if (rx->parts.size() < n_threads) rx->parts.resize(n_threads);
     std::vector<Part> &parts = rx->parts;
-    for (Part &p : parts) { p.out.clear(); p.rearm.clear(); }
+    for (Part &p : parts) { p.out.clear(); p.rearm.clear(); p.bursts.clear(); }
     if (n_threads == 1) {
         run_range(0, n_ch, parts[0]);
     } else {
@@ -573,9 +579,15 @@ int harvest_slot(same_batch *rx, same_batch::Slot &sl)
         // every thread's slice lands at its prefix offset; the copies run side by side
         std::vector<std::thread> pool;
         size_t at = 0;
+        if (rx->burst_seq_head > 4096 && rx->burst_seq_head * 2 > rx->burst_seq.size()) {
+            rx->burst_seq.erase(rx->burst_seq.begin(), rx->burst_seq.begin() + (std::ptrdiff_t)rx->burst_seq_head);
+            rx->burst_seq_head = 0;
+        }
+        const size_t seq0 = rx->queue.base + (size_t)(dst - rx->queue.data());
         for (size_t t = 0; t < parts.size(); ++t) {
             const Part &p = parts[t];
             if (p.out.empty()) continue;
+            for (uint32_t i : p.bursts) rx->burst_seq.push_back(seq0 + at + i);
             same_rx_event *to = dst + at;
             at += p.out.size();
             auto copy = [to, &p]() { std::memcpy(to, p.out.data(), p.out.size() * sizeof(same_rx_event)); };
@@ -1101,6 +1113,7 @@ int same_batch_reset(same_batch *rx)
     HIP_TRY(hipStreamSynchronize(rx->own_stream));
     rx->counter = 0;
     rx->queue.clear(); rx->queue_head = 0;   // event_queue.clear() receiver.rs:194
+    rx->burst_seq.clear(); rx->burst_seq_head = 0;
     for (auto &t : rx->transport) t.reset();
     for (auto &o : rx->tp.sym_off) o = 0;
     for (auto &t : rx->tp.synth) t.reset();
@@ -1204,39 +1217,32 @@ int same_batch_pack_bursts(same_batch *rx, uint32_t first_channel, uint8_t *out,
 {
     if (!rx || !n_records) return fail(SAME_EINVAL, "null argument");
     static_assert(SAME_BURST_RECORD_BYTES == 16 + SAME_EVENT_MAX_BYTES, "record layout");
-    const same_rx_event *ev = rx->queue.data() + rx->queue_head;
-    const size_t n_ev = rx->queue.size() - rx->queue_head;
-    // where each thread's bursts go: count per slice, then copy side by side
+    // the queued bursts by the index the harvest keeps (no scan of the whole queue: bursts are a fifth of the events)
+    const size_t first_seq = rx->queue.base + rx->queue_head;
+    while (rx->burst_seq_head < rx->burst_seq.size() && rx->burst_seq[rx->burst_seq_head] < first_seq) ++rx->burst_seq_head;
+    const size_t n_b = rx->burst_seq.size() - rx->burst_seq_head;
+    const size_t *seq = rx->burst_seq.data() + rx->burst_seq_head;
+    const same_rx_event *q = rx->queue.data();
+    const size_t base = rx->queue.base;
+    *n_records = n_b;
+    if (!out || !cap) return SAME_OK;
+    const size_t n_copy = std::min(n_b, cap);
     const unsigned hw = std::thread::hardware_concurrency();
-    const size_t n_threads = (out && n_ev >= 32768) ? std::min<size_t>({8u, hw ? hw : 1u}) : 1u;
-    std::vector<size_t> count(n_threads + 1, 0);
-    auto slice = [&](size_t t) { return std::pair<size_t, size_t>(n_ev * t / n_threads, n_ev * (t + 1) / n_threads); };
-    auto count_slice = [&](size_t t) {
-        size_t c = 0;
-        for (size_t i = slice(t).first; i < slice(t).second; ++i) c += ev[i].kind == SAME_LINK_BURST;
-        count[t + 1] = c;
-    };
+    const size_t n_threads = n_copy >= 8192 ? std::min<size_t>({8u, hw ? hw : 1u}) : 1u;
     auto copy_slice = [&](size_t t) {
-        size_t at = count[t];
-        for (size_t i = slice(t).first; i < slice(t).second && at < cap; ++i) {
-            if (ev[i].kind != SAME_LINK_BURST) continue;
-            uint8_t *r = out + at++ * SAME_BURST_RECORD_BYTES;
-            const uint32_t ch = ev[i].channel + first_channel, len = std::min<uint32_t>(ev[i].len, SAME_EVENT_MAX_BYTES);
-            std::memcpy(r, &ch, 4); std::memcpy(r + 4, &ev[i].sample_counter, 8); std::memcpy(r + 12, &len, 4);
-            std::memcpy(r + 16, ev[i].bytes, len);
+        for (size_t i = n_copy * t / n_threads; i < n_copy * (t + 1) / n_threads; ++i) {
+            const same_rx_event &e = q[seq[i] - base];
+            uint8_t *r = out + i * SAME_BURST_RECORD_BYTES;
+            const uint32_t ch = e.channel + first_channel, len = std::min<uint32_t>(e.len, SAME_EVENT_MAX_BYTES);
+            std::memcpy(r, &ch, 4); std::memcpy(r + 4, &e.sample_counter, 8); std::memcpy(r + 12, &len, 4);
+            std::memcpy(r + 16, e.bytes, len);
             std::memset(r + 16 + len, 0, SAME_EVENT_MAX_BYTES - len);
         }
     };
-    auto run = [&](auto fn) {
-        std::vector<std::thread> pool;
-        for (size_t t = 1; t < n_threads; ++t) pool.emplace_back(fn, t);
-        fn(0);
-        for (std::thread &th : pool) th.join();
-    };
-    run(count_slice);
-    for (size_t t = 0; t < n_threads; ++t) count[t + 1] += count[t];
-    *n_records = count[n_threads];
-    if (out && cap) run(copy_slice);
+    std::vector<std::thread> pool;
+    for (size_t t = 1; t < n_threads; ++t) pool.emplace_back(copy_slice, t);
+    copy_slice(0);
+    for (std::thread &th : pool) th.join();
     return SAME_OK;
 }
 
