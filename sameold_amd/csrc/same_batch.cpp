@@ -11,8 +11,11 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
+#include <condition_variable>
 #include <cstring>
 #include <deque>
+#include <functional>
+#include <mutex>
 #include <new>
 #include <string>
 #include <thread>
@@ -92,6 +95,70 @@ struct EventQueue {
 struct HarvestPart { std::vector<same_rx_event> out; std::vector<uint32_t> rearm; std::vector<uint32_t> bursts; /* indices into out */ };
 
 using same::TickSynth;
+
+// A few parked worker threads per batch for the harvest (replay, queue copy, burst packing): starting and joining 60
+// std::threads per launch costs more than the work some of them do, and eight ranks share one host.
+class WorkerPool {
+public:
+    ~WorkerPool()
+    {
+        { std::lock_guard<std::mutex> g(mu_); stop_ = true; }
+        cv_.notify_all();
+        for (std::thread &t : threads_) t.join();
+    }
+    // fn(0) .. fn(n - 1), the caller taking part; returns when all are done
+    void run(size_t n, const std::function<void(size_t)> &fn)
+    {
+        if (n <= 1) { if (n) fn(0); return; }
+        while (threads_.size() + 1 < n) threads_.emplace_back([this] { loop(); });
+        {
+            std::lock_guard<std::mutex> g(mu_);
+            fn_ = &fn; next_ = 0; count_ = n; pending_ = n; ++generation_;
+        }
+        cv_.notify_all();
+        work();
+        std::unique_lock<std::mutex> lk(mu_);
+        done_.wait(lk, [this] { return pending_ == 0; });
+        fn_ = nullptr;
+    }
+
+private:
+    void work()
+    {
+        for (;;) {
+            size_t i;
+            const std::function<void(size_t)> *fn;
+            {
+                std::lock_guard<std::mutex> g(mu_);
+                if (!fn_ || next_ >= count_) return;
+                i = next_++; fn = fn_;
+            }
+            (*fn)(i);
+            std::lock_guard<std::mutex> g(mu_);
+            if (--pending_ == 0) done_.notify_all();
+        }
+    }
+    void loop()
+    {
+        uint64_t seen = 0;
+        for (;;) {
+            {
+                std::unique_lock<std::mutex> lk(mu_);
+                cv_.wait(lk, [&] { return stop_ || generation_ != seen; });
+                if (stop_) return;
+                seen = generation_;
+            }
+            work();
+        }
+    }
+    std::vector<std::thread> threads_;
+    std::mutex mu_;
+    std::condition_variable cv_, done_;
+    const std::function<void(size_t)> *fn_ = nullptr;
+    size_t next_ = 0, count_ = 0, pending_ = 0;
+    uint64_t generation_ = 0;
+    bool stop_ = false;
+};
 
 struct same_batch {
     same_rx_builder builder{};
@@ -175,6 +242,7 @@ struct same_batch {
     std::vector<size_t> burst_seq;      // event numbers (EventQueue::base + index) of the queued SAME_LINK_BURST events, ascending
     size_t burst_seq_head = 0;          // entries before this one have been polled or dropped
     std::vector<HarvestPart> parts;     // per host thread, kept between harvests for their capacity
+    WorkerPool workers;
     // transport layer, one assembler per channel (unless SAME_BATCH_LINK_ONLY)
     std::vector<same::Transport> transport;
     uint64_t *h_wake = nullptr;      // host mirror of State::wake_sample (pinned, n_channels words, zero = unarmed)
@@ -561,10 +629,7 @@ int harvest_slot(same_batch *rx, same_batch::Slot &sl)
             cut[t] = (uint32_t)(std::lower_bound(cfirst.begin(), cfirst.end(), target) - cfirst.begin());
             cut[t] = std::min(std::max(cut[t], cut[t - 1u]), n_ch);
         }
-        std::vector<std::thread> pool;
-        for (uint32_t t = 1; t < n_threads; ++t) pool.emplace_back(run_range, cut[t], cut[t + 1u], std::ref(parts[t]));
-        run_range(cut[0], cut[1], parts[0]);
-        for (std::thread &th : pool) th.join();
+        rx->workers.run(n_threads, [&](size_t t) { run_range(cut[t], cut[t + 1u], parts[t]); });
     }
     auto t_replayed = std::chrono::steady_clock::now();
     size_t total = 0;
@@ -577,23 +642,21 @@ int harvest_slot(same_batch *rx, same_batch::Slot &sl)
     if (total && !dst) return fail(SAME_ENOMEM, "event queue");
     {
         // every thread's slice lands at its prefix offset; the copies run side by side
-        std::vector<std::thread> pool;
         size_t at = 0;
         if (rx->burst_seq_head > 4096 && rx->burst_seq_head * 2 > rx->burst_seq.size()) {
             rx->burst_seq.erase(rx->burst_seq.begin(), rx->burst_seq.begin() + (std::ptrdiff_t)rx->burst_seq_head);
             rx->burst_seq_head = 0;
         }
         const size_t seq0 = rx->queue.base + (size_t)(dst - rx->queue.data());
+        std::vector<std::pair<same_rx_event *, const Part *>> jobs;
         for (size_t t = 0; t < parts.size(); ++t) {
             const Part &p = parts[t];
             if (p.out.empty()) continue;
             for (uint32_t i : p.bursts) rx->burst_seq.push_back(seq0 + at + i);
-            same_rx_event *to = dst + at;
+            jobs.emplace_back(dst + at, &p);
             at += p.out.size();
-            auto copy = [to, &p]() { std::memcpy(to, p.out.data(), p.out.size() * sizeof(same_rx_event)); };
-            if (n_threads > 1 && at < total) pool.emplace_back(copy); else copy();
         }
-        for (std::thread &th : pool) th.join();
+        rx->workers.run(jobs.size(), [&](size_t j) { std::memcpy(jobs[j].first, jobs[j].second->out.data(), jobs[j].second->out.size() * sizeof(same_rx_event)); });
     }
     for (Part &p : parts) rearm.insert(rearm.end(), p.rearm.begin(), p.rearm.end());
     // force_eom_at_sample (receiver.rs:321-328) lives on the host; tell the device when to
@@ -1239,10 +1302,7 @@ int same_batch_pack_bursts(same_batch *rx, uint32_t first_channel, uint8_t *out,
             std::memset(r + 16 + len, 0, SAME_EVENT_MAX_BYTES - len);
         }
     };
-    std::vector<std::thread> pool;
-    for (size_t t = 1; t < n_threads; ++t) pool.emplace_back(copy_slice, t);
-    copy_slice(0);
-    for (std::thread &th : pool) th.join();
+    rx->workers.run(n_threads, copy_slice);
     return SAME_OK;
 }
 
