@@ -214,6 +214,7 @@ struct same_batch {
         uint32_t n_desc = 0;
         uint32_t *d_final_col = nullptr;
         float *d_energy = nullptr; size_t energy_cap = 0;   // scout scratch
+        uint32_t *d_sort = nullptr;                          // planner's bucket-sort scratch
         uint32_t last_chunks = 1;
         bool last_per_channel = false;
         std::vector<int64_t> sym_off;        // per channel: reported symbol count - the device's
@@ -703,7 +704,7 @@ int harvest(same_batch *rx);
 // How a call of n samples is cut into time-parallel chunks: fills geom / pc and returns the number of
 // chunks, or 1 when the call runs as one strict launch (mode off, configuration without a pipeline kernel,
 // call too short).
-uint32_t plan_chunks(same_batch *rx, size_t n, same::ChunkGeom &geom, same::PipeChunks &pc)
+uint32_t plan_chunks(same_batch *rx, size_t n, same::ChunkGeom &geom, same::PipeChunks &pc, uint32_t column_cap = 32768u)
 {
     same_batch::TimePar &tp = rx->tp;
     if (!tp.enabled || !rx->use_fast || rx->force_generic) return 1;
@@ -714,7 +715,10 @@ uint32_t plan_chunks(same_batch *rx, size_t n, same::ChunkGeom &geom, same::Pipe
     const double sps = (double)rx->P.input_rate / 520.83;
     // state columns the pipeline takes at full speed: 32 768 at 22.05 kHz (two workgroups per CU), 16 384 at
     // 44.1 / 48 kHz (their window ring leaves room for one)
-    const uint32_t k_cap = (rx->P.ntaps == 42u ? 32768u : 16384u) / C;
+    // (column_cap 65 536: the channel-major path, whose workgroups are composed of pieces of similar length and may come
+    // in two rounds)
+    const uint32_t k_cap = (rx->P.ntaps == 42u ? column_cap : 16384u) / C;
+    if (column_cap > 32768u) Pv.knob_pipe = 1;           // the pipeline kernel whatever the column count
     uint32_t k_max = tp.max_chunks ? std::min(tp.max_chunks, k_cap) : k_cap;
     for (uint32_t K = k_max; K >= 2u; --K) {
         Pv.n_channels = K * C;
@@ -760,6 +764,7 @@ int ensure_wide_state(same_batch *rx, uint32_t columns)
     tp.Pv = rx->P;
     tp.Pv.n_channels = columns;
     tp.Pv.ticks = 0; tp.Pv.trace_cap = 0;
+    if (columns > 32768u) tp.Pv.knob_pipe = 1;
     if (columns > tp.cap_columns) {
         if (tp.blob) HIP_TRY(hipFree(tp.blob));
         tp.blob = nullptr; tp.cap_columns = 0;
@@ -904,11 +909,11 @@ int process_channel_major_native(same_batch *rx, const float *d_x, size_t n, hip
     if (!tp.enabled || n > ((size_t)1 << 22)) return 0;
     same::ChunkGeom geom{};
     same::PipeChunks pc{};
-    const uint32_t n_chunks = plan_chunks(rx, n, geom, pc);
+    const uint32_t n_chunks = plan_chunks(rx, n, geom, pc, 65536u);
     if (n_chunks < 2u) return 0;
     const uint32_t C = rx->P.n_channels, columns = n_chunks * C, fb = geom.block_len;
     same::Params Pv = rx->P;
-    Pv.n_channels = columns; Pv.ticks = 0; Pv.trace_cap = 0;
+    Pv.n_channels = columns; Pv.ticks = 0; Pv.trace_cap = 0; Pv.knob_pipe = 1;
     // 16-byte loads from every lane's stream, whole blocks only, full 64-column workgroups
     if (n % fb != 0 || n % 4 != 0 || fb % 4 != 0 || n < 64u * 256u || n / 256 > 7000u || n_chunks > 63u || same::pipe_workgroup_channels(Pv) != (uint32_t)same::kWave ||
         C % same::kWave != 0u) return 0;
@@ -927,7 +932,7 @@ int process_channel_major_native(same_batch *rx, const float *d_x, size_t n, hip
         if (sl.d_geom) HIP_TRY(hipFree(sl.d_geom));
         if (sl.h_geom) HIP_TRY(hipHostFree(sl.h_geom));
         sl.d_geom = nullptr; sl.h_geom = nullptr; sl.geom_cap = 0;
-        HIP_TRY(hipMalloc((void **)&sl.d_geom, ((size_t)3 * columns + columns / same::kWave) * sizeof(uint32_t)));
+        HIP_TRY(hipMalloc((void **)&sl.d_geom, ((size_t)4 * columns + columns / same::kWave) * sizeof(uint32_t)));
         HIP_TRY(hipHostMalloc((void **)&sl.h_geom, (size_t)2 * columns * sizeof(uint32_t), hipHostMallocDefault));
         sl.geom_cap = columns;
     }
@@ -942,15 +947,17 @@ int process_channel_major_native(same_batch *rx, const float *d_x, size_t n, hip
         HIP_TRY(hipMalloc((void **)&tp.d_energy, e_need * sizeof(float)));
         tp.energy_cap = e_need;
     }
-    uint32_t *d_own = sl.d_geom, *d_row0 = sl.d_geom + columns, *d_nom = sl.d_geom + 2 * (size_t)columns, *d_wg = sl.d_geom + 3 * (size_t)columns;
+    uint32_t *d_own = sl.d_geom, *d_row0 = sl.d_geom + columns, *d_nom = sl.d_geom + 2 * (size_t)columns,
+             *d_perm = sl.d_geom + 3 * (size_t)columns, *d_wg = sl.d_geom + 4 * (size_t)columns;
+    if (!tp.d_sort) HIP_TRY(hipMalloc((void **)&tp.d_sort, same::tp_sort_scratch_bytes()));
     HIP_TRY(same::launch_counters(sl.d_counters, sl.h_counters_dev, 0, stream));
     if (rx->timing) HIP_TRY(hipEventRecord(sl.ev_start, stream));
-    HIP_TRY(same::launch_tp_plan(d_x, plan, tp.d_energy, d_own, d_row0, d_nom, d_wg, stream));
+    HIP_TRY(same::launch_tp_plan(d_x, plan, tp.d_energy, d_own, d_row0, d_nom, d_perm, d_wg, tp.d_sort, stream));
     HIP_TRY(same::launch_init_state(tp.Pv, tp.Sv, 0, stream));
     HIP_TRY(same::launch_copy_state_columns(tp.d_desc_in, tp.n_desc, C, columns, nullptr, C, stream));
     HIP_TRY(same::launch_fill_u64(sl.d_handover, columns, same::kNoHandover, stream));
     pc.handover = sl.d_handover;
-    pc.col_row0 = d_row0; pc.col_nominal = d_nom; pc.wg_blocks = d_wg;
+    pc.col_row0 = d_row0; pc.col_nominal = d_nom; pc.wg_blocks = d_wg; pc.col_perm = d_perm;
     pc.in_samples = n; pc.whole_samples = (uint32_t)n;
     hipError_t e = same::launch_demod_pipe(tp.Pv, tp.Sv, O, rx->d_taps, d_x, (uint32_t)(n / fb), rx->counter, stream, pc);
     if (e != hipSuccess) return fail(SAME_EHIP, "time-parallel demod kernel launch failed: %s", hipGetErrorString(e));
@@ -1154,6 +1161,7 @@ void same_batch_free(same_batch *rx)
     if (rx->tp.d_desc_out) (void)hipFree(rx->tp.d_desc_out);
     if (rx->tp.d_final_col) (void)hipFree(rx->tp.d_final_col);
     if (rx->tp.d_energy) (void)hipFree(rx->tp.d_energy);
+    if (rx->tp.d_sort) (void)hipFree(rx->tp.d_sort);
     if (rx->copy_stream) (void)hipStreamDestroy(rx->copy_stream);
     if (rx->h_wake) (void)hipHostFree(rx->h_wake);
     if (rx->d_stage) (void)hipFree(rx->d_stage);

@@ -144,6 +144,8 @@ struct PipeChunks {
     const uint32_t *col_row0;      // [n_chunks * in_channels] first sample, relative to the call's first; multiple of 4
     const uint32_t *col_nominal;   // [n_chunks * in_channels] blocks before a hand-over is allowed
     const uint32_t *wg_blocks;     // [workgroups]
+    const uint32_t *col_perm;      // [n_chunks * in_channels] grid position -> state column (pieces of similar length share a
+                                   // workgroup; chunk 0 and last-chunk columns keep workgroups of their own), null = identity
     uint64_t in_samples;           // channel-major input: samples per channel (the pitch of a channel)
     uint32_t whole_samples;        // samples of the call that are whole blocks
 };

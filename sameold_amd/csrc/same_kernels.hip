@@ -404,11 +404,57 @@ __global__ __launch_bounds__(256) void tp_boundaries_kernel(const float *__restr
         nominal[v] = k + 1 < K ? (own_start[(size_t)(k + 1) * g.channels + c] - r + kB - 1u) / kB : 0xffffffffu;
     }
 }
-// One wavefront per workgroup of the demodulation launch (64 columns): how many blocks it runs at most, and -- last
-// chunk -- one common first row for its lanes, so that they all end with the input (they store the channels' state).
-__global__ void tp_align_kernel(TpPlan g, uint32_t *__restrict__ row0, uint32_t *__restrict__ wg_blocks)
+// Pieces of similar length share a workgroup (a workgroup runs as long as its longest lane, and with more workgroups
+// than the machine holds at once the long ones should start first): a bucket sort of the state columns by length,
+// descending, in three groups that keep workgroups of their own -- last chunk (grid positions 0 .. C-1: they end with
+// the input and store the channels' state), chunk 0 (they load it), everything in between.
+constexpr uint32_t kSortBuckets = 4096, kSortBucketBlocks = 4;
+__device__ __forceinline__ void tp_sort_key(const TpPlan &g, const uint32_t *row0, const uint32_t *nominal, uint32_t v,
+                                            uint32_t *group, uint32_t *bucket)
 {
-    const uint32_t v = blockIdx.x * kWave + threadIdx.x;
+    const uint32_t chunk = v / g.channels;
+    const uint32_t avail = (g.whole_samples - row0[v]) / g.block_len;
+    *group = chunk + 1u == g.n_chunks ? 0u : (chunk == 0u ? 1u : 2u);
+    const uint32_t len = *group == 0u ? avail : min(nominal[v], avail);
+    *bucket = kSortBuckets - 1u - min(len / kSortBucketBlocks, kSortBuckets - 1u);         // longest first
+}
+__global__ void tp_sort_hist_kernel(TpPlan g, const uint32_t *row0, const uint32_t *nominal, uint32_t *hist)
+{
+    const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= g.n_chunks * g.channels) return;
+    uint32_t grp, b;
+    tp_sort_key(g, row0, nominal, v, &grp, &b);
+    atomicAdd(&hist[grp * kSortBuckets + b], 1u);
+}
+__global__ void tp_sort_scan_kernel(TpPlan g, uint32_t *hist)
+{
+    // one wavefront: exclusive prefix sums per group, each offset by where its group starts in the grid
+    const uint32_t lane = threadIdx.x;
+    const uint32_t base[3] = {0u, g.channels, 2u * g.channels};
+    for (uint32_t grp = 0; grp < 3u; ++grp) {
+        uint32_t run = base[grp];
+        for (uint32_t i = 0; i < kSortBuckets; i += kWave) {
+            const uint32_t n = hist[grp * kSortBuckets + i + lane];
+            uint32_t incl = n;
+            for (int off = 1; off < (int)kWave; off <<= 1) { const uint32_t t = (uint32_t)__shfl_up((int)incl, off); if ((int)lane >= off) incl += t; }
+            hist[grp * kSortBuckets + i + lane] = run + incl - n;
+            run += (uint32_t)__shfl((int)incl, kWave - 1);
+        }
+    }
+}
+__global__ void tp_sort_scatter_kernel(TpPlan g, const uint32_t *row0, const uint32_t *nominal, uint32_t *hist, uint32_t *perm)
+{
+    const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= g.n_chunks * g.channels) return;
+    uint32_t grp, b;
+    tp_sort_key(g, row0, nominal, v, &grp, &b);
+    perm[atomicAdd(&hist[grp * kSortBuckets + b], 1u)] = v;
+}
+// One wavefront per workgroup of the demodulation launch (64 grid positions): how many blocks it runs at most, and --
+// last chunk -- one common first row for its lanes, so that they all end with the input.
+__global__ void tp_align_kernel(TpPlan g, const uint32_t *__restrict__ perm, uint32_t *__restrict__ row0, uint32_t *__restrict__ wg_blocks)
+{
+    const uint32_t v = perm[blockIdx.x * kWave + threadIdx.x];
     const uint32_t chunk = v / g.channels;
     uint32_t avail = (g.whole_samples - row0[v]) / g.block_len;
     uint32_t m = avail;
@@ -417,14 +463,21 @@ __global__ void tp_align_kernel(TpPlan g, uint32_t *__restrict__ row0, uint32_t 
     if (threadIdx.x == 0) wg_blocks[blockIdx.x] = m;
 }
 hipError_t launch_tp_plan(const float *x, const TpPlan &g, float *energy, uint32_t *own_start, uint32_t *row0,
-                          uint32_t *nominal, uint32_t *wg_blocks, hipStream_t stream)
+                          uint32_t *nominal, uint32_t *perm, uint32_t *wg_blocks, uint32_t *sort_scratch, hipStream_t stream)
 {
     const size_t n = (size_t)g.channels * g.scout_blocks;
+    const uint32_t columns = g.n_chunks * g.channels;
     hipLaunchKernelGGL(tp_scout_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, x, g, energy);
     hipLaunchKernelGGL(tp_boundaries_kernel, dim3(g.channels), dim3(256), (size_t)g.scout_blocks * 8, stream, energy, g, own_start, row0, nominal);
-    hipLaunchKernelGGL(tp_align_kernel, dim3(g.n_chunks * g.channels / kWave), dim3(kWave), 0, stream, g, row0, wg_blocks);
+    hipError_t e = hipMemsetAsync(sort_scratch, 0, 3u * kSortBuckets * sizeof(uint32_t), stream);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(tp_sort_hist_kernel, dim3((columns + 255) / 256), dim3(256), 0, stream, g, row0, nominal, sort_scratch);
+    hipLaunchKernelGGL(tp_sort_scan_kernel, dim3(1), dim3(kWave), 0, stream, g, sort_scratch);
+    hipLaunchKernelGGL(tp_sort_scatter_kernel, dim3((columns + 255) / 256), dim3(256), 0, stream, g, row0, nominal, sort_scratch, perm);
+    hipLaunchKernelGGL(tp_align_kernel, dim3(columns / kWave), dim3(kWave), 0, stream, g, perm, row0, wg_blocks);
     return hipGetLastError();
 }
+size_t tp_sort_scratch_bytes() { return 3u * kSortBuckets * sizeof(uint32_t); }
 
 __global__ void fill_u64_kernel(uint64_t *p, size_t n, uint64_t v)
 {

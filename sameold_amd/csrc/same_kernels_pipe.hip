@@ -664,7 +664,10 @@ __global__ __launch_bounds__((pipe_dcw<NT, LANES, SPLIT>() ? 5 : 4) * kWave, SHA
     const uint32_t lane = threadIdx.x & (kWave - 1u);
     const uint32_t role = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // 0..3 = stage 1..4, 4 = DC wave
     const uint32_t C = P.n_channels;
-    const uint32_t c = blockIdx.x * (uint32_t)LANES + lane;  // C % LANES == 0 (host)
+    // state column of this lane: its grid position, or -- per-column geometry with pieces sorted by length -- what the
+    // planner's permutation puts there
+    const uint32_t c = (K.n_chunks > 1u && K.col_perm) ? K.col_perm[blockIdx.x * (uint32_t)LANES + lane]
+                                                       : blockIdx.x * (uint32_t)LANES + lane;  // C % LANES == 0 (host)
     // Time-parallel chunks: state column c = chunk * Cin + cin reads input column cin
     // from the chunk's first row on; a workgroup never straddles chunks (Cin % LANES == 0, host).
     uint32_t cin = c, Cin = C, n_nominal = n_blocks;
@@ -673,12 +676,12 @@ __global__ __launch_bounds__((pipe_dcw<NT, LANES, SPLIT>() ? 5 : 4) * kWave, SHA
     const SampleT *xl = nullptr;                             // ... and its own stream in a channel-major input
     uint32_t avail_l = 0;
     if (K.n_chunks > 1u) {
-        const uint32_t wgs = K.in_channels / (uint32_t)LANES;
-        const uint32_t chunk = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x / wgs));
-        cin = (blockIdx.x - chunk * wgs) * (uint32_t)LANES + lane;
         Cin = K.in_channels;
-        may_leave = chunk + 1u < K.n_chunks;
         if (K.col_row0) {
+            const uint32_t chunk_l = c / Cin;                                // (per lane when the columns are permuted)
+            cin = c - chunk_l * Cin;
+            // workgroups are homogeneous: all chunk 0, all last chunk, or all in between (the planner sees to it)
+            may_leave = (uint32_t)__builtin_amdgcn_readfirstlane((int)chunk_l) + 1u < K.n_chunks;
             const uint32_t row_abs = K.col_row0[c];
             xl = x + (size_t)cin * K.in_samples + row_abs;
             avail_l = (K.whole_samples - row_abs) / (uint32_t)kB;
@@ -690,6 +693,10 @@ __global__ __launch_bounds__((pipe_dcw<NT, LANES, SPLIT>() ? 5 : 4) * kWave, SHA
             counter0 += (uint64_t)row_first;
             row_l = (int32_t)(row_abs - row_first);
         } else {
+            const uint32_t wgs = K.in_channels / (uint32_t)LANES;
+            const uint32_t chunk = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x / wgs));
+            cin = (blockIdx.x - chunk * wgs) * (uint32_t)LANES + lane;
+            may_leave = chunk + 1u < K.n_chunks;
             const uint32_t first_block = chunk * K.stride_blocks;
             x += (size_t)first_block * kB * Cin;
             counter0 += (uint64_t)first_block * kB;
