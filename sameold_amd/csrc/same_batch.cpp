@@ -438,15 +438,19 @@ int harvest_slot(same_batch *rx, same_batch::Slot &sl)
         const same::ChunkGeom &g = sl.geom;
         const uint32_t *own = sl.h_geom, *rows = sl.h_geom + n_bins;
         double len_sum = 0, run_sum = 0; uint64_t len_max = 0, run_max = 0, n_len = 0, n_run = 0, n_inf = 0, n_late = 0;
+        uint32_t worst_c = 0;
         for (uint32_t k = 0; k + 1u < g.n_chunks; ++k)
             for (uint32_t c = 0; c < n_ch; ++c) {
                 const uint64_t end = own[(size_t)(k + 1u) * n_ch + c], len = end - rows[(size_t)k * n_ch + c];
-                len_sum += (double)len; len_max = std::max(len_max, len); ++n_len;
+                len_sum += (double)len; if (len > len_max) { len_max = len; worst_c = c; } ++n_len;
                 const uint64_t h = sl.h_handover[(size_t)k * n_ch + c];
                 if (h == same::kNoHandover) { ++n_inf; continue; }
                 const uint64_t run = h - g.counter0 > end ? h - g.counter0 - end : 0;
                 run_sum += (double)run; run_max = std::max(run_max, run); ++n_run; n_late += run > 2u * g.block_len;
             }
+        std::fprintf(stderr, "[same] longest piece on channel %u, its cuts:", worst_c);
+        for (uint32_t k = 0; k < g.n_chunks; ++k) std::fprintf(stderr, " %u", own[(size_t)k * n_ch + worst_c]);
+        std::fprintf(stderr, "\n");
         std::fprintf(stderr, "[same] per-channel chunks: length mean %.0f max %llu samples; run-on mean %.0f max %llu, %llu of %llu columns ran on "
                              "more than two blocks, %llu never handed over\n", len_sum / std::max<uint64_t>(n_len, 1), (unsigned long long)len_max,
                      run_sum / std::max<uint64_t>(n_run, 1), (unsigned long long)run_max, (unsigned long long)n_late, (unsigned long long)n_run,

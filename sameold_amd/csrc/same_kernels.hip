@@ -364,7 +364,10 @@ __global__ __launch_bounds__(256) void tp_boundaries_kernel(const float *__restr
     if (tid != 0) return;
     for (int j = 1; j < NB; ++j) if (lastq[j] < 0) lastq[j] = lastq[j - 1];      // running "latest allowed"
     const uint32_t kB = g.block_len;
-    const int min_blocks = (int)((2u * g.warmup_samples + kScoutBlock - 1u) / kScoutBlock);      // shortest own range, in scout blocks
+    // shortest own range, in scout blocks.  Small on purpose: with a large minimum the greedy cut below is no longer
+    // optimal (a cut just before a burst may be unreachable from the latest allowed cut before it, while the burst's
+    // end is out of reach from there), and the bisection over it no longer monotone
+    const int min_blocks = 2;
     // greedy cut for a given limit L (scout blocks per chunk): always at the latest allowed instant in reach; returns
     // the number of pieces, cuts in cut[1..].  forced: where no allowed instant is in reach, cut at the limit -- the
     // chunk before it then runs on until idle; only used when no plan without such cuts exists
