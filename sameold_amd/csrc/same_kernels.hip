@@ -453,6 +453,11 @@ __global__ void tp_sort_scatter_kernel(TpPlan g, const uint32_t *row0, const uin
     tp_sort_key(g, row0, nominal, v, &grp, &b);
     perm[atomicAdd(&hist[grp * kSortBuckets + b], 1u)] = v;
 }
+__global__ void tp_iota_kernel(uint32_t *perm, uint32_t n)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) perm[i] = i;
+}
 // One wavefront per workgroup of the demodulation launch (64 grid positions): how many blocks it runs at most, and --
 // last chunk -- one common first row for its lanes, so that they all end with the input.
 __global__ void tp_align_kernel(TpPlan g, const uint32_t *__restrict__ perm, uint32_t *__restrict__ row0, uint32_t *__restrict__ wg_blocks)
@@ -466,17 +471,21 @@ __global__ void tp_align_kernel(TpPlan g, const uint32_t *__restrict__ perm, uin
     if (threadIdx.x == 0) wg_blocks[blockIdx.x] = m;
 }
 hipError_t launch_tp_plan(const float *x, const TpPlan &g, float *energy, uint32_t *own_start, uint32_t *row0,
-                          uint32_t *nominal, uint32_t *perm, uint32_t *wg_blocks, uint32_t *sort_scratch, hipStream_t stream)
+                          uint32_t *nominal, uint32_t *perm, uint32_t *wg_blocks, uint32_t *sort_scratch, bool sorted, hipStream_t stream)
 {
     const size_t n = (size_t)g.channels * g.scout_blocks;
     const uint32_t columns = g.n_chunks * g.channels;
     hipLaunchKernelGGL(tp_scout_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, x, g, energy);
     hipLaunchKernelGGL(tp_boundaries_kernel, dim3(g.channels), dim3(256), (size_t)g.scout_blocks * 8, stream, energy, g, own_start, row0, nominal);
-    hipError_t e = hipMemsetAsync(sort_scratch, 0, 3u * kSortBuckets * sizeof(uint32_t), stream);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(tp_sort_hist_kernel, dim3((columns + 255) / 256), dim3(256), 0, stream, g, row0, nominal, sort_scratch);
-    hipLaunchKernelGGL(tp_sort_scan_kernel, dim3(1), dim3(kWave), 0, stream, g, sort_scratch);
-    hipLaunchKernelGGL(tp_sort_scatter_kernel, dim3((columns + 255) / 256), dim3(256), 0, stream, g, row0, nominal, sort_scratch, perm);
+    if (sorted) {
+        hipError_t e = hipMemsetAsync(sort_scratch, 0, 3u * kSortBuckets * sizeof(uint32_t), stream);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(tp_sort_hist_kernel, dim3((columns + 255) / 256), dim3(256), 0, stream, g, row0, nominal, sort_scratch);
+        hipLaunchKernelGGL(tp_sort_scan_kernel, dim3(1), dim3(kWave), 0, stream, g, sort_scratch);
+        hipLaunchKernelGGL(tp_sort_scatter_kernel, dim3((columns + 255) / 256), dim3(256), 0, stream, g, row0, nominal, sort_scratch, perm);
+    } else {
+        hipLaunchKernelGGL(tp_iota_kernel, dim3((columns + 255) / 256), dim3(256), 0, stream, perm, columns);
+    }
     hipLaunchKernelGGL(tp_align_kernel, dim3(columns / kWave), dim3(kWave), 0, stream, g, perm, row0, wg_blocks);
     return hipGetLastError();
 }

@@ -351,7 +351,8 @@ def test_flush_and_reset_in_time_parallel_mode(sa):
         rx.reset()
 
 
-@pytest.mark.parametrize("n_ch,seconds,chunks,noise", [(256, 10.0, 8, 0.0), (128, 12.0, 5, 0.0), (192, 9.0, 8, 0.05)])
+@pytest.mark.parametrize("n_ch,seconds,chunks,noise", [(256, 10.0, 8, 0.0), (128, 12.0, 5, 0.0), (192, 9.0, 8, 0.05),
+                                                        (4096, 6.0, 12, 0.0)])      # (49 152 columns: pieces sorted into workgroups)
 def test_per_channel_boundaries_on_channel_major_input(sa, ob, monkeypatch, n_ch, seconds, chunks, noise):
     """A channel-major f32 input of whole blocks is read where it lies: an energy scout and a planner on the device
     put every chunk boundary of every channel at an idle instant (no run-on), each state column streams its own
