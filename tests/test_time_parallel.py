@@ -368,7 +368,9 @@ def test_per_channel_boundaries_on_channel_major_input(sa, ob, monkeypatch, n_ch
     rx.time_parallel_config(max_chunks=chunks)
     rx.process_tensor(xc, layout=sa.LAYOUT_CHANNEL_MAJOR)
     rx.sync()
-    assert rx.time_parallel_chunks() == chunks and rx.time_parallel_per_channel()
+    # (the planner may settle for fewer chunks than asked for when they would own too little)
+    assert chunks - 1 <= rx.time_parallel_chunks() <= chunks and rx.time_parallel_per_channel()
+    assert n_ch * rx.time_parallel_chunks() > 32768 or n_ch < 4096      # the big case exercises the sorted order
     got = rx.poll_events_np()
     assert_contract(sa, got, ref, rate, n_ch, lambda c: sa.synth_payload(3000 + n_ch, c), exact_bursts=(noise == 0.0))
     # and a second call continues from the state the last chunks left
