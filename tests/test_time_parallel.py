@@ -89,7 +89,7 @@ def payload_len(burst, payload):
     return len(payload) if burst[:4] == payload[:4] else 4
 
 
-def assert_contract(sa, got, ref, rate, n_ch, payload_of, exact_bursts=True, what=""):
+def assert_contract(sa, got, ref, rate, n_ch, payload_of, exact_bursts=True, what="", t_end=None):
     """got / ref: event arrays (kind, channel, sample_counter, len, bytes) ordered by channel then time;
     ref from the oracle or from a strict batch.  payload_of(c) = what channel c transmits."""
     sps = rate / 520.83
@@ -100,10 +100,16 @@ def assert_contract(sa, got, ref, rate, n_ch, payload_of, exact_bursts=True, wha
     for c in range(n_ch):
         pay = payload_of(c)
         bg, br = burst_records(g[c]), burst_records(r[c])
+        if t_end is not None:
+            # a burst that ends within the event tolerance of the end of the input is reported by one mode in this call
+            # and by the other in the next
+            bg = [x for x in bg if x[2] <= t_end - 2 * tol]
+            br = [x for x in br if x[2] <= t_end - 2 * tol]
         n_bursts += len(br)
         if exact_bursts:
             assert len(bg) == len(br), f"{what} channel {c}: {len(bg)} bursts, reference {len(br)}"
-            assert message_list(g[c]) == message_list(r[c]), f"{what} channel {c}: transport messages differ"
+            if t_end is None or not any(int(e["sample_counter"]) > t_end - 8 * tol for e in list(g[c][g[c]["kind"] >= 18]) + list(r[c][r[c]["kind"] >= 18])):
+                assert message_list(g[c]) == message_list(r[c]), f"{what} channel {c}: transport messages differ"
             pairs = list(zip(bg, br))
         else:
             # noisy input: the reference itself misses a burst now and then (an early false sync inside the
@@ -372,7 +378,7 @@ def test_per_channel_boundaries_on_channel_major_input(sa, ob, monkeypatch, n_ch
     assert chunks - 1 <= rx.time_parallel_chunks() <= chunks and rx.time_parallel_per_channel()
     assert n_ch * rx.time_parallel_chunks() > 32768 or n_ch < 4096      # the big case exercises the sorted order
     got = rx.poll_events_np()
-    assert_contract(sa, got, ref, rate, n_ch, lambda c: sa.synth_payload(3000 + n_ch, c), exact_bursts=(noise == 0.0))
+    assert_contract(sa, got, ref, rate, n_ch, lambda c: sa.synth_payload(3000 + n_ch, c), exact_bursts=(noise == 0.0), t_end=n)
     # and a second call continues from the state the last chunks left
     rx.process_tensor(xc, layout=sa.LAYOUT_CHANNEL_MAJOR)
     rx.sync()
