@@ -458,7 +458,8 @@ __device__ __forceinline__ void rx_end(const Params &P, Lane &L, Ctx &X)
 // ---------------------------------------------------------------------------------
 template <typename Ctx>
 __device__ __forceinline__ uint32_t rx_symbol(const Params &P, Lane &L, const State &S, Ctx &X,
-                                              uint32_t c, float zero, float sym, uint32_t *burst_len)
+                                              uint32_t c, float zero, float sym, uint32_t *burst_len,
+                                              bool have_pre = false, float pre0 = 0.0f, float pre1 = 0.0f)
 {
     // Written as straight-line selects wherever the work is a few integer operations: a
     // 64-lane wavefront has lanes in every state at once, so every branch region executes
@@ -471,7 +472,8 @@ __device__ __forceinline__ uint32_t rx_symbol(const Params &P, Lane &L, const St
     // the symbol the equalizer may step over below (history offset 14/15 from the oldest sample
     // once this symbol is in): slots slot+16/+17, distinct from the two written here, so the
     // reads are issued first and their latency hides under the squelch arithmetic
-    const float eq_in0 = X.hist_get((slot + 16u) & 63u), eq_in1 = X.hist_get((slot + 17u) & 63u);
+    // (have_pre: the caller has read them already, together with the symbol itself -- one LDS round trip instead of two)
+    const float eq_in0 = have_pre ? pre0 : X.hist_get((slot + 16u) & 63u), eq_in1 = have_pre ? pre1 : X.hist_get((slot + 17u) & 63u);
     X.hist_put(slot, zero);
     X.hist_put(slot + 1u, sym);
     const uint32_t fill = min(64u, L.sq_fill + 2u);
@@ -704,9 +706,11 @@ __device__ __forceinline__ bool ted_timing(const Params &P, Lane &L, float sa_lo
 // count of the next instant (next_fire_count); ted_commit, once the sample is there, selects by its sign bit.
 struct TedAhead {
     float zero;              // h1 after the shift: the symbol estimate's first sample (and the TED's middle tap)
-    float terr[2];           // [0]: the new sample is >= +0.0, [1]: it carries a sign bit
-    float avg[2], inst[2];   // period_avg / period_inst after the instant
-    int cstar[2];            // next_fire_count(period_inst, 0)
+    // ..0: the new sample is >= +0.0, ..1: it carries a sign bit.  Scalars, selected -- never indexed: the struct lives
+    // across loop iterations in the pipeline's stage 2, and a runtime index would send it to scratch memory
+    float terr0, terr1;
+    float avg0, avg1, inst0, inst1;   // period_avg / period_inst after the instant
+    int cstar0, cstar1;               // next_fire_count(period_inst, 0)
     uint32_t flags;          // with the TED phase toggled
     bool have;
 };
@@ -723,10 +727,8 @@ __device__ __forceinline__ TedAhead ted_ahead(const Params &P, const Lane &L, fl
     const bool bw_locked = (L.flags & F_BW_LOCKED) != 0;
     const float alpha = bw_locked ? P.alpha_locked : P.alpha_unlocked;
     const float beta = bw_locked ? P.beta_locked : P.beta_unlocked;
-    const float inst0 = L.period_inst + offset;
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-        const float sg2 = k ? -1.0f : 1.0f;                 // rs_signum(h2)
+    const float inst_plain = L.period_inst + offset;
+    auto half = [&](float sg2, float *terr_out, float *avg_out, float *inst_out, int *cstar_out) {   // sg2 = rs_signum(h2)
         const float dsg = rs_signum(h0) - sg2;
         const float terr = h1 * dsg;
         const float e0 = terr - q;
@@ -737,24 +739,26 @@ __device__ __forceinline__ TedAhead ted_ahead(const Params &P, const Lane &L, fl
         const float t = avg1 + ai;
         float inst1 = t + offset;
         inst1 = (inst1 < 0.0f) ? avg1 : inst1;
-        A.terr[k] = terr;
-        A.avg[k] = A.have ? avg1 : L.period_avg;
-        A.inst[k] = A.have ? inst1 : inst0;
-        A.cstar[k] = next_fire_count(A.inst[k], 0u);
-    }
+        *terr_out = terr;
+        *avg_out = A.have ? avg1 : L.period_avg;
+        *inst_out = A.have ? inst1 : inst_plain;
+        *cstar_out = next_fire_count(*inst_out, 0u);
+    };
+    half(1.0f, &A.terr0, &A.avg0, &A.inst0, &A.cstar0);
+    half(-1.0f, &A.terr1, &A.avg1, &A.inst1, &A.cstar1);
     return A;
 }
 __device__ __forceinline__ bool ted_commit(Lane &L, const TedAhead &A, float sa_low, float *zero_out, float *sym_out,
                                            float *terr_out, int *cstar_out)
 {
-    const int k = (int)(__float_as_uint(sa_low) >> 31);     // the sign bit, as rs_signum reads it
+    const bool neg = (__float_as_uint(sa_low) >> 31) != 0u;     // the sign bit, as rs_signum reads it
     L.h0 = L.h1; L.h1 = L.h2; L.h2 = sa_low;
     L.flags = A.flags;
-    L.period_avg = A.avg[k];
-    L.period_inst = A.inst[k];
+    L.period_avg = neg ? A.avg1 : A.avg0;
+    L.period_inst = neg ? A.inst1 : A.inst0;
     L.until_next_ted = L.period_inst;                       // receiver.rs:382
-    *zero_out = A.zero; *sym_out = sa_low; *terr_out = A.terr[k];
-    *cstar_out = A.cstar[k];
+    *zero_out = A.zero; *sym_out = sa_low; *terr_out = neg ? A.terr1 : A.terr0;
+    *cstar_out = neg ? A.cstar1 : A.cstar0;
     return A.have;
 }
 
@@ -765,7 +769,8 @@ __device__ __forceinline__ bool ted_commit(Lane &L, const TedAhead &A, float sa_
 template <typename Ctx>
 __device__ __forceinline__ uint32_t symbol_link(const Params &P, Lane &L, const State &S, Ctx &X, uint32_t c,
                                                 float zero, float sym, float terr, float until_next_ted,
-                                                uint64_t counter, uint32_t *burst_len, bool *emit)
+                                                uint64_t counter, uint32_t *burst_len, bool *emit,
+                                                bool have_pre = false, float pre0 = 0.0f, float pre1 = 0.0f)
 {
     if (P.trace_cap) {
         uint32_t n = S.trace_n[c];
@@ -777,7 +782,7 @@ __device__ __forceinline__ uint32_t symbol_link(const Params &P, Lane &L, const 
         S.trace_n[c] = n + 1;
     }
     X.mark(2);
-    uint32_t link = rx_symbol(P, L, S, X, c, zero, sym, burst_len);
+    uint32_t link = rx_symbol(P, L, S, X, c, zero, sym, burst_len, have_pre, pre0, pre1);
     X.mark(5);
     const uint32_t last = (L.flags & F_LINK_MASK) >> F_LINK_SHIFT;
     *emit = link != last || link == 3u;

@@ -34,7 +34,7 @@ struct ProfMarks {
 // one-wavefront kernel: shader-clock time per section of the block loop, summed over the blocks of wavefront 0
 static __device__ unsigned long long g_same_prof[9];
 // per stage of workgroup 0: cycles working, waiting at the step barrier, handling feedback
-static __device__ unsigned long long g_same_prof_pipe[9];
+static __device__ unsigned long long g_same_prof_pipe[15];    // roles 0..4 (4 = DC wave)
 // [role] = HW_ID of workgroup 0's wavefront in that role (SIMD = bits 5:4); [5] cycles stage 2 polled
 // the helper for the filter magnitudes, [6] cycles the helper spent filtering, [7] second instants of a block
 static __device__ unsigned long long g_same_prof_hw[8];
@@ -85,14 +85,14 @@ static __device__ unsigned long long g_same_prof_s2[8];
 #define PIPE_PROFILE_EXPORTS()                                                                                  \
     static int prof_fetch_(const void *sym, unsigned long long *out, size_t n, int reset)                       \
     {                                                                                                           \
-        unsigned long long z[9] = {0};                                                                          \
+        unsigned long long z[15] = {0};                                                                         \
         if (hipMemcpyFromSymbol(out, sym, n * sizeof(unsigned long long)) != hipSuccess) return -1;             \
         if (reset && hipMemcpyToSymbol(sym, z, n * sizeof(unsigned long long)) != hipSuccess) return -1;        \
         return 0;                                                                                               \
     }                                                                                                           \
     extern "C" int same_debug_profile_s2(unsigned long long *out8, int reset) { return prof_fetch_(HIP_SYMBOL(same::g_same_prof_s2), out8, 8, reset); }   \
     extern "C" int same_debug_profile_hw(unsigned long long *out8, int reset) { return prof_fetch_(HIP_SYMBOL(same::g_same_prof_hw), out8, 8, reset); }   \
-    extern "C" int same_debug_profile_pipe(unsigned long long *out9, int reset) { return prof_fetch_(HIP_SYMBOL(same::g_same_prof_pipe), out9, 9, reset); }
+    extern "C" int same_debug_profile_pipe(unsigned long long *out15, int reset) { return prof_fetch_(HIP_SYMBOL(same::g_same_prof_pipe), out15, 15, reset); }
 #else
 namespace same { struct ProfMarks { __device__ __forceinline__ void mark(int) {} }; }
 #define PIPE_PROF_TAP_PAD 0

@@ -29,7 +29,7 @@ for r in range(reps):
 
 if hasattr(rx._L, "same_debug_profile"):
     import ctypes
-    buf = (ctypes.c_ulonglong * 9)()
+    buf = (ctypes.c_ulonglong * 15)()
     rx._L.same_debug_profile(buf, 1)
     names = ["sample phase", "matched filter", "timing loop", "squelch", "equalizer step", "byte/framer", "events+ticks", "post/latch", "(one mark)"]
     tot = sum(buf)
@@ -40,21 +40,23 @@ if hasattr(rx._L, "same_debug_profile"):
 
 if hasattr(rx._L, "same_debug_profile_pipe") and "pipe" in rx.kernel_name():
     import ctypes
-    buf = (ctypes.c_ulonglong * 9)()
+    buf = (ctypes.c_ulonglong * 15)()
     rx._L.same_debug_profile_pipe(buf, 1)
     nstep = reps * (T // {22050: 20, 48000: 32, 44100: 36}.get(rate, 32) + 3)
     if os.environ.get("SAME_P3_MARKS"):
         for name, v in zip(["other (mailbox, barrier, idle)", "squelch", "equalizer step", "byte/framer", "events+wake-ups", "-"], buf):
             print(f"  stage 3 {name:32s} {v/nstep:8.1f} clk/step (each mark costs ~340 clk, charged to the section after it)")
     else:
-      for r, name in enumerate(["stage 1 (sample phase)", "stage 2 (filters + timing)", "stage 3 (symbol path)"]):
+      for r, name in enumerate(["stage 1 (sample phase)", "stage 2 (filters + timing)", "stage 3 (symbol path)", "stage 4 (helper: filters, events)", "DC wave"]):
         w, b, f = buf[3 * r], buf[3 * r + 1], buf[3 * r + 2]
+        if w + b + f == 0:
+            continue
         print(f"  {name:28s} work {w/nstep:8.1f}  barrier wait {b/nstep:8.1f}  feedback {f/nstep:8.1f}  clk/step (total {(w+b+f)/nstep:8.1f})")
     if hasattr(rx._L, "same_debug_profile_hw"):
         hw = (ctypes.c_ulonglong * 8)()
         rx._L.same_debug_profile_hw(hw, 1)
-        print("  HW_ID (SIMD) per role [stage1, stage2, stage3, stage4]:",
-              [f"{int(v) & 0xffffffff:#x} (simd {(int(v) >> 4) & 3})" for v in hw[:4]])
+        print("  HW_ID (SIMD) per role [stage1, stage2, stage3, stage4, DC wave]:",
+              [f"{int(v) & 0xffffffff:#x} (simd {(int(v) >> 4) & 3}, wave slot {int(v) & 15})" for v in hw[:5]])
         print(f"  stage 2 polled stage 4 for the space magnitude {hw[5]/nstep:8.1f} clk/step; stage 4's space filter took {hw[6]/nstep:8.1f} clk/step")
         print(f"  second TED instants inside one block (all workgroups): {int(hw[7])}")
 

@@ -24,7 +24,7 @@ for r in range(reps):
 
 if hasattr(rx._L, "same_debug_profile_pipe"):
     import ctypes
-    buf = (ctypes.c_ulonglong * 9)()
+    buf = (ctypes.c_ulonglong * 15)()
     rx._L.same_debug_profile_pipe(buf, 1)
     names = ["stage 1", "stage 2", "stage 3"]
     tot = [buf[3 * r] + buf[3 * r + 1] + buf[3 * r + 2] for r in range(3)]
