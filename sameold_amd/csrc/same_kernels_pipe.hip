@@ -141,6 +141,49 @@ __device__ __forceinline__ float demod_half(const float4 *tlds, const float *wri
     return rs_hypot(acc.x, acc.y);
 }
 
+// Both matched filters in one wavefront, their accumulation chains interleaved (the dependent packed adds of one
+// hide under the other's): the two magnitudes separately.
+template <int NT, int RING>
+__device__ __forceinline__ void demod_pair(const float4 *tlds, const float *wring, uint32_t lane, uint32_t newest, float *hm_out, float *hs_out)
+{
+    constexpr int CH = 14;
+    float2v am = {0.0f, 0.0f}, as = {0.0f, 0.0f};
+    const float *wm = wring + ((int)newest + RING - (CH - 1)) * (int)kWave + (int)lane;
+#pragma unroll 1
+    for (int base = 0; base + CH <= NT; base += CH) {
+        float w[CH];
+        float4 h[CH];
+#pragma unroll
+        for (int j = 0; j < CH; ++j) w[j] = wm[(CH - 1 - j) * (int)kWave];
+        wm -= CH * (int)kWave;
+#pragma unroll
+        for (int j = 0; j < CH; ++j) h[j] = tlds[base + j];
+#pragma unroll
+        for (int j = 0; j < CH; ++j) {
+            const float2v x2 = {w[j], w[j]};
+            const float2v hm = {h[j].x, h[j].y}, hs = {h[j].z, h[j].w};
+            const float2v pm = x2 * hm, ps = x2 * hs;
+            am += pm; as += ps;
+        }
+    }
+    constexpr int REM = NT % CH;
+    if (REM) {
+        float w[REM ? REM : 1];
+#pragma unroll
+        for (int j = 0; j < REM; ++j) w[j] = wm[(CH - 1 - j) * (int)kWave];
+#pragma unroll
+        for (int j = 0; j < REM; ++j) {
+            const float4 t = tlds[NT - REM + j];
+            const float2v x2 = {w[j], w[j]};
+            const float2v hm = {t.x, t.y}, hs = {t.z, t.w};
+            const float2v pm = x2 * hm, ps = x2 * hs;
+            am += pm; as += ps;
+        }
+    }
+    *hm_out = rs_hypot(am.x, am.y);
+    *hs_out = rs_hypot(as.x, as.y);
+}
+
 // The same with the filter chosen per lane (which 0: mark, 1: space): narrow workgroups (16 or 32 channels)
 // leave half of the helper wavefront's lanes idle, so lanes 0 .. LANES-1 take the mark filter of channel
 // `ch` and lanes LANES .. 2*LANES-1 its space filter -- both filters in the time of one.  The taps are then
@@ -680,6 +723,11 @@ __global__ __launch_bounds__((pipe_dcw<NT, LANES, SPLIT>() ? 5 : 4) * kWave, SHA
     // PACKED: workgroups of 16 or 32 channels -- the helper wavefront computes BOTH matched filters (mark on its
     // lanes 0 .. LANES-1, space on LANES .. 2*LANES-1) and stage 2 keeps only the timing loop
     constexpr bool PACKED = SPLIT && LANES <= 32;
+    // HELPER_BOTH: stage 2 computes no filter of its own.  Besides the PACKED workgroups: the two-per-CU build at
+    // 22.05 kHz, where the helper runs both filters in every lane with their accumulation chains interleaved
+    // (demod_pair) -- 32 768 channels x 2 s 4.34 -> 4.21 ms, the time-parallel launch of configs[1] 4.49 -> 4.39 ms
+    // on one box; at 48 kHz (92 taps, one workgroup per CU) the same is 4 % slower, so not there.
+    constexpr bool HELPER_BOTH = PACKED || (SPLIT && SHARE && NT == 42);
     // DCW: a fifth wavefront runs the DC blocker one block ahead (DcStage / AgcStage above)
     constexpr bool DCW = pipe_dcw<NT, LANES, SPLIT>();
     static_assert(kB <= 64, "the sample index travels in six bits of the stage 3 -> 4 word");
@@ -775,7 +823,7 @@ __global__ __launch_bounds__((pipe_dcw<NT, LANES, SPLIT>() ? 5 : 4) * kWave, SHA
         P3_T0();
         auto step = [&](uint32_t s, auto buf) -> bool {
             const uint32_t blk = s + (AHEAD ? 2u : 1u);                // BUF = blk & 1
-            if (blk < n_blocks) {
+            if (blk < n_blocks && !PROF_SKIP(P, 128)) {
                 D.template fetch<decltype(buf)::value>(x, blk, n_blocks, cin, Cin);
                 D.block(P, ycol + ((blk & YMASK) * (uint32_t)kB) * LP);
             }
@@ -814,7 +862,7 @@ __global__ __launch_bounds__((pipe_dcw<NT, LANES, SPLIT>() ? 5 : 4) * kWave, SHA
         bool left = false;
         for (uint32_t s = 0; s < n_steps; ++s) {
             M.rotate();
-            if (s + (AHEAD ? 1u : 0u) < n_blocks) M.block(P, wcol, s + (AHEAD ? 1u : 0u));
+            if (s + (AHEAD ? 1u : 0u) < n_blocks && !PROF_SKIP(P, 64)) M.block(P, wcol, s + (AHEAD ? 1u : 0u));
             P3_LAP(p3_work);
             lds_barrier();                                             // A
             P3_LAP(p3_wait);
@@ -852,7 +900,7 @@ __global__ __launch_bounds__((pipe_dcw<NT, LANES, SPLIT>() ? 5 : 4) * kWave, SHA
         uint32_t stop_at = 0xffffffffu;                                // time-parallel chunk: leave after this step
         auto step = [&](uint32_t s, auto buf) -> bool {
             M.rotate();
-            if (s < n_blocks) {
+            if (s < n_blocks && !PROF_SKIP(P, 64)) {
                 M.template fetch<decltype(buf)::value>(x, s, n_blocks, cin, Cin);
                 P1_INPUTS_ARRIVED(kB);
                 M.block(P, wcol);
@@ -970,7 +1018,7 @@ __global__ __launch_bounds__((pipe_dcw<NT, LANES, SPLIT>() ? 5 : 4) * kWave, SHA
             const uint32_t k_flags = L.flags;
             const int k_cstar = cstar, k_until = until;
             const bool active = s >= 1u && s <= n_blocks;
-            if (active) { do_block(s - 1u, false); if (stale) --stale; }
+            if (active && !PROF_SKIP(P, 32)) { do_block(s - 1u, false); if (stale) --stale; }
             else if (s == 0u) post_cands(1u);
             P3_LAP(p3_work);
             lds_barrier();                                             // A
@@ -1034,7 +1082,7 @@ __global__ __launch_bounds__((pipe_dcw<NT, LANES, SPLIT>() ? 5 : 4) * kWave, SHA
                 const float rem = L.until_next_ted - (float)cstar;          // receiver.rs:352
                 if constexpr (SPLIT) {
                     float hm = 0.0f;
-                    if constexpr (!PACKED) hm = demod_half<NT, RING, 0>(tlds, wring, lane, wpos + (uint32_t)fk);
+                    if constexpr (!HELPER_BOTH) hm = demod_half<NT, RING, 0>(tlds, wring, lane, wpos + (uint32_t)fk);
                     S2_LAP(0);
                     // while the helper wavefront is still filtering: the timing loop for both signs of the soft
                     // sample it will deliver (same_dev_common.h: ted_ahead / ted_commit)
@@ -1043,7 +1091,7 @@ __global__ __launch_bounds__((pipe_dcw<NT, LANES, SPLIT>() ? 5 : 4) * kWave, SHA
                     if (P.knob_prio & 2) { while ((int32_t)(seqbox[0] - seq) < 0) __builtin_amdgcn_s_sleep(2); }
                     else { while ((int32_t)(seqbox[0] - seq) < 0) {} }   // stage 4 has posted this pass
                     SPIN_END();
-                    if constexpr (PACKED) hm = __uint_as_float(markbox[lane]);
+                    if constexpr (HELPER_BOTH) hm = __uint_as_float(markbox[lane]);
                     const float hs = __uint_as_float(spacebox[lane]);
                     S2_LAP(1);
                     sa_low = rs_clamp(hm - hs, -1.0f, 1.0f);
@@ -1093,7 +1141,7 @@ __global__ __launch_bounds__((pipe_dcw<NT, LANES, SPLIT>() ? 5 : 4) * kWave, SHA
             const uint32_t k_flags = L.flags;
             const int k_cstar = cstar, k_until = until;
             const bool active = s >= 1u && s <= n_blocks;
-            if (active) do_block(s - 1u, 2u * s + 1u);
+            if (active && !PROF_SKIP(P, 32)) do_block(s - 1u, 2u * s + 1u);
             else if (SPLIT && s == 0u) posbox[lane] = (uint32_t)until;       // block 0's instant
             P3_LAP(p3_work);
             lds_barrier();                                             // A
@@ -1170,7 +1218,7 @@ __global__ __launch_bounds__((pipe_dcw<NT, LANES, SPLIT>() ? 5 : 4) * kWave, SHA
                 const float pre0 = X.hist_get((pslot + 16u) & 63u), pre1 = X.hist_get((pslot + 17u) & 63u);
                 const uint32_t hdr = sb[0], zero_w = sb[kWave], sym_w = sb[2 * kWave];
                 uint32_t fbv = 0, io0 = 0, io1 = 0xffffffffu, io2 = 0;
-                if (hdr & 1u) {
+                if ((hdr & 1u) && !PROF_SKIP(P, 16)) {
                     const uint32_t fk = hdr >> 8;
                     const float zero = __uint_as_float(zero_w), sym = __uint_as_float(sym_w);
                     float terr = 0.0f, unt = 0.0f;
@@ -1267,6 +1315,10 @@ __global__ __launch_bounds__((pipe_dcw<NT, LANES, SPLIT>() ? 5 : 4) * kWave, SHA
             if constexpr (PACKED) {
                 const float mag = demod_half_dyn<NT, RING>(tlds, wring, fch, wpos + pos, which);
                 (which ? spacebox : markbox)[fch] = __float_as_uint(mag);
+            } else if constexpr (HELPER_BOTH) {
+                float hm, hs;
+                demod_pair<NT, RING>(tlds, wring, lane, wpos + pos, &hm, &hs);
+                markbox[lane] = __float_as_uint(hm); spacebox[lane] = __float_as_uint(hs);
             } else {
                 spacebox[lane] = __float_as_uint(demod_half<NT, RING, 1>(tlds, wring, lane, wpos + pos));
             }
@@ -1275,11 +1327,15 @@ __global__ __launch_bounds__((pipe_dcw<NT, LANES, SPLIT>() ? 5 : 4) * kWave, SHA
             // SPLIT: first the matched filter(s) of block s-1 for stage 2, which waits for them
             const bool active = SPLIT && !AHEAD && s >= 1u && s <= n_blocks;
             uint32_t pos = 0xffffffffu;
+            // what stage 3 posted last step, read together with the instant's position (one LDS round trip, not two)
+            const bool evt_step = s >= 3u && evt_lane && !PROF_SKIP(P, 8);
+            const lds_u32 *io = iobox + ((s - 1u) & 1u) * kP3IoWords + lane;
+            const uint32_t io0 = evt_step ? io[0] : 0u;
             HELP_BEGIN();
             if constexpr (AHEAD) {
                 // the magnitudes at this lane's candidate for block s's first instant (posted by stage 2 during the
                 // last step, read by it in the next)
-                if (s < n_blocks) {
+                if (s < n_blocks && !PROF_SKIP(P, 256)) {
                     const uint32_t cpos = (candbox[(s & 1u) * kWave + fch] >> (8u * cnd)) & 0xffu;
                     if (cpos < (uint32_t)kB)
                         resbox[(s & 1u) * kWave + lane] = __float_as_uint(demod_half_dyn<NT, RING>(tlds, wring, fch, wpos + cpos, which));
@@ -1289,15 +1345,13 @@ __global__ __launch_bounds__((pipe_dcw<NT, LANES, SPLIT>() ? 5 : 4) * kWave, SHA
             if (active) {
                 pos = posbox[((s - 1u) & 1u) * kWave + fch];               // posted by stage 2 during the last step
                 if (P.knob_prio & 1) __builtin_amdgcn_s_setprio(3);
-                if (pos < (uint32_t)kB) filter(pos);
+                if (pos < (uint32_t)kB && !PROF_SKIP(P, 256)) filter(pos);
                 if (lane == 0u) seqbox[0] = 2u * s + 1u;                    // (LDS operations of a wavefront stay in order)
                 if (P.knob_prio & 1) __builtin_amdgcn_s_setprio(0);
             }
             HELP_END(SPLIT);
-            if (s >= 3u && evt_lane) {
+            if (evt_step) {
                 const uint32_t blk = s - 3u;
-                const lds_u32 *io = iobox + ((s - 1u) & 1u) * kP3IoWords + lane;   // what stage 3 posted last step
-                const uint32_t io0 = io[0];
                 if (io0 & 1u) {
                     L.sq_symbols += 1;         // as rx_symbol counted it (rx/codesquelch.rs:232)
                     const uint32_t link = (io0 >> 1) & 3u, fk = (io0 >> 4) & 63u;

@@ -82,6 +82,9 @@ static __device__ unsigned long long g_same_prof_s2[8];
 #define HELP_BEGIN() const unsigned long long help_t0 = clock64()
 #define HELP_END(on_) do { if ((on_) && blockIdx.x == 0 && lane == 0) g_same_prof_hw[6] += clock64() - help_t0; } while (0)
 #define COUNT_SECOND_INSTANT() atomicAdd(&g_same_prof_hw[7], 1ull)          /* lanes that took this path (any workgroup) */
+/* knock-out experiments (results are garbage, the timing says what the step is waiting for): SAME_PIPE_PRIO bits
+   8 helper's event half, 16 stage 3's symbol path, 32 stage 2's block, 64 stage 1's AGC block, 128 DC blocker, 256 helper's filters */
+#define PROF_SKIP(P_, bit_) (((P_).knob_prio & (bit_)) != 0)
 #define PIPE_PROFILE_EXPORTS()                                                                                  \
     static int prof_fetch_(const void *sym, unsigned long long *out, size_t n, int reset)                       \
     {                                                                                                           \
@@ -115,5 +118,6 @@ namespace same { struct ProfMarks { __device__ __forceinline__ void mark(int) {}
 #define HELP_BEGIN() do {} while (0)
 #define HELP_END(on_) do {} while (0)
 #define COUNT_SECOND_INSTANT() do {} while (0)
+#define PROF_SKIP(P_, bit_) false
 #define PIPE_PROFILE_EXPORTS()
 #endif
