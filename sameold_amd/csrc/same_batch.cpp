@@ -950,7 +950,14 @@ int process_channel_major_native(same_batch *rx, const float *d_x, size_t n, hip
     }
     same::TpPlan plan{};
     plan.channels = C; plan.n_chunks = n_chunks; plan.block_len = fb;
-    plan.warmup_samples = geom.warmup_blocks * fb; plan.whole_samples = (uint32_t)n; plan.in_samples = n;
+    // Warm-up: a per-channel boundary lies in silence, so all a fresh receiver needs before the next burst begins is a
+    // full squelch history (32 symbols; the preamble that follows is 128): 40 symbols unless the caller set one
+    {
+        const double sps = (double)rx->P.input_rate / 520.83;
+        const uint32_t warm = tp.warmup ? tp.warmup : (uint32_t)(40.0 * sps + 0.5);
+        plan.warmup_samples = std::min(geom.warmup_blocks, (warm + fb - 1u) / fb) * fb;
+    }
+    plan.whole_samples = (uint32_t)n; plan.in_samples = n;
     plan.scout_blocks = (uint32_t)(n / 256);
     const size_t e_need = (size_t)C * plan.scout_blocks;
     if (tp.energy_cap < e_need) {

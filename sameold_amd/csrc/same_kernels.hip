@@ -330,8 +330,8 @@ __global__ void tp_scout_kernel(const float *__restrict__ x, TpPlan g, float *__
     energy[i] = e;
 }
 // A boundary may sit at a scout block j when the channel has been quiet from kQuietBefore
-// blocks before it (the carrier stopped >= 3 072 samples ago: the link layer is back to NoCarrier -- 32 symbols of
-// squelch history plus the framer's invalid bytes after the last symbol above the squelch) to one block after it.
+// blocks before it (the carrier stopped >= 2 048 samples ago: the link layer is back to NoCarrier -- 31 symbols of
+// power history, 1 312 samples, plus the framer's end -- or the chunk simply runs on until it is) to one block after it.
 // "Quiet": below 8 % of the channel's loudest reading.  Among all ways to cut the call at such instants into at most
 // n_chunks pieces the planner takes one that minimises the LONGEST piece (a workgroup runs as long as its longest
 // lane): bisection on that length, each trial a greedy scan that always cuts at the latest allowed instant.  Chunks
@@ -348,7 +348,7 @@ __global__ __launch_bounds__(256) void tp_boundaries_kernel(const float *__restr
     float *e = tp_lds;                                             // [NB]
     int *lastq = reinterpret_cast<int *>(tp_lds + NB);             // [NB] latest allowed instant at or before block j (-1: none)
     __shared__ float red[256];
-    constexpr int kQuietBefore = 12, kQuietAfter = 1;
+    constexpr int kQuietBefore = 8, kQuietAfter = 1;
     float m = 0.0f;
     for (int j = (int)tid; j < NB; j += 256) { const float v = energy[(size_t)c * NB + j]; e[j] = v; m = fmaxf(m, v); }
     red[tid] = m;

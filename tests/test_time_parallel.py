@@ -105,6 +105,11 @@ def assert_contract(sa, got, ref, rate, n_ch, payload_of, exact_bursts=True, wha
             # and by the other in the next
             bg = [x for x in bg if x[2] <= t_end - 2 * tol]
             br = [x for x in br if x[2] <= t_end - 2 * tol]
+            # (... and one within the tolerance of THAT limit may fall on either side of it in the two modes)
+            while len(bg) > len(br) and bg[-1][2] > t_end - 3 * tol:
+                bg.pop()
+            while len(br) > len(bg) and br[-1][2] > t_end - 3 * tol:
+                br.pop()
         n_bursts += len(br)
         if exact_bursts:
             assert len(bg) == len(br), f"{what} channel {c}: {len(bg)} bursts, reference {len(br)}"
