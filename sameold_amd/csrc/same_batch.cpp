@@ -331,6 +331,7 @@ void read_knobs(same_batch *rx)
     rx->P.knob_pipe_split = tri("SAME_PIPE_SPLIT");
     rx->P.knob_mirror = tri("SAME_MIRROR");
     rx->P.knob_pipe_ahead = tri("SAME_PIPE_AHEAD");
+    rx->P.knob_pipe_share = tri("SAME_PIPE_SHARE");
     rx->P.knob_prio = num("SAME_PIPE_PRIO", 0);
     rx->debug = std::getenv("SAME_DEBUG") != nullptr;
     rx->host_threads = std::max(0, num("SAME_HOST_THREADS", 0));
@@ -968,6 +969,10 @@ int process_channel_major_native(same_batch *rx, const float *d_x, size_t n, hip
     }
     uint32_t *d_own = sl.d_geom, *d_row0 = sl.d_geom + columns, *d_nom = sl.d_geom + 2 * (size_t)columns,
              *d_perm = sl.d_geom + 3 * (size_t)columns, *d_perm2 = sl.d_geom + 4 * (size_t)columns, *d_wg = sl.d_geom + 5 * (size_t)columns;
+    // pieces sorted by length into workgroups only when the workgroups come in more than one round (the long ones
+    // first).  Within one round neither the sorted order nor a long workgroup beside a short one on every CU
+    // (SAME_TP_SORT=2) pays: a 64-channel workgroup that has its CU to itself runs only ~15 % faster (3 785 against
+    // 4 475 clk per step), and the sort costs what that buys (4.09-4.12 against 4.08 ms on one box, 4.09 against 4.28 on another)
     const int sort_mode = tp.sort_mode >= 0 ? tp.sort_mode : (columns > 32768u ? 1 : 0);
     if (!tp.d_sort) HIP_TRY(hipMalloc((void **)&tp.d_sort, same::tp_sort_scratch_bytes()));
     HIP_TRY(same::launch_counters(sl.d_counters, sl.h_counters_dev, 0, stream));
@@ -978,8 +983,6 @@ int process_channel_major_native(same_batch *rx, const float *d_x, size_t n, hip
     HIP_TRY(same::launch_copy_state_columns(tp.d_desc_in, tp.n_desc, C, columns, nullptr, C, stream));
     HIP_TRY(same::launch_fill_u64(sl.d_handover, columns, same::kNoHandover, stream));
     pc.handover = sl.d_handover;
-    // (the sorted order only pays when the workgroups come in more than one round; within one round it merely scatters
-    // the state columns: 4.77 against 4.49 ms)
     pc.col_row0 = d_row0; pc.col_nominal = d_nom; pc.wg_blocks = d_wg; pc.col_perm = sort_mode != 0 ? d_perm : nullptr;
     pc.in_samples = n; pc.whole_samples = (uint32_t)n;
     hipError_t e = same::launch_demod_pipe(tp.Pv, tp.Sv, O, rx->d_taps, d_x, (uint32_t)(n / fb), rx->counter, stream, pc);

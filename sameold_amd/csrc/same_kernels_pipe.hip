@@ -1472,7 +1472,7 @@ static hipError_t launch_pipe_cfg(const Params &P, const State &S, const Output 
     // 4.14 ms, stage 1 + 2 and 3 + 4 4.19 ms, 1 + 4 and 2 + 3 4.20 ms, by wavefront number 4.20 ms, one box),
     // so they are left where they fall.
     constexpr bool CAN_SHARE = (NT == 42);
-    const bool share = CAN_SHARE && P.n_channels > 16384u;
+    const bool share = CAN_SHARE && (P.knob_pipe_share != 0 ? P.knob_pipe_share > 0 : P.n_channels > 16384u);
     const bool med3 = agc_clamp_is_med3(P);
     const bool share_split = P.knob_pipe_split != 0 ? P.knob_pipe_split > 0 : true;
 #define SAME_PIPE_LAUNCH(NFF, NFB, M3)                                                                                  \
