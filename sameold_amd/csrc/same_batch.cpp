@@ -332,6 +332,7 @@ void read_knobs(same_batch *rx)
     rx->P.knob_mirror = tri("SAME_MIRROR");
     rx->P.knob_pipe_ahead = tri("SAME_PIPE_AHEAD");
     rx->P.knob_pipe_share = tri("SAME_PIPE_SHARE");
+    rx->P.knob_fast_dense = tri("SAME_FAST_DENSE");
     rx->P.knob_prio = num("SAME_PIPE_PRIO", 0);
     rx->debug = std::getenv("SAME_DEBUG") != nullptr;
     rx->host_threads = std::max(0, num("SAME_HOST_THREADS", 0));

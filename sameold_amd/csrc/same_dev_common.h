@@ -812,22 +812,24 @@ __device__ __forceinline__ void symbol_io(const Params &P, Lane &L, const State 
 template <typename Ctx>
 __device__ __forceinline__ void ted_symbol(const Params &P, Lane &L, const State &S, const Output &O,
                                            Ctx &X, uint32_t c, float zero, float sym, float terr,
-                                           float until_next_ted, uint64_t counter)
+                                           float until_next_ted, uint64_t counter,
+                                           bool have_pre = false, float pre0 = 0.0f, float pre1 = 0.0f)
 {
     uint32_t burst_len = 0;
     bool emit = false;
-    const uint32_t link = symbol_link(P, L, S, X, c, zero, sym, terr, until_next_ted, counter, &burst_len, &emit);
+    const uint32_t link = symbol_link(P, L, S, X, c, zero, sym, terr, until_next_ted, counter, &burst_len, &emit, have_pre, pre0, pre1);
     symbol_io(P, L, S, O, X, c, link, emit, counter, burst_len);
 }
 
 template <typename Ctx>
 __device__ __forceinline__ void ted_instant(const Params &P, Lane &L, const State &S,
                                             const Output &O, Ctx &X, uint32_t c, float sa_low,
-                                            float rem, uint64_t counter)
+                                            float rem, uint64_t counter,
+                                            bool have_pre = false, float pre0 = 0.0f, float pre1 = 0.0f)
 {
     float zero, sym, terr;
     if (!ted_timing(P, L, sa_low, rem, &zero, &sym, &terr)) return;
-    ted_symbol(P, L, S, O, X, c, zero, sym, terr, L.until_next_ted, counter);
+    ted_symbol(P, L, S, O, X, c, zero, sym, terr, L.until_next_ted, counter, have_pre, pre0, pre1);
 }
 
 

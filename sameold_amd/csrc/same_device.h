@@ -55,6 +55,7 @@ struct Params {
     int32_t knob_pipe_lanes;  // SAME_PIPE_LANES: 0 unset, else 16 / 32 / 64 channels per workgroup
     int32_t knob_pipe_split;  // SAME_PIPE_SPLIT
     int32_t knob_mirror;      // SAME_MIRROR (one-wavefront kernel's mirrored window)
+    int32_t knob_fast_dense;  // SAME_FAST_DENSE (one-wavefront kernel: the two-per-SIMD build whatever the channel count)
     int32_t knob_pipe_share;  // SAME_PIPE_SHARE (the two-workgroups-per-CU register budget whatever the channel count)
     int32_t knob_pipe_ahead;  // SAME_PIPE_AHEAD (16-channel workgroups: candidate filtering a block ahead; +1 on)
     int32_t knob_prio;        // SAME_PIPE_PRIO bit mask (experiments): 1 raise the issue priority of the pipeline's critical

@@ -42,7 +42,8 @@ template <int NT, bool MIRROR> struct FastRing {
 
 template <int NFF, int NFB>
 struct FastCtx : TickRingGlobal, ProfMarks {
-    float *hist;                       // LDS column of this lane: slot i at hist[i * kWave]
+    float *hist;                       // this lane's column of the squelch history: slot i at hist[i * hstride]
+    uint32_t hstride = kWave;          // (LDS: [64][64]; the dense one-wavefront build reads the state array itself, stride = channels)
     float ffc[NFF], ffw[NFF], fbc[NFB], fbw[NFB];
     float sffc[NFF], sffw[NFF], sfbc[NFB], sfbw[NFB];   // equalizer at the last completed byte
     __device__ __forceinline__ void emit(const Params &P, const State &S, const Output &O, uint32_t c, uint32_t kind,
@@ -62,8 +63,8 @@ struct FastCtx : TickRingGlobal, ProfMarks {
 #pragma unroll
         for (int i = 0; i < NFB; ++i) { fbc[i] = sfbc[i]; fbw[i] = sfbw[i]; }
     }
-    __device__ __forceinline__ void hist_put(uint32_t slot, float v) { hist[slot * kWave] = v; }
-    __device__ __forceinline__ float hist_get(uint32_t slot) const { return hist[slot * kWave]; }
+    __device__ __forceinline__ void hist_put(uint32_t slot, float v) { hist[(size_t)slot * hstride] = v; }
+    __device__ __forceinline__ float hist_get(uint32_t slot) const { return hist[(size_t)slot * hstride]; }
     __device__ __forceinline__ uint32_t eq_symbols(const Params &P, Lane &L, const float *samples, int nsym)
     {
         uint32_t bits = 0;

@@ -38,8 +38,11 @@
 namespace same {
 
 
-template <int NT, int DCL, int NFF, int NFB, bool MED3, bool MIRROR, typename SampleT>
-__global__ __launch_bounds__(kWave) void demod_fast_kernel(Params P, State S, Output O,
+// DENSE: built for two wavefronts per SIMD (batches of more than 1 024 wavefronts, i.e. beyond 65 536 channels): at
+// most 256 registers, and the squelch sample history -- 16 of the 33 KB of LDS a wavefront takes, touched four times
+// per symbol -- stays in the HBM state array it comes from, so that eight wavefronts fit a CU's LDS instead of four.
+template <int NT, int DCL, int NFF, int NFB, bool MED3, bool MIRROR, typename SampleT, bool DENSE = false>
+__global__ __launch_bounds__(kWave, DENSE ? 2 : 1) void demod_fast_kernel(Params P, State S, Output O,
                                                            const float4 *__restrict__ taps,
                                                            const SampleT *__restrict__ x,
                                                            uint32_t n_blocks, uint64_t counter0)
@@ -66,16 +69,17 @@ __global__ __launch_bounds__(kWave) void demod_fast_kernel(Params P, State S, Ou
     // never read (the filters reach down to slot RING - NT + 1 at most) and is not stored.
     constexpr int WSKIP = MIRROR ? kB : 0;
     static_assert(!MIRROR || kB <= RING - NT + 1, "the first block's low copy would be read");
-    float *hcol = lds + TAPF + lane;                             // [64][64]
-    float *ffcol = hcol + kSquelchHist * LP;                     // [DCL][64] (LDS DC path)
+    constexpr int HROWS = DENSE ? 0 : kSquelchHist;              // rows of LDS the squelch history takes
+    float *hcol = lds + TAPF + lane;                             // [64][64] (not DENSE)
+    float *ffcol = hcol + HROWS * LP;                            // [DCL][64] (LDS DC path)
     float *fbcol = ffcol + DCL * LP;
-    float *wring = lds + TAPF + (kSquelchHist + (DC_REGS ? 0 : 2 * DCL) - WSKIP) * LP;   // logical slot 0
+    float *wring = lds + TAPF + (HROWS + (DC_REGS ? 0 : 2 * DCL) - WSKIP) * LP;   // logical slot 0
     float *wcol = wring + lane;
 
     Lane L;
     lane_load(L, S, c);
     FastCtx<NFF, NFB> X;
-    X.hist = hcol;
+    if constexpr (DENSE) { X.hist = S.sq_hist + c; X.hstride = C; } else { X.hist = hcol; }
     FAST_MARKS_BEGIN(X, lds, NT);
 #pragma unroll
     for (int i = 0; i < NFF; ++i) {
@@ -103,7 +107,7 @@ __global__ __launch_bounds__(kWave) void demod_fast_kernel(Params P, State S, Ou
         if (MIRROR) wcol[(2u * (uint32_t)RING - m) * LP] = v;
     }
 #pragma unroll 2
-    for (int i = 0; i < kSquelchHist; ++i) { const float *row = S.sq_hist + (size_t)i * C; hcol[i * LP] = row[c]; }
+    for (int i = 0; i < HROWS; ++i) { const float *row = S.sq_hist + (size_t)i * C; hcol[i * LP] = row[c]; }
 
     // ring positions common to all channels
     uint32_t dpos = (uint32_t)(counter0 % (uint64_t)DCL);
@@ -136,6 +140,14 @@ __global__ __launch_bounds__(kWave) void demod_fast_kernel(Params P, State S, Ou
 
     FAST_MARKS_START(X);
     for (uint32_t blk = 0; blk < n_blocks; ++blk) {
+        // DENSE: the two history samples a symbol's equalizer step takes (rx_symbol: slots +16 / +17 from the squelch's
+        // write position) come from HBM; fetched here, a block's worth of work ahead of their use.  A block completes
+        // at most one symbol, and only a symbol writes the history, so they cannot go stale in between.
+        [[maybe_unused]] float hpre0 = 0.0f, hpre1 = 0.0f;
+        if constexpr (DENSE) {
+            const uint32_t pslot = (uint32_t)(2u * (uint32_t)L.sq_symbols) & 63u;
+            hpre0 = X.hist_get((pslot + 16u) & 63u); hpre1 = X.hist_get((pslot + 17u) & 63u);
+        }
         float xs[kB];
 #pragma unroll
         for (int k = 0; k < kB; ++k) xs[k] = xn[k];
@@ -232,7 +244,7 @@ __global__ __launch_bounds__(kWave) void demod_fast_kernel(Params P, State S, Ou
             const float rem = L.until_next_ted - (float)cstar;          // receiver.rs:352
             const uint32_t locked_before = L.flags & F_AGC_LOCKED;
             ted_instant(P, L, S, O, X, c, sa_low, rem,
-                        counter0 + (uint64_t)blk * kB + (uint32_t)fk + 1u);
+                        counter0 + (uint64_t)blk * kB + (uint32_t)fk + 1u, DENSE, hpre0, hpre1);
             cstar = next_fire_count(L.until_next_ted, 0u);
             until = fk + cstar;
             if ((L.flags & F_AGC_LOCKED) != locked_before) {
@@ -279,7 +291,7 @@ __global__ __launch_bounds__(kWave) void demod_fast_kernel(Params P, State S, Ou
         row[c] = wcol[(MIRROR ? j + (uint32_t)RING : j) * LP];       // the high copy is always there
     }
 #pragma unroll 2
-    for (int i = 0; i < kSquelchHist; ++i) { float *row = S.sq_hist + (size_t)i * C; row[c] = hcol[i * LP]; }
+    for (int i = 0; i < HROWS; ++i) { float *row = S.sq_hist + (size_t)i * C; row[c] = hcol[i * LP]; }
     if constexpr (DC_REGS) {
         dpos = (uint32_t)(counter1 % (uint64_t)DCL);
 #pragma unroll
@@ -302,13 +314,13 @@ __global__ __launch_bounds__(kWave) void demod_fast_kernel(Params P, State S, Ou
 // ---------------------------------------------------------------------------------
 // dispatch
 // ---------------------------------------------------------------------------------
-template <int NT, int DCL, bool MIRROR>
+template <int NT, int DCL, bool MIRROR, bool DENSE = false>
 static constexpr size_t fast_lds_bytes()
 {
     constexpr int kB = FastBlock<NT, MIRROR>::len;
     constexpr int RING = FastRing<NT, MIRROR>::slots;
     constexpr size_t TAPF = (size_t)((NT * 4 + PIPE_PROF_TAP_PAD + 63) / 64 * 64);
-    return (TAPF + (size_t)((MIRROR ? 2 * RING - kB : RING) + kSquelchHist + ((DCL <= kB && DCL <= 16) ? 0 : 2 * DCL)) * kWave) * sizeof(float);
+    return (TAPF + (size_t)((MIRROR ? 2 * RING - kB : RING) + (DENSE ? 0 : kSquelchHist) + ((DCL <= kB && DCL <= 16) ? 0 : 2 * DCL)) * kWave) * sizeof(float);
 }
 
 // The mirrored window costs 16 KB of LDS per wavefront: 3 wavefronts fit a CU's 160 KB instead
@@ -328,7 +340,10 @@ static hipError_t launch_fast_cfg(const Params &P, const State &S, const Output 
     const uint32_t grid = (P.n_channels + kWave - 1) / kWave;
     constexpr bool CAN_MIRROR = (NT == 42);
     const bool mirror = CAN_MIRROR && fast_use_mirror(P, max_block_len(P));
-    const size_t lds = mirror ? fast_lds_bytes<NT, DCL, CAN_MIRROR>() : fast_lds_bytes<NT, DCL, false>();
+    // more wavefronts than one per SIMD (1 024): the dense build, two per SIMD (22.05 kHz; SAME_FAST_DENSE=0/1 overrides)
+    constexpr bool CAN_DENSE = (NT == 42);
+    const bool dense = CAN_DENSE && !mirror && (P.knob_fast_dense != 0 ? P.knob_fast_dense > 0 : grid > 1024u);
+    const size_t lds = mirror ? fast_lds_bytes<NT, DCL, CAN_MIRROR>() : (dense ? fast_lds_bytes<NT, DCL, false, CAN_DENSE>() : fast_lds_bytes<NT, DCL, false>());
     // v_med3_f32 == f32::clamp unless a bound is -0.0 (or NaN, which the builder rejects)
     const bool med3 = !(P.agc_min == 0.0f && std::signbit(P.agc_min)) && !(P.agc_max == 0.0f && std::signbit(P.agc_max));
 #define SAME_FAST_M(NFF, NFB, M3, MI)                                                                       \
@@ -337,6 +352,8 @@ static hipError_t launch_fast_cfg(const Params &P, const State &S, const Output 
 #define SAME_FAST(NFF, NFB, M3)                                                                         \
     do {                                                                                                \
         if (mirror) SAME_FAST_M(NFF, NFB, M3, CAN_MIRROR);                                              \
+        else if (dense) hipLaunchKernelGGL((demod_fast_kernel<NT, DCL, NFF, NFB, M3, false, SampleT, CAN_DENSE>), dim3(grid), dim3(kWave), lds, \
+                                           stream, P, S, O, taps, x, n_blocks, counter0);               \
         else SAME_FAST_M(NFF, NFB, M3, false);                                                          \
     } while (0)
     if (P.eq_nff == 6u && P.eq_nfb == 4u) { if (med3) SAME_FAST(6, 4, true); else SAME_FAST(6, 4, false); }

@@ -506,6 +506,29 @@ def test_channel_counts_around_the_workgroup_widths(sa, n_ch, kernel):
     assert sum(len(v) for v in b.values()) >= n_ch and a == b
 
 
+def test_dense_one_wavefront_build_equals_the_default(sa, ob, monkeypatch):
+    """Batches of more than 1 024 wavefronts (beyond 65 536 channels) run the one-wavefront kernel in a build for two
+    wavefronts per SIMD: half the registers, the squelch history in the HBM state array instead of LDS (fetched a
+    block ahead).  Forced here on a small ragged batch fed in chunks: every event equals the default build's and
+    the oracle's."""
+    n_ch, n = 4112, 22050 * 3           # not a multiple of 16: the one-wavefront kernel, with a ragged last wavefront
+    x = sa.synth_afsk(n_ch, n, 22050, seed=4112, noise_sigma=0.03)
+    out = {}
+    for dense in ("0", "1"):
+        monkeypatch.setenv("SAME_FAST_DENSE", dense)
+        rx = sa.SameReceiverBuilder(22050).build_batch(n_ch)
+        assert rx.kernel_name() == "demod_fast_kernel"
+        for off in range(0, n, 20011):
+            rx.process_tensor(x[off:off + 20011].contiguous())
+        rx.sync()
+        out[dense] = events_by_channel(rx)
+    assert sum(len(v) for v in out["0"].values()) > 2 * n_ch and out["1"] == out["0"]
+    cfg = ob.default_config(22050)
+    xh = x.cpu().numpy()
+    for c in (0, 777, 4111):
+        assert out["1"].get(c, []) == oracle_events(ob, cfg, xh[:, c]), f"channel {c}"
+
+
 @pytest.mark.parametrize("amp", [300.0, 6000.0])
 def test_two_instants_in_one_block(sa, ob, amp):
     """The 22.05 kHz pipeline's blocks are 20 samples, instants at least 19.45 apart: when the timing loop runs
