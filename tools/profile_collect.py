@@ -109,6 +109,42 @@ for v, d in per.items():
                     "source": f"profiles/{R}_pmc_FETCH_SIZE.csv, {R}_pmc_WRITE_SIZE.csv; FETCH_SIZE counts this kernel shape's wavefront loads x{corr:g}: r01_fetch_calibration.txt"})
 json.dump(traffic, open(os.path.join(OUT, f"{R}_traffic.json"), "w"), indent=1)
 shutil.copy(os.path.join(P, "pmc_summary.txt"), os.path.join(OUT, f"{R}_pmc_summary.txt"))
+
+# ---- instruction mix per block of the bench line (the SQ pass: --steps 2 --warmup 1, three launches per block)
+try:
+    rows = counters("sq")
+    mix = collections.OrderedDict()
+    seen_disp = collections.defaultdict(set)
+    for r in sorted(rows, key=lambda r: int(r["Dispatch_Id"])):
+        v = variant(r["Kernel_Name"]) or short(r["Kernel_Name"])
+        if v == "share64":
+            for cand in ("time_parallel_time_major", "time_parallel", "scaled"):
+                if r["Dispatch_Id"] in seen_disp[cand] or len(seen_disp[cand]) < 3 or cand == "scaled":
+                    v = cand
+                    break
+        seen_disp[v].add(r["Dispatch_Id"])
+        mix.setdefault(v, collections.defaultdict(float))[r["Counter_Name"]] += float(r["Counter_Value"])
+    lanes = {"strict": 16}
+    with open(os.path.join(OUT, f"{R}_pmc_instruction_mix.txt"), "w") as o:
+        o.write("Wavefront instructions per input sample of one workgroup (its 16 or 64 channels advance one sample), per block of the\n"
+                "bench line: `rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_ANY\n"
+                "-- python3 bench.py --no-cpu-baseline --check 0 --steps 2 --warmup 1` (tools/profile_round.sh), summed over the launches of a\n"
+                "block.  Time-parallel blocks: per sample of the INPUT (their columns also process warm-ups and run-ons).\n\n")
+        for v, c in mix.items():
+            if v not in sizes:
+                continue
+            cc, tt = sizes[v]
+            n = len(seen_disp[v])
+            wg = lanes.get(v, 64)
+            per = cc / wg * tt * n                      # workgroup-samples over the block's launches
+            o.write(f"[{v}] {cc} ch x {tt} samples, {n} launches, {wg}-channel workgroups\n")
+            o.write(f"  VALU {c['SQ_INSTS_VALU'] / per:7.1f}   SALU {c['SQ_INSTS_SALU'] / per:6.1f}   LDS {c['SQ_INSTS_LDS'] / per:6.1f}   per workgroup-sample"
+                    f"  (= {c['SQ_INSTS_VALU'] / per / wg * 64 / 64:.2f} VALU per channel-sample x {wg})\n")
+            wc = c["SQ_WAVE_CYCLES"]
+            o.write(f"  wave cycles {wc / max(c['SQ_WAVES'], 1):.3e} per wavefront; VALU issuing {c['SQ_ACTIVE_INST_VALU'] / wc:.1%} of wave cycles, waiting (any) {c['SQ_WAIT_ANY'] / wc:.1%}\n\n")
+    print(open(os.path.join(OUT, f"{R}_pmc_instruction_mix.txt")).read())
+except Exception as e:      # an old profile directory without the SQ pass
+    print("no instruction mix:", e)
 print(open(os.path.join(OUT, f"{R}_rocprofv3_kernel_trace_demod.txt")).read())
 print(json.dumps(traffic, indent=1))
 print("bench value", bench["value"], "ms_per_step", bench["ms_per_step"], "frac", bench["roofline"]["frac"], "mode", bench["config"].get("mode"))
