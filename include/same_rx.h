@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define SAME_RX_ABI_VERSION 1
+#define SAME_RX_ABI_VERSION 2   /* 2: hip_stream NULL is the legacy default stream (SAME_STREAM_OWN selects the library's); SAME_BATCH_RELAXED */
 
 /* ------------------------------------------------------------------ errors */
 enum {
@@ -134,7 +134,8 @@ typedef struct same_rx_event {
  * Input layout (f32 PCM, unscaled i16-range values as the reference expects,
  * lib.rs:78-81).  TIME_MAJOR is the native, coalesced layout:
  *   SAME_LAYOUT_TIME_MAJOR     x[t * n_channels + c]
- *   SAME_LAYOUT_CHANNEL_MAJOR  x[c * n_samples + t]   (transposed on the device first)
+ *   SAME_LAYOUT_CHANNEL_MAJOR  x[c * n_samples + t]   (transposed on the device first, slab by slab -- except in
+ *                              time-parallel mode, where a 16-byte aligned f32 buffer of whole blocks is read in place)
  */
 enum { SAME_LAYOUT_TIME_MAJOR = 0, SAME_LAYOUT_CHANNEL_MAJOR = 1 };
 
@@ -158,7 +159,19 @@ enum {
      * sample rates than 22.05 / 44.1 / 48 kHz, non-default equalizer orders and channel counts that are
      * not a multiple of 16 run as ordinary strict launches.  Not combinable with
      * SAME_BATCH_TRACE_SYMBOLS. */
-    SAME_BATCH_TIME_PARALLEL = 1u << 3
+    SAME_BATCH_TIME_PARALLEL = 1u << 3,
+    /* Relaxed arithmetic ("fast mode" of the north star; same_kernels_relaxed.hip).  The reference's algorithm, every
+     * decision and feedback path at the sample it happens, with the rounding of the floating-point expressions given
+     * up: matched filters as fused multiply-adds into four partial sums instead of one newest-first chain
+     * (rx/filter.rs:363-377), |mark| and |space| as an f32 square root instead of hypot (rx/demod.rs:163), the AGC update
+     * as gain * (1 - bw |x|) + bw (rx/agc.rs:72-77), reciprocals for the timing loop's and the equalizer's divisions.
+     * The timing trajectory is chaotic in the last bit of those sums, so the contract is the
+     * time-parallel mode's, whose chunks run this arithmetic as well (SAME_RELAXED=0 in the environment keeps them
+     * strict): transmitted burst bytes and transport messages EQUAL, link events within
+     * SAME_TP_EVENT_TOLERANCE_SYMBOLS symbols, soft symbols of an open squelch within 0.05 with equal sign
+     * (tests/test_relaxed.py).  22.05 kHz with the default DC-blocker length, default or disabled equalizer and a
+     * non-negative AGC floor; any other configuration runs strict.  Strict mode (no flag) stays bit-exact. */
+    SAME_BATCH_RELAXED = 1u << 4
 };
 #define SAME_TP_EVENT_TOLERANCE_SYMBOLS 2
 

@@ -227,6 +227,8 @@ struct same_batch {
     float last_ms = 0.0f;
     bool overflowed = false;
     bool use_fast = false;           // configuration has a latency-optimised kernel
+    bool relaxed = false;            // SAME_BATCH_RELAXED (or time-parallel mode): the relaxed-arithmetic kernel runs whole blocks
+    int knob_relaxed = 0;            // SAME_RELAXED: -1 never (time-parallel chunks keep the strict pipeline), +1 as if SAME_BATCH_RELAXED were set
     bool force_generic = false;      // SAME_BATCH_GENERIC_KERNEL (tests compare both kernels)
     bool debug = false;              // SAME_DEBUG: harvest statistics on stderr
     int host_threads = 0;            // SAME_HOST_THREADS: harvest threads (0 = choose)
@@ -337,6 +339,7 @@ void read_knobs(same_batch *rx)
     rx->debug = std::getenv("SAME_DEBUG") != nullptr;
     rx->host_threads = std::max(0, num("SAME_HOST_THREADS", 0));
     rx->tp.sort_mode = num("SAME_TP_SORT", -1);
+    rx->knob_relaxed = tri("SAME_RELAXED");
 }
 
 int ensure_output(same_batch *rx, same_batch::Slot &sl, size_t n_samples, same::Output &O, size_t n_columns = 0)
@@ -719,10 +722,34 @@ uint32_t plan_chunks(same_batch *rx, size_t n, same::ChunkGeom &geom, same::Pipe
     same_batch::TimePar &tp = rx->tp;
     if (!tp.enabled || !rx->use_fast || rx->force_generic) return 1;
     const uint32_t C = rx->P.n_channels;
+    const double sps = (double)rx->P.input_rate / 520.83;
+    auto fill = [&](uint32_t K, uint32_t fb) -> bool {
+        const uint32_t warm = tp.warmup ? tp.warmup : (uint32_t)(64.0 * sps + 0.5);
+        const uint32_t WB = (warm + fb - 1u) / fb;
+        const uint64_t TB = n / fb;
+        if (TB <= WB) return false;
+        const uint64_t SB = (TB - WB) / K;
+        const uint64_t min_own = tp.min_own ? tp.min_own : 4ull * WB * fb;
+        if (SB == 0 || SB * fb < min_own) return false;
+        geom.counter0 = rx->counter;
+        geom.n_chunks = K; geom.block_len = fb; geom.stride_blocks = (uint32_t)SB; geom.warmup_blocks = WB;
+        pc.n_chunks = K; pc.in_channels = C; pc.stride_blocks = (uint32_t)SB; pc.nominal_blocks = (uint32_t)SB + WB;
+        pc.handover = nullptr;
+        return true;
+    };
+    if (rx->relaxed) {
+        // the relaxed kernel: one wavefront per 64 state columns, any number of them (65 536 = one per SIMD)
+        if (C % same::kWave != 0u || C > 32768u) return 1;
+        const uint32_t fb = same::relaxed_block_len(rx->P);
+        const uint32_t k_cap = std::min(63u, 65536u / C);
+        const uint32_t k_max = tp.max_chunks ? std::min(tp.max_chunks, k_cap) : std::min(k_cap, std::max(2u, column_cap / C));
+        for (uint32_t K = k_max; K >= 2u; --K)
+            if (fill(K, fb)) return K;
+        return 1;
+    }
     if (C % 16u != 0u || C > 16384u) return 1;
     same::Params Pv = rx->P;
     Pv.ticks = 0; Pv.trace_cap = 0;
-    const double sps = (double)rx->P.input_rate / 520.83;
     // state columns the pipeline takes at full speed: 32 768 at 22.05 kHz (two workgroups per CU), 16 384 at
     // 44.1 / 48 kHz (their window ring leaves room for one)
     // (column_cap 65 536: the channel-major path, whose workgroups are composed of pieces of similar length and may come
@@ -734,18 +761,7 @@ uint32_t plan_chunks(same_batch *rx, size_t n, same::ChunkGeom &geom, same::Pipe
         Pv.n_channels = K * C;
         if (!same::pipe_kernel_selected(Pv) || C % same::pipe_workgroup_channels(Pv) != 0u) continue;
         const uint32_t fb = same::pipe_block_len(Pv);
-        const uint32_t warm = tp.warmup ? tp.warmup : (uint32_t)(64.0 * sps + 0.5);
-        const uint32_t WB = (warm + fb - 1u) / fb;
-        const uint64_t TB = n / fb;
-        if (TB <= WB) return 1;
-        const uint64_t SB = (TB - WB) / K;
-        const uint64_t min_own = tp.min_own ? tp.min_own : 4ull * WB * fb;
-        if (SB == 0 || SB * fb < min_own) continue;
-        geom.counter0 = rx->counter;
-        geom.n_chunks = K; geom.block_len = fb; geom.stride_blocks = (uint32_t)SB; geom.warmup_blocks = WB;
-        pc.n_chunks = K; pc.in_channels = C; pc.stride_blocks = (uint32_t)SB; pc.nominal_blocks = (uint32_t)SB + WB;
-        pc.handover = nullptr;
-        return K;
+        if (fill(K, fb)) return K;
     }
     return 1;
 }
@@ -840,9 +856,11 @@ int process_time_major(same_batch *rx, const SampleT *d_x, size_t n_samples, hip
             const uint32_t total_blocks = (uint32_t)(n / fbk);
             hipError_t e;
             if constexpr (sizeof(SampleT) == 4)
-                e = same::launch_demod_pipe(tp.Pv, tp.Sv, O, rx->d_taps, (const float *)xp, total_blocks, rx->counter, stream, pc);
+                e = rx->relaxed ? same::launch_demod_relaxed(tp.Pv, tp.Sv, O, rx->d_taps, (const float *)xp, total_blocks, rx->counter, stream, pc)
+                                : same::launch_demod_pipe(tp.Pv, tp.Sv, O, rx->d_taps, (const float *)xp, total_blocks, rx->counter, stream, pc);
             else
-                e = same::launch_demod_pipe_i16(tp.Pv, tp.Sv, O, rx->d_taps, (const int16_t *)xp, total_blocks, rx->counter, stream, pc);
+                e = rx->relaxed ? same::launch_demod_relaxed_i16(tp.Pv, tp.Sv, O, rx->d_taps, (const int16_t *)xp, total_blocks, rx->counter, stream, pc)
+                                : same::launch_demod_pipe_i16(tp.Pv, tp.Sv, O, rx->d_taps, (const int16_t *)xp, total_blocks, rx->counter, stream, pc);
             if (e != hipSuccess) return fail(SAME_EHIP, "time-parallel demod kernel launch failed: %s", hipGetErrorString(e));
             // the channel's state afterwards is that of the chunk which ran to the end of the input
             HIP_TRY(same::launch_chunk_final_column(sl.d_handover, C, geom, tp.d_final_col, stream));
@@ -872,9 +890,15 @@ int process_time_major(same_batch *rx, const SampleT *d_x, size_t n_samples, hip
         // whole blocks (16 or 18 samples) go to the latency-optimised kernel when the
         // configuration has one; the generic kernel takes the remainder (and every other
         // configuration)
-        const size_t fb = rx->use_fast ? same::fast_block_len(rx->P) : 16;
+        const size_t fb = rx->relaxed ? same::relaxed_block_len(rx->P) : (rx->use_fast ? same::fast_block_len(rx->P) : 16);
         size_t n_fast = (rx->use_fast && !rx->force_generic) ? (n / fb) * fb : 0;
-        if (n_fast) {
+        if (n_fast && rx->relaxed) {
+            if constexpr (sizeof(SampleT) == 4)
+                e = same::launch_demod_relaxed(rx->P, rx->S, O, rx->d_taps, (const float *)xp, (uint32_t)(n_fast / fb), rx->counter, stream);
+            else
+                e = same::launch_demod_relaxed_i16(rx->P, rx->S, O, rx->d_taps, (const int16_t *)xp, (uint32_t)(n_fast / fb), rx->counter, stream);
+            if (e != hipSuccess) return fail(SAME_EHIP, "relaxed demod kernel launch failed: %s", hipGetErrorString(e));
+        } else if (n_fast) {
             const bool pipe = same::pipe_kernel_selected(rx->P);
             if constexpr (sizeof(SampleT) == 4)
                 e = pipe ? same::launch_demod_pipe(rx->P, rx->S, O, rx->d_taps, (const float *)xp, (uint32_t)(n_fast / fb), rx->counter, stream)
@@ -928,9 +952,10 @@ int process_channel_major_native(same_batch *rx, const float *d_x, size_t n, hip
     const uint32_t C = rx->P.n_channels, columns = n_chunks * C, fb = geom.block_len;
     same::Params Pv = rx->P;
     Pv.n_channels = columns; Pv.ticks = 0; Pv.trace_cap = 0; Pv.knob_pipe = 1;
-    // 16-byte loads from every lane's stream, whole blocks only, full 64-column workgroups
-    if (n % fb != 0 || n % 4 != 0 || fb % 4 != 0 || n < 64u * 256u || n / 256 > 7000u || n_chunks > 63u || same::pipe_workgroup_channels(Pv) != (uint32_t)same::kWave ||
-        C % same::kWave != 0u) return 0;
+    // 16-byte loads from every lane's stream (the scout's too: 16-byte aligned base and pitch; the relaxed kernel reads
+    // 8 bytes at a time from even rows), whole blocks only, full 64-column workgroups
+    if (n % fb != 0 || n % 4 != 0 || ((uintptr_t)d_x & 15u) != 0u || n < 64u * 256u || n / 256 > 7000u || n_chunks > 63u || C % same::kWave != 0u) return 0;
+    if (rx->relaxed ? fb % 2 != 0 : (fb % 4 != 0 || same::pipe_workgroup_channels(Pv) != (uint32_t)same::kWave)) return 0;
     same_batch::Slot &sl = rx->slot[rx->launch_seq & 1];
     same_batch::Slot &prev = rx->slot[(rx->launch_seq & 1) ^ 1];
     int rc = harvest_slot(rx, sl);
@@ -986,7 +1011,8 @@ int process_channel_major_native(same_batch *rx, const float *d_x, size_t n, hip
     pc.handover = sl.d_handover;
     pc.col_row0 = d_row0; pc.col_nominal = d_nom; pc.wg_blocks = d_wg; pc.col_perm = sort_mode != 0 ? d_perm : nullptr;
     pc.in_samples = n; pc.whole_samples = (uint32_t)n;
-    hipError_t e = same::launch_demod_pipe(tp.Pv, tp.Sv, O, rx->d_taps, d_x, (uint32_t)(n / fb), rx->counter, stream, pc);
+    hipError_t e = rx->relaxed ? same::launch_demod_relaxed(tp.Pv, tp.Sv, O, rx->d_taps, d_x, (uint32_t)(n / fb), rx->counter, stream, pc)
+                               : same::launch_demod_pipe(tp.Pv, tp.Sv, O, rx->d_taps, d_x, (uint32_t)(n / fb), rx->counter, stream, pc);
     if (e != hipSuccess) return fail(SAME_EHIP, "time-parallel demod kernel launch failed: %s", hipGetErrorString(e));
     // the channels' state afterwards: the last chunk's columns (they end with the input)
     HIP_TRY(same::launch_copy_state_columns(tp.d_desc_out, tp.n_desc, columns, C, nullptr, C, stream, (n_chunks - 1u) * C));
@@ -1134,6 +1160,10 @@ int same_batch_new(const same_rx_builder *b, uint32_t n_channels, int device, ui
     rx->tp.cus = (uint32_t)prop.multiProcessorCount;
     rx->use_fast = same::fast_kernel_supported(rx->P);
     rx->force_generic = (flags & SAME_BATCH_GENERIC_KERNEL) != 0;
+    // Relaxed arithmetic: asked for (SAME_BATCH_RELAXED), or implied by the time-parallel mode, whose contract is the
+    // same one (SAME_RELAXED=0 keeps that mode on the strict pipeline kernel; =1 turns it on for any batch)
+    rx->relaxed = (((flags & (SAME_BATCH_RELAXED | SAME_BATCH_TIME_PARALLEL)) != 0 && rx->knob_relaxed >= 0) || rx->knob_relaxed > 0) &&
+                  rx->use_fast && !rx->force_generic && same::relaxed_kernel_supported(rx->P);
     if (same::demod_lds_bytes(rx->P) > 160 * 1024)
         return cleanup(fail(SAME_EINVAL, "configuration needs %zu bytes of LDS per wavefront (limit 160 KiB)", same::demod_lds_bytes(rx->P)));
     TRY_OR_CLEAN(hipStreamCreateWithFlags(&rx->own_stream, hipStreamNonBlocking));
@@ -1391,6 +1421,7 @@ int same_batch_time_parallel_per_channel(const same_batch *rx) { return rx && rx
 const char *same_batch_kernel_name(const same_batch *rx)
 {
     if (!rx) return "";
+    if (rx->relaxed) return "demod_relaxed_kernel";
     if (rx->use_fast && !rx->force_generic) 
     {
         const uint32_t st = same::pipe_kernel_stages(rx->P);

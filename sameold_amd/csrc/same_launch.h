@@ -29,6 +29,16 @@ hipError_t launch_demod_pipe_i16(const Params &P, const State &S, const Output &
                                  const int16_t *x, uint32_t n_blocks, uint64_t counter0, hipStream_t stream,
                                  const PipeChunks &chunks = PipeChunks{});
 uint32_t pipe_workgroup_channels(const Params &P);   // channels per workgroup the pipeline would use for this batch
+// relaxed-arithmetic throughput kernel (same_kernels_relaxed.hip): 22.05 kHz, one wavefront per 64 state columns,
+// whole blocks of relaxed_block_len() samples; takes time-parallel chunks like the pipeline
+bool relaxed_kernel_supported(const Params &P);
+uint32_t relaxed_block_len(const Params &P);
+hipError_t launch_demod_relaxed(const Params &P, const State &S, const Output &O, const float4 *taps,
+                                const float *x, uint32_t n_blocks, uint64_t counter0, hipStream_t stream,
+                                const PipeChunks &chunks = PipeChunks{});
+hipError_t launch_demod_relaxed_i16(const Params &P, const State &S, const Output &O, const float4 *taps,
+                                    const int16_t *x, uint32_t n_blocks, uint64_t counter0, hipStream_t stream,
+                                    const PipeChunks &chunks = PipeChunks{});
 hipError_t launch_demod_fast(const Params &P, const State &S, const Output &O, const float4 *taps,
                              const float *x, uint32_t n_blocks, uint64_t counter0, hipStream_t stream);
 hipError_t launch_demod_fast_i16(const Params &P, const State &S, const Output &O, const float4 *taps,

@@ -42,6 +42,23 @@ static __device__ unsigned long long g_same_prof_hw[8];
 // [2] combine + timing loop + next instant, [3] posting (mailboxes), [4] checkpoint + loop + barrier entry
 static __device__ unsigned long long g_same_prof_s2[8];
 }  // namespace same
+// relaxed kernel (same_kernels_relaxed.hip), wavefront 0: shader-clock time per section of a sub-block
+// [0] DC blocker (with the wait for its inputs) [1] AGC + window push [2] matched filters [3] timing loop + symbol path
+// [4] AGC replay, loop ends [5] hand-over check; [6] sub-blocks [7] TED passes
+namespace same { static __device__ unsigned long long g_same_prof_relaxed[8]; }
+#define RX_T0() unsigned long long rx_acc[6] = {0, 0, 0, 0, 0, 0}, rx_n[2] = {0, 0}, rx_t = clock64()
+#define RX_LAP(i) do { const unsigned long long t_ = clock64(); rx_acc[i] += t_ - rx_t; rx_t = t_; } while (0)
+#define RX_COUNT(i) do { rx_n[i] += 1; } while (0)
+#define RX_REPORT() do { if (blockIdx.x == 0 && lane == 0) { for (int i_ = 0; i_ < 6; ++i_) atomicAdd(&same::g_same_prof_relaxed[i_], rx_acc[i_]); \
+        atomicAdd(&same::g_same_prof_relaxed[6], rx_n[0]); atomicAdd(&same::g_same_prof_relaxed[7], rx_n[1]); } } while (0)
+#define RELAXED_PROFILE_EXPORTS()                                                                               \
+    extern "C" int same_debug_profile_relaxed(unsigned long long *out8, int reset)                              \
+    {                                                                                                           \
+        unsigned long long z[8] = {0};                                                                          \
+        if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(same::g_same_prof_relaxed), sizeof(z)) != hipSuccess) return -1;       \
+        if (reset && hipMemcpyToSymbol(HIP_SYMBOL(same::g_same_prof_relaxed), z, sizeof(z)) != hipSuccess) return -1;   \
+        return 0;                                                                                               \
+    }
 #define PIPE_PROF_TAP_PAD 20
 #define FAST_MARKS_BEGIN(X_, lds_, nt_) do { (X_).pl = reinterpret_cast<unsigned long long *>((lds_) + (nt_) * 4); \
         for (int i_ = 0; i_ < 10; ++i_) (X_).pl[i_] = 0; } while (0)
@@ -98,6 +115,11 @@ static __device__ unsigned long long g_same_prof_s2[8];
     extern "C" int same_debug_profile_pipe(unsigned long long *out15, int reset) { return prof_fetch_(HIP_SYMBOL(same::g_same_prof_pipe), out15, 15, reset); }
 #else
 namespace same { struct ProfMarks { __device__ __forceinline__ void mark(int) {} }; }
+#define RX_T0() do {} while (0)
+#define RX_LAP(i) do {} while (0)
+#define RX_COUNT(i) do {} while (0)
+#define RX_REPORT() do {} while (0)
+#define RELAXED_PROFILE_EXPORTS()
 #define PIPE_PROF_TAP_PAD 0
 #define FAST_MARKS_BEGIN(X_, lds_, nt_) do {} while (0)
 #define FAST_MARKS_START(X_) do {} while (0)

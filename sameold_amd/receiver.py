@@ -25,7 +25,7 @@ LIB_PATH = os.path.join(_HERE, "libsame_rx.so")
 LINK_NO_CARRIER, LINK_SEARCHING, LINK_READING, LINK_BURST = 0, 1, 2, 3
 TRANSPORT_IDLE, TRANSPORT_ASSEMBLING, TRANSPORT_MSG_START, TRANSPORT_MSG_END, TRANSPORT_MSG_ERR = 16, 17, 18, 19, 20
 LAYOUT_TIME_MAJOR, LAYOUT_CHANNEL_MAJOR = 0, 1
-BATCH_LINK_ONLY, BATCH_TRACE_SYMBOLS, BATCH_GENERIC_KERNEL, BATCH_TIME_PARALLEL = 1, 2, 4, 8
+BATCH_LINK_ONLY, BATCH_TRACE_SYMBOLS, BATCH_GENERIC_KERNEL, BATCH_TIME_PARALLEL, BATCH_RELAXED = 1, 2, 4, 8, 16
 TP_EVENT_TOLERANCE_SYMBOLS = 2      # SAME_TP_EVENT_TOLERANCE_SYMBOLS
 STREAM_OWN = (1 << 64) - 1          # SAME_STREAM_OWN: (void *)-1, the library's own stream
 EVENT_MAX_BYTES = 288
@@ -313,8 +313,8 @@ class SameReceiverBuilder:
 
     def build_batch(self, n_channels: int, device: int = 0, link_only: bool = False,
                     trace_symbols: bool = False, generic_kernel: bool = False,
-                    time_parallel: bool = False) -> "SameBatchReceiver":
-        return SameBatchReceiver(self, n_channels, device, link_only, trace_symbols, generic_kernel, time_parallel)
+                    time_parallel: bool = False, relaxed: bool = False) -> "SameBatchReceiver":
+        return SameBatchReceiver(self, n_channels, device, link_only, trace_symbols, generic_kernel, time_parallel, relaxed)
 
 
 class SameBatchReceiver:
@@ -322,11 +322,12 @@ class SameBatchReceiver:
 
     def __init__(self, builder: SameReceiverBuilder, n_channels: int, device: int = 0,
                  link_only: bool = False, trace_symbols: bool = False, generic_kernel: bool = False,
-                 time_parallel: bool = False):
+                 time_parallel: bool = False, relaxed: bool = False):
         self._L = load_library()
         h = C.c_void_p()
         flags = ((BATCH_LINK_ONLY if link_only else 0) | (BATCH_TRACE_SYMBOLS if trace_symbols else 0)
-                 | (BATCH_GENERIC_KERNEL if generic_kernel else 0) | (BATCH_TIME_PARALLEL if time_parallel else 0))
+                 | (BATCH_GENERIC_KERNEL if generic_kernel else 0) | (BATCH_TIME_PARALLEL if time_parallel else 0)
+                 | (BATCH_RELAXED if relaxed else 0))
         _check(self._L.same_batch_new(builder._h, n_channels, device, flags, C.byref(h)))
         self._h = h
         self._inflight = []          # input tensors of launches that may still be running (process_tensor)
@@ -399,9 +400,10 @@ class SameBatchReceiver:
         if stream is None:
             self.order_after(torch.cuda.current_stream(x.device).cuda_stream)
         self._inflight.append(x)
+        self.process_device_ptr(x.data_ptr(), n, layout, stream, x.dtype == torch.int16)
+        # (trimmed AFTER the call: it is the call that collects launch k-2, whose input may be dropped only then)
         if len(self._inflight) > 2:
             del self._inflight[0]
-        self.process_device_ptr(x.data_ptr(), n, layout, stream, x.dtype == torch.int16)
 
     def process_host(self, x: np.ndarray, layout: int = LAYOUT_TIME_MAJOR):
         """x: numpy float32/int16 array, [T, C] (time-major) or [C, T]."""

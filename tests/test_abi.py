@@ -30,7 +30,7 @@ def test_exports_every_declared_symbol(lib):
     assert len(syms) > 50
     missing = [s for s in syms if not hasattr(lib, s)]
     assert not missing, missing
-    assert lib.same_rx_abi_version() == 1
+    assert lib.same_rx_abi_version() == 2
 
 
 def test_builder_defaults_and_clamping(lib):
