@@ -207,6 +207,7 @@ struct same_batch {
         uint32_t max_chunks = 0, min_own = 0, warmup = 0;     // same_batch_time_parallel_config (0 = default)
         uint32_t cap_columns = 0;                             // columns the wide state blob holds
         uint32_t carved_columns = 0;                          // columns Pv / Sv / the descriptor tables are laid out for
+        int carved_kernel = -1;                               // ... and the kernel choice Pv's knobs were set for
         same::Params Pv{};
         same::State Sv{};
         void *blob = nullptr;
@@ -219,6 +220,10 @@ struct same_batch {
         uint32_t cus = 0;                                    // compute units of the device
         uint32_t last_chunks = 1;
         bool last_per_channel = false;
+        // which kernel runs the chunks of the call being planned: the wavefront pipeline (strict, or its FASTMATH build
+        // when the batch is relaxed) or the one-wavefront relaxed kernel
+        enum Kernel { kPipe = 0, kPipeRelaxed = 1, kWaveRelaxed = 2 } kernel = kPipe;
+        int knob_kernel = 0;                                  // SAME_TP_KERNEL: 1 pipeline, 2 one-wavefront relaxed kernel, 0 choose
         std::vector<int64_t> sym_off;        // per channel: reported symbol count - the device's
         std::vector<TickSynth> synth;
     } tp;
@@ -227,7 +232,8 @@ struct same_batch {
     float last_ms = 0.0f;
     bool overflowed = false;
     bool use_fast = false;           // configuration has a latency-optimised kernel
-    bool relaxed = false;            // SAME_BATCH_RELAXED (or time-parallel mode): the relaxed-arithmetic kernel runs whole blocks
+    bool relaxed = false;            // relaxed arithmetic in time-parallel chunks (SAME_BATCH_TIME_PARALLEL or SAME_BATCH_RELAXED)
+    bool relaxed_plain = false;      // ... and in ordinary launches: the one-wavefront relaxed kernel runs whole blocks (SAME_BATCH_RELAXED)
     int knob_relaxed = 0;            // SAME_RELAXED: -1 never (time-parallel chunks keep the strict pipeline), +1 as if SAME_BATCH_RELAXED were set
     bool force_generic = false;      // SAME_BATCH_GENERIC_KERNEL (tests compare both kernels)
     bool debug = false;              // SAME_DEBUG: harvest statistics on stderr
@@ -340,6 +346,7 @@ void read_knobs(same_batch *rx)
     rx->host_threads = std::max(0, num("SAME_HOST_THREADS", 0));
     rx->tp.sort_mode = num("SAME_TP_SORT", -1);
     rx->knob_relaxed = tri("SAME_RELAXED");
+    { const char *e = std::getenv("SAME_TP_KERNEL"); rx->tp.knob_kernel = !e ? 0 : (std::strcmp(e, "wave") == 0 ? 2 : (std::strcmp(e, "pipe") == 0 ? 1 : 0)); }
 }
 
 int ensure_output(same_batch *rx, same_batch::Slot &sl, size_t n_samples, same::Output &O, size_t n_columns = 0)
@@ -737,19 +744,22 @@ uint32_t plan_chunks(same_batch *rx, size_t n, same::ChunkGeom &geom, same::Pipe
         pc.handover = nullptr;
         return true;
     };
-    if (rx->relaxed) {
-        // the relaxed kernel: one wavefront per 64 state columns, any number of them (65 536 = one per SIMD)
-        if (C % same::kWave != 0u || C > 32768u) return 1;
+    // Relaxed batches: the pipeline's FASTMATH build while the state columns fit the pipeline (whole 64-channel
+    // workgroups), the one-wavefront relaxed kernel beyond (SAME_TP_KERNEL=pipe / wave overrides)
+    const bool pipe_fm = rx->relaxed && tp.knob_kernel != 2 && C % same::kWave == 0u && C <= 16384u;
+    if (rx->relaxed && !pipe_fm && tp.knob_kernel != 1 && C % same::kWave == 0u && C <= 65536u) {
+        // one wavefront per 64 state columns, any number of them
         const uint32_t fb = same::relaxed_block_len(rx->P);
-        const uint32_t k_cap = std::min(63u, 65536u / C);
+        const uint32_t k_cap = std::min(63u, 131072u / C);
         const uint32_t k_max = tp.max_chunks ? std::min(tp.max_chunks, k_cap) : std::min(k_cap, std::max(2u, column_cap / C));
         for (uint32_t K = k_max; K >= 2u; --K)
-            if (fill(K, fb)) return K;
+            if (fill(K, fb)) { tp.kernel = same_batch::TimePar::kWaveRelaxed; return K; }
         return 1;
     }
     if (C % 16u != 0u || C > 16384u) return 1;
     same::Params Pv = rx->P;
     Pv.ticks = 0; Pv.trace_cap = 0;
+    if (pipe_fm) { Pv.knob_pipe_lanes = 64; Pv.knob_pipe_share = 1; Pv.knob_pipe_split = 1; Pv.knob_pipe = 1; }
     // state columns the pipeline takes at full speed: 32 768 at 22.05 kHz (two workgroups per CU), 16 384 at
     // 44.1 / 48 kHz (their window ring leaves room for one)
     // (column_cap 65 536: the channel-major path, whose workgroups are composed of pieces of similar length and may come
@@ -760,8 +770,9 @@ uint32_t plan_chunks(same_batch *rx, size_t n, same::ChunkGeom &geom, same::Pipe
     for (uint32_t K = k_max; K >= 2u; --K) {
         Pv.n_channels = K * C;
         if (!same::pipe_kernel_selected(Pv) || C % same::pipe_workgroup_channels(Pv) != 0u) continue;
+        if (pipe_fm && !same::pipe_relaxed_supported(Pv)) continue;
         const uint32_t fb = same::pipe_block_len(Pv);
-        if (fill(K, fb)) return K;
+        if (fill(K, fb)) { tp.kernel = pipe_fm ? same_batch::TimePar::kPipeRelaxed : same_batch::TimePar::kPipe; return K; }
     }
     return 1;
 }
@@ -783,7 +794,7 @@ int ensure_handover(same_batch::Slot &sl, uint32_t columns)
 int ensure_wide_state(same_batch *rx, uint32_t columns)
 {
     same_batch::TimePar &tp = rx->tp;
-    if (tp.carved_columns == columns) return SAME_OK;
+    if (tp.carved_columns == columns && tp.carved_kernel == (int)tp.kernel) return SAME_OK;
     int rc = harvest(rx);                    // nothing in flight may still use the old layout
     if (rc) return rc;
     HIP_TRY(hipDeviceSynchronize());
@@ -791,6 +802,7 @@ int ensure_wide_state(same_batch *rx, uint32_t columns)
     tp.Pv.n_channels = columns;
     tp.Pv.ticks = 0; tp.Pv.trace_cap = 0;
     if (columns > 32768u) tp.Pv.knob_pipe = 1;
+    if (tp.kernel == same_batch::TimePar::kPipeRelaxed) { tp.Pv.knob_pipe_lanes = 64; tp.Pv.knob_pipe_share = 1; tp.Pv.knob_pipe_split = 1; tp.Pv.knob_pipe = 1; }
     if (columns > tp.cap_columns) {
         if (tp.blob) HIP_TRY(hipFree(tp.blob));
         tp.blob = nullptr; tp.cap_columns = 0;
@@ -812,6 +824,7 @@ int ensure_wide_state(same_batch *rx, uint32_t columns)
     HIP_TRY(hipMemcpy(tp.d_desc_in, in.data(), in.size() * sizeof(same::StateArrayDesc), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(tp.d_desc_out, out.data(), out.size() * sizeof(same::StateArrayDesc), hipMemcpyHostToDevice));
     tp.carved_columns = columns;
+    tp.carved_kernel = (int)tp.kernel;
     return SAME_OK;
 }
 
@@ -856,11 +869,13 @@ int process_time_major(same_batch *rx, const SampleT *d_x, size_t n_samples, hip
             const uint32_t total_blocks = (uint32_t)(n / fbk);
             hipError_t e;
             if constexpr (sizeof(SampleT) == 4)
-                e = rx->relaxed ? same::launch_demod_relaxed(tp.Pv, tp.Sv, O, rx->d_taps, (const float *)xp, total_blocks, rx->counter, stream, pc)
-                                : same::launch_demod_pipe(tp.Pv, tp.Sv, O, rx->d_taps, (const float *)xp, total_blocks, rx->counter, stream, pc);
+                e = tp.kernel == same_batch::TimePar::kWaveRelaxed
+                        ? same::launch_demod_relaxed(tp.Pv, tp.Sv, O, rx->d_taps, (const float *)xp, total_blocks, rx->counter, stream, pc)
+                        : same::launch_demod_pipe(tp.Pv, tp.Sv, O, rx->d_taps, (const float *)xp, total_blocks, rx->counter, stream, pc, tp.kernel == same_batch::TimePar::kPipeRelaxed);
             else
-                e = rx->relaxed ? same::launch_demod_relaxed_i16(tp.Pv, tp.Sv, O, rx->d_taps, (const int16_t *)xp, total_blocks, rx->counter, stream, pc)
-                                : same::launch_demod_pipe_i16(tp.Pv, tp.Sv, O, rx->d_taps, (const int16_t *)xp, total_blocks, rx->counter, stream, pc);
+                e = tp.kernel == same_batch::TimePar::kWaveRelaxed
+                        ? same::launch_demod_relaxed_i16(tp.Pv, tp.Sv, O, rx->d_taps, (const int16_t *)xp, total_blocks, rx->counter, stream, pc)
+                        : same::launch_demod_pipe_i16(tp.Pv, tp.Sv, O, rx->d_taps, (const int16_t *)xp, total_blocks, rx->counter, stream, pc, tp.kernel == same_batch::TimePar::kPipeRelaxed);
             if (e != hipSuccess) return fail(SAME_EHIP, "time-parallel demod kernel launch failed: %s", hipGetErrorString(e));
             // the channel's state afterwards is that of the chunk which ran to the end of the input
             HIP_TRY(same::launch_chunk_final_column(sl.d_handover, C, geom, tp.d_final_col, stream));
@@ -890,9 +905,9 @@ int process_time_major(same_batch *rx, const SampleT *d_x, size_t n_samples, hip
         // whole blocks (16 or 18 samples) go to the latency-optimised kernel when the
         // configuration has one; the generic kernel takes the remainder (and every other
         // configuration)
-        const size_t fb = rx->relaxed ? same::relaxed_block_len(rx->P) : (rx->use_fast ? same::fast_block_len(rx->P) : 16);
+        const size_t fb = rx->relaxed_plain ? same::relaxed_block_len(rx->P) : (rx->use_fast ? same::fast_block_len(rx->P) : 16);
         size_t n_fast = (rx->use_fast && !rx->force_generic) ? (n / fb) * fb : 0;
-        if (n_fast && rx->relaxed) {
+        if (n_fast && rx->relaxed_plain) {
             if constexpr (sizeof(SampleT) == 4)
                 e = same::launch_demod_relaxed(rx->P, rx->S, O, rx->d_taps, (const float *)xp, (uint32_t)(n_fast / fb), rx->counter, stream);
             else
@@ -950,12 +965,14 @@ int process_channel_major_native(same_batch *rx, const float *d_x, size_t n, hip
     const uint32_t n_chunks = plan_chunks(rx, n, geom, pc, want_cols > 32768u ? 65536u : 32768u);
     if (n_chunks < 2u) return 0;
     const uint32_t C = rx->P.n_channels, columns = n_chunks * C, fb = geom.block_len;
+    const bool wave = tp.kernel == same_batch::TimePar::kWaveRelaxed;
     same::Params Pv = rx->P;
     Pv.n_channels = columns; Pv.ticks = 0; Pv.trace_cap = 0; Pv.knob_pipe = 1;
+    if (tp.kernel == same_batch::TimePar::kPipeRelaxed) { Pv.knob_pipe_lanes = 64; Pv.knob_pipe_share = 1; Pv.knob_pipe_split = 1; }
     // 16-byte loads from every lane's stream (the scout's too: 16-byte aligned base and pitch; the relaxed kernel reads
     // 8 bytes at a time from even rows), whole blocks only, full 64-column workgroups
     if (n % fb != 0 || n % 4 != 0 || ((uintptr_t)d_x & 15u) != 0u || n < 64u * 256u || n / 256 > 7000u || n_chunks > 63u || C % same::kWave != 0u) return 0;
-    if (rx->relaxed ? fb % 2 != 0 : (fb % 4 != 0 || same::pipe_workgroup_channels(Pv) != (uint32_t)same::kWave)) return 0;
+    if (wave ? fb % 2 != 0 : (fb % 4 != 0 || same::pipe_workgroup_channels(Pv) != (uint32_t)same::kWave)) return 0;
     same_batch::Slot &sl = rx->slot[rx->launch_seq & 1];
     same_batch::Slot &prev = rx->slot[(rx->launch_seq & 1) ^ 1];
     int rc = harvest_slot(rx, sl);
@@ -1011,8 +1028,8 @@ int process_channel_major_native(same_batch *rx, const float *d_x, size_t n, hip
     pc.handover = sl.d_handover;
     pc.col_row0 = d_row0; pc.col_nominal = d_nom; pc.wg_blocks = d_wg; pc.col_perm = sort_mode != 0 ? d_perm : nullptr;
     pc.in_samples = n; pc.whole_samples = (uint32_t)n;
-    hipError_t e = rx->relaxed ? same::launch_demod_relaxed(tp.Pv, tp.Sv, O, rx->d_taps, d_x, (uint32_t)(n / fb), rx->counter, stream, pc)
-                               : same::launch_demod_pipe(tp.Pv, tp.Sv, O, rx->d_taps, d_x, (uint32_t)(n / fb), rx->counter, stream, pc);
+    hipError_t e = wave ? same::launch_demod_relaxed(tp.Pv, tp.Sv, O, rx->d_taps, d_x, (uint32_t)(n / fb), rx->counter, stream, pc)
+                        : same::launch_demod_pipe(tp.Pv, tp.Sv, O, rx->d_taps, d_x, (uint32_t)(n / fb), rx->counter, stream, pc, tp.kernel == same_batch::TimePar::kPipeRelaxed);
     if (e != hipSuccess) return fail(SAME_EHIP, "time-parallel demod kernel launch failed: %s", hipGetErrorString(e));
     // the channels' state afterwards: the last chunk's columns (they end with the input)
     HIP_TRY(same::launch_copy_state_columns(tp.d_desc_out, tp.n_desc, columns, C, nullptr, C, stream, (n_chunks - 1u) * C));
@@ -1164,6 +1181,8 @@ int same_batch_new(const same_rx_builder *b, uint32_t n_channels, int device, ui
     // same one (SAME_RELAXED=0 keeps that mode on the strict pipeline kernel; =1 turns it on for any batch)
     rx->relaxed = (((flags & (SAME_BATCH_RELAXED | SAME_BATCH_TIME_PARALLEL)) != 0 && rx->knob_relaxed >= 0) || rx->knob_relaxed > 0) &&
                   rx->use_fast && !rx->force_generic && same::relaxed_kernel_supported(rx->P);
+    // (a call of a time-parallel batch that is too short to be cut stays strict unless relaxed arithmetic was asked for)
+    rx->relaxed_plain = rx->relaxed && ((flags & SAME_BATCH_RELAXED) != 0 || rx->knob_relaxed > 0);
     if (same::demod_lds_bytes(rx->P) > 160 * 1024)
         return cleanup(fail(SAME_EINVAL, "configuration needs %zu bytes of LDS per wavefront (limit 160 KiB)", same::demod_lds_bytes(rx->P)));
     TRY_OR_CLEAN(hipStreamCreateWithFlags(&rx->own_stream, hipStreamNonBlocking));
@@ -1421,7 +1440,14 @@ int same_batch_time_parallel_per_channel(const same_batch *rx) { return rx && rx
 const char *same_batch_kernel_name(const same_batch *rx)
 {
     if (!rx) return "";
-    if (rx->relaxed) return "demod_relaxed_kernel";
+    if (rx->tp.last_chunks > 1u) {
+        switch (rx->tp.kernel) {
+        case same_batch::TimePar::kWaveRelaxed: return "demod_relaxed_kernel";
+        case same_batch::TimePar::kPipeRelaxed: return "demod_pipe_kernel<fastmath>";
+        default: return "demod_pipe_kernel";
+        }
+    }
+    if (rx->relaxed_plain) return "demod_relaxed_kernel";
     if (rx->use_fast && !rx->force_generic) 
     {
         const uint32_t st = same::pipe_kernel_stages(rx->P);

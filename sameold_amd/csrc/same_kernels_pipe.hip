@@ -33,6 +33,7 @@
 #include "same_fast_common.h"
 #include "same_launch.h"
 #include "same_profile.h"
+#include "same_relaxed_common.h"
 
 namespace same {
 
@@ -278,7 +279,8 @@ struct IoCtx : TickRingGlobal {
 };
 
 // Stage 1 state: DC blocker, AGC, input prefetch, and what a replay needs of its last three blocks
-template <int NT_, bool MED3, typename SampleT>
+// FM: relaxed AGC step (same_relaxed_common.h) -- the FASTMATH build of time-parallel launches
+template <int NT_, bool MED3, typename SampleT, bool FM = false>
 struct SampleStage {
     static constexpr int NT = NT_, DCL = PipeGeom<NT_>::DCL, kB = PipeLayout<NT_>::B, RING = PipeLayout<NT_>::RING;
     static constexpr uint32_t LP = kWave;
@@ -385,7 +387,7 @@ struct SampleStage {
                 float *wlow = wcol + (wp[j] == 0u ? (uint32_t)RING : wp[j]) * LP;
 #pragma unroll
                 for (int k = 0; k < kB; ++k) {
-                    const float out = agc_step<MED3>(P, yv[k], g, (k <= fk) ? bw0 : bw1);
+                    const float out = FM ? agc_step_relaxed(P, yv[k], g, (k <= fk) ? bw0 : bw1) : agc_step<MED3>(P, yv[k], g, (k <= fk) ? bw0 : bw1);
                     wlow[k * LP] = out;
                     wblk[(k + RING) * LP] = out;
                 }
@@ -399,7 +401,7 @@ struct SampleStage {
         float *wlow = wcol + (wp[j] == 0u ? (uint32_t)RING : wp[j]) * LP;
 #pragma unroll
         for (int k = 0; k < kB; ++k) {
-            const float out = agc_step<MED3>(P, ys[jj][k], g, (k <= fk) ? bw0 : bw1);
+            const float out = FM ? agc_step_relaxed(P, ys[jj][k], g, (k <= fk) ? bw0 : bw1) : agc_step<MED3>(P, ys[jj][k], g, (k <= fk) ? bw0 : bw1);
             wlow[k * LP] = out;
             wblk[(k + RING) * LP] = out;
         }
@@ -711,13 +713,17 @@ template <int NT, int LANES, bool SPLIT> constexpr bool pipe_can_ahead() { retur
 // known a block ahead; stage 2 posts it, stage 4 computes the space magnitude first thing in its
 // step, posts it and bumps a sequence word that stage 2 polls before it combines the two -- a
 // hand-over inside the step, no extra block of latency.
-template <int NT, int NFF, int NFB, bool MED3, bool SHARE, int LANES, bool SPLIT, typename SampleT, bool AHEAD = false>
+// FM (FASTMATH): the relaxed arithmetic of same_relaxed_common.h in every stage -- matched filters as fused multiply-adds
+// into partial sums with an f32 square root, the AGC's two-operation gain chain, the equalizer's fused steps.  Built for
+// the 64-channel two-per-CU form the time-parallel launches use; its parity contract is that mode's (include/same_rx.h).
+template <int NT, int NFF, int NFB, bool MED3, bool SHARE, int LANES, bool SPLIT, typename SampleT, bool AHEAD = false, bool FM = false>
 __global__ __launch_bounds__((pipe_dcw<NT, LANES, SPLIT>() ? 5 : 4) * kWave, SHARE ? 2 : 1) void demod_pipe_kernel(Params P, State S, Output O,
                                                                 const float4 *__restrict__ taps,
                                                                 const SampleT *__restrict__ x,
                                                                 uint32_t n_blocks, uint64_t counter0, PipeChunks K)
 {
     static_assert(!AHEAD || pipe_can_ahead<NT, LANES, SPLIT>(), "AHEAD is built for 16-channel DCW workgroups");
+    static_assert(!FM || (SPLIT && SHARE && NT == 42 && LANES == 64 && !AHEAD), "FASTMATH is built for the 64-channel two-per-CU form");
     constexpr int kB = PipeLayout<NT, AHEAD>::B, RING = PipeLayout<NT, AHEAD>::RING;
     constexpr uint32_t LP = kWave, kPipeTapFloats = PipeLayout<NT, AHEAD>::tap_floats;
     // PACKED: workgroups of 16 or 32 channels -- the helper wavefront computes BOTH matched filters (mark on its
@@ -891,7 +897,7 @@ __global__ __launch_bounds__((pipe_dcw<NT, LANES, SPLIT>() ? 5 : 4) * kWave, SHA
         for (uint32_t i = lane; i < (uint32_t)NT; i += kWave) tlds[i] = taps[i];
         if (LANES < (int)kWave && lane >= (uint32_t)LANES) return;      // (the wavefront goes on without them)
         P3_HWID(0);
-        SampleStage<NT, MED3, SampleT> M;
+        SampleStage<NT, MED3, SampleT, FM> M;
         M.ycol = wring + (2u * (uint32_t)RING) * LP + lane;           // behind the window
         M.xl = xl; M.avail = avail_l;
         M.load(P, S, x, c, C, cin, Cin, counter0, wcol, n_blocks);
@@ -1070,6 +1076,7 @@ __global__ __launch_bounds__((pipe_dcw<NT, LANES, SPLIT>() ? 5 : 4) * kWave, SHA
         int cstar = next_fire_count(L.until_next_ted, L.ted_clock);
         int until = cstar - (int)L.ted_clock - 1;      // block-relative index of the firing sample
         uint32_t wpos = 0;
+        [[maybe_unused]] const float inv_spt = 1.0f / P.samples_per_ted;
         // one block: the instant, if this lane has one in it; hands a completed symbol to stage 3
         S2_BEGIN();
         auto do_block = [&](uint32_t blk, uint32_t seq) {
@@ -1080,7 +1087,18 @@ __global__ __launch_bounds__((pipe_dcw<NT, LANES, SPLIT>() ? 5 : 4) * kWave, SHA
                 const int fk = until;
                 float sa_low;
                 const float rem = L.until_next_ted - (float)cstar;          // receiver.rs:352
-                if constexpr (SPLIT) {
+                if constexpr (FM) {
+                    // FASTMATH: the helper's relaxed filters take a fraction of the look-ahead's time (ted_ahead evaluates
+                    // the loop for both signs to hide the strict filters' latency), so wait for them and run the loop once
+                    SPIN_BEGIN();
+                    while ((int32_t)(seqbox[0] - seq) < 0) {}
+                    SPIN_END();
+                    const float hm = __uint_as_float(markbox[lane]), hs = __uint_as_float(spacebox[lane]);
+                    S2_LAP(1);
+                    sa_low = __builtin_amdgcn_fmed3f(hm - hs, -1.0f, 1.0f);
+                    if (ted_timing_relaxed(P, L, inv_spt, sa_low, rem, &zero, &sym, &terr)) { hdr = 1u | ((uint32_t)fk << 8); next = L.until_next_ted; }
+                    cstar = next_fire_count(L.until_next_ted, 0u);
+                } else if constexpr (SPLIT) {
                     float hm = 0.0f;
                     if constexpr (!HELPER_BOTH) hm = demod_half<NT, RING, 0>(tlds, wring, lane, wpos + (uint32_t)fk);
                     S2_LAP(0);
@@ -1110,10 +1128,17 @@ __global__ __launch_bounds__((pipe_dcw<NT, LANES, SPLIT>() ? 5 : 4) * kWave, SHA
                     // two instants completes a symbol.
                     const int fk2 = until;
                     COUNT_SECOND_INSTANT();
-                    const float sa2 = demod_fast<NT, RING, true>(tlds, wring, lane, wpos + (uint32_t)fk2);
+                    float sa2;
+                    if constexpr (FM) {
+                        float hm2, hs2;
+                        demod_pair_relaxed<NT, RING, false>(lds_addr(lds), lds_addr(wcol), wpos + (uint32_t)fk2, &hm2, &hs2);
+                        sa2 = __builtin_amdgcn_fmed3f(hm2 - hs2, -1.0f, 1.0f);
+                    } else {
+                        sa2 = demod_fast<NT, RING, true>(tlds, wring, lane, wpos + (uint32_t)fk2);
+                    }
                     const float rem2 = L.until_next_ted - (float)cstar;
                     float z2 = 0.0f, s2 = 0.0f, e2 = 0.0f;
-                    if (ted_timing(P, L, sa2, rem2, &z2, &s2, &e2)) {
+                    if (FM ? ted_timing_relaxed(P, L, inv_spt, sa2, rem2, &z2, &s2, &e2) : ted_timing(P, L, sa2, rem2, &z2, &s2, &e2)) {
                         hdr = 1u | ((uint32_t)fk2 << 8); zero = z2; sym = s2; terr = e2; next = L.until_next_ted;
                     }
                     cstar = next_fire_count(L.until_next_ted, 0u);
@@ -1189,7 +1214,7 @@ __global__ __launch_bounds__((pipe_dcw<NT, LANES, SPLIT>() ? 5 : 4) * kWave, SHA
         Lane L;
         lane_load(L, S, c);
         L.ended = 0u;
-        FastCtx<NFF, NFB> X;
+        std::conditional_t<FM, RelaxFastCtx<NFF, NFB>, FastCtx<NFF, NFB>> X;
         X.hist = hcol;
         P3_MARKS_BEGIN(X, lds, NT);       // (profile builds: per-section marks of the symbol path)
 #pragma unroll
@@ -1317,7 +1342,8 @@ __global__ __launch_bounds__((pipe_dcw<NT, LANES, SPLIT>() ? 5 : 4) * kWave, SHA
                 (which ? spacebox : markbox)[fch] = __float_as_uint(mag);
             } else if constexpr (HELPER_BOTH) {
                 float hm, hs;
-                demod_pair<NT, RING>(tlds, wring, lane, wpos + pos, &hm, &hs);
+                if constexpr (FM) demod_pair_relaxed<NT, RING, true>(lds_addr(lds), lds_addr(wcol), wpos + pos, &hm, &hs);
+                else demod_pair<NT, RING>(tlds, wring, lane, wpos + pos, &hm, &hs);
                 markbox[lane] = __float_as_uint(hm); spacebox[lane] = __float_as_uint(hs);
             } else {
                 spacebox[lane] = __float_as_uint(demod_half<NT, RING, 1>(tlds, wring, lane, wpos + pos));
@@ -1436,14 +1462,14 @@ bool pipe_kernel_selected(const Params &P) { return pipe_kernel_stages(P) != 0u;
 uint32_t pipe_block_len(const Params &P)
 { return P.ntaps == 42u ? (uint32_t)kBlockPipe22 : (P.ntaps == 92u ? (uint32_t)PipeGeom<92>::B : (uint32_t)PipeGeom<84>::B); }
 
-template <int NT, int NFF, int NFB, bool M3, bool SHARE, int LANES, bool SPLIT, typename SampleT, bool AHEAD = false>
+template <int NT, int NFF, int NFB, bool M3, bool SHARE, int LANES, bool SPLIT, typename SampleT, bool AHEAD = false, bool FM = false>
 static hipError_t launch_pipe_one(const Params &P, const State &S, const Output &O, const float4 *taps,
                                   const SampleT *x, uint32_t n_blocks, uint64_t counter0, hipStream_t stream,
                                   const PipeChunks &K)
 {
     constexpr bool DCW = pipe_dcw<NT, LANES, SPLIT>();
     constexpr size_t lds = pipe_lds_bytes<NT, DCW, AHEAD>();
-    auto *kernel = demod_pipe_kernel<NT, NFF, NFB, M3, SHARE, LANES, SPLIT, SampleT, AHEAD>;
+    auto *kernel = demod_pipe_kernel<NT, NFF, NFB, M3, SHARE, LANES, SPLIT, SampleT, AHEAD, FM>;
     if (lds > 64u * 1024u) {
         // more than the default 64 KB of dynamic LDS per workgroup: opt in, once per kernel and device
         static bool opted_in[64] = {};
@@ -1464,8 +1490,19 @@ static hipError_t launch_pipe_one(const Params &P, const State &S, const Output 
 template <int NT, typename SampleT>
 static hipError_t launch_pipe_cfg(const Params &P, const State &S, const Output &O, const float4 *taps,
                                   const SampleT *x, uint32_t n_blocks, uint64_t counter0, hipStream_t stream,
-                                  const PipeChunks &K)
+                                  const PipeChunks &K, bool relaxed)
 {
+    if constexpr (NT == 42) {
+        // FASTMATH: the 64-channel two-per-CU form with the relaxed arithmetic (pipe_relaxed_supported)
+        if (relaxed) {
+            if (!pipe_relaxed_supported(P)) return hipErrorInvalidValue;
+            if (P.eq_nff == 6u && P.eq_nfb == 4u)
+                return launch_pipe_one<NT, 6, 4, true, true, 64, true, SampleT, false, true>(P, S, O, taps, x, n_blocks, counter0, stream, K);
+            return launch_pipe_one<NT, 1, 1, true, true, 64, true, SampleT, false, true>(P, S, O, taps, x, n_blocks, counter0, stream, K);
+        }
+    } else {
+        if (relaxed) return hipErrorInvalidValue;
+    }
     // two workgroups per CU (22.05 kHz only, where their LDS allows it): the register-capped build, with
     // stage 2 split (same box, 32 768 channels x 2 s: 4.27-4.29 ms unsplit, 4.18-4.24 ms split).  Which stages
     // of the two workgroups meet on a SIMD makes no measurable difference there (dealt by SIMD id: like + like
@@ -1507,19 +1544,26 @@ static hipError_t launch_pipe_cfg(const Params &P, const State &S, const Output 
 template <typename SampleT>
 static hipError_t launch_pipe_t(const Params &P, const State &S, const Output &O, const float4 *taps,
                                 const SampleT *x, uint32_t n_blocks, uint64_t counter0, hipStream_t stream,
-                                const PipeChunks &K)
+                                const PipeChunks &K, bool relaxed)
 {
-    if (P.ntaps == 42u) return launch_pipe_cfg<42, SampleT>(P, S, O, taps, x, n_blocks, counter0, stream, K);
-    if (P.ntaps == 92u) return launch_pipe_cfg<92, SampleT>(P, S, O, taps, x, n_blocks, counter0, stream, K);
-    return launch_pipe_cfg<84, SampleT>(P, S, O, taps, x, n_blocks, counter0, stream, K);
+    if (P.ntaps == 42u) return launch_pipe_cfg<42, SampleT>(P, S, O, taps, x, n_blocks, counter0, stream, K, relaxed);
+    if (P.ntaps == 92u) return launch_pipe_cfg<92, SampleT>(P, S, O, taps, x, n_blocks, counter0, stream, K, relaxed);
+    return launch_pipe_cfg<84, SampleT>(P, S, O, taps, x, n_blocks, counter0, stream, K, relaxed);
 }
 
 hipError_t launch_demod_pipe(const Params &P, const State &S, const Output &O, const float4 *taps,
-                             const float *x, uint32_t n_blocks, uint64_t counter0, hipStream_t stream, const PipeChunks &K)
-{ return launch_pipe_t<float>(P, S, O, taps, x, n_blocks, counter0, stream, K); }
+                             const float *x, uint32_t n_blocks, uint64_t counter0, hipStream_t stream, const PipeChunks &K, bool relaxed)
+{ return launch_pipe_t<float>(P, S, O, taps, x, n_blocks, counter0, stream, K, relaxed); }
 hipError_t launch_demod_pipe_i16(const Params &P, const State &S, const Output &O, const float4 *taps,
-                                 const int16_t *x, uint32_t n_blocks, uint64_t counter0, hipStream_t stream, const PipeChunks &K)
-{ return launch_pipe_t<int16_t>(P, S, O, taps, x, n_blocks, counter0, stream, K); }
+                                 const int16_t *x, uint32_t n_blocks, uint64_t counter0, hipStream_t stream, const PipeChunks &K, bool relaxed)
+{ return launch_pipe_t<int16_t>(P, S, O, taps, x, n_blocks, counter0, stream, K, relaxed); }
+// The FASTMATH build exists for 22.05 kHz in 64-channel workgroups (whole groups of 64 state columns), default or disabled
+// equalizer, a non-negative AGC floor
+bool pipe_relaxed_supported(const Params &P)
+{
+    return P.ntaps == 42u && P.dc_len == 16u && (P.n_channels % kWave) == 0u && P.agc_min >= 0.0f && pipe_kernel_stages(P) != 0u &&
+           pipe_lanes(P) == kWave && ((P.eq_nff == 6u && P.eq_nfb == 4u) || (P.eq_nff == 1u && P.eq_nfb == 1u));
+}
 uint32_t pipe_workgroup_channels(const Params &P) { return pipe_lanes(P); }
 
 }  // namespace same

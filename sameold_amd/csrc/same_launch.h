@@ -22,12 +22,14 @@ uint32_t fast_block_len(const Params &P);   // samples per block of the fast ker
 bool pipe_kernel_selected(const Params &P);
 uint32_t pipe_kernel_stages(const Params &P);     // 0 (not selected) or non-zero
 uint32_t pipe_block_len(const Params &P);         // samples per block of the pipeline at this rate
+// relaxed: the FASTMATH build (relaxed arithmetic, same_relaxed_common.h); only where pipe_relaxed_supported(P)
 hipError_t launch_demod_pipe(const Params &P, const State &S, const Output &O, const float4 *taps,
                              const float *x, uint32_t n_blocks, uint64_t counter0, hipStream_t stream,
-                             const PipeChunks &chunks = PipeChunks{});
+                             const PipeChunks &chunks = PipeChunks{}, bool relaxed = false);
 hipError_t launch_demod_pipe_i16(const Params &P, const State &S, const Output &O, const float4 *taps,
                                  const int16_t *x, uint32_t n_blocks, uint64_t counter0, hipStream_t stream,
-                                 const PipeChunks &chunks = PipeChunks{});
+                                 const PipeChunks &chunks = PipeChunks{}, bool relaxed = false);
+bool pipe_relaxed_supported(const Params &P);
 uint32_t pipe_workgroup_channels(const Params &P);   // channels per workgroup the pipeline would use for this batch
 // relaxed-arithmetic throughput kernel (same_kernels_relaxed.hip): 22.05 kHz, one wavefront per 64 state columns,
 // whole blocks of relaxed_block_len() samples; takes time-parallel chunks like the pipeline

@@ -1,0 +1,340 @@
+// same_relaxed_common.h -- the relaxed-arithmetic building blocks shared by same_kernels_relaxed.hip (one wavefront per
+// 64 state columns) and the FASTMATH build of the wavefront pipeline (same_kernels_pipe.hip): matched-filter chunks
+// with asm-issued LDS loads, the relaxed AGC step, timing loop and equalizer step.  What "relaxed" means and what it
+// guarantees: include/same_rx.h, SAME_BATCH_RELAXED.
+//
+// Citations: file:line under /root/reference/crates/sameold/src/ ("rx/" = receiver/).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include "same_dev_common.h"
+#include "same_device.h"
+#include "same_fast_common.h"
+
+namespace same {
+
+constexpr int kRelaxChunk = 14;                 // taps per filter chunk
+
+// acc += {w.lo, w.lo} * h   /   acc += {w.hi, w.hi} * h: packed f32 FMA with the window sample broadcast by op_sel
+// (the compiler would materialise the splat with a v_mov per tap).  volatile: they stay in program order between the
+// load statements of demod_relaxed.
+__device__ __forceinline__ void pk_fma_lo(float2v &acc, float2v w, float2v h)
+{ asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(acc) : "v"(w), "v"(h)); }
+__device__ __forceinline__ void pk_fma_hi(float2v &acc, float2v w, float2v h)
+{ asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(acc) : "v"(w), "v"(h)); }
+
+typedef float float4v __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) float lds_float;
+__device__ __forceinline__ uint32_t lds_addr(const float *p) { return (uint32_t)(uintptr_t)(const lds_float *)p; }
+
+// One chunk of 14 taps of both matched filters (rx/filter.rs:363-377 re-associated): `wa` = LDS byte address of the
+// chunk's LOWEST window slot (the sample tap base + 13 multiplies; slots are 256 bytes apart), `ta` = LDS byte address
+// of tap `base` (16 bytes per tap: mark re/im, space re/im).  Even / odd taps accumulate separately.
+//
+// The loads -- 7 x ds_read2st64_b32 (two window slots each) and 14 x ds_read_b128 (one tap; a wave-uniform address,
+// i.e. a broadcast) -- are issued back to back from asm statements.  Left to itself the compiler loads two taps,
+// waits, multiplies, loads the next two ...: fourteen exposed LDS round trips per chunk.  WIDE (builds with registers
+// to spare): all 21 loads at once, the first half's products under the second half's latency (70 registers of
+// loads); otherwise two rounds of 7 taps (36 registers).
+#define RELAX_TAP(acc_m, acc_s, fma, win_, tap_) do { const float2v hm_ = {tap_.x, tap_.y}, hs_ = {tap_.z, tap_.w}; fma(acc_m, win_, hm_); fma(acc_s, win_, hs_); } while (0)
+template <bool WIDE>
+__device__ __forceinline__ void relax_filter_chunk(uint32_t wa, uint32_t ta, float2v &am0, float2v &am1, float2v &as0, float2v &as1)
+{
+    static_assert(kRelaxChunk == 14, "the load sequence below is written out for 14 taps");
+    float2v w0, w1, w2, w3, w4, w5, w6;                  // wK = {tap base + 13 - 2K, tap base + 12 - 2K}
+    float4v t0, t1, t2, t3, t4, t5, t6;
+    if constexpr (WIDE) {
+        float4v t7, t8, t9, t10, t11, t12, t13;
+        asm volatile(
+            "ds_read2st64_b32 %[w0], %[wa] offset1:1\n\t"
+            "ds_read2st64_b32 %[w1], %[wa] offset0:2 offset1:3\n\t"
+            "ds_read2st64_b32 %[w2], %[wa] offset0:4 offset1:5\n\t"
+            "ds_read2st64_b32 %[w3], %[wa] offset0:6 offset1:7\n\t"
+            "ds_read_b128 %[t13], %[ta] offset:208\n\t"
+            "ds_read_b128 %[t12], %[ta] offset:192\n\t"
+            "ds_read_b128 %[t11], %[ta] offset:176\n\t"
+            "ds_read_b128 %[t10], %[ta] offset:160\n\t"
+            "ds_read_b128 %[t9], %[ta] offset:144\n\t"
+            "ds_read_b128 %[t8], %[ta] offset:128\n\t"
+            "ds_read_b128 %[t7], %[ta] offset:112\n\t"
+            "ds_read2st64_b32 %[w4], %[wa] offset0:8 offset1:9\n\t"
+            "ds_read2st64_b32 %[w5], %[wa] offset0:10 offset1:11\n\t"
+            "ds_read2st64_b32 %[w6], %[wa] offset0:12 offset1:13\n\t"
+            "ds_read_b128 %[t6], %[ta] offset:96\n\t"
+            "ds_read_b128 %[t5], %[ta] offset:80\n\t"
+            "ds_read_b128 %[t4], %[ta] offset:64\n\t"
+            "ds_read_b128 %[t3], %[ta] offset:48\n\t"
+            "ds_read_b128 %[t2], %[ta] offset:32\n\t"
+            "ds_read_b128 %[t1], %[ta] offset:16\n\t"
+            "ds_read_b128 %[t0], %[ta]\n\t"
+            "s_waitcnt lgkmcnt(10)"
+            : [w0] "=&v"(w0), [w1] "=&v"(w1), [w2] "=&v"(w2), [w3] "=&v"(w3), [w4] "=&v"(w4), [w5] "=&v"(w5), [w6] "=&v"(w6),
+              [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3), [t4] "=&v"(t4), [t5] "=&v"(t5), [t6] "=&v"(t6),
+              [t7] "=&v"(t7), [t8] "=&v"(t8), [t9] "=&v"(t9), [t10] "=&v"(t10), [t11] "=&v"(t11), [t12] "=&v"(t12), [t13] "=&v"(t13)
+            : [wa] "v"(wa), [ta] "v"(ta)
+            : "memory");
+        RELAX_TAP(am0, as0, pk_fma_lo, w0, t13); RELAX_TAP(am1, as1, pk_fma_hi, w0, t12);
+        RELAX_TAP(am0, as0, pk_fma_lo, w1, t11); RELAX_TAP(am1, as1, pk_fma_hi, w1, t10);
+        RELAX_TAP(am0, as0, pk_fma_lo, w2, t9); RELAX_TAP(am1, as1, pk_fma_hi, w2, t8);
+        RELAX_TAP(am0, as0, pk_fma_lo, w3, t7);
+        // the second half has landed by now, as a rule; the values travel through the statement so that nothing that
+        // reads them can be moved above it
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+v"(w4), "+v"(w5), "+v"(w6), "+v"(t0), "+v"(t1), "+v"(t2), "+v"(t3), "+v"(t4), "+v"(t5), "+v"(t6));
+    } else {
+        asm volatile(
+            "ds_read2st64_b32 %[w0], %[wa] offset1:1\n\t"
+            "ds_read2st64_b32 %[w1], %[wa] offset0:2 offset1:3\n\t"
+            "ds_read2st64_b32 %[w2], %[wa] offset0:4 offset1:5\n\t"
+            "ds_read2st64_b32 %[w3], %[wa] offset0:6 offset1:7\n\t"
+            "ds_read_b128 %[t6], %[ta] offset:208\n\t"
+            "ds_read_b128 %[t5], %[ta] offset:192\n\t"
+            "ds_read_b128 %[t4], %[ta] offset:176\n\t"
+            "ds_read_b128 %[t3], %[ta] offset:160\n\t"
+            "ds_read_b128 %[t2], %[ta] offset:144\n\t"
+            "ds_read_b128 %[t1], %[ta] offset:128\n\t"
+            "ds_read_b128 %[t0], %[ta] offset:112\n\t"
+            "s_waitcnt lgkmcnt(0)"
+            : [w0] "=&v"(w0), [w1] "=&v"(w1), [w2] "=&v"(w2), [w3] "=&v"(w3),
+              [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3), [t4] "=&v"(t4), [t5] "=&v"(t5), [t6] "=&v"(t6)
+            : [wa] "v"(wa), [ta] "v"(ta)
+            : "memory");
+        RELAX_TAP(am0, as0, pk_fma_lo, w0, t6); RELAX_TAP(am1, as1, pk_fma_hi, w0, t5);
+        RELAX_TAP(am0, as0, pk_fma_lo, w1, t4); RELAX_TAP(am1, as1, pk_fma_hi, w1, t3);
+        RELAX_TAP(am0, as0, pk_fma_lo, w2, t2); RELAX_TAP(am1, as1, pk_fma_hi, w2, t1);
+        RELAX_TAP(am0, as0, pk_fma_lo, w3, t0);
+        asm volatile(
+            "ds_read2st64_b32 %[w4], %[wa] offset0:8 offset1:9\n\t"
+            "ds_read2st64_b32 %[w5], %[wa] offset0:10 offset1:11\n\t"
+            "ds_read2st64_b32 %[w6], %[wa] offset0:12 offset1:13\n\t"
+            "ds_read_b128 %[t6], %[ta] offset:96\n\t"
+            "ds_read_b128 %[t5], %[ta] offset:80\n\t"
+            "ds_read_b128 %[t4], %[ta] offset:64\n\t"
+            "ds_read_b128 %[t3], %[ta] offset:48\n\t"
+            "ds_read_b128 %[t2], %[ta] offset:32\n\t"
+            "ds_read_b128 %[t1], %[ta] offset:16\n\t"
+            "ds_read_b128 %[t0], %[ta]\n\t"
+            "s_waitcnt lgkmcnt(0)"
+            : [w4] "=&v"(w4), [w5] "=&v"(w5), [w6] "=&v"(w6),
+              [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3), [t4] "=&v"(t4), [t5] "=&v"(t5), [t6] "=&v"(t6)
+            : [wa] "v"(wa), [ta] "v"(ta)
+            : "memory");
+    }
+    RELAX_TAP(am1, as1, pk_fma_hi, w3, t6);
+    RELAX_TAP(am0, as0, pk_fma_lo, w4, t5); RELAX_TAP(am1, as1, pk_fma_hi, w4, t4);
+    RELAX_TAP(am0, as0, pk_fma_lo, w5, t3); RELAX_TAP(am1, as1, pk_fma_hi, w5, t2);
+    RELAX_TAP(am0, as0, pk_fma_lo, w6, t1); RELAX_TAP(am1, as1, pk_fma_hi, w6, t0);
+}
+#undef RELAX_TAP
+
+// |mark| - |space| clamped to +-1 (rx/demod.rs:163-164) with the magnitudes as f32 square roots
+__device__ __forceinline__ float relax_magnitude(float2v a) { return __builtin_amdgcn_sqrtf(__builtin_fmaf(a.x, a.x, a.y * a.y)); }
+
+// FskDemod::demod_now rx/demod.rs:156-164 at the instant whose sample sits in ring slot `newest` of a ring whose first
+// 13 slots are stored twice (same_kernels_relaxed.hip): tap j multiplies slot (newest - j) mod RING; a chunk is read
+// upwards from its lowest slot, moved into the mirror when it would wrap.
+template <int NT, int RING, bool WIDE>
+__device__ __forceinline__ float demod_relaxed(uint32_t taps_lds, uint32_t wcol_lds, int newest)
+{
+    constexpr int CH = kRelaxChunk;
+    float2v am0 = {0.0f, 0.0f}, am1 = {0.0f, 0.0f}, as0 = {0.0f, 0.0f}, as1 = {0.0f, 0.0f};
+    int top = newest;
+#pragma unroll 1
+    for (int base = 0; base < NT; base += CH) {
+        int s = top;
+        s += s < 0 ? RING : 0;
+        s += s < CH - 1 ? RING : 0;                          // slots RING .. RING + CH - 2 repeat slots 0 .. CH - 2
+        relax_filter_chunk<WIDE>(wcol_lds + (uint32_t)(s - (CH - 1)) * (kWave * 4u), taps_lds + (uint32_t)base * 16u, am0, am1, as0, as1);
+        top -= CH;
+    }
+    return __builtin_amdgcn_fmed3f(relax_magnitude(am0 + am1) - relax_magnitude(as0 + as1), -1.0f, 1.0f);
+}
+
+// The same over the pipeline's fully mirrored window (same_fast_common.h): tap j at slot newest + RING - j, no wrap.
+// `wlane_lds` = LDS byte address of logical slot 0 of this lane's column; the two magnitudes separately.
+template <int NT, int RING, bool WIDE>
+__device__ __forceinline__ void demod_pair_relaxed(uint32_t taps_lds, uint32_t wlane_lds, uint32_t newest, float *hm_out, float *hs_out)
+{
+    constexpr int CH = kRelaxChunk;
+    static_assert(NT % CH == 0, "whole chunks");
+    float2v am0 = {0.0f, 0.0f}, am1 = {0.0f, 0.0f}, as0 = {0.0f, 0.0f}, as1 = {0.0f, 0.0f};
+    uint32_t wa = wlane_lds + (newest + (uint32_t)RING - (uint32_t)(CH - 1)) * (kWave * 4u);
+    uint32_t ta = taps_lds;
+#pragma unroll 1
+    for (int base = 0; base < NT; base += CH) {
+        relax_filter_chunk<WIDE>(wa, ta, am0, am1, as0, as1);
+        wa -= (uint32_t)CH * (kWave * 4u);
+        ta += (uint32_t)CH * 16u;
+    }
+    *hm_out = relax_magnitude(am0 + am1);
+    *hs_out = relax_magnitude(as0 + as1);
+}
+
+// One AGC step, rx/agc.rs:72-77, as gain * (1 - bw |y|) + bw: the same update algebraically while gain >= 0 (the
+// launchers check the floor), one fused multiply-add and the clamp on the gain's dependency chain.  bw_eff = 0 for a
+// locked AGC: gain * 1 + 0.
+__device__ __forceinline__ float agc_step_relaxed(const Params &P, float y, float &gain, float bw_eff)
+{
+    const float a = __builtin_fmaf(-bw_eff, fabsf(y), 1.0f);
+    const float out = y * gain;
+    gain = __builtin_amdgcn_fmed3f(__builtin_fmaf(gain, a, bw_eff), P.agc_min, P.agc_max);
+    return out;
+}
+
+// ZeroCrossingTed::input + TimingLoop::advance_loop (rx/symsync.rs:198-287), the relaxed form of ted_timing
+__device__ __forceinline__ bool ted_timing_relaxed(const Params &P, Lane &L, float inv_spt, float sa_low, float rem,
+                                                   float *zero_out, float *sym_out, float *terr_out)
+{
+    L.h0 = L.h1; L.h1 = L.h2; L.h2 = sa_low;
+    L.flags ^= F_TED_PHASE;
+    const bool have = (L.flags & F_TED_PHASE) != 0;
+    const float dsg = rs_signum(L.h0) - rs_signum(L.h2);
+    const float terr = L.h1 * dsg;
+    const float offset = __builtin_amdgcn_fmed3f(rem, -0.5f, 0.5f);
+    const float e = __builtin_amdgcn_fmed3f(__builtin_fmaf(-offset, inv_spt, terr), -1.0f, 1.0f);
+    const bool bw_locked = (L.flags & F_BW_LOCKED) != 0;
+    const float alpha = bw_locked ? P.alpha_locked : P.alpha_unlocked;
+    const float beta = bw_locked ? P.beta_locked : P.beta_unlocked;
+    const float avg1 = __builtin_amdgcn_fmed3f(__builtin_fmaf(beta, e, L.period_avg), P.period_min, P.period_max);
+    float inst1 = __builtin_fmaf(alpha, e, avg1) + offset;
+    inst1 = (inst1 < 0.0f) ? avg1 : inst1;
+    const float inst0 = L.period_inst + offset;
+    L.period_avg = have ? avg1 : L.period_avg;
+    L.period_inst = have ? inst1 : inst0;
+    L.until_next_ted = L.period_inst;
+    *zero_out = L.h1; *sym_out = L.h2; *terr_out = terr;
+    return have;
+}
+
+// Equalizer::estimate_symbol + evolve (rx/equalize.rs:249-332, 354-386), the relaxed form of eq_symbol_core:
+// fused multiply-adds, two partial sums per filter, v_rcp_f32 for the NLMS gains.
+template <int NFF, int NFB>
+__device__ __forceinline__ uint32_t eq_symbol_relaxed(const Params &P, Lane &L, float (&ffc)[NFF], float (&ffw)[NFF],
+                                                      float (&fbc)[NFB], float (&fbw)[NFB], float in0, float in1)
+{
+    uint32_t mode = (L.flags & F_EQ_MODE_MASK) >> F_EQ_MODE_SHIFT;
+    if (NFF >= 2) {
+#pragma unroll
+        for (int i = 0; i + 2 < NFF; ++i) ffw[i] = ffw[i + 2];
+        ffw[NFF >= 2 ? NFF - 2 : 0] = in0;
+        ffw[NFF - 1] = in1;
+    } else {
+        ffw[0] = in1;
+    }
+    float f0 = 0.0f, f1 = 0.0f, q0 = 0.0f, q1 = 0.0f;
+#pragma unroll
+    for (int i = 0; i < NFF; ++i) {
+        if (i & 1) { f1 = __builtin_fmaf(ffw[NFF - 1 - i], ffc[i], f1); q1 = __builtin_fmaf(ffw[i], ffw[i], q1); }
+        else { f0 = __builtin_fmaf(ffw[NFF - 1 - i], ffc[i], f0); q0 = __builtin_fmaf(ffw[i], ffw[i], q0); }
+    }
+    // the feedback window holds an exact 0.0 in every other slot (push(&[decision, 0.0]), rx/equalize.rs:304): those
+    // taps contribute nothing and are never updated (see eq_symbol_core)
+    constexpr auto fb_zero = [](int widx) { return ((NFB - 1 - widx) & 1) == 0; };
+    float fb = 0.0f, qb = 0.0f;
+#pragma unroll
+    for (int i = 0; i < NFB; ++i) {
+        if (!fb_zero(NFB - 1 - i)) fb = __builtin_fmaf(fbw[NFB - 1 - i], fbc[i], fb);
+        if (!fb_zero(i)) qb = __builtin_fmaf(fbw[i], fbw[i], qb);
+    }
+    const float sym_val = (f0 + f1) - fb;
+    float sym_est, err;
+    bool evolve = true;
+    if (mode == 2u) {                                  // EnabledTraining :278-301
+        sym_est = (L.eq_word & 1u) ? 1.0f : -1.0f;
+        L.eq_word >>= 1;
+        err = sym_est - sym_val;
+        L.eq_count += 1;
+        if (L.eq_count >= 32u) mode = 1u;
+    } else if (mode == 1u) {                           // EnabledFeedback :266-277
+        sym_est = rs_signum(sym_val);
+        err = sym_est - sym_val;
+    } else {                                           // Disabled :262-265
+        sym_est = rs_signum(sym_val); err = 0.0f; evolve = false;
+    }
+    if (evolve) {
+        const float gf = P.eq_relaxation * __builtin_amdgcn_rcpf(P.eq_regularization + (q0 + q1));
+        const float gb = P.eq_relaxation * __builtin_amdgcn_rcpf(P.eq_regularization + qb);
+        const float ge = gf * err, gn = -(gb * err);
+#pragma unroll
+        for (int i = 0; i < NFF; ++i) ffc[i] = __builtin_fmaf(ge, ffw[NFF - 1 - i], ffc[i]);
+#pragma unroll
+        for (int i = 0; i < NFB; ++i) { if (!fb_zero(NFB - 1 - i)) fbc[i] = __builtin_fmaf(gn, fbw[NFB - 1 - i], fbc[i]); }
+    }
+    if (NFB >= 2) {
+#pragma unroll
+        for (int i = 0; i + 2 < NFB; ++i) fbw[i] = fbw[i + 2];
+        fbw[NFB >= 2 ? NFB - 2 : 0] = sym_est;
+        fbw[NFB - 1] = 0.0f;
+    } else {
+        fbw[0] = 0.0f;
+    }
+    L.flags = (L.flags & ~F_EQ_MODE_MASK) | (mode << F_EQ_MODE_SHIFT);
+    return sym_est >= 0.0f ? 1u : 0u;
+}
+
+// The symbol path's context: the equalizer (20 floats) in registers with the relaxed step; the squelch's sample
+// history and the equalizer as of the last completed byte (written once per byte while a preamble is being acquired,
+// read back on a byte-clock re-alignment: rare, and 20 registers) in the HBM state arrays.
+template <int NFF, int NFB>
+struct RelaxCtx : TickRingGlobal {
+    const State *S;
+    uint32_t c, C;
+    float *hist;                       // this lane's column of S.sq_hist: slot i at hist[i * C]
+    float ffc[NFF], ffw[NFF], fbc[NFB], fbw[NFB];
+    __device__ __forceinline__ void mark(int) const {}
+    __device__ __forceinline__ void emit(const Params &P, const State &St, const Output &O, uint32_t ch, uint32_t kind,
+                                         uint64_t sample_counter, uint64_t symbols, uint32_t burst_len)
+    { emit_event(P, St, O, ch, kind, sample_counter, symbols, burst_len); }
+    __device__ __forceinline__ void hist_put(uint32_t slot, float v) { hist[(size_t)slot * C] = v; }
+    __device__ __forceinline__ float hist_get(uint32_t slot) const { return hist[(size_t)slot * C]; }
+    __device__ __forceinline__ void eq_snapshot(const Params &)
+    {
+#pragma unroll
+        for (int i = 0; i < NFF; ++i) { S->eq_snap_ffc[i * C + c] = ffc[i]; S->eq_snap_ffw[i * C + c] = ffw[i]; }
+#pragma unroll
+        for (int i = 0; i < NFB; ++i) { S->eq_snap_fbc[i * C + c] = fbc[i]; S->eq_snap_fbw[i * C + c] = fbw[i]; }
+    }
+    __device__ __forceinline__ void eq_restore(const Params &)
+    {
+#pragma unroll
+        for (int i = 0; i < NFF; ++i) { ffc[i] = S->eq_snap_ffc[i * C + c]; ffw[i] = S->eq_snap_ffw[i * C + c]; }
+#pragma unroll
+        for (int i = 0; i < NFB; ++i) { fbc[i] = S->eq_snap_fbc[i * C + c]; fbw[i] = S->eq_snap_fbw[i * C + c]; }
+    }
+    __device__ __forceinline__ void eq_reset(const Params &)
+    {
+#pragma unroll
+        for (int i = 0; i < NFF; ++i) { ffc[i] = (i == 0) ? 1.0f : 0.0f; ffw[i] = 0.0f; }
+#pragma unroll
+        for (int i = 0; i < NFB; ++i) { fbc[i] = (i == 0) ? 1.0f : 0.0f; fbw[i] = 0.0f; }
+    }
+    __device__ __forceinline__ uint32_t eq_symbols(const Params &P, Lane &L, const float *samples, int nsym)
+    {
+        uint32_t bits = 0;
+#pragma unroll 1
+        for (int b = 0; b < nsym; ++b)
+            bits |= eq_symbol_relaxed<NFF, NFB>(P, L, ffc, ffw, fbc, fbw, samples[2 * b], samples[2 * b + 1]) << b;
+        return bits;
+    }
+    __device__ __forceinline__ uint32_t eq_symbol1(const Params &P, Lane &L, float in0, float in1)
+    { return eq_symbol_relaxed<NFF, NFB>(P, L, ffc, ffw, fbc, fbw, in0, in1); }
+};
+
+// FastCtx (equalizer and its snapshot in registers, squelch history in LDS) with the relaxed equalizer step: the
+// symbol stage of the pipeline's FASTMATH build
+template <int NFF, int NFB>
+struct RelaxFastCtx : FastCtx<NFF, NFB> {
+    __device__ __forceinline__ uint32_t eq_symbols(const Params &P, Lane &L, const float *samples, int nsym)
+    {
+        uint32_t bits = 0;
+#pragma unroll 1
+        for (int b = 0; b < nsym; ++b)
+            bits |= eq_symbol_relaxed<NFF, NFB>(P, L, this->ffc, this->ffw, this->fbc, this->fbw, samples[2 * b], samples[2 * b + 1]) << b;
+        return bits;
+    }
+    __device__ __forceinline__ uint32_t eq_symbol1(const Params &P, Lane &L, float in0, float in1)
+    { return eq_symbol_relaxed<NFF, NFB>(P, L, this->ffc, this->ffw, this->fbc, this->fbw, in0, in1); }
+};
+
+}  // namespace same

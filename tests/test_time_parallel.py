@@ -1,8 +1,10 @@
 """Time-parallel ("fast") mode, SAME_BATCH_TIME_PARALLEL: the parity contract of include/same_rx.h.
 
-Every chunk's arithmetic is the strict, bit-exact one; what the mode approximates is the state a chunk
-starts from (a freshly built receiver one warm-up before the samples it owns).  Against the oracle on
-the same samples:
+The mode approximates the state a chunk starts from (a freshly built receiver one warm-up before the samples it
+owns) and, by default, runs the chunks in relaxed arithmetic (the pipeline's FASTMATH build: fused multiply-add
+partial sums in the matched filters, f32 square root, two-operation AGC chain, SAME_BATCH_RELAXED's contract);
+SAME_RELAXED=0 keeps every chunk's arithmetic strict.  EVERY test of this module runs both ways (the `arith`
+fixture).  Against the oracle on the same samples:
   * bursts: their number and order per channel and every transmitted byte (the header, or NNNN): EQUAL.
     The up to frame_max_invalid + 1 bytes a burst carries after them are decoded from the silence that
     follows the carrier and depend on the symbol clock's phase to the sample; they are not compared
@@ -28,6 +30,17 @@ pytestmark = pytest.mark.gpu
 
 SOFT_SYMBOL_TOLERANCE = 0.05
 SOFT_INSTANT_TOLERANCE = 8       # samples (a fifth of a symbol at 22.05 kHz; measured: max 6, mean 0.9)
+
+
+@pytest.fixture(autouse=True, params=["fastmath", "strict"])
+def arith(request, monkeypatch):
+    """The arithmetic inside the chunks: the default (relaxed: the pipeline's FASTMATH build wherever the batch is
+    whole 64-channel workgroups at 22.05 kHz) or strict (SAME_RELAXED=0); read when a batch is created."""
+    if request.param == "strict":
+        monkeypatch.setenv("SAME_RELAXED", "0")
+    else:
+        monkeypatch.delenv("SAME_RELAXED", raising=False)
+    return request.param
 
 
 @pytest.fixture(scope="module")
@@ -89,14 +102,17 @@ def payload_len(burst, payload):
     return len(payload) if burst[:4] == payload[:4] else 4
 
 
-def assert_contract(sa, got, ref, rate, n_ch, payload_of, exact_bursts=True, what="", t_end=None):
+def assert_contract(sa, got, ref, rate, n_ch, payload_of, exact_bursts=True, what="", t_end=None, garbled_per_mille=0):
     """got / ref: event arrays (kind, channel, sample_counter, len, bytes) ordered by channel then time;
-    ref from the oracle or from a strict batch.  payload_of(c) = what channel c transmits."""
+    ref from the oracle or from a strict batch.  payload_of(c) = what channel c transmits.
+    garbled_per_mille: bursts per thousand (at least one) whose transmitted bytes may differ -- 0 except for relaxed
+    arithmetic on NOISY input, where a marginal acquisition now and then goes the other way (measured: 1-2 in 22 000 bursts
+    at noise sigma 0.05-0.1, tools/noise_probe.py; strict mode loses 2-10 bursts in the same runs)."""
     sps = rate / 520.83
     tol = sa.receiver.TP_EVENT_TOLERANCE_SYMBOLS * sps
     g, r = split(got, n_ch), split(ref, n_ch)
     worst = {"reading": 0, "burst": 0, "no_carrier": 0, "searching": 0}
-    n_bursts = n_missing = 0
+    n_bursts = n_missing = n_garbled = 0
     for c in range(n_ch):
         pay = payload_of(c)
         bg, br = burst_records(g[c]), burst_records(r[c])
@@ -130,7 +146,10 @@ def assert_contract(sa, got, ref, rate, n_ch, payload_of, exact_bursts=True, wha
             n_missing += len(bg) - j
         for x, y in pairs:
             n = payload_len(y[4], pay)
-            assert x[4][:n] == y[4][:n], f"{what} channel {c}: burst payload differs: {x[4]!r} vs {y[4]!r}"
+            if x[4][:n] != y[4][:n]:
+                n_garbled += 1
+                assert garbled_per_mille, f"{what} channel {c}: burst payload differs: {x[4]!r} vs {y[4]!r}"
+                continue
             for name, i in (("reading", 1), ("burst", 2), ("no_carrier", 3)):
                 if x[i] is not None and y[i] is not None:
                     d = abs(x[i] - y[i])
@@ -142,6 +161,7 @@ def assert_contract(sa, got, ref, rate, n_ch, payload_of, exact_bursts=True, wha
                 assert d <= 16 * 8 * sps, f"{what} channel {c}: Searching outside the preamble"
     if not exact_bursts:
         assert n_missing <= max(4, n_bursts // 25), f"{what}: {n_missing} of {n_bursts} bursts unmatched"
+    assert n_garbled <= max(1, n_bursts * garbled_per_mille // 1000) * (1 if garbled_per_mille else 0), f"{what}: {n_garbled} of {n_bursts} payloads differ"
     return worst
 
 
@@ -156,7 +176,7 @@ def strict_events(sa, x, rate, builder=None, link_only=False):
 @pytest.mark.parametrize("n_ch,seconds,chunks,noise,rate", [(256, 10.0, 8, 0.0, 22050), (512, 8.0, 4, 0.05, 22050),
                                                             (192, 12.0, 6, 0.0, 22050), (256, 6.0, 4, 0.02, 48000),
                                                             (128, 6.0, 3, 0.0, 44100)])
-def test_time_parallel_meets_the_contract(sa, ob, n_ch, seconds, chunks, noise, rate):
+def test_time_parallel_meets_the_contract(sa, ob, arith, n_ch, seconds, chunks, noise, rate):
     from helpers.oracle_compare import assert_every_channel_matches_oracle
     n = int(rate * seconds)
     x = sa.synth_afsk(n_ch, n, rate, seed=1000 + n_ch, noise_sigma=noise)
@@ -169,7 +189,8 @@ def test_time_parallel_meets_the_contract(sa, ob, n_ch, seconds, chunks, noise, 
     assert rx.time_parallel_chunks() == chunks
     got = rx.poll_events_np()
     assert len(got[got["kind"] == 3]) >= 2 * n_ch
-    assert_contract(sa, got, ref, rate, n_ch, lambda c: sa.synth_payload(1000 + n_ch, c), exact_bursts=(noise == 0.0))
+    assert_contract(sa, got, ref, rate, n_ch, lambda c: sa.synth_payload(1000 + n_ch, c), exact_bursts=(noise == 0.0),
+                    garbled_per_mille=(1 if noise > 0.0 and arith == "fastmath" and rate == 22050 else 0))
 
 
 def test_time_parallel_streaming_calls_continue_the_channel_state(sa):
@@ -286,10 +307,42 @@ def test_soft_symbols_of_a_chunk_that_starts_fresh(sa, ob):
     assert err.max() <= SOFT_SYMBOL_TOLERANCE, stats
 
 
-def test_awgn_tally_statistically_equal(sa):
+def assert_awgn_tallies_equal(sa, got, ref, payloads, n, grid, strict_arithmetic):
+    """AWGN Monte-Carlo trials (configs[4]) decoded two ways.  Strict arithmetic on both sides: all but a handful of
+    marginal trials decode to the same bytes.  Relaxed arithmetic on one side: at the grid points where noise puts bit
+    errors into a burst, WHICH marginal symbols flip is chaotic in the last bit of the matched-filter sums, so there the
+    contract is statistical -- detection, intact headers and bit errors per grid point equal within sampling error --
+    and trial by trial only where strict mode decodes (nearly) every header intact."""
+    from sameold_amd import montecarlo as mc
+    ta, tb = mc.new_tally(grid), mc.new_tally(grid)
+    mc.score_bursts(ref, payloads, 0, n, grid, ta)
+    mc.score_bursts(got, payloads, 0, n, grid, tb)
+    g, r = split(got, n), split(ref, n)
+    differ = np.zeros(grid, np.int64)
+    for c in range(n):
+        bg, br = burst_list(g[c]), burst_list(r[c])
+        if not strict_arithmetic:        # the transmitted bytes; what follows them is decoded from the noise after the carrier
+            bg = [b[:payload_len(b, payloads[c])] for b in bg]
+            br = [b[:payload_len(b, payloads[c])] for b in br]
+        differ[c % grid] += bg != br
+    print("trials that decode differently per grid point:", differ.tolist(), "bit errors", tb["bit_errors"].tolist(), "vs", ta["bit_errors"].tolist())
+    if strict_arithmetic:
+        assert differ.sum() <= n // 100, f"{differ.sum()} of {n} trials decode differently"
+    else:
+        clean = ta["intact"] >= 0.99 * np.maximum(ta["trials"], 1)
+        assert clean.any() and np.all(differ[clean] <= 0.03 * ta["trials"][clean] + 2), (differ, clean)
+        be_a, be_b = ta["bit_errors"].astype(np.float64), tb["bit_errors"].astype(np.float64)
+        assert np.all(np.abs(be_a - be_b) <= 0.15 * np.maximum(be_a, be_b) + 60), (be_a, be_b)
+    for k in ("detected", "intact"):
+        # binomial: |difference| within 4 sigma of the strict count per grid point
+        sig = np.sqrt(np.maximum(ta[k] * (1 - ta[k] / np.maximum(ta["trials"], 1)), 1.0))
+        assert np.all(np.abs(ta[k] - tb[k]) <= 4 * sig + 2), (k, ta[k], tb[k])
+
+
+def test_awgn_tally_statistically_equal(sa, arith):
     """configs[4] through the time-parallel mode: every 2 s trial cut in two (the boundary falls inside the
-    burst, so the first chunk runs on and the second joins mid-burst).  Burst lists must agree with strict
-    mode on all but a handful of marginal trials, and the tallies must be statistically equal."""
+    burst, so the first chunk runs on and the second joins mid-burst).  Strict chunks: burst lists agree with strict mode
+    on all but a handful of marginal trials; relaxed chunks: the tallies are statistically equal (see above)."""
     from sameold_amd import montecarlo as mc
     n, grid, rate, seed = 4096, 15, 22050, 31
     T = 2 * rate - (2 * rate) % 20
@@ -301,16 +354,7 @@ def test_awgn_tally_statistically_equal(sa):
     assert rx.time_parallel_chunks() == 2
     got = rx.poll_events_np()
     payloads = [sa.synth_payload(seed, c) for c in range(n)]
-    ta, tb = mc.new_tally(grid), mc.new_tally(grid)
-    mc.score_bursts(ref, payloads, 0, n, grid, ta)
-    mc.score_bursts(got, payloads, 0, n, grid, tb)
-    g, r = split(got, n), split(ref, n)
-    differ = sum(burst_list(g[c]) != burst_list(r[c]) for c in range(n))
-    assert differ <= n // 100, f"{differ} of {n} trials decode differently"
-    for k in ("detected", "intact"):
-        # binomial: |difference| within 4 sigma of the strict count per grid point
-        sig = np.sqrt(np.maximum(ta[k] * (1 - ta[k] / np.maximum(ta["trials"], 1)), 1.0))
-        assert np.all(np.abs(ta[k] - tb[k]) <= 4 * sig + 2), (k, ta[k], tb[k])
+    assert_awgn_tallies_equal(sa, got, ref, payloads, n, grid, strict_arithmetic=(arith == "strict"))
 
 
 def test_time_parallel_i16_and_channel_major_inputs(sa):
@@ -364,14 +408,14 @@ def test_flush_and_reset_in_time_parallel_mode(sa):
 
 @pytest.mark.parametrize("n_ch,seconds,chunks,noise", [(256, 10.0, 8, 0.0), (128, 12.0, 5, 0.0), (192, 9.0, 8, 0.05),
                                                         (4096, 6.0, 12, 0.0)])      # (49 152 columns: pieces sorted into workgroups)
-def test_per_channel_boundaries_on_channel_major_input(sa, ob, monkeypatch, n_ch, seconds, chunks, noise):
+def test_per_channel_boundaries_on_channel_major_input(sa, ob, arith, monkeypatch, n_ch, seconds, chunks, noise):
     """A channel-major f32 input of whole blocks is read where it lies: an energy scout and a planner on the device
     put every chunk boundary of every channel at an idle instant (no run-on), each state column streams its own
     contiguous samples.  Same contract as the uniform cut."""
     monkeypatch.setenv("SAME_PIPE_LANES", "64")      # (small test batches would otherwise get 16-channel workgroups)
     rate = 22050
     n = int(rate * seconds)
-    n -= n % 20
+    n -= n % 420                     # whole blocks of every kernel that may take the chunks (20 and 42 samples)
     x = sa.synth_afsk(n_ch, n, rate, seed=3000 + n_ch, noise_sigma=noise)
     ref = strict_events(sa, x, rate)
     xc = x.t().contiguous()
@@ -383,7 +427,8 @@ def test_per_channel_boundaries_on_channel_major_input(sa, ob, monkeypatch, n_ch
     assert chunks - 1 <= rx.time_parallel_chunks() <= chunks and rx.time_parallel_per_channel()
     assert n_ch * rx.time_parallel_chunks() > 32768 or n_ch < 4096      # the big case exercises the sorted order
     got = rx.poll_events_np()
-    assert_contract(sa, got, ref, rate, n_ch, lambda c: sa.synth_payload(3000 + n_ch, c), exact_bursts=(noise == 0.0), t_end=n)
+    assert_contract(sa, got, ref, rate, n_ch, lambda c: sa.synth_payload(3000 + n_ch, c), exact_bursts=(noise == 0.0), t_end=n,
+                    garbled_per_mille=(1 if noise > 0.0 and arith == "fastmath" else 0))
     # and a second call continues from the state the last chunks left
     rx.process_tensor(xc, layout=sa.LAYOUT_CHANNEL_MAJOR)
     rx.sync()
@@ -398,7 +443,7 @@ def test_per_channel_boundaries_fall_back_when_there_is_no_quiet_instant(sa, mon
     import torch
     monkeypatch.setenv("SAME_PIPE_LANES", "64")
     rate, n_ch, n = 22050, 128, 22050 * 8
-    n -= n % 20
+    n -= n % 420
     x = sa.synth_afsk(n_ch, n, rate, seed=77)
     gen = torch.Generator(device="cuda"); gen.manual_seed(5)
     x[:, ::4] += torch.randn((n, n_ch // 4), device="cuda", generator=gen) * 3000.0      # every fourth channel drowned in noise

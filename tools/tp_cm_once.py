@@ -26,7 +26,7 @@ if hasattr(rx._L, "same_debug_profile_pipe"):
     import ctypes
     buf = (ctypes.c_ulonglong * 15)()
     rx._L.same_debug_profile_pipe(buf, 1)
-    names = ["stage 1", "stage 2", "stage 3"]
-    tot = [buf[3 * r] + buf[3 * r + 1] + buf[3 * r + 2] for r in range(3)]
-    for r in range(3):
+    names = ["stage 1", "stage 2", "stage 3", "stage 4 (helper)"]
+    tot = [buf[3 * r] + buf[3 * r + 1] + buf[3 * r + 2] for r in range(4)]
+    for r in range(4):
         print(f"  {names[r]}: work {buf[3 * r] / max(tot[r], 1):.3f}  barrier wait {buf[3 * r + 1] / max(tot[r], 1):.3f}  feedback {buf[3 * r + 2] / max(tot[r], 1):.3f}  (fractions of workgroup 0's time; total {tot[r]} clk)")
