@@ -1031,8 +1031,11 @@ int process_channel_major_native(same_batch *rx, const float *d_x, size_t n, hip
     hipError_t e = wave ? same::launch_demod_relaxed(tp.Pv, tp.Sv, O, rx->d_taps, d_x, (uint32_t)(n / fb), rx->counter, stream, pc)
                         : same::launch_demod_pipe(tp.Pv, tp.Sv, O, rx->d_taps, d_x, (uint32_t)(n / fb), rx->counter, stream, pc, tp.kernel == same_batch::TimePar::kPipeRelaxed);
     if (e != hipSuccess) return fail(SAME_EHIP, "time-parallel demod kernel launch failed: %s", hipGetErrorString(e));
-    // the channels' state afterwards: the last chunk's columns (they end with the input)
-    HIP_TRY(same::launch_copy_state_columns(tp.d_desc_out, tp.n_desc, columns, C, nullptr, C, stream, (n_chunks - 1u) * C));
+    // The channels' state afterwards: that of the chunk the hand-over chain ends in, as the host's stitch follows it --
+    // the last chunk as a rule (its columns end with the input); an earlier one where a burst ran on to the end of the
+    // call without a hand-over (a forced cut on a channel that is never quiet: its events are the ones that are kept).
+    HIP_TRY(same::launch_chunk_final_column_pc(sl.d_handover, d_own, C, n_chunks, rx->counter, tp.d_final_col, stream));
+    HIP_TRY(same::launch_copy_state_columns(tp.d_desc_out, tp.n_desc, columns, C, tp.d_final_col, C, stream));
     sl.chunked = true; sl.per_channel = true;
     sl.geom = geom;
     sl.end_blocks = rx->counter + n;

@@ -316,6 +316,32 @@ hipError_t launch_chunk_final_column(const uint64_t *handover, uint32_t in_chann
     hipLaunchKernelGGL(chunk_final_column_kernel, dim3((in_channels + 255) / 256), dim3(256), 0, stream, handover, in_channels, g, final_col);
     return hipGetLastError();
 }
+// the same for per-channel boundaries: the chunk that owns a hand-over instant is the last one whose own range
+// (own_start[k][c], relative to the call's first sample) begins at or before it
+__global__ void chunk_final_column_pc_kernel(const uint64_t *handover, const uint32_t *own_start, uint32_t C, uint32_t K,
+                                             uint64_t counter0, uint32_t *final_col)
+{
+    const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    uint32_t cur = 0;
+    for (;;) {
+        const uint64_t h = handover[(size_t)cur * C + c];
+        if (h == kNoHandover) break;
+        uint32_t nxt = cur;
+        for (uint32_t k = cur + 1u; k < K; ++k)
+            if (counter0 + own_start[(size_t)k * C + c] <= h) nxt = k;
+        if (nxt <= cur) break;
+        cur = nxt;
+    }
+    final_col[c] = cur * C + c;
+}
+hipError_t launch_chunk_final_column_pc(const uint64_t *handover, const uint32_t *own_start, uint32_t in_channels, uint32_t n_chunks,
+                                        uint64_t counter0, uint32_t *final_col, hipStream_t stream)
+{
+    hipLaunchKernelGGL(chunk_final_column_pc_kernel, dim3((in_channels + 255) / 256), dim3(256), 0, stream, handover, own_start,
+                       in_channels, n_chunks, counter0, final_col);
+    return hipGetLastError();
+}
 // ---- per-channel chunk boundaries (channel-major input) ----------------------------------------------------------
 constexpr uint32_t kScoutBlock = 256;        // samples per energy reading (one 64-byte sector of them is read)
 __global__ void tp_scout_kernel(const float *__restrict__ x, TpPlan g, float *__restrict__ energy)

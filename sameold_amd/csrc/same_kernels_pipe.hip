@@ -417,7 +417,14 @@ struct SampleStage {
 #pragma unroll
         for (int k = 0; k < kB; ++k) xs[k] = xn[BUF][k];
         if (xl) {
-            if (blk + 2 < avail) load_block_cm(xn[BUF], blk + 2u);       // per lane: its stream ends where the input does
+            if (blk + 2 < avail) {
+                load_block_cm(xn[BUF], blk + 2u);       // per lane: its stream ends where the input does
+            } else {
+                // ... and silence follows it: a lane that runs on with its workgroup past the end of its stream must not
+                // chew on stale registers (its events from there on are never kept, but its state may be)
+#pragma unroll
+                for (int k = 0; k < kB; ++k) xn[BUF][k] = 0.0f;
+            }
         } else if (blk + 2 < n_blocks) {
             const SampleT *xb = x + ((size_t)(blk + 2) * kB) * Cin;      // wave-uniform
 #pragma unroll

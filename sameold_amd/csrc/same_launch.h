@@ -56,6 +56,9 @@ hipError_t launch_copy_state_columns(const StateArrayDesc *desc, uint32_t n_desc
 // final_col[c] = the state column (chunk * in_channels + c) whose chunk ran to the end of the input
 hipError_t launch_chunk_final_column(const uint64_t *handover, uint32_t in_channels, ChunkGeom g, uint32_t *final_col,
                                      hipStream_t stream);
+// ... with per-channel boundaries: own_start [n_chunks][in_channels], relative to the call's first sample (counter0)
+hipError_t launch_chunk_final_column_pc(const uint64_t *handover, const uint32_t *own_start, uint32_t in_channels, uint32_t n_chunks,
+                                        uint64_t counter0, uint32_t *final_col, hipStream_t stream);
 hipError_t launch_fill_u64(uint64_t *p, size_t n, uint64_t v, hipStream_t stream);
 // Per-channel chunk boundaries for a channel-major input (time-parallel mode): an energy scout over
 // one 64-byte sector per 256-sample block, then per channel the idle instant nearest to every nominal boundary.

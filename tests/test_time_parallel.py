@@ -436,6 +436,32 @@ def test_per_channel_boundaries_on_channel_major_input(sa, ob, arith, monkeypatc
     assert len(again[again["kind"] == 3]) >= len(got[got["kind"] == 3]) - n_ch // 8
 
 
+def test_per_channel_boundaries_streaming_calls_with_bursts_across_the_call_boundary(sa, monkeypatch):
+    """Channel-major calls back to back, cut where bursts are in progress on many channels (every channel's schedule has its
+    own lead-in): the state a call leaves is that of the chunk its hand-over chain ends in, so the burst that straddles the
+    boundary is delivered whole by the next call.  The whole stream must meet the contract against strict mode."""
+    monkeypatch.setenv("SAME_PIPE_LANES", "64")
+    rate, n_ch = 22050, 256
+    part = 22050 * 5
+    part -= part % 420
+    x = sa.synth_afsk(n_ch, 4 * part, rate, seed=9090)
+    ref = strict_events(sa, x, rate)
+    rx = sa.SameReceiverBuilder(rate).build_batch(n_ch, time_parallel=True)
+    rx.time_parallel_config(max_chunks=4)
+    for i in range(4):
+        rx.process_tensor(x[i * part:(i + 1) * part].t().contiguous(), layout=sa.LAYOUT_CHANNEL_MAJOR)
+        assert rx.time_parallel_per_channel() and rx.time_parallel_chunks() >= 3
+    rx.sync()
+    got = rx.poll_events_np()
+    got = got[np.lexsort((np.arange(len(got)), got["channel"]))]
+    # bursts in progress at a boundary: a good third of the channels at each of the three
+    link = ref[ref["kind"] <= 3]
+    busy = sum(int(np.any((link["channel"] == c) & (link["kind"] == 2) & (link["sample_counter"] < b) &
+                          (np.roll(link["sample_counter"], -1) > b))) for b in (part, 2 * part, 3 * part) for c in range(n_ch))
+    assert busy >= n_ch // 2, busy
+    assert_contract(sa, got, ref, rate, n_ch, lambda c: sa.synth_payload(9090, c), what="streaming channel-major", t_end=4 * part)
+
+
 def test_per_channel_boundaries_fall_back_when_there_is_no_quiet_instant(sa, monkeypatch):
     """Channels that are never quiet (noise as loud as the bursts) leave the planner no allowed instant: it cuts at the
     length limit and the chunks run on until idle, as with uniform boundaries.  Whatever the two modes decode there
