@@ -233,6 +233,7 @@ struct same_batch {
     bool overflowed = false;
     bool use_fast = false;           // configuration has a latency-optimised kernel
     bool relaxed = false;            // relaxed arithmetic in time-parallel chunks (SAME_BATCH_TIME_PARALLEL or SAME_BATCH_RELAXED)
+    bool last_plain_fm = false;      // the last ordinary launch ran the pipeline's FASTMATH build
     bool relaxed_plain = false;      // ... and in ordinary launches: the one-wavefront relaxed kernel runs whole blocks (SAME_BATCH_RELAXED)
     int knob_relaxed = 0;            // SAME_RELAXED: -1 never (time-parallel chunks keep the strict pipeline), +1 as if SAME_BATCH_RELAXED were set
     bool force_generic = false;      // SAME_BATCH_GENERIC_KERNEL (tests compare both kernels)
@@ -346,6 +347,7 @@ void read_knobs(same_batch *rx)
     rx->host_threads = std::max(0, num("SAME_HOST_THREADS", 0));
     rx->tp.sort_mode = num("SAME_TP_SORT", -1);
     rx->knob_relaxed = tri("SAME_RELAXED");
+    { const char *e = std::getenv("SAME_RELAXED_KERNEL"); rx->P.knob_relaxed_kernel = !e ? 0 : (std::strcmp(e, "solo") == 0 ? 1 : (std::strcmp(e, "duo") == 0 ? 2 : (std::strcmp(e, "trio") == 0 ? 3 : 0))); }
     { const char *e = std::getenv("SAME_TP_KERNEL"); rx->tp.knob_kernel = !e ? 0 : (std::strcmp(e, "wave") == 0 ? 2 : (std::strcmp(e, "pipe") == 0 ? 1 : 0)); }
 }
 
@@ -749,11 +751,16 @@ uint32_t plan_chunks(same_batch *rx, size_t n, same::ChunkGeom &geom, same::Pipe
     const bool pipe_fm = rx->relaxed && tp.knob_kernel != 2 && C % same::kWave == 0u && C <= 16384u;
     if (rx->relaxed && !pipe_fm && tp.knob_kernel != 1 && C % same::kWave == 0u && C <= 65536u) {
         // one wavefront per 64 state columns, any number of them
-        const uint32_t fb = same::relaxed_block_len(rx->P);
-        const uint32_t k_cap = std::min(63u, 131072u / C);
-        const uint32_t k_max = tp.max_chunks ? std::min(tp.max_chunks, k_cap) : std::min(k_cap, std::max(2u, column_cap / C));
-        for (uint32_t K = k_max; K >= 2u; --K)
-            if (fill(K, fb)) { tp.kernel = same_batch::TimePar::kWaveRelaxed; return K; }
+        // (up to 262 144 state columns, 16 pieces per channel unless the caller asks for more: a piece is a burst with its
+        // margins at least, so more only sit empty)
+        (void)column_cap;
+        const uint32_t k_cap = std::min(63u, 262144u / C);
+        const uint32_t k_max = tp.max_chunks ? std::min(tp.max_chunks, k_cap) : std::min(k_cap, 16u);
+        same::Params Pk = rx->P;
+        for (uint32_t K = k_max; K >= 2u; --K) {
+            Pk.n_channels = K * C;                           // (the block length follows the form the column count selects)
+            if (fill(K, same::relaxed_block_len(Pk))) { tp.kernel = same_batch::TimePar::kWaveRelaxed; return K; }
+        }
         return 1;
     }
     if (C % 16u != 0u || C > 16384u) return 1;
@@ -905,9 +912,23 @@ int process_time_major(same_batch *rx, const SampleT *d_x, size_t n_samples, hip
         // whole blocks (16 or 18 samples) go to the latency-optimised kernel when the
         // configuration has one; the generic kernel takes the remainder (and every other
         // configuration)
-        const size_t fb = rx->relaxed_plain ? same::relaxed_block_len(rx->P) : (rx->use_fast ? same::fast_block_len(rx->P) : 16);
+        // SAME_BATCH_RELAXED on an ordinary launch: the pipeline's FASTMATH build while the batch fits it (whole 64-channel
+        // workgroups, up to 32 768 channels: four wavefronts per 64 channels), the one- / two-wavefront relaxed kernel beyond
+        // (SAME_RELAXED_KERNEL=solo / duo forces that one)
+        same::Params Pfm = rx->P;
+        Pfm.knob_pipe_lanes = 64; Pfm.knob_pipe_share = 1; Pfm.knob_pipe_split = 1; Pfm.knob_pipe = 1;
+        const bool plain_fm = rx->relaxed_plain && rx->P.knob_relaxed_kernel == 0 && rx->P.n_channels <= 32768u && same::pipe_relaxed_supported(Pfm);
+        rx->last_plain_fm = plain_fm;
+        const size_t fb = plain_fm ? same::pipe_block_len(Pfm)
+                                   : (rx->relaxed_plain ? same::relaxed_block_len(rx->P) : (rx->use_fast ? same::fast_block_len(rx->P) : 16));
         size_t n_fast = (rx->use_fast && !rx->force_generic) ? (n / fb) * fb : 0;
-        if (n_fast && rx->relaxed_plain) {
+        if (n_fast && plain_fm) {
+            if constexpr (sizeof(SampleT) == 4)
+                e = same::launch_demod_pipe(Pfm, rx->S, O, rx->d_taps, (const float *)xp, (uint32_t)(n_fast / fb), rx->counter, stream, same::PipeChunks{}, true);
+            else
+                e = same::launch_demod_pipe_i16(Pfm, rx->S, O, rx->d_taps, (const int16_t *)xp, (uint32_t)(n_fast / fb), rx->counter, stream, same::PipeChunks{}, true);
+            if (e != hipSuccess) return fail(SAME_EHIP, "relaxed pipeline launch failed: %s", hipGetErrorString(e));
+        } else if (n_fast && rx->relaxed_plain) {
             if constexpr (sizeof(SampleT) == 4)
                 e = same::launch_demod_relaxed(rx->P, rx->S, O, rx->d_taps, (const float *)xp, (uint32_t)(n_fast / fb), rx->counter, stream);
             else
@@ -1450,7 +1471,7 @@ const char *same_batch_kernel_name(const same_batch *rx)
         default: return "demod_pipe_kernel";
         }
     }
-    if (rx->relaxed_plain) return "demod_relaxed_kernel";
+    if (rx->relaxed_plain) return rx->last_plain_fm ? "demod_pipe_kernel<fastmath>" : "demod_relaxed_kernel";
     if (rx->use_fast && !rx->force_generic) 
     {
         const uint32_t st = same::pipe_kernel_stages(rx->P);

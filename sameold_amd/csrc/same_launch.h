@@ -34,7 +34,8 @@ uint32_t pipe_workgroup_channels(const Params &P);   // channels per workgroup t
 // relaxed-arithmetic throughput kernel (same_kernels_relaxed.hip): 22.05 kHz, one wavefront per 64 state columns,
 // whole blocks of relaxed_block_len() samples; takes time-parallel chunks like the pipeline
 bool relaxed_kernel_supported(const Params &P);
-uint32_t relaxed_block_len(const Params &P);
+uint32_t relaxed_block_len(const Params &P);      // samples per block of the form relaxed_kernel_kind(P) picks for P.n_channels columns
+uint32_t relaxed_kernel_kind(const Params &P);    // 0 solo, 1 duo, 2 trio (same_kernels_relaxed.hip)
 hipError_t launch_demod_relaxed(const Params &P, const State &S, const Output &O, const float4 *taps,
                                 const float *x, uint32_t n_blocks, uint64_t counter0, hipStream_t stream,
                                 const PipeChunks &chunks = PipeChunks{});

@@ -36,6 +36,15 @@ def sa():
     return sameold_amd
 
 
+@pytest.fixture(autouse=True, params=["solo", "duo"])
+def wave_kernel(request, monkeypatch):
+    """The relaxed kernels proper: one wavefront per 64 channels ("solo") or two ("duo": sample phase | instants).  Without
+    SAME_RELAXED_KERNEL a relaxed batch of up to 32 768 channels runs the pipeline's FASTMATH build, which
+    tests/test_time_parallel.py and test_relaxed_batches_on_the_pipeline cover.  Read when a batch is created."""
+    monkeypatch.setenv("SAME_RELAXED_KERNEL", request.param)
+    return request.param
+
+
 @pytest.fixture(scope="module")
 def ob():
     from oracle import binding
@@ -174,6 +183,20 @@ def test_relaxed_awgn_tally_statistically_equal(sa):
     _, got = relaxed_events(sa, x, rate, link_only=True)
     payloads = [sa.synth_payload(seed, c) for c in range(n)]
     assert_awgn_tallies_equal(sa, got, ref, payloads, n, grid, strict_arithmetic=False)
+
+
+def test_relaxed_batches_on_the_pipeline(sa, monkeypatch):
+    """The default for a relaxed batch of whole 64-channel groups up to 32 768 channels: the wavefront pipeline's FASTMATH
+    build on an ordinary launch (no time-parallel cut).  Same contract."""
+    monkeypatch.delenv("SAME_RELAXED_KERNEL", raising=False)
+    rate, n_ch, n = 22050, 512, 22050 * 8
+    for noise, seed in ((0.0, 71), (0.05, 72)):
+        x = sa.synth_afsk(n_ch, n, rate, seed=seed, noise_sigma=noise)
+        ref = strict_events(sa, x, rate)
+        rx, got = relaxed_events(sa, x, rate, calls=[60000, 77, n - 60077])
+        assert rx.kernel_name() == "demod_pipe_kernel<fastmath>"
+        assert_contract(sa, got, ref, rate, n_ch, lambda c: sa.synth_payload(seed, c), exact_bursts=(noise == 0.0), what="pipeline fastmath",
+                        garbled_per_mille=(1 if noise > 0.0 else 0))
 
 
 def test_configurations_without_a_relaxed_kernel_run_strict(sa):

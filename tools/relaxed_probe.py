@@ -79,7 +79,7 @@ def profile_report(rx, reps):
     import ctypes
     buf = (ctypes.c_ulonglong * 8)()
     rx._L.same_debug_profile_relaxed(buf, 1)
-    names = ["DC blocker (+ input wait)", "AGC + window push", "matched filters", "timing loop + symbol path", "replay / loop ends", "hand-over check"]
+    names = ["DC blocker (+ input wait)", "AGC + window push", "matched filters", "timing loop + symbol path", "replay / loop ends (duo: B posting + barrier wait)", "hand-over check (duo: A barrier wait + replay)"]
     nsb = max(int(buf[6]), 1)
     tot = sum(buf[:6])
     for n, v in zip(names, buf[:6]):
