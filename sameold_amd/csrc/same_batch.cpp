@@ -197,7 +197,7 @@ struct same_batch {
         size_t handover_cap = 0;
         // per-channel chunk boundaries (channel-major input): device arrays of the launch, host copies for the stitch
         bool per_channel = false;
-        uint32_t *d_geom = nullptr;      // [own_start | row0 | nominal | perm | perm scratch] x columns, then wg_blocks
+        uint32_t *d_geom = nullptr;      // [own_start | row0 | nominal | perm] x columns, then wg_blocks
         uint32_t *h_geom = nullptr;      // pinned: own_start | row0
         size_t geom_cap = 0;
     } slot[2];
@@ -216,8 +216,7 @@ struct same_batch {
         uint32_t *d_final_col = nullptr;
         float *d_energy = nullptr; size_t energy_cap = 0;   // scout scratch
         uint32_t *d_sort = nullptr;                          // planner's bucket-sort scratch
-        int sort_mode = -1;                                  // SAME_TP_SORT: -1 choose, 0 grid order, 1 pieces sorted by length, 2 ... and long beside short
-        uint32_t cus = 0;                                    // compute units of the device
+        int sort_mode = -1;                                  // SAME_TP_SORT: -1 choose, 0 grid order, 1 pieces sorted by length into workgroups
         uint32_t last_chunks = 1;
         bool last_per_channel = false;
         // which kernel runs the chunks of the call being planned: the wavefront pipeline (strict, or its FASTMATH build
@@ -339,7 +338,6 @@ void read_knobs(same_batch *rx)
     rx->P.knob_pipe_lanes = num("SAME_PIPE_LANES", 0);
     rx->P.knob_pipe_split = tri("SAME_PIPE_SPLIT");
     rx->P.knob_mirror = tri("SAME_MIRROR");
-    rx->P.knob_pipe_ahead = tri("SAME_PIPE_AHEAD");
     rx->P.knob_pipe_share = tri("SAME_PIPE_SHARE");
     rx->P.knob_fast_dense = tri("SAME_FAST_DENSE");
     rx->P.knob_prio = num("SAME_PIPE_PRIO", 0);
@@ -347,7 +345,7 @@ void read_knobs(same_batch *rx)
     rx->host_threads = std::max(0, num("SAME_HOST_THREADS", 0));
     rx->tp.sort_mode = num("SAME_TP_SORT", -1);
     rx->knob_relaxed = tri("SAME_RELAXED");
-    { const char *e = std::getenv("SAME_RELAXED_KERNEL"); rx->P.knob_relaxed_kernel = !e ? 0 : (std::strcmp(e, "solo") == 0 ? 1 : (std::strcmp(e, "duo") == 0 ? 2 : (std::strcmp(e, "trio") == 0 ? 3 : 0))); }
+    { const char *e = std::getenv("SAME_RELAXED_KERNEL"); rx->P.knob_relaxed_kernel = !e ? 0 : (std::strcmp(e, "solo") == 0 ? 1 : (std::strcmp(e, "duo") == 0 ? 2 : 0)); }
     { const char *e = std::getenv("SAME_TP_KERNEL"); rx->tp.knob_kernel = !e ? 0 : (std::strcmp(e, "wave") == 0 ? 2 : (std::strcmp(e, "pipe") == 0 ? 1 : 0)); }
 }
 
@@ -1009,7 +1007,7 @@ int process_channel_major_native(same_batch *rx, const float *d_x, size_t n, hip
         if (sl.d_geom) HIP_TRY(hipFree(sl.d_geom));
         if (sl.h_geom) HIP_TRY(hipHostFree(sl.h_geom));
         sl.d_geom = nullptr; sl.h_geom = nullptr; sl.geom_cap = 0;
-        HIP_TRY(hipMalloc((void **)&sl.d_geom, ((size_t)5 * columns + columns / same::kWave) * sizeof(uint32_t)));
+        HIP_TRY(hipMalloc((void **)&sl.d_geom, ((size_t)4 * columns + columns / same::kWave) * sizeof(uint32_t)));
         HIP_TRY(hipHostMalloc((void **)&sl.h_geom, (size_t)2 * columns * sizeof(uint32_t), hipHostMallocDefault));
         sl.geom_cap = columns;
     }
@@ -1032,17 +1030,15 @@ int process_channel_major_native(same_batch *rx, const float *d_x, size_t n, hip
         tp.energy_cap = e_need;
     }
     uint32_t *d_own = sl.d_geom, *d_row0 = sl.d_geom + columns, *d_nom = sl.d_geom + 2 * (size_t)columns,
-             *d_perm = sl.d_geom + 3 * (size_t)columns, *d_perm2 = sl.d_geom + 4 * (size_t)columns, *d_wg = sl.d_geom + 5 * (size_t)columns;
-    // pieces sorted by length into workgroups only when the workgroups come in more than one round (the long ones
-    // first).  Within one round neither the sorted order nor a long workgroup beside a short one on every CU
-    // (SAME_TP_SORT=2) pays: a 64-channel workgroup that has its CU to itself runs only ~15 % faster (3 785 against
-    // 4 475 clk per step), and the sort costs what that buys (4.09-4.12 against 4.08 ms on one box, 4.09 against 4.28 on another)
-    const int sort_mode = tp.sort_mode >= 0 ? tp.sort_mode : (columns > 32768u ? 1 : 0);
+             *d_perm = sl.d_geom + 3 * (size_t)columns, *d_wg = sl.d_geom + 4 * (size_t)columns;
+    // pieces sorted by length into workgroups only when the workgroups come in more than one round (the long ones first;
+    // SAME_TP_SORT=0 / 1 overrides).  Within one round neither the sorted order nor a long workgroup beside a short one on
+    // every CU pays (round 2).
+    const int sort_mode = tp.sort_mode >= 0 ? (tp.sort_mode ? 1 : 0) : (columns > 32768u ? 1 : 0);
     if (!tp.d_sort) HIP_TRY(hipMalloc((void **)&tp.d_sort, same::tp_sort_scratch_bytes()));
     HIP_TRY(same::launch_counters(sl.d_counters, sl.h_counters_dev, 0, stream));
     if (rx->timing) HIP_TRY(hipEventRecord(sl.ev_start, stream));
-    HIP_TRY(same::launch_tp_plan(d_x, plan, tp.d_energy, d_own, d_row0, d_nom, d_perm, d_wg, tp.d_sort, sort_mode != 0, stream,
-                                 sort_mode == 2 ? tp.cus : 0u, d_perm2));
+    HIP_TRY(same::launch_tp_plan(d_x, plan, tp.d_energy, d_own, d_row0, d_nom, d_perm, d_wg, tp.d_sort, sort_mode != 0, stream));
     HIP_TRY(same::launch_init_state(tp.Pv, tp.Sv, 0, stream));
     HIP_TRY(same::launch_copy_state_columns(tp.d_desc_in, tp.n_desc, C, columns, nullptr, C, stream));
     HIP_TRY(same::launch_fill_u64(sl.d_handover, columns, same::kNoHandover, stream));
@@ -1198,7 +1194,6 @@ int same_batch_new(const same_rx_builder *b, uint32_t n_channels, int device, ui
     TRY_OR_CLEAN(hipGetDeviceProperties(&prop, device));
     if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
         return cleanup(fail(SAME_ENODEVICE, "device %d is %s; this build carries gfx950 code only", device, prop.gcnArchName));
-    rx->tp.cus = (uint32_t)prop.multiProcessorCount;
     rx->use_fast = same::fast_kernel_supported(rx->P);
     rx->force_generic = (flags & SAME_BATCH_GENERIC_KERNEL) != 0;
     // Relaxed arithmetic: asked for (SAME_BATCH_RELAXED), or implied by the time-parallel mode, whose contract is the

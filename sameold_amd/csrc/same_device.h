@@ -57,10 +57,8 @@ struct Params {
     int32_t knob_mirror;      // SAME_MIRROR (one-wavefront kernel's mirrored window)
     int32_t knob_fast_dense;  // SAME_FAST_DENSE (one-wavefront kernel: the two-per-SIMD build whatever the channel count)
     int32_t knob_pipe_share;  // SAME_PIPE_SHARE (the two-workgroups-per-CU register budget whatever the channel count)
-    int32_t knob_pipe_ahead;  // SAME_PIPE_AHEAD (16-channel workgroups: candidate filtering a block ahead; +1 on)
-    int32_t knob_relaxed_kernel;  // SAME_RELAXED_KERNEL: 0 choose, 1 "solo" (one wavefront per 64 columns), 2 "duo" (two)
-    int32_t knob_prio;        // SAME_PIPE_PRIO bit mask (experiments): 1 raise the issue priority of the pipeline's critical
-                              // wavefronts (stage 2, the helper's filter), 2 s_sleep in stage 2's poll loop
+    int32_t knob_relaxed_kernel;  // SAME_RELAXED_KERNEL: 0 choose (incl. the pipeline's FASTMATH build), 1 "solo" (one wavefront per 64 columns), 2 "duo" (two)
+    int32_t knob_prio;        // SAME_PIPE_PRIO: knock-out mask of SAME_PROFILE builds (same_profile.h PROF_SKIP); unused otherwise
 };
 
 // flag bits of State::flags

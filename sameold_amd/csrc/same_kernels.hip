@@ -484,33 +484,6 @@ __global__ void tp_iota_kernel(uint32_t *perm, uint32_t n)
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) perm[i] = i;
 }
-// A launch of at most two workgroups per CU is resident all at once, and the dispatcher puts grid positions w and
-// w + (number of CUs) on the same CU (tools/placement_probe.hip).  A workgroup that has a CU to itself runs faster per
-// sample than one that shares it, so the launch ends sooner when every CU holds a long and a short workgroup: the
-// workgroups the bucket sort formed are ranked by length; the longest `cus` take positions 0 .. cus-1 in descending
-// order, the rest positions cus .. in ascending order (the shortest beside the longest).  One workgroup of 1 024 threads.
-__global__ __launch_bounds__(1024) void tp_pair_kernel(TpPlan g, uint32_t cus, const uint32_t *__restrict__ row0, const uint32_t *__restrict__ nominal,
-                                                       const uint32_t *__restrict__ perm_in, uint32_t *__restrict__ perm_out)
-{
-    __shared__ uint32_t len[1024];
-    const uint32_t G = g.n_chunks * g.channels / kWave, w = threadIdx.x;
-    uint32_t mine = 0;
-    if (w < G) {
-        for (uint32_t l = 0; l < kWave; ++l) {
-            const uint32_t v = perm_in[w * kWave + l];
-            const uint32_t avail = (g.whole_samples - row0[v]) / g.block_len;
-            const bool last = v / g.channels + 1u == g.n_chunks;
-            mine = max(mine, last ? avail : min(nominal[v], avail));
-        }
-        len[w] = mine;
-    }
-    __syncthreads();
-    if (w >= G) return;
-    uint32_t rank = 0;
-    for (uint32_t u = 0; u < G; ++u) { const uint32_t lu = len[u]; rank += (lu > mine || (lu == mine && u < w)) ? 1u : 0u; }
-    const uint32_t pos = (G <= cus || rank < cus) ? rank : cus + (G - 1u - rank);
-    for (uint32_t l = 0; l < kWave; ++l) perm_out[pos * kWave + l] = perm_in[w * kWave + l];
-}
 // One wavefront per workgroup of the demodulation launch (64 grid positions): how many blocks it runs at most, and --
 // last chunk -- one common first row for its lanes, so that they all end with the input.
 __global__ void tp_align_kernel(TpPlan g, const uint32_t *__restrict__ perm, uint32_t *__restrict__ row0, uint32_t *__restrict__ wg_blocks)
@@ -524,8 +497,7 @@ __global__ void tp_align_kernel(TpPlan g, const uint32_t *__restrict__ perm, uin
     if (threadIdx.x == 0) wg_blocks[blockIdx.x] = m;
 }
 hipError_t launch_tp_plan(const float *x, const TpPlan &g, float *energy, uint32_t *own_start, uint32_t *row0,
-                          uint32_t *nominal, uint32_t *perm, uint32_t *wg_blocks, uint32_t *sort_scratch, bool sorted, hipStream_t stream,
-                          uint32_t pair_cus, uint32_t *perm_scratch)
+                          uint32_t *nominal, uint32_t *perm, uint32_t *wg_blocks, uint32_t *sort_scratch, bool sorted, hipStream_t stream)
 {
     const size_t n = (size_t)g.channels * g.scout_blocks;
     const uint32_t columns = g.n_chunks * g.channels;
@@ -536,10 +508,7 @@ hipError_t launch_tp_plan(const float *x, const TpPlan &g, float *energy, uint32
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL(tp_sort_hist_kernel, dim3((columns + 255) / 256), dim3(256), 0, stream, g, row0, nominal, sort_scratch);
         hipLaunchKernelGGL(tp_sort_scan_kernel, dim3(1), dim3(kWave), 0, stream, g, sort_scratch);
-        const bool pair = pair_cus != 0u && perm_scratch != nullptr && columns / kWave <= 1024u;
-        hipLaunchKernelGGL(tp_sort_scatter_kernel, dim3((columns + 255) / 256), dim3(256), 0, stream, g, row0, nominal, sort_scratch,
-                           pair ? perm_scratch : perm);
-        if (pair) hipLaunchKernelGGL(tp_pair_kernel, dim3(1), dim3(1024), 0, stream, g, pair_cus, row0, nominal, perm_scratch, perm);
+        hipLaunchKernelGGL(tp_sort_scatter_kernel, dim3((columns + 255) / 256), dim3(256), 0, stream, g, row0, nominal, sort_scratch, perm);
     } else {
         hipLaunchKernelGGL(tp_iota_kernel, dim3((columns + 255) / 256), dim3(256), 0, stream, perm, columns);
     }

@@ -62,10 +62,8 @@ template <int NT> struct PipeGeom;
 template <> struct PipeGeom<42> { static constexpr int DCL = 16, B = kBlockPipe22; };   // 22.05 kHz
 template <> struct PipeGeom<92> { static constexpr int DCL = 35, B = kBlockPipe48; };       // 48 kHz
 template <> struct PipeGeom<84> { static constexpr int DCL = 32, B = kBlockPipe44; };       // 44.1 kHz
-// AHEAD (see pipe_ahead below): stage 1 runs one more block ahead, so the ring holds six blocks and the DC wave's
-// ring eight
-template <int NT, bool AHEAD = false> struct PipeLayout {
-    static constexpr int B = PipeGeom<NT>::B, RING = (AHEAD ? 6 : 5) * B;
+template <int NT> struct PipeLayout {
+    static constexpr int B = PipeGeom<NT>::B, RING = 5 * B;
     // stage 1 keeps the DC-blocker outputs of its last three blocks for a replay: in registers
     // (3 x 20) at 22.05 kHz, in an LDS ring of three blocks at 44.1 / 48 kHz, where 3 x 32 more
     // registers per lane would spill and the CU's LDS has room
@@ -73,7 +71,7 @@ template <int NT, bool AHEAD = false> struct PipeLayout {
     static constexpr uint32_t yring_floats = YLDS ? 3u * (uint32_t)B * kWave : 0u;
     // DCW builds (a fifth wavefront runs the DC blocker a block ahead, see DcStage): its outputs of four
     // blocks -- the one being written, the one stage 1 consumes, two more for a replay
-    static constexpr uint32_t dcw_blocks = AHEAD ? 8u : 4u;
+    static constexpr uint32_t dcw_blocks = 4u;
     static constexpr uint32_t dcw_ring_floats = dcw_blocks * (uint32_t)B * kWave;
     static constexpr uint32_t tap_floats = (uint32_t)((NT * 4 + PIPE_PROF_TAP_PAD + 63) / 64 * 64);
     static_assert(B <= RING - NT + 1, "the first block's low copy would be read");
@@ -603,11 +601,11 @@ struct DcStage {
     }
 };
 
-template <int NT_, bool MED3, bool AHEAD = false>
+template <int NT_, bool MED3>
 struct AgcStage {
-    static constexpr int kB = PipeLayout<NT_, AHEAD>::B, RING = PipeLayout<NT_, AHEAD>::RING;
-    static constexpr int DEPTH = AHEAD ? 4 : 3;         // blocks a replay reaches back over, the current one included
-    static constexpr uint32_t LP = kWave, YMASK = PipeLayout<NT_, AHEAD>::dcw_blocks - 1u;
+    static constexpr int kB = PipeLayout<NT_>::B, RING = PipeLayout<NT_>::RING;
+    static constexpr int DEPTH = 3;                     // blocks a replay reaches back over, the current one included
+    static constexpr uint32_t LP = kWave, YMASK = PipeLayout<NT_>::dcw_blocks - 1u;
     const float *ycol;                   // this lane's column of the DC wave's ring [4 or 8][kB][64]; block b in slot b & YMASK
     float gain;
     bool locked;                         // this stage's belief of the AGC lock
@@ -662,7 +660,7 @@ struct AgcStage {
         wnext += kB;
         if (wnext == (uint32_t)RING) wnext = 0;
     }
-    // the lock flipped at sample fk of block s - 2 (history slot 2; 3 when this stage is a block further ahead): redo
+    // the lock flipped at sample fk of block s - 2 (history slot 2): redo
     // the AGC from there on, through every later block that exists (blocks < n_blocks)
     __device__ __forceinline__ void replay(const Params &P, float *wcol, uint32_t s, int fk, bool new_locked, uint32_t n_blocks)
     {
@@ -694,17 +692,6 @@ struct AgcStage {
 
 // wavefronts per workgroup: five in DCW builds
 template <int NT, int LANES, bool SPLIT> constexpr bool pipe_dcw() { return NT == 42 && LANES <= 32 && SPLIT; }
-// AHEAD (16-channel DCW workgroups): the matched filters leave the TED -> loop -> next-instant recurrence.  The next
-// instant's position depends on the sample still on its way only through its sign (ted_ahead), so after every block
-// stage 2 knows the (at most two) positions the first instant of the block AFTER the next can have.  The helper
-// wavefront -- 2 candidates x 2 filters x 16 channels = its 64 lanes -- computes the magnitudes at both while stage 2
-// works on the block before; a step later stage 2 picks the pair whose position matches the one the loop arrived at
-// (or, when neither does: a second instant in a block, a replay, computes the filters itself) and only runs the
-// timing loop.  For the window to hold the candidates' samples stage 1 runs one more block ahead (ring of six
-// blocks, replay over four), the DC wave two.  Each candidate is the same newest-first 42-tap chain over the same
-// window: bit-identical.
-template <int NT, int LANES, bool SPLIT> constexpr bool pipe_can_ahead() { return pipe_dcw<NT, LANES, SPLIT>() && LANES == 16; }
-
 // SHARE: built for two wavefronts per SIMD (half of the 512-entry register file each, a few
 // spills) -- what lets two workgroups, eight wavefronts, share a CU's four SIMDs beyond 16 384
 // channels.  Smaller batches use the unconstrained build (2 % faster).
@@ -723,16 +710,15 @@ template <int NT, int LANES, bool SPLIT> constexpr bool pipe_can_ahead() { retur
 // FM (FASTMATH): the relaxed arithmetic of same_relaxed_common.h in every stage -- matched filters as fused multiply-adds
 // into partial sums with an f32 square root, the AGC's two-operation gain chain, the equalizer's fused steps.  Built for
 // the 64-channel two-per-CU form the time-parallel launches use; its parity contract is that mode's (include/same_rx.h).
-template <int NT, int NFF, int NFB, bool MED3, bool SHARE, int LANES, bool SPLIT, typename SampleT, bool AHEAD = false, bool FM = false>
+template <int NT, int NFF, int NFB, bool MED3, bool SHARE, int LANES, bool SPLIT, typename SampleT, bool FM = false>
 __global__ __launch_bounds__((pipe_dcw<NT, LANES, SPLIT>() ? 5 : 4) * kWave, SHARE ? 2 : 1) void demod_pipe_kernel(Params P, State S, Output O,
                                                                 const float4 *__restrict__ taps,
                                                                 const SampleT *__restrict__ x,
                                                                 uint32_t n_blocks, uint64_t counter0, PipeChunks K)
 {
-    static_assert(!AHEAD || pipe_can_ahead<NT, LANES, SPLIT>(), "AHEAD is built for 16-channel DCW workgroups");
-    static_assert(!FM || (SPLIT && SHARE && NT == 42 && LANES == 64 && !AHEAD), "FASTMATH is built for the 64-channel two-per-CU form");
-    constexpr int kB = PipeLayout<NT, AHEAD>::B, RING = PipeLayout<NT, AHEAD>::RING;
-    constexpr uint32_t LP = kWave, kPipeTapFloats = PipeLayout<NT, AHEAD>::tap_floats;
+    static_assert(!FM || (SPLIT && SHARE && NT == 42 && LANES == 64), "FASTMATH is built for the 64-channel two-per-CU form");
+    constexpr int kB = PipeLayout<NT>::B, RING = PipeLayout<NT>::RING;
+    constexpr uint32_t LP = kWave, kPipeTapFloats = PipeLayout<NT>::tap_floats;
     // PACKED: workgroups of 16 or 32 channels -- the helper wavefront computes BOTH matched filters (mark on its
     // lanes 0 .. LANES-1, space on LANES .. 2*LANES-1) and stage 2 keeps only the timing loop
     constexpr bool PACKED = SPLIT && LANES <= 32;
@@ -801,14 +787,6 @@ __global__ __launch_bounds__((pipe_dcw<NT, LANES, SPLIT>() ? 5 : 4) * kWave, SHA
     lds_u32 *posbox = againbox + kWave;                        // SPLIT: [2][64] sample index of block b's instant
     lds_u32 *spacebox = posbox + 2u * kWave;                   // SPLIT: [64] space-filter magnitude
     lds_u32 *markbox = spacebox + kWave;                       // PACKED: [64] mark-filter magnitude
-    lds_u32 *candbox = posbox;                                 // AHEAD: [2][64] candidate positions of block b's first instant (two bytes)
-    lds_u32 *resbox = spacebox;                                // AHEAD: [2][candidate][filter][16] magnitudes for block b
-    // AHEAD: a candidate position travels as a byte, 0xff = none; equal candidates are filtered once
-    auto cand_word = [](int a, int b) -> uint32_t {
-        const uint32_t ua = (a >= 0 && a < kB) ? (uint32_t)a : 0xffu;
-        const uint32_t ub = (b >= 0 && b < kB && b != a) ? (uint32_t)b : 0xffu;
-        return ua | (ub << 8);
-    };
     float *hcol = lds + kPipeTapFloats + kP3MailWords + lane;
     float *wring = lds + kPipeTapFloats + kP3MailWords + (kSquelchHist - kB) * LP;   // logical slot 0
     float *wcol = wring + lane;
@@ -824,18 +802,14 @@ __global__ __launch_bounds__((pipe_dcw<NT, LANES, SPLIT>() ? 5 : 4) * kWave, SHA
         DcStage<NT, SampleT> D;
         D.load(P, S, x, c, C, cin, Cin, counter0, n_blocks);
         float *ycol = dcw_ring + lane;
-        constexpr uint32_t YMASK = PipeLayout<NT, AHEAD>::dcw_blocks - 1u;
+        constexpr uint32_t YMASK = PipeLayout<NT>::dcw_blocks - 1u;
         D.template fetch<0>(x, 0u, n_blocks, cin, Cin);               // block 0 before anyone starts
         D.block(P, ycol);
         lds_barrier();                                                 // prologue (every role of a DCW build has one)
-        if constexpr (AHEAD) {                                         // ... two when stage 1 starts a block ahead as well
-            if (n_blocks > 1u) { D.template fetch<1>(x, 1u, n_blocks, cin, Cin); D.block(P, ycol + (uint32_t)kB * LP); }
-            lds_barrier();
-        }
         uint32_t stop_at = 0xffffffffu;
         P3_T0();
         auto step = [&](uint32_t s, auto buf) -> bool {
-            const uint32_t blk = s + (AHEAD ? 2u : 1u);                // BUF = blk & 1
+            const uint32_t blk = s + 1u;                               // BUF = blk & 1
             if (blk < n_blocks && !PROF_SKIP(P, 128)) {
                 D.template fetch<decltype(buf)::value>(x, blk, n_blocks, cin, Cin);
                 D.block(P, ycol + ((blk & YMASK) * (uint32_t)kB) * LP);
@@ -853,8 +827,8 @@ __global__ __launch_bounds__((pipe_dcw<NT, LANES, SPLIT>() ? 5 : 4) * kWave, SHA
         };
         bool left = false;
         for (uint32_t s = 0; s < n_steps && !left; s += 2u) {
-            left = step(s, std::integral_constant<int, AHEAD ? 0 : 1>{});          // block s + 1 is odd when s is even
-            if (!left && s + 1u < n_steps) left = step(s + 1u, std::integral_constant<int, AHEAD ? 1 : 0>{});
+            left = step(s, std::integral_constant<int, 1>{});          // block s + 1 is odd when s is even
+            if (!left && s + 1u < n_steps) left = step(s + 1u, std::integral_constant<int, 0>{});
         }
         P3_REPORT(4);
         if (left) return;
@@ -865,17 +839,16 @@ __global__ __launch_bounds__((pipe_dcw<NT, LANES, SPLIT>() ? 5 : 4) * kWave, SHA
         for (uint32_t i = lane; i < (uint32_t)NT; i += kWave) tlds[i] = taps[i];
         if (LANES < (int)kWave && lane >= (uint32_t)LANES) return;
         P3_HWID(0);
-        AgcStage<NT, MED3, AHEAD> M;
+        AgcStage<NT, MED3> M;
         M.ycol = dcw_ring + lane;
         M.load(P, S, c, C, counter0, wcol);
         lds_barrier();                                                 // prologue: block 0's DC outputs are in the ring
-        if constexpr (AHEAD) { M.rotate(); M.block(P, wcol, 0u); lds_barrier(); }   // block 0 before anyone reads the window
         P3_T0();
         uint32_t stop_at = 0xffffffffu;
         bool left = false;
         for (uint32_t s = 0; s < n_steps; ++s) {
             M.rotate();
-            if (s + (AHEAD ? 1u : 0u) < n_blocks && !PROF_SKIP(P, 64)) M.block(P, wcol, s + (AHEAD ? 1u : 0u));
+            if (s < n_blocks && !PROF_SKIP(P, 64)) M.block(P, wcol, s);
             P3_LAP(p3_work);
             lds_barrier();                                             // A
             P3_LAP(p3_wait);
@@ -946,138 +919,11 @@ __global__ __launch_bounds__((pipe_dcw<NT, LANES, SPLIT>() ? 5 : 4) * kWave, SHA
         if (left) return;                                              // handed over: this chunk's state is not needed
         lds_barrier();                                                 // (stage 2 -> 3: final TED phase)
         M.store(P, S, c, C, counter1, wcol);
-    } else if (AHEAD && role == 1u) {
-        // ------------------------------ stage 2 (AHEAD): timing loop over the helper's magnitudes, block s-1 ------
-        if (LANES < (int)kWave && lane >= (uint32_t)LANES) return;
-        P3_HWID(1);
-        Lane L;
-        lane_load(L, S, c);
-        int cstar = next_fire_count(L.until_next_ted, L.ted_clock);
-        int until = cstar - (int)L.ted_clock - 1;      // index of the next instant, relative to the block about to be processed
-        uint32_t wpos = 0;
-        // the timing loop's update at the NEXT instant for both signs of its sample (it stays valid until that
-        // instant: nothing else changes the loop's state)
-        TedAhead A = ted_ahead(P, L, L.until_next_ted - (float)cstar);          // rem: receiver.rs:352
-        // candidates for block `for_blk`'s first instant, from `until` relative to block for_blk - 1: that block has
-        // no instant (the next one is exact), or it has one and the one after it lies cstar[sign] samples on
-        auto post_cands = [&](uint32_t for_blk) {
-            int ca, cb;
-            if (until >= kB) { ca = until - kB; cb = ca; }
-            else { ca = until + A.cstar0 - kB; cb = until + A.cstar1 - kB; }
-            candbox[(for_blk & 1u) * kWave + lane] = cand_word(ca, cb);
-        };
-        candbox[lane] = cand_word(until, until);                         // block 0's instant is known exactly
-        lds_barrier();                                                 // prologue
-        lds_barrier();
-        uint32_t stale = 0;             // per lane: the helper's magnitudes for the next `stale` blocks predate a replay
-        S2_BEGIN();
-        auto do_block = [&](uint32_t blk, bool redo) {
-            S2_LAP(4);
-            uint32_t hdr = 0;
-            float zero = 0.0f, sym = 0.0f, terr = 0.0f, next = 0.0f;
-            if (until < kB) {
-                const int fk = until;
-                const uint32_t par = (blk & 1u) * kWave;
-                // (tags and both candidates' magnitudes in one LDS round trip)
-                const uint32_t tags = candbox[par + lane];
-                const uint32_t ma = resbox[par + lane], sa = resbox[par + (uint32_t)LANES + lane],
-                               mb = resbox[par + 2u * (uint32_t)LANES + lane], sb2 = resbox[par + 3u * (uint32_t)LANES + lane];
-                const bool hit_a = (tags & 0xffu) == (uint32_t)fk, hit_b = ((tags >> 8) & 0xffu) == (uint32_t)fk;
-                float sa_low;
-                if (!redo && stale == 0u && (hit_a || hit_b)) {
-                    const float hm = __uint_as_float(hit_a ? ma : mb), hs = __uint_as_float(hit_a ? sa : sb2);
-                    sa_low = rs_clamp(hm - hs, -1.0f, 1.0f);
-                } else {
-                    COUNT_SECOND_INSTANT();
-                    sa_low = demod_fast<NT, RING, true>(tlds, wring, lane, wpos + (uint32_t)fk);
-                }
-                S2_LAP(1);
-                int cs;
-                if (ted_commit(L, A, sa_low, &zero, &sym, &terr, &cs)) { hdr = 1u | ((uint32_t)fk << 8); next = L.until_next_ted; }
-                cstar = cs;
-                until = fk + cstar;
-                if (until < kB) {
-                    // A second instant in the same block (the loop at its fastest): rare, this wavefront computes
-                    // both filters itself.  Exactly one of the two instants completes a symbol.
-                    const int fk2 = until;
-                    COUNT_SECOND_INSTANT();
-                    const float sa2 = demod_fast<NT, RING, true>(tlds, wring, lane, wpos + (uint32_t)fk2);
-                    const float rem2 = L.until_next_ted - (float)cstar;
-                    float z2 = 0.0f, s2 = 0.0f, e2 = 0.0f;
-                    if (ted_timing(P, L, sa2, rem2, &z2, &s2, &e2)) {
-                        hdr = 1u | ((uint32_t)fk2 << 8); zero = z2; sym = s2; terr = e2; next = L.until_next_ted;
-                    }
-                    cstar = next_fire_count(L.until_next_ted, 0u);
-                    until = fk2 + cstar;
-                }
-            }
-            until -= kB;
-            S2_LAP(2);
-            A = ted_ahead(P, L, L.until_next_ted - (float)cstar);
-            post_cands(blk + 2u);
-            lds_u32 *sb = symbox + (blk & 1u) * kP3SymWords + lane;
-            sb[0] = hdr;
-            sb[kWave] = __float_as_uint(zero); sb[2 * kWave] = __float_as_uint(sym);
-            if (P.trace_cap) { sb[3 * kWave] = __float_as_uint(terr); sb[4 * kWave] = __float_as_uint(next); }
-            S2_LAP(3);
-        };
-        P3_T0();
-        uint32_t stop_at = 0xffffffffu;
-        bool left = false;
-        for (uint32_t s = 0; s < n_steps; ++s) {
-            // this lane's state before block s-1, in case stage 3 sends it back there
-            const float k_h0 = L.h0, k_h1 = L.h1, k_h2 = L.h2, k_avg = L.period_avg, k_inst = L.period_inst,
-                        k_unt = L.until_next_ted;
-            const uint32_t k_flags = L.flags;
-            const int k_cstar = cstar, k_until = until;
-            const bool active = s >= 1u && s <= n_blocks;
-            if (active && !PROF_SKIP(P, 32)) { do_block(s - 1u, false); if (stale) --stale; }
-            else if (s == 0u) post_cands(1u);
-            P3_LAP(p3_work);
-            lds_barrier();                                             // A
-            P3_LAP(p3_wait);
-            if (s >= 2u && s <= last_fb_step) {
-                const lds_u32 *fb = fbbox + (s & 1u) * kP3FbWords;
-                const uint32_t fbw = (uint32_t)__builtin_amdgcn_readfirstlane((int)fb[kWave]);
-                if (fbw & 2u) stop_at = s + 1u;
-                if (fbw & 1u) {
-                    const uint32_t v = fb[lane];
-                    if (v & 1u) {
-                        L.h0 = k_h0; L.h1 = k_h1; L.h2 = k_h2; L.period_avg = k_avg; L.period_inst = k_inst;
-                        L.until_next_ted = k_unt; L.flags = k_flags; cstar = k_cstar; until = k_until;
-                        L.flags = (L.flags & ~F_BW_LOCKED) | ((v & 4u) ? F_BW_LOCKED : 0u);
-                        if (v & 8u) {                                    // end(): symsync.reset()
-                            L.flags &= ~F_TED_PHASE;
-                            L.h0 = 0.0f; L.h1 = 0.0f; L.h2 = 0.0f;
-                            L.period_avg = P.samples_per_ted; L.period_inst = P.samples_per_ted;
-                        }
-                        A = ted_ahead(P, L, L.until_next_ted - (float)cstar);
-                        stale = 1u;                                      // the magnitudes for block s were computed before the correction
-                    }
-                    lds_barrier();                                     // B: stage 1 has corrected the window
-                    if ((v & 1u) && active) do_block(s - 1u, true);
-                    lds_barrier();                                     // C
-                    P3_LAP(p3_fb);
-                }
-            }
-            if (active) { wpos += kB; if (wpos == (uint32_t)RING) wpos = 0; }
-            if (s == stop_at) { left = true; break; }
-        }
-        P3_REPORT(1);
-        S2_REPORT();
-        if (left) return;
-        phasebox[lane] = L.flags & F_TED_PHASE;
-        lds_barrier();                                                 // stage 3 merges the phase bit
-        L.ted_clock = (uint32_t)(cstar - until - 1);
-        S.until_next_ted[c] = L.until_next_ted; S.ted_clock[c] = L.ted_clock;
-        S.ted_h0[c] = L.h0; S.ted_h1[c] = L.h1; S.ted_h2[c] = L.h2;
-        S.period_avg[c] = L.period_avg; S.period_inst[c] = L.period_inst;
     } else if (role == 1u) {
         // ------------------------------ stage 2: filters + timing loop, block s-1 --------------
         if (LANES < (int)kWave && lane >= (uint32_t)LANES) return;
         P3_HWID(1);
         if constexpr (DCW) lds_barrier();                              // prologue
-        if (P.knob_prio & 1) __builtin_amdgcn_s_setprio(2);
         Lane L;
         lane_load(L, S, c);
         int cstar = next_fire_count(L.until_next_ted, L.ted_clock);
@@ -1113,8 +959,7 @@ __global__ __launch_bounds__((pipe_dcw<NT, LANES, SPLIT>() ? 5 : 4) * kWave, SHA
                     // sample it will deliver (same_dev_common.h: ted_ahead / ted_commit)
                     const TedAhead A = ted_ahead(P, L, rem);
                     SPIN_BEGIN();
-                    if (P.knob_prio & 2) { while ((int32_t)(seqbox[0] - seq) < 0) __builtin_amdgcn_s_sleep(2); }
-                    else { while ((int32_t)(seqbox[0] - seq) < 0) {} }   // stage 4 has posted this pass
+                    while ((int32_t)(seqbox[0] - seq) < 0) {}        // stage 4 has posted this pass
                     SPIN_END();
                     if constexpr (HELPER_BOTH) hm = __uint_as_float(markbox[lane]);
                     const float hs = __uint_as_float(spacebox[lane]);
@@ -1217,7 +1062,6 @@ __global__ __launch_bounds__((pipe_dcw<NT, LANES, SPLIT>() ? 5 : 4) * kWave, SHA
         if (LANES < (int)kWave && lane >= (uint32_t)LANES) return;
         P3_HWID(2);
         if constexpr (DCW) lds_barrier();                              // prologue
-        if constexpr (AHEAD) lds_barrier();
         Lane L;
         lane_load(L, S, c);
         L.ended = 0u;
@@ -1323,14 +1167,11 @@ __global__ __launch_bounds__((pipe_dcw<NT, LANES, SPLIT>() ? 5 : 4) * kWave, SHA
         // ------------------------------ stage 4: link events + wake-ups, block s-3 -------------
         // PACKED: lanes LANES .. 2*LANES-1 stay for the filter half of every step (the space filter of channel
         // lane - LANES, while lanes 0 .. LANES-1 compute the mark filter) and sit the event half out.
-        // AHEAD: all 64 lanes filter -- lane = [candidate][filter][channel]
         const bool evt_lane = lane < (uint32_t)LANES;
-        if (LANES < (int)kWave && lane >= (uint32_t)(AHEAD ? 4 * LANES : (PACKED ? 2 * LANES : LANES))) return;
+        if (LANES < (int)kWave && lane >= (uint32_t)(PACKED ? 2 * LANES : LANES)) return;
         if constexpr (DCW) lds_barrier();                              // prologue
-        if constexpr (AHEAD) lds_barrier();
         const uint32_t fch = PACKED ? (lane & (uint32_t)(LANES - 1)) : lane;      // the channel this lane filters for
         const uint32_t which = PACKED ? ((lane & (uint32_t)LANES) ? 1u : 0u) : 1u;   // 0 mark, 1 space
-        const uint32_t cnd = AHEAD ? lane / (uint32_t)(2 * LANES) : 0u;           // AHEAD: which of the two candidates
         Lane L;
         if (evt_lane) lane_load(L, S, c);      // uses sq_symbols, tk_next, tk_last, wake_*, F_TICK_AGAIN
         P3_HWID(3);
@@ -1358,29 +1199,17 @@ __global__ __launch_bounds__((pipe_dcw<NT, LANES, SPLIT>() ? 5 : 4) * kWave, SHA
         };
         for (uint32_t s = 0; s < n_steps; ++s) {
             // SPLIT: first the matched filter(s) of block s-1 for stage 2, which waits for them
-            const bool active = SPLIT && !AHEAD && s >= 1u && s <= n_blocks;
+            const bool active = SPLIT && s >= 1u && s <= n_blocks;
             uint32_t pos = 0xffffffffu;
             // what stage 3 posted last step, read together with the instant's position (one LDS round trip, not two)
             const bool evt_step = s >= 3u && evt_lane && !PROF_SKIP(P, 8);
             const lds_u32 *io = iobox + ((s - 1u) & 1u) * kP3IoWords + lane;
             const uint32_t io0 = evt_step ? io[0] : 0u;
             HELP_BEGIN();
-            if constexpr (AHEAD) {
-                // the magnitudes at this lane's candidate for block s's first instant (posted by stage 2 during the
-                // last step, read by it in the next)
-                if (s < n_blocks && !PROF_SKIP(P, 256)) {
-                    const uint32_t cpos = (candbox[(s & 1u) * kWave + fch] >> (8u * cnd)) & 0xffu;
-                    if (cpos < (uint32_t)kB)
-                        resbox[(s & 1u) * kWave + lane] = __float_as_uint(demod_half_dyn<NT, RING>(tlds, wring, fch, wpos + cpos, which));
-                    wpos += kB; if (wpos == (uint32_t)RING) wpos = 0;
-                }
-            }
             if (active) {
                 pos = posbox[((s - 1u) & 1u) * kWave + fch];               // posted by stage 2 during the last step
-                if (P.knob_prio & 1) __builtin_amdgcn_s_setprio(3);
                 if (pos < (uint32_t)kB && !PROF_SKIP(P, 256)) filter(pos);
                 if (lane == 0u) seqbox[0] = 2u * s + 1u;                    // (LDS operations of a wavefront stay in order)
-                if (P.knob_prio & 1) __builtin_amdgcn_s_setprio(0);
             }
             HELP_END(SPLIT);
             if (evt_step) {
@@ -1402,9 +1231,9 @@ __global__ __launch_bounds__((pipe_dcw<NT, LANES, SPLIT>() ? 5 : 4) * kWave, SHA
                 const uint32_t fbw = (uint32_t)__builtin_amdgcn_readfirstlane((int)fb[kWave]);
                 if (fbw & 2u) stop_at = s + 1u;
                 if (fbw & 1u) {
-                    const uint32_t v = (SPLIT && !AHEAD) ? fb[fch] : 0u;
+                    const uint32_t v = SPLIT ? fb[fch] : 0u;
                     lds_barrier();                                     // B: stage 1 has corrected the window
-                    if (SPLIT && !AHEAD) {
+                    if (SPLIT) {
                         if ((v & 1u) && active && pos < (uint32_t)kB) filter(pos);
                         if (lane == 0u) seqbox[0] = 2u * s + 2u;
                     }
@@ -1426,10 +1255,10 @@ __global__ __launch_bounds__((pipe_dcw<NT, LANES, SPLIT>() ? 5 : 4) * kWave, SHA
 // ---------------------------------------------------------------------------------
 // dispatch
 // ---------------------------------------------------------------------------------
-template <int NT, bool DCW = false, bool AHEAD = false>
+template <int NT, bool DCW = false>
 static constexpr size_t pipe_lds_bytes()
 {
-    using LY = PipeLayout<NT, AHEAD>;
+    using LY = PipeLayout<NT>;
     return ((size_t)LY::tap_floats + kP3MailWords + (DCW ? LY::dcw_ring_floats : LY::yring_floats) +
             (size_t)(kSquelchHist + 2 * LY::RING - LY::B) * kWave) * sizeof(float);
 }
@@ -1469,14 +1298,14 @@ bool pipe_kernel_selected(const Params &P) { return pipe_kernel_stages(P) != 0u;
 uint32_t pipe_block_len(const Params &P)
 { return P.ntaps == 42u ? (uint32_t)kBlockPipe22 : (P.ntaps == 92u ? (uint32_t)PipeGeom<92>::B : (uint32_t)PipeGeom<84>::B); }
 
-template <int NT, int NFF, int NFB, bool M3, bool SHARE, int LANES, bool SPLIT, typename SampleT, bool AHEAD = false, bool FM = false>
+template <int NT, int NFF, int NFB, bool M3, bool SHARE, int LANES, bool SPLIT, typename SampleT, bool FM = false>
 static hipError_t launch_pipe_one(const Params &P, const State &S, const Output &O, const float4 *taps,
                                   const SampleT *x, uint32_t n_blocks, uint64_t counter0, hipStream_t stream,
                                   const PipeChunks &K)
 {
     constexpr bool DCW = pipe_dcw<NT, LANES, SPLIT>();
-    constexpr size_t lds = pipe_lds_bytes<NT, DCW, AHEAD>();
-    auto *kernel = demod_pipe_kernel<NT, NFF, NFB, M3, SHARE, LANES, SPLIT, SampleT, AHEAD, FM>;
+    constexpr size_t lds = pipe_lds_bytes<NT, DCW>();
+    auto *kernel = demod_pipe_kernel<NT, NFF, NFB, M3, SHARE, LANES, SPLIT, SampleT, FM>;
     if (lds > 64u * 1024u) {
         // more than the default 64 KB of dynamic LDS per workgroup: opt in, once per kernel and device
         static bool opted_in[64] = {};
@@ -1504,8 +1333,8 @@ static hipError_t launch_pipe_cfg(const Params &P, const State &S, const Output 
         if (relaxed) {
             if (!pipe_relaxed_supported(P)) return hipErrorInvalidValue;
             if (P.eq_nff == 6u && P.eq_nfb == 4u)
-                return launch_pipe_one<NT, 6, 4, true, true, 64, true, SampleT, false, true>(P, S, O, taps, x, n_blocks, counter0, stream, K);
-            return launch_pipe_one<NT, 1, 1, true, true, 64, true, SampleT, false, true>(P, S, O, taps, x, n_blocks, counter0, stream, K);
+                return launch_pipe_one<NT, 6, 4, true, true, 64, true, SampleT, true>(P, S, O, taps, x, n_blocks, counter0, stream, K);
+            return launch_pipe_one<NT, 1, 1, true, true, 64, true, SampleT, true>(P, S, O, taps, x, n_blocks, counter0, stream, K);
         }
     } else {
         if (relaxed) return hipErrorInvalidValue;
@@ -1532,12 +1361,6 @@ static hipError_t launch_pipe_cfg(const Params &P, const State &S, const Output 
 #define SAME_PIPE_LANES_LAUNCH(LN)                                                                                          \
         (split ? launch_pipe_one<NT, 6, 4, true, false, LN, true, SampleT>(P, S, O, taps, x, n_blocks, counter0, stream, K)    \
                : launch_pipe_one<NT, 6, 4, true, false, LN, false, SampleT>(P, S, O, taps, x, n_blocks, counter0, stream, K))
-        if constexpr (pipe_can_ahead<NT, 16, true>()) {
-            // 16-channel workgroups, SAME_PIPE_AHEAD=1: the helper filters both candidate positions a block ahead.  Not
-            // the default: measured 11.8-12.1 ms against 11.7 at configs[1] (DESIGN.md 4.4b has why)
-            if (lanes == 16u && split && P.knob_pipe_ahead > 0)
-                return launch_pipe_one<NT, 6, 4, true, false, 16, true, SampleT, true>(P, S, O, taps, x, n_blocks, counter0, stream, K);
-        }
         if (lanes == 16u) return SAME_PIPE_LANES_LAUNCH(16);
         if (lanes == 32u) return SAME_PIPE_LANES_LAUNCH(32);
         return SAME_PIPE_LANES_LAUNCH(64);

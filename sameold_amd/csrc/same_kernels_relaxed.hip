@@ -764,473 +764,6 @@ __global__ __launch_bounds__(2 * kWave, 2) void demod_duo_kernel(Params P, State
     }
 }
 
-// =====================================================================================
-// Three wavefronts per 64 state columns ("trio"), the form for launches that leave SIMDs idle (time-parallel launches of
-// small batches: a column's samples are a serial chain, and what shortens a launch there is the time a sub-block takes,
-// not the work it costs).  Sub-blocks of 18 samples -- below the shortest distance of two TED instants (19.45), so at
-// most one instant each, and at most one SYMBOL in two of them (symbols are at least 38.9 samples apart) -- and three
-// stages on three SIMDs of a CU:
-//   A  sample phase of sub-block s            DC blocker, AGC (on its belief of the lock), window push
-//   F  instant of sub-block s - 1             matched filters, timing loop; hands a completed symbol on through LDS
-//   C  symbol of sub-blocks s - 3 and s - 2   squelch, equalizer, framer, link events; the authoritative flags -- on
-//                                             every other step, so that (nearly) every lane has a symbol when it runs:
-//                                             the symbol path is the longest stage, and one pass costs what it costs
-//                                             however few of the 64 lanes take part
-// C's feedback -- AGC lock, loop bandwidth, the timing-loop reset of end() (receiver.rs:423-438, 479-490) -- is rare
-// (about three symbols per burst) and arrives two or three sub-blocks late: A redoes the AGC from the sample after the
-// symbol's instant through the sub-blocks it has produced since (saved DC outputs and starting gains of four sub-blocks),
-// F goes back to its state from before the sub-block after the symbol's, applies the change and processes the one or two
-// sub-blocks since again over the corrected window, replacing what it had handed on.  One barrier per sub-block, three
-// when a correction is due.  Every column still executes the reference's sequence of operations, in relaxed arithmetic.
-// =====================================================================================
-template <int NT> struct TrioLayout {
-    static constexpr int SB = 18, DCL = RelaxGeom<NT>::DCL;
-    static constexpr int RING = 5 * SB, MIRROR = kRelaxChunk - 1;       // F's filters reach back over four sub-blocks while A writes the fifth
-    static constexpr uint32_t tap_floats = (uint32_t)((NT * 4 + 63) / 64 * 64);
-    static constexpr uint32_t sym_words = 5u * kWave;                   // per sub-block (mod 4): header, zero, sym, terr, until
-    static constexpr uint32_t mail_words = 4u * sym_words + 2u * kWave + kWave + 64u;   // + feedback words (two parities), final TED phase, flag words
-    static constexpr size_t lds_bytes = ((size_t)tap_floats + mail_words + (size_t)(RING + MIRROR) * kWave) * sizeof(float);
-    static_assert(NT - 1 + SB <= 4 * SB, "F's filters reach into the sub-block A writes");
-    static_assert(SB >= DCL, "the DC windows are the tail of the previous sub-block");
-};
-
-template <int NT, int NFF, int NFB, typename SampleT, bool CM, bool TICKS>
-__global__ __launch_bounds__(3 * kWave, 2) void demod_trio_kernel(Params P, State S, Output O,
-                                                                  const float4 *__restrict__ taps,
-                                                                  const SampleT *__restrict__ x,
-                                                                  uint32_t n_sub, uint64_t counter0, PipeChunks K)
-{
-    using LY = TrioLayout<NT>;
-    constexpr int SB = LY::SB, DCL = LY::DCL, RING = LY::RING, MIR = LY::MIRROR;
-    constexpr int HOFF = SB - DCL;
-    constexpr uint32_t LP = kWave;
-    static_assert(!CM || std::is_same<SampleT, float>::value, "channel-major streams are f32");
-    extern __shared__ float lds[];
-    const uint32_t lane = threadIdx.x & (kWave - 1u);
-    const uint32_t role = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // 0 A, 1 F, 2 C
-    float4 *tlds = reinterpret_cast<float4 *>(lds);
-    if (role == 0u) for (uint32_t i = lane; i < (uint32_t)NT; i += kWave) tlds[i] = taps[i];
-    duo_u32 *mail = (duo_u32 *)(lds + LY::tap_floats);
-    duo_u32 *symbox = mail;                                  // [4][5][64]: what F hands on for sub-block sb, in slot sb & 3
-    duo_u32 *fbbox = mail + 4u * LY::sym_words;              // [2][64]: bit 0 valid, 1 AGC lock, 2 loop bandwidth locked, 3 end(),
-                                                             //          4 the symbol sat in sub-block s - 3 (else s - 2), bits 8.. sample index
-    duo_u32 *phasebox = fbbox + 2u * kWave;                  // [64] F's final TED phase bit
-    duo_u32 *flagbox = phasebox + kWave;                     // [2]: bit 0 a correction is due, bit 1 leave
-    const uint32_t C = P.n_channels;                         // whole groups of 64 (launcher)
-    uint32_t c = blockIdx.x * kWave + lane;
-    if (K.n_chunks > 1u && K.col_perm) c = K.col_perm[c];
-    uint32_t cin = c, Cin = C, n_nominal = n_sub;            // (in sub-blocks)
-    bool may_leave = false;
-    int32_t row_l = 0;
-    const float *xl = nullptr;
-    uint32_t avail_l = 0xffffffffu;
-    if constexpr (CM) {
-        Cin = K.in_channels;
-        const uint32_t chunk_l = c / Cin;
-        cin = c - chunk_l * Cin;
-        may_leave = (uint32_t)__builtin_amdgcn_readfirstlane((int)chunk_l) + 1u < K.n_chunks;
-        const uint32_t row_abs = K.col_row0[c];
-        xl = reinterpret_cast<const float *>(x) + (size_t)cin * K.in_samples + row_abs;
-        avail_l = (K.whole_samples - row_abs) / (uint32_t)SB;
-        n_sub = K.wg_blocks[blockIdx.x];
-        n_nominal = may_leave ? K.col_nominal[c] : n_sub;
-        const uint32_t row_first = (uint32_t)__builtin_amdgcn_readfirstlane((int)row_abs);
-        counter0 += (uint64_t)row_first;
-        row_l = (int32_t)(row_abs - row_first);
-    } else if (K.n_chunks > 1u) {
-        Cin = K.in_channels;
-        const uint32_t wgs = K.in_channels / kWave;
-        const uint32_t chunk = blockIdx.x / wgs;
-        cin = (blockIdx.x - chunk * wgs) * kWave + lane;
-        may_leave = chunk + 1u < K.n_chunks;
-        const uint32_t first_block = chunk * K.stride_blocks;
-        x += (size_t)first_block * SB * Cin;
-        counter0 += (uint64_t)first_block * SB;
-        n_sub -= first_block;
-        n_nominal = may_leave ? K.nominal_blocks : n_sub;
-    }
-    float *wcol = lds + LY::tap_floats + LY::mail_words + lane;      // ring slot 0 of this lane
-    const uint64_t counter1 = counter0 + (uint64_t)n_sub * SB;
-    const uint32_t n_steps = n_sub + 3u;                     // A: steps 0 .. n_sub-1, F: 1 .. n_sub, C: the even steps up to n_sub + 2
-    auto ring_base = [](uint32_t sb) -> uint32_t { return (sb % 5u) * (uint32_t)SB; };
-
-    if (role == 0u) {
-        // ------------------------------------------------ A: sample phase of sub-block s ------------------------------
-        float sum0 = S.dc_sum0[c], sum1 = S.dc_sum1[c], gain = S.agc_gain[c];
-        bool locked = (S.flags[c] & F_AGC_LOCKED) != 0u;             // this wavefront's belief of the AGC lock
-        {
-            const uint32_t G = P.win_ring;
-#pragma unroll 2
-            for (uint32_t m = 1; m < (uint32_t)NT; ++m) {
-                const uint32_t g = (uint32_t)(counter0 - (uint64_t)m) & (G - 1u);
-                const float *row = S.win_ring + (size_t)g * C;
-                wcol[((uint32_t)RING - m) * LP] = row[c];
-            }
-        }
-        static_assert(RING - (NT - 1) > MIR, "the carried-over window would need mirroring");
-        // Everything per sub-block lives in four sets of registers, sub-block q in set q & 3 (the step loop is unrolled four
-        // times, so the sets are named statically): inputs x (the one being computed, its predecessor -- the DC blocker's
-        // input window --, and the two being fetched: a step is shorter than an HBM round trip, so loads are issued two
-        // steps ahead), DC-blocker outputs ys and starting gain g0 (for a replay reaching three sub-blocks back);
-        // first-stage averages of the last even and odd sub-block.
-        float x0[SB], x1[SB], x2[SB], x3[SB], me[SB], mo[SB];
-        float y0[SB], y1[SB], y2[SB], y3[SB];
-        float g00 = gain, g01 = gain, g02 = gain, g03 = gain;
-        {
-            const uint32_t dpos = (uint32_t)(counter0 % (uint64_t)DCL);
-#pragma unroll
-            for (int k = 0; k < DCL; ++k) {
-                uint32_t slot = dpos + (uint32_t)k;
-                if (slot >= (uint32_t)DCL) slot -= (uint32_t)DCL;
-                const float *r0 = S.dc_ff_ring + (size_t)slot * C, *r1 = S.dc_fb_ring + (size_t)slot * C;
-                x3[k + HOFF] = r0[c];
-                mo[k + HOFF] = r1[c];
-            }
-#pragma unroll
-            for (int k = 0; k < SB; ++k) { y0[k] = 0.0f; y1[k] = 0.0f; y2[k] = 0.0f; y3[k] = 0.0f; }
-        }
-        const uint32_t voff = cin * (uint32_t)sizeof(SampleT), row_bytes = Cin * (uint32_t)sizeof(SampleT);
-        auto load_sub = [&](float (&dst)[SB], uint32_t sb) __attribute__((always_inline)) {
-            if constexpr (CM) {
-                if (sb < avail_l) {
-                    const float2 *p = reinterpret_cast<const float2 *>(xl + (size_t)sb * SB);
-#pragma unroll
-                    for (int j = 0; j < SB / 2; ++j) { const float2 v = p[j]; dst[2 * j] = v.x; dst[2 * j + 1] = v.y; }
-                } else {
-#pragma unroll
-                    for (int k = 0; k < SB; ++k) dst[k] = 0.0f;
-                }
-            } else {
-                const SampleT *xr = x + (size_t)sb * SB * Cin;
-                const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<SampleT *>(xr), 0, 0x7fffffff, 0x00020000);
-#pragma unroll
-                for (int k = 0; k < SB; ++k) {
-                    if constexpr (sizeof(SampleT) == 4) dst[k] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, voff, (uint32_t)k * row_bytes, 0));
-                    else dst[k] = (float)(int16_t)__builtin_amdgcn_raw_buffer_load_b16(rs, voff, (uint32_t)k * row_bytes, 0);
-                }
-            }
-        };
-        static_assert((SB & 1) == 0, "8-byte loads, packed pairs");
-        auto agc_pass = [&](const float (&ys)[SB], uint32_t base, float g, int fk, float bwa, float bwb) __attribute__((always_inline)) -> float {
-            float *wblk = wcol + base * LP;
-            auto one = [&](int k) __attribute__((always_inline)) -> float {
-                const float bw = (k <= fk) ? bwa : bwb;
-                const float a = __builtin_fmaf(-bw, fabsf(ys[k]), 1.0f);
-                const float out = ys[k] * g;
-                g = __builtin_amdgcn_fmed3f(__builtin_fmaf(g, a, bw), P.agc_min, P.agc_max);
-                return out;
-            };
-            if (base == 0u) {                                // (wave-uniform) the ring's first MIR slots are stored twice
-#pragma unroll
-                for (int k = 0; k < MIR; ++k) { const float o = one(k); wblk[k * LP] = o; wblk[(k + RING) * LP] = o; }
-            } else {
-#pragma unroll
-                for (int k = 0; k < MIR; ++k) wblk[k * LP] = one(k);
-            }
-#pragma unroll
-            for (int k = MIR; k < SB; ++k) wblk[k * LP] = one(k);
-            return g;
-        };
-        auto sample_phase = [&](auto par, uint32_t sb) __attribute__((always_inline)) {
-            constexpr int PAR = decltype(par)::value;            // sb & 3
-            float (&xin)[SB] = *(PAR == 0 ? &x0 : (PAR == 1 ? &x1 : (PAR == 2 ? &x2 : &x3)));
-            float (&xold)[SB] = *(PAR == 0 ? &x3 : (PAR == 1 ? &x0 : (PAR == 2 ? &x1 : &x2)));
-            float (&xnext2)[SB] = *(PAR == 0 ? &x2 : (PAR == 1 ? &x3 : (PAR == 2 ? &x0 : &x1)));
-            float (&ys)[SB] = *(PAR == 0 ? &y0 : (PAR == 1 ? &y1 : (PAR == 2 ? &y2 : &y3)));
-            float (&mnew)[SB] = *((PAR & 1) == 0 ? &me : &mo);
-            float (&mold)[SB] = *((PAR & 1) == 0 ? &mo : &me);
-            auto xw = [&](int i) -> float { return i < DCL ? xold[i + HOFF] : xin[i - DCL]; };     // the input window, oldest first
-            auto mw = [&](int k) -> float { return k < DCL ? mold[k + HOFF] : mnew[k - DCL]; };
-            // ---- DC blocker rx/dcblock.rs:45-49, 104-108 (strict) ----
-            const float2v inv = {P.dc_inv_len, P.dc_inv_len};
-#pragma unroll
-            for (int k = 0; k < SB; k += 2) {
-                const float2v x2v = {xin[k], xin[k + 1]}, xo2 = {xw(k), xw(k + 1)};
-                const float2v d0 = x2v - xo2;
-                const float s0a = sum0 + d0.x, s0b = s0a + d0.y;
-                sum0 = s0b;
-                const float2v s0 = {s0a, s0b};
-                const float2v m0 = s0 * inv;
-                mnew[k] = m0.x; mnew[k + 1] = m0.y;
-                const float2v sig = {xw(k + 1), xw(k + 2)};
-                const float2v mo2 = {mw(k), mw(k + 1)};
-                const float2v d1 = m0 - mo2;
-                const float s1a = sum1 + d1.x, s1b = s1a + d1.y;
-                sum1 = s1b;
-                const float2v s1 = {s1a, s1b};
-                const float2v m1 = s1 * inv;
-                const float2v yv = sig - m1;
-                ys[k] = yv.x; ys[k + 1] = yv.y;
-            }
-            // Sub-block sb + 2 into the set sub-block sb - 2 has left (its last use was as sb - 1's window).  Unconditional
-            // (past the end: the last sub-block again) so that the number of loads in flight is the same on every path and
-            // the wait for sub-block sb + 1's inputs, a step from now, does not have to cover these as well.
-            load_sub(xnext2, min(sb + 2u, n_sub - 1u));
-            if constexpr (PAR == 0) g00 = gain; else if constexpr (PAR == 1) g01 = gain; else if constexpr (PAR == 2) g02 = gain; else g03 = gain;
-            const float bw = locked ? 0.0f : P.agc_bw;
-            gain = agc_pass(ys, ring_base(sb), gain, SB, bw, bw);
-        };
-        // The lock flipped at sample fk of sub-block s - back (back = 2 or 3; PAR = s & 3): redo the AGC from there through
-        // the sub-blocks produced since (those below n_sub).
-        auto replay = [&](auto par, uint32_t s, uint32_t back, int fk, bool new_locked) __attribute__((always_inline)) {
-            constexpr int PAR = decltype(par)::value;
-            const float bw0 = locked ? 0.0f : P.agc_bw;
-            locked = new_locked;
-            const float bw1 = locked ? 0.0f : P.agc_bw;
-            float g = 0.0f;
-            bool started = false;
-            auto one_sub = [&](auto d_) __attribute__((always_inline)) {
-                constexpr int D = decltype(d_)::value;           // sub-block s - D, in set (PAR - D) & 3
-                constexpr int Q = (PAR - D) & 3;
-                if ((uint32_t)D > back || s < (uint32_t)D || s - (uint32_t)D >= n_sub) return;
-                float (&ys)[SB] = *(Q == 0 ? &y0 : (Q == 1 ? &y1 : (Q == 2 ? &y2 : &y3)));
-                float &gq = *(Q == 0 ? &g00 : (Q == 1 ? &g01 : (Q == 2 ? &g02 : &g03)));
-                if (!started) { g = agc_pass(ys, ring_base(s - (uint32_t)D), gq, fk, bw0, bw1); started = true; }
-                else { gq = g; g = agc_pass(ys, ring_base(s - (uint32_t)D), g, -1, bw1, bw1); }
-            };
-            one_sub(std::integral_constant<int, 3>{});
-            one_sub(std::integral_constant<int, 2>{});
-            one_sub(std::integral_constant<int, 1>{});
-            one_sub(std::integral_constant<int, 0>{});
-            if (started) gain = g;
-        };
-        load_sub(x0, 0u);
-        load_sub(x1, min(1u, n_sub - 1u));
-        duo_barrier();                                       // prologue: taps and the carried-over window are in LDS
-        bool left = false;
-        uint32_t rnd = 0;                                    // rounds so far (a step is one round, plus one per correction): mailbox parity
-        RX_T0();
-        auto step = [&](auto par, uint32_t s) __attribute__((always_inline)) {
-            if (s < n_sub) sample_phase(par, s);
-            RX_LAP(0); RX_COUNT(0);
-            uint32_t fw;
-            do {
-                duo_barrier();                               // 1
-                RX_LAP(1);
-                fw = (uint32_t)__builtin_amdgcn_readfirstlane((int)flagbox[rnd & 1u]);
-                if (fw & 1u) {
-                    const uint32_t v = fbbox[(rnd & 1u) * kWave + lane];
-                    const bool new_locked = (v & 2u) != 0u;
-                    if ((v & 1u) && new_locked != locked) replay(par, s, (v & 16u) ? 3u : 2u, (int)(v >> 8), new_locked);
-                    duo_barrier();                           // 2: the window is corrected
-                    duo_barrier();                           // 3: F has redone its sub-blocks
-                }
-                ++rnd;
-            } while (fw & 1u);                               // (after a correction C looks again: F's redo may have produced a symbol)
-            left = (fw & 2u) != 0u;
-        };
-        for (uint32_t s = 0; s < n_steps && !left; s += 4u) {
-            step(std::integral_constant<int, 0>{}, s);
-            if (!left && s + 1u < n_steps) step(std::integral_constant<int, 1>{}, s + 1u);
-            if (!left && s + 2u < n_steps) step(std::integral_constant<int, 2>{}, s + 2u);
-            if (!left && s + 3u < n_steps) step(std::integral_constant<int, 3>{}, s + 3u);
-        }
-        RX_REPORT();
-        if (left) return;
-        duo_barrier();                                       // (F -> C: final TED phase)
-        S.dc_sum0[c] = sum0; S.dc_sum1[c] = sum1; S.agc_gain[c] = gain;
-        {
-            const uint32_t G = P.win_ring;
-            const uint32_t wnext = ring_base(n_sub);
-#pragma unroll 2
-            for (uint32_t m = 1; m <= G; ++m) {
-                const uint32_t g = (uint32_t)(counter1 - (uint64_t)m) & (G - 1u);
-                float *row = S.win_ring + (size_t)g * C;
-                const uint32_t j = wnext >= m ? wnext - m : wnext + (uint32_t)RING - m;
-                row[c] = wcol[j * LP];
-            }
-            const uint32_t dpos = (uint32_t)(counter1 % (uint64_t)DCL);
-            // the last sub-block's inputs sit in set (n_sub - 1) & 3 (no sub-block at all: the carried-over window is still in
-            // x3), its averages in the even / odd set
-            const uint32_t lastb = (n_sub - 1u) & 3u;
-#pragma unroll
-            for (int k = 0; k < DCL; ++k) {
-                uint32_t slot = dpos + (uint32_t)k;
-                if (slot >= (uint32_t)DCL) slot -= (uint32_t)DCL;
-                float *r0 = S.dc_ff_ring + (size_t)slot * C, *r1 = S.dc_fb_ring + (size_t)slot * C;
-                r0[c] = lastb == 0u ? x0[k + HOFF] : (lastb == 1u ? x1[k + HOFF] : (lastb == 2u ? x2[k + HOFF] : x3[k + HOFF]));
-                r1[c] = (n_sub & 1u) ? me[k + HOFF] : mo[k + HOFF];
-            }
-        }
-    } else if (role == 1u) {
-        // ------------------------------------------------ F: the instant of sub-block s - 1 ---------------------------
-        const uint32_t taps_lds = lds_addr(lds), wcol_lds = lds_addr(wcol);
-        Lane L;
-        lane_load_link(L, S, c);
-        const float inv_spt = 1.0f / P.samples_per_ted;
-        int cstar = next_fire_count(L.until_next_ted, L.ted_clock);
-        int until = cstar - (int)L.ted_clock - 1;
-        auto do_sub = [&](uint32_t sb) __attribute__((always_inline)) {
-            uint32_t hdr = 0;
-            float zero = 0.0f, sym = 0.0f, terr = 0.0f, next = 0.0f;
-            if (until < SB) {
-                const int fk = until;
-                const float sa_low = demod_relaxed<NT, RING, true>(taps_lds, wcol_lds, (int)ring_base(sb) + fk);
-                const float rem = L.until_next_ted - (float)cstar;          // receiver.rs:352
-                if (ted_timing_relaxed(P, L, inv_spt, sa_low, rem, &zero, &sym, &terr)) { hdr = 1u | ((uint32_t)fk << 8); next = L.until_next_ted; }
-                cstar = next_fire_count(L.until_next_ted, 0u);
-                until = fk + cstar;                          // >= SB: instants are more than a sub-block apart
-            }
-            until -= SB;
-            duo_u32 *sb_ = symbox + (sb & 3u) * LY::sym_words + lane;
-            sb_[0] = hdr;
-            sb_[kWave] = __float_as_uint(zero); sb_[2 * kWave] = __float_as_uint(sym);
-            if (P.trace_cap) { sb_[3 * kWave] = __float_as_uint(terr); sb_[4 * kWave] = __float_as_uint(next); }
-        };
-        // this lane's state before sub-block s - 1 (k1) and before s - 2 (k2), in case C sends it back there
-        struct Snap { float h0, h1, h2, avg, inst, unt; uint32_t flags; int cstar, until; };
-        auto snap = [&]() -> Snap { return Snap{L.h0, L.h1, L.h2, L.period_avg, L.period_inst, L.until_next_ted, L.flags, cstar, until}; };
-        auto restore = [&](const Snap &k) {
-            L.h0 = k.h0; L.h1 = k.h1; L.h2 = k.h2; L.period_avg = k.avg; L.period_inst = k.inst;
-            L.until_next_ted = k.unt; L.flags = k.flags; cstar = k.cstar; until = k.until;
-        };
-        Snap k1 = snap(), k2 = k1;
-        duo_barrier();                                       // prologue
-        bool left = false;
-        uint32_t rnd = 0;
-        RX_T0();
-        for (uint32_t s = 0; s < n_steps && !left; ++s) {
-            k2 = k1; k1 = snap();
-            const bool active = s >= 1u && s <= n_sub;
-            if (active) do_sub(s - 1u);
-            else symbox[((s - 1u) & 3u) * LY::sym_words + lane] = 0u;    // (nothing to hand on: step 0 and the steps after n_sub)
-            RX_LAP(2); RX_COUNT(1);
-            uint32_t fw;
-            do {
-                duo_barrier();                               // 1
-                RX_LAP(3);
-                fw = (uint32_t)__builtin_amdgcn_readfirstlane((int)flagbox[rnd & 1u]);
-                if (fw & 1u) {
-                    const uint32_t v = fbbox[(rnd & 1u) * kWave + lane];
-                    const bool far = (v & 16u) != 0u;        // the symbol sat in sub-block s - 3: sub-blocks s - 2 and s - 1 are redone
-                    if (v & 1u) {
-                        restore(far ? k2 : k1);
-                        L.flags = (L.flags & ~F_BW_LOCKED) | ((v & 4u) ? F_BW_LOCKED : 0u);
-                        if (v & 8u) {                        // end(): symsync.reset() rx/symsync.rs:166-170, 265-271
-                            L.flags &= ~F_TED_PHASE;
-                            L.h0 = 0.0f; L.h1 = 0.0f; L.h2 = 0.0f;
-                            L.period_avg = P.samples_per_ted; L.period_inst = P.samples_per_ted;
-                        }
-                    }
-                    duo_barrier();                           // 2: A has corrected the window
-                    if (v & 1u) {
-                        if (far) { k2 = snap(); if (s >= 2u && s - 2u < n_sub) do_sub(s - 2u); }
-                        k1 = snap();                         // (the state before sub-block s - 1, as corrected)
-                        if (active) do_sub(s - 1u);
-                    }
-                    duo_barrier();                           // 3
-                }
-                ++rnd;
-            } while (fw & 1u);
-            left = (fw & 2u) != 0u;
-        }
-        RX_REPORT();
-        if (left) return;
-        phasebox[lane] = L.flags & F_TED_PHASE;
-        duo_barrier();                                       // C merges the phase bit
-        L.ted_clock = (uint32_t)(cstar - until - 1);
-        S.until_next_ted[c] = L.until_next_ted; S.ted_clock[c] = L.ted_clock;
-        S.ted_h0[c] = L.h0; S.ted_h1[c] = L.h1; S.ted_h2[c] = L.h2;
-        S.period_avg[c] = L.period_avg; S.period_inst[c] = L.period_inst;
-    } else {
-        // ------------------------------------------------ C: the symbol of sub-blocks s - 3 and s - 2 (even steps) ----
-        Lane L;
-        if constexpr (TICKS) lane_load(L, S, c); else lane_load_link(L, S, c);
-        RelaxCtx<NFF, NFB> X;
-        X.S = &S; X.c = c; X.C = C;
-        X.hist = S.sq_hist + c;
-#pragma unroll
-        for (int i = 0; i < NFF; ++i) { X.ffc[i] = S.eq_ffc[i * C + c]; X.ffw[i] = S.eq_ffw[i * C + c]; }
-#pragma unroll
-        for (int i = 0; i < NFB; ++i) { X.fbc[i] = S.eq_fbc[i * C + c]; X.fbw[i] = S.eq_fbw[i * C + c]; }
-        bool lane_done = false, left = false;
-        flagbox[0] = 0u; flagbox[1] = 0u;
-        // the two history samples a symbol's equalizer step takes (rx_symbol: slots +16 / +17 from the squelch's write
-        // position), fetched ahead of the symbol that may use them: only a symbol moves the write position
-        uint32_t pslot = (uint32_t)(2u * (uint32_t)L.sq_symbols) & 63u;
-        float hpre0 = X.hist_get((pslot + 16u) & 63u), hpre1 = X.hist_get((pslot + 17u) & 63u);
-        duo_barrier();                                       // prologue
-        RX_T0();
-        uint32_t rnd = 0;
-        for (uint32_t s = 0; s < n_steps && !left; ++s) {
-            const bool mine = s >= 2u && (s & 1u) == 0u;     // the pair of sub-blocks s - 3, s - 2
-            const uint32_t jb = s - 2u;
-            bool recheck = false;                            // a correction had F redo sub-block s - 2: look at it again
-            bool any_fb;
-            uint32_t round = 0;
-            do {
-                uint32_t fbv = 0u, leave = 0u;
-                if (mine) {
-                    // At most one of the two sub-blocks carries a symbol of this lane (symbols are more than two sub-blocks
-                    // apart) -- except right after end(): the timing loop's reset makes the very next instant complete a
-                    // symbol (rx/symsync.rs:278-287), which F's redo of sub-block s - 2 then hands on; the second round
-                    // takes it.
-                    const duo_u32 *sa_ = symbox + ((s - 3u) & 3u) * LY::sym_words + lane, *sb_ = symbox + (jb & 3u) * LY::sym_words + lane;
-                    const uint32_t hdr_a = (round == 0u && s >= 3u) ? sa_[0] : 0u;
-                    const uint32_t hdr_b = (round == 0u || recheck) ? sb_[0] : 0u;
-                    const bool far = (hdr_a & 1u) != 0u;
-                    const duo_u32 *sy = far ? sa_ : sb_;
-                    const uint32_t hdr = far ? hdr_a : hdr_b;
-                    const float zero = __uint_as_float(sy[kWave]), sym = __uint_as_float(sy[2 * kWave]);
-                    recheck = false;
-                    if (hdr & 1u) {
-                        const uint32_t fk = hdr >> 8, j = far ? s - 3u : jb;
-                        float terr = 0.0f, unt = 0.0f;
-                        if (P.trace_cap) { terr = __uint_as_float(sy[3 * kWave]); unt = __uint_as_float(sy[4 * kWave]); }
-                        const uint32_t before = L.flags & (F_AGC_LOCKED | F_BW_LOCKED);
-                        L.ended = 0u;
-                        const uint64_t counter = counter0 + (int64_t)row_l + (uint64_t)j * SB + fk + 1u;
-                        uint32_t burst_len = 0;
-                        bool emit = false;
-                        const uint32_t link = symbol_link(P, L, S, X, c, zero, sym, terr, unt, counter, &burst_len, &emit, true, hpre0, hpre1);
-                        if constexpr (TICKS) symbol_io(P, L, S, O, X, c, link, emit, counter, burst_len);
-                        else if (emit) X.emit(P, S, O, c, link, counter, L.sq_symbols, burst_len);
-                        const uint32_t after = L.flags & (F_AGC_LOCKED | F_BW_LOCKED);
-                        if (after != before || L.ended) {
-                            fbv = 1u | ((after & F_AGC_LOCKED) ? 2u : 0u) | ((after & F_BW_LOCKED) ? 4u : 0u) | (L.ended ? 8u : 0u) | (far ? 16u : 0u) | (fk << 8);
-                            recheck = far;
-                        }
-                        pslot = (uint32_t)(2u * (uint32_t)L.sq_symbols) & 63u;
-                        hpre0 = X.hist_get((pslot + 16u) & 63u); hpre1 = X.hist_get((pslot + 17u) & 63u);
-                    }
-                }
-                any_fb = __builtin_amdgcn_ballot_w64(fbv != 0u) != 0ull;
-                if (mine && !any_fb && may_leave && jb < n_sub) {
-                    // a chunk that hands over: from its nominal end on, the end of the first pair of sub-blocks after which the
-                    // link state is NoCarrier (see demod_relaxed_kernel)
-                    if (!lane_done && jb + 1u >= n_nominal && (L.flags & F_LINK_MASK) == 0u && jb < avail_l) {
-                        lane_done = true;
-                        K.handover[c] = counter0 + (int64_t)row_l + (uint64_t)(jb + 1u) * SB;
-                    }
-                    if (__builtin_amdgcn_ballot_w64(!lane_done) == 0ull) leave = 2u;
-                }
-                if (any_fb) fbbox[(rnd & 1u) * kWave + lane] = fbv;
-                if (lane == 0u) flagbox[rnd & 1u] = (any_fb ? 1u : 0u) | leave;
-                RX_LAP(4);
-                duo_barrier();                               // 1
-                if (any_fb) { duo_barrier(); duo_barrier(); }    // 2, 3: A and F catch up
-                RX_LAP(5);
-                ++rnd; ++round;
-                left = leave != 0u;
-            } while (any_fb);
-        }
-        RX_REPORT();
-        if (left) return;
-        duo_barrier();                                       // F's final TED phase
-        L.flags = (L.flags & ~F_TED_PHASE) | (phasebox[lane] & F_TED_PHASE);
-        S.sq_data[c] = L.sq_data; S.sq_power[c] = L.sq_power; S.sq_phist[c] = L.sq_phist;
-        S.sq_fill[c] = L.sq_fill; S.sq_clock[c] = L.sq_clock; S.sq_symbols[c] = L.sq_symbols;
-        S.eq_word[c] = L.eq_word; S.eq_count[c] = L.eq_count;
-        S.fr_word[c] = L.fr_word; S.fr_count[c] = L.fr_count; S.fr_invalid[c] = L.fr_invalid;
-        S.fr_len[c] = L.fr_len; S.flags[c] = L.flags;
-        if constexpr (TICKS) { S.tk_next[c] = L.tk_next; S.tk_last[c] = L.tk_last; S.wake_fired[c] = L.wake_fired; }
-#pragma unroll
-        for (int i = 0; i < NFF; ++i) { S.eq_ffc[i * C + c] = X.ffc[i]; S.eq_ffw[i * C + c] = X.ffw[i]; }
-#pragma unroll
-        for (int i = 0; i < NFB; ++i) { S.eq_fbc[i * C + c] = X.fbc[i]; S.eq_fbw[i * C + c] = X.fbw[i]; }
-    }
-}
-
 // ---------------------------------------------------------------------------------
 // dispatch
 // ---------------------------------------------------------------------------------
@@ -1244,19 +777,19 @@ bool relaxed_kernel_supported(const Params &P)
     if (!(P.agc_min >= 0.0f)) return false;
     return max_block_len(P) >= (uint32_t)kBlockMirror;
 }
-// Which of the three forms runs a launch over P.n_channels state columns: 2 trio (three wavefronts per 64 columns, 18-sample
-// sub-blocks) while that leaves SIMDs idle, 1 duo (two, 42-sample blocks) up to three wavefronts per SIMD, 0 solo beyond --
-// or what SAME_RELAXED_KERNEL asks for.  Whole groups of 64 columns for duo and trio.
+// Which form runs a launch over P.n_channels state columns: 1 duo (two wavefronts per 64 columns) while that leaves the
+// launch at no more than three wavefronts per SIMD, 0 solo beyond -- or what SAME_RELAXED_KERNEL asks for.  Whole groups
+// of 64 columns for duo.  (A third form -- sample phase | filters + timing loop | symbol path on three wavefronts, 18-sample
+// sub-blocks, the symbol stage on every step or on every other -- was built and measured in round 3: 3.9-4.1 ms where the
+// pipeline's FASTMATH build takes 3.8; not kept.)
 uint32_t relaxed_kernel_kind(const Params &P)
 {
     const bool whole = (P.n_channels % kWave) == 0u;
     if (P.knob_relaxed_kernel == 1 || !whole) return 0u;
     if (P.knob_relaxed_kernel == 2) return 1u;
-    if (P.knob_relaxed_kernel == 3) return 2u;
-    if (P.n_channels <= 40960u) return 2u;
     return P.n_channels <= 98304u ? 1u : 0u;
 }
-uint32_t relaxed_block_len(const Params &P) { return relaxed_kernel_kind(P) == 2u ? (uint32_t)TrioLayout<42>::SB : (uint32_t)RelaxLayout<42>::B; }
+uint32_t relaxed_block_len(const Params &P) { (void)P; return (uint32_t)RelaxLayout<42>::B; }
 
 template <int NFF, int NFB, typename SampleT, bool CM, bool TICKS, int OCC>
 static void launch_relaxed_one(const Params &P, const State &S, const Output &O, const float4 *taps, const SampleT *x,
@@ -1286,17 +819,6 @@ static hipError_t launch_relaxed_t(const Params &P, const State &S, const Output
     const uint32_t grid = (P.n_channels + kWave - 1) / kWave;
     const bool eq64 = P.eq_nff == 6u && P.eq_nfb == 4u, ticks = P.ticks != 0u;
     const uint32_t kind = relaxed_kernel_kind(P);
-    if (kind == 2u) {
-#define SAME_TRIO_GO(NFF, NFB, CM_, TK) hipLaunchKernelGGL((demod_trio_kernel<42, NFF, NFB, SampleT, CM_, TK>), dim3(P.n_channels / kWave), dim3(3 * kWave), \
-                                                          TrioLayout<42>::lds_bytes, stream, P, S, O, taps, x, n_blocks, counter0, K)
-        if constexpr (std::is_same<SampleT, float>::value) {
-            if (cm) { if (eq64) SAME_TRIO_GO(6, 4, true, false); else SAME_TRIO_GO(1, 1, true, false); return hipGetLastError(); }
-        }
-        if (eq64) { if (ticks) SAME_TRIO_GO(6, 4, false, true); else SAME_TRIO_GO(6, 4, false, false); }
-        else { if (ticks) SAME_TRIO_GO(1, 1, false, true); else SAME_TRIO_GO(1, 1, false, false); }
-#undef SAME_TRIO_GO
-        return hipGetLastError();
-    }
     if (kind == 1u) {
 #define SAME_DUO_GO(NFF, NFB, CM_, TK) launch_duo_one<NFF, NFB, SampleT, CM_, TK>(P, S, O, taps, x, n_blocks, counter0, stream, K)
         if constexpr (std::is_same<SampleT, float>::value) {

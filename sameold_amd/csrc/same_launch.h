@@ -35,7 +35,7 @@ uint32_t pipe_workgroup_channels(const Params &P);   // channels per workgroup t
 // whole blocks of relaxed_block_len() samples; takes time-parallel chunks like the pipeline
 bool relaxed_kernel_supported(const Params &P);
 uint32_t relaxed_block_len(const Params &P);      // samples per block of the form relaxed_kernel_kind(P) picks for P.n_channels columns
-uint32_t relaxed_kernel_kind(const Params &P);    // 0 solo, 1 duo, 2 trio (same_kernels_relaxed.hip)
+uint32_t relaxed_kernel_kind(const Params &P);    // 0 solo (one wavefront per 64 columns), 1 duo (two) (same_kernels_relaxed.hip)
 hipError_t launch_demod_relaxed(const Params &P, const State &S, const Output &O, const float4 *taps,
                                 const float *x, uint32_t n_blocks, uint64_t counter0, hipStream_t stream,
                                 const PipeChunks &chunks = PipeChunks{});
@@ -71,8 +71,7 @@ struct TpPlan {
 // energy [channels][scout_blocks] (scratch), own_start [n_chunks][channels], row0 / nominal / perm [n_chunks * channels],
 // wg_blocks [n_chunks * channels / 64], sort_scratch tp_sort_scratch_bytes()
 hipError_t launch_tp_plan(const float *x, const TpPlan &g, float *energy, uint32_t *own_start, uint32_t *row0,
-                          uint32_t *nominal, uint32_t *perm, uint32_t *wg_blocks, uint32_t *sort_scratch, bool sorted, hipStream_t stream,
-                          uint32_t pair_cus = 0, uint32_t *perm_scratch = nullptr);   // pair_cus: tp_pair_kernel (perm_scratch [n_chunks * channels])
+                          uint32_t *nominal, uint32_t *perm, uint32_t *wg_blocks, uint32_t *sort_scratch, bool sorted, hipStream_t stream);
 size_t tp_sort_scratch_bytes();
 hipError_t launch_transpose_f32(const float *in, float *out, uint32_t n_channels, uint32_t n_samples,
                                 hipStream_t stream);

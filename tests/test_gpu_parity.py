@@ -479,12 +479,6 @@ def test_pipeline_workgroup_widths(sa, ob, monkeypatch, rate):
     rx = sa.SameReceiverBuilder(rate).build_batch(n_ch)
     rx.process_host(x)
     assert events_by_channel(rx) == out["64"]
-    # ... or have the helper filter both candidate positions of the next instant a block ahead (AHEAD):
-    monkeypatch.delenv("SAME_PIPE_SPLIT"); monkeypatch.setenv("SAME_PIPE_AHEAD", "1")
-    rx = sa.SameReceiverBuilder(rate).build_batch(n_ch)
-    for off in range(0, n, 44444):
-        rx.process_host(x[off:off + 44444])
-    assert events_by_channel(rx) == out["64"]
     cfg = ob.default_config(rate)
     for c in range(0, n_ch, 23):
         assert out["16"].get(c, []) == oracle_events(ob, cfg, x[:, c]), f"channel {c}"
@@ -544,12 +538,8 @@ def test_two_instants_in_one_block(sa, ob, amp):
     xd = torch.from_numpy(x).cuda()
     traced = list(range(1, n_ch, 8))
     out = {}
-    # "ahead": the pipeline with the helper filtering both candidate positions of the next instant a block ahead
-    # (SAME_PIPE_AHEAD=1, 16-channel workgroups); a second instant in a block is one of the cases its cache misses
-    for variant in ("pipe", "fast", "ahead"):
-        os.environ["SAME_PIPE"] = PIPE_ENV["pipe" if variant == "ahead" else variant]
-        if variant == "ahead":
-            os.environ["SAME_PIPE_AHEAD"] = "1"
+    for variant in ("pipe", "fast"):
+        os.environ["SAME_PIPE"] = PIPE_ENV[variant]
         try:
             rx = sa.SameReceiverBuilder(22050).build_batch(n_ch, trace_symbols=True)
             assert rx.kernel_name() == ("demod_fast_kernel" if variant == "fast" else "demod_pipe_kernel")
@@ -559,11 +549,7 @@ def test_two_instants_in_one_block(sa, ob, amp):
             out[variant] = (events_by_channel(rx), [rx.read_trace(c, cap=8192) for c in traced])
         finally:
             os.environ.pop("SAME_PIPE", None)
-            os.environ.pop("SAME_PIPE_AHEAD", None)
-    assert out["pipe"][0] == out["fast"][0] and out["ahead"][0] == out["fast"][0]
-    for ta, tf in zip(out["ahead"][1], out["fast"][1]):
-        for f in ("sample_counter", "zero", "sym", "err", "next"):
-            assert np.array_equal(ta[f].view(np.uint32 if f != "sample_counter" else ta[f].dtype), tf[f].view(np.uint32 if f != "sample_counter" else tf[f].dtype)), f
+    assert out["pipe"][0] == out["fast"][0]
     tight = 0
     for tp, tf in zip(out["pipe"][1], out["fast"][1]):
         assert len(tp) > 1500 and np.array_equal(tp["sample_counter"], tf["sample_counter"])

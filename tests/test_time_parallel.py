@@ -488,3 +488,71 @@ def test_per_channel_boundaries_fall_back_when_there_is_no_quiet_instant(sa, mon
         e["channel"] = np.array([remap[int(c)] for c in e["channel"]], dtype=np.uint32)
         return e
     assert_contract(sa, only_clean(got), only_clean(ref), rate, len(clean), lambda i: sa.synth_payload(77, int(clean[i])))
+
+
+def test_bench_configuration_of_the_headline_mode(sa, ob, arith):
+    """BASELINE.json configs[1] exactly as bench.py runs its headline mode: 4 096 channels x 220 500 samples per call, seed
+    20260000, channel-major input, default knobs and chunk count -- and two more calls on carried state, which is what the
+    bench's timed steps are.  One continuous stream of three calls (bursts straddle the call boundaries; bench.py itself
+    feeds one buffer again and again, a discontinuity per step that means nothing to check): strict mode against the oracle
+    on every channel of the first call, the time-parallel receiver against strict mode over the whole stream."""
+    import bench
+    from helpers.oracle_compare import assert_every_channel_matches_oracle
+    rate, n_ch, n, seed = 22050, 4096, 220500, 20260000
+    x3 = sa.synth_afsk(n_ch, 3 * n, rate, seed=seed)      # (its first n samples are the bench's input: the generator is causal)
+    strict = sa.SameReceiverBuilder(rate).build_batch(n_ch)
+    tp = sa.SameReceiverBuilder(rate).build_batch(n_ch, time_parallel=True)
+    refs, gots = [], []
+    for k in range(3):
+        x = x3[k * n:(k + 1) * n]
+        strict.process_tensor(x.contiguous()); strict.sync()
+        tp.process_tensor(x.t().contiguous(), layout=sa.LAYOUT_CHANNEL_MAJOR); tp.sync()
+        assert tp.time_parallel_chunks() == 8 and tp.time_parallel_per_channel()
+        assert tp.kernel_name() == ("demod_pipe_kernel<fastmath>" if arith == "fastmath" else "demod_pipe_kernel")
+        refs.append(strict.poll_events_np()); gots.append(tp.poll_events_np())
+        if k == 0:
+            assert_every_channel_matches_oracle(ob, ob.default_config(rate), x.contiguous(), refs[0])
+            assert_contract(sa, gots[0], refs[0], rate, n_ch, lambda c: sa.synth_payload(seed, c), what="first call", t_end=n)
+    ref, got = np.concatenate(refs), np.concatenate(gots)
+    ref = ref[np.lexsort((np.arange(len(ref)), ref["channel"]))]
+    got = got[np.lexsort((np.arange(len(got)), got["channel"]))]
+    per_call = [int((g["kind"] == 3).sum()) for g in gots], [int((r["kind"] == 3).sum()) for r in refs]
+    print("bursts per call, time-parallel / strict:", per_call)
+    assert_contract(sa, got, ref, rate, n_ch, lambda c: sa.synth_payload(seed, c), what="three calls", t_end=3 * n)
+    ok, note = bench.tp_contract(sa, ref, got, n_ch, seed, "three calls on carried state", t_end=3 * n, rate=rate)
+    print(note)
+    assert ok, note
+
+
+def test_a_weak_burst_beside_a_strong_one(sa, monkeypatch):
+    """The boundary planner calls a stretch quiet when the scout's energy is below 8 % of the channel's own loudest reading:
+    a burst five times weaker than its neighbours looks quiet, so cuts may fall inside it and the chunk before runs on
+    through it.  Every other burst of every other channel at 0.2 of its amplitude: the contract holds all the same."""
+    import torch
+    monkeypatch.setenv("SAME_PIPE_LANES", "64")
+    rate, n_ch = 22050, 256
+    n = 22050 * 12
+    n -= n % 420
+    x = sa.synth_afsk(n_ch, n, rate, seed=5150)
+    ev = split(strict_events(sa, x, rate, link_only=True), n_ch)
+    scale = torch.ones((n, n_ch), device=x.device)
+    weak = 0
+    for c in range(0, n_ch, 2):
+        t_s = [int(t) for t in ev[c][ev[c]["kind"] == 1]["sample_counter"]]
+        t_b = [int(t) for t in ev[c][ev[c]["kind"] == 3]["sample_counter"]]
+        for i, tb in enumerate(t_b):
+            if i % 2 == 1:
+                ts = max([t for t in t_s if t < tb] or [0])
+                scale[max(ts - 6000, 0):min(tb + 2000, n), c] = 0.2     # from well before the preamble to after the last byte
+                weak += 1
+    assert weak >= n_ch // 2
+    x = (x * scale).contiguous()
+    ref = strict_events(sa, x, rate)
+    rx = sa.SameReceiverBuilder(rate).build_batch(n_ch, time_parallel=True)
+    rx.time_parallel_config(max_chunks=8)
+    rx.process_tensor(x.t().contiguous(), layout=sa.LAYOUT_CHANNEL_MAJOR)
+    rx.sync()
+    assert rx.time_parallel_per_channel()
+    got = rx.poll_events_np()
+    assert len(ref[ref["kind"] == 3]) >= 4 * n_ch          # the weak bursts decode in strict mode (the AGC takes care of the level)
+    assert_contract(sa, got, ref, rate, n_ch, lambda c: sa.synth_payload(5150, c), what="weak beside strong", t_end=n)

@@ -16,8 +16,6 @@ F='rep 1\|stage \|DC wave\|polled\|second\|HW_ID'
 {
 echo "### configs[1]: 4 096 channels x 10 s, 16-channel workgroups, five wavefronts (clk per 20-sample step of workgroup 0)"
 python3 tools/run_once.py 4096 10 2 2>&1 | grep "$F"
-echo; echo "### the same with SAME_PIPE_AHEAD=1 (helper filters both candidate positions a block ahead)"
-SAME_PIPE_AHEAD=1 python3 tools/run_once.py 4096 10 2 2>&1 | grep "$F"
 for p in 16 440 504; do
   echo; echo "### configs[1], knock-out mask $p (8 helper's events, 16 symbol path, 32 stage 2, 64 AGC, 128 DC blocker, 256 helper's filters)"
   SAME_PIPE_PRIO=$p python3 tools/run_once.py 4096 10 2 2>&1 | grep "rep 1\|stage \|DC wave"

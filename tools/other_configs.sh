@@ -16,9 +16,8 @@ echo; echo "### 44.1 kHz and 48 kHz, 16 384 channels x 2 s; configs[2] at full l
 python3 tools/run_once.py 16384 2 3 44100 2>&1 | grep "rep 2"
 python3 tools/run_once.py 16384 2 3 48000 2>&1 | grep "rep 2"
 python3 tools/run_once.py 16384 10 2 48000 2>&1 | grep "rep 1"
-echo; echo "### configs[1] variants: strict default, SAME_PIPE_AHEAD=1, one wavefront per 64 channels (SAME_PIPE=0), time-parallel"
+echo; echo "### configs[1] variants: strict default, one wavefront per 64 channels (SAME_PIPE=0), time-parallel"
 python3 tools/run_once.py 4096 10 3 2>&1 | grep "rep 2"
-SAME_PIPE_AHEAD=1 python3 tools/run_once.py 4096 10 3 2>&1 | grep "rep 2"
 SAME_PIPE=0 python3 tools/run_once.py 4096 10 3 2>&1 | grep "rep 2"
 python3 tools/tp_cm_once.py 4096 10 3 2>&1 | grep "rep 2"
 } > $OUT/configs.txt 2>&1
