@@ -977,11 +977,14 @@ int process_channel_major_native(same_batch *rx, const float *d_x, size_t n, hip
     if (!tp.enabled || n > ((size_t)1 << 22)) return 0;
     same::ChunkGeom geom{};
     same::PipeChunks pc{};
-    // One round of workgroups (32 768 columns) unless the caller asks for more chunks: the launch is as long as its
-    // longest piece, and that is a burst with its margins however many pieces there are (measured at 4 096 channels:
-    // 8 pieces 4.33 ms, 12 pieces 4.55, 16 pieces 4.6-4.9 with the pieces sorted by length into workgroups)
-    const uint32_t want_cols = tp.max_chunks ? tp.max_chunks * rx->P.n_channels : 0u;
-    const uint32_t n_chunks = plan_chunks(rx, n, geom, pc, want_cols > 32768u ? 65536u : 32768u);
+    // A quarter more state columns than the machine holds at once (40 960: 10 pieces per channel at 4 096 channels) unless
+    // the caller asks for a number of chunks: the launch is as long as its longest piece, a burst with its margins however
+    // many pieces there are, but with 8 pieces the planner cannot give every long burst a piece of its own (longest piece
+    // 39.9 k samples, with 10 or more 37.5 k), and beyond 10 the extra workgroups only add rounds.  Measured at 4 096
+    // channels x 10 s, pieces sorted by length into workgroups: 8 pieces 3.84 ms (unsorted 3.83), 9 3.47, 10 3.45, 11 3.70,
+    // 12 3.85, 16 4.2.
+    const uint32_t want_cols = tp.max_chunks ? tp.max_chunks * rx->P.n_channels : 40960u;
+    const uint32_t n_chunks = plan_chunks(rx, n, geom, pc, tp.max_chunks ? (want_cols > 32768u ? 65536u : 32768u) : 40960u);
     if (n_chunks < 2u) return 0;
     const uint32_t C = rx->P.n_channels, columns = n_chunks * C, fb = geom.block_len;
     const bool wave = tp.kernel == same_batch::TimePar::kWaveRelaxed;
@@ -1007,7 +1010,7 @@ int process_channel_major_native(same_batch *rx, const float *d_x, size_t n, hip
         if (sl.d_geom) HIP_TRY(hipFree(sl.d_geom));
         if (sl.h_geom) HIP_TRY(hipHostFree(sl.h_geom));
         sl.d_geom = nullptr; sl.h_geom = nullptr; sl.geom_cap = 0;
-        HIP_TRY(hipMalloc((void **)&sl.d_geom, ((size_t)4 * columns + columns / same::kWave) * sizeof(uint32_t)));
+        HIP_TRY(hipMalloc((void **)&sl.d_geom, ((size_t)5 * columns + 3 * (columns / same::kWave)) * sizeof(uint32_t)));
         HIP_TRY(hipHostMalloc((void **)&sl.h_geom, (size_t)2 * columns * sizeof(uint32_t), hipHostMallocDefault));
         sl.geom_cap = columns;
     }
@@ -1030,7 +1033,8 @@ int process_channel_major_native(same_batch *rx, const float *d_x, size_t n, hip
         tp.energy_cap = e_need;
     }
     uint32_t *d_own = sl.d_geom, *d_row0 = sl.d_geom + columns, *d_nom = sl.d_geom + 2 * (size_t)columns,
-             *d_perm = sl.d_geom + 3 * (size_t)columns, *d_wg = sl.d_geom + 4 * (size_t)columns;
+             *d_perm = sl.d_geom + 3 * (size_t)columns, *d_wg = sl.d_geom + 4 * (size_t)columns,
+             *d_wg2 = d_wg + columns / same::kWave, *d_perm2 = d_wg2 + 2 * (columns / same::kWave);      // (d_wg2: [2][workgroups])
     // pieces sorted by length into workgroups only when the workgroups come in more than one round (the long ones first;
     // SAME_TP_SORT=0 / 1 overrides).  Within one round neither the sorted order nor a long workgroup beside a short one on
     // every CU pays (round 2).
@@ -1038,7 +1042,11 @@ int process_channel_major_native(same_batch *rx, const float *d_x, size_t n, hip
     if (!tp.d_sort) HIP_TRY(hipMalloc((void **)&tp.d_sort, same::tp_sort_scratch_bytes()));
     HIP_TRY(same::launch_counters(sl.d_counters, sl.h_counters_dev, 0, stream));
     if (rx->timing) HIP_TRY(hipEventRecord(sl.ev_start, stream));
-    HIP_TRY(same::launch_tp_plan(d_x, plan, tp.d_energy, d_own, d_row0, d_nom, d_perm, d_wg, tp.d_sort, sort_mode != 0, stream));
+    // (sorted: the workgroups once more, longest first whatever their group -- those that wait for a free CU are then the short ones)
+    const bool lpt = sort_mode != 0;
+    HIP_TRY(same::launch_tp_plan(d_x, plan, tp.d_energy, d_own, d_row0, d_nom, d_perm, d_wg, tp.d_sort, sort_mode != 0, stream,
+                                 lpt ? d_perm2 : nullptr, lpt ? d_wg2 : nullptr));
+    if (lpt) { d_perm = d_perm2; d_wg = d_wg2; }
     HIP_TRY(same::launch_init_state(tp.Pv, tp.Sv, 0, stream));
     HIP_TRY(same::launch_copy_state_columns(tp.d_desc_in, tp.n_desc, C, columns, nullptr, C, stream));
     HIP_TRY(same::launch_fill_u64(sl.d_handover, columns, same::kNoHandover, stream));

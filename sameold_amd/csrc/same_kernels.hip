@@ -486,7 +486,8 @@ __global__ void tp_iota_kernel(uint32_t *perm, uint32_t n)
 }
 // One wavefront per workgroup of the demodulation launch (64 grid positions): how many blocks it runs at most, and --
 // last chunk -- one common first row for its lanes, so that they all end with the input.
-__global__ void tp_align_kernel(TpPlan g, const uint32_t *__restrict__ perm, uint32_t *__restrict__ row0, uint32_t *__restrict__ wg_blocks)
+__global__ void tp_align_kernel(TpPlan g, const uint32_t *__restrict__ perm, uint32_t *__restrict__ row0, const uint32_t *__restrict__ nominal,
+                                uint32_t *__restrict__ wg_blocks, uint32_t *__restrict__ wg_len)
 {
     const uint32_t v = perm[blockIdx.x * kWave + threadIdx.x];
     const uint32_t chunk = v / g.channels;
@@ -495,9 +496,32 @@ __global__ void tp_align_kernel(TpPlan g, const uint32_t *__restrict__ perm, uin
     for (int off = 32; off > 0; off >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, off));
     if (chunk + 1u == g.n_chunks) row0[v] = g.whole_samples - m * g.block_len;
     if (threadIdx.x == 0) wg_blocks[blockIdx.x] = m;
+    if (wg_len) {
+        // how long the workgroup will run if every lane hands over on time: its longest lane's warm-up + own range
+        uint32_t len = chunk + 1u == g.n_chunks ? m : min(nominal[v], avail);
+        for (int off = 32; off > 0; off >>= 1) len = max(len, (uint32_t)__shfl_xor((int)len, off));
+        if (threadIdx.x == 0) wg_len[blockIdx.x] = len;
+    }
+}
+// Longest workgroups first, whatever group they are of: with more workgroups than the machine holds at once the ones that
+// wait must be the short ones, and the long ones -- which set the launch's length -- should start at time zero.  One
+// wavefront per workgroup of the demodulation launch: its rank among all of them by length (ties by position), then
+// its 64 grid positions and its block count move to that rank.
+__global__ void tp_wg_order_kernel(uint32_t n_wg, const uint32_t *__restrict__ perm, const uint32_t *__restrict__ wg_blocks,
+                                   const uint32_t *__restrict__ wg_len, uint32_t *__restrict__ perm_out, uint32_t *__restrict__ wg_blocks_out)
+{
+    const uint32_t w = blockIdx.x, lane = threadIdx.x;
+    const uint32_t mine = wg_len[w];
+    uint32_t rank = 0;
+    for (uint32_t j = lane; j < n_wg; j += kWave) { const uint32_t b = wg_len[j]; rank += (b > mine || (b == mine && j < w)) ? 1u : 0u; }
+    for (int off = 32; off > 0; off >>= 1) rank += (uint32_t)__shfl_xor((int)rank, off);
+    const uint32_t pos = rank;
+    perm_out[pos * kWave + lane] = perm[w * kWave + lane];
+    if (lane == 0) wg_blocks_out[pos] = wg_blocks[w];
 }
 hipError_t launch_tp_plan(const float *x, const TpPlan &g, float *energy, uint32_t *own_start, uint32_t *row0,
-                          uint32_t *nominal, uint32_t *perm, uint32_t *wg_blocks, uint32_t *sort_scratch, bool sorted, hipStream_t stream)
+                          uint32_t *nominal, uint32_t *perm, uint32_t *wg_blocks, uint32_t *sort_scratch, bool sorted, hipStream_t stream,
+                          uint32_t *perm_out, uint32_t *wg_blocks_out)
 {
     const size_t n = (size_t)g.channels * g.scout_blocks;
     const uint32_t columns = g.n_chunks * g.channels;
@@ -512,7 +536,12 @@ hipError_t launch_tp_plan(const float *x, const TpPlan &g, float *energy, uint32
     } else {
         hipLaunchKernelGGL(tp_iota_kernel, dim3((columns + 255) / 256), dim3(256), 0, stream, perm, columns);
     }
-    hipLaunchKernelGGL(tp_align_kernel, dim3(columns / kWave), dim3(kWave), 0, stream, g, perm, row0, wg_blocks);
+    // (the workgroups' lengths sit behind the reordered block counts: wg_blocks_out[n_wg ..])
+    uint32_t *wg_len = perm_out ? wg_blocks_out + columns / kWave : nullptr;
+    hipLaunchKernelGGL(tp_align_kernel, dim3(columns / kWave), dim3(kWave), 0, stream, g, perm, row0, nominal, wg_blocks, wg_len);
+    if (perm_out)
+        hipLaunchKernelGGL(tp_wg_order_kernel, dim3(columns / kWave), dim3(kWave), 0, stream, columns / kWave, perm, wg_blocks, wg_len,
+                           perm_out, wg_blocks_out);
     return hipGetLastError();
 }
 size_t tp_sort_scratch_bytes() { return 3u * kSortBuckets * sizeof(uint32_t); }

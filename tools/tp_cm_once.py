@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """One time-parallel pass over a channel-major input (per-channel chunk boundaries); SAME_DEBUG=1 prints how the
-boundaries came out.   python tools/tp_cm_once.py CHANNELS SECONDS [REPS]"""
+boundaries came out.   [TP_CHUNKS=K] [TP_WARMUP=samples] python tools/tp_cm_once.py CHANNELS SECONDS [REPS]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -12,6 +12,8 @@ xc = x.t().contiguous()
 del x
 torch.cuda.synchronize()
 rx = sa.SameReceiverBuilder(22050).build_batch(C, link_only=True, time_parallel=True)
+if os.environ.get("TP_CHUNKS"):
+    rx.time_parallel_config(max_chunks=int(os.environ["TP_CHUNKS"]), warmup_samples=int(os.environ.get("TP_WARMUP", "0")))
 rx.set_kernel_timing(True)
 for r in range(reps):
     if r:
