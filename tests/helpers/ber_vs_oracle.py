@@ -135,6 +135,11 @@ def main():
             res["rows_relaxed_mode"] = mc.summarise(total[2], 0.0, 1.0)
             res["relaxed_mode_note"] = ("SAME_BATCH_RELAXED over the same noisy samples: its contract under noise is statistical (include/same_rx.h), "
                                         "the rows are filed for comparison, not asserted equal")
+    print(json.dumps({k: v for k, v in res.items() if not k.startswith("rows")}))
+    if a.out:
+        with open(a.out, "w") as f:
+            json.dump(res, f, indent=1)
+
 
 if __name__ == "__main__":
     main()
