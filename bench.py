@@ -89,13 +89,17 @@ def spawn_ranks(args):
 
 
 def plumbing(args):
-    """The N-rank path without a GPU: gloo process group, every rank fabricates the burst records of
-    its own channel shard, one gather per step to rank 0, max-over-ranks timing, rank 0 prints the
-    JSON line.  No demodulation happens (value 0); tests/test_distributed_cpu.py runs this."""
+    """The N-rank path without a GPU: gloo process group; every rank fabricates the link events of its own channel shard
+    (Reading + Burst per transmission, the device's record layout), packs the bursts as the bench does (global channel
+    numbers), one gather per step to rank 0, max-over-ranks timing; rank 0 checks what arrived record by record and prints
+    the JSON line with the same `ranks` block as a real run.  `--workload configs3` sizes it like a real step of the
+    262 144-channel workload (32 768 channels per rank, 3 bursts per 4 channels: ~7.5 MB of records per rank per step).
+    No demodulation happens (value 0); tests/test_distributed_cpu.py runs this with 2 and with 8 ranks."""
     import numpy as np
     import torch
     import torch.distributed as dist
     from sameold_amd import distributed as sd
+    from sameold_amd.receiver import EVENT_DTYPE
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     if world > 1:
@@ -103,27 +107,57 @@ def plumbing(args):
         dist.init_process_group("gloo")
     C = args.channels
     first_ch = rank * C
-    per_rank = 3 + rank
-    recs = sd.pack_bursts([(first_ch + i, 1000 * rank + i, b"ZCZC-PLUMBING-%d-" % rank) for i in range(per_rank)])
-    got = 0
+    per_rank = (3 * C) // 4 if args.workload == "configs3" else 3 + rank
+
+    def fabricate(r):
+        n = (3 * C) // 4 if args.workload == "configs3" else 3 + r
+        ev = np.zeros(2 * n, dtype=EVENT_DTYPE)
+        ch = (np.arange(n, dtype=np.uint32) * 4) // 3 if args.workload == "configs3" else np.arange(n, dtype=np.uint32)
+        ev["kind"][0::2] = 2; ev["kind"][1::2] = 3                       # Reading, then the Burst
+        ev["channel"][0::2] = ch; ev["channel"][1::2] = ch
+        ev["sample_counter"][0::2] = 1000 * r + np.arange(n); ev["sample_counter"][1::2] = 1000 * r + np.arange(n) + 500
+        text = np.frombuffer(b"ZCZC-PLUMBING-%03d-" % r, dtype=np.uint8)
+        ev["len"][1::2] = len(text)
+        ev["bytes"][1::2, :len(text)] = text
+        return ev, ch
+
+    mine, _ = fabricate(rank)
+    got = None
     t0 = time.perf_counter()
     for _ in range(args.warmup + args.steps):
-        r = sd.gather_records(recs, torch.device("cpu"))
-        got = len(r) if r is not None else 0
+        recs = sd.pack_burst_events(mine, first_ch, zero_padded=True)
+        got = sd.gather_records(recs, torch.device("cpu"))
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    per = torch.tensor([float(rank), float(per_rank), float(len(recs)), elapsed], dtype=torch.float64)
     if world > 1:
+        allr = [torch.zeros_like(per) for _ in range(world)]
+        dist.all_gather(allr, per)
         t = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    else:
+        allr = [per]
     if rank == 0:
+        # what arrived: every rank's records, in rank order, with global channel numbers and the payload untouched
+        want = []
+        for r in range(world):
+            ev, ch = fabricate(r)
+            want.append(sd.pack_burst_events(ev, r * C, zero_padded=True))
+        want = np.concatenate(want)
+        intact = got is not None and got.shape == want.shape and bool((got == want).all())
         print(json.dumps({"metric": "plumbing (no demodulation)", "value": 0.0, "unit": "Msamples/s", "n_gpus": world,
-                          "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / max(args.steps, 1) * 1e3, 3),
-                          "scaling": "weak", "data": "fabricated burst records",
-                          "config": {"workload": "plumbing", "channels_per_gpu": C,
-                                     "bursts_gathered_last_step": int(got),
-                                     "first_channels": [r * C for r in range(world)]}}), flush=True)
+                          "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / max(args.steps + args.warmup, 1) * 1e3, 3),
+                          "scaling": "weak", "data": "fabricated link events",
+                          "config": {"workload": "plumbing" + (" at the size of configs[3]" if args.workload == "configs3" else ""), "channels_per_gpu": C,
+                                     "bursts_gathered_last_step": int(len(got)) if got is not None else 0,
+                                     "gathered_records_intact": intact,
+                                     "record_bytes_per_rank_per_step": int(recs.nbytes),
+                                     "first_channels": [r * C for r in range(world)]},
+                          "ranks": {"ranks_seen": len(allr), "rank_ids": [int(t[0]) for t in allr],
+                                    "bursts_per_rank": [int(t[2]) for t in allr],
+                                    "first_channel_per_rank": [r * C for r in range(world)]}}), flush=True)
     if world > 1:
         dist.destroy_process_group()
 

@@ -156,6 +156,31 @@ def test_bench_gpus_2_starts_two_ranks_itself():
     assert out["config"]["first_channels"] == [0, 16]
 
 
+def test_bench_gpus_8_plumbing_runs_the_real_pack_and_gather_path():
+    """The driver's 8-GPU line, as far as it can be checked without a GPU: `bench.py --gpus 8 --workload configs3 --plumbing`
+    starts eight ranks, every one packs fabricated link events with the bench's own packing (global channel numbers) and the
+    step's one gather brings them to rank 0, which compares what arrived with what every rank made, record for record, and
+    prints the per-rank block a real run prints."""
+    import json
+    import subprocess
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    env["OMP_NUM_THREADS"] = "1"
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--plumbing", "--workload", "configs3", "--channels", "2048",
+                        "--steps", "2", "--warmup", "1"], capture_output=True, text=True, timeout=600, env=env)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 8
+    assert out["config"]["gathered_records_intact"] is True
+    assert out["config"]["bursts_gathered_last_step"] == 8 * (3 * 2048 // 4)
+    assert out["ranks"]["ranks_seen"] == 8 and out["ranks"]["rank_ids"] == list(range(8))
+    assert out["ranks"]["bursts_per_rank"] == [3 * 2048 // 4] * 8
+    assert out["ranks"]["first_channel_per_rank"] == [r * 2048 for r in range(8)]
+
+
 def test_bench_refuses_a_world_size_that_contradicts_gpus():
     import subprocess
     env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
