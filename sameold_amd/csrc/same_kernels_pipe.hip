@@ -510,7 +510,7 @@ struct SampleStage {
     }
 };
 
-// ---- stage 1 cut in two (DCW builds: 16- and 32-channel workgroups at 22.05 kHz) ------------------------
+// ---- stage 1 cut in two (DCW builds: 16- and 32-channel workgroups at 22.05 kHz, 64-channel ones at 44.1 / 48 kHz) ----
 // The DC blocker takes no feedback from anything downstream (rx/dcblock.rs:45-49), so a fifth wavefront runs
 // it one block AHEAD of the AGC and hands its outputs over through a four-block LDS ring; what is left of
 // stage 1 -- AGC, window push, the replay of an AGC lock flip -- reads them from there.  Same operations in
@@ -690,8 +690,11 @@ struct AgcStage {
     }
 };
 
-// wavefronts per workgroup: five in DCW builds
-template <int NT, int LANES, bool SPLIT> constexpr bool pipe_dcw() { return NT == 42 && LANES <= 32 && SPLIT; }
+// wavefronts per workgroup: five in DCW builds.  44.1 / 48 kHz (one workgroup per CU, 32-sample blocks): stage 1 was one of
+// the two long stages there; with the DC blocker on a wavefront of its own 16 384 channels x 2 s run 6.41 -> 5.80 ms at
+// 48 kHz and 5.49 -> 4.86 ms at 44.1 kHz (round 1: 6.10 / 5.14; the 6 % in between came in with the time-parallel
+// bookkeeping of every stage's step loop, commit 145fa23, and a build without it did not win it back).
+template <int NT, int LANES, bool SPLIT> constexpr bool pipe_dcw() { return SPLIT && ((NT == 42 && LANES <= 32) || (NT != 42 && LANES == 64)); }
 // SHARE: built for two wavefronts per SIMD (half of the 512-entry register file each, a few
 // spills) -- what lets two workgroups, eight wavefronts, share a CU's four SIMDs beyond 16 384
 // channels.  Smaller batches use the unconstrained build (2 % faster).
