@@ -3,7 +3,7 @@
 bench line, rocprofv3 kernel/domain stats, per-launch durations of every demod kernel variant the bench
 runs, the PMC passes restricted to them, and rNN_traffic.json (what bench.py reports as roofline.traffic).
 
-    python tools/profile_collect.py [round-prefix, default r02]
+    python tools/profile_collect.py [round-prefix, default r03]
 
 FETCH_SIZE correction: 1.0 for the 16-channel workgroup shape (64-byte rows per wavefront load), 2.0 for
 64 channels per wavefront (profiles/r01_fetch_calibration.txt); picked from the kernel's template arguments."""
@@ -12,7 +12,7 @@ import collections, csv, glob, json, os, re, shutil, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 P = os.path.join(ROOT, "gpurun_out", "prof")
 OUT = os.path.join(ROOT, "profiles")
-R = sys.argv[1] if len(sys.argv) > 1 else "r02"
+R = sys.argv[1] if len(sys.argv) > 1 else "r03"
 
 
 def one(pattern):
@@ -24,18 +24,29 @@ def short(name):
     return name.split("(")[0].replace("void same::", "")
 
 
-def variant(name):
-    """Which block of the bench line a demod kernel instance belongs to, from its template arguments
-    <NT, NFF, NFB, MED3, SHARE, LANES, SPLIT, SampleT>."""
-    m = re.search(r"demod_pipe_kernel<(\d+), \d+, \d+, \w+, (\w+), (\d+)", name)
+def classify(name, wgs, state, n1):
+    """Which block of the bench line a demodulation launch belongs to, from the kernel's template arguments
+    <NT, NFF, NFB, MED3, SHARE, LANES, SPLIT, SampleT, FASTMATH> and its workgroup count (bench.py runs the blocks in a fixed
+    order; `state` counts what has been seen, n1 = launches per configs[1] block)."""
+    if "demod_relaxed_kernel" in name or "demod_duo_kernel" in name:
+        return "scaled_long_time_parallel"
+    m = re.search(r"demod_pipe_kernel<(\d+), \d+, \d+, \w+, (\w+), (\d+), \w+, \w+, (\w+)>", name)
     if not m:
         return None
-    nt, share, lanes = int(m.group(1)), m.group(2) in ("true", "1"), int(m.group(3))
+    nt, share, lanes, fm = int(m.group(1)), m.group(2) in ("true", "1"), int(m.group(3)), m.group(4) in ("true", "1")
     if nt == 92:
         return "configs2_48k"
     if lanes == 16:
         return "strict"
-    return "share64"          # time-parallel configs[1] (8 x 4096 columns) and the 32 768-channel block: told apart by grid size / order
+    cols = wgs * 64
+    if fm and cols == C:
+        return "relaxed"
+    if cols > 32768:
+        return "time_parallel" if fm else "time_parallel_strict_chunks"
+    if fm:          # 32 768 columns: configs[1] cut uniformly on the time-major buffer first, the 32 768-channel shard later
+        state["fm512"] = state.get("fm512", 0) + 1
+        return "time_parallel_time_major" if state["fm512"] <= n1 else "scaled_relaxed"
+    return "scaled"
 
 
 bench = json.loads(open(os.path.join(P, "bench.json")).read().strip().splitlines()[-1])
@@ -43,30 +54,40 @@ shutil.copy(os.path.join(P, "bench.json"), os.path.join(OUT, f"{R}_bench_4096ch_
 shutil.copy(one("trace/*/*_kernel_stats.csv"), os.path.join(OUT, f"{R}_rocprofv3_kernel_stats.csv"))
 shutil.copy(one("trace/*/*_domain_stats.csv"), os.path.join(OUT, f"{R}_rocprofv3_domain_stats.csv"))
 C, T = bench["config"]["channels_per_gpu"], bench["config"]["samples_per_channel"]
+CONFIGS1 = ("strict", "time_parallel", "time_parallel_time_major", "time_parallel_strict_chunks", "relaxed")
 
 # ---- per-launch durations, in launch order, per block
-rows = [r for r in csv.DictReader(open(one("trace/*/*_kernel_trace.csv"))) if "demod_pipe_kernel" in r["Kernel_Name"] or "demod_fast_kernel" in r["Kernel_Name"]]
-rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+DEMOD = ("demod_pipe_kernel", "demod_fast_kernel", "demod_relaxed_kernel", "demod_duo_kernel")
+all_rows = list(csv.DictReader(open(one("trace/*/*_kernel_trace.csv"))))
+all_rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+rows = [r for r in all_rows if any(k in r["Kernel_Name"] for k in DEMOD)]
 blocks = collections.OrderedDict()
+state = {}
+n1_trace = bench["steps"] + bench["warmup"] + 1          # (+ the untimed pass after the timed ones)
 for r in rows:
-    v = variant(r["Kernel_Name"]) or short(r["Kernel_Name"])
-    grid = int(r.get("Grid_Size_X", r.get("Grid_Size", "0")) or 0)
-    if v == "share64":
-        # launch order of bench.py: configs[1] time-parallel on the time-major buffer, then on the channel-major copy
-        # (steps + warm-up launches each), then the 32 768-channel block
-        n1 = bench["steps"] + bench["warmup"]
-        done = len(blocks.get("time_parallel_time_major", [])) + len(blocks.get("time_parallel", []))
-        v = "time_parallel_time_major" if done < n1 else ("time_parallel" if done < 2 * n1 else "scaled")
-    blocks.setdefault(v, []).append(((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6, short(r["Kernel_Name"]), grid))
+    wgs = int(r["Grid_Size_X"]) // max(int(r["Workgroup_Size_X"]), 1)
+    v = classify(r["Kernel_Name"], wgs, state, n1_trace) or short(r["Kernel_Name"])
+    blocks.setdefault(v, []).append(((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6, short(r["Kernel_Name"]), wgs))
+# the small kernels a time-parallel launch brackets with its HIP events (scout, planner, sort, state columns)
+side = collections.defaultdict(list)
+for r in all_rows:
+    n = short(r["Kernel_Name"])
+    if n.startswith(("tp_", "copy_state_columns", "init_state", "chunk_final", "fill_u64")):
+        side[n].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
 log = open(os.path.join(P, "trace_bench.log")).read()
 with open(os.path.join(OUT, f"{R}_rocprofv3_kernel_trace_demod.txt"), "w") as o:
-    o.write("demodulation kernel launches of\n`rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --no-cpu-baseline --check 0`\n"
-            "(tools/profile_round.sh), durations in ms in launch order, per block of the bench line:\n")
+    o.write("demodulation kernel launches of\n`rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --no-cpu-baseline --check 0 --no-carried-state-check`\n"
+            "(tools/profile_round.sh), durations in ms in launch order, per block of the bench line (workgroups = grid / workgroup size):\n")
     for v, lst in blocks.items():
-        n_timed = bench["steps"] if v in ("strict", "time_parallel", "time_parallel_time_major") else max(bench["steps"], 10)
+        n_timed = bench["steps"] if v in CONFIGS1 else max(bench["steps"], 10)
         d = [x[0] for x in lst]
-        o.write(f"\n[{v}] {lst[0][1]}  grid {lst[0][2]}  ({len(d)} launches)\n  " + " ".join(f"{x:.3f}" for x in d) + "\n")
-        o.write(f"  average of the last {min(n_timed, len(d))} (the timed ones): {sum(d[-n_timed:]) / min(n_timed, len(d)):.3f} ms; of all: {sum(d) / len(d):.3f} ms\n")
+        extra = 1 if v in CONFIGS1 else 0       # the last launch of a configs[1] block is the untimed pass after the timed ones
+        timed = d[len(d) - extra - n_timed:len(d) - extra] if len(d) > extra + n_timed - 1 else d
+        o.write(f"\n[{v}] {lst[0][1]}  {lst[0][2]} workgroups  ({len(d)} launches)\n  " + " ".join(f"{x:.3f}" for x in d) + "\n")
+        o.write(f"  average of the {len(timed)} timed ones: {sum(timed) / max(len(timed), 1):.3f} ms; of all: {sum(d) / len(d):.3f} ms\n")
+    o.write("\nkernels beside them inside a time-parallel launch's HIP events (microseconds, average over all their launches):\n")
+    for n, d in sorted(side.items()):
+        o.write(f"  {n:32s} {sum(d) / len(d):8.1f} us  x {len(d)}\n")
     m = re.findall(r'"kernel_ms": ([0-9.]+)', log)
     o.write(f"\nbench.py's own HIP-event figures printed by that profiled run (kernel_ms, in the order of the JSON line): {' '.join(m)}\n")
     o.write(f"An unprofiled `python bench.py` on the same box: {R}_bench_4096ch_10s.json.\n")
@@ -84,15 +105,15 @@ for d, name in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
         w = csv.DictWriter(f, fieldnames=list(rows[0].keys()))
         w.writeheader(); w.writerows(rows)
     seen = collections.defaultdict(list)
-    order = []
+    state = {}
     for r in sorted(rows, key=lambda r: int(r["Dispatch_Id"])):
-        v = variant(r["Kernel_Name"]) or short(r["Kernel_Name"])
-        if v == "share64":      # --steps 2 --warmup 1: three launches per configs[1] block, in bench.py's order
-            v = "time_parallel_time_major" if len(seen["time_parallel_time_major"]) < 3 else ("time_parallel" if len(seen["time_parallel"]) < 3 else "scaled")
+        wgs = int(r["Grid_Size"]) // max(int(r["Workgroup_Size"]), 1)
+        v = classify(r["Kernel_Name"], wgs, state, 4) or short(r["Kernel_Name"])     # --steps 2 --warmup 1: four launches per configs[1] block
         seen[v].append(float(r["Counter_Value"]))
     for v, vals in seen.items():
         per[v][name] = (sum(vals) / len(vals), len(vals))
-sizes = {"strict": (C, T), "time_parallel": (C, T), "time_parallel_time_major": (C, T), "scaled": (32768, 44100), "configs2_48k": (16384, 96000)}
+sizes = {"strict": (C, T), "time_parallel": (C, T), "time_parallel_time_major": (C, T), "time_parallel_strict_chunks": (C, T), "relaxed": (C, T),
+         "scaled": (32768, 44100), "scaled_relaxed": (32768, 44100), "configs2_48k": (16384, 96000)}
 for v, d in per.items():
     if "FETCH_SIZE" not in d or "WRITE_SIZE" not in d or v not in sizes:
         continue
@@ -102,7 +123,7 @@ for v, d in per.items():
     corr = 1.0 if v == "strict" else 2.0
     cc, tt = sizes[v]
     hbm = int(round(d["FETCH_SIZE"][0] * 1024 * corr + d["WRITE_SIZE"][0] * 1024))
-    traffic.append({"mode": v if v in ("strict", "time_parallel", "time_parallel_time_major") else "strict", "block": v, "workload": f"{cc} ch x {tt} samples",
+    traffic.append({"mode": v if v in CONFIGS1 else ("relaxed" if v == "scaled_relaxed" else "strict"), "block": v, "workload": f"{cc} ch x {tt} samples",
                     "hbm_bytes_per_launch": hbm, "algorithmic_bytes_per_launch": 4 * cc * tt, "ratio": round(hbm / (4.0 * cc * tt), 4),
                     "fetch_size_kb": round(d["FETCH_SIZE"][0], 1), "write_size_kb": round(d["WRITE_SIZE"][0], 1), "fetch_correction": corr,
                     "launches": d["FETCH_SIZE"][1],
@@ -115,13 +136,13 @@ try:
     rows = counters("sq")
     mix = collections.OrderedDict()
     seen_disp = collections.defaultdict(set)
+    state = {}
+    by_disp = {}
     for r in sorted(rows, key=lambda r: int(r["Dispatch_Id"])):
-        v = variant(r["Kernel_Name"]) or short(r["Kernel_Name"])
-        if v == "share64":
-            for cand in ("time_parallel_time_major", "time_parallel", "scaled"):
-                if r["Dispatch_Id"] in seen_disp[cand] or len(seen_disp[cand]) < 3 or cand == "scaled":
-                    v = cand
-                    break
+        if r["Dispatch_Id"] not in by_disp:
+            wgs = int(r["Grid_Size"]) // max(int(r["Workgroup_Size"]), 1)
+            by_disp[r["Dispatch_Id"]] = classify(r["Kernel_Name"], wgs, state, 4) or short(r["Kernel_Name"])
+        v = by_disp[r["Dispatch_Id"]]
         seen_disp[v].add(r["Dispatch_Id"])
         mix.setdefault(v, collections.defaultdict(float))[r["Counter_Name"]] += float(r["Counter_Value"])
     lanes = {"strict": 16}
