@@ -215,7 +215,6 @@ struct same_batch {
         uint32_t n_desc = 0;
         uint32_t *d_final_col = nullptr;
         float *d_energy = nullptr; size_t energy_cap = 0;   // scout scratch
-        uint32_t *d_sort = nullptr;                          // planner's bucket-sort scratch
         int sort_mode = -1;                                  // SAME_TP_SORT: -1 choose, 0 grid order, 1 pieces sorted by length into workgroups
         uint32_t last_chunks = 1;
         bool last_per_channel = false;
@@ -1039,12 +1038,11 @@ int process_channel_major_native(same_batch *rx, const float *d_x, size_t n, hip
     // SAME_TP_SORT=0 / 1 overrides).  Within one round neither the sorted order nor a long workgroup beside a short one on
     // every CU pays (round 2).
     const int sort_mode = tp.sort_mode >= 0 ? (tp.sort_mode ? 1 : 0) : (columns > 32768u ? 1 : 0);
-    if (!tp.d_sort) HIP_TRY(hipMalloc((void **)&tp.d_sort, same::tp_sort_scratch_bytes()));
     HIP_TRY(same::launch_counters(sl.d_counters, sl.h_counters_dev, 0, stream));
     if (rx->timing) HIP_TRY(hipEventRecord(sl.ev_start, stream));
     // (sorted: the workgroups once more, longest first whatever their group -- those that wait for a free CU are then the short ones)
     const bool lpt = sort_mode != 0;
-    HIP_TRY(same::launch_tp_plan(d_x, plan, tp.d_energy, d_own, d_row0, d_nom, d_perm, d_wg, tp.d_sort, sort_mode != 0, stream,
+    HIP_TRY(same::launch_tp_plan(d_x, plan, tp.d_energy, d_own, d_row0, d_nom, d_perm, d_wg, sort_mode != 0, stream,
                                  lpt ? d_perm2 : nullptr, lpt ? d_wg2 : nullptr));
     if (lpt) { d_perm = d_perm2; d_wg = d_wg2; }
     HIP_TRY(same::launch_init_state(tp.Pv, tp.Sv, 0, stream));
@@ -1265,7 +1263,6 @@ void same_batch_free(same_batch *rx)
     if (rx->tp.d_desc_out) (void)hipFree(rx->tp.d_desc_out);
     if (rx->tp.d_final_col) (void)hipFree(rx->tp.d_final_col);
     if (rx->tp.d_energy) (void)hipFree(rx->tp.d_energy);
-    if (rx->tp.d_sort) (void)hipFree(rx->tp.d_sort);
     if (rx->copy_stream) (void)hipStreamDestroy(rx->copy_stream);
     if (rx->h_wake) (void)hipHostFree(rx->h_wake);
     if (rx->d_stage) (void)hipFree(rx->d_stage);

@@ -363,42 +363,48 @@ __global__ void tp_scout_kernel(const float *__restrict__ x, TpPlan g, float *__
 // lane): bisection on that length, each trial a greedy scan that always cuts at the latest allowed instant.  Chunks
 // that are left over own nothing (they warm up and hand over at once).  Where a stretch has no quiet instant at all
 // the cut falls where the length limit puts it and the chunk before it runs on until idle, as with uniform boundaries.
-__global__ __launch_bounds__(256) void tp_boundaries_kernel(const float *__restrict__ energy, TpPlan g, uint32_t *__restrict__ own_start,
-                                                             uint32_t *__restrict__ row0, uint32_t *__restrict__ nominal)
+__global__ __launch_bounds__(kWave) void tp_boundaries_kernel(const float *__restrict__ energy, TpPlan g, uint32_t *__restrict__ own_start,
+                                                               uint32_t *__restrict__ row0, uint32_t *__restrict__ nominal)
 {
-    // one workgroup per channel: the readings and the "latest quiet instant" table live in LDS, the 256 threads fill
-    // them together, thread 0 runs the (short) bisection
+    // one wavefront per channel: the readings, the "latest quiet instant" table and the cuts live in LDS; the search for
+    // the shortest feasible limit runs 64 candidates at a time, one per lane
     extern __shared__ float tp_lds[];
-    const uint32_t c = blockIdx.x, tid = threadIdx.x;
+    const uint32_t c = blockIdx.x, lane = threadIdx.x;
     const int NB = (int)g.scout_blocks, K = (int)g.n_chunks;
     float *e = tp_lds;                                             // [NB]
     int *lastq = reinterpret_cast<int *>(tp_lds + NB);             // [NB] latest allowed instant at or before block j (-1: none)
-    __shared__ float red[256];
+    int *cut = lastq + NB;                                         // [64]
     constexpr int kQuietBefore = 8, kQuietAfter = 1;
     float m = 0.0f;
-    for (int j = (int)tid; j < NB; j += 256) { const float v = energy[(size_t)c * NB + j]; e[j] = v; m = fmaxf(m, v); }
-    red[tid] = m;
+    for (int j = (int)lane; j < NB; j += (int)kWave) { const float v = energy[(size_t)c * NB + j]; e[j] = v; m = fmaxf(m, v); }
+    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+    const float thr = 0.08f * m;
     __syncthreads();
-    for (int off = 128; off > 0; off >>= 1) { if ((int)tid < off) red[tid] = fmaxf(red[tid], red[tid + off]); __syncthreads(); }
-    const float thr = 0.08f * red[0];
-    for (int j = (int)tid; j < NB; j += 256) {
+    // allowed instants, and the running "latest allowed": every lane a contiguous stretch, the stretches' last values
+    // scanned across the wavefront
+    const int S = (NB + (int)kWave - 1) / (int)kWave, j0 = (int)lane * S, j1 = min(j0 + S, NB);
+    int run = -1;
+    for (int j = j0; j < j1; ++j) {
         bool ok = j - kQuietBefore >= 0 && j + kQuietAfter < NB;
         if (ok) for (int t = j - kQuietBefore; t <= j + kQuietAfter; ++t) if (e[t] > thr) { ok = false; break; }
-        lastq[j] = ok ? j : -1;
+        if (ok) run = j;
+        lastq[j] = run;
     }
+    int before = run;                                              // inclusive scan (max) of the stretches' last values ...
+    for (int off = 1; off < (int)kWave; off <<= 1) { const int o = __shfl_up(before, off); if ((int)lane >= off) before = max(before, o); }
+    before = __shfl_up(before, 1);                                 // ... made exclusive
+    if (lane == 0) before = -1;
+    for (int j = j0; j < j1; ++j) if (lastq[j] < 0) lastq[j] = before;
     __syncthreads();
-    if (tid != 0) return;
-    for (int j = 1; j < NB; ++j) if (lastq[j] < 0) lastq[j] = lastq[j - 1];      // running "latest allowed"
     const uint32_t kB = g.block_len;
     // shortest own range, in scout blocks.  Small on purpose: with a large minimum the greedy cut below is no longer
     // optimal (a cut just before a burst may be unreachable from the latest allowed cut before it, while the burst's
-    // end is out of reach from there), and the bisection over it no longer monotone
+    // end is out of reach from there), and the search over it no longer monotone
     const int min_blocks = 2;
     // greedy cut for a given limit L (scout blocks per chunk): always at the latest allowed instant in reach; returns
-    // the number of pieces, cuts in cut[1..].  forced: where no allowed instant is in reach, cut at the limit -- the
-    // chunk before it then runs on until idle; only used when no plan without such cuts exists
-    int cut[64];
-    auto plan = [&](int L, bool store, bool forced) {
+    // the number of pieces, cuts in cut[1..] when `store`.  forced: where no allowed instant is in reach, cut at the
+    // limit -- the chunk before it then runs on until idle; only used when no plan without such cuts exists
+    auto plan = [&](int L, bool store, bool forced) __attribute__((always_inline)) {
         int pos = 0, n = 1;
         while (NB - pos > L) {
             int q = lastq[min(pos + L, NB - 1)];
@@ -411,26 +417,38 @@ __global__ __launch_bounds__(256) void tp_boundaries_kernel(const float *__restr
         }
         return n;
     };
-    bool forced = false;
+    const bool forced = plan(NB - 1, false, false) > K;            // not even the loosest limit works with clean cuts only
+    // the smallest limit in [lo, NB] whose plan has at most K pieces (feasibility is monotone in the limit): 64 evenly
+    // spaced candidates, then the stretch below the first feasible one, until the stretch is a single value
     int lo = (NB + K - 1) / K, hi = NB;
-    if (plan(NB - 1, false, false) > K) forced = true;          // not even the loosest limit works with clean cuts only
-    while (lo < hi) { const int mid = (lo + hi) / 2; if (plan(mid, false, forced) <= K) hi = mid; else lo = mid + 1; }
-    const int used = plan(lo, true, forced);
+    while (lo < hi) {
+        const int step = (hi - lo + (int)kWave - 1) / (int)kWave;            // candidates lo, lo + step, ... (at or beyond hi: feasible)
+        const int cand = lo + step * (int)lane;
+        const bool ok = cand >= hi || plan(cand, false, forced) <= K;
+        const unsigned long long okm = __builtin_amdgcn_ballot_w64(ok);
+        if (okm == 0ull) { lo += step * ((int)kWave - 1) + 1; continue; }    // every candidate below hi fails
+        const int first = __builtin_ctzll(okm);
+        hi = min(lo + step * first, hi);
+        if (first > 0) lo += step * (first - 1) + 1;
+    }
+    int used = 0;
+    if (lane == 0) used = plan(lo, true, forced);
+    used = __shfl(used, 0);
+    __syncthreads();
     // `used` pieces: cuts 1 .. used-1.  Chunks that are left over sit, empty, at the last cut: the piece after it is
     // the last chunk (K-1), which ends with the input and leaves the channel's state.
-    own_start[c] = 0;
-    for (int k = 1; k < K; ++k) {
+    auto own = [&](int k) __attribute__((always_inline)) -> uint32_t {
         const int i = k < used ? k : used - 1;
-        uint32_t p = i >= 1 ? (uint32_t)cut[i] * kScoutBlock : 0u;
-        p -= p % kB;
-        own_start[(size_t)k * g.channels + c] = p;
-    }
-    for (int k = 0; k < K; ++k) {
-        const uint32_t p = own_start[(size_t)k * g.channels + c];
+        uint32_t p = (k >= 1 && i >= 1) ? (uint32_t)cut[i] * kScoutBlock : 0u;
+        return p - p % kB;
+    };
+    for (int k = (int)lane; k < K; k += (int)kWave) {
+        const uint32_t p = own(k);
         const uint32_t r = (k == 0 || p < g.warmup_samples) ? 0u : p - g.warmup_samples;     // multiples of the block length
         const size_t v = (size_t)k * g.channels + c;
+        own_start[v] = p;
         row0[v] = r;
-        nominal[v] = k + 1 < K ? (own_start[(size_t)(k + 1) * g.channels + c] - r + kB - 1u) / kB : 0xffffffffu;
+        nominal[v] = k + 1 < K ? (own(k + 1) - r + kB - 1u) / kB : 0xffffffffu;
     }
 }
 // Pieces of similar length share a workgroup (a workgroup runs as long as its longest lane, and with more workgroups
@@ -447,37 +465,45 @@ __device__ __forceinline__ void tp_sort_key(const TpPlan &g, const uint32_t *row
     const uint32_t len = *group == 0u ? avail : min(nominal[v], avail);
     *bucket = kSortBuckets - 1u - min(len / kSortBucketBlocks, kSortBuckets - 1u);         // longest first
 }
-__global__ void tp_sort_hist_kernel(TpPlan g, const uint32_t *row0, const uint32_t *nominal, uint32_t *hist)
+// One workgroup sorts them all: histogram, scan and scatter in LDS (three launches with global atomics -- every empty
+// piece on the same counter -- took 160 us for 40 960 columns; this takes 48).
+constexpr uint32_t kSortThreads = 1024;
+__global__ __launch_bounds__(kSortThreads) void tp_sort_kernel(TpPlan g, const uint32_t *__restrict__ row0, const uint32_t *__restrict__ nominal,
+                                                                uint32_t *__restrict__ perm)
 {
-    const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
-    if (v >= g.n_chunks * g.channels) return;
-    uint32_t grp, b;
-    tp_sort_key(g, row0, nominal, v, &grp, &b);
-    atomicAdd(&hist[grp * kSortBuckets + b], 1u);
-}
-__global__ void tp_sort_scan_kernel(TpPlan g, uint32_t *hist)
-{
-    // one wavefront: exclusive prefix sums per group, each offset by where its group starts in the grid
-    const uint32_t lane = threadIdx.x;
+    __shared__ uint32_t hist[3u * kSortBuckets];
+    __shared__ uint32_t wave_sum[kSortThreads / kWave];
+    const uint32_t tid = threadIdx.x, lane = tid & (kWave - 1u), wave = tid / kWave, n = g.n_chunks * g.channels;
+    for (uint32_t i = tid; i < 3u * kSortBuckets; i += kSortThreads) hist[i] = 0u;
+    __syncthreads();
+    for (uint32_t v = tid; v < n; v += kSortThreads) {
+        uint32_t grp, b;
+        tp_sort_key(g, row0, nominal, v, &grp, &b);
+        atomicAdd(&hist[grp * kSortBuckets + b], 1u);
+    }
+    __syncthreads();
+    // exclusive prefix sums per group, each offset by where its group starts in the grid: a thread owns four buckets
+    constexpr uint32_t PER = kSortBuckets / kSortThreads;
+    static_assert(PER * kSortThreads == kSortBuckets, "buckets per thread");
     const uint32_t base[3] = {0u, g.channels, 2u * g.channels};
     for (uint32_t grp = 0; grp < 3u; ++grp) {
-        uint32_t run = base[grp];
-        for (uint32_t i = 0; i < kSortBuckets; i += kWave) {
-            const uint32_t n = hist[grp * kSortBuckets + i + lane];
-            uint32_t incl = n;
-            for (int off = 1; off < (int)kWave; off <<= 1) { const uint32_t t = (uint32_t)__shfl_up((int)incl, off); if ((int)lane >= off) incl += t; }
-            hist[grp * kSortBuckets + i + lane] = run + incl - n;
-            run += (uint32_t)__shfl((int)incl, kWave - 1);
-        }
+        uint32_t *h = hist + grp * kSortBuckets + tid * PER;
+        uint32_t mine = 0;
+        for (uint32_t i = 0; i < PER; ++i) mine += h[i];
+        uint32_t incl = mine;
+        for (int off = 1; off < (int)kWave; off <<= 1) { const uint32_t t = (uint32_t)__shfl_up((int)incl, off); if ((int)lane >= off) incl += t; }
+        if (lane == kWave - 1u) wave_sum[wave] = incl;
+        __syncthreads();
+        uint32_t before = base[grp] + incl - mine;
+        for (uint32_t w = 0; w < wave; ++w) before += wave_sum[w];
+        for (uint32_t i = 0; i < PER; ++i) { const uint32_t c = h[i]; h[i] = before; before += c; }
+        __syncthreads();
     }
-}
-__global__ void tp_sort_scatter_kernel(TpPlan g, const uint32_t *row0, const uint32_t *nominal, uint32_t *hist, uint32_t *perm)
-{
-    const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
-    if (v >= g.n_chunks * g.channels) return;
-    uint32_t grp, b;
-    tp_sort_key(g, row0, nominal, v, &grp, &b);
-    perm[atomicAdd(&hist[grp * kSortBuckets + b], 1u)] = v;
+    for (uint32_t v = tid; v < n; v += kSortThreads) {
+        uint32_t grp, b;
+        tp_sort_key(g, row0, nominal, v, &grp, &b);
+        perm[atomicAdd(&hist[grp * kSortBuckets + b], 1u)] = v;
+    }
 }
 __global__ void tp_iota_kernel(uint32_t *perm, uint32_t n)
 {
@@ -520,19 +546,15 @@ __global__ void tp_wg_order_kernel(uint32_t n_wg, const uint32_t *__restrict__ p
     if (lane == 0) wg_blocks_out[pos] = wg_blocks[w];
 }
 hipError_t launch_tp_plan(const float *x, const TpPlan &g, float *energy, uint32_t *own_start, uint32_t *row0,
-                          uint32_t *nominal, uint32_t *perm, uint32_t *wg_blocks, uint32_t *sort_scratch, bool sorted, hipStream_t stream,
+                          uint32_t *nominal, uint32_t *perm, uint32_t *wg_blocks, bool sorted, hipStream_t stream,
                           uint32_t *perm_out, uint32_t *wg_blocks_out)
 {
     const size_t n = (size_t)g.channels * g.scout_blocks;
     const uint32_t columns = g.n_chunks * g.channels;
     hipLaunchKernelGGL(tp_scout_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, x, g, energy);
-    hipLaunchKernelGGL(tp_boundaries_kernel, dim3(g.channels), dim3(256), (size_t)g.scout_blocks * 8, stream, energy, g, own_start, row0, nominal);
+    hipLaunchKernelGGL(tp_boundaries_kernel, dim3(g.channels), dim3(kWave), (size_t)g.scout_blocks * 8 + 64 * sizeof(int), stream, energy, g, own_start, row0, nominal);
     if (sorted) {
-        hipError_t e = hipMemsetAsync(sort_scratch, 0, 3u * kSortBuckets * sizeof(uint32_t), stream);
-        if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(tp_sort_hist_kernel, dim3((columns + 255) / 256), dim3(256), 0, stream, g, row0, nominal, sort_scratch);
-        hipLaunchKernelGGL(tp_sort_scan_kernel, dim3(1), dim3(kWave), 0, stream, g, sort_scratch);
-        hipLaunchKernelGGL(tp_sort_scatter_kernel, dim3((columns + 255) / 256), dim3(256), 0, stream, g, row0, nominal, sort_scratch, perm);
+        hipLaunchKernelGGL(tp_sort_kernel, dim3(1), dim3(kSortThreads), 0, stream, g, row0, nominal, perm);
     } else {
         hipLaunchKernelGGL(tp_iota_kernel, dim3((columns + 255) / 256), dim3(256), 0, stream, perm, columns);
     }
@@ -544,7 +566,6 @@ hipError_t launch_tp_plan(const float *x, const TpPlan &g, float *energy, uint32
                            perm_out, wg_blocks_out);
     return hipGetLastError();
 }
-size_t tp_sort_scratch_bytes() { return 3u * kSortBuckets * sizeof(uint32_t); }
 
 __global__ void fill_u64_kernel(uint64_t *p, size_t n, uint64_t v)
 {

@@ -69,12 +69,11 @@ struct TpPlan {
     uint32_t scout_blocks;    // whole_samples / 256
 };
 // energy [channels][scout_blocks] (scratch), own_start [n_chunks][channels], row0 / nominal / perm [n_chunks * channels],
-// wg_blocks [n_chunks * channels / 64], sort_scratch tp_sort_scratch_bytes(); perm_out / wg_blocks_out (same sizes, may be
+// wg_blocks [n_chunks * channels / 64]; perm_out / wg_blocks_out (same sizes, may be
 // null; wg_blocks_out [2][workgroups]): the workgroups of perm / wg_blocks once more, longest first
 hipError_t launch_tp_plan(const float *x, const TpPlan &g, float *energy, uint32_t *own_start, uint32_t *row0,
-                          uint32_t *nominal, uint32_t *perm, uint32_t *wg_blocks, uint32_t *sort_scratch, bool sorted, hipStream_t stream,
+                          uint32_t *nominal, uint32_t *perm, uint32_t *wg_blocks, bool sorted, hipStream_t stream,
                           uint32_t *perm_out = nullptr, uint32_t *wg_blocks_out = nullptr);
-size_t tp_sort_scratch_bytes();
 hipError_t launch_transpose_f32(const float *in, float *out, uint32_t n_channels, uint32_t n_samples,
                                 hipStream_t stream);
 hipError_t launch_transpose_i16(const int16_t *in, int16_t *out, uint32_t n_channels, uint32_t n_samples,
