@@ -180,7 +180,7 @@ struct same_batch {
         uint32_t *d_counters = nullptr;  // [0] n_events [1] n_bursts [2] overflow
         uint32_t *h_counters = nullptr;  // pinned, host-mapped
         uint32_t *h_counters_dev = nullptr;  // device view of h_counters
-        hipEvent_t ev_start = nullptr, ev_stop = nullptr, ev_done = nullptr;
+        hipEvent_t ev_start = nullptr, ev_stop = nullptr, ev_done = nullptr, ev_planned = nullptr;
         // pinned landing buffers of the read-back, grown on demand.  A copy into pageable memory
         // is staged by the runtime (blit kernel + host memcpy per chunk) and, queued beside the
         // next launch, holds that launch up for as long as the host is busy.
@@ -215,6 +215,8 @@ struct same_batch {
         uint32_t n_desc = 0;
         uint32_t *d_final_col = nullptr;
         float *d_energy = nullptr; size_t energy_cap = 0;   // scout scratch
+        hipEvent_t ev_plan_prev = nullptr; bool plan_recorded = false;
+        int knob_plan_stream = 0;                            // SAME_TP_PLAN_STREAM=0: planning kernels stay on the launch stream (A/B measurements)
         int sort_mode = -1;                                  // SAME_TP_SORT: -1 choose, 0 grid order, 1 pieces sorted by length into workgroups
         uint32_t last_chunks = 1;
         bool last_per_channel = false;
@@ -227,6 +229,9 @@ struct same_batch {
     } tp;
     uint64_t launch_seq = 0;
     hipStream_t copy_stream = nullptr;   // read-back of finished launches, beside the compute stream
+    // Time-parallel launches on the library's own stream: scout, planner and sort of call k + 1 run here, beside the tail of
+    // launch k (whose short workgroups have left their CUs by then); the own stream waits for them (Slot::ev_planned)
+    hipStream_t plan_stream = nullptr;
     float last_ms = 0.0f;
     bool overflowed = false;
     bool use_fast = false;           // configuration has a latency-optimised kernel
@@ -343,6 +348,7 @@ void read_knobs(same_batch *rx)
     rx->debug = std::getenv("SAME_DEBUG") != nullptr;
     rx->host_threads = std::max(0, num("SAME_HOST_THREADS", 0));
     rx->tp.sort_mode = num("SAME_TP_SORT", -1);
+    rx->tp.knob_plan_stream = tri("SAME_TP_PLAN_STREAM");
     rx->knob_relaxed = tri("SAME_RELAXED");
     { const char *e = std::getenv("SAME_RELAXED_KERNEL"); rx->P.knob_relaxed_kernel = !e ? 0 : (std::strcmp(e, "solo") == 0 ? 1 : (std::strcmp(e, "duo") == 0 ? 2 : 0)); }
     { const char *e = std::getenv("SAME_TP_KERNEL"); rx->tp.knob_kernel = !e ? 0 : (std::strcmp(e, "wave") == 0 ? 2 : (std::strcmp(e, "pipe") == 0 ? 1 : 0)); }
@@ -1042,8 +1048,24 @@ int process_channel_major_native(same_batch *rx, const float *d_x, size_t n, hip
     if (rx->timing) HIP_TRY(hipEventRecord(sl.ev_start, stream));
     // (sorted: the workgroups once more, longest first whatever their group -- those that wait for a free CU are then the short ones)
     const bool lpt = sort_mode != 0;
-    HIP_TRY(same::launch_tp_plan(d_x, plan, tp.d_energy, d_own, d_row0, d_nom, d_perm, d_wg, sort_mode != 0, stream,
+    // On the library's own stream the planning kernels go to the plan stream: they need the input (ordered by
+    // same_batch_order_after, which both streams honour) and this slot's geometry buffers (free since the harvest above),
+    // not the previous launch -- so they run beside its tail instead of after it (~0.25 ms of small kernels per call at
+    // configs[1]).  On a caller's stream everything stays in that stream's order.
+    const bool side = stream == rx->own_stream && tp.knob_plan_stream >= 0;
+    hipStream_t ps = side ? rx->plan_stream : stream;
+    // (the energy map is one buffer for both slots: this call's scout after the previous call's planner, whichever
+    // streams the two ran on)
+    if (tp.plan_recorded) HIP_TRY(hipStreamWaitEvent(ps, tp.ev_plan_prev, 0));
+    HIP_TRY(same::launch_tp_plan(d_x, plan, tp.d_energy, d_own, d_row0, d_nom, d_perm, d_wg, sort_mode != 0, ps,
                                  lpt ? d_perm2 : nullptr, lpt ? d_wg2 : nullptr));
+    if (!tp.ev_plan_prev) HIP_TRY(hipEventCreateWithFlags(&tp.ev_plan_prev, hipEventDisableTiming));
+    HIP_TRY(hipEventRecord(tp.ev_plan_prev, ps));
+    tp.plan_recorded = true;
+    if (side) {
+        HIP_TRY(hipEventRecord(sl.ev_planned, ps));
+        HIP_TRY(hipStreamWaitEvent(stream, sl.ev_planned, 0));
+    }
     if (lpt) { d_perm = d_perm2; d_wg = d_wg2; }
     HIP_TRY(same::launch_init_state(tp.Pv, tp.Sv, 0, stream));
     HIP_TRY(same::launch_copy_state_columns(tp.d_desc_in, tp.n_desc, C, columns, nullptr, C, stream));
@@ -1212,11 +1234,13 @@ int same_batch_new(const same_rx_builder *b, uint32_t n_channels, int device, ui
         return cleanup(fail(SAME_EINVAL, "configuration needs %zu bytes of LDS per wavefront (limit 160 KiB)", same::demod_lds_bytes(rx->P)));
     TRY_OR_CLEAN(hipStreamCreateWithFlags(&rx->own_stream, hipStreamNonBlocking));
     TRY_OR_CLEAN(hipStreamCreateWithFlags(&rx->copy_stream, hipStreamNonBlocking));
+    TRY_OR_CLEAN(hipStreamCreateWithFlags(&rx->plan_stream, hipStreamNonBlocking));
     TRY_OR_CLEAN(hipEventCreateWithFlags(&rx->ev_order, hipEventDisableTiming));
     for (auto &sl : rx->slot) {
         TRY_OR_CLEAN(hipEventCreate(&sl.ev_start));
         TRY_OR_CLEAN(hipEventCreate(&sl.ev_stop));
         TRY_OR_CLEAN(hipEventCreateWithFlags(&sl.ev_done, hipEventDisableTiming));
+        TRY_OR_CLEAN(hipEventCreateWithFlags(&sl.ev_planned, hipEventDisableTiming));
         TRY_OR_CLEAN(hipMalloc((void **)&sl.d_counters, 4 * sizeof(uint32_t)));
         TRY_OR_CLEAN(hipHostMalloc((void **)&sl.h_counters, 4 * sizeof(uint32_t), hipHostMallocMapped));
         TRY_OR_CLEAN(hipHostGetDevicePointer((void **)&sl.h_counters_dev, sl.h_counters, 0));
@@ -1253,6 +1277,7 @@ void same_batch_free(same_batch *rx)
         if (sl.ev_start) (void)hipEventDestroy(sl.ev_start);
         if (sl.ev_stop) (void)hipEventDestroy(sl.ev_stop);
         if (sl.ev_done) (void)hipEventDestroy(sl.ev_done);
+        if (sl.ev_planned) (void)hipEventDestroy(sl.ev_planned);
         if (sl.d_handover) (void)hipFree(sl.d_handover);
         if (sl.h_handover) (void)hipHostFree(sl.h_handover);
         if (sl.d_geom) (void)hipFree(sl.d_geom);
@@ -1263,7 +1288,9 @@ void same_batch_free(same_batch *rx)
     if (rx->tp.d_desc_out) (void)hipFree(rx->tp.d_desc_out);
     if (rx->tp.d_final_col) (void)hipFree(rx->tp.d_final_col);
     if (rx->tp.d_energy) (void)hipFree(rx->tp.d_energy);
+    if (rx->tp.ev_plan_prev) (void)hipEventDestroy(rx->tp.ev_plan_prev);
     if (rx->copy_stream) (void)hipStreamDestroy(rx->copy_stream);
+    if (rx->plan_stream) (void)hipStreamDestroy(rx->plan_stream);
     if (rx->h_wake) (void)hipHostFree(rx->h_wake);
     if (rx->d_stage) (void)hipFree(rx->d_stage);
     if (rx->d_stage2) (void)hipFree(rx->d_stage2);
@@ -1335,6 +1362,7 @@ int same_batch_order_after(same_batch *rx, void *producer_stream)
     HIP_TRY(hipSetDevice(rx->device));
     HIP_TRY(hipEventRecord(rx->ev_order, (hipStream_t)producer_stream));
     HIP_TRY(hipStreamWaitEvent(rx->own_stream, rx->ev_order, 0));
+    HIP_TRY(hipStreamWaitEvent(rx->plan_stream, rx->ev_order, 0));      // (the planner reads the input too)
     return SAME_OK;
 }
 
