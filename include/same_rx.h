@@ -268,6 +268,10 @@ int same_batch_read_trace(same_batch *rx, uint32_t channel, same_symbol_trace *o
 /* device timing of the demodulation kernel(s) of the last process call, measured with
  * HIP events on the stream the kernel ran on (milliseconds); for bench.py's roofline */
 int same_batch_last_kernel_ms(same_batch *rx, float *ms);
+/* the demodulation kernel alone: equal to the above except for a time-parallel launch on a channel-major input, whose
+ * figure above also covers the scout / planner / sort kernels (when they are not hidden under the previous launch) and
+ * the state-column copies */
+int same_batch_last_demod_kernel_ms(same_batch *rx, float *ms);
 /* enable/disable that timing (off by default: two event records per call) */
 void same_batch_set_kernel_timing(same_batch *rx, int enable);
 /* name of the kernel variant the last call dispatched to (static string) */

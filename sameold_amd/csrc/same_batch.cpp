@@ -181,6 +181,8 @@ struct same_batch {
         uint32_t *h_counters = nullptr;  // pinned, host-mapped
         uint32_t *h_counters_dev = nullptr;  // device view of h_counters
         hipEvent_t ev_start = nullptr, ev_stop = nullptr, ev_done = nullptr, ev_planned = nullptr;
+        hipEvent_t ev_k0 = nullptr, ev_k1 = nullptr;         // around the demodulation kernel alone (time-parallel launches bracket more with ev_start / ev_stop)
+        bool have_k = false;
         // pinned landing buffers of the read-back, grown on demand.  A copy into pageable memory
         // is staged by the runtime (blit kernel + host memcpy per chunk) and, queued beside the
         // next launch, holds that launch up for as long as the host is busy.
@@ -251,6 +253,7 @@ struct same_batch {
     // kernel timing
     bool timing = false;
     bool have_timing = false;
+    float last_demod_ms = 0.0f;         // the demodulation kernel alone (= last_ms unless the launch brackets planning kernels too)
     // ordered host-side event queue
     EventQueue queue;                   // events not yet polled: [queue_head, size)
     size_t queue_head = 0;
@@ -406,6 +409,8 @@ int harvest_slot(same_batch *rx, same_batch::Slot &sl)
     sl.in_flight = false;
     if (rx->timing) {
         HIP_TRY(hipEventElapsedTime(&rx->last_ms, sl.ev_start, sl.ev_stop));
+        rx->last_demod_ms = rx->last_ms;
+        if (sl.have_k) HIP_TRY(hipEventElapsedTime(&rx->last_demod_ms, sl.ev_k0, sl.ev_k1));
         rx->have_timing = true;
     }
     auto t_waited = std::chrono::steady_clock::now();
@@ -855,6 +860,7 @@ int process_time_major(same_batch *rx, const SampleT *d_x, size_t n_samples, hip
         same::PipeChunks pc{};
         const uint32_t n_chunks = plan_chunks(rx, n, geom, pc);
         rx->tp.last_chunks = n_chunks;
+        sl.have_k = false;
         same::Output O{};
         if (n_chunks > 1u) {
             // Time-parallel launch: every channel as n_chunks state columns side by side.
@@ -1073,9 +1079,12 @@ int process_channel_major_native(same_batch *rx, const float *d_x, size_t n, hip
     pc.handover = sl.d_handover;
     pc.col_row0 = d_row0; pc.col_nominal = d_nom; pc.wg_blocks = d_wg; pc.col_perm = sort_mode != 0 ? d_perm : nullptr;
     pc.in_samples = n; pc.whole_samples = (uint32_t)n;
+    sl.have_k = rx->timing;
+    if (rx->timing) HIP_TRY(hipEventRecord(sl.ev_k0, stream));
     hipError_t e = wave ? same::launch_demod_relaxed(tp.Pv, tp.Sv, O, rx->d_taps, d_x, (uint32_t)(n / fb), rx->counter, stream, pc)
                         : same::launch_demod_pipe(tp.Pv, tp.Sv, O, rx->d_taps, d_x, (uint32_t)(n / fb), rx->counter, stream, pc, tp.kernel == same_batch::TimePar::kPipeRelaxed);
     if (e != hipSuccess) return fail(SAME_EHIP, "time-parallel demod kernel launch failed: %s", hipGetErrorString(e));
+    if (rx->timing) HIP_TRY(hipEventRecord(sl.ev_k1, stream));
     // The channels' state afterwards: that of the chunk the hand-over chain ends in, as the host's stitch follows it --
     // the last chunk as a rule (its columns end with the input); an earlier one where a burst ran on to the end of the
     // call without a hand-over (a forced cut on a channel that is never quiet: its events are the ones that are kept).
@@ -1239,6 +1248,8 @@ int same_batch_new(const same_rx_builder *b, uint32_t n_channels, int device, ui
     for (auto &sl : rx->slot) {
         TRY_OR_CLEAN(hipEventCreate(&sl.ev_start));
         TRY_OR_CLEAN(hipEventCreate(&sl.ev_stop));
+        TRY_OR_CLEAN(hipEventCreate(&sl.ev_k0));
+        TRY_OR_CLEAN(hipEventCreate(&sl.ev_k1));
         TRY_OR_CLEAN(hipEventCreateWithFlags(&sl.ev_done, hipEventDisableTiming));
         TRY_OR_CLEAN(hipEventCreateWithFlags(&sl.ev_planned, hipEventDisableTiming));
         TRY_OR_CLEAN(hipMalloc((void **)&sl.d_counters, 4 * sizeof(uint32_t)));
@@ -1276,6 +1287,8 @@ void same_batch_free(same_batch *rx)
         if (sl.h_bursts) (void)hipHostFree(sl.h_bursts);
         if (sl.ev_start) (void)hipEventDestroy(sl.ev_start);
         if (sl.ev_stop) (void)hipEventDestroy(sl.ev_stop);
+        if (sl.ev_k0) (void)hipEventDestroy(sl.ev_k0);
+        if (sl.ev_k1) (void)hipEventDestroy(sl.ev_k1);
         if (sl.ev_done) (void)hipEventDestroy(sl.ev_done);
         if (sl.ev_planned) (void)hipEventDestroy(sl.ev_planned);
         if (sl.d_handover) (void)hipFree(sl.d_handover);
@@ -1477,6 +1490,13 @@ int same_batch_last_kernel_ms(same_batch *rx, float *ms)
     // duration of the most recently collected launch; never waits for one still running
     if (!rx->have_timing) return fail(SAME_EINVAL, "no timed launch yet");
     *ms = rx->last_ms;
+    return SAME_OK;
+}
+int same_batch_last_demod_kernel_ms(same_batch *rx, float *ms)
+{
+    if (!rx || !ms) return fail(SAME_EINVAL, "null argument");
+    if (!rx->have_timing) return fail(SAME_EINVAL, "no timed launch yet");
+    *ms = rx->last_demod_ms;
     return SAME_OK;
 }
 int same_batch_time_parallel_config(same_batch *rx, uint32_t max_chunks, uint32_t min_own_samples, uint32_t warmup_samples)

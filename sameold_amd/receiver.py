@@ -185,6 +185,7 @@ def load_library() -> C.CDLL:
     sig("same_batch_pack_bursts", C.c_int, vp, u32, vp, C.c_size_t, P(C.c_size_t))
     sig("same_batch_read_trace", C.c_int, vp, u32, P(SymbolTrace), C.c_size_t, P(C.c_size_t))
     sig("same_batch_last_kernel_ms", C.c_int, vp, P(f32))
+    sig("same_batch_last_demod_kernel_ms", C.c_int, vp, P(f32))
     sig("same_batch_set_kernel_timing", None, vp, C.c_int)
     sig("same_batch_kernel_name", C.c_char_p, vp)
 
@@ -431,6 +432,12 @@ class SameBatchReceiver:
     def last_kernel_ms(self) -> float:
         ms = C.c_float()
         _check(self._L.same_batch_last_kernel_ms(self._h, C.byref(ms)))
+        return ms.value
+
+    def last_demod_kernel_ms(self) -> float:
+        """The demodulation kernel alone (a channel-major time-parallel launch's last_kernel_ms covers its planning kernels too)."""
+        ms = C.c_float()
+        _check(self._L.same_batch_last_demod_kernel_ms(self._h, C.byref(ms)))
         return ms.value
 
     def poll_events(self, max_events: int = 1 << 20) -> List[Event]:
