@@ -71,8 +71,9 @@ for r in rows:
 # the small kernels a time-parallel launch brackets with its HIP events (scout, planner, sort, state columns)
 side = collections.defaultdict(list)
 for r in all_rows:
-    n = short(r["Kernel_Name"])
+    n = short(r["Kernel_Name"]).replace("same::", "")
     if n.startswith(("tp_", "copy_state_columns", "init_state", "chunk_final", "fill_u64")):
+        n = f"{n} x{int(r['Grid_Size_X']) // max(int(r['Workgroup_Size_X']), 1)}"
         side[n].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
 log = open(os.path.join(P, "trace_bench.log")).read()
 with open(os.path.join(OUT, f"{R}_rocprofv3_kernel_trace_demod.txt"), "w") as o:
@@ -85,9 +86,11 @@ with open(os.path.join(OUT, f"{R}_rocprofv3_kernel_trace_demod.txt"), "w") as o:
         timed = d[len(d) - extra - n_timed:len(d) - extra] if len(d) > extra + n_timed - 1 else d
         o.write(f"\n[{v}] {lst[0][1]}  {lst[0][2]} workgroups  ({len(d)} launches)\n  " + " ".join(f"{x:.3f}" for x in d) + "\n")
         o.write(f"  average of the {len(timed)} timed ones: {sum(timed) / max(len(timed), 1):.3f} ms; of all: {sum(d) / len(d):.3f} ms\n")
-    o.write("\nkernels beside them inside a time-parallel launch's HIP events (microseconds, average over all their launches):\n")
+    o.write("\nkernels around a time-parallel launch (name x workgroups; microseconds: shortest / average over their launches).  Scout,\n"
+            "planner and sort run on the plan stream BESIDE the previous launch's tail when the caller keeps two calls in flight (their\n"
+            "durations then stretch -- they wait for CUs the tail still holds -- and are hidden); the shortest figure is what they take alone:\n")
     for n, d in sorted(side.items()):
-        o.write(f"  {n:32s} {sum(d) / len(d):8.1f} us  x {len(d)}\n")
+        o.write(f"  {n:40s} {min(d):8.1f} / {sum(d) / len(d):8.1f} us  x {len(d)}\n")
     m = re.findall(r'"kernel_ms": ([0-9.]+)', log)
     o.write(f"\nbench.py's own HIP-event figures printed by that profiled run (kernel_ms, in the order of the JSON line): {' '.join(m)}\n")
     o.write(f"An unprofiled `python bench.py` on the same box: {R}_bench_4096ch_10s.json.\n")
