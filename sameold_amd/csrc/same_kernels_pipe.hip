@@ -278,7 +278,10 @@ struct IoCtx : TickRingGlobal {
 
 // Stage 1 state: DC blocker, AGC, input prefetch, and what a replay needs of its last three blocks
 // FM: relaxed AGC step (same_relaxed_common.h) -- the FASTMATH build of time-parallel launches
-template <int NT_, bool MED3, typename SampleT, bool FM = false>
+// CMODE: 1 = the input is channel-major with per-lane streams (xl), 0 = it is not, 2 = decided at run time.  The two
+// compile-time forms exist because a conditional load anywhere between two reads of the prefetch registers makes the
+// compiler wait for all outstanding loads at the reads (see fetch).
+template <int NT_, bool MED3, typename SampleT, bool FM = false, int CMODE = 2>
 struct SampleStage {
     static constexpr int NT = NT_, DCL = PipeGeom<NT_>::DCL, kB = PipeLayout<NT_>::B, RING = PipeLayout<NT_>::RING;
     static constexpr uint32_t LP = kWave;
@@ -334,7 +337,7 @@ struct SampleStage {
             xp[k] = r0[c];
             mp[k] = r1[c];
         }
-        if (xl) {
+        if (CMODE == 1 || (CMODE == 2 && xl)) {
 #pragma unroll
             for (int k = 0; k < kB; ++k) { xn[0][k] = 0.0f; xn[1][k] = 0.0f; }
             if (avail > 0u) load_block_cm(xn[0], 0u);
@@ -412,9 +415,20 @@ struct SampleStage {
     __device__ __forceinline__ void fetch(const SampleT *__restrict__ x, uint32_t blk, uint32_t n_blocks,
                                           uint32_t cin, uint32_t Cin)
     {
+        if constexpr (CMODE == 1) {
+            // per lane: its stream ends where the input does, and silence follows it (a lane that runs on with its workgroup
+            // past the end of its stream must not chew on stale samples); the load itself is unconditional, see below
+            const bool live = blk < avail;
+#pragma unroll
+            for (int k = 0; k < kB; ++k) xs[k] = live ? xn[BUF][k] : 0.0f;
+            load_block_cm(xn[BUF], min(blk + 2u, avail - 1u));      // (avail >= 1: the planner leaves two scout blocks behind every cut)
+            return;
+        }
 #pragma unroll
         for (int k = 0; k < kB; ++k) xs[k] = xn[BUF][k];
-        if (xl) {
+        if (CMODE == 1 || (CMODE == 2 && xl)) {
+            // (this form stays conditional: the unconditional one measured the same here, 3.6 against 3.55 ms, and one build
+            // of it ran the sorted time-parallel launch three times slower)
             if (blk + 2 < avail) {
                 load_block_cm(xn[BUF], blk + 2u);       // per lane: its stream ends where the input does
             } else {
@@ -423,8 +437,13 @@ struct SampleStage {
 #pragma unroll
                 for (int k = 0; k < kB; ++k) xn[BUF][k] = 0.0f;
             }
-        } else if (blk + 2 < n_blocks) {
-            const SampleT *xb = x + ((size_t)(blk + 2) * kB) * Cin;      // wave-uniform
+        } else {
+            // Issued unconditionally (past the end: the last block once more): a load behind a condition makes the compiler
+            // wait for ALL outstanding loads (`s_waitcnt vmcnt(0)`) where the registers are read, i.e. also for the block
+            // fetched one step ago -- which halves the prefetch distance and left this stage waiting ~1 400 clk per step for
+            // memory (SAME_P1_SPLIT profile, round 3: 32 768 ch x 2 s 3.78 -> 3.58 ms relaxed; configs[1] strict 12.1 -> 11.4 ms).
+            // It only pays where the other form is compiled out (CMODE 0): with both in one kernel the wait stays as it was.
+            const SampleT *xb = x + ((size_t)min(blk + 2u, n_blocks - 1u) * kB) * Cin;      // wave-uniform
 #pragma unroll
             for (int k = 0; k < kB; ++k) { const SampleT *row = xb + (size_t)k * Cin; xn[BUF][k] = (float)row[cin]; }
         }
@@ -549,11 +568,10 @@ struct DcStage {
     {
 #pragma unroll
         for (int k = 0; k < kB; ++k) xs[k] = xn[BUF][k];
-        if (blk + 2 < n_blocks) {
-            const SampleT *xb = x + ((size_t)(blk + 2) * kB) * Cin;      // wave-uniform
+        // (unconditional, past the end the last block once more: see SampleStage::fetch)
+        const SampleT *xb = x + ((size_t)min(blk + 2u, n_blocks - 1u) * kB) * Cin;      // wave-uniform
 #pragma unroll
-            for (int k = 0; k < kB; ++k) { const SampleT *row = xb + (size_t)k * Cin; xn[BUF][k] = (float)row[cin]; }
-        }
+        for (int k = 0; k < kB; ++k) { const SampleT *row = xb + (size_t)k * Cin; xn[BUF][k] = (float)row[cin]; }
     }
     // DC blocker (rx/dcblock.rs:45-49, 104-108) of the fetched block; outputs to y[k * LP]
     __device__ __forceinline__ void block(const Params &P, float *y)
@@ -713,13 +731,14 @@ template <int NT, int LANES, bool SPLIT> constexpr bool pipe_dcw() { return SPLI
 // FM (FASTMATH): the relaxed arithmetic of same_relaxed_common.h in every stage -- matched filters as fused multiply-adds
 // into partial sums with an f32 square root, the AGC's two-operation gain chain, the equalizer's fused steps.  Built for
 // the 64-channel two-per-CU form the time-parallel launches use; its parity contract is that mode's (include/same_rx.h).
-template <int NT, int NFF, int NFB, bool MED3, bool SHARE, int LANES, bool SPLIT, typename SampleT, bool FM = false>
+template <int NT, int NFF, int NFB, bool MED3, bool SHARE, int LANES, bool SPLIT, typename SampleT, bool FM = false, int CMODE = 2>
 __global__ __launch_bounds__((pipe_dcw<NT, LANES, SPLIT>() ? 5 : 4) * kWave, SHARE ? 2 : 1) void demod_pipe_kernel(Params P, State S, Output O,
                                                                 const float4 *__restrict__ taps,
                                                                 const SampleT *__restrict__ x,
                                                                 uint32_t n_blocks, uint64_t counter0, PipeChunks K)
 {
     static_assert(!FM || (SPLIT && SHARE && NT == 42 && LANES == 64), "FASTMATH is built for the 64-channel two-per-CU form");
+    if constexpr (CMODE == 0) { K.col_row0 = nullptr; K.col_perm = nullptr; }       // (the host launches this build for nothing else)
     constexpr int kB = PipeLayout<NT>::B, RING = PipeLayout<NT>::RING;
     constexpr uint32_t LP = kWave, kPipeTapFloats = PipeLayout<NT>::tap_floats;
     // PACKED: workgroups of 16 or 32 channels -- the helper wavefront computes BOTH matched filters (mark on its
@@ -880,7 +899,7 @@ __global__ __launch_bounds__((pipe_dcw<NT, LANES, SPLIT>() ? 5 : 4) * kWave, SHA
         for (uint32_t i = lane; i < (uint32_t)NT; i += kWave) tlds[i] = taps[i];
         if (LANES < (int)kWave && lane >= (uint32_t)LANES) return;      // (the wavefront goes on without them)
         P3_HWID(0);
-        SampleStage<NT, MED3, SampleT, FM> M;
+        SampleStage<NT, MED3, SampleT, FM, CMODE> M;
         M.ycol = wring + (2u * (uint32_t)RING) * LP + lane;           // behind the window
         M.xl = xl; M.avail = avail_l;
         M.load(P, S, x, c, C, cin, Cin, counter0, wcol, n_blocks);
@@ -1308,17 +1327,21 @@ static hipError_t launch_pipe_one(const Params &P, const State &S, const Output 
 {
     constexpr bool DCW = pipe_dcw<NT, LANES, SPLIT>();
     constexpr size_t lds = pipe_lds_bytes<NT, DCW>();
-    auto *kernel = demod_pipe_kernel<NT, NFF, NFB, M3, SHARE, LANES, SPLIT, SampleT, FM>;
+    // FASTMATH: one build per input form (see SampleStage); everything else decides at run time
+    const bool cm = K.n_chunks > 1u && K.col_row0 != nullptr;
+    auto *kernel = !FM ? demod_pipe_kernel<NT, NFF, NFB, M3, SHARE, LANES, SPLIT, SampleT, FM, 2>
+                       : (cm ? demod_pipe_kernel<NT, NFF, NFB, M3, SHARE, LANES, SPLIT, SampleT, FM, FM ? 1 : 2>
+                             : demod_pipe_kernel<NT, NFF, NFB, M3, SHARE, LANES, SPLIT, SampleT, FM, FM ? 0 : 2>);
     if (lds > 64u * 1024u) {
         // more than the default 64 KB of dynamic LDS per workgroup: opt in, once per kernel and device
-        static bool opted_in[64] = {};
+        static bool opted_in[2][64] = {};
         int dev = 0;
         if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
-        if (!opted_in[dev]) {
+        if (!opted_in[cm][dev]) {
             const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) return e;
-            opted_in[dev] = true;
+            opted_in[cm][dev] = true;
         }
     }
     if (K.n_chunks > 1u && (K.in_channels % (uint32_t)LANES) != 0u) return hipErrorInvalidValue;   // a workgroup would straddle chunks

@@ -21,7 +21,7 @@ for r in range(reps):
     t0 = time.perf_counter()
     rx.process_tensor(xc, layout=sa.LAYOUT_CHANNEL_MAJOR)
     rx.sync()
-    print(f"rep {r}: kernel {rx.last_kernel_ms():.3f} ms  wall {(time.perf_counter() - t0) * 1e3:.1f} ms  chunks {rx.time_parallel_chunks()} "
+    print(f"rep {r}: kernel {rx.last_kernel_ms():.3f} ms (demodulation alone {rx.last_demod_kernel_ms():.3f})  wall {(time.perf_counter() - t0) * 1e3:.1f} ms  chunks {rx.time_parallel_chunks()} "
           f"per-channel {rx.time_parallel_per_channel()}  events {len(rx.poll_events_np())}", flush=True)
 
 if hasattr(rx._L, "same_debug_profile_pipe"):
