@@ -1327,11 +1327,13 @@ static hipError_t launch_pipe_one(const Params &P, const State &S, const Output 
 {
     constexpr bool DCW = pipe_dcw<NT, LANES, SPLIT>();
     constexpr size_t lds = pipe_lds_bytes<NT, DCW>();
-    // FASTMATH: one build per input form (see SampleStage); everything else decides at run time
+    // The two-per-CU builds (what time-parallel launches and batches beyond 16 384 channels run): one build per input
+    // form (see SampleStage); everything else decides at run time
+    constexpr bool FORMS = FM || (SHARE && SPLIT && LANES == 64);
     const bool cm = K.n_chunks > 1u && K.col_row0 != nullptr;
-    auto *kernel = !FM ? demod_pipe_kernel<NT, NFF, NFB, M3, SHARE, LANES, SPLIT, SampleT, FM, 2>
-                       : (cm ? demod_pipe_kernel<NT, NFF, NFB, M3, SHARE, LANES, SPLIT, SampleT, FM, FM ? 1 : 2>
-                             : demod_pipe_kernel<NT, NFF, NFB, M3, SHARE, LANES, SPLIT, SampleT, FM, FM ? 0 : 2>);
+    auto *kernel = !FORMS ? demod_pipe_kernel<NT, NFF, NFB, M3, SHARE, LANES, SPLIT, SampleT, FM, 2>
+                          : (cm ? demod_pipe_kernel<NT, NFF, NFB, M3, SHARE, LANES, SPLIT, SampleT, FM, FORMS ? 1 : 2>
+                                : demod_pipe_kernel<NT, NFF, NFB, M3, SHARE, LANES, SPLIT, SampleT, FM, FORMS ? 0 : 2>);
     if (lds > 64u * 1024u) {
         // more than the default 64 KB of dynamic LDS per workgroup: opt in, once per kernel and device
         static bool opted_in[2][64] = {};
