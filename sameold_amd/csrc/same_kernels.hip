@@ -484,10 +484,13 @@ __global__ __launch_bounds__(kSortThreads) void tp_sort_kernel(TpPlan g, const u
     const uint32_t tid = threadIdx.x, lane = tid & (kWave - 1u), wave = tid / kWave, n = g.n_chunks * g.channels;
     for (uint32_t i = tid; i < 3u * kSortBuckets; i += kSortThreads) hist[i] = 0u;
     __syncthreads();
+    // (the last chunks, group 0, keep their channel order: tp_align gives the lanes of such a workgroup one common first
+    // row, so what a last-chunk column computes depends on who its neighbours are -- they must not depend on the order
+    // in which atomics land)
     for (uint32_t v = tid; v < n; v += kSortThreads) {
         uint32_t grp, b;
         tp_sort_key(g, row0, nominal, v, &grp, &b);
-        atomicAdd(&hist[grp * kSortBuckets + b], 1u);
+        if (grp != 0u) atomicAdd(&hist[grp * kSortBuckets + b], 1u);
     }
     __syncthreads();
     // exclusive prefix sums per group, each offset by where its group starts in the grid: a thread owns four buckets
@@ -510,7 +513,8 @@ __global__ __launch_bounds__(kSortThreads) void tp_sort_kernel(TpPlan g, const u
     for (uint32_t v = tid; v < n; v += kSortThreads) {
         uint32_t grp, b;
         tp_sort_key(g, row0, nominal, v, &grp, &b);
-        perm[atomicAdd(&hist[grp * kSortBuckets + b], 1u)] = v;
+        if (grp == 0u) perm[v - (g.n_chunks - 1u) * g.channels] = v;
+        else perm[atomicAdd(&hist[grp * kSortBuckets + b], 1u)] = v;
     }
 }
 __global__ void tp_iota_kernel(uint32_t *perm, uint32_t n)
