@@ -26,11 +26,11 @@ def short(name):
 
 def classify(name, wgs, state, n1):
     """Which block of the bench line a demodulation launch belongs to, from the kernel's template arguments
-    <NT, NFF, NFB, MED3, SHARE, LANES, SPLIT, SampleT, FASTMATH> and its workgroup count (bench.py runs the blocks in a fixed
+    <NT, NFF, NFB, MED3, SHARE, LANES, SPLIT, SampleT, FASTMATH, input form> and its workgroup count (bench.py runs the blocks in a fixed
     order; `state` counts what has been seen, n1 = launches per configs[1] block)."""
     if "demod_relaxed_kernel" in name or "demod_duo_kernel" in name:
         return "scaled_long_time_parallel"
-    m = re.search(r"demod_pipe_kernel<(\d+), \d+, \d+, \w+, (\w+), (\d+), \w+, \w+, (\w+)>", name)
+    m = re.search(r"demod_pipe_kernel<(\d+), \d+, \d+, \w+, (\w+), (\d+), \w+, \w+, (\w+)(?:, \d+)?>", name)
     if not m:
         return None
     nt, share, lanes, fm = int(m.group(1)), m.group(2) in ("true", "1"), int(m.group(3)), m.group(4) in ("true", "1")
