@@ -201,7 +201,9 @@ int same_batch_device(const same_batch *rx);
  * cases `d_x` must stay valid, and unmodified, until the launch has finished: until
  * same_batch_sync returns, or until the second-next process call on this handle returns
  * (at most two launches are in flight; a process call collects the launch before the
- * previous one).  A caching allocator must not be allowed to reuse the buffer earlier. */
+ * previous one).  A caching allocator must not be allowed to reuse the buffer earlier.
+ * Successive launches of one batch are ordered among themselves whatever streams they are
+ * given: a launch continues the state the previous one leaves, and waits for it. */
 #define SAME_STREAM_OWN ((void *)(intptr_t)-1)
 int same_batch_process_device(same_batch *rx, const float *d_x, size_t n_samples,
                               uint32_t layout, void *hip_stream);

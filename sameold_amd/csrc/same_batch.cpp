@@ -856,6 +856,8 @@ int process_time_major(same_batch *rx, const SampleT *d_x, size_t n_samples, hip
         same_batch::Slot &prev = rx->slot[(rx->launch_seq & 1) ^ 1];
         int rc = harvest_slot(rx, sl);          // its buffers are about to be reused
         if (rc) return rc;
+        // a launch continues the state the previous one leaves: on another stream than that one, wait for it
+        if (prev.in_flight && rx->last_stream != stream) HIP_TRY(hipStreamWaitEvent(stream, prev.ev_done, 0));
         same::ChunkGeom geom{};
         same::PipeChunks pc{};
         const uint32_t n_chunks = plan_chunks(rx, n, geom, pc);
@@ -1010,6 +1012,8 @@ int process_channel_major_native(same_batch *rx, const float *d_x, size_t n, hip
     same_batch::Slot &prev = rx->slot[(rx->launch_seq & 1) ^ 1];
     int rc = harvest_slot(rx, sl);
     if (rc) return rc;
+    // a launch continues the state the previous one leaves: on another stream than that one, wait for it
+    if (prev.in_flight && rx->last_stream != stream) HIP_TRY(hipStreamWaitEvent(stream, prev.ev_done, 0));
     rc = ensure_wide_state(rx, columns);
     if (rc) return rc;
     same::Output O{};

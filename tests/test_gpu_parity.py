@@ -841,6 +841,25 @@ def test_process_tensor_is_ordered_after_the_producer_stream(sa, ob):
         assert got.get(c, []) == oracle_events(ob, cfg, want[:, c], link_only=True), f"channel {c}"
 
 
+def test_successive_launches_are_ordered_whatever_their_streams(sa, ob):
+    """A launch continues the state the previous one leaves.  Calls of one stream handed alternately to the library's own
+    stream and to two streams of the caller, back to back without a synchronise: the library orders them itself (an event
+    wait on the previous launch when the stream changes); every channel's events must equal the oracle's over the whole
+    stream."""
+    import torch
+    n_ch, part = 2048, 22050
+    x = sa.synth_afsk(n_ch, 6 * part, 22050, seed=4242)
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Stream(), torch.cuda.Stream()
+    rx = sa.SameReceiverBuilder(22050).build_batch(n_ch, link_only=True)
+    for i, st in enumerate([None, a.cuda_stream, b.cuda_stream, None, b.cuda_stream, a.cuda_stream]):
+        rx.process_tensor(x[i * part:(i + 1) * part].contiguous(), stream=st)
+    rx.sync()
+    ev = rx.poll_events_np()
+    ev = ev[np.lexsort((np.arange(len(ev)), ev["channel"]))]
+    assert assert_every_channel_matches_oracle(ob, ob.default_config(22050), x, ev) > 4 * n_ch
+
+
 def test_audio_after_an_early_flush_is_refused_until_reset(sa):
     """flush() returns at its first message while the device has run over all 4 s of zeros; real audio
     presented next must not be silently skipped (round-1 advisor finding)."""

@@ -462,6 +462,64 @@ def test_per_channel_boundaries_streaming_calls_with_bursts_across_the_call_boun
     assert_contract(sa, got, ref, rate, n_ch, lambda c: sa.synth_payload(9090, c), what="streaming channel-major", t_end=4 * part)
 
 
+def test_planning_on_the_plan_stream_and_on_a_callers_stream(sa, monkeypatch):
+    """Channel-major calls of one stream alternately on the library's own stream (scout, planner and sort then run on the
+    plan stream, beside the previous launch) and on a stream of the caller (everything in that stream's order): both
+    streams' planning shares the energy map, the launches share the wide state.  Two calls stay in flight throughout; the
+    whole stream must meet the contract, and SAME_TP_PLAN_STREAM=0 must deliver the very same events."""
+    import torch
+    monkeypatch.setenv("SAME_PIPE_LANES", "64")
+    rate, n_ch = 22050, 4096
+    part = 22050 * 3
+    part -= part % 420
+    x = sa.synth_afsk(n_ch, 4 * part, rate, seed=5151)
+    ref = strict_events(sa, x, rate)
+    parts = [x[i * part:(i + 1) * part].t().contiguous() for i in range(4)]
+    torch.cuda.synchronize()
+    mine = torch.cuda.Stream()
+
+    def run():
+        rx = sa.SameReceiverBuilder(rate).build_batch(n_ch, time_parallel=True)
+        for i, p in enumerate(parts):
+            if i % 2 == 0:
+                rx.process_tensor(p, layout=sa.LAYOUT_CHANNEL_MAJOR)                                  # own stream + plan stream
+            else:
+                rx.process_tensor(p, layout=sa.LAYOUT_CHANNEL_MAJOR, stream=mine.cuda_stream)       # the caller's stream
+            assert rx.time_parallel_per_channel()
+        rx.sync()
+        got = rx.poll_events_np()
+        return got[np.lexsort((np.arange(len(got)), got["channel"]))]
+
+    got = run()
+    assert_contract(sa, got, ref, rate, n_ch, lambda c: sa.synth_payload(5151, c), what="alternating streams", t_end=4 * part)
+    monkeypatch.setenv("SAME_TP_PLAN_STREAM", "0")
+    same = run()
+    assert len(same) == len(got) and np.array_equal(same["kind"], got["kind"]) and np.array_equal(same["sample_counter"], got["sample_counter"])
+    assert np.array_equal(same["bytes"], got["bytes"])
+
+
+def test_sorted_launches_are_deterministic_and_the_timers_nest(sa, monkeypatch):
+    """Pieces sorted by length into workgroups (more state columns than the machine holds at once): which pieces share a
+    workgroup depends on the order atomics land in, what every column computes must not -- two runs deliver identical
+    events.  And the demodulation kernel's own timer lies inside the launch's."""
+    rate, n_ch = 22050, 4096
+    n = 22050 * 6
+    n -= n % 420
+    xc = sa.synth_afsk(n_ch, n, rate, seed=777).t().contiguous()
+    runs = []
+    for _ in range(2):
+        rx = sa.SameReceiverBuilder(rate).build_batch(n_ch, time_parallel=True)
+        rx.set_kernel_timing(True)
+        rx.process_tensor(xc, layout=sa.LAYOUT_CHANNEL_MAJOR)
+        rx.sync()
+        assert rx.time_parallel_per_channel() and n_ch * rx.time_parallel_chunks() > 32768
+        assert 0.0 < rx.last_demod_kernel_ms() <= rx.last_kernel_ms()
+        runs.append(rx.poll_events_np())
+    a, b = runs
+    assert len(a) == len(b) and np.array_equal(a["kind"], b["kind"]) and np.array_equal(a["channel"], b["channel"])
+    assert np.array_equal(a["sample_counter"], b["sample_counter"]) and np.array_equal(a["bytes"], b["bytes"])
+
+
 def test_per_channel_boundaries_fall_back_when_there_is_no_quiet_instant(sa, monkeypatch):
     """Channels that are never quiet (noise as loud as the bursts) leave the planner no allowed instant: it cuts at the
     length limit and the chunks run on until idle, as with uniform boundaries.  Whatever the two modes decode there
