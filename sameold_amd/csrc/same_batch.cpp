@@ -433,7 +433,12 @@ int harvest_slot(same_batch *rx, same_batch::Slot &sl)
     HIP_TRY(grow(&sl.h_bursts, &sl.h_bursts_bytes, bu_bytes));
     const same::DevEvent *evs = static_cast<const same::DevEvent *>(sl.h_events);
     const uint8_t *bursts = static_cast<const uint8_t *>(sl.h_bursts);
-    if (n_events) HIP_TRY(hipMemcpyAsync(sl.h_events, sl.d_events, ev_bytes, hipMemcpyDeviceToHost, rx->copy_stream));
+    // the event log first: it is what the sort below needs, and the sort runs while the burst pool (the larger copy) and
+    // the chunk geometry are still on their way
+    if (n_events) {
+        HIP_TRY(hipMemcpyAsync(sl.h_events, sl.d_events, ev_bytes, hipMemcpyDeviceToHost, rx->copy_stream));
+        HIP_TRY(hipStreamSynchronize(rx->copy_stream));
+    }
     if (n_bursts) HIP_TRY(hipMemcpyAsync(sl.h_bursts, sl.d_bursts, bu_bytes, hipMemcpyDeviceToHost, rx->copy_stream));
     const uint32_t n_ch = rx->P.n_channels;
     const uint32_t n_bins = sl.chunked ? sl.geom.n_chunks * n_ch : n_ch;     // state columns of the launch
@@ -442,7 +447,6 @@ int harvest_slot(same_batch *rx, same_batch::Slot &sl)
         if (sl.per_channel)
             HIP_TRY(hipMemcpyAsync(sl.h_geom, sl.d_geom, (size_t)2 * n_bins * sizeof(uint32_t), hipMemcpyDeviceToHost, rx->copy_stream));
     }
-    if (n_events || n_bursts || sl.chunked) HIP_TRY(hipStreamSynchronize(rx->copy_stream));
     auto t_copied = std::chrono::steady_clock::now();
     // Per column the device emits in time order (a lane takes its log slots one after the
     // other); across lanes the atomic cursor interleaves.  A stable counting sort by column
@@ -459,6 +463,7 @@ int harvest_slot(same_batch *rx, same_batch::Slot &sl)
         for (uint32_t i = 0; i < n_events; ++i)
             if (evs[i].kind != same::kDevEventNone) order[fill[std::min(evs[i].channel, n_bins - 1u)]++] = i;
     }
+    if (n_bursts || sl.chunked) HIP_TRY(hipStreamSynchronize(rx->copy_stream));      // bursts, hand-overs, geometry
     if (dbg && sl.chunked && sl.per_channel) {
         // how the per-channel boundaries came out: chunk lengths (own range + warm-up) and run-ons, in samples
         const same::ChunkGeom &g = sl.geom;
