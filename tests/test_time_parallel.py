@@ -548,6 +548,40 @@ def test_per_channel_boundaries_fall_back_when_there_is_no_quiet_instant(sa, mon
     assert_contract(sa, only_clean(got), only_clean(ref), rate, len(clean), lambda i: sa.synth_payload(77, int(clean[i])))
 
 
+def test_streaming_channel_major_calls_with_noise_and_forced_cuts(sa, monkeypatch, arith):
+    """Four channel-major calls of one stream, bursts straddling the call boundaries, with mild noise on every channel
+    (the contract is statistical there) and every eighth channel drowned in noise (no quiet instant: forced cuts, chunks
+    that run on, calls that end without a hand-over -- the state carried on is then that of the chunk the chain stops in).
+    The channels that can be decoded must meet the contract over the whole stream; the drowned ones must not disturb
+    them or stall the calls."""
+    import torch
+    monkeypatch.setenv("SAME_PIPE_LANES", "64")
+    rate, n_ch = 22050, 256
+    part = 22050 * 5
+    part -= part % 420
+    x = sa.synth_afsk(n_ch, 4 * part, rate, seed=8181, noise_sigma=0.03)
+    gen = torch.Generator(device="cuda"); gen.manual_seed(9)
+    x[:, ::8] += torch.randn((4 * part, n_ch // 8), device="cuda", generator=gen) * 3000.0
+    ref = strict_events(sa, x, rate)
+    rx = sa.SameReceiverBuilder(rate).build_batch(n_ch, time_parallel=True)
+    rx.time_parallel_config(max_chunks=4)
+    for i in range(4):
+        rx.process_tensor(x[i * part:(i + 1) * part].t().contiguous(), layout=sa.LAYOUT_CHANNEL_MAJOR)
+        assert rx.time_parallel_per_channel()
+    rx.sync()
+    got = rx.poll_events_np()
+    got = got[np.lexsort((np.arange(len(got)), got["channel"]))]
+    clean = np.array([c for c in range(n_ch) if c % 8], dtype=np.uint32)
+    remap = np.full(n_ch, -1, dtype=np.int64); remap[clean] = np.arange(len(clean))
+
+    def only_clean(ev):
+        e = ev[np.isin(ev["channel"], clean)].copy()
+        e["channel"] = remap[e["channel"]].astype(np.uint32)
+        return e
+    assert_contract(sa, only_clean(got), only_clean(ref), rate, len(clean), lambda i: sa.synth_payload(8181, int(clean[i])), exact_bursts=False,
+                    what="noisy streaming channel-major", t_end=4 * part, garbled_per_mille=(2 if arith == "fastmath" else 1))
+
+
 def test_bench_configuration_of_the_headline_mode(sa, ob, arith):
     """BASELINE.json configs[1] exactly as bench.py runs its headline mode: 4 096 channels x 220 500 samples per call, seed
     20260000, channel-major input, default knobs and chunk count (10) -- and two more calls on carried state, which is what the
