@@ -778,7 +778,7 @@ bool relaxed_kernel_supported(const Params &P)
     return max_block_len(P) >= (uint32_t)kBlockMirror;
 }
 // Which form runs a launch over P.n_channels state columns: 1 duo (two wavefronts per 64 columns) while that leaves the
-// launch at no more than three wavefronts per SIMD, 0 solo beyond -- or what SAME_RELAXED_KERNEL asks for.  Whole groups
+// launch at no more than two wavefronts per SIMD (65 536 columns), 0 solo beyond -- or what SAME_RELAXED_KERNEL asks for.  Whole groups
 // of 64 columns for duo.  (A third form -- sample phase | filters + timing loop | symbol path on three wavefronts, 18-sample
 // sub-blocks, the symbol stage on every step or on every other -- was built and measured in round 3: 3.9-4.1 ms where the
 // pipeline's FASTMATH build takes 3.8; not kept.)
@@ -787,7 +787,7 @@ uint32_t relaxed_kernel_kind(const Params &P)
     const bool whole = (P.n_channels % kWave) == 0u;
     if (P.knob_relaxed_kernel == 1 || !whole) return 0u;
     if (P.knob_relaxed_kernel == 2) return 1u;
-    return P.n_channels <= 98304u ? 1u : 0u;
+    return P.n_channels <= 65536u ? 1u : 0u;      // (measured, 2 s launches: 65 536 columns duo 6.5 against solo 7.0 ms; 81 920: 11.8 against 9.0; 98 304: 12.1 against 9.8)
 }
 uint32_t relaxed_block_len(const Params &P) { (void)P; return (uint32_t)RelaxLayout<42>::B; }
 
