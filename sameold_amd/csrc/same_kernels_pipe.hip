@@ -1212,7 +1212,7 @@ __global__ __launch_bounds__((pipe_dcw<NT, LANES, SPLIT>() ? 5 : 4) * kWave, SHA
                 (which ? spacebox : markbox)[fch] = __float_as_uint(mag);
             } else if constexpr (HELPER_BOTH) {
                 float hm, hs;
-                if constexpr (FM) demod_pair_relaxed<NT, RING, true>(lds_addr(lds), lds_addr(wcol), wpos + pos, &hm, &hs);
+                if constexpr (FM) demod_pair_relaxed_42<RING>(lds_addr(lds), lds_addr(wcol), wpos + pos, &hm, &hs);
                 else demod_pair<NT, RING>(tlds, wring, lane, wpos + pos, &hm, &hs);
                 markbox[lane] = __float_as_uint(hm); spacebox[lane] = __float_as_uint(hs);
             } else {

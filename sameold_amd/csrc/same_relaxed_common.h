@@ -171,6 +171,82 @@ __device__ __forceinline__ void demod_pair_relaxed(uint32_t taps_lds, uint32_t w
     *hs_out = relax_magnitude(as0 + as1);
 }
 
+// The same for 42 taps with the loads of the three chunks software-pipelined across each other: a chunk is read in two
+// parts (A: its 8 lowest window slots = taps base+13 .. base+6, 12 loads; B: the 6 above = taps base+5 .. base, 9 loads),
+// three register sets take the parts in turn, and while one part's products issue the next two parts' loads are in
+// flight.  LDS returns in order, so "at most N outstanding" names the part that has landed.  For the pipeline's helper
+// wavefront, whose filters are the first link of the chain a step waits for.
+struct RelaxPart { float2v w0, w1, w2, w3; float4v t0, t1, t2, t3, t4, t5, t6, t7; };
+#define RELAX_LOAD_A(P_, wa_, ta_)                                                                         \
+    asm volatile("ds_read2st64_b32 %[w0], %[wa] offset0:0 offset1:1\n\t"                            \
+                 "ds_read2st64_b32 %[w1], %[wa] offset0:2 offset1:3\n\t"                            \
+                 "ds_read2st64_b32 %[w2], %[wa] offset0:4 offset1:5\n\t"                            \
+                 "ds_read2st64_b32 %[w3], %[wa] offset0:6 offset1:7\n\t"                            \
+                 "ds_read_b128 %[t7], %[ta] offset:208\n\t"                                                   \
+                 "ds_read_b128 %[t6], %[ta] offset:192\n\t"                                                   \
+                 "ds_read_b128 %[t5], %[ta] offset:176\n\t"                                                   \
+                 "ds_read_b128 %[t4], %[ta] offset:160\n\t"                                                   \
+                 "ds_read_b128 %[t3], %[ta] offset:144\n\t"                                                   \
+                 "ds_read_b128 %[t2], %[ta] offset:128\n\t"                                                   \
+                 "ds_read_b128 %[t1], %[ta] offset:112\n\t"                                                   \
+                 "ds_read_b128 %[t0], %[ta] offset:96"                                                        \
+                 : [w0] "=&v"(P_.w0), [w1] "=&v"(P_.w1), [w2] "=&v"(P_.w2), [w3] "=&v"(P_.w3), [t0] "=&v"(P_.t0), [t1] "=&v"(P_.t1), \
+                   [t2] "=&v"(P_.t2), [t3] "=&v"(P_.t3), [t4] "=&v"(P_.t4), [t5] "=&v"(P_.t5), [t6] "=&v"(P_.t6), [t7] "=&v"(P_.t7)   \
+                 : [wa] "v"(wa_), [ta] "v"(ta_) : "memory")
+#define RELAX_LOAD_B(P_, wa_, ta_)                                                                         \
+    asm volatile("ds_read2st64_b32 %[w0], %[wa] offset0:8 offset1:9\n\t"                            \
+                 "ds_read2st64_b32 %[w1], %[wa] offset0:10 offset1:11\n\t"                          \
+                 "ds_read2st64_b32 %[w2], %[wa] offset0:12 offset1:13\n\t"                          \
+                 "ds_read_b128 %[t5], %[ta] offset:80\n\t"                                                    \
+                 "ds_read_b128 %[t4], %[ta] offset:64\n\t"                                                    \
+                 "ds_read_b128 %[t3], %[ta] offset:48\n\t"                                                    \
+                 "ds_read_b128 %[t2], %[ta] offset:32\n\t"                                                    \
+                 "ds_read_b128 %[t1], %[ta] offset:16\n\t"                                                    \
+                 "ds_read_b128 %[t0], %[ta] offset:0"                                                         \
+                 : [w0] "=&v"(P_.w0), [w1] "=&v"(P_.w1), [w2] "=&v"(P_.w2), [t0] "=&v"(P_.t0), [t1] "=&v"(P_.t1),        \
+                   [t2] "=&v"(P_.t2), [t3] "=&v"(P_.t3), [t4] "=&v"(P_.t4), [t5] "=&v"(P_.t5)                              \
+                 : [wa] "v"(wa_), [ta] "v"(ta_) : "memory")
+// (the values travel through the wait statement so that nothing that reads them can be moved above it)
+#define RELAX_WAIT_A(P_, n_) asm volatile("s_waitcnt lgkmcnt(" #n_ ")" : "+v"(P_.w0), "+v"(P_.w1), "+v"(P_.w2), "+v"(P_.w3), "+v"(P_.t0), "+v"(P_.t1), \
+                                          "+v"(P_.t2), "+v"(P_.t3), "+v"(P_.t4), "+v"(P_.t5), "+v"(P_.t6), "+v"(P_.t7))
+#define RELAX_WAIT_B(P_, n_) asm volatile("s_waitcnt lgkmcnt(" #n_ ")" : "+v"(P_.w0), "+v"(P_.w1), "+v"(P_.w2), "+v"(P_.t0), "+v"(P_.t1), \
+                                          "+v"(P_.t2), "+v"(P_.t3), "+v"(P_.t4), "+v"(P_.t5))
+#define RELAX_TAP2(fma, win_, tap_) do { const float2v hm_ = {tap_.x, tap_.y}, hs_ = {tap_.z, tap_.w}; fma(am, win_, hm_); fma(as, win_, hs_); } while (0)
+// part A: window pairs w0..w3 = {base+13, base+12} .. {base+7, base+6} against taps t7 (base+13) .. t0 (base+6)
+#define RELAX_FMA_A(P_) do { { float2v &am = am0, &as = as0; RELAX_TAP2(pk_fma_lo, P_.w0, P_.t7); } { float2v &am = am1, &as = as1; RELAX_TAP2(pk_fma_hi, P_.w0, P_.t6); } \
+                             { float2v &am = am0, &as = as0; RELAX_TAP2(pk_fma_lo, P_.w1, P_.t5); } { float2v &am = am1, &as = as1; RELAX_TAP2(pk_fma_hi, P_.w1, P_.t4); } \
+                             { float2v &am = am0, &as = as0; RELAX_TAP2(pk_fma_lo, P_.w2, P_.t3); } { float2v &am = am1, &as = as1; RELAX_TAP2(pk_fma_hi, P_.w2, P_.t2); } \
+                             { float2v &am = am0, &as = as0; RELAX_TAP2(pk_fma_lo, P_.w3, P_.t1); } { float2v &am = am1, &as = as1; RELAX_TAP2(pk_fma_hi, P_.w3, P_.t0); } } while (0)
+// part B: window pairs w0..w2 = {base+5, base+4} .. {base+1, base} against taps t5 (base+5) .. t0 (base)
+#define RELAX_FMA_B(P_) do { { float2v &am = am0, &as = as0; RELAX_TAP2(pk_fma_lo, P_.w0, P_.t5); } { float2v &am = am1, &as = as1; RELAX_TAP2(pk_fma_hi, P_.w0, P_.t4); } \
+                             { float2v &am = am0, &as = as0; RELAX_TAP2(pk_fma_lo, P_.w1, P_.t3); } { float2v &am = am1, &as = as1; RELAX_TAP2(pk_fma_hi, P_.w1, P_.t2); } \
+                             { float2v &am = am0, &as = as0; RELAX_TAP2(pk_fma_lo, P_.w2, P_.t1); } { float2v &am = am1, &as = as1; RELAX_TAP2(pk_fma_hi, P_.w2, P_.t0); } } while (0)
+template <int RING>
+__device__ __forceinline__ void demod_pair_relaxed_42(uint32_t taps_lds, uint32_t wlane_lds, uint32_t newest, float *hm_out, float *hs_out)
+{
+    static_assert(kRelaxChunk == 14, "three chunks of 14 taps, written out");
+    float2v am0 = {0.0f, 0.0f}, am1 = {0.0f, 0.0f}, as0 = {0.0f, 0.0f}, as1 = {0.0f, 0.0f};
+    // chunk c (taps 14 c .. 14 c + 13): its lowest window slot is newest + RING - 13 - 14 c, its first tap at 224 c bytes
+    const uint32_t wa0 = wlane_lds + (newest + (uint32_t)RING - 13u) * (kWave * 4u);
+    const uint32_t wa1 = wa0 - 14u * (kWave * 4u), wa2 = wa1 - 14u * (kWave * 4u);
+    const uint32_t ta0 = taps_lds, ta1 = taps_lds + 224u, ta2 = taps_lds + 448u;
+    RelaxPart X, Y, Z;
+    RELAX_LOAD_A(X, wa0, ta0);             // 12 loads
+    RELAX_LOAD_B(Y, wa0, ta0);             //  9
+    RELAX_WAIT_A(X, 9);  RELAX_FMA_A(X);
+    RELAX_LOAD_A(Z, wa1, ta1);             // in flight: B0 9, A1 12
+    RELAX_WAIT_B(Y, 12); RELAX_FMA_B(Y);
+    RELAX_LOAD_B(X, wa1, ta1);             // A1 12, B1 9
+    RELAX_WAIT_A(Z, 9);  RELAX_FMA_A(Z);
+    RELAX_LOAD_A(Y, wa2, ta2);             // B1 9, A2 12
+    RELAX_WAIT_B(X, 12); RELAX_FMA_B(X);
+    RELAX_LOAD_B(Z, wa2, ta2);             // A2 12, B2 9
+    RELAX_WAIT_A(Y, 9);  RELAX_FMA_A(Y);
+    RELAX_WAIT_B(Z, 0);  RELAX_FMA_B(Z);
+    *hm_out = relax_magnitude(am0 + am1);
+    *hs_out = relax_magnitude(as0 + as1);
+}
+
 // One AGC step, rx/agc.rs:72-77, as gain * (1 - bw |y|) + bw: the same update algebraically while gain >= 0 (the
 // launchers check the floor), one fused multiply-add and the clamp on the gain's dependency chain.  bw_eff = 0 for a
 // locked AGC: gain * 1 + 0.
