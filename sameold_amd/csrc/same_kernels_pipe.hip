@@ -963,16 +963,19 @@ __global__ __launch_bounds__((pipe_dcw<NT, LANES, SPLIT>() ? 5 : 4) * kWave, SHA
                 float sa_low;
                 const float rem = L.until_next_ted - (float)cstar;          // receiver.rs:352
                 if constexpr (FM) {
-                    // FASTMATH: the helper's relaxed filters take a fraction of the look-ahead's time (ted_ahead evaluates
-                    // the loop for both signs to hide the strict filters' latency), so wait for them and run the loop once
+                    // FASTMATH: while the helper wavefront is still filtering, the relaxed timing loop for both signs of the
+                    // soft sample it will deliver (ted_ahead_relaxed: bit-identical to running ted_timing_relaxed afterwards);
+                    // what follows the filters on the chain to the next instant is then ted_commit's selection
+                    const TedAhead A = ted_ahead_relaxed(P, L, inv_spt, rem);
                     SPIN_BEGIN();
                     while ((int32_t)(seqbox[0] - seq) < 0) {}
                     SPIN_END();
                     const float hm = __uint_as_float(markbox[lane]), hs = __uint_as_float(spacebox[lane]);
                     S2_LAP(1);
                     sa_low = __builtin_amdgcn_fmed3f(hm - hs, -1.0f, 1.0f);
-                    if (ted_timing_relaxed(P, L, inv_spt, sa_low, rem, &zero, &sym, &terr)) { hdr = 1u | ((uint32_t)fk << 8); next = L.until_next_ted; }
-                    cstar = next_fire_count(L.until_next_ted, 0u);
+                    int cs;
+                    if (ted_commit(L, A, sa_low, &zero, &sym, &terr, &cs)) { hdr = 1u | ((uint32_t)fk << 8); next = L.until_next_ted; }
+                    cstar = cs;
                 } else if constexpr (SPLIT) {
                     float hm = 0.0f;
                     if constexpr (!HELPER_BOTH) hm = demod_half<NT, RING, 0>(tlds, wring, lane, wpos + (uint32_t)fk);

@@ -283,6 +283,39 @@ __device__ __forceinline__ bool ted_timing_relaxed(const Params &P, Lane &L, flo
     return have;
 }
 
+// ted_timing_relaxed evaluated AHEAD of the sample, for both of its signs (the loop reads the new sample only through
+// rs_signum): the same operations on the same operands, so ted_commit (same_dev_common.h), once the sample is there,
+// selects a result that is bit-identical to ted_timing_relaxed's.  The pipeline's stage 2 computes this while it
+// waits for the helper's filters; what is left on the chain filters -> next instant is the selection.
+__device__ __forceinline__ TedAhead ted_ahead_relaxed(const Params &P, const Lane &L, float inv_spt, float rem)
+{
+    TedAhead A;
+    const float h0 = L.h1, h1 = L.h2;
+    A.zero = h1;
+    A.flags = L.flags ^ F_TED_PHASE;
+    A.have = (A.flags & F_TED_PHASE) != 0;
+    const float offset = __builtin_amdgcn_fmed3f(rem, -0.5f, 0.5f);
+    const bool bw_locked = (L.flags & F_BW_LOCKED) != 0;
+    const float alpha = bw_locked ? P.alpha_locked : P.alpha_unlocked;
+    const float beta = bw_locked ? P.beta_locked : P.beta_unlocked;
+    const float inst_plain = L.period_inst + offset;
+    auto half = [&](float sg2, float *terr_out, float *avg_out, float *inst_out, int *cstar_out) __attribute__((always_inline)) {
+        const float dsg = rs_signum(h0) - sg2;
+        const float terr = h1 * dsg;
+        const float e = __builtin_amdgcn_fmed3f(__builtin_fmaf(-offset, inv_spt, terr), -1.0f, 1.0f);
+        const float avg1 = __builtin_amdgcn_fmed3f(__builtin_fmaf(beta, e, L.period_avg), P.period_min, P.period_max);
+        float inst1 = __builtin_fmaf(alpha, e, avg1) + offset;
+        inst1 = (inst1 < 0.0f) ? avg1 : inst1;
+        *terr_out = terr;
+        *avg_out = A.have ? avg1 : L.period_avg;
+        *inst_out = A.have ? inst1 : inst_plain;
+        *cstar_out = next_fire_count(*inst_out, 0u);
+    };
+    half(1.0f, &A.terr0, &A.avg0, &A.inst0, &A.cstar0);
+    half(-1.0f, &A.terr1, &A.avg1, &A.inst1, &A.cstar1);
+    return A;
+}
+
 // Equalizer::estimate_symbol + evolve (rx/equalize.rs:249-332, 354-386), the relaxed form of eq_symbol_core:
 // fused multiply-adds, two partial sums per filter, v_rcp_f32 for the NLMS gains.
 template <int NFF, int NFB>
