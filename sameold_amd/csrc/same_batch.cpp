@@ -176,6 +176,10 @@ struct same_batch {
     // harvest launch k (copy back, order, transport layer) while launch k+1 runs.
     struct Slot {
         same::DevEvent *d_events = nullptr; uint32_t event_cap = 0;
+        // the log's indices ordered by state column, made on the device behind the launch (launch_event_sort)
+        uint32_t *d_sort = nullptr; size_t sort_words = 0;          // cnt [bins] | first [bins + 1] | order [event_cap]
+        uint32_t *h_sort = nullptr; size_t h_sort_words = 0;        // pinned: first [bins + 1] | order [event_cap]
+        uint32_t sort_bins = 0;
         uint8_t *d_bursts = nullptr; uint32_t burst_cap = 0;
         uint32_t *d_counters = nullptr;  // [0] n_events [1] n_bursts [2] overflow
         uint32_t *h_counters = nullptr;  // pinned, host-mapped
@@ -380,6 +384,22 @@ int ensure_output(same_batch *rx, same_batch::Slot &sl, size_t n_samples, same::
         HIP_TRY(hipMalloc((void **)&sl.d_bursts, bcap * same::kBurstCap));
         sl.burst_cap = (uint32_t)bcap;
     }
+    {
+        const size_t need = 2 * n_ch + 1 + sl.event_cap, need_h = n_ch + 1 + sl.event_cap;
+        if (need > sl.sort_words) {
+            if (sl.d_sort) HIP_TRY(hipFree(sl.d_sort));
+            sl.d_sort = nullptr; sl.sort_words = 0;
+            HIP_TRY(hipMalloc((void **)&sl.d_sort, need * sizeof(uint32_t)));
+            sl.sort_words = need;
+        }
+        if (need_h > sl.h_sort_words) {
+            if (sl.h_sort) HIP_TRY(hipHostFree(sl.h_sort));
+            sl.h_sort = nullptr; sl.h_sort_words = 0;
+            HIP_TRY(hipHostMalloc((void **)&sl.h_sort, need_h * sizeof(uint32_t), hipHostMallocDefault));
+            sl.h_sort_words = need_h;
+        }
+        sl.sort_bins = (uint32_t)n_ch;
+    }
     O.events = sl.d_events; O.event_cap = sl.event_cap;
     O.bursts = sl.d_bursts; O.burst_cap = sl.burst_cap;
     O.n_events = sl.d_counters; O.n_bursts = sl.d_counters + 1; O.overflow = sl.d_counters + 2;
@@ -435,34 +455,29 @@ int harvest_slot(same_batch *rx, same_batch::Slot &sl)
     const uint8_t *bursts = static_cast<const uint8_t *>(sl.h_bursts);
     // the event log first: it is what the sort below needs, and the sort runs while the burst pool (the larger copy) and
     // the chunk geometry are still on their way
-    if (n_events) {
-        HIP_TRY(hipMemcpyAsync(sl.h_events, sl.d_events, ev_bytes, hipMemcpyDeviceToHost, rx->copy_stream));
-        HIP_TRY(hipStreamSynchronize(rx->copy_stream));
-    }
-    if (n_bursts) HIP_TRY(hipMemcpyAsync(sl.h_bursts, sl.d_bursts, bu_bytes, hipMemcpyDeviceToHost, rx->copy_stream));
     const uint32_t n_ch = rx->P.n_channels;
     const uint32_t n_bins = sl.chunked ? sl.geom.n_chunks * n_ch : n_ch;     // state columns of the launch
+    if (n_bins != sl.sort_bins) return fail(SAME_EINVAL, "internal: event sort made for %u columns, launch has %u", sl.sort_bins, n_bins);
+    // (the column offsets and the sorted indices come with the log: the device made them behind the launch)
+    HIP_TRY(hipMemcpyAsync(sl.h_sort, sl.d_sort + n_bins, ((size_t)n_bins + 1 + n_events) * sizeof(uint32_t), hipMemcpyDeviceToHost, rx->copy_stream));
+    if (n_events) HIP_TRY(hipMemcpyAsync(sl.h_events, sl.d_events, ev_bytes, hipMemcpyDeviceToHost, rx->copy_stream));
+    HIP_TRY(hipStreamSynchronize(rx->copy_stream));
+    if (n_bursts) HIP_TRY(hipMemcpyAsync(sl.h_bursts, sl.d_bursts, bu_bytes, hipMemcpyDeviceToHost, rx->copy_stream));
     if (sl.chunked) {
         HIP_TRY(hipMemcpyAsync(sl.h_handover, sl.d_handover, (size_t)n_bins * sizeof(uint64_t), hipMemcpyDeviceToHost, rx->copy_stream));
         if (sl.per_channel)
             HIP_TRY(hipMemcpyAsync(sl.h_geom, sl.d_geom, (size_t)2 * n_bins * sizeof(uint32_t), hipMemcpyDeviceToHost, rx->copy_stream));
     }
     auto t_copied = std::chrono::steady_clock::now();
-    // Per column the device emits in time order (a lane takes its log slots one after the
-    // other); across lanes the atomic cursor interleaves.  A stable counting sort by column
-    // therefore yields (column, time) order in O(n).
-    std::vector<uint32_t> first(n_bins + 1u, 0u);
-    // (slots a wavefront reserved but did not use carry kDevEventNone and are dropped here)
-    for (uint32_t i = 0; i < n_events; ++i)
-        if (evs[i].kind != same::kDevEventNone) first[std::min(evs[i].channel, n_bins - 1u) + 1u]++;
-    for (uint32_t c = 0; c < n_bins; ++c) first[c + 1u] += first[c];
+    // Per column the device emits in time order (a lane takes its log slots one after the other); across lanes the
+    // atomic cursor interleaves.  The device has counted the events per column and scattered the log's indices into
+    // column ranges (launch_event_sort); inside a range they stand in the order the scatter's atomics landed, and the
+    // replay threads sort each range (a handful of indices) back into log order = time order before they walk it.
+    // (slots a wavefront reserved but did not use carry kDevEventNone and were skipped there)
+    std::vector<uint32_t> first(sl.h_sort, sl.h_sort + n_bins + 1u);
+    uint32_t *order = sl.h_sort + n_bins + 1u;
     const uint32_t n_real = first[n_bins];
-    std::vector<uint32_t> order(n_real);
-    {
-        std::vector<uint32_t> fill(first.begin(), first.end() - 1);
-        for (uint32_t i = 0; i < n_events; ++i)
-            if (evs[i].kind != same::kDevEventNone) order[fill[std::min(evs[i].channel, n_bins - 1u)]++] = i;
-    }
+    if (n_real > n_events) return fail(SAME_EHIP, "internal: event sort counted %u of %u events", n_real, n_events);
     if (n_bursts || sl.chunked) HIP_TRY(hipStreamSynchronize(rx->copy_stream));      // bursts, hand-overs, geometry
     if (dbg && sl.chunked && sl.per_channel) {
         // how the per-channel boundaries came out: chunk lengths (own range + warm-up) and run-ons, in samples
@@ -623,6 +638,9 @@ int harvest_slot(same_batch *rx, same_batch::Slot &sl)
         same_rx_event ev;
         std::memset(&ev, 0, sizeof(ev));
         for (uint32_t c = c0; c < c1; ++c) {
+            // this channel's column ranges back into log order (see above)
+            for (uint32_t col = c; col < n_bins; col += n_ch)
+                if (first[col + 1u] - first[col] > 1u) std::sort(order + first[col], order + first[col + 1u]);
             if (sl.chunked) stitch(part, ev, c);
             else
                 for (uint32_t k = first[c]; k < first[c + 1u]; ++k)
@@ -970,6 +988,8 @@ int process_time_major(same_batch *rx, const SampleT *d_x, size_t n_samples, hip
         }
         }
         if (rx->timing) HIP_TRY(hipEventRecord(sl.ev_stop, stream));
+        HIP_TRY(same::launch_event_sort(sl.d_events, sl.d_counters, sl.event_cap, sl.sort_bins, sl.d_sort, sl.d_sort + sl.sort_bins,
+                                        sl.d_sort + 2 * (size_t)sl.sort_bins + 1, stream));
         HIP_TRY(same::launch_counters(sl.d_counters, sl.h_counters_dev, 1, stream));
         HIP_TRY(hipEventRecord(sl.ev_done, stream));
         sl.in_flight = true;
@@ -1103,6 +1123,8 @@ int process_channel_major_native(same_batch *rx, const float *d_x, size_t n, hip
     sl.geom = geom;
     sl.end_blocks = rx->counter + n;
     if (rx->timing) HIP_TRY(hipEventRecord(sl.ev_stop, stream));
+    HIP_TRY(same::launch_event_sort(sl.d_events, sl.d_counters, sl.event_cap, sl.sort_bins, sl.d_sort, sl.d_sort + sl.sort_bins,
+                                    sl.d_sort + 2 * (size_t)sl.sort_bins + 1, stream));
     HIP_TRY(same::launch_counters(sl.d_counters, sl.h_counters_dev, 1, stream));
     HIP_TRY(hipEventRecord(sl.ev_done, stream));
     sl.in_flight = true;
@@ -1289,6 +1311,8 @@ void same_batch_free(same_batch *rx)
     if (rx->d_state_blob) (void)hipFree(rx->d_state_blob);
     for (auto &sl : rx->slot) {
         if (sl.d_events) (void)hipFree(sl.d_events);
+        if (sl.d_sort) (void)hipFree(sl.d_sort);
+        if (sl.h_sort) (void)hipHostFree(sl.h_sort);
         if (sl.d_bursts) (void)hipFree(sl.d_bursts);
         if (sl.d_counters) (void)hipFree(sl.d_counters);
         if (sl.h_counters) (void)hipHostFree(sl.h_counters);
