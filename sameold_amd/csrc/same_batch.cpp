@@ -177,8 +177,9 @@ struct same_batch {
     struct Slot {
         same::DevEvent *d_events = nullptr; uint32_t event_cap = 0;
         // the log's indices ordered by state column, made on the device behind the launch (launch_event_sort)
-        uint32_t *d_sort = nullptr; size_t sort_words = 0;          // cnt [bins] | first [bins + 1] | order [event_cap]
-        uint32_t *h_sort = nullptr; size_t h_sort_words = 0;        // pinned: first [bins + 1] | order [event_cap]
+        uint32_t *d_sort = nullptr; size_t sort_words = 0;          // cnt [bins] | first [bins + 1]
+        uint32_t *h_sort = nullptr; size_t h_sort_words = 0;        // pinned: first [bins + 1]
+        same::DevEvent *d_sorted = nullptr; uint32_t sorted_cap = 0; // the log's records in column order
         uint32_t sort_bins = 0;
         uint8_t *d_bursts = nullptr; uint32_t burst_cap = 0;
         uint32_t *d_counters = nullptr;  // [0] n_events [1] n_bursts [2] overflow
@@ -385,7 +386,13 @@ int ensure_output(same_batch *rx, same_batch::Slot &sl, size_t n_samples, same::
         sl.burst_cap = (uint32_t)bcap;
     }
     {
-        const size_t need = 2 * n_ch + 1 + sl.event_cap, need_h = n_ch + 1 + sl.event_cap;
+        const size_t need = 2 * n_ch + 1, need_h = n_ch + 1;
+        if (sl.event_cap > sl.sorted_cap) {
+            if (sl.d_sorted) HIP_TRY(hipFree(sl.d_sorted));
+            sl.d_sorted = nullptr; sl.sorted_cap = 0;
+            HIP_TRY(hipMalloc((void **)&sl.d_sorted, (size_t)sl.event_cap * sizeof(same::DevEvent)));
+            sl.sorted_cap = sl.event_cap;
+        }
         if (need > sl.sort_words) {
             if (sl.d_sort) HIP_TRY(hipFree(sl.d_sort));
             sl.d_sort = nullptr; sl.sort_words = 0;
@@ -458,9 +465,10 @@ int harvest_slot(same_batch *rx, same_batch::Slot &sl)
     const uint32_t n_ch = rx->P.n_channels;
     const uint32_t n_bins = sl.chunked ? sl.geom.n_chunks * n_ch : n_ch;     // state columns of the launch
     if (n_bins != sl.sort_bins) return fail(SAME_EINVAL, "internal: event sort made for %u columns, launch has %u", sl.sort_bins, n_bins);
-    // (the column offsets and the sorted indices come with the log: the device made them behind the launch)
-    HIP_TRY(hipMemcpyAsync(sl.h_sort, sl.d_sort + n_bins, ((size_t)n_bins + 1 + n_events) * sizeof(uint32_t), hipMemcpyDeviceToHost, rx->copy_stream));
-    if (n_events) HIP_TRY(hipMemcpyAsync(sl.h_events, sl.d_events, ev_bytes, hipMemcpyDeviceToHost, rx->copy_stream));
+    // (the log arrives ordered by column, with the columns' offsets: the device did that behind the launch; at most
+    // n_events records are real, the exact count is the last offset)
+    HIP_TRY(hipMemcpyAsync(sl.h_sort, sl.d_sort + n_bins, ((size_t)n_bins + 1) * sizeof(uint32_t), hipMemcpyDeviceToHost, rx->copy_stream));
+    if (n_events) HIP_TRY(hipMemcpyAsync(sl.h_events, sl.d_sorted, ev_bytes, hipMemcpyDeviceToHost, rx->copy_stream));
     HIP_TRY(hipStreamSynchronize(rx->copy_stream));
     if (n_bursts) HIP_TRY(hipMemcpyAsync(sl.h_bursts, sl.d_bursts, bu_bytes, hipMemcpyDeviceToHost, rx->copy_stream));
     if (sl.chunked) {
@@ -470,14 +478,17 @@ int harvest_slot(same_batch *rx, same_batch::Slot &sl)
     }
     auto t_copied = std::chrono::steady_clock::now();
     // Per column the device emits in time order (a lane takes its log slots one after the other); across lanes the
-    // atomic cursor interleaves.  The device has counted the events per column and scattered the log's indices into
-    // column ranges (launch_event_sort); inside a range they stand in the order the scatter's atomics landed, and the
-    // replay threads sort each range (a handful of indices) back into log order = time order before they walk it.
+    // atomic cursor interleaves.  The device has counted the events per column and moved the records into column
+    // ranges (launch_event_sort: `evs` is that ordered copy, a record's `channel` holding its index in the log); inside
+    // a range they stand in the order the scatter's atomics landed, and the replay threads sort each range (a handful
+    // of records) back into log order = time order before they walk it.
     // (slots a wavefront reserved but did not use carry kDevEventNone and were skipped there)
     std::vector<uint32_t> first(sl.h_sort, sl.h_sort + n_bins + 1u);
-    uint32_t *order = sl.h_sort + n_bins + 1u;
+    same::DevEvent *evs_mut = static_cast<same::DevEvent *>(sl.h_events);
     const uint32_t n_real = first[n_bins];
     if (n_real > n_events) return fail(SAME_EHIP, "internal: event sort counted %u of %u events", n_real, n_events);
+    // (what follows indexes the ordered copy directly)
+    struct Identity { uint32_t operator[](uint32_t i) const { return i; } } order;
     if (n_bursts || sl.chunked) HIP_TRY(hipStreamSynchronize(rx->copy_stream));      // bursts, hand-overs, geometry
     if (dbg && sl.chunked && sl.per_channel) {
         // how the per-channel boundaries came out: chunk lengths (own range + warm-up) and run-ons, in samples
@@ -640,7 +651,9 @@ int harvest_slot(same_batch *rx, same_batch::Slot &sl)
         for (uint32_t c = c0; c < c1; ++c) {
             // this channel's column ranges back into log order (see above)
             for (uint32_t col = c; col < n_bins; col += n_ch)
-                if (first[col + 1u] - first[col] > 1u) std::sort(order + first[col], order + first[col + 1u]);
+                if (first[col + 1u] - first[col] > 1u)
+                    std::sort(evs_mut + first[col], evs_mut + first[col + 1u],
+                              [](const same::DevEvent &a, const same::DevEvent &b) { return a.channel < b.channel; });
             if (sl.chunked) stitch(part, ev, c);
             else
                 for (uint32_t k = first[c]; k < first[c + 1u]; ++k)
@@ -989,7 +1002,7 @@ int process_time_major(same_batch *rx, const SampleT *d_x, size_t n_samples, hip
         }
         if (rx->timing) HIP_TRY(hipEventRecord(sl.ev_stop, stream));
         HIP_TRY(same::launch_event_sort(sl.d_events, sl.d_counters, sl.event_cap, sl.sort_bins, sl.d_sort, sl.d_sort + sl.sort_bins,
-                                        sl.d_sort + 2 * (size_t)sl.sort_bins + 1, stream));
+                                        sl.d_sorted, stream));
         HIP_TRY(same::launch_counters(sl.d_counters, sl.h_counters_dev, 1, stream));
         HIP_TRY(hipEventRecord(sl.ev_done, stream));
         sl.in_flight = true;
@@ -1124,7 +1137,7 @@ int process_channel_major_native(same_batch *rx, const float *d_x, size_t n, hip
     sl.end_blocks = rx->counter + n;
     if (rx->timing) HIP_TRY(hipEventRecord(sl.ev_stop, stream));
     HIP_TRY(same::launch_event_sort(sl.d_events, sl.d_counters, sl.event_cap, sl.sort_bins, sl.d_sort, sl.d_sort + sl.sort_bins,
-                                    sl.d_sort + 2 * (size_t)sl.sort_bins + 1, stream));
+                                    sl.d_sorted, stream));
     HIP_TRY(same::launch_counters(sl.d_counters, sl.h_counters_dev, 1, stream));
     HIP_TRY(hipEventRecord(sl.ev_done, stream));
     sl.in_flight = true;
@@ -1312,6 +1325,7 @@ void same_batch_free(same_batch *rx)
     for (auto &sl : rx->slot) {
         if (sl.d_events) (void)hipFree(sl.d_events);
         if (sl.d_sort) (void)hipFree(sl.d_sort);
+        if (sl.d_sorted) (void)hipFree(sl.d_sorted);
         if (sl.h_sort) (void)hipHostFree(sl.h_sort);
         if (sl.d_bursts) (void)hipFree(sl.d_bursts);
         if (sl.d_counters) (void)hipFree(sl.d_counters);

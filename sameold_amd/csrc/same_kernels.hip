@@ -231,7 +231,7 @@ hipError_t launch_counters(uint32_t *dev, uint32_t *host_mapped, int publish, hi
 // The event log ordered by state column on the device (the host did this with a serial counting sort: 0.35 ms of a
 // 2.2 ms harvest at configs[1]): events per column, an exclusive scan, and the log indices scattered into their
 // column's range.  The scatter's order inside a range is that of its atomics; the host sorts each range (a handful of
-// indices) back into log order, which is the column's time order.
+// records) back into log order, which is the column's time order.
 // ---------------------------------------------------------------------------------
 __global__ void ev_hist_kernel(const DevEvent *__restrict__ ev, const uint32_t *__restrict__ counters, uint32_t cap, uint32_t n_bins,
                                uint32_t *__restrict__ cnt)
@@ -258,20 +258,28 @@ __global__ __launch_bounds__(1024) void ev_scan_kernel(uint32_t n_bins, uint32_t
     if (tid == 1023u) first[n_bins] = run;          // (the last thread's stretch ends with the last column, or is empty behind it)
 }
 __global__ void ev_scatter_kernel(const DevEvent *__restrict__ ev, const uint32_t *__restrict__ counters, uint32_t cap, uint32_t n_bins,
-                                  uint32_t *__restrict__ fill, uint32_t *__restrict__ order)
+                                  uint32_t *__restrict__ fill, DevEvent *__restrict__ sorted)
 {
+    // the records themselves move (the host then walks a column's events in one contiguous stretch instead of chasing
+    // indices through the log); `channel`, which the range implies, carries the record's log index for the host's
+    // fix-up of the order inside a range
     const uint32_t n = min(counters[0], cap);
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
-        if (ev[i].kind != kDevEventNone) order[atomicAdd(&fill[min(ev[i].channel, n_bins - 1u)], 1u)] = i;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        DevEvent e = ev[i];
+        if (e.kind == kDevEventNone) continue;
+        const uint32_t pos = atomicAdd(&fill[min(e.channel, n_bins - 1u)], 1u);
+        e.channel = i;
+        sorted[pos] = e;
+    }
 }
 hipError_t launch_event_sort(const DevEvent *ev, const uint32_t *counters, uint32_t cap, uint32_t n_bins, uint32_t *cnt, uint32_t *first,
-                             uint32_t *order, hipStream_t stream)
+                             DevEvent *sorted, hipStream_t stream)
 {
     hipError_t e = hipMemsetAsync(cnt, 0, (size_t)n_bins * sizeof(uint32_t), stream);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(ev_hist_kernel, dim3(256), dim3(256), 0, stream, ev, counters, cap, n_bins, cnt);
     hipLaunchKernelGGL(ev_scan_kernel, dim3(1), dim3(1024), 0, stream, n_bins, cnt, first);
-    hipLaunchKernelGGL(ev_scatter_kernel, dim3(256), dim3(256), 0, stream, ev, counters, cap, n_bins, cnt, order);
+    hipLaunchKernelGGL(ev_scatter_kernel, dim3(256), dim3(256), 0, stream, ev, counters, cap, n_bins, cnt, sorted);
     return hipGetLastError();
 }
 

@@ -48,10 +48,10 @@ hipError_t launch_demod_fast_i16(const Params &P, const State &S, const Output &
                                  const int16_t *x, uint32_t n_blocks, uint64_t counter0, hipStream_t stream);
 // zero the launch cursors (publish = 0) or copy them to host-mapped memory (publish = 1)
 hipError_t launch_counters(uint32_t *dev, uint32_t *host_mapped, int publish, hipStream_t stream);
-// the log's indices ordered by state column: first [n_bins + 1] (exclusive offsets), order [cap] (log indices, a column's
-// in any order), cnt [n_bins] scratch; counters[0] = events logged
+// the log ordered by state column: first [n_bins + 1] (exclusive offsets), sorted [cap] (the records, a column's in any
+// order, their `channel` replaced by their index in the log), cnt [n_bins] scratch; counters[0] = events logged
 hipError_t launch_event_sort(const DevEvent *ev, const uint32_t *counters, uint32_t cap, uint32_t n_bins, uint32_t *cnt, uint32_t *first,
-                             uint32_t *order, hipStream_t stream);
+                             DevEvent *sorted, hipStream_t stream);
 hipError_t launch_init_state(const Params &P, const State &S, int is_reset, hipStream_t stream);
 // Column copies between state blobs of different widths: for every array of `desc` (device memory,
 // n_desc entries) and every column col < n_cols, dst[row][col] = src[row][src_col ? src_col[col] : col + src_base].
