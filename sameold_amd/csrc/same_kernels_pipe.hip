@@ -1119,6 +1119,7 @@ __global__ __launch_bounds__((pipe_dcw<NT, LANES, SPLIT>() ? 5 : 4) * kWave, SHA
                 const float pre0 = X.hist_get((pslot + 16u) & 63u), pre1 = X.hist_get((pslot + 17u) & 63u);
                 const uint32_t hdr = sb[0], zero_w = sb[kWave], sym_w = sb[2 * kWave];
                 uint32_t fbv = 0, io0 = 0, io1 = 0xffffffffu, io2 = 0;
+                bool want_slot = false;                                // this lane has just finished a burst
                 if ((hdr & 1u) && !PROF_SKIP(P, 16)) {
                     const uint32_t fk = hdr >> 8;
                     const float zero = __uint_as_float(zero_w), sym = __uint_as_float(sym_w);
@@ -1131,13 +1132,49 @@ __global__ __launch_bounds__((pipe_dcw<NT, LANES, SPLIT>() ? 5 : 4) * kWave, SHA
                     const uint32_t link = symbol_link(P, L, S, X, c, zero, sym, terr, unt,
                                                       counter0 + (int64_t)row_l + (uint64_t)blk * kB + fk + 1u, &burst_len, &emit,
                                                       true, pre0, pre1);
-                    if (emit && link == 3u) io1 = burst_to_pool(S, O, c);
+                    if constexpr (NT == 42) want_slot = emit && link == 3u;
+                    else if (emit && link == 3u) io1 = burst_to_pool(S, O, c);    // (44.1 / 48 kHz: the kernels are at the register limit and the shared copy below cost them 10 %)
                     io0 = 1u | (link << 1) | (emit ? 8u : 0u) | (fk << 4);
                     io2 = burst_len;
                     const uint32_t after = L.flags & (F_AGC_LOCKED | F_BW_LOCKED);
                     if (after != before || L.ended)
                         fbv = 1u | ((after & F_AGC_LOCKED) ? 2u : 0u) | ((after & F_BW_LOCKED) ? 4u : 0u) |
                               (L.ended ? 8u : 0u) | (fk << 8);
+                }
+                // Finished bursts go into the pool here, outside the lanes' divergent paths and with the whole wavefront:
+                // one slot reservation for all of them and one round trip through memory per burst (72 words: a word per
+                // lane and eight more at 64 lanes), where a lane by itself made seven round trips of ~1 us each -- with the whole
+                // workgroup waiting at the step barrier for it, in ~2 % of a 64-channel workgroup's steps.
+                if constexpr (NT == 42) {
+                    uint64_t pend = __builtin_amdgcn_ballot_w64(want_slot);
+                    if (pend != 0ull) {
+                        const uint32_t n_new = (uint32_t)__popcll(pend);
+                        uint32_t base = 0;
+                        if (lane == 0u) base = atomicAdd(O.n_events + 1, n_new);
+                        base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+                        uint32_t k = 0;
+                        while (pend != 0ull) {
+                            const int j = __builtin_ctzll(pend);
+                            pend &= pend - 1ull;
+                            const uint32_t b = base + k++;
+                            const uint32_t cj = (uint32_t)__builtin_amdgcn_readlane((int)c, j);
+                            if (b < O.burst_cap) {
+                                const uint32_t *src = reinterpret_cast<const uint32_t *>(S.fr_msg + (size_t)cj * kBurstCap);
+                                uint32_t *dst = reinterpret_cast<uint32_t *>(O.bursts + (size_t)b * kBurstCap);
+                                // (narrow workgroups have only LANES lanes left in this wavefront: more words per lane)
+                                constexpr uint32_t kWords = (uint32_t)kBurstCap / 4u, kPer = (kWords + (uint32_t)LANES - 1u) / (uint32_t)LANES;
+                                uint32_t t[kPer];
+#pragma unroll
+                                for (uint32_t i = 0; i < kPer; ++i) { const uint32_t w = lane + i * (uint32_t)LANES; t[i] = w < kWords ? src[w] : 0u; }
+#pragma unroll
+                                for (uint32_t i = 0; i < kPer; ++i) { const uint32_t w = lane + i * (uint32_t)LANES; if (w < kWords) dst[w] = t[i]; }
+                                if ((int)lane == j) io1 = b;
+                            } else {
+                                if (lane == 0u) atomicOr(O.n_events + 2, 2u);
+                                if ((int)lane == j) io1 = 0xffffffffu;
+                            }
+                        }
+                    }
                 }
                 lds_u32 *io = iobox + (s & 1u) * kP3IoWords + lane;
                 io[0] = io0;
