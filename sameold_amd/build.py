@@ -17,8 +17,8 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libsame_rx.so")
-SOURCES = ["same_kernels.hip", "same_kernels_fast.hip", "same_kernels_pipe.hip", "same_kernels_relaxed.hip", "same_synth.hip", "same_batch.cpp", "same_config.cpp", "same_transport.cpp", "same_place.cpp"]
-HEADERS = ["same_dev_common.h", "same_fast_common.h", "same_relaxed_common.h", "same_profile.h", "same_device.h", "same_launch.h", "same_config.h", "same_transport.h", "../../include/same_rx.h",
+SOURCES = ["same_kernels.hip", "same_kernels_fast.hip", "same_kernels_pipe.hip", "same_kernels_relaxed.hip", "same_kernels_sym.hip", "same_synth.hip", "same_batch.cpp", "same_config.cpp", "same_transport.cpp", "same_place.cpp"]
+HEADERS = ["same_dev_common.h", "same_fast_common.h", "same_relaxed_common.h", "same_pipe_common.h", "same_profile.h", "same_device.h", "same_launch.h", "same_config.h", "same_transport.h", "../../include/same_rx.h",
            "../../include/same_place.h", "samedec_main.cpp"]
 SAMEDEC = os.path.join(HERE, "samedec_gpu")      # the command-line decoder (host-only program, dlopens LIB)
 ARCH = "gfx950"

@@ -244,6 +244,7 @@ struct same_batch {
     bool use_fast = false;           // configuration has a latency-optimised kernel
     bool relaxed = false;            // relaxed arithmetic in time-parallel chunks (SAME_BATCH_TIME_PARALLEL or SAME_BATCH_RELAXED)
     bool last_plain_fm = false;      // the last ordinary launch ran the pipeline's FASTMATH build
+    bool last_fm_sym = false;        // ... or rather the symbol-paced pipeline (same_kernels_sym.hip)
     bool relaxed_plain = false;      // ... and in ordinary launches: the one-wavefront relaxed kernel runs whole blocks (SAME_BATCH_RELAXED)
     int knob_relaxed = 0;            // SAME_RELAXED: -1 never (time-parallel chunks keep the strict pipeline), +1 as if SAME_BATCH_RELAXED were set
     bool force_generic = false;      // SAME_BATCH_GENERIC_KERNEL (tests compare both kernels)
@@ -353,6 +354,7 @@ void read_knobs(same_batch *rx)
     rx->P.knob_pipe_share = tri("SAME_PIPE_SHARE");
     rx->P.knob_fast_dense = tri("SAME_FAST_DENSE");
     rx->P.knob_prio = num("SAME_PIPE_PRIO", 0);
+    rx->P.knob_sym = tri("SAME_SYM");
     rx->debug = std::getenv("SAME_DEBUG") != nullptr;
     rx->host_threads = std::max(0, num("SAME_HOST_THREADS", 0));
     rx->tp.sort_mode = num("SAME_TP_SORT", -1);
@@ -421,6 +423,22 @@ int ensure_stage(void **p, size_t *have, size_t need)
     HIP_TRY(hipMalloc(p, need));
     *have = need;
     return SAME_OK;
+}
+
+// The relaxed-arithmetic pipeline of a launch over Pv.n_channels state columns: the symbol-paced one (36-sample steps,
+// same_kernels_sym.hip) where it is built, else the FASTMATH build of the 20-sample pipeline
+uint32_t fm_block_len(const same::Params &Pv) { return same::sym_kernel_supported(Pv) ? same::sym_block_len(Pv) : same::pipe_block_len(Pv); }
+template <typename SampleT>
+hipError_t launch_fm(const same::Params &Pv, const same::State &Sv, const same::Output &O, const float4 *taps, const SampleT *x,
+                     uint32_t n_blocks, uint64_t counter0, hipStream_t stream, const same::PipeChunks &pc)
+{
+    if constexpr (sizeof(SampleT) == 4) {
+        if (same::sym_kernel_supported(Pv)) return same::launch_demod_sym(Pv, Sv, O, taps, (const float *)x, n_blocks, counter0, stream, pc);
+        return same::launch_demod_pipe(Pv, Sv, O, taps, (const float *)x, n_blocks, counter0, stream, pc, true);
+    } else {
+        if (same::sym_kernel_supported(Pv)) return same::launch_demod_sym_i16(Pv, Sv, O, taps, (const int16_t *)x, n_blocks, counter0, stream, pc);
+        return same::launch_demod_pipe_i16(Pv, Sv, O, taps, (const int16_t *)x, n_blocks, counter0, stream, pc, true);
+    }
 }
 
 // Collect the finished launch: copy its event log back, order it, run the transport
@@ -822,7 +840,7 @@ uint32_t plan_chunks(same_batch *rx, size_t n, same::ChunkGeom &geom, same::Pipe
         Pv.n_channels = K * C;
         if (!same::pipe_kernel_selected(Pv) || C % same::pipe_workgroup_channels(Pv) != 0u) continue;
         if (pipe_fm && !same::pipe_relaxed_supported(Pv)) continue;
-        const uint32_t fb = same::pipe_block_len(Pv);
+        const uint32_t fb = pipe_fm ? fm_block_len(Pv) : same::pipe_block_len(Pv);
         if (fill(K, fb)) { tp.kernel = pipe_fm ? same_batch::TimePar::kPipeRelaxed : same_batch::TimePar::kPipe; return K; }
     }
     return 1;
@@ -922,14 +940,16 @@ int process_time_major(same_batch *rx, const SampleT *d_x, size_t n_samples, hip
             const SampleT *xp = d_x + done * C;
             const uint32_t total_blocks = (uint32_t)(n / fbk);
             hipError_t e;
-            if constexpr (sizeof(SampleT) == 4)
+            if (tp.kernel == same_batch::TimePar::kPipeRelaxed)
+                e = launch_fm(tp.Pv, tp.Sv, O, rx->d_taps, xp, total_blocks, rx->counter, stream, pc);
+            else if constexpr (sizeof(SampleT) == 4)
                 e = tp.kernel == same_batch::TimePar::kWaveRelaxed
                         ? same::launch_demod_relaxed(tp.Pv, tp.Sv, O, rx->d_taps, (const float *)xp, total_blocks, rx->counter, stream, pc)
-                        : same::launch_demod_pipe(tp.Pv, tp.Sv, O, rx->d_taps, (const float *)xp, total_blocks, rx->counter, stream, pc, tp.kernel == same_batch::TimePar::kPipeRelaxed);
+                        : same::launch_demod_pipe(tp.Pv, tp.Sv, O, rx->d_taps, (const float *)xp, total_blocks, rx->counter, stream, pc, false);
             else
                 e = tp.kernel == same_batch::TimePar::kWaveRelaxed
                         ? same::launch_demod_relaxed_i16(tp.Pv, tp.Sv, O, rx->d_taps, (const int16_t *)xp, total_blocks, rx->counter, stream, pc)
-                        : same::launch_demod_pipe_i16(tp.Pv, tp.Sv, O, rx->d_taps, (const int16_t *)xp, total_blocks, rx->counter, stream, pc, tp.kernel == same_batch::TimePar::kPipeRelaxed);
+                        : same::launch_demod_pipe_i16(tp.Pv, tp.Sv, O, rx->d_taps, (const int16_t *)xp, total_blocks, rx->counter, stream, pc, false);
             if (e != hipSuccess) return fail(SAME_EHIP, "time-parallel demod kernel launch failed: %s", hipGetErrorString(e));
             // the channel's state afterwards is that of the chunk which ran to the end of the input
             HIP_TRY(same::launch_chunk_final_column(sl.d_handover, C, geom, tp.d_final_col, stream));
@@ -966,14 +986,12 @@ int process_time_major(same_batch *rx, const SampleT *d_x, size_t n_samples, hip
         Pfm.knob_pipe_lanes = 64; Pfm.knob_pipe_share = 1; Pfm.knob_pipe_split = 1; Pfm.knob_pipe = 1;
         const bool plain_fm = rx->relaxed_plain && rx->P.knob_relaxed_kernel == 0 && rx->P.n_channels <= 32768u && same::pipe_relaxed_supported(Pfm);
         rx->last_plain_fm = plain_fm;
-        const size_t fb = plain_fm ? same::pipe_block_len(Pfm)
+        const size_t fb = plain_fm ? fm_block_len(Pfm)
                                    : (rx->relaxed_plain ? same::relaxed_block_len(rx->P) : (rx->use_fast ? same::fast_block_len(rx->P) : 16));
         size_t n_fast = (rx->use_fast && !rx->force_generic) ? (n / fb) * fb : 0;
         if (n_fast && plain_fm) {
-            if constexpr (sizeof(SampleT) == 4)
-                e = same::launch_demod_pipe(Pfm, rx->S, O, rx->d_taps, (const float *)xp, (uint32_t)(n_fast / fb), rx->counter, stream, same::PipeChunks{}, true);
-            else
-                e = same::launch_demod_pipe_i16(Pfm, rx->S, O, rx->d_taps, (const int16_t *)xp, (uint32_t)(n_fast / fb), rx->counter, stream, same::PipeChunks{}, true);
+            e = launch_fm(Pfm, rx->S, O, rx->d_taps, xp, (uint32_t)(n_fast / fb), rx->counter, stream, same::PipeChunks{});
+            rx->last_fm_sym = same::sym_kernel_supported(Pfm);
             if (e != hipSuccess) return fail(SAME_EHIP, "relaxed pipeline launch failed: %s", hipGetErrorString(e));
         } else if (n_fast && rx->relaxed_plain) {
             if constexpr (sizeof(SampleT) == 4)
@@ -1124,7 +1142,8 @@ int process_channel_major_native(same_batch *rx, const float *d_x, size_t n, hip
     sl.have_k = rx->timing;
     if (rx->timing) HIP_TRY(hipEventRecord(sl.ev_k0, stream));
     hipError_t e = wave ? same::launch_demod_relaxed(tp.Pv, tp.Sv, O, rx->d_taps, d_x, (uint32_t)(n / fb), rx->counter, stream, pc)
-                        : same::launch_demod_pipe(tp.Pv, tp.Sv, O, rx->d_taps, d_x, (uint32_t)(n / fb), rx->counter, stream, pc, tp.kernel == same_batch::TimePar::kPipeRelaxed);
+                        : (tp.kernel == same_batch::TimePar::kPipeRelaxed ? launch_fm(tp.Pv, tp.Sv, O, rx->d_taps, d_x, (uint32_t)(n / fb), rx->counter, stream, pc)
+                                                                          : same::launch_demod_pipe(tp.Pv, tp.Sv, O, rx->d_taps, d_x, (uint32_t)(n / fb), rx->counter, stream, pc, false));
     if (e != hipSuccess) return fail(SAME_EHIP, "time-parallel demod kernel launch failed: %s", hipGetErrorString(e));
     if (rx->timing) HIP_TRY(hipEventRecord(sl.ev_k1, stream));
     // The channels' state afterwards: that of the chunk the hand-over chain ends in, as the host's stitch follows it --
@@ -1562,11 +1581,11 @@ const char *same_batch_kernel_name(const same_batch *rx)
     if (rx->tp.last_chunks > 1u) {
         switch (rx->tp.kernel) {
         case same_batch::TimePar::kWaveRelaxed: return "demod_relaxed_kernel";
-        case same_batch::TimePar::kPipeRelaxed: return "demod_pipe_kernel<fastmath>";
+        case same_batch::TimePar::kPipeRelaxed: return same::sym_kernel_supported(rx->tp.Pv) ? "demod_sym_kernel" : "demod_pipe_kernel<fastmath>";
         default: return "demod_pipe_kernel";
         }
     }
-    if (rx->relaxed_plain) return rx->last_plain_fm ? "demod_pipe_kernel<fastmath>" : "demod_relaxed_kernel";
+    if (rx->relaxed_plain) return rx->last_plain_fm ? (rx->last_fm_sym ? "demod_sym_kernel" : "demod_pipe_kernel<fastmath>") : "demod_relaxed_kernel";
     if (rx->use_fast && !rx->force_generic) 
     {
         const uint32_t st = same::pipe_kernel_stages(rx->P);

@@ -58,6 +58,7 @@ struct Params {
     int32_t knob_fast_dense;  // SAME_FAST_DENSE (one-wavefront kernel: the two-per-SIMD build whatever the channel count)
     int32_t knob_pipe_share;  // SAME_PIPE_SHARE (the two-workgroups-per-CU register budget whatever the channel count)
     int32_t knob_relaxed_kernel;  // SAME_RELAXED_KERNEL: 0 choose (incl. the pipeline's FASTMATH build), 1 "solo" (one wavefront per 64 columns), 2 "duo" (two)
+    int32_t knob_sym;         // SAME_SYM=0 -> -1: relaxed launches keep the 20-sample pipeline's FASTMATH build instead of the symbol-paced pipeline (same_kernels_sym.hip)
     int32_t knob_prio;        // SAME_PIPE_PRIO: knock-out mask of SAME_PROFILE builds (same_profile.h PROF_SKIP); unused otherwise
 };
 

@@ -32,24 +32,11 @@
 #include "same_device.h"
 #include "same_fast_common.h"
 #include "same_launch.h"
+#include "same_pipe_common.h"
 #include "same_profile.h"
 #include "same_relaxed_common.h"
 
 namespace same {
-
-// Mailbox words in LDS.  The address space is part of the type: a plain `volatile uint32_t *`
-// derived from the LDS base degrades to a generic pointer, and every access becomes a
-// system-scope FLAT instruction followed by s_waitcnt vmcnt(0).
-typedef volatile __attribute__((address_space(3))) uint32_t lds_u32;
-
-// Workgroup barrier for stages that talk through LDS only.  __syncthreads() also waits for the
-// wavefront's outstanding GLOBAL memory operations (vmcnt(0)): stage 1's input prefetch for the
-// next block and stage 3's framer-byte and event stores would be waited for at every step,
-// although no other wavefront ever reads them.  LDS traffic is ordered by lgkmcnt alone.
-__device__ __forceinline__ void lds_barrier()
-{
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-}
 
 // Geometry per sample rate (filter length NT): DC-blocker window, samples per block, window ring.
 // The ring is five blocks at every rate: NT - 1 samples back from an instant early in block s-1
@@ -221,60 +208,6 @@ __device__ __forceinline__ float demod_half_dyn(const float4 *tlds, const float 
     }
     return rs_hypot(acc.x, acc.y);
 }
-
-// Stage 3 keeps the framer rows; a finished burst is copied into the pool here, its slot travels on.
-__device__ __forceinline__ uint32_t burst_to_pool(const State &S, const Output &O, uint32_t c)
-{
-    const uint32_t b = atomicAdd(O.n_events + 1, 1u);
-    if (b >= O.burst_cap) { atomicOr(O.n_events + 2, 2u); return 0xffffffffu; }
-    copy_burst_row(O.bursts + (size_t)b * kBurstCap, S.fr_msg + (size_t)c * kBurstCap);
-    return b;
-}
-
-// Stage 4's context: the event log.  emit_event takes a slot with a returning atomic per event --
-// an L2 round trip on the critical path of whichever stage emits.  Here the wavefront reserves
-// runs of 64 slots (one atomic per run) and hands them out with a ballot; slots of a run that stay
-// unused are marked kDevEventNone for the host to skip.  The deadline ring stays in HBM.
-constexpr uint32_t kEvChunk = 64;
-struct IoCtx : TickRingGlobal {
-    lds_u32 *chunk;            // LDS: [0] first slot of the current run, [1] slots of it already handed out
-    uint32_t pending_slot;     // burst-pool slot of the Burst event about to be emitted
-    __device__ __forceinline__ void mark(int) const {}
-    __device__ __forceinline__ void emit(const Params &P, const State &S, const Output &O, uint32_t c, uint32_t kind,
-                                         uint64_t sample_counter, uint64_t symbols, uint32_t burst_len)
-    {
-        const uint64_t act = __builtin_amdgcn_ballot_w64(true);          // the lanes emitting right now
-        const uint32_t n = (uint32_t)__popcll(act);
-        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(act >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)act, 0u));
-        uint32_t base = chunk[0], used = chunk[1];
-        if (used + n > kEvChunk) {                                       // wave-uniform
-            for (uint32_t i = used + rank; i < kEvChunk; i += n)
-                if (base + i < O.event_cap) { O.events[base + i].channel = 0; O.events[base + i].kind = kDevEventNone; }
-            uint32_t nb = 0;
-            if (rank == 0u) nb = atomicAdd(O.n_events, kEvChunk);
-            base = (uint32_t)__builtin_amdgcn_readfirstlane((int)nb);    // first active lane = rank 0
-            used = 0;
-        }
-        const uint32_t e = base + used + rank;
-        chunk[0] = base; chunk[1] = used + n;
-        if (e < O.event_cap) {
-            DevEvent ev;
-            ev.channel = c; ev.kind = kind; ev.sample_counter = sample_counter;
-            ev.symbol_count = symbols; ev.burst_len = burst_len;
-            ev.burst_slot = kind == 3u ? pending_slot : 0xffffffffu;
-            O.events[e] = ev;
-        } else {
-            atomicOr(O.n_events + 2, 1u);
-        }
-    }
-    // end of the launch, all lanes: mark what is left of the current run as empty
-    __device__ __forceinline__ void retire(const Output &O, uint32_t lane, uint32_t lanes)
-    {
-        const uint32_t base = chunk[0], used = chunk[1];
-        for (uint32_t i = used + lane; i < kEvChunk; i += lanes)
-            if (base + i < O.event_cap) { O.events[base + i].channel = 0; O.events[base + i].kind = kDevEventNone; }
-    }
-};
 
 // Stage 1 state: DC blocker, AGC, input prefetch, and what a replay needs of its last three blocks
 // FM: relaxed AGC step (same_relaxed_common.h) -- the FASTMATH build of time-parallel launches

@@ -1,0 +1,803 @@
+// same_kernels_sym.hip -- the symbol-paced wavefront pipeline: relaxed arithmetic, 22.05 kHz, 36-sample steps.
+//
+// The four-stage pipeline of same_kernels_pipe.hip steps in blocks of 20 samples, because a block may hold at most one
+// TED instant for the matched filters to be evaluated "after the block".  A symbol, however, is two instants (42.3
+// samples): with 64 lanes at 64 symbol phases every 20-sample step runs the filters, the timing loop and the whole
+// symbol path for the ~47 % of its lanes that happen to have an instant in it -- twice per symbol at half occupancy --
+// and the chain filters -> timing update -> next instant sits inside every step (DESIGN.md 4.7, round 3's attribution).
+//
+// Here the unit of work downstream of the sample phase is the SYMBOL, not the block:
+//   * of the two instants of a symbol only the second one (B, the one that completes the symbol) feeds a decision back
+//     into the timing loop; the first (A) just shifts the TED's history and adds the clock offset to the period
+//     (rx/symsync.rs:236-241), so where B falls is known as soon as A's position is -- before either filter has run.
+//     The timing wavefront therefore evaluates BOTH matched-filter pairs of a symbol in one pass (their loads and
+//     accumulation chains interleaved) and runs the two timing updates after them: once per symbol and lane;
+//   * a step is 36 samples, less than the shortest symbol the timing loop can command (two instants at least 19 samples
+//     apart each: max_block_len), so every lane completes AT MOST one symbol per step and ~85 % of the lanes complete
+//     exactly one: filters, timing loop and symbol path run once per step at ~85 % occupancy;
+//   * the sample phase (DC blocker, AGC, window push) runs 36 samples per step and barrier: the fixed costs of a step
+//     (barrier, feedback word, mailboxes) are paid per 36 samples instead of per 20.
+//
+// Four wavefronts per 64 state columns, on the four SIMDs of a CU:
+//   S  sample phase of block s: input prefetch (a whole step ahead), DC blocker, relaxed AGC, window push; keeps the
+//      DC blocker's outputs of its last three blocks (packed f16) for the replay of an AGC lock flip
+//   T  timing: the symbol whose instants lie in the samples S has finished (blocks < s): two filter pairs, two updates
+//   Y  symbol path of the symbol T handed over one step earlier: squelch, equalizer, framer (same_dev_common.h)
+//   E  link events and transport wake-ups of what Y handed over one step earlier
+// Feedback (agc.lock / loop bandwidth / symsync.reset, receiver.rs:431-432, 479-490) travels back exactly as in
+// same_kernels_pipe.hip: S and T run ahead on their belief, Y posts a change with the sample it happened at, S redoes
+// the AGC from the sample after it, T goes back to its state before the step's symbol and processes it again.
+//
+// Window ring: five blocks of 36 slots, the first 13 slots stored twice (a 14-tap filter chunk never wraps).  T reads at
+// most 119 samples back from the end of block s-1 (a lane may lag up to 52 samples behind after a symsync.reset, the
+// symbol's first filter reaches 25 + 41 further) while S writes block s: four readable blocks and the one being written.
+//
+// Parity contract: that of SAME_BATCH_RELAXED / the time-parallel mode (include/same_rx.h): transmitted bytes and
+// transport messages equal strict mode's, link events within SAME_TP_EVENT_TOLERANCE_SYMBOLS symbols, soft symbols of
+// an open squelch within 0.05.  The arithmetic is same_relaxed_common.h's.
+//
+// Citations: file:line under /root/reference/crates/sameold/src/ ("rx/" = receiver/).
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdlib>
+#include <type_traits>
+
+#include "same_dev_common.h"
+#include "same_device.h"
+#include "same_fast_common.h"
+#include "same_launch.h"
+#include "same_pipe_common.h"
+#include "same_profile.h"
+#include "same_relaxed_common.h"
+
+namespace same {
+
+constexpr int kSymBlock = 36;
+template <int NT> struct SymLayout {
+    static constexpr int B = kSymBlock, DCL = 16, NBLK = 5, RING = NBLK * B, MIR = kRelaxChunk - 1;
+    static constexpr uint32_t tap_floats = (uint32_t)((NT * 4 + PIPE_PROF_TAP_PAD + 63) / 64 * 64);
+    static constexpr uint32_t sym_words = 5u * kWave;             // per parity: header, zero, sym, terr, until
+    static constexpr uint32_t fb_words = kWave + 32u;             // per parity: one word per lane + the any-flag
+    static constexpr uint32_t io_words = 3u * kWave;              // per parity: symbol word, burst-pool slot, burst length
+    static constexpr uint32_t mail_words = 2u * sym_words + 2u * fb_words + 2u * io_words + 2u * kWave;   // + final TED phase, wake-up flag
+    static constexpr size_t lds_bytes = ((size_t)tap_floats + mail_words + (size_t)kSquelchHist * kWave + (size_t)(RING + MIR) * kWave) * sizeof(float);
+    static_assert(NT == 42 && NT % kRelaxChunk == 0, "three filter chunks of 14 taps");
+    static_assert(B % 4 == 0 && B >= DCL && B % 2 == 0, "16-byte loads per lane; the DC windows are the tail of a block");
+    // reach: lag <= 52, first instant of a symbol <= 25 before the second, NT - 1 taps back
+    static_assert(52 + 1 + 25 + (NT - 1) <= (NBLK - 1) * B, "the timing wavefront would read the block being written");
+};
+
+// two DC-blocker outputs as packed f16 (round toward zero: a finite value never becomes an infinity)
+__device__ __forceinline__ uint32_t sym_pack(float a, float b)
+{
+    return __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(a, b));
+}
+__device__ __forceinline__ void sym_unpack(uint32_t w, float *a, float *b)
+{
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    const h2 h = __builtin_bit_cast(h2, w);
+    *a = (float)h.x; *b = (float)h.y;
+}
+
+// LDS byte address of the lowest window slot of chunk c (taps 14 c .. 14 c + 13) of a filter whose newest sample sits in
+// ring slot n: slots n - 14 c - 13 .. n - 14 c modulo RING, read upwards, moved into the mirror when they would wrap
+template <int RING>
+__device__ __forceinline__ uint32_t sym_chunk_addr(uint32_t wcol_lds, int n, int c)
+{
+    int top = n - kRelaxChunk * c;
+    top += top < 0 ? RING : 0;
+    top += top < kRelaxChunk - 1 ? RING : 0;              // slots RING .. RING + 12 repeat slots 0 .. 12
+    return wcol_lds + (uint32_t)(top - (kRelaxChunk - 1)) * (kWave * 4u);
+}
+
+// FskDemod::demod_now rx/demod.rs:156-164 at TWO instants (ring slots n1, n2) in one pass: six chunks of 14 taps, their
+// LDS loads software-pipelined across each other as in demod_pair_relaxed_42 (three register sets, a part's products
+// under the next two parts' latency).  |mark| - |space| clamped to +-1 for each.
+template <int RING>
+__device__ __forceinline__ void sym_demod2(uint32_t taps_lds, uint32_t wcol_lds, int n1, int n2, float *sa1, float *sa2)
+{
+    static_assert(kRelaxChunk == 14, "chunks of 14 taps, written out");
+    float2v am0 = {0.0f, 0.0f}, am1 = {0.0f, 0.0f}, as0 = {0.0f, 0.0f}, as1 = {0.0f, 0.0f};
+    float2v bm0 = {0.0f, 0.0f}, bm1 = {0.0f, 0.0f}, bs0 = {0.0f, 0.0f}, bs1 = {0.0f, 0.0f};
+    const uint32_t wa0 = sym_chunk_addr<RING>(wcol_lds, n1, 0), wa1 = sym_chunk_addr<RING>(wcol_lds, n1, 1), wa2 = sym_chunk_addr<RING>(wcol_lds, n1, 2);
+    const uint32_t wb0 = sym_chunk_addr<RING>(wcol_lds, n2, 0), wb1 = sym_chunk_addr<RING>(wcol_lds, n2, 1), wb2 = sym_chunk_addr<RING>(wcol_lds, n2, 2);
+    const uint32_t ta0 = taps_lds, ta1 = taps_lds + 224u, ta2 = taps_lds + 448u;
+    RelaxPart X, Y, Z;
+    RELAX_LOAD_A(X, wa0, ta0);
+    RELAX_LOAD_B(Y, wa0, ta0);
+    RELAX_WAIT_A(X, 9);  RELAX_FMA_A(X);
+    RELAX_LOAD_A(Z, wa1, ta1);
+    RELAX_WAIT_B(Y, 12); RELAX_FMA_B(Y);
+    RELAX_LOAD_B(X, wa1, ta1);
+    RELAX_WAIT_A(Z, 9);  RELAX_FMA_A(Z);
+    RELAX_LOAD_A(Y, wa2, ta2);
+    RELAX_WAIT_B(X, 12); RELAX_FMA_B(X);
+    RELAX_LOAD_B(Z, wa2, ta2);
+    RELAX_WAIT_A(Y, 9);  RELAX_FMA_A(Y);
+    RELAX_LOAD_A(X, wb0, ta0);
+    RELAX_WAIT_B(Z, 12); RELAX_FMA_B(Z);
+    RELAX_LOAD_B(Y, wb0, ta0);
+    {
+        // the second filter's accumulators under the names the product macros use
+        float2v &am0 = bm0, &am1 = bm1, &as0 = bs0, &as1 = bs1;
+        RELAX_WAIT_A(X, 9);  RELAX_FMA_A(X);
+        RELAX_LOAD_A(Z, wb1, ta1);
+        RELAX_WAIT_B(Y, 12); RELAX_FMA_B(Y);
+        RELAX_LOAD_B(X, wb1, ta1);
+        RELAX_WAIT_A(Z, 9);  RELAX_FMA_A(Z);
+        RELAX_LOAD_A(Y, wb2, ta2);
+        RELAX_WAIT_B(X, 12); RELAX_FMA_B(X);
+        RELAX_LOAD_B(Z, wb2, ta2);
+        RELAX_WAIT_A(Y, 9);  RELAX_FMA_A(Y);
+        RELAX_WAIT_B(Z, 0);  RELAX_FMA_B(Z);
+    }
+    *sa1 = __builtin_amdgcn_fmed3f(relax_magnitude(am0 + am1) - relax_magnitude(as0 + as1), -1.0f, 1.0f);
+    *sa2 = __builtin_amdgcn_fmed3f(relax_magnitude(bm0 + bm1) - relax_magnitude(bs0 + bs1), -1.0f, 1.0f);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// S: the sample phase.  Inputs alternate between two register buffers (block b in buffer b & 1); the loads of block
+// s + 1 are issued at the top of step s, unconditionally (a load behind a condition makes the compiler wait for every
+// outstanding load at the reads), so they have a whole step to arrive.
+// CMODE: 1 = channel-major input with per-lane streams, 0 = time-major rows.
+// ---------------------------------------------------------------------------------------------------------------------
+template <typename SampleT, int CMODE>
+struct SymSample {
+    static constexpr int B = SymLayout<42>::B, DCL = SymLayout<42>::DCL, RING = SymLayout<42>::RING, MIR = SymLayout<42>::MIR;
+    static constexpr uint32_t LP = kWave;
+    float sum0, sum1, gain;
+    bool locked;                         // this wavefront's belief of the AGC lock
+    float xp[DCL], mp[DCL];              // the last DCL inputs / first-stage averages, oldest first
+    float xa[B], xb[B];                  // inputs: block b waits in (b & 1 ? xb : xa)
+    uint32_t ysh[3][B / 2];              // DC-blocker outputs of the last three blocks, packed f16: [0] newest
+    float g0[3];                         // the AGC gain each of them started with
+    uint32_t wp[3];                      // their ring positions
+    uint32_t wnext;                      // ring position of the block produced next
+    uint32_t last_blk;                   // the block in history slot 0
+    const SampleT *xl = nullptr;         // CMODE 1: this lane's own stream
+    uint32_t avail = 0;                  // ... and the blocks it holds
+
+    __device__ __forceinline__ void request(float (&dst)[B], const SampleT *__restrict__ x, uint32_t blk, uint32_t n_blocks, uint32_t cin, uint32_t Cin) const
+    {
+        if constexpr (CMODE == 1) {
+            const uint32_t b = min(blk, avail - 1u);                 // (avail >= 1: the planner leaves two scout blocks behind every cut)
+            const float4 *p4 = reinterpret_cast<const float4 *>(xl + (size_t)b * B);
+#pragma unroll
+            for (int j = 0; j < B / 4; ++j) { const float4 v = p4[j]; dst[4 * j] = v.x; dst[4 * j + 1] = v.y; dst[4 * j + 2] = v.z; dst[4 * j + 3] = v.w; }
+        } else {
+            const SampleT *xr = x + ((size_t)min(blk, n_blocks - 1u) * B) * Cin;      // wave-uniform
+#pragma unroll
+            for (int k = 0; k < B; ++k) { const SampleT *row = xr + (size_t)k * Cin; dst[k] = (float)row[cin]; }
+        }
+    }
+
+    __device__ __forceinline__ void load(const Params &P, const State &S, const SampleT *__restrict__ x, uint32_t c, uint32_t C,
+                                         uint32_t cin, uint32_t Cin, uint64_t counter0, float *wcol, uint32_t n_blocks)
+    {
+        // the window the last launch left: sample counter0 - m sits in the state's slot (counter0 - m) mod win_ring; the
+        // launch's first sample goes to ring slot 0, so it belongs in slot RING - m (never one of the mirrored slots)
+        const uint32_t G = P.win_ring;
+#pragma unroll 2
+        for (uint32_t m = 1; m <= G; ++m) {
+            const uint32_t g = (uint32_t)(counter0 - (uint64_t)m) & (G - 1u);
+            const float *row = S.win_ring + (size_t)g * C;
+            if (m <= (uint32_t)(RING - B)) wcol[((uint32_t)RING - m) * LP] = row[c];
+        }
+        sum0 = S.dc_sum0[c]; sum1 = S.dc_sum1[c]; gain = S.agc_gain[c];
+        locked = (S.flags[c] & F_AGC_LOCKED) != 0u;
+        const uint32_t dpos = (uint32_t)(counter0 % (uint64_t)DCL);
+#pragma unroll
+        for (int k = 0; k < DCL; ++k) {
+            uint32_t slot = dpos + (uint32_t)k;
+            if (slot >= (uint32_t)DCL) slot -= (uint32_t)DCL;
+            const float *r0 = S.dc_ff_ring + (size_t)slot * C, *r1 = S.dc_fb_ring + (size_t)slot * C;
+            xp[k] = r0[c];
+            mp[k] = r1[c];
+        }
+#pragma unroll
+        for (int k = 0; k < B; ++k) xb[k] = 0.0f;
+        request(xa, x, 0u, n_blocks, cin, Cin);
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            g0[j] = gain; wp[j] = 0;
+#pragma unroll
+            for (int k = 0; k < B / 2; ++k) ysh[j][k] = 0u;
+        }
+        wnext = 0; last_blk = 0;
+    }
+
+    // AGC (rx/agc.rs:72-77, relaxed) and window push (receiver.rs:345-346) of one block from its packed DC-blocker
+    // outputs: bandwidth bwa up to sample fk, bwb after it
+    template <int J>
+    __device__ __forceinline__ float redo(const Params &P, float *wcol, float g, int fk, float bwa, float bwb)
+    {
+        float *wblk = wcol + wp[J] * LP;
+        const bool mirror = wp[J] == 0u;
+#pragma unroll
+        for (int k = 0; k < B; k += 2) {
+            float y0, y1;
+            sym_unpack(ysh[J][k / 2], &y0, &y1);
+            const float o0 = agc_step_relaxed(P, y0, g, (k <= fk) ? bwa : bwb);
+            const float o1 = agc_step_relaxed(P, y1, g, (k + 1 <= fk) ? bwa : bwb);
+            wblk[k * LP] = o0; wblk[(k + 1) * LP] = o1;
+            if (k < MIR && mirror) wblk[(k + RING) * LP] = o0;
+            if (k + 1 < MIR && mirror) wblk[(k + 1 + RING) * LP] = o1;
+        }
+        return g;
+    }
+
+    // DC blocker (rx/dcblock.rs:45-49, 104-108: the reference's operations in its order), AGC and window push of block
+    // `blk`, whose inputs are X
+    __device__ __forceinline__ void block(const Params &P, float *wcol, float (&X)[B], uint32_t blk)
+    {
+        if constexpr (CMODE == 1) {
+            // per lane: its stream ends where the input does, and silence follows it
+            const bool live = blk < avail;
+#pragma unroll
+            for (int k = 0; k < B; ++k) X[k] = live ? X[k] : 0.0f;
+        }
+        // history moves on by one block
+#pragma unroll
+        for (int k = 0; k < B / 2; ++k) { ysh[2][k] = ysh[1][k]; ysh[1][k] = ysh[0][k]; }
+        g0[2] = g0[1]; g0[1] = g0[0]; wp[2] = wp[1]; wp[1] = wp[0];
+        g0[0] = gain; wp[0] = wnext; last_blk = blk;
+        float *wblk = wcol + wnext * LP;
+        const bool mirror = wnext == 0u;                               // wave-uniform
+        const float bw = locked ? 0.0f : P.agc_bw;
+        float mnew[B], head[MIR + 1];
+        auto xw = [&](int i) __attribute__((always_inline)) { return i < DCL ? xp[i < DCL ? i : 0] : X[i >= DCL ? i - DCL : 0]; };
+        const float2v inv = {P.dc_inv_len, P.dc_inv_len};
+#pragma unroll
+        for (int k = 0; k < B; k += 2) {
+            const float2v x2 = {X[k], X[k + 1]}, xo = {xw(k), xw(k + 1)};
+            const float2v d0 = x2 - xo;
+            const float s0a = sum0 + d0.x, s0b = s0a + d0.y;
+            sum0 = s0b;
+            const float2v s0 = {s0a, s0b};
+            const float2v ma0 = s0 * inv;
+            const float2v sig = {xw(k + 1), xw(k + 2)};
+            const float2v mo = {k < DCL ? mp[k < DCL ? k : 0] : mnew[k >= DCL ? k - DCL : 0],
+                                k + 1 < DCL ? mp[k + 1 < DCL ? k + 1 : 0] : mnew[k + 1 >= DCL ? k + 1 - DCL : 0]};
+            const float2v d1 = ma0 - mo;
+            const float s1a = sum1 + d1.x, s1b = s1a + d1.y;
+            sum1 = s1b;
+            const float2v s1 = {s1a, s1b};
+            const float2v ma1 = s1 * inv;
+            const float2v y2 = sig - ma1;
+            mnew[k] = ma0.x; mnew[k + 1] = ma0.y;
+            ysh[0][k / 2] = sym_pack(y2.x, y2.y);
+            const float o0 = agc_step_relaxed(P, y2.x, gain, bw);
+            const float o1 = agc_step_relaxed(P, y2.y, gain, bw);
+            wblk[k * LP] = o0; wblk[(k + 1) * LP] = o1;
+            if (k < MIR) head[k] = o0;
+            if (k + 1 < MIR) head[k + 1] = o1;
+        }
+        if (mirror) {
+#pragma unroll
+            for (int k = 0; k < MIR; ++k) wblk[(k + RING) * LP] = head[k];
+        }
+#pragma unroll
+        for (int k = 0; k < DCL; ++k) { xp[k] = X[B - DCL + k]; mp[k] = mnew[B - DCL + k]; }
+        wnext += B;
+        if (wnext == (uint32_t)RING) wnext = 0;
+    }
+
+    // the lock flipped at sample `fk` of block `b` (this lane; b <= last_blk): redo the AGC from there on.  A flip further
+    // back than the history reaches (a lane that lagged a whole block behind: after a symsync.reset, and only if the very
+    // next symbol locks again) takes effect from the start of the oldest block kept.
+    __device__ __forceinline__ void replay(const Params &P, float *wcol, uint32_t b, int fk, bool new_locked)
+    {
+        const float bw0 = locked ? 0.0f : P.agc_bw;
+        locked = new_locked;
+        const float bw1 = locked ? 0.0f : P.agc_bw;
+        uint32_t j = last_blk - b;
+        if (j > 2u) { j = 2u; fk = -1; }
+        float g = 0.0f;
+        if (j >= 2u) { g = redo<2>(P, wcol, g0[2], fk, bw0, bw1); }
+        if (j >= 1u) {
+            const bool first = j == 1u;
+            const float gs = first ? g0[1] : g;
+            g0[1] = gs;
+            g = redo<1>(P, wcol, gs, first ? fk : -1, bw0, bw1);
+        }
+        {
+            const bool first = j == 0u;
+            const float gs = first ? g0[0] : g;
+            g0[0] = gs;
+            g = redo<0>(P, wcol, gs, first ? fk : -1, bw0, bw1);
+        }
+        gain = g;
+    }
+
+    __device__ __forceinline__ void store(const Params &P, const State &S, uint32_t c, uint32_t C, uint64_t counter1, const float *wcol)
+    {
+        S.dc_sum0[c] = sum0; S.dc_sum1[c] = sum1; S.agc_gain[c] = gain;
+        const uint32_t dpos = (uint32_t)(counter1 % (uint64_t)DCL);
+#pragma unroll
+        for (int k = 0; k < DCL; ++k) {
+            uint32_t slot = dpos + (uint32_t)k;
+            if (slot >= (uint32_t)DCL) slot -= (uint32_t)DCL;
+            float *r0 = S.dc_ff_ring + (size_t)slot * C, *r1 = S.dc_fb_ring + (size_t)slot * C;
+            r0[c] = xp[k];
+            r1[c] = mp[k];
+        }
+        const uint32_t G = P.win_ring;
+#pragma unroll 2
+        for (uint32_t m = 1; m <= G; ++m) {
+            const uint32_t g = (uint32_t)(counter1 - (uint64_t)m) & (G - 1u);
+            const uint32_t j = wnext >= m ? wnext - m : wnext + (uint32_t)RING - m;
+            float *row = S.win_ring + (size_t)g * C;
+            row[c] = wcol[j * LP];
+        }
+    }
+};
+
+// ---------------------------------------------------------------------------------------------------------------------
+template <int NFF, int NFB, typename SampleT, int CMODE>
+__global__ __launch_bounds__(4 * kWave, 2) void demod_sym_kernel(Params P, State S, Output O, const float4 *__restrict__ taps,
+                                                                 const SampleT *__restrict__ x, uint32_t n_blocks, uint64_t counter0,
+                                                                 PipeChunks K)
+{
+    constexpr int NT = 42;
+    using LY = SymLayout<NT>;
+    constexpr int kB = LY::B, RING = LY::RING;
+    constexpr uint32_t LP = kWave;
+    static_assert(CMODE == 0 || std::is_same<SampleT, float>::value, "channel-major streams are f32");
+    if constexpr (CMODE == 0) { K.col_row0 = nullptr; K.col_perm = nullptr; }       // (the host launches this build for nothing else)
+    extern __shared__ float lds[];
+    const uint32_t lane = threadIdx.x & (kWave - 1u);
+    const uint32_t role = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // 0 S, 1 T, 2 Y, 3 E
+    const uint32_t C = P.n_channels;
+    // state column of this lane (time-parallel launches may permute them: pieces of similar length share a workgroup)
+    const uint32_t c = (K.n_chunks > 1u && K.col_perm) ? K.col_perm[blockIdx.x * kWave + lane] : blockIdx.x * kWave + lane;
+    // Time-parallel chunks, exactly as demod_pipe_kernel takes them
+    uint32_t cin = c, Cin = C, n_nominal = n_blocks;
+    bool may_leave = false;
+    int32_t row_l = 0;
+    const SampleT *xl = nullptr;
+    uint32_t avail_l = 0;
+    if (K.n_chunks > 1u) {
+        Cin = K.in_channels;
+        if (K.col_row0) {
+            const uint32_t chunk_l = c / Cin;
+            cin = c - chunk_l * Cin;
+            may_leave = (uint32_t)__builtin_amdgcn_readfirstlane((int)chunk_l) + 1u < K.n_chunks;
+            const uint32_t row_abs = K.col_row0[c];
+            xl = x + (size_t)cin * K.in_samples + row_abs;
+            avail_l = (K.whole_samples - row_abs) / (uint32_t)kB;
+            n_blocks = K.wg_blocks[blockIdx.x];
+            n_nominal = may_leave ? K.col_nominal[c] : n_blocks;
+            const uint32_t row_first = (uint32_t)__builtin_amdgcn_readfirstlane((int)row_abs);
+            counter0 += (uint64_t)row_first;
+            row_l = (int32_t)(row_abs - row_first);
+        } else {
+            const uint32_t wgs = K.in_channels / kWave;
+            const uint32_t chunk = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x / wgs));
+            cin = (blockIdx.x - chunk * wgs) * kWave + lane;
+            may_leave = chunk + 1u < K.n_chunks;
+            const uint32_t first_block = chunk * K.stride_blocks;
+            x += (size_t)first_block * kB * Cin;
+            counter0 += (uint64_t)first_block * kB;
+            n_blocks -= first_block;
+            n_nominal = may_leave ? K.nominal_blocks : n_blocks;
+        }
+    }
+    // LDS: taps | mailboxes | squelch history [64][64] | window ring [RING + MIR][64]
+    float4 *tlds = reinterpret_cast<float4 *>(lds);
+    lds_u32 *mail = (lds_u32 *)(lds + LY::tap_floats);
+    lds_u32 *symbox = mail;                                    // [2][5][64]
+    lds_u32 *fbbox = mail + 2u * LY::sym_words;                // [2][64 + flag]
+    lds_u32 *iobox = fbbox + 2u * LY::fb_words;                // [2][3][64]
+    lds_u32 *phasebox = iobox + 2u * LY::io_words;             // [64] T's final TED phase bit
+    lds_u32 *againbox = phasebox + kWave;                      // [64] E's final F_TICK_AGAIN bit
+    lds_u32 *chunkbox = fbbox + kWave + 2u;                    // [2], in the first feedback box's padding
+    float *hcol = lds + LY::tap_floats + LY::mail_words + lane;
+    float *wring = lds + LY::tap_floats + LY::mail_words + kSquelchHist * LP;      // ring slot 0
+    float *wcol = wring + lane;
+    const uint64_t counter1 = counter0 + (uint64_t)n_blocks * kB;
+    // Steps: S produces block s in step s < n_blocks; T processes symbols that end before sample 36 s in steps 1 .. n_blocks
+    // and the instants left over before the end of the input in step n_blocks + 1; Y runs one step behind T, E one behind Y.
+    const uint32_t n_steps = n_blocks + 4u;
+    const uint32_t last_fb_step = n_blocks + 2u;               // Y runs in steps 2 .. n_blocks + 2
+    // A symbol travels as `off` = its sample index - 36 (s_T - 2), s_T the step T processed it in: 0 <= off < 72 + 36.
+    // Y (one step later) and E (two) rebuild the index from their own step number.
+
+    if (role == 0u) {
+        // ------------------------------------------ S: sample phase, block s -----------------------------------------
+        for (uint32_t i = lane; i < (uint32_t)NT; i += kWave) tlds[i] = taps[i];
+        P3_HWID(0);
+        SymSample<SampleT, CMODE> M;
+        M.xl = xl; M.avail = avail_l;
+        M.load(P, S, x, c, C, cin, Cin, counter0, wcol, n_blocks);
+        P3_T0();
+        uint32_t stop_at = 0xffffffffu;
+        auto step = [&](uint32_t s, auto buf) __attribute__((always_inline)) -> bool {
+            constexpr int BUF = decltype(buf)::value;
+            if (s < n_blocks && !PROF_SKIP(P, 64)) {
+                if constexpr (BUF == 0) { M.request(M.xb, x, s + 1u, n_blocks, cin, Cin); M.block(P, wcol, M.xa, s); }
+                else { M.request(M.xa, x, s + 1u, n_blocks, cin, Cin); M.block(P, wcol, M.xb, s); }
+            }
+            P3_LAP(p3_work);
+            lds_barrier();                                             // A
+            P3_LAP(p3_wait);
+            if (s >= 2u && s <= last_fb_step) {
+                const lds_u32 *fb = fbbox + (s & 1u) * LY::fb_words;
+                const uint32_t fbw = (uint32_t)__builtin_amdgcn_readfirstlane((int)fb[kWave]);
+                if (fbw & 2u) stop_at = s + 1u;
+                if (fbw & 1u) {
+                    const uint32_t v = fb[lane];
+                    const bool new_locked = (v & 2u) != 0u;
+                    if ((v & 1u) && new_locked != M.locked) {
+                        // the symbol's sample: 36 (s - 3) + off
+                        const uint32_t off = v >> 8;
+                        const uint32_t b = off >= 2u * (uint32_t)kB ? s - 1u : (off >= (uint32_t)kB ? s - 2u : s - 3u);
+                        const int fk = (int)(off % (uint32_t)kB);
+                        M.replay(P, wcol, b, fk, new_locked);
+                    }
+                    lds_barrier();                                     // B: the window is corrected
+                    lds_barrier();                                     // C: T has redone its step
+                    P3_LAP(p3_fb);
+                }
+            }
+            return s == stop_at;
+        };
+        bool left = false;
+        for (uint32_t s = 0; s < n_steps && !left; s += 2u) {
+            left = step(s, std::integral_constant<int, 0>{});
+            if (!left && s + 1u < n_steps) left = step(s + 1u, std::integral_constant<int, 1>{});
+        }
+        SYM_REPORT(0);
+        if (left) return;                                              // handed over: this chunk's state is not needed
+        lds_barrier();                                                 // (T -> Y: final TED phase)
+        M.store(P, S, c, C, counter1, wcol);
+    } else if (role == 1u) {
+        // ------------------------------------------ T: one symbol per lane and step -----------------------------------
+        P3_HWID(1);
+        const uint32_t taps_lds = lds_addr(lds), wcol_lds = lds_addr(wcol);
+        Lane L;
+        lane_load(L, S, c);
+        const float inv_spt = 1.0f / P.samples_per_ted;
+        int cstar = next_fire_count(L.until_next_ted, L.ted_clock);
+        int rel = cstar - (int)L.ted_clock - 1;        // index of the next instant, relative to the end of the finished samples
+        // One pass over the wavefront: per lane the next symbol -- instant A (completes nothing: where B falls does not depend
+        // on A's sample) and instant B, or B alone right after a symsync.reset -- if both lie in finished samples; `single`:
+        // one instant whatever it is (the instants left over at the end of the input).  wb = ring slot of the sample at rel 0.
+        uint32_t hdr = 0;
+        float zero = 0.0f, sym = 0.0f, terr = 0.0f, next = 0.0f;
+        auto pass = [&](uint32_t wb, bool single, int off_base) __attribute__((always_inline)) {
+            const bool typeA = !single && (L.flags & F_TED_PHASE) != 0u;
+            const int p1 = rel;
+            const float rem1 = L.until_next_ted - (float)cstar;                      // receiver.rs:352
+            const float instA = L.period_inst + __builtin_amdgcn_fmed3f(rem1, -0.5f, 0.5f);   // rx/symsync.rs:236-241
+            const int c2 = next_fire_count(instA, 0u);
+            const int p2 = typeA ? p1 + c2 : p1;
+            const bool ready = p2 < 0;
+            if (__builtin_amdgcn_ballot_w64(ready) == 0ull) return;
+            SYM_T_BEGIN();
+            SYM_COUNT(13, 1);
+            auto slot = [&](int p) __attribute__((always_inline)) { int n = (int)wb + (ready ? p : -1); n += n < 0 ? RING : 0; return n; };
+            float sa1, sa2;
+            sym_demod2<RING>(taps_lds, wcol_lds, slot(p1), slot(p2), &sa1, &sa2);
+            SYM_T_LAP(15);
+            if (ready) {
+                float z, sy, te;
+                bool have;
+                if (typeA) {
+                    (void)ted_timing_relaxed(P, L, inv_spt, sa1, rem1, &z, &sy, &te);
+                    const float rem2 = L.until_next_ted - (float)c2;
+                    have = ted_timing_relaxed(P, L, inv_spt, sa2, rem2, &z, &sy, &te);
+                } else {
+                    have = ted_timing_relaxed(P, L, inv_spt, sa1, rem1, &z, &sy, &te);
+                }
+                cstar = next_fire_count(L.until_next_ted, 0u);
+                rel = p2 + cstar;
+                if (have) { hdr = 1u | ((uint32_t)(p2 + off_base) << 8); zero = z; sym = sy; terr = te; next = L.until_next_ted; }
+            }
+            SYM_T_LAP(16);
+        };
+        auto work = [&](uint32_t s) __attribute__((always_inline)) {
+            hdr = 0;
+            if (s <= n_blocks) {
+                pass((s % (uint32_t)LY::NBLK) * (uint32_t)kB, false, 2 * kB);
+            } else {
+                // the instants left before the end of the input, one at a time (rel is relative to it)
+                const uint32_t wb = (n_blocks % (uint32_t)LY::NBLK) * (uint32_t)kB;
+                while (__builtin_amdgcn_ballot_w64(rel < 0) != 0ull) pass(wb, true, kB);
+            }
+            lds_u32 *sb = symbox + (s & 1u) * LY::sym_words + lane;
+            sb[0] = hdr;
+            sb[kWave] = __float_as_uint(zero); sb[2 * kWave] = __float_as_uint(sym);
+            if (P.trace_cap) { sb[3 * kWave] = __float_as_uint(terr); sb[4 * kWave] = __float_as_uint(next); }
+        };
+        P3_T0();
+        uint32_t stop_at = 0xffffffffu;
+        bool left = false;
+        for (uint32_t s = 0; s < n_steps; ++s) {
+            const bool active = s >= 1u && s <= n_blocks + 1u;
+            if (s >= 1u && s <= n_blocks) rel -= kB;                   // block s - 1 is finished
+            // this lane's state before the step's symbol, in case Y sends it back there
+            const float k_h0 = L.h0, k_h1 = L.h1, k_h2 = L.h2, k_avg = L.period_avg, k_inst = L.period_inst, k_unt = L.until_next_ted;
+            const uint32_t k_flags = L.flags;
+            const int k_cstar = cstar, k_rel = rel;
+            if (active && !PROF_SKIP(P, 32)) work(s);
+            P3_LAP(p3_work);
+            lds_barrier();                                             // A
+            P3_LAP(p3_wait);
+            if (s >= 2u && s <= last_fb_step) {
+                const lds_u32 *fb = fbbox + (s & 1u) * LY::fb_words;
+                const uint32_t fbw = (uint32_t)__builtin_amdgcn_readfirstlane((int)fb[kWave]);
+                if (fbw & 2u) stop_at = s + 1u;
+                if (fbw & 1u) {
+                    SYM_COUNT(14, 1);
+                    const uint32_t v = fb[lane];
+                    // every lane goes back (a lane without a change redoes its step over an unchanged window: same results)
+                    L.h0 = k_h0; L.h1 = k_h1; L.h2 = k_h2; L.period_avg = k_avg; L.period_inst = k_inst;
+                    L.until_next_ted = k_unt; L.flags = k_flags; cstar = k_cstar; rel = k_rel;
+                    if (v & 1u) {
+                        L.flags = (L.flags & ~F_BW_LOCKED) | ((v & 4u) ? F_BW_LOCKED : 0u);
+                        if (v & 8u) {                                    // end(): symsync.reset()
+                            L.flags &= ~F_TED_PHASE;
+                            L.h0 = 0.0f; L.h1 = 0.0f; L.h2 = 0.0f;
+                            L.period_avg = P.samples_per_ted; L.period_inst = P.samples_per_ted;
+                        }
+                    }
+                    lds_barrier();                                     // B: S has corrected the window
+                    if (active) work(s);
+                    lds_barrier();                                     // C
+                    P3_LAP(p3_fb);
+                }
+            }
+            if (s == stop_at) { left = true; break; }
+        }
+        SYM_REPORT(1);
+        SYM_COUNT(12, n_steps);
+        if (left) return;
+        phasebox[lane] = L.flags & F_TED_PHASE;
+        lds_barrier();                                                 // Y merges the phase bit
+        L.ted_clock = (uint32_t)(cstar - rel - 1);
+        S.until_next_ted[c] = L.until_next_ted; S.ted_clock[c] = L.ted_clock;
+        S.ted_h0[c] = L.h0; S.ted_h1[c] = L.h1; S.ted_h2[c] = L.h2;
+        S.period_avg[c] = L.period_avg; S.period_inst[c] = L.period_inst;
+    } else if (role == 2u) {
+        // ------------------------------------------ Y: symbol path --------------------------------------------------
+        P3_HWID(2);
+        Lane L;
+        lane_load(L, S, c);
+        L.ended = 0u;
+        RelaxFastCtx<NFF, NFB> X;
+        X.hist = hcol;
+        P3_MARKS_BEGIN(X, lds, NT);
+#pragma unroll
+        for (int i = 0; i < NFF; ++i) {
+            X.ffc[i] = S.eq_ffc[i * C + c]; X.ffw[i] = S.eq_ffw[i * C + c];
+            X.sffc[i] = S.eq_snap_ffc[i * C + c]; X.sffw[i] = S.eq_snap_ffw[i * C + c];
+        }
+#pragma unroll
+        for (int i = 0; i < NFB; ++i) {
+            X.fbc[i] = S.eq_fbc[i * C + c]; X.fbw[i] = S.eq_fbw[i * C + c];
+            X.sfbc[i] = S.eq_snap_fbc[i * C + c]; X.sfbw[i] = S.eq_snap_fbw[i * C + c];
+        }
+#pragma unroll 2
+        for (int i = 0; i < kSquelchHist; ++i) { const float *row = S.sq_hist + (size_t)i * C; hcol[i * LP] = row[c]; }
+        P3_T0();
+        uint32_t stop_at = 0xffffffffu;
+        bool left = false, lane_done = false, leave_posted = false;
+        for (uint32_t s = 0; s < n_steps; ++s) {
+            bool any = false;
+            if (s >= 2u && s <= last_fb_step) {
+                const uint32_t blk = min(s - 2u, n_blocks - 1u);       // every symbol up to the end of this block has been seen after this step
+                const lds_u32 *sb = symbox + ((s - 1u) & 1u) * LY::sym_words + lane;
+                // everything this step reads from LDS in one round trip: the symbol T handed on and the two history samples
+                // its equalizer step takes (rx_symbol: slots +16/+17 from the squelch's write position)
+                const uint32_t pslot = (uint32_t)(2u * (uint32_t)L.sq_symbols) & 63u;
+                const float pre0 = X.hist_get((pslot + 16u) & 63u), pre1 = X.hist_get((pslot + 17u) & 63u);
+                const uint32_t hdr = sb[0], zero_w = sb[kWave], sym_w = sb[2 * kWave];
+                uint32_t fbv = 0, io0 = 0, io1 = 0xffffffffu, io2 = 0;
+                bool want_slot = false;                                // this lane has just finished a burst
+                if ((hdr & 1u) && !PROF_SKIP(P, 16)) {
+                    const uint32_t off = hdr >> 8;
+                    const float zero = __uint_as_float(zero_w), sym = __uint_as_float(sym_w);
+                    float terr = 0.0f, unt = 0.0f;
+                    if (P.trace_cap) { terr = __uint_as_float(sb[3 * kWave]); unt = __uint_as_float(sb[4 * kWave]); }
+                    const uint32_t before = L.flags & (F_AGC_LOCKED | F_BW_LOCKED);
+                    L.ended = 0u;
+                    uint32_t burst_len = 0;
+                    bool emit = false;
+                    // sample index 36 (s - 3) + off; the counter is that of the sample after it
+                    const uint64_t counter = counter0 + (int64_t)row_l + (uint64_t)((int64_t)kB * ((int64_t)s - 3) + (int64_t)off) + 1u;
+                    const uint32_t link = symbol_link(P, L, S, X, c, zero, sym, terr, unt, counter, &burst_len, &emit, true, pre0, pre1);
+                    want_slot = emit && link == 3u;
+                    io0 = 1u | (link << 1) | (emit ? 8u : 0u) | (off << 4);
+                    io2 = burst_len;
+                    const uint32_t after = L.flags & (F_AGC_LOCKED | F_BW_LOCKED);
+                    if (after != before || L.ended)
+                        fbv = 1u | ((after & F_AGC_LOCKED) ? 2u : 0u) | ((after & F_BW_LOCKED) ? 4u : 0u) | (L.ended ? 8u : 0u) | (off << 8);
+                }
+                // finished bursts go into the pool with the whole wavefront: one slot reservation for all of them and one
+                // coalesced round trip per burst (same_kernels_pipe.hip)
+                uint64_t pend = __builtin_amdgcn_ballot_w64(want_slot);
+                if (pend != 0ull) {
+                    const uint32_t n_new = (uint32_t)__popcll(pend);
+                    uint32_t base = 0;
+                    if (lane == 0u) base = atomicAdd(O.n_events + 1, n_new);
+                    base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+                    uint32_t k = 0;
+                    while (pend != 0ull) {
+                        const int j = __builtin_ctzll(pend);
+                        pend &= pend - 1ull;
+                        const uint32_t b = base + k++;
+                        const uint32_t cj = (uint32_t)__builtin_amdgcn_readlane((int)c, j);
+                        if (b < O.burst_cap) {
+                            const uint32_t *src = reinterpret_cast<const uint32_t *>(S.fr_msg + (size_t)cj * kBurstCap);
+                            uint32_t *dst = reinterpret_cast<uint32_t *>(O.bursts + (size_t)b * kBurstCap);
+                            constexpr uint32_t kWords = (uint32_t)kBurstCap / 4u, kPer = (kWords + kWave - 1u) / kWave;
+                            uint32_t t[kPer];
+#pragma unroll
+                            for (uint32_t i = 0; i < kPer; ++i) { const uint32_t w = lane + i * kWave; t[i] = w < kWords ? src[w] : 0u; }
+#pragma unroll
+                            for (uint32_t i = 0; i < kPer; ++i) { const uint32_t w = lane + i * kWave; if (w < kWords) dst[w] = t[i]; }
+                            if ((int)lane == j) io1 = b;
+                        } else {
+                            if (lane == 0u) atomicOr(O.n_events + 2, 2u);
+                            if ((int)lane == j) io1 = 0xffffffffu;
+                        }
+                    }
+                }
+                lds_u32 *io = iobox + (s & 1u) * LY::io_words + lane;
+                io[0] = io0;
+                if (__builtin_amdgcn_ballot_w64((io0 & 8u) != 0u && ((io0 >> 1) & 3u) == 3u) != 0ull) { io[kWave] = io1; io[2 * kWave] = io2; }
+                lds_u32 *fb = fbbox + (s & 1u) * LY::fb_words;
+                fb[lane] = fbv;
+                any = __builtin_amdgcn_ballot_w64(fbv != 0u) != 0ull;
+                // Time-parallel chunk that hands over: from its nominal end on, a lane's hand-over instant is
+                // the end of the first block after which its link state is NoCarrier; once every lane has one the workgroup
+                // leaves (one more step: E still has to log this step's events)
+                uint32_t leave = 0u;
+                if (may_leave && !leave_posted) {
+                    if (!lane_done && blk + 1u >= n_nominal && (L.flags & F_LINK_MASK) == 0u && (xl == nullptr || blk < avail_l)) {
+                        lane_done = true;
+                        K.handover[c] = counter0 + (int64_t)row_l + (uint64_t)(blk + 1u) * kB;
+                    }
+                    if (__builtin_amdgcn_ballot_w64(!lane_done) == 0ull) { leave = 2u; leave_posted = true; stop_at = s + 1u; }
+                }
+                if (lane == 0u) fb[kWave] = (any ? 1u : 0u) | leave;
+            }
+            P3_LAP(p3_work);
+            lds_barrier();                                             // A
+            P3_LAP(p3_wait);
+            if (any) { lds_barrier(); lds_barrier(); P3_LAP(p3_fb); }   // B, C: the earlier wavefronts catch up
+            if (s == stop_at) { left = true; break; }
+        }
+        SYM_REPORT(2);
+        P3_MARKS_REPORT(X);
+        if (left) return;
+        lds_barrier();                                                 // T's TED phase, E's wake-up flag
+        L.flags = (L.flags & ~(F_TED_PHASE | F_TICK_AGAIN)) | (phasebox[lane] & F_TED_PHASE) | (againbox[lane] & F_TICK_AGAIN);
+        S.sq_data[c] = L.sq_data; S.sq_power[c] = L.sq_power; S.sq_phist[c] = L.sq_phist;
+        S.sq_fill[c] = L.sq_fill; S.sq_clock[c] = L.sq_clock; S.sq_symbols[c] = L.sq_symbols;
+        S.eq_word[c] = L.eq_word; S.eq_count[c] = L.eq_count;
+        S.fr_word[c] = L.fr_word; S.fr_count[c] = L.fr_count; S.fr_invalid[c] = L.fr_invalid;
+        S.fr_len[c] = L.fr_len; S.flags[c] = L.flags;
+#pragma unroll
+        for (int i = 0; i < NFF; ++i) {
+            S.eq_ffc[i * C + c] = X.ffc[i]; S.eq_ffw[i * C + c] = X.ffw[i];
+            S.eq_snap_ffc[i * C + c] = X.sffc[i]; S.eq_snap_ffw[i * C + c] = X.sffw[i];
+        }
+#pragma unroll
+        for (int i = 0; i < NFB; ++i) {
+            S.eq_fbc[i * C + c] = X.fbc[i]; S.eq_fbw[i * C + c] = X.fbw[i];
+            S.eq_snap_fbc[i * C + c] = X.sfbc[i]; S.eq_snap_fbw[i * C + c] = X.sfbw[i];
+        }
+#pragma unroll 2
+        for (int i = 0; i < kSquelchHist; ++i) { float *row = S.sq_hist + (size_t)i * C; row[c] = hcol[i * LP]; }
+    } else {
+        // ------------------------------------------ E: link events + wake-ups ----------------------------------------
+        Lane L;
+        lane_load(L, S, c);      // uses sq_symbols, tk_next, tk_last, wake_*, F_TICK_AGAIN
+        P3_HWID(3);
+        IoCtx X;
+        X.chunk = chunkbox;
+        chunkbox[0] = 0u; chunkbox[1] = kEvChunk;       // nothing reserved yet
+        X.pending_slot = 0xffffffffu;
+        uint32_t stop_at = 0xffffffffu;
+        bool left = false;
+        P3_T0();
+        for (uint32_t s = 0; s < n_steps; ++s) {
+            if (s >= 3u && !PROF_SKIP(P, 8)) {
+                const lds_u32 *io = iobox + ((s - 1u) & 1u) * LY::io_words + lane;
+                const uint32_t io0 = io[0];
+                if (io0 & 1u) {
+                    L.sq_symbols += 1;         // as rx_symbol counted it (rx/codesquelch.rs:232)
+                    const uint32_t link = (io0 >> 1) & 3u, off = (io0 >> 4) & 127u;
+                    const bool burst = (io0 & 8u) != 0u && link == 3u;
+                    uint32_t burst_len = 0;
+                    if (burst) { X.pending_slot = io[kWave]; burst_len = io[2 * kWave]; }
+                    const uint64_t counter = counter0 + (int64_t)row_l + (uint64_t)((int64_t)kB * ((int64_t)s - 4) + (int64_t)off) + 1u;
+                    symbol_io(P, L, S, O, X, c, link, (io0 & 8u) != 0u, counter, burst_len);
+                }
+            }
+            P3_LAP(p3_work);
+            lds_barrier();                                             // A
+            P3_LAP(p3_wait);
+            if (s >= 2u && s <= last_fb_step) {
+                const lds_u32 *fb = fbbox + (s & 1u) * LY::fb_words;
+                const uint32_t fbw = (uint32_t)__builtin_amdgcn_readfirstlane((int)fb[kWave]);
+                if (fbw & 2u) stop_at = s + 1u;
+                if (fbw & 1u) { lds_barrier(); lds_barrier(); P3_LAP(p3_fb); }       // B, C
+            }
+            if (s == stop_at) { left = true; break; }
+        }
+        SYM_REPORT(3);
+        X.retire(O, lane, kWave);
+        if (left) return;
+        againbox[lane] = L.flags & F_TICK_AGAIN;
+        lds_barrier();                                                 // Y merges the flag bits
+        S.tk_next[c] = L.tk_next; S.tk_last[c] = L.tk_last; S.wake_fired[c] = L.wake_fired;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// dispatch
+// ---------------------------------------------------------------------------------------------------------------------
+// 22.05 kHz with the reference's default DC-blocker length, the default or the disabled equalizer, a non-negative AGC
+// floor, whole groups of 64 state columns, and a timing loop whose shortest symbol is longer than a step (two instants at
+// least max_block_len + 1 = 19 samples apart each)
+bool sym_kernel_supported(const Params &P)
+{
+    if (P.knob_sym < 0) return false;
+    if (!(P.ntaps == 42u && P.dc_len == 16u && P.win_ring >= 64u && (P.n_channels % kWave) == 0u)) return false;
+    if (!((P.eq_nff == 6u && P.eq_nfb == 4u) || (P.eq_nff == 1u && P.eq_nfb == 1u))) return false;
+    if (!(P.agc_min >= 0.0f)) return false;
+    return 2u * (max_block_len(P) + 1u) > (uint32_t)kSymBlock;
+}
+uint32_t sym_block_len(const Params &P) { (void)P; return (uint32_t)kSymBlock; }
+
+template <int NFF, int NFB, typename SampleT>
+static hipError_t launch_sym_one(const Params &P, const State &S, const Output &O, const float4 *taps, const SampleT *x,
+                                 uint32_t n_blocks, uint64_t counter0, hipStream_t stream, const PipeChunks &K)
+{
+    constexpr size_t lds = SymLayout<42>::lds_bytes;
+    const bool cm = K.n_chunks > 1u && K.col_row0 != nullptr;
+    if (cm && !std::is_same<SampleT, float>::value) return hipErrorInvalidValue;
+    if (K.n_chunks > 1u && (K.in_channels % kWave) != 0u) return hipErrorInvalidValue;   // a workgroup would straddle chunks
+    if (n_blocks == 0u) return hipSuccess;
+    auto go = [&](auto kernel) -> hipError_t {
+        if (lds > 64u * 1024u) {
+            // more than the default 64 KB of dynamic LDS per workgroup: opt in, once per kernel and device
+            static bool opted_in[64] = {};
+            int dev = 0;
+            if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
+            if (!opted_in[dev]) {
+                const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                if (e != hipSuccess) return e;
+                opted_in[dev] = true;
+            }
+        }
+        hipLaunchKernelGGL(kernel, dim3(P.n_channels / kWave), dim3(4 * kWave), lds, stream, P, S, O, taps, x, n_blocks, counter0, K);
+        return hipGetLastError();
+    };
+    if constexpr (std::is_same<SampleT, float>::value) {
+        if (cm) return go(demod_sym_kernel<NFF, NFB, float, 1>);
+    }
+    return go(demod_sym_kernel<NFF, NFB, SampleT, 0>);
+}
+
+template <typename SampleT>
+static hipError_t launch_sym_t(const Params &P, const State &S, const Output &O, const float4 *taps, const SampleT *x,
+                               uint32_t n_blocks, uint64_t counter0, hipStream_t stream, const PipeChunks &K)
+{
+    if (!sym_kernel_supported(P)) return hipErrorInvalidValue;
+    if (P.eq_nff == 6u && P.eq_nfb == 4u) return launch_sym_one<6, 4, SampleT>(P, S, O, taps, x, n_blocks, counter0, stream, K);
+    return launch_sym_one<1, 1, SampleT>(P, S, O, taps, x, n_blocks, counter0, stream, K);
+}
+hipError_t launch_demod_sym(const Params &P, const State &S, const Output &O, const float4 *taps, const float *x,
+                            uint32_t n_blocks, uint64_t counter0, hipStream_t stream, const PipeChunks &K)
+{ return launch_sym_t<float>(P, S, O, taps, x, n_blocks, counter0, stream, K); }
+hipError_t launch_demod_sym_i16(const Params &P, const State &S, const Output &O, const float4 *taps, const int16_t *x,
+                                uint32_t n_blocks, uint64_t counter0, hipStream_t stream, const PipeChunks &K)
+{ return launch_sym_t<int16_t>(P, S, O, taps, x, n_blocks, counter0, stream, K); }
+
+}  // namespace same
+
+SYM_PROFILE_EXPORTS()

@@ -30,6 +30,16 @@ hipError_t launch_demod_pipe_i16(const Params &P, const State &S, const Output &
                                  const int16_t *x, uint32_t n_blocks, uint64_t counter0, hipStream_t stream,
                                  const PipeChunks &chunks = PipeChunks{}, bool relaxed = false);
 bool pipe_relaxed_supported(const Params &P);
+// symbol-paced pipeline (same_kernels_sym.hip): relaxed arithmetic, 22.05 kHz, 36-sample steps, whole groups of 64 state
+// columns; takes time-parallel chunks like the pipeline
+bool sym_kernel_supported(const Params &P);
+uint32_t sym_block_len(const Params &P);
+hipError_t launch_demod_sym(const Params &P, const State &S, const Output &O, const float4 *taps,
+                            const float *x, uint32_t n_blocks, uint64_t counter0, hipStream_t stream,
+                            const PipeChunks &chunks = PipeChunks{});
+hipError_t launch_demod_sym_i16(const Params &P, const State &S, const Output &O, const float4 *taps,
+                                const int16_t *x, uint32_t n_blocks, uint64_t counter0, hipStream_t stream,
+                                const PipeChunks &chunks = PipeChunks{});
 uint32_t pipe_workgroup_channels(const Params &P);   // channels per workgroup the pipeline would use for this batch
 // relaxed-arithmetic throughput kernel (same_kernels_relaxed.hip): 22.05 kHz, one wavefront per 64 state columns,
 // whole blocks of relaxed_block_len() samples; takes time-parallel chunks like the pipeline

@@ -60,6 +60,23 @@ namespace same { static __device__ unsigned long long g_same_prof_relaxed[8]; }
         return 0;                                                                                               \
     }
 #define PIPE_PROF_TAP_PAD 20
+// symbol-paced pipeline (same_kernels_sym.hip), workgroup 0: [3 r .. 3 r + 2] cycles role r (sample, timing, symbol, events) worked /
+// waited at the step barrier / spent in feedback rounds; [12] steps, [13] units the timing wavefront processed (wavefront passes),
+// [14] feedback rounds, [15] cycles of the timing wavefront's filters, [16] of its timing updates and posting
+namespace same { static __device__ unsigned long long g_same_prof_sym[20]; }
+#define SYM_REPORT(role_) do { if (blockIdx.x == 0 && lane == 0) { same::g_same_prof_sym[3 * (role_)] += p3_work; \
+        same::g_same_prof_sym[3 * (role_) + 1] += p3_wait; same::g_same_prof_sym[3 * (role_) + 2] += p3_fb; } } while (0)
+#define SYM_COUNT(i_, n_) do { if (blockIdx.x == 0 && lane == 0) same::g_same_prof_sym[i_] += (n_); } while (0)
+#define SYM_T_BEGIN() unsigned long long symt_t = clock64()
+#define SYM_T_LAP(i_) do { const unsigned long long t_ = clock64(); if (blockIdx.x == 0 && lane == 0) same::g_same_prof_sym[i_] += t_ - symt_t; symt_t = t_; } while (0)
+#define SYM_PROFILE_EXPORTS()                                                                                   \
+    extern "C" int same_debug_profile_sym(unsigned long long *out20, int reset)                                 \
+    {                                                                                                           \
+        unsigned long long z[20] = {0};                                                                         \
+        if (hipMemcpyFromSymbol(out20, HIP_SYMBOL(same::g_same_prof_sym), sizeof(z)) != hipSuccess) return -1;  \
+        if (reset && hipMemcpyToSymbol(HIP_SYMBOL(same::g_same_prof_sym), z, sizeof(z)) != hipSuccess) return -1; \
+        return 0;                                                                                               \
+    }
 #define FAST_MARKS_BEGIN(X_, lds_, nt_) do { (X_).pl = reinterpret_cast<unsigned long long *>((lds_) + (nt_) * 4); \
         for (int i_ = 0; i_ < 10; ++i_) (X_).pl[i_] = 0; } while (0)
 #define FAST_MARKS_START(X_) do { (X_).pl[0] = clock64(); } while (0)
@@ -121,6 +138,11 @@ namespace same { struct ProfMarks { __device__ __forceinline__ void mark(int) {}
 #define RX_REPORT() do {} while (0)
 #define RELAXED_PROFILE_EXPORTS()
 #define PIPE_PROF_TAP_PAD 0
+#define SYM_REPORT(role_) do {} while (0)
+#define SYM_COUNT(i_, n_) do {} while (0)
+#define SYM_T_BEGIN() do {} while (0)
+#define SYM_T_LAP(i_) do {} while (0)
+#define SYM_PROFILE_EXPORTS()
 #define FAST_MARKS_BEGIN(X_, lds_, nt_) do {} while (0)
 #define FAST_MARKS_START(X_) do {} while (0)
 #define FAST_MARKS_REPORT(X_) do {} while (0)

@@ -1,0 +1,122 @@
+#!/usr/bin/env python3
+"""Round 4: the symbol-paced pipeline (same_kernels_sym.hip) beside the 20-sample FASTMATH pipeline (SAME_SYM=0):
+parity against strict mode and kernel time.   python tools/sym_probe.py [parity|time|tp|all]"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+import sameold_amd as sa
+
+
+def split(ev, n_ch):
+    first = np.searchsorted(ev["channel"], np.arange(n_ch + 1))
+    return [ev[first[c]:first[c + 1]] for c in range(n_ch)]
+
+
+def bursts(e):
+    b = e[e["kind"] == 3]
+    return [(int(r["sample_counter"]), r["bytes"][: min(int(r["len"]), 288)].tobytes()) for r in b]
+
+
+def parity(n_ch=256, secs=10.0, noise=0.0, seed=11, chunked=False):
+    rate = 22050
+    n = int(rate * secs); n -= n % 180
+    x = sa.synth_afsk(n_ch, n, rate, seed=seed, noise_sigma=noise)
+    out = {}
+    for name, kw in (("strict", {}), ("relaxed", {"relaxed": True})):
+        rx = sa.SameReceiverBuilder(rate).build_batch(n_ch, **kw)
+        if chunked and name == "relaxed":
+            cuts = [0, 36 * 7, 36 * 7 + 5000, n // 3 + 17, n // 2, n]
+            for a, b in zip(cuts[:-1], cuts[1:]):
+                rx.process_tensor(x[a:b].contiguous())
+        else:
+            rx.process_tensor(x)
+        rx.sync()
+        out[name] = split(rx.poll_events_np(), n_ch)
+        print(name, rx.kernel_name(), sum(len(e) for e in out[name]), "events", flush=True)
+    nb = bad = 0; worst = 0; kinds_bad = 0
+    for c in range(n_ch):
+        pay = sa.synth_payload(seed, c)
+        a, b = bursts(out["strict"][c]), bursts(out["relaxed"][c])
+        nb += len(a)
+        la = out["strict"][c]; lb = out["relaxed"][c]
+        ka = la[la["kind"] <= 3]["kind"].tolist(); kb = lb[lb["kind"] <= 3]["kind"].tolist()
+        if ka != kb:
+            kinds_bad += 1
+            if kinds_bad < 4: print("channel", c, "link kinds differ", ka[:24], kb[:24])
+        if len(a) != len(b):
+            bad += 1
+            if bad < 5: print("channel", c, "bursts", len(a), len(b))
+            continue
+        for (ta, ba), (tb, bb) in zip(a, b):
+            k = len(pay) if ba[:4] == pay[:4] else 4
+            worst = max(worst, abs(ta - tb))
+            if ba[:k] != bb[:k]:
+                bad += 1
+                if bad < 5: print("channel", c, ba[:k], bb[:k])
+    print(f"parity ({'chunked calls' if chunked else 'one call'}, noise {noise}): {nb} bursts, {bad} differing, {kinds_bad} channels with other link-event kinds, "
+          f"burst instants at most {worst} samples apart", flush=True)
+    ma = [out["strict"][c][out["strict"][c]["kind"] >= 18]["bytes"].tobytes() for c in range(n_ch)]
+    mb = [out["relaxed"][c][out["relaxed"][c]["kind"] >= 18]["bytes"].tobytes() for c in range(n_ch)]
+    print("transport messages equal:", ma == mb, flush=True)
+
+
+def timeit(n_ch, secs, reps=3, relaxed=True, tp=False, cm=False, chunks=0):
+    rate = 22050
+    n = int(rate * secs); n -= n % 180
+    x = sa.synth_afsk(n_ch, n, rate, seed=20260000)
+    if cm:
+        x = x.t().contiguous()
+    torch.cuda.synchronize()
+    rx = sa.SameReceiverBuilder(rate).build_batch(n_ch, link_only=True, relaxed=relaxed, time_parallel=tp)
+    if tp and chunks:
+        rx.time_parallel_config(max_chunks=chunks)
+    rx.set_kernel_timing(True)
+    best = 1e9
+    for r in range(reps):
+        if r: rx.reset()
+        rx.process_tensor(x, layout=sa.LAYOUT_CHANNEL_MAJOR if cm else sa.LAYOUT_TIME_MAJOR); rx.sync()
+        ms = rx.last_kernel_ms(); best = min(best, ms)
+        try:
+            dm = rx.last_demod_kernel_ms()
+        except Exception:
+            dm = ms
+        ev = rx.poll_events_np()
+    print(f"SAME_SYM={os.environ.get('SAME_SYM','-')} {n_ch} ch x {n} tp={tp} cm={cm} chunks={rx.time_parallel_chunks()} [{rx.kernel_name()}]: best {best:.3f} ms "
+          f"(demod alone {dm:.3f}) = {4*n_ch*n/best/1e9/8*100:.2f} % of 8 TB/s; bursts {int((ev['kind']==3).sum())}", flush=True)
+    return rx
+
+
+def prof(rx):
+    import ctypes
+    L = rx._L
+    if not hasattr(L, "same_debug_profile_sym"):
+        return
+    out = (ctypes.c_ulonglong * 20)()
+    if L.same_debug_profile_sym(out, 1) != 0:
+        return
+    v = list(out)
+    steps = max(v[12], 1)
+    names = ["S sample", "T timing", "Y symbol", "E events"]
+    for r in range(4):
+        print(f"  {names[r]:9s} work {v[3*r]/steps:8.1f}  barrier wait {v[3*r+1]/steps:8.1f}  feedback {v[3*r+2]/steps:8.1f}  clk/step")
+    print(f"  steps {steps}, T passes {v[13]}, feedback rounds {v[14]} ({100.0*v[14]/steps:.1f} % of steps); T filters {v[15]/max(v[13],1):.0f} clk/pass, timing+post {v[16]/max(v[13],1):.0f} clk/pass", flush=True)
+
+
+what = sys.argv[1] if len(sys.argv) > 1 else "all"
+if what in ("parity", "all"):
+    parity()
+    parity(noise=0.05, seed=12)
+    parity(chunked=True, seed=13)
+if what in ("time", "all"):
+    for sym in ("1", "0"):
+        os.environ["SAME_SYM"] = sym
+        rx = timeit(32768, 2.0)
+        if sym == "1": prof(rx)
+        timeit(4096, 2.0)
+if what in ("tp", "all"):
+    for sym in ("1", "0"):
+        os.environ["SAME_SYM"] = sym
+        rx = timeit(4096, 10.0, tp=True, cm=True, reps=4)
+        if sym == "1": prof(rx)
+        timeit(4096, 10.0, tp=True, cm=False, reps=3)
