@@ -18,15 +18,21 @@
 //   * the sample phase (DC blocker, AGC, window push) runs 36 samples per step and barrier: the fixed costs of a step
 //     (barrier, feedback word, mailboxes) are paid per 36 samples instead of per 20.
 //
-// Four wavefronts per 64 state columns, on the four SIMDs of a CU:
-//   S  sample phase of block s: input prefetch (a whole step ahead), DC blocker, relaxed AGC, window push; keeps the
-//      DC blocker's outputs of its last three blocks (packed f16) for the replay of an AGC lock flip
-//   T  timing: the symbol whose instants lie in the samples S has finished (blocks < s): two filter pairs, two updates
-//   Y  symbol path of the symbol T handed over one step earlier: squelch, equalizer, framer (same_dev_common.h)
-//   E  link events and transport wake-ups of what Y handed over one step earlier
+// Four wavefronts per 64 state columns, on the four SIMDs of a CU, their work per step balanced by instruction count
+// (the first cut -- sample phase | filters + timing | symbol path | events -- ran 4 900 / 5 400 / 3 200 / 700 clk per step):
+//   T  input prefetch (a whole step ahead) and DC blocker of block s + 1 -- it takes no feedback from anything
+//      (rx/dcblock.rs:45-49) -- handed to S through a two-block LDS ring; then the link events and transport wake-ups of
+//      what Y handed over one step earlier
+//   S  the matched-filter pair at the FIRST instant of the step's symbol (E posts where); then AGC (relaxed) and window push
+//      of block s from the DC blocker's outputs (it keeps those of its last three blocks, packed f16, for the replay of an
+//      AGC lock flip)
+//   E  the symbol whose instants lie in finished samples (blocks < s): the matched-filter pair at its SECOND instant, then
+//      the two timing updates and where the next symbol's instants fall
+//   Y  symbol path of the symbol E handed over one step earlier: squelch, equalizer, framer (same_dev_common.h); the
+//      squelch's sample history stays in the HBM state arrays (two loads a step, issued ahead)
 // Feedback (agc.lock / loop bandwidth / symsync.reset, receiver.rs:431-432, 479-490) travels back exactly as in
-// same_kernels_pipe.hip: S and T run ahead on their belief, Y posts a change with the sample it happened at, S redoes
-// the AGC from the sample after it, T goes back to its state before the step's symbol and processes it again.
+// same_kernels_pipe.hip: S and E run ahead on their belief, Y posts a change with the sample it happened at, S redoes
+// the AGC from the sample after it, E goes back to its state before the step's symbol and processes it again.
 //
 // Window ring: five blocks of 36 slots, the first 13 slots stored twice (a 14-tap filter chunk never wraps).  T reads at
 // most 119 samples back from the end of block s-1 (a lane may lag up to 52 samples behind after a symsync.reset, the
@@ -42,6 +48,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <type_traits>
+#include <utility>
 
 #include "same_dev_common.h"
 #include "same_device.h"
@@ -54,19 +61,34 @@
 namespace same {
 
 constexpr int kSymBlock = 36;
+constexpr uint32_t kSymDrain = 5u;        // steps after the last block in which T processes the instants left before the end of the input, one per step
 template <int NT> struct SymLayout {
     static constexpr int B = kSymBlock, DCL = 16, NBLK = 5, RING = NBLK * B, MIR = kRelaxChunk - 1;
     static constexpr uint32_t tap_floats = (uint32_t)((NT * 4 + PIPE_PROF_TAP_PAD + 63) / 64 * 64);
     static constexpr uint32_t sym_words = 5u * kWave;             // per parity: header, zero, sym, terr, until
     static constexpr uint32_t fb_words = kWave + 32u;             // per parity: one word per lane + the any-flag
     static constexpr uint32_t io_words = 3u * kWave;              // per parity: symbol word, burst-pool slot, burst length
-    static constexpr uint32_t mail_words = 2u * sym_words + 2u * fb_words + 2u * io_words + 2u * kWave;   // + final TED phase, wake-up flag
-    static constexpr size_t lds_bytes = ((size_t)tap_floats + mail_words + (size_t)kSquelchHist * kWave + (size_t)(RING + MIR) * kWave) * sizeof(float);
+    static constexpr uint32_t pos_words = 2u * kWave;             // per parity: ring slots of the symbol's two instants (-1: none)
+    static constexpr uint32_t mail_words = 2u * sym_words + 2u * fb_words + 2u * io_words + 2u * kWave +   // + final TED phase, wake-up flag
+                                           2u * pos_words + kWave;                                        // + the first instant's soft sample, from S
+    static constexpr uint32_t yring_floats = 2u * (uint32_t)B * kWave;
+    static constexpr size_t lds_bytes = ((size_t)tap_floats + mail_words + yring_floats + (size_t)(RING + MIR) * kWave) * sizeof(float);
     static_assert(NT == 42 && NT % kRelaxChunk == 0, "three filter chunks of 14 taps");
     static_assert(B % 4 == 0 && B >= DCL && B % 2 == 0, "16-byte loads per lane; the DC windows are the tail of a block");
     // reach: lag <= 52, first instant of a symbol <= 25 before the second, NT - 1 taps back
-    static_assert(52 + 1 + 25 + (NT - 1) <= (NBLK - 1) * B, "the timing wavefront would read the block being written");
+    static_assert(52 + 1 + 25 + (NT - 1) <= (NBLK - 1) * B, "the filters would read the block being written");
+    static_assert(lds_bytes <= 80u * 1024u, "two workgroups per CU");
 };
+
+// f(integral_constant<int, 0>) ... f(integral_constant<int, N - 1>): a loop that is straight-line code from the start.  A
+// `#pragma unroll` loop over a register array is still a loop with a runtime index when the first scalar-replacement pass
+// runs; where the vectoriser then gets at the array before the next one (overlapping pair loads of the DC blocker's input
+// window), the array stays in scratch memory -- and on gfx950 a scratch load counts in vmcnt, so every read of it also
+// waited for the input prefetch just issued (T's DC blocker: 5 800 clk per step instead of 2 000).
+template <typename F, int... I>
+__device__ __forceinline__ void sym_static_for_(F &&f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
+template <int N, typename F>
+__device__ __forceinline__ void sym_static_for(F &&f) { sym_static_for_(static_cast<F &&>(f), std::make_integer_sequence<int, N>{}); }
 
 // two DC-blocker outputs as packed f16 (round toward zero: a finite value never becomes an infinity)
 __device__ __forceinline__ uint32_t sym_pack(float a, float b)
@@ -91,9 +113,45 @@ __device__ __forceinline__ uint32_t sym_chunk_addr(uint32_t wcol_lds, int n, int
     return wcol_lds + (uint32_t)(top - (kRelaxChunk - 1)) * (kWave * 4u);
 }
 
-// FskDemod::demod_now rx/demod.rs:156-164 at TWO instants (ring slots n1, n2) in one pass: six chunks of 14 taps, their
-// LDS loads software-pipelined across each other as in demod_pair_relaxed_42 (three register sets, a part's products
-// under the next two parts' latency).  |mark| - |space| clamped to +-1 for each.
+// FskDemod::demod_now rx/demod.rs:156-164 at TWO instants (ring slots n1, n2) in one pass.  A chunk of 14 taps is read in
+// four parts -- two window pairs of either filter and the four taps they meet (8 LDS loads, 16 packed products), the last
+// part one pair each and two taps -- so one tap load serves both filters; three register sets take the parts in turn and a
+// part's products issue under the next part's latency.  LDS returns in order: "at most N outstanding" names the part that
+// has landed (N = the loads of the one part issued after it).
+struct SymPart { float2v a0, a1, b0, b1; float4v t0, t1, t2, t3; };
+#define SYM_LOAD2(P_, wa_, wb_, ta_, o0, o1, o2, o3, q0, q1, q2, q3)                                              \
+    asm volatile("ds_read2st64_b32 %[a0], %[wa] offset0:" #o0 " offset1:" #o1 "\n\t"                              \
+                 "ds_read2st64_b32 %[b0], %[wb] offset0:" #o0 " offset1:" #o1 "\n\t"                              \
+                 "ds_read_b128 %[t0], %[ta] offset:" #q0 "\n\t"                                                   \
+                 "ds_read_b128 %[t1], %[ta] offset:" #q1 "\n\t"                                                   \
+                 "ds_read2st64_b32 %[a1], %[wa] offset0:" #o2 " offset1:" #o3 "\n\t"                              \
+                 "ds_read2st64_b32 %[b1], %[wb] offset0:" #o2 " offset1:" #o3 "\n\t"                              \
+                 "ds_read_b128 %[t2], %[ta] offset:" #q2 "\n\t"                                                   \
+                 "ds_read_b128 %[t3], %[ta] offset:" #q3                                                          \
+                 : [a0] "=&v"(P_.a0), [a1] "=&v"(P_.a1), [b0] "=&v"(P_.b0), [b1] "=&v"(P_.b1),                    \
+                   [t0] "=&v"(P_.t0), [t1] "=&v"(P_.t1), [t2] "=&v"(P_.t2), [t3] "=&v"(P_.t3)                     \
+                 : [wa] "v"(wa_), [wb] "v"(wb_), [ta] "v"(ta_) : "memory")
+#define SYM_LOAD1(P_, wa_, wb_, ta_, o0, o1, q0, q1)                                                              \
+    asm volatile("ds_read2st64_b32 %[a0], %[wa] offset0:" #o0 " offset1:" #o1 "\n\t"                              \
+                 "ds_read2st64_b32 %[b0], %[wb] offset0:" #o0 " offset1:" #o1 "\n\t"                              \
+                 "ds_read_b128 %[t0], %[ta] offset:" #q0 "\n\t"                                                   \
+                 "ds_read_b128 %[t1], %[ta] offset:" #q1                                                          \
+                 : [a0] "=&v"(P_.a0), [b0] "=&v"(P_.b0), [t0] "=&v"(P_.t0), [t1] "=&v"(P_.t1)                     \
+                 : [wa] "v"(wa_), [wb] "v"(wb_), [ta] "v"(ta_) : "memory")
+// (the values travel through the wait statement so that nothing that reads them can be moved above it)
+#define SYM_WAIT2(P_, n_) asm volatile("s_waitcnt lgkmcnt(" #n_ ")" : "+v"(P_.a0), "+v"(P_.a1), "+v"(P_.b0), "+v"(P_.b1), "+v"(P_.t0), "+v"(P_.t1), "+v"(P_.t2), "+v"(P_.t3))
+#define SYM_WAIT1(P_, n_) asm volatile("s_waitcnt lgkmcnt(" #n_ ")" : "+v"(P_.a0), "+v"(P_.b0), "+v"(P_.t0), "+v"(P_.t1))
+#define SYM_TAPS(fma, win1_, win2_, tap_, m1_, s1_, m2_, s2_) do { const float2v hm_ = {tap_.x, tap_.y}, hs_ = {tap_.z, tap_.w}; \
+        fma(m1_, win1_, hm_); fma(s1_, win1_, hs_); fma(m2_, win2_, hm_); fma(s2_, win2_, hs_); } while (0)
+// pairs {lowest + 2K, lowest + 2K + 1} meet taps {13 - 2K, 12 - 2K}; the lower slot's products go to the ..0 sums, the upper's to ..1
+#define SYM_FMA2(P_) do { SYM_TAPS(pk_fma_lo, P_.a0, P_.b0, P_.t0, am0, as0, bm0, bs0); SYM_TAPS(pk_fma_hi, P_.a0, P_.b0, P_.t1, am1, as1, bm1, bs1); \
+                          SYM_TAPS(pk_fma_lo, P_.a1, P_.b1, P_.t2, am0, as0, bm0, bs0); SYM_TAPS(pk_fma_hi, P_.a1, P_.b1, P_.t3, am1, as1, bm1, bs1); } while (0)
+#define SYM_FMA1(P_) do { SYM_TAPS(pk_fma_lo, P_.a0, P_.b0, P_.t0, am0, as0, bm0, bs0); SYM_TAPS(pk_fma_hi, P_.a0, P_.b0, P_.t1, am1, as1, bm1, bs1); } while (0)
+// the four parts of a chunk: window pairs 0-1 / 2-3 / 4-5 / 6 with taps 13..10 / 9..6 / 5..2 / 1..0 (16 bytes per tap)
+#define SYM_P1(P_, c_) SYM_LOAD2(P_, wa##c_, wb##c_, ta##c_, 0, 1, 2, 3, 208, 192, 176, 160)
+#define SYM_P2(P_, c_) SYM_LOAD2(P_, wa##c_, wb##c_, ta##c_, 4, 5, 6, 7, 144, 128, 112, 96)
+#define SYM_P3(P_, c_) SYM_LOAD2(P_, wa##c_, wb##c_, ta##c_, 8, 9, 10, 11, 80, 64, 48, 32)
+#define SYM_P4(P_, c_) SYM_LOAD1(P_, wa##c_, wb##c_, ta##c_, 12, 13, 16, 0)
 template <int RING>
 __device__ __forceinline__ void sym_demod2(uint32_t taps_lds, uint32_t wcol_lds, int n1, int n2, float *sa1, float *sa2)
 {
@@ -102,6 +160,33 @@ __device__ __forceinline__ void sym_demod2(uint32_t taps_lds, uint32_t wcol_lds,
     float2v bm0 = {0.0f, 0.0f}, bm1 = {0.0f, 0.0f}, bs0 = {0.0f, 0.0f}, bs1 = {0.0f, 0.0f};
     const uint32_t wa0 = sym_chunk_addr<RING>(wcol_lds, n1, 0), wa1 = sym_chunk_addr<RING>(wcol_lds, n1, 1), wa2 = sym_chunk_addr<RING>(wcol_lds, n1, 2);
     const uint32_t wb0 = sym_chunk_addr<RING>(wcol_lds, n2, 0), wb1 = sym_chunk_addr<RING>(wcol_lds, n2, 1), wb2 = sym_chunk_addr<RING>(wcol_lds, n2, 2);
+    const uint32_t ta0 = taps_lds, ta1 = taps_lds + 224u, ta2 = taps_lds + 448u;
+    SymPart X, Y, Z;
+    SYM_P1(X, 0);
+    SYM_P2(Y, 0);
+    SYM_WAIT2(X, 8); SYM_FMA2(X); SYM_P3(Z, 0);
+    SYM_WAIT2(Y, 8); SYM_FMA2(Y); SYM_P4(X, 0);
+    SYM_WAIT2(Z, 4); SYM_FMA2(Z); SYM_P1(Y, 1);
+    SYM_WAIT1(X, 8); SYM_FMA1(X); SYM_P2(Z, 1);
+    SYM_WAIT2(Y, 8); SYM_FMA2(Y); SYM_P3(X, 1);
+    SYM_WAIT2(Z, 8); SYM_FMA2(Z); SYM_P4(Y, 1);
+    SYM_WAIT2(X, 4); SYM_FMA2(X); SYM_P1(Z, 2);
+    SYM_WAIT1(Y, 8); SYM_FMA1(Y); SYM_P2(X, 2);
+    SYM_WAIT2(Z, 8); SYM_FMA2(Z); SYM_P3(Y, 2);
+    SYM_WAIT2(X, 8); SYM_FMA2(X); SYM_P4(Z, 2);
+    SYM_WAIT2(Y, 4); SYM_FMA2(Y);
+    SYM_WAIT1(Z, 0); SYM_FMA1(Z);
+    *sa1 = __builtin_amdgcn_fmed3f(relax_magnitude(am0 + am1) - relax_magnitude(as0 + as1), -1.0f, 1.0f);
+    *sa2 = __builtin_amdgcn_fmed3f(relax_magnitude(bm0 + bm1) - relax_magnitude(bs0 + bs1), -1.0f, 1.0f);
+}
+
+// ... and at ONE instant: the three chunks' loads software-pipelined across each other as in demod_pair_relaxed_42
+// (same_relaxed_common.h), over this ring's partial mirror
+template <int RING>
+__device__ __forceinline__ float sym_demod1(uint32_t taps_lds, uint32_t wcol_lds, int n)
+{
+    float2v am0 = {0.0f, 0.0f}, am1 = {0.0f, 0.0f}, as0 = {0.0f, 0.0f}, as1 = {0.0f, 0.0f};
+    const uint32_t wa0 = sym_chunk_addr<RING>(wcol_lds, n, 0), wa1 = sym_chunk_addr<RING>(wcol_lds, n, 1), wa2 = sym_chunk_addr<RING>(wcol_lds, n, 2);
     const uint32_t ta0 = taps_lds, ta1 = taps_lds + 224u, ta2 = taps_lds + 448u;
     RelaxPart X, Y, Z;
     RELAX_LOAD_A(X, wa0, ta0);
@@ -115,65 +200,141 @@ __device__ __forceinline__ void sym_demod2(uint32_t taps_lds, uint32_t wcol_lds,
     RELAX_WAIT_B(X, 12); RELAX_FMA_B(X);
     RELAX_LOAD_B(Z, wa2, ta2);
     RELAX_WAIT_A(Y, 9);  RELAX_FMA_A(Y);
-    RELAX_LOAD_A(X, wb0, ta0);
-    RELAX_WAIT_B(Z, 12); RELAX_FMA_B(Z);
-    RELAX_LOAD_B(Y, wb0, ta0);
-    {
-        // the second filter's accumulators under the names the product macros use
-        float2v &am0 = bm0, &am1 = bm1, &as0 = bs0, &as1 = bs1;
-        RELAX_WAIT_A(X, 9);  RELAX_FMA_A(X);
-        RELAX_LOAD_A(Z, wb1, ta1);
-        RELAX_WAIT_B(Y, 12); RELAX_FMA_B(Y);
-        RELAX_LOAD_B(X, wb1, ta1);
-        RELAX_WAIT_A(Z, 9);  RELAX_FMA_A(Z);
-        RELAX_LOAD_A(Y, wb2, ta2);
-        RELAX_WAIT_B(X, 12); RELAX_FMA_B(X);
-        RELAX_LOAD_B(Z, wb2, ta2);
-        RELAX_WAIT_A(Y, 9);  RELAX_FMA_A(Y);
-        RELAX_WAIT_B(Z, 0);  RELAX_FMA_B(Z);
-    }
-    *sa1 = __builtin_amdgcn_fmed3f(relax_magnitude(am0 + am1) - relax_magnitude(as0 + as1), -1.0f, 1.0f);
-    *sa2 = __builtin_amdgcn_fmed3f(relax_magnitude(bm0 + bm1) - relax_magnitude(bs0 + bs1), -1.0f, 1.0f);
+    RELAX_WAIT_B(Z, 0);  RELAX_FMA_B(Z);
+    return __builtin_amdgcn_fmed3f(relax_magnitude(am0 + am1) - relax_magnitude(as0 + as1), -1.0f, 1.0f);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// S: the sample phase.  Inputs alternate between two register buffers (block b in buffer b & 1); the loads of block
-// s + 1 are issued at the top of step s, unconditionally (a load behind a condition makes the compiler wait for every
-// outstanding load at the reads), so they have a whole step to arrive.
-// CMODE: 1 = channel-major input with per-lane streams, 0 = time-major rows.
+// T's sample half: input prefetch and DC blocker, one block ahead of S.  Inputs alternate between two register buffers
+// (block b in buffer b & 1); the loads of block b + 1 are issued just before block b is computed, unconditionally (a load
+// behind a condition makes the compiler wait for every outstanding load at the reads), so they have a whole
+// step to arrive.  CMODE: 1 = channel-major input with per-lane streams, 0 = time-major rows.
 // ---------------------------------------------------------------------------------------------------------------------
 template <typename SampleT, int CMODE>
-struct SymSample {
-    static constexpr int B = SymLayout<42>::B, DCL = SymLayout<42>::DCL, RING = SymLayout<42>::RING, MIR = SymLayout<42>::MIR;
+struct SymDc {
+    static constexpr int B = SymLayout<42>::B, DCL = SymLayout<42>::DCL;
     static constexpr uint32_t LP = kWave;
-    float sum0, sum1, gain;
+    // Everything is kept as aligned PAIRS (samples 2 i, 2 i + 1) and every access is a whole pair with a compile-time index:
+    // the packed operations want aligned register pairs anyway, and an array that is read as pairs at both even and odd
+    // offsets does not survive as registers (see sym_static_for).
+    typedef float2v Pairs[B / 2];
+    float sum0, sum1;
+    float2v xp[DCL / 2], mp[DCL / 2];    // the last DCL inputs / first-stage averages, oldest first
+    Pairs xa, xb;                        // inputs: block b waits in (b & 1 ? xb : xa)
+    const SampleT *xl = nullptr;         // CMODE 1: this lane's own stream
+    uint32_t avail = 0;                  // ... and the blocks it holds
+
+    __device__ __forceinline__ void request(Pairs &dst, const SampleT *__restrict__ x, uint32_t blk, uint32_t n_blocks, uint32_t cin, uint32_t Cin) const
+    {
+        if constexpr (CMODE == 1) {
+            const uint32_t b = min(blk, avail - 1u);                 // (avail >= 1: the planner leaves two scout blocks behind every cut)
+            const float4 *p4 = reinterpret_cast<const float4 *>(xl + (size_t)b * B);
+            sym_static_for<B / 4>([&](auto j_) __attribute__((always_inline)) {
+                constexpr int j = decltype(j_)::value;
+                const float4 v = p4[j];
+                dst[2 * j] = float2v{v.x, v.y}; dst[2 * j + 1] = float2v{v.z, v.w};
+            });
+        } else {
+            const SampleT *xr = x + ((size_t)min(blk, n_blocks - 1u) * B) * Cin;      // wave-uniform
+            sym_static_for<B / 2>([&](auto h_) __attribute__((always_inline)) {
+                constexpr int h = decltype(h_)::value;
+                const SampleT *r0 = xr + (size_t)(2 * h) * Cin, *r1 = xr + (size_t)(2 * h + 1) * Cin;
+                dst[h] = float2v{(float)r0[cin], (float)r1[cin]};
+            });
+        }
+    }
+    __device__ __forceinline__ void load(const State &S, const SampleT *__restrict__ x, uint32_t c, uint32_t C, uint32_t cin, uint32_t Cin,
+                                         uint64_t counter0, uint32_t n_blocks)
+    {
+        sum0 = S.dc_sum0[c]; sum1 = S.dc_sum1[c];
+        const uint32_t dpos = (uint32_t)(counter0 % (uint64_t)DCL);
+        sym_static_for<DCL / 2>([&](auto h_) __attribute__((always_inline)) {
+            constexpr int h = decltype(h_)::value;
+            uint32_t s0 = dpos + (uint32_t)(2 * h), s1 = s0 + 1u;
+            if (s0 >= (uint32_t)DCL) s0 -= (uint32_t)DCL;
+            if (s1 >= (uint32_t)DCL) s1 -= (uint32_t)DCL;
+            xp[h] = float2v{(S.dc_ff_ring + (size_t)s0 * C)[c], (S.dc_ff_ring + (size_t)s1 * C)[c]};
+            mp[h] = float2v{(S.dc_fb_ring + (size_t)s0 * C)[c], (S.dc_fb_ring + (size_t)s1 * C)[c]};
+        });
+        sym_static_for<B / 2>([&](auto h_) __attribute__((always_inline)) { xb[decltype(h_)::value] = float2v{0.0f, 0.0f}; });
+        request(xa, x, 0u, n_blocks, cin, Cin);
+    }
+    // DC blocker (rx/dcblock.rs:45-49, 104-108: the reference's operations in its order) of block `blk`, whose inputs are
+    // X; outputs to y[k * LP]
+    __device__ __forceinline__ void block(const Params &P, float *y, Pairs &X, uint32_t blk)
+    {
+        if constexpr (CMODE == 1) {
+            // per lane: its stream ends where the input does, and silence follows it
+            const bool live = blk < avail;
+            sym_static_for<B / 2>([&](auto h_) __attribute__((always_inline)) {
+                constexpr int h = decltype(h_)::value;
+                X[h] = float2v{live ? X[h].x : 0.0f, live ? X[h].y : 0.0f};
+            });
+        }
+        Pairs mnew;
+        const float2v inv = {P.dc_inv_len, P.dc_inv_len};
+        sym_static_for<B / 2>([&](auto h_) __attribute__((always_inline)) {
+            constexpr int h = decltype(h_)::value;                     // samples k = 2 h, 2 h + 1
+            // the input window before this block, oldest first, as pairs: 0 .. DCL/2 - 1 the history, then this block's inputs
+            auto xw = [&](auto i_) __attribute__((always_inline)) -> float2v {
+                constexpr int i = decltype(i_)::value;
+                if constexpr (i < DCL / 2) return xp[i]; else return X[i - DCL / 2];
+            };
+            auto mw = [&](auto i_) __attribute__((always_inline)) -> float2v {
+                constexpr int i = decltype(i_)::value;
+                if constexpr (i < DCL / 2) return mp[i]; else return mnew[i - DCL / 2];
+            };
+            const float2v xo = xw(std::integral_constant<int, h>{}), xn = xw(std::integral_constant<int, h + 1>{});
+            const float2v d0 = X[h] - xo;
+            const float s0a = sum0 + d0.x, s0b = s0a + d0.y;
+            sum0 = s0b;
+            const float2v s0 = {s0a, s0b};
+            const float2v ma0 = s0 * inv;
+            const float2v d1 = ma0 - mw(std::integral_constant<int, h>{});
+            const float s1a = sum1 + d1.x, s1b = s1a + d1.y;
+            sum1 = s1b;
+            const float2v s1 = {s1a, s1b};
+            const float2v ma1 = s1 * inv;
+            mnew[h] = ma0;
+            // the delayed input (front of the window after the push): window entries k + 1, k + 2
+            y[(2 * h) * LP] = xo.y - ma1.x;
+            y[(2 * h + 1) * LP] = xn.x - ma1.y;
+        });
+        sym_static_for<DCL / 2>([&](auto h_) __attribute__((always_inline)) {
+            constexpr int h = decltype(h_)::value;
+            xp[h] = X[(B - DCL) / 2 + h]; mp[h] = mnew[(B - DCL) / 2 + h];
+        });
+    }
+    __device__ __forceinline__ void store(const State &S, uint32_t c, uint32_t C, uint64_t counter1)
+    {
+        S.dc_sum0[c] = sum0; S.dc_sum1[c] = sum1;
+        const uint32_t dpos = (uint32_t)(counter1 % (uint64_t)DCL);
+        sym_static_for<DCL / 2>([&](auto h_) __attribute__((always_inline)) {
+            constexpr int h = decltype(h_)::value;
+            uint32_t s0 = dpos + (uint32_t)(2 * h), s1 = s0 + 1u;
+            if (s0 >= (uint32_t)DCL) s0 -= (uint32_t)DCL;
+            if (s1 >= (uint32_t)DCL) s1 -= (uint32_t)DCL;
+            (S.dc_ff_ring + (size_t)s0 * C)[c] = xp[h].x; (S.dc_ff_ring + (size_t)s1 * C)[c] = xp[h].y;
+            (S.dc_fb_ring + (size_t)s0 * C)[c] = mp[h].x; (S.dc_fb_ring + (size_t)s1 * C)[c] = mp[h].y;
+        });
+    }
+};
+
+// ---------------------------------------------------------------------------------------------------------------------
+// S: AGC and window push, with what a replay needs of its last three blocks
+// ---------------------------------------------------------------------------------------------------------------------
+struct SymAgc {
+    static constexpr int B = SymLayout<42>::B, RING = SymLayout<42>::RING, MIR = SymLayout<42>::MIR;
+    static constexpr uint32_t LP = kWave;
+    float gain;
     bool locked;                         // this wavefront's belief of the AGC lock
-    float xp[DCL], mp[DCL];              // the last DCL inputs / first-stage averages, oldest first
-    float xa[B], xb[B];                  // inputs: block b waits in (b & 1 ? xb : xa)
     uint32_t ysh[3][B / 2];              // DC-blocker outputs of the last three blocks, packed f16: [0] newest
     float g0[3];                         // the AGC gain each of them started with
     uint32_t wp[3];                      // their ring positions
     uint32_t wnext;                      // ring position of the block produced next
     uint32_t last_blk;                   // the block in history slot 0
-    const SampleT *xl = nullptr;         // CMODE 1: this lane's own stream
-    uint32_t avail = 0;                  // ... and the blocks it holds
 
-    __device__ __forceinline__ void request(float (&dst)[B], const SampleT *__restrict__ x, uint32_t blk, uint32_t n_blocks, uint32_t cin, uint32_t Cin) const
-    {
-        if constexpr (CMODE == 1) {
-            const uint32_t b = min(blk, avail - 1u);                 // (avail >= 1: the planner leaves two scout blocks behind every cut)
-            const float4 *p4 = reinterpret_cast<const float4 *>(xl + (size_t)b * B);
-#pragma unroll
-            for (int j = 0; j < B / 4; ++j) { const float4 v = p4[j]; dst[4 * j] = v.x; dst[4 * j + 1] = v.y; dst[4 * j + 2] = v.z; dst[4 * j + 3] = v.w; }
-        } else {
-            const SampleT *xr = x + ((size_t)min(blk, n_blocks - 1u) * B) * Cin;      // wave-uniform
-#pragma unroll
-            for (int k = 0; k < B; ++k) { const SampleT *row = xr + (size_t)k * Cin; dst[k] = (float)row[cin]; }
-        }
-    }
-
-    __device__ __forceinline__ void load(const Params &P, const State &S, const SampleT *__restrict__ x, uint32_t c, uint32_t C,
-                                         uint32_t cin, uint32_t Cin, uint64_t counter0, float *wcol, uint32_t n_blocks)
+    __device__ __forceinline__ void load(const Params &P, const State &S, uint32_t c, uint32_t C, uint64_t counter0, float *wcol)
     {
         // the window the last launch left: sample counter0 - m sits in the state's slot (counter0 - m) mod win_ring; the
         // launch's first sample goes to ring slot 0, so it belongs in slot RING - m (never one of the mirrored slots)
@@ -184,20 +345,8 @@ struct SymSample {
             const float *row = S.win_ring + (size_t)g * C;
             if (m <= (uint32_t)(RING - B)) wcol[((uint32_t)RING - m) * LP] = row[c];
         }
-        sum0 = S.dc_sum0[c]; sum1 = S.dc_sum1[c]; gain = S.agc_gain[c];
+        gain = S.agc_gain[c];
         locked = (S.flags[c] & F_AGC_LOCKED) != 0u;
-        const uint32_t dpos = (uint32_t)(counter0 % (uint64_t)DCL);
-#pragma unroll
-        for (int k = 0; k < DCL; ++k) {
-            uint32_t slot = dpos + (uint32_t)k;
-            if (slot >= (uint32_t)DCL) slot -= (uint32_t)DCL;
-            const float *r0 = S.dc_ff_ring + (size_t)slot * C, *r1 = S.dc_fb_ring + (size_t)slot * C;
-            xp[k] = r0[c];
-            mp[k] = r1[c];
-        }
-#pragma unroll
-        for (int k = 0; k < B; ++k) xb[k] = 0.0f;
-        request(xa, x, 0u, n_blocks, cin, Cin);
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
             g0[j] = gain; wp[j] = 0;
@@ -214,29 +363,44 @@ struct SymSample {
     {
         float *wblk = wcol + wp[J] * LP;
         const bool mirror = wp[J] == 0u;
+        float head[MIR + 1];
+        // (every lane in here locks from the block's first sample on: the gain stands still)
+        const bool frozen = __builtin_amdgcn_ballot_w64(!(bwb == 0.0f && fk < 0)) == 0ull;
+        if (frozen) {
 #pragma unroll
-        for (int k = 0; k < B; k += 2) {
-            float y0, y1;
-            sym_unpack(ysh[J][k / 2], &y0, &y1);
-            const float o0 = agc_step_relaxed(P, y0, g, (k <= fk) ? bwa : bwb);
-            const float o1 = agc_step_relaxed(P, y1, g, (k + 1 <= fk) ? bwa : bwb);
-            wblk[k * LP] = o0; wblk[(k + 1) * LP] = o1;
-            if (k < MIR && mirror) wblk[(k + RING) * LP] = o0;
-            if (k + 1 < MIR && mirror) wblk[(k + 1 + RING) * LP] = o1;
+            for (int k = 0; k < B; k += 2) {
+                float y0, y1;
+                sym_unpack(ysh[J][k / 2], &y0, &y1);
+                const float o0 = y0 * g, o1 = y1 * g;
+                wblk[k * LP] = o0; wblk[(k + 1) * LP] = o1;
+                if (k < MIR) head[k] = o0;
+                if (k + 1 < MIR) head[k + 1] = o1;
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < B; k += 2) {
+                float y0, y1;
+                sym_unpack(ysh[J][k / 2], &y0, &y1);
+                const float o0 = agc_step_relaxed(P, y0, g, (k <= fk) ? bwa : bwb);
+                const float o1 = agc_step_relaxed(P, y1, g, (k + 1 <= fk) ? bwa : bwb);
+                wblk[k * LP] = o0; wblk[(k + 1) * LP] = o1;
+                if (k < MIR) head[k] = o0;
+                if (k + 1 < MIR) head[k + 1] = o1;
+            }
+        }
+        if (mirror) {
+#pragma unroll
+            for (int k = 0; k < MIR; ++k) wblk[(k + RING) * LP] = head[k];
         }
         return g;
     }
 
-    // DC blocker (rx/dcblock.rs:45-49, 104-108: the reference's operations in its order), AGC and window push of block
-    // `blk`, whose inputs are X
-    __device__ __forceinline__ void block(const Params &P, float *wcol, float (&X)[B], uint32_t blk)
+    // AGC and window push of block `blk`, whose DC-blocker outputs are y[k * LP]
+    __device__ __forceinline__ void block(const Params &P, float *wcol, const float *y, uint32_t blk)
     {
-        if constexpr (CMODE == 1) {
-            // per lane: its stream ends where the input does, and silence follows it
-            const bool live = blk < avail;
+        float yv[B];
 #pragma unroll
-            for (int k = 0; k < B; ++k) X[k] = live ? X[k] : 0.0f;
-        }
+        for (int k = 0; k < B; ++k) yv[k] = y[k * LP];
         // history moves on by one block
 #pragma unroll
         for (int k = 0; k < B / 2; ++k) { ysh[2][k] = ysh[1][k]; ysh[1][k] = ysh[0][k]; }
@@ -245,30 +409,12 @@ struct SymSample {
         float *wblk = wcol + wnext * LP;
         const bool mirror = wnext == 0u;                               // wave-uniform
         const float bw = locked ? 0.0f : P.agc_bw;
-        float mnew[B], head[MIR + 1];
-        auto xw = [&](int i) __attribute__((always_inline)) { return i < DCL ? xp[i < DCL ? i : 0] : X[i >= DCL ? i - DCL : 0]; };
-        const float2v inv = {P.dc_inv_len, P.dc_inv_len};
+        float head[MIR + 1];
 #pragma unroll
         for (int k = 0; k < B; k += 2) {
-            const float2v x2 = {X[k], X[k + 1]}, xo = {xw(k), xw(k + 1)};
-            const float2v d0 = x2 - xo;
-            const float s0a = sum0 + d0.x, s0b = s0a + d0.y;
-            sum0 = s0b;
-            const float2v s0 = {s0a, s0b};
-            const float2v ma0 = s0 * inv;
-            const float2v sig = {xw(k + 1), xw(k + 2)};
-            const float2v mo = {k < DCL ? mp[k < DCL ? k : 0] : mnew[k >= DCL ? k - DCL : 0],
-                                k + 1 < DCL ? mp[k + 1 < DCL ? k + 1 : 0] : mnew[k + 1 >= DCL ? k + 1 - DCL : 0]};
-            const float2v d1 = ma0 - mo;
-            const float s1a = sum1 + d1.x, s1b = s1a + d1.y;
-            sum1 = s1b;
-            const float2v s1 = {s1a, s1b};
-            const float2v ma1 = s1 * inv;
-            const float2v y2 = sig - ma1;
-            mnew[k] = ma0.x; mnew[k + 1] = ma0.y;
-            ysh[0][k / 2] = sym_pack(y2.x, y2.y);
-            const float o0 = agc_step_relaxed(P, y2.x, gain, bw);
-            const float o1 = agc_step_relaxed(P, y2.y, gain, bw);
+            ysh[0][k / 2] = sym_pack(yv[k], yv[k + 1]);
+            const float o0 = agc_step_relaxed(P, yv[k], gain, bw);
+            const float o1 = agc_step_relaxed(P, yv[k + 1], gain, bw);
             wblk[k * LP] = o0; wblk[(k + 1) * LP] = o1;
             if (k < MIR) head[k] = o0;
             if (k + 1 < MIR) head[k + 1] = o1;
@@ -277,8 +423,6 @@ struct SymSample {
 #pragma unroll
             for (int k = 0; k < MIR; ++k) wblk[(k + RING) * LP] = head[k];
         }
-#pragma unroll
-        for (int k = 0; k < DCL; ++k) { xp[k] = X[B - DCL + k]; mp[k] = mnew[B - DCL + k]; }
         wnext += B;
         if (wnext == (uint32_t)RING) wnext = 0;
     }
@@ -312,16 +456,7 @@ struct SymSample {
 
     __device__ __forceinline__ void store(const Params &P, const State &S, uint32_t c, uint32_t C, uint64_t counter1, const float *wcol)
     {
-        S.dc_sum0[c] = sum0; S.dc_sum1[c] = sum1; S.agc_gain[c] = gain;
-        const uint32_t dpos = (uint32_t)(counter1 % (uint64_t)DCL);
-#pragma unroll
-        for (int k = 0; k < DCL; ++k) {
-            uint32_t slot = dpos + (uint32_t)k;
-            if (slot >= (uint32_t)DCL) slot -= (uint32_t)DCL;
-            float *r0 = S.dc_ff_ring + (size_t)slot * C, *r1 = S.dc_fb_ring + (size_t)slot * C;
-            r0[c] = xp[k];
-            r1[c] = mp[k];
-        }
+        S.agc_gain[c] = gain;
         const uint32_t G = P.win_ring;
 #pragma unroll 2
         for (uint32_t m = 1; m <= G; ++m) {
@@ -383,7 +518,7 @@ __global__ __launch_bounds__(4 * kWave, 2) void demod_sym_kernel(Params P, State
             n_nominal = may_leave ? K.nominal_blocks : n_blocks;
         }
     }
-    // LDS: taps | mailboxes | squelch history [64][64] | window ring [RING + MIR][64]
+    // LDS: taps | mailboxes | DC-blocker outputs [2][36][64] | window ring [RING + MIR][64]
     float4 *tlds = reinterpret_cast<float4 *>(lds);
     lds_u32 *mail = (lds_u32 *)(lds + LY::tap_floats);
     lds_u32 *symbox = mail;                                    // [2][5][64]
@@ -391,33 +526,50 @@ __global__ __launch_bounds__(4 * kWave, 2) void demod_sym_kernel(Params P, State
     lds_u32 *iobox = fbbox + 2u * LY::fb_words;                // [2][3][64]
     lds_u32 *phasebox = iobox + 2u * LY::io_words;             // [64] T's final TED phase bit
     lds_u32 *againbox = phasebox + kWave;                      // [64] E's final F_TICK_AGAIN bit
+    lds_u32 *posbox = againbox + kWave;                        // [2][2][64] ring slots of the two instants of step s's symbol (parity s & 1)
+    lds_u32 *sabox = posbox + 2u * LY::pos_words;              // [64] the first instant's soft sample
     lds_u32 *chunkbox = fbbox + kWave + 2u;                    // [2], in the first feedback box's padding
-    float *hcol = lds + LY::tap_floats + LY::mail_words + lane;
-    float *wring = lds + LY::tap_floats + LY::mail_words + kSquelchHist * LP;      // ring slot 0
+    lds_u32 *seqbox = fbbox + kWave + 4u;                      // S's progress with the first instants' filters: 2 * step + pass
+    float *yring = lds + LY::tap_floats + LY::mail_words;      // [2][kB][64]: block b in half b & 1
+    float *wring = yring + LY::yring_floats;                   // ring slot 0
     float *wcol = wring + lane;
     const uint64_t counter1 = counter0 + (uint64_t)n_blocks * kB;
-    // Steps: S produces block s in step s < n_blocks; T processes symbols that end before sample 36 s in steps 1 .. n_blocks
-    // and the instants left over before the end of the input in step n_blocks + 1; Y runs one step behind T, E one behind Y.
-    const uint32_t n_steps = n_blocks + 4u;
-    const uint32_t last_fb_step = n_blocks + 2u;               // Y runs in steps 2 .. n_blocks + 2
-    // A symbol travels as `off` = its sample index - 36 (s_T - 2), s_T the step T processed it in: 0 <= off < 72 + 36.
-    // Y (one step later) and E (two) rebuild the index from their own step number.
+    // Steps: T computes the DC blocker of block s + 1 in step s (block 0 before the first), S the AGC of block s in step
+    // s < n_blocks; T finishes symbols that end before sample 36 s in steps 1 .. n_blocks and the instants left before the
+    // end of the input, one per step, in the kSymDrain steps after; Y runs one step behind T, E's events one behind Y.
+    const uint32_t last_t_step = n_blocks + kSymDrain;
+    const uint32_t last_fb_step = last_t_step + 1u;            // Y runs in steps 2 .. last_t_step + 1
+    const uint32_t n_steps = last_t_step + 3u;
+    // A symbol travels as `off` = its sample index - 36 * base, base = s_T - 2 for the step s_T <= n_blocks T finished it
+    // in, n_blocks - 3 in the steps after: 0 <= off < 128.  Y (one step later) and E (two) rebuild the index.
+    auto sym_index = [&](uint32_t s_t, uint32_t off) __attribute__((always_inline)) -> int64_t {
+        const int64_t base = s_t <= n_blocks ? (int64_t)s_t - 2 : (int64_t)n_blocks - 3;
+        return (int64_t)kB * base + (int64_t)off;
+    };
 
     if (role == 0u) {
-        // ------------------------------------------ S: sample phase, block s -----------------------------------------
+        // ------------------------------------------ S: AGC + window push, block s -------------------------------------
         for (uint32_t i = lane; i < (uint32_t)NT; i += kWave) tlds[i] = taps[i];
         P3_HWID(0);
-        SymSample<SampleT, CMODE> M;
-        M.xl = xl; M.avail = avail_l;
-        M.load(P, S, x, c, C, cin, Cin, counter0, wcol, n_blocks);
+        SymAgc M;
+        M.load(P, S, c, C, counter0, wcol);
+        const uint32_t taps_lds = lds_addr(lds), wcol_lds = lds_addr(wcol);
+        if (lane == 0u) seqbox[0] = 0u;
+        // the matched filters of the FIRST instant of the step's symbol, at the positions E posted (E takes the second)
+        auto filter_a = [&](uint32_t s, uint32_t seq) __attribute__((always_inline)) {
+            const uint32_t n1 = posbox[(s & 1u) * LY::pos_words + lane];
+            if (__builtin_amdgcn_ballot_w64(n1 != 0xffffffffu) == 0ull) return;
+            const float sa1 = sym_demod1<RING>(taps_lds, wcol_lds, n1 == 0xffffffffu ? 0 : (int)n1);
+            sabox[lane] = __float_as_uint(sa1);
+            if (lane == 0u) seqbox[0] = seq;                           // (LDS operations of a wavefront stay in order)
+        };
+        lds_barrier();                                                 // prologue: block 0's DC outputs are in the ring
         P3_T0();
         uint32_t stop_at = 0xffffffffu;
-        auto step = [&](uint32_t s, auto buf) __attribute__((always_inline)) -> bool {
-            constexpr int BUF = decltype(buf)::value;
-            if (s < n_blocks && !PROF_SKIP(P, 64)) {
-                if constexpr (BUF == 0) { M.request(M.xb, x, s + 1u, n_blocks, cin, Cin); M.block(P, wcol, M.xa, s); }
-                else { M.request(M.xa, x, s + 1u, n_blocks, cin, Cin); M.block(P, wcol, M.xb, s); }
-            }
+        bool left = false;
+        for (uint32_t s = 0; s < n_steps; ++s) {
+            if (s >= 1u && s <= last_t_step && !PROF_SKIP(P, 256)) filter_a(s, 2u * s + 1u);
+            if (s < n_blocks && !PROF_SKIP(P, 64)) M.block(P, wcol, yring + ((s & 1u) * (uint32_t)kB) * LP + lane, s);
             P3_LAP(p3_work);
             lds_barrier();                                             // A
             P3_LAP(p3_wait);
@@ -429,98 +581,61 @@ __global__ __launch_bounds__(4 * kWave, 2) void demod_sym_kernel(Params P, State
                     const uint32_t v = fb[lane];
                     const bool new_locked = (v & 2u) != 0u;
                     if ((v & 1u) && new_locked != M.locked) {
-                        // the symbol's sample: 36 (s - 3) + off
-                        const uint32_t off = v >> 8;
-                        const uint32_t b = off >= 2u * (uint32_t)kB ? s - 1u : (off >= (uint32_t)kB ? s - 2u : s - 3u);
-                        const int fk = (int)(off % (uint32_t)kB);
-                        M.replay(P, wcol, b, fk, new_locked);
+                        const int64_t idx = sym_index(s - 1u, v >> 8);
+                        const uint32_t b = (uint32_t)(idx / kB);
+                        M.replay(P, wcol, b, (int)(idx - (int64_t)b * kB), new_locked);
                     }
-                    lds_barrier();                                     // B: the window is corrected
-                    lds_barrier();                                     // C: T has redone its step
+                    lds_barrier();                                     // B: the window is corrected, E has posted the positions again
+                    if (s >= 1u && s <= last_t_step) filter_a(s, 2u * s + 2u);
+                    lds_barrier();                                     // C: E has redone the step's symbol
                     P3_LAP(p3_fb);
                 }
             }
-            return s == stop_at;
-        };
-        bool left = false;
-        for (uint32_t s = 0; s < n_steps && !left; s += 2u) {
-            left = step(s, std::integral_constant<int, 0>{});
-            if (!left && s + 1u < n_steps) left = step(s + 1u, std::integral_constant<int, 1>{});
+            if (s == stop_at) { left = true; break; }
         }
         SYM_REPORT(0);
         if (left) return;                                              // handed over: this chunk's state is not needed
-        lds_barrier();                                                 // (T -> Y: final TED phase)
+        lds_barrier();                                                 // (E -> Y: final TED phase)
         M.store(P, S, c, C, counter1, wcol);
     } else if (role == 1u) {
-        // ------------------------------------------ T: one symbol per lane and step -----------------------------------
+        // ------------------------------------------ T: input prefetch and DC blocker of block s + 1; link events + wake-ups ----
         P3_HWID(1);
-        const uint32_t taps_lds = lds_addr(lds), wcol_lds = lds_addr(wcol);
+        SymDc<SampleT, CMODE> D;
+        D.xl = xl; D.avail = avail_l;
+        D.load(S, x, c, C, cin, Cin, counter0, n_blocks);
         Lane L;
-        lane_load(L, S, c);
-        const float inv_spt = 1.0f / P.samples_per_ted;
-        int cstar = next_fire_count(L.until_next_ted, L.ted_clock);
-        int rel = cstar - (int)L.ted_clock - 1;        // index of the next instant, relative to the end of the finished samples
-        // One pass over the wavefront: per lane the next symbol -- instant A (completes nothing: where B falls does not depend
-        // on A's sample) and instant B, or B alone right after a symsync.reset -- if both lie in finished samples; `single`:
-        // one instant whatever it is (the instants left over at the end of the input).  wb = ring slot of the sample at rel 0.
-        uint32_t hdr = 0;
-        float zero = 0.0f, sym = 0.0f, terr = 0.0f, next = 0.0f;
-        auto pass = [&](uint32_t wb, bool single, int off_base) __attribute__((always_inline)) {
-            const bool typeA = !single && (L.flags & F_TED_PHASE) != 0u;
-            const int p1 = rel;
-            const float rem1 = L.until_next_ted - (float)cstar;                      // receiver.rs:352
-            const float instA = L.period_inst + __builtin_amdgcn_fmed3f(rem1, -0.5f, 0.5f);   // rx/symsync.rs:236-241
-            const int c2 = next_fire_count(instA, 0u);
-            const int p2 = typeA ? p1 + c2 : p1;
-            const bool ready = p2 < 0;
-            if (__builtin_amdgcn_ballot_w64(ready) == 0ull) return;
-            SYM_T_BEGIN();
-            SYM_COUNT(13, 1);
-            auto slot = [&](int p) __attribute__((always_inline)) { int n = (int)wb + (ready ? p : -1); n += n < 0 ? RING : 0; return n; };
-            float sa1, sa2;
-            sym_demod2<RING>(taps_lds, wcol_lds, slot(p1), slot(p2), &sa1, &sa2);
-            SYM_T_LAP(15);
-            if (ready) {
-                float z, sy, te;
-                bool have;
-                if (typeA) {
-                    (void)ted_timing_relaxed(P, L, inv_spt, sa1, rem1, &z, &sy, &te);
-                    const float rem2 = L.until_next_ted - (float)c2;
-                    have = ted_timing_relaxed(P, L, inv_spt, sa2, rem2, &z, &sy, &te);
-                } else {
-                    have = ted_timing_relaxed(P, L, inv_spt, sa1, rem1, &z, &sy, &te);
-                }
-                cstar = next_fire_count(L.until_next_ted, 0u);
-                rel = p2 + cstar;
-                if (have) { hdr = 1u | ((uint32_t)(p2 + off_base) << 8); zero = z; sym = sy; terr = te; next = L.until_next_ted; }
-            }
-            SYM_T_LAP(16);
-        };
-        auto work = [&](uint32_t s) __attribute__((always_inline)) {
-            hdr = 0;
-            if (s <= n_blocks) {
-                pass((s % (uint32_t)LY::NBLK) * (uint32_t)kB, false, 2 * kB);
-            } else {
-                // the instants left before the end of the input, one at a time (rel is relative to it)
-                const uint32_t wb = (n_blocks % (uint32_t)LY::NBLK) * (uint32_t)kB;
-                while (__builtin_amdgcn_ballot_w64(rel < 0) != 0ull) pass(wb, true, kB);
-            }
-            lds_u32 *sb = symbox + (s & 1u) * LY::sym_words + lane;
-            sb[0] = hdr;
-            sb[kWave] = __float_as_uint(zero); sb[2 * kWave] = __float_as_uint(sym);
-            if (P.trace_cap) { sb[3 * kWave] = __float_as_uint(terr); sb[4 * kWave] = __float_as_uint(next); }
-        };
+        lane_load(L, S, c);      // the event half uses sq_symbols, tk_next, tk_last, wake_*, F_TICK_AGAIN
+        IoCtx X;
+        X.chunk = chunkbox;
+        chunkbox[0] = 0u; chunkbox[1] = kEvChunk;       // nothing reserved yet
+        X.pending_slot = 0xffffffffu;
+        // prologue: block 0's DC outputs
+        if (n_blocks > 1u) D.request(D.xb, x, 1u, n_blocks, cin, Cin);
+        D.block(P, yring + lane, D.xa, 0u);
+        lds_barrier();
         P3_T0();
         uint32_t stop_at = 0xffffffffu;
-        bool left = false;
-        for (uint32_t s = 0; s < n_steps; ++s) {
-            const bool active = s >= 1u && s <= n_blocks + 1u;
-            if (s >= 1u && s <= n_blocks) rel -= kB;                   // block s - 1 is finished
-            // this lane's state before the step's symbol, in case Y sends it back there
-            const float k_h0 = L.h0, k_h1 = L.h1, k_h2 = L.h2, k_avg = L.period_avg, k_inst = L.period_inst, k_unt = L.until_next_ted;
-            const uint32_t k_flags = L.flags;
-            const int k_cstar = cstar, k_rel = rel;
-            if (active && !PROF_SKIP(P, 32)) work(s);
+        auto step = [&](uint32_t s, auto buf) __attribute__((always_inline)) -> bool {
+            constexpr int BUF = decltype(buf)::value;                  // block s + 1 waits in buffer BUF = (s + 1) & 1
+            if (s + 1u < n_blocks && !PROF_SKIP(P, 128)) {
+                float *y = yring + (((s + 1u) & 1u) * (uint32_t)kB) * LP + lane;
+                if constexpr (BUF == 0) { D.request(D.xb, x, s + 2u, n_blocks, cin, Cin); D.block(P, y, D.xa, s + 1u); }
+                else { D.request(D.xa, x, s + 2u, n_blocks, cin, Cin); D.block(P, y, D.xb, s + 1u); }
+            }
+            // the link event and the wake-ups of what Y handed over in the last step
+            if (s >= 3u && !PROF_SKIP(P, 8)) {
+                const lds_u32 *io = iobox + ((s - 1u) & 1u) * LY::io_words + lane;
+                const uint32_t io0 = io[0];
+                if (io0 & 1u) {
+                    L.sq_symbols += 1;         // as rx_symbol counted it (rx/codesquelch.rs:232)
+                    const uint32_t link = (io0 >> 1) & 3u, off = (io0 >> 4) & 127u;
+                    const bool burst = (io0 & 8u) != 0u && link == 3u;
+                    uint32_t burst_len = 0;
+                    if (burst) { X.pending_slot = io[kWave]; burst_len = io[2 * kWave]; }
+                    const uint64_t counter = counter0 + (int64_t)row_l + (uint64_t)sym_index(s - 2u, off) + 1u;
+                    symbol_io(P, L, S, O, X, c, link, (io0 & 8u) != 0u, counter, burst_len);
+                }
+            }
             P3_LAP(p3_work);
             lds_barrier();                                             // A
             P3_LAP(p3_wait);
@@ -528,37 +643,22 @@ __global__ __launch_bounds__(4 * kWave, 2) void demod_sym_kernel(Params P, State
                 const lds_u32 *fb = fbbox + (s & 1u) * LY::fb_words;
                 const uint32_t fbw = (uint32_t)__builtin_amdgcn_readfirstlane((int)fb[kWave]);
                 if (fbw & 2u) stop_at = s + 1u;
-                if (fbw & 1u) {
-                    SYM_COUNT(14, 1);
-                    const uint32_t v = fb[lane];
-                    // every lane goes back (a lane without a change redoes its step over an unchanged window: same results)
-                    L.h0 = k_h0; L.h1 = k_h1; L.h2 = k_h2; L.period_avg = k_avg; L.period_inst = k_inst;
-                    L.until_next_ted = k_unt; L.flags = k_flags; cstar = k_cstar; rel = k_rel;
-                    if (v & 1u) {
-                        L.flags = (L.flags & ~F_BW_LOCKED) | ((v & 4u) ? F_BW_LOCKED : 0u);
-                        if (v & 8u) {                                    // end(): symsync.reset()
-                            L.flags &= ~F_TED_PHASE;
-                            L.h0 = 0.0f; L.h1 = 0.0f; L.h2 = 0.0f;
-                            L.period_avg = P.samples_per_ted; L.period_inst = P.samples_per_ted;
-                        }
-                    }
-                    lds_barrier();                                     // B: S has corrected the window
-                    if (active) work(s);
-                    lds_barrier();                                     // C
-                    P3_LAP(p3_fb);
-                }
+                if (fbw & 1u) { lds_barrier(); lds_barrier(); P3_LAP(p3_fb); }       // B, C: the others replay (the DC blocker never does)
             }
-            if (s == stop_at) { left = true; break; }
+            return s == stop_at;
+        };
+        bool left = false;
+        for (uint32_t s = 0; s < n_steps && !left; s += 2u) {
+            left = step(s, std::integral_constant<int, 1>{});          // block s + 1 is odd when s is even
+            if (!left && s + 1u < n_steps) left = step(s + 1u, std::integral_constant<int, 0>{});
         }
         SYM_REPORT(1);
-        SYM_COUNT(12, n_steps);
+        X.retire(O, lane, kWave);
         if (left) return;
-        phasebox[lane] = L.flags & F_TED_PHASE;
-        lds_barrier();                                                 // Y merges the phase bit
-        L.ted_clock = (uint32_t)(cstar - rel - 1);
-        S.until_next_ted[c] = L.until_next_ted; S.ted_clock[c] = L.ted_clock;
-        S.ted_h0[c] = L.h0; S.ted_h1[c] = L.h1; S.ted_h2[c] = L.h2;
-        S.period_avg[c] = L.period_avg; S.period_inst[c] = L.period_inst;
+        againbox[lane] = L.flags & F_TICK_AGAIN;
+        lds_barrier();                                                 // Y merges the flag bits
+        D.store(S, c, C, counter1);
+        S.tk_next[c] = L.tk_next; S.tk_last[c] = L.tk_last; S.wake_fired[c] = L.wake_fired;
     } else if (role == 2u) {
         // ------------------------------------------ Y: symbol path --------------------------------------------------
         P3_HWID(2);
@@ -566,7 +666,8 @@ __global__ __launch_bounds__(4 * kWave, 2) void demod_sym_kernel(Params P, State
         lane_load(L, S, c);
         L.ended = 0u;
         RelaxFastCtx<NFF, NFB> X;
-        X.hist = hcol;
+        X.hist = S.sq_hist + c;                                        // the squelch's sample history stays in the state array
+        X.hstride = C;
         P3_MARKS_BEGIN(X, lds, NT);
 #pragma unroll
         for (int i = 0; i < NFF; ++i) {
@@ -578,8 +679,7 @@ __global__ __launch_bounds__(4 * kWave, 2) void demod_sym_kernel(Params P, State
             X.fbc[i] = S.eq_fbc[i * C + c]; X.fbw[i] = S.eq_fbw[i * C + c];
             X.sfbc[i] = S.eq_snap_fbc[i * C + c]; X.sfbw[i] = S.eq_snap_fbw[i * C + c];
         }
-#pragma unroll 2
-        for (int i = 0; i < kSquelchHist; ++i) { const float *row = S.sq_hist + (size_t)i * C; hcol[i * LP] = row[c]; }
+        lds_barrier();                                                 // prologue
         P3_T0();
         uint32_t stop_at = 0xffffffffu;
         bool left = false, lane_done = false, leave_posted = false;
@@ -588,8 +688,8 @@ __global__ __launch_bounds__(4 * kWave, 2) void demod_sym_kernel(Params P, State
             if (s >= 2u && s <= last_fb_step) {
                 const uint32_t blk = min(s - 2u, n_blocks - 1u);       // every symbol up to the end of this block has been seen after this step
                 const lds_u32 *sb = symbox + ((s - 1u) & 1u) * LY::sym_words + lane;
-                // everything this step reads from LDS in one round trip: the symbol T handed on and the two history samples
-                // its equalizer step takes (rx_symbol: slots +16/+17 from the squelch's write position)
+                // the two history samples the symbol's equalizer step takes (rx_symbol: slots +16/+17 from the squelch's write
+                // position), fetched ahead of their use; only a symbol writes the history, so they cannot go stale
                 const uint32_t pslot = (uint32_t)(2u * (uint32_t)L.sq_symbols) & 63u;
                 const float pre0 = X.hist_get((pslot + 16u) & 63u), pre1 = X.hist_get((pslot + 17u) & 63u);
                 const uint32_t hdr = sb[0], zero_w = sb[kWave], sym_w = sb[2 * kWave];
@@ -604,8 +704,8 @@ __global__ __launch_bounds__(4 * kWave, 2) void demod_sym_kernel(Params P, State
                     L.ended = 0u;
                     uint32_t burst_len = 0;
                     bool emit = false;
-                    // sample index 36 (s - 3) + off; the counter is that of the sample after it
-                    const uint64_t counter = counter0 + (int64_t)row_l + (uint64_t)((int64_t)kB * ((int64_t)s - 3) + (int64_t)off) + 1u;
+                    // the counter is that of the sample after the symbol's
+                    const uint64_t counter = counter0 + (int64_t)row_l + (uint64_t)sym_index(s - 1u, off) + 1u;
                     const uint32_t link = symbol_link(P, L, S, X, c, zero, sym, terr, unt, counter, &burst_len, &emit, true, pre0, pre1);
                     want_slot = emit && link == 3u;
                     io0 = 1u | (link << 1) | (emit ? 8u : 0u) | (off << 4);
@@ -689,33 +789,87 @@ __global__ __launch_bounds__(4 * kWave, 2) void demod_sym_kernel(Params P, State
             S.eq_fbc[i * C + c] = X.fbc[i]; S.eq_fbw[i * C + c] = X.fbw[i];
             S.eq_snap_fbc[i * C + c] = X.sfbc[i]; S.eq_snap_fbw[i * C + c] = X.sfbw[i];
         }
-#pragma unroll 2
-        for (int i = 0; i < kSquelchHist; ++i) { float *row = S.sq_hist + (size_t)i * C; row[c] = hcol[i * LP]; }
     } else {
-        // ------------------------------------------ E: link events + wake-ups ----------------------------------------
-        Lane L;
-        lane_load(L, S, c);      // uses sq_symbols, tk_next, tk_last, wake_*, F_TICK_AGAIN
+        // ------------------------------------------ E: one symbol per lane and step: matched filters, timing loop --------
         P3_HWID(3);
-        IoCtx X;
-        X.chunk = chunkbox;
-        chunkbox[0] = 0u; chunkbox[1] = kEvChunk;       // nothing reserved yet
-        X.pending_slot = 0xffffffffu;
+        const uint32_t taps_lds = lds_addr(lds), wcol_lds = lds_addr(wcol);
+        Lane L;
+        lane_load(L, S, c);
+        const float inv_spt = 1.0f / P.samples_per_ted;
+        int cstar = next_fire_count(L.until_next_ted, L.ted_clock);
+        int rel = cstar - (int)L.ted_clock - 1;        // index of the next instant, relative to the end of the finished samples
+        // The plan of step s, made at the end of step s - 1 (or again after a feedback): per lane the next symbol -- instant A
+        // (completes nothing: where B falls does not depend on A's sample) and instant B, or B alone right after a
+        // symsync.reset -- if both lie in finished samples; in the steps after the last block: one instant whatever it is.
+        // S filters at A (where there is one), this wavefront at B.
+        bool pl_typeA = false, pl_ready = false, pl_single = false;
+        int pl_p2 = 0, pl_c2 = 0;
+        uint32_t pl_n2 = 0;
+        float pl_rem1 = 0.0f, pl_instA = 0.0f;
+        auto plan = [&](uint32_t s) __attribute__((always_inline)) {
+            pl_single = s > n_blocks;
+            const uint32_t wb = (min(s, n_blocks) % (uint32_t)LY::NBLK) * (uint32_t)kB;      // ring slot of the sample at rel 0
+            pl_typeA = !pl_single && (L.flags & F_TED_PHASE) != 0u;
+            pl_rem1 = L.until_next_ted - (float)cstar;                                 // receiver.rs:352
+            pl_instA = L.period_inst + __builtin_amdgcn_fmed3f(pl_rem1, -0.5f, 0.5f);   // rx/symsync.rs:236-241
+            pl_c2 = next_fire_count(pl_instA, 0u);
+            pl_p2 = pl_typeA ? rel + pl_c2 : rel;
+            pl_ready = pl_p2 < 0 && s >= 1u && s <= last_t_step;
+            auto slot = [&](int p) __attribute__((always_inline)) { int n = (int)wb + p; n += n < 0 ? RING : 0; return (uint32_t)n; };
+            pl_n2 = pl_ready ? slot(pl_p2) : 0u;
+            posbox[(s & 1u) * LY::pos_words + lane] = (pl_ready && pl_typeA) ? slot(rel) : 0xffffffffu;
+        };
+        auto work = [&](uint32_t s, uint32_t seq) __attribute__((always_inline)) {
+            uint32_t hdr = 0;
+            float zero = 0.0f, sym = 0.0f, terr = 0.0f, next = 0.0f;
+            if (__builtin_amdgcn_ballot_w64(pl_ready) != 0ull) {
+                SYM_T_BEGIN();
+                SYM_COUNT(13, 1);
+                const float sa2 = sym_demod1<RING>(taps_lds, wcol_lds, (int)pl_n2);
+                SYM_T_LAP(15);
+                float sa1 = 0.0f;
+                if (__builtin_amdgcn_ballot_w64(pl_ready && pl_typeA) != 0ull) {
+                    while ((int32_t)(seqbox[0] - seq) < 0) {}           // S has posted this pass
+                    sa1 = __uint_as_float(sabox[lane]);
+                }
+                SYM_T_LAP(17);
+                if (pl_ready) {
+                    float z, sy, te;
+                    bool have;
+                    if (pl_typeA) {
+                        // ZeroCrossingTed::input + TimingLoop::input without a symbol, rx/symsync.rs:236-241, 278-287
+                        L.h0 = L.h1; L.h1 = L.h2; L.h2 = sa1;
+                        L.flags ^= F_TED_PHASE;
+                        L.period_inst = pl_instA; L.until_next_ted = pl_instA;
+                        have = ted_timing_relaxed(P, L, inv_spt, sa2, pl_instA - (float)pl_c2, &z, &sy, &te);
+                    } else {
+                        have = ted_timing_relaxed(P, L, inv_spt, sa2, pl_rem1, &z, &sy, &te);
+                    }
+                    cstar = next_fire_count(L.until_next_ted, 0u);
+                    rel = pl_p2 + cstar;
+                    if (have) { hdr = 1u | ((uint32_t)(pl_p2 + (pl_single ? 3 * kB : 2 * kB)) << 8); zero = z; sym = sy; terr = te; next = L.until_next_ted; }
+                }
+                SYM_T_LAP(16);
+            }
+            lds_u32 *sb = symbox + (s & 1u) * LY::sym_words + lane;
+            sb[0] = hdr;
+            sb[kWave] = __float_as_uint(zero); sb[2 * kWave] = __float_as_uint(sym);
+            if (P.trace_cap) { sb[3 * kWave] = __float_as_uint(terr); sb[4 * kWave] = __float_as_uint(next); }
+        };
+        plan(0u);                                                      // (nothing: step 0 finishes no symbol)
+        lds_barrier();                                                 // prologue
+        P3_T0();
         uint32_t stop_at = 0xffffffffu;
         bool left = false;
-        P3_T0();
         for (uint32_t s = 0; s < n_steps; ++s) {
-            if (s >= 3u && !PROF_SKIP(P, 8)) {
-                const lds_u32 *io = iobox + ((s - 1u) & 1u) * LY::io_words + lane;
-                const uint32_t io0 = io[0];
-                if (io0 & 1u) {
-                    L.sq_symbols += 1;         // as rx_symbol counted it (rx/codesquelch.rs:232)
-                    const uint32_t link = (io0 >> 1) & 3u, off = (io0 >> 4) & 127u;
-                    const bool burst = (io0 & 8u) != 0u && link == 3u;
-                    uint32_t burst_len = 0;
-                    if (burst) { X.pending_slot = io[kWave]; burst_len = io[2 * kWave]; }
-                    const uint64_t counter = counter0 + (int64_t)row_l + (uint64_t)((int64_t)kB * ((int64_t)s - 4) + (int64_t)off) + 1u;
-                    symbol_io(P, L, S, O, X, c, link, (io0 & 8u) != 0u, counter, burst_len);
-                }
+            // this lane's state before the step's symbol, in case Y sends it back there
+            const float k_h0 = L.h0, k_h1 = L.h1, k_h2 = L.h2, k_avg = L.period_avg, k_inst = L.period_inst, k_unt = L.until_next_ted;
+            const uint32_t k_flags = L.flags;
+            const int k_cstar = cstar, k_rel = rel;
+            if (!PROF_SKIP(P, 32)) {
+                work(s, 2u * s + 1u);
+                if (s + 1u <= n_blocks) rel -= kB;                     // block s is finished when step s + 1 begins
+                plan(s + 1u);
             }
             P3_LAP(p3_work);
             lds_barrier();                                             // A
@@ -724,16 +878,40 @@ __global__ __launch_bounds__(4 * kWave, 2) void demod_sym_kernel(Params P, State
                 const lds_u32 *fb = fbbox + (s & 1u) * LY::fb_words;
                 const uint32_t fbw = (uint32_t)__builtin_amdgcn_readfirstlane((int)fb[kWave]);
                 if (fbw & 2u) stop_at = s + 1u;
-                if (fbw & 1u) { lds_barrier(); lds_barrier(); P3_LAP(p3_fb); }       // B, C
+                if (fbw & 1u) {
+                    SYM_COUNT(14, 1);
+                    const uint32_t v = fb[lane];
+                    // every lane goes back (a lane without a change redoes its step over an unchanged window: same results)
+                    L.h0 = k_h0; L.h1 = k_h1; L.h2 = k_h2; L.period_avg = k_avg; L.period_inst = k_inst;
+                    L.until_next_ted = k_unt; L.flags = k_flags; cstar = k_cstar; rel = k_rel;
+                    if (v & 1u) {
+                        L.flags = (L.flags & ~F_BW_LOCKED) | ((v & 4u) ? F_BW_LOCKED : 0u);
+                        if (v & 8u) {                                    // end(): symsync.reset()
+                            L.flags &= ~F_TED_PHASE;
+                            L.h0 = 0.0f; L.h1 = 0.0f; L.h2 = 0.0f;
+                            L.period_avg = P.samples_per_ted; L.period_inst = P.samples_per_ted;
+                        }
+                    }
+                    plan(s);                                           // S filters again, at these positions
+                    lds_barrier();                                     // B: S has corrected the window
+                    work(s, 2u * s + 2u);
+                    if (s + 1u <= n_blocks) rel -= kB;
+                    plan(s + 1u);
+                    lds_barrier();                                     // C
+                    P3_LAP(p3_fb);
+                }
             }
             if (s == stop_at) { left = true; break; }
         }
         SYM_REPORT(3);
-        X.retire(O, lane, kWave);
+        SYM_COUNT(12, n_steps);
         if (left) return;
-        againbox[lane] = L.flags & F_TICK_AGAIN;
-        lds_barrier();                                                 // Y merges the flag bits
-        S.tk_next[c] = L.tk_next; S.tk_last[c] = L.tk_last; S.wake_fired[c] = L.wake_fired;
+        phasebox[lane] = L.flags & F_TED_PHASE;
+        lds_barrier();                                                 // Y merges the phase bit
+        L.ted_clock = (uint32_t)(cstar - rel - 1);
+        S.until_next_ted[c] = L.until_next_ted; S.ted_clock[c] = L.ted_clock;
+        S.ted_h0[c] = L.h0; S.ted_h1[c] = L.h1; S.ted_h2[c] = L.h2;
+        S.period_avg[c] = L.period_avg; S.period_inst[c] = L.period_inst;
     }
 }
 

@@ -9,6 +9,7 @@ import sameold_amd as sa
 
 
 def split(ev, n_ch):
+    ev = ev[np.lexsort((np.arange(len(ev)), ev["channel"]))]        # (several calls: each harvest is ordered by channel)
     first = np.searchsorted(ev["channel"], np.arange(n_ch + 1))
     return [ev[first[c]:first[c + 1]] for c in range(n_ch)]
 
@@ -100,7 +101,7 @@ def prof(rx):
     names = ["S sample", "T timing", "Y symbol", "E events"]
     for r in range(4):
         print(f"  {names[r]:9s} work {v[3*r]/steps:8.1f}  barrier wait {v[3*r+1]/steps:8.1f}  feedback {v[3*r+2]/steps:8.1f}  clk/step")
-    print(f"  steps {steps}, T passes {v[13]}, feedback rounds {v[14]} ({100.0*v[14]/steps:.1f} % of steps); T filters {v[15]/max(v[13],1):.0f} clk/pass, timing+post {v[16]/max(v[13],1):.0f} clk/pass", flush=True)
+    print(f"  steps {steps}, T passes {v[13]}, feedback rounds {v[14]} ({100.0*v[14]/steps:.1f} % of steps); E's filter {v[15]/max(v[13],1):.0f} clk/pass, waiting for S's {v[17]/max(v[13],1):.0f}, timing+post {v[16]/max(v[13],1):.0f} clk/pass", flush=True)
 
 
 what = sys.argv[1] if len(sys.argv) > 1 else "all"
