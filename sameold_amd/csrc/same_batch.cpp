@@ -222,6 +222,7 @@ struct same_batch {
         uint32_t n_desc = 0;
         uint32_t *d_final_col = nullptr;
         float *d_energy = nullptr; size_t energy_cap = 0;   // scout scratch
+        float *d_hist = nullptr; size_t hist_cap = 0;       // squelch histories by grid position (PipeChunks::hist_scratch)
         hipEvent_t ev_plan_prev = nullptr; bool plan_recorded = false;
         int knob_plan_stream = 0;                            // SAME_TP_PLAN_STREAM=0: planning kernels stay on the launch stream (A/B measurements)
         int sort_mode = -1;                                  // SAME_TP_SORT: -1 choose, 0 grid order, 1 pieces sorted by length into workgroups
@@ -1139,6 +1140,17 @@ int process_channel_major_native(same_batch *rx, const float *d_x, size_t n, hip
     pc.handover = sl.d_handover;
     pc.col_row0 = d_row0; pc.col_nominal = d_nom; pc.wg_blocks = d_wg; pc.col_perm = sort_mode != 0 ? d_perm : nullptr;
     pc.in_samples = n; pc.whole_samples = (uint32_t)n;
+    pc.hist_scratch = nullptr;
+    if (pc.col_perm && tp.kernel == same_batch::TimePar::kPipeRelaxed && same::sym_kernel_supported(tp.Pv)) {
+        const size_t h_need = (size_t)columns * same::kSquelchHist;
+        if (tp.hist_cap < h_need) {
+            if (tp.d_hist) HIP_TRY(hipFree(tp.d_hist));
+            tp.d_hist = nullptr; tp.hist_cap = 0;
+            HIP_TRY(hipMalloc((void **)&tp.d_hist, h_need * sizeof(float)));
+            tp.hist_cap = h_need;
+        }
+        pc.hist_scratch = tp.d_hist;
+    }
     sl.have_k = rx->timing;
     if (rx->timing) HIP_TRY(hipEventRecord(sl.ev_k0, stream));
     hipError_t e = wave ? same::launch_demod_relaxed(tp.Pv, tp.Sv, O, rx->d_taps, d_x, (uint32_t)(n / fb), rx->counter, stream, pc)
@@ -1367,6 +1379,7 @@ void same_batch_free(same_batch *rx)
     if (rx->tp.d_desc_out) (void)hipFree(rx->tp.d_desc_out);
     if (rx->tp.d_final_col) (void)hipFree(rx->tp.d_final_col);
     if (rx->tp.d_energy) (void)hipFree(rx->tp.d_energy);
+    if (rx->tp.d_hist) (void)hipFree(rx->tp.d_hist);
     if (rx->tp.ev_plan_prev) (void)hipEventDestroy(rx->tp.ev_plan_prev);
     if (rx->copy_stream) (void)hipStreamDestroy(rx->copy_stream);
     if (rx->plan_stream) (void)hipStreamDestroy(rx->plan_stream);

@@ -149,6 +149,9 @@ struct PipeChunks {
     const uint32_t *wg_blocks;     // [workgroups]
     const uint32_t *col_perm;      // [n_chunks * in_channels] grid position -> state column (pieces of similar length share a
                                    // workgroup; chunk 0 and last-chunk columns keep workgroups of their own), null = identity
+    float *hist_scratch;           // with col_perm: [kSquelchHist][n_chunks * in_channels] by GRID POSITION, or null.  A kernel that keeps
+                                   // the squelch's sample history in global memory (same_kernels_sym.hip) works on this copy: a
+                                   // wavefront's permuted columns are 64 different cache lines per access of the state array
     uint64_t in_samples;           // channel-major input: samples per channel (the pitch of a channel)
     uint32_t whole_samples;        // samples of the call that are whole blocks
 };

@@ -666,8 +666,15 @@ __global__ __launch_bounds__(4 * kWave, 2) void demod_sym_kernel(Params P, State
         lane_load(L, S, c);
         L.ended = 0u;
         RelaxFastCtx<NFF, NFB> X;
-        X.hist = S.sq_hist + c;                                        // the squelch's sample history stays in the state array
+        // the squelch's sample history stays in global memory: the state array itself, or -- where the columns of a wavefront
+        // are permuted -- a copy by grid position (coalesced; the state array is read and written once per launch)
+        const bool hist_copy = K.n_chunks > 1u && K.col_perm != nullptr && K.hist_scratch != nullptr;
+        X.hist = hist_copy ? K.hist_scratch + (blockIdx.x * kWave + lane) : S.sq_hist + c;
         X.hstride = C;
+        if (hist_copy) {
+#pragma unroll 4
+            for (int i = 0; i < kSquelchHist; ++i) X.hist[(size_t)i * C] = S.sq_hist[(size_t)i * C + c];
+        }
         P3_MARKS_BEGIN(X, lds, NT);
 #pragma unroll
         for (int i = 0; i < NFF; ++i) {
@@ -679,6 +686,11 @@ __global__ __launch_bounds__(4 * kWave, 2) void demod_sym_kernel(Params P, State
             X.fbc[i] = S.eq_fbc[i * C + c]; X.fbw[i] = S.eq_fbw[i * C + c];
             X.sfbc[i] = S.eq_snap_fbc[i * C + c]; X.sfbw[i] = S.eq_snap_fbw[i * C + c];
         }
+        float pre0, pre1;
+        {
+            const uint32_t pslot = (uint32_t)(2u * (uint32_t)L.sq_symbols) & 63u;
+            pre0 = X.hist_get((pslot + 16u) & 63u); pre1 = X.hist_get((pslot + 17u) & 63u);
+        }
         lds_barrier();                                                 // prologue
         P3_T0();
         uint32_t stop_at = 0xffffffffu;
@@ -688,10 +700,8 @@ __global__ __launch_bounds__(4 * kWave, 2) void demod_sym_kernel(Params P, State
             if (s >= 2u && s <= last_fb_step) {
                 const uint32_t blk = min(s - 2u, n_blocks - 1u);       // every symbol up to the end of this block has been seen after this step
                 const lds_u32 *sb = symbox + ((s - 1u) & 1u) * LY::sym_words + lane;
-                // the two history samples the symbol's equalizer step takes (rx_symbol: slots +16/+17 from the squelch's write
-                // position), fetched ahead of their use; only a symbol writes the history, so they cannot go stale
-                const uint32_t pslot = (uint32_t)(2u * (uint32_t)L.sq_symbols) & 63u;
-                const float pre0 = X.hist_get((pslot + 16u) & 63u), pre1 = X.hist_get((pslot + 17u) & 63u);
+                // (pre0 / pre1: the two history samples the symbol's equalizer step takes, rx_symbol: slots +16/+17 from the
+                // squelch's write position -- fetched at the end of the step before, see below)
                 const uint32_t hdr = sb[0], zero_w = sb[kWave], sym_w = sb[2 * kWave];
                 uint32_t fbv = 0, io0 = 0, io1 = 0xffffffffu, io2 = 0;
                 bool want_slot = false;                                // this lane has just finished a burst
@@ -744,6 +754,13 @@ __global__ __launch_bounds__(4 * kWave, 2) void demod_sym_kernel(Params P, State
                         }
                     }
                 }
+                // The history samples of this lane's NEXT symbol, whenever it comes: global memory is a step away (1-2 us under
+                // load), so they are requested now.  Only this lane's own symbols write its history, and never those two slots
+                // (the next symbol writes slots +0/+1 of its position, these are +16/+17): they cannot go stale.
+                {
+                    const uint32_t pslot = (uint32_t)(2u * (uint32_t)L.sq_symbols) & 63u;
+                    pre0 = X.hist_get((pslot + 16u) & 63u); pre1 = X.hist_get((pslot + 17u) & 63u);
+                }
                 lds_u32 *io = iobox + (s & 1u) * LY::io_words + lane;
                 io[0] = io0;
                 if (__builtin_amdgcn_ballot_w64((io0 & 8u) != 0u && ((io0 >> 1) & 3u) == 3u) != 0ull) { io[kWave] = io1; io[2 * kWave] = io2; }
@@ -770,6 +787,8 @@ __global__ __launch_bounds__(4 * kWave, 2) void demod_sym_kernel(Params P, State
             if (s == stop_at) { left = true; break; }
         }
         SYM_REPORT(2);
+        SYM_COUNT(18, 1);                                              // launches of workgroup 0 ...
+        SYM_COUNT(19, left ? stop_at + 1u : n_steps);                  // ... and the steps they ran
         P3_MARKS_REPORT(X);
         if (left) return;
         lds_barrier();                                                 // T's TED phase, E's wake-up flag
@@ -779,6 +798,10 @@ __global__ __launch_bounds__(4 * kWave, 2) void demod_sym_kernel(Params P, State
         S.eq_word[c] = L.eq_word; S.eq_count[c] = L.eq_count;
         S.fr_word[c] = L.fr_word; S.fr_count[c] = L.fr_count; S.fr_invalid[c] = L.fr_invalid;
         S.fr_len[c] = L.fr_len; S.flags[c] = L.flags;
+        if (hist_copy) {
+#pragma unroll 4
+            for (int i = 0; i < kSquelchHist; ++i) S.sq_hist[(size_t)i * C + c] = X.hist[(size_t)i * C];
+        }
 #pragma unroll
         for (int i = 0; i < NFF; ++i) {
             S.eq_ffc[i * C + c] = X.ffc[i]; S.eq_ffw[i * C + c] = X.ffw[i];
@@ -802,6 +825,7 @@ __global__ __launch_bounds__(4 * kWave, 2) void demod_sym_kernel(Params P, State
         // (completes nothing: where B falls does not depend on A's sample) and instant B, or B alone right after a
         // symsync.reset -- if both lie in finished samples; in the steps after the last block: one instant whatever it is.
         // S filters at A (where there is one), this wavefront at B.
+        SYM_T_DECL();
         bool pl_typeA = false, pl_ready = false, pl_single = false;
         int pl_p2 = 0, pl_c2 = 0;
         uint32_t pl_n2 = 0;
@@ -824,7 +848,7 @@ __global__ __launch_bounds__(4 * kWave, 2) void demod_sym_kernel(Params P, State
             float zero = 0.0f, sym = 0.0f, terr = 0.0f, next = 0.0f;
             if (__builtin_amdgcn_ballot_w64(pl_ready) != 0ull) {
                 SYM_T_BEGIN();
-                SYM_COUNT(13, 1);
+                SYM_TCOUNT(13, 1);
                 const float sa2 = sym_demod1<RING>(taps_lds, wcol_lds, (int)pl_n2);
                 SYM_T_LAP(15);
                 float sa1 = 0.0f;
@@ -879,7 +903,7 @@ __global__ __launch_bounds__(4 * kWave, 2) void demod_sym_kernel(Params P, State
                 const uint32_t fbw = (uint32_t)__builtin_amdgcn_readfirstlane((int)fb[kWave]);
                 if (fbw & 2u) stop_at = s + 1u;
                 if (fbw & 1u) {
-                    SYM_COUNT(14, 1);
+                    SYM_TCOUNT(14, 1);
                     const uint32_t v = fb[lane];
                     // every lane goes back (a lane without a change redoes its step over an unchanged window: same results)
                     L.h0 = k_h0; L.h1 = k_h1; L.h2 = k_h2; L.period_avg = k_avg; L.period_inst = k_inst;
@@ -904,6 +928,7 @@ __global__ __launch_bounds__(4 * kWave, 2) void demod_sym_kernel(Params P, State
             if (s == stop_at) { left = true; break; }
         }
         SYM_REPORT(3);
+        SYM_T_REPORT();
         SYM_COUNT(12, n_steps);
         if (left) return;
         phasebox[lane] = L.flags & F_TED_PHASE;

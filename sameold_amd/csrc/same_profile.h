@@ -67,8 +67,12 @@ namespace same { static __device__ unsigned long long g_same_prof_sym[20]; }
 #define SYM_REPORT(role_) do { if (blockIdx.x == 0 && lane == 0) { same::g_same_prof_sym[3 * (role_)] += p3_work; \
         same::g_same_prof_sym[3 * (role_) + 1] += p3_wait; same::g_same_prof_sym[3 * (role_) + 2] += p3_fb; } } while (0)
 #define SYM_COUNT(i_, n_) do { if (blockIdx.x == 0 && lane == 0) same::g_same_prof_sym[i_] += (n_); } while (0)
-#define SYM_T_BEGIN() unsigned long long symt_t = clock64()
-#define SYM_T_LAP(i_) do { const unsigned long long t_ = clock64(); if (blockIdx.x == 0 && lane == 0) same::g_same_prof_sym[i_] += t_ - symt_t; symt_t = t_; } while (0)
+#define SYM_TCOUNT(i_, n_) do { symt_n[(i_) - 13] += (n_); } while (0)
+#define SYM_T_DECL() unsigned long long symt_acc[3] = {0, 0, 0}, symt_n[2] = {0, 0}, symt_t = 0
+#define SYM_T_BEGIN() do { symt_t = clock64(); } while (0)
+#define SYM_T_LAP(i_) do { const unsigned long long t_ = clock64(); symt_acc[(i_) - 15] += t_ - symt_t; symt_t = t_; } while (0)
+#define SYM_T_REPORT() do { if (blockIdx.x == 0 && lane == 0) { for (int i_ = 0; i_ < 3; ++i_) same::g_same_prof_sym[15 + i_] += symt_acc[i_]; \
+        same::g_same_prof_sym[13] += symt_n[0]; same::g_same_prof_sym[14] += symt_n[1]; } } while (0)
 #define SYM_PROFILE_EXPORTS()                                                                                   \
     extern "C" int same_debug_profile_sym(unsigned long long *out20, int reset)                                 \
     {                                                                                                           \
@@ -140,8 +144,11 @@ namespace same { struct ProfMarks { __device__ __forceinline__ void mark(int) {}
 #define PIPE_PROF_TAP_PAD 0
 #define SYM_REPORT(role_) do {} while (0)
 #define SYM_COUNT(i_, n_) do {} while (0)
+#define SYM_TCOUNT(i_, n_) do {} while (0)
+#define SYM_T_DECL() do {} while (0)
 #define SYM_T_BEGIN() do {} while (0)
 #define SYM_T_LAP(i_) do {} while (0)
+#define SYM_T_REPORT() do {} while (0)
 #define SYM_PROFILE_EXPORTS()
 #define FAST_MARKS_BEGIN(X_, lds_, nt_) do {} while (0)
 #define FAST_MARKS_START(X_) do {} while (0)
