@@ -669,7 +669,7 @@ def main():
                 # -- 4 pieces per channel = 131 072 state columns on the relaxed kernel of same_kernels_relaxed.hip
                 try:
                     Tl = int(args.rate * 10)
-                    Tl -= Tl % 420
+                    Tl -= Tl % 1260
                     x4 = sa.synth_afsk(Cs, Tl, args.rate, seed=779, device=local_rank)
                     x4c = x4.t().contiguous()
                     del x4

@@ -1062,8 +1062,11 @@ int process_channel_major_native(same_batch *rx, const float *d_x, size_t n, hip
     Pv.n_channels = columns; Pv.ticks = 0; Pv.trace_cap = 0; Pv.knob_pipe = 1;
     if (tp.kernel == same_batch::TimePar::kPipeRelaxed) { Pv.knob_pipe_lanes = 64; Pv.knob_pipe_share = 1; Pv.knob_pipe_split = 1; }
     // 16-byte loads from every lane's stream (the scout's too: 16-byte aligned base and pitch; the relaxed kernel reads
-    // 8 bytes at a time from even rows), whole blocks only, full 64-column workgroups
-    if (n % fb != 0 || n % 4 != 0 || ((uintptr_t)d_x & 15u) != 0u || n < 64u * 256u || n / 256 > 7000u || n_chunks > 63u || C % same::kWave != 0u) return 0;
+    // 8 bytes at a time from even rows), full 64-column workgroups.  What is left of the call behind its last whole block
+    // (less than a block) goes through the any-configuration kernel on the channels' own state afterwards.
+    const size_t n_call = n;
+    n -= n % fb;
+    if (n_call % 4 != 0 || ((uintptr_t)d_x & 15u) != 0u || n < 64u * 256u || n / 256 > 7000u || n_chunks > 63u || C % same::kWave != 0u) return 0;
     if (wave ? fb % 2 != 0 : (fb % 4 != 0 || same::pipe_workgroup_channels(Pv) != (uint32_t)same::kWave)) return 0;
     same_batch::Slot &sl = rx->slot[rx->launch_seq & 1];
     same_batch::Slot &prev = rx->slot[(rx->launch_seq & 1) ^ 1];
@@ -1095,7 +1098,7 @@ int process_channel_major_native(same_batch *rx, const float *d_x, size_t n, hip
         const uint32_t warm = tp.warmup ? tp.warmup : (uint32_t)(40.0 * sps + 0.5);
         plan.warmup_samples = std::min(geom.warmup_blocks, (warm + fb - 1u) / fb) * fb;
     }
-    plan.whole_samples = (uint32_t)n; plan.in_samples = n;
+    plan.whole_samples = (uint32_t)n; plan.in_samples = n_call;
     plan.scout_blocks = (uint32_t)(n / 256);
     const size_t e_need = (size_t)C * plan.scout_blocks;
     if (tp.energy_cap < e_need) {
@@ -1139,7 +1142,7 @@ int process_channel_major_native(same_batch *rx, const float *d_x, size_t n, hip
     HIP_TRY(same::launch_fill_u64(sl.d_handover, columns, same::kNoHandover, stream));
     pc.handover = sl.d_handover;
     pc.col_row0 = d_row0; pc.col_nominal = d_nom; pc.wg_blocks = d_wg; pc.col_perm = sort_mode != 0 ? d_perm : nullptr;
-    pc.in_samples = n; pc.whole_samples = (uint32_t)n;
+    pc.in_samples = n_call; pc.whole_samples = (uint32_t)n;
     pc.hist_scratch = nullptr;
     if (pc.col_perm && tp.kernel == same_batch::TimePar::kPipeRelaxed && same::sym_kernel_supported(tp.Pv)) {
         const size_t h_need = (size_t)columns * same::kSquelchHist;
@@ -1163,6 +1166,18 @@ int process_channel_major_native(same_batch *rx, const float *d_x, size_t n, hip
     // call without a hand-over (a forced cut on a channel that is never quiet: its events are the ones that are kept).
     HIP_TRY(same::launch_chunk_final_column_pc(sl.d_handover, d_own, C, n_chunks, rx->counter, tp.d_final_col, stream));
     HIP_TRY(same::launch_copy_state_columns(tp.d_desc_out, tp.n_desc, columns, C, tp.d_final_col, C, stream));
+    if (n < n_call) {
+        // less than a block is left: its [C][r] corner of the input transposed to rows, then the any-configuration kernel
+        const size_t r = n_call - n;
+        int rc2 = ensure_stage(&rx->d_stage, &rx->stage_bytes, r * C * sizeof(float));
+        if (rc2) return rc2;
+        rc2 = ensure_stage(&rx->d_stage2, &rx->stage2_bytes, r * C * sizeof(float));
+        if (rc2) return rc2;
+        HIP_TRY(hipMemcpy2DAsync(rx->d_stage, r * sizeof(float), d_x + n, n_call * sizeof(float), r * sizeof(float), C, hipMemcpyDeviceToDevice, stream));
+        hipError_t e2 = same::launch_transpose_f32((const float *)rx->d_stage, (float *)rx->d_stage2, C, (uint32_t)r, stream);
+        if (e2 == hipSuccess) e2 = same::launch_demod(rx->P, rx->S, O, rx->d_taps, (const float *)rx->d_stage2, (uint32_t)r, rx->counter + n, stream);
+        if (e2 != hipSuccess) return fail(SAME_EHIP, "demod kernel launch failed: %s", hipGetErrorString(e2));
+    }
     sl.chunked = true; sl.per_channel = true;
     sl.geom = geom;
     sl.end_blocks = rx->counter + n;
@@ -1174,7 +1189,7 @@ int process_channel_major_native(same_batch *rx, const float *d_x, size_t n, hip
     sl.in_flight = true;
     sl.seq = ++rx->launch_seq;
     rx->last_stream = stream;
-    rx->counter += n;
+    rx->counter += n_call;
     sl.end_counter = rx->counter;
     tp.last_chunks = n_chunks; tp.last_per_channel = true;
     rc = harvest_slot(rx, prev);          // while this launch runs, bring in the previous one
@@ -1196,6 +1211,10 @@ int process_device_any(same_batch *rx, const SampleT *d_x, size_t n_samples, uin
         if (done) return done < 0 ? done : SAME_OK;
     }
     // channel-major: transpose slabs of time through a staging buffer
+    // (the staging buffers are the batch's own: a launch still in flight on ANOTHER stream may be reading its input out of
+    // them -- successive launches are ordered whatever their streams, so this call's first staging write waits for it)
+    for (same_batch::Slot &sl : rx->slot)
+        if (sl.in_flight && rx->last_stream != stream) HIP_TRY(hipStreamWaitEvent(stream, sl.ev_done, 0));
     const size_t slab = std::min<size_t>(n_samples, (size_t)1 << 16);
     int rc = ensure_stage(&rx->d_stage2, &rx->stage2_bytes, slab * rx->P.n_channels * sizeof(SampleT));
     if (rc) return rc;

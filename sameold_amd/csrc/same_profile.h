@@ -80,6 +80,13 @@ namespace same { static __device__ unsigned long long g_same_prof_sym[20]; }
         if (hipMemcpyFromSymbol(out20, HIP_SYMBOL(same::g_same_prof_sym), sizeof(z)) != hipSuccess) return -1;  \
         if (reset && hipMemcpyToSymbol(HIP_SYMBOL(same::g_same_prof_sym), z, sizeof(z)) != hipSuccess) return -1; \
         return 0;                                                                                               \
+    }                                                                                                           \
+    extern "C" int same_debug_profile_sym_marks(unsigned long long *out15, int reset)   /* SAME_P3_MARKS build: Y's sections */ \
+    {                                                                                                           \
+        unsigned long long z[15] = {0};                                                                         \
+        if (hipMemcpyFromSymbol(out15, HIP_SYMBOL(same::g_same_prof_pipe), sizeof(z)) != hipSuccess) return -1; \
+        if (reset && hipMemcpyToSymbol(HIP_SYMBOL(same::g_same_prof_pipe), z, sizeof(z)) != hipSuccess) return -1; \
+        return 0;                                                                                               \
     }
 #define FAST_MARKS_BEGIN(X_, lds_, nt_) do { (X_).pl = reinterpret_cast<unsigned long long *>((lds_) + (nt_) * 4); \
         for (int i_ = 0; i_ < 10; ++i_) (X_).pl[i_] = 0; } while (0)

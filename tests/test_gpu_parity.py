@@ -860,6 +860,25 @@ def test_successive_launches_are_ordered_whatever_their_streams(sa, ob):
     assert assert_every_channel_matches_oracle(ob, ob.default_config(22050), x, ev) > 4 * n_ch
 
 
+def test_successive_channel_major_launches_are_ordered_whatever_their_streams(sa, ob):
+    """The same with CHANNEL-MAJOR calls of a strict batch, which go through the batch's own staging buffers (copy + transpose,
+    slab by slab): a launch still in flight on another stream reads its input out of those buffers, so the next call's
+    first staging write must wait for it (round-3 advisor finding)."""
+    import torch
+    n_ch, part = 1024, 22050
+    x = sa.synth_afsk(n_ch, 6 * part, 22050, seed=4343)
+    parts = [x[i * part:(i + 1) * part].t().contiguous() for i in range(6)]
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Stream(), torch.cuda.Stream()
+    rx = sa.SameReceiverBuilder(22050).build_batch(n_ch, link_only=True)
+    for i, st in enumerate([None, a.cuda_stream, b.cuda_stream, None, b.cuda_stream, a.cuda_stream]):
+        rx.process_tensor(parts[i], layout=sa.LAYOUT_CHANNEL_MAJOR, stream=st)
+    rx.sync()
+    ev = rx.poll_events_np()
+    ev = ev[np.lexsort((np.arange(len(ev)), ev["channel"]))]
+    assert assert_every_channel_matches_oracle(ob, ob.default_config(22050), x, ev) > 4 * n_ch
+
+
 def test_audio_after_an_early_flush_is_refused_until_reset(sa):
     """flush() returns at its first message while the device has run over all 4 s of zeros; real audio
     presented next must not be silently skipped (round-1 advisor finding)."""

@@ -223,7 +223,7 @@ def test_time_parallel_chunks_on_the_relaxed_kernel(sa, monkeypatch, layout):
     monkeypatch.setenv("SAME_TP_KERNEL", "wave")
     rate, n_ch = 22050, 256
     n = 22050 * 10
-    n -= n % 420
+    n -= n % 1260
     x = sa.synth_afsk(n_ch, 2 * n, rate, seed=4242)
     ref = strict_events(sa, x, rate)
     rx = sa.SameReceiverBuilder(rate).build_batch(n_ch, time_parallel=True)

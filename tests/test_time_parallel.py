@@ -415,7 +415,7 @@ def test_per_channel_boundaries_on_channel_major_input(sa, ob, arith, monkeypatc
     monkeypatch.setenv("SAME_PIPE_LANES", "64")      # (small test batches would otherwise get 16-channel workgroups)
     rate = 22050
     n = int(rate * seconds)
-    n -= n % 420                     # whole blocks of every kernel that may take the chunks (20 and 42 samples)
+    n -= n % 1260                    # whole blocks of every kernel that may take the chunks (20, 36 and 42 samples)
     x = sa.synth_afsk(n_ch, n, rate, seed=3000 + n_ch, noise_sigma=noise)
     ref = strict_events(sa, x, rate)
     xc = x.t().contiguous()
@@ -436,6 +436,27 @@ def test_per_channel_boundaries_on_channel_major_input(sa, ob, arith, monkeypatc
     assert len(again[again["kind"] == 3]) >= len(got[got["kind"] == 3]) - n_ch // 8
 
 
+def test_channel_major_call_that_is_not_whole_blocks(sa, ob, arith, monkeypatch):
+    """A channel-major call whose length is no multiple of the kernel's block still takes the per-channel path: the
+    samples behind the last whole block go through the any-configuration kernel on the channels' own state, and the next
+    call continues from there."""
+    monkeypatch.setenv("SAME_PIPE_LANES", "64")      # (small test batches would otherwise get 16-channel workgroups)
+    rate, n_ch = 22050, 256
+    n = 22050 * 5 + 26                 # a multiple of 4 (16-byte streams), of neither 20 nor 36
+    assert n % 4 == 0 and n % 20 != 0 and n % 36 != 0
+    x = sa.synth_afsk(n_ch, 2 * n, rate, seed=8800)
+    ref = strict_events(sa, x, rate)
+    parts = [x[i * n:(i + 1) * n].t().contiguous() for i in range(2)]       # (kept alive: the launches are asynchronous)
+    rx = sa.SameReceiverBuilder(rate).build_batch(n_ch, time_parallel=True)
+    for i in range(2):
+        rx.process_tensor(parts[i], layout=sa.LAYOUT_CHANNEL_MAJOR)
+        assert rx.time_parallel_chunks() >= 2 and rx.time_parallel_per_channel()
+    rx.sync()
+    got = rx.poll_events_np()
+    got = got[np.lexsort((np.arange(len(got)), got["channel"]))]
+    assert_contract(sa, got, ref, rate, n_ch, lambda c: sa.synth_payload(8800, c), exact_bursts=True, t_end=2 * n)
+
+
 def test_per_channel_boundaries_streaming_calls_with_bursts_across_the_call_boundary(sa, monkeypatch):
     """Channel-major calls back to back, cut where bursts are in progress on many channels (every channel's schedule has its
     own lead-in): the state a call leaves is that of the chunk its hand-over chain ends in, so the burst that straddles the
@@ -443,7 +464,7 @@ def test_per_channel_boundaries_streaming_calls_with_bursts_across_the_call_boun
     monkeypatch.setenv("SAME_PIPE_LANES", "64")
     rate, n_ch = 22050, 256
     part = 22050 * 5
-    part -= part % 420
+    part -= part % 1260
     x = sa.synth_afsk(n_ch, 4 * part, rate, seed=9090)
     ref = strict_events(sa, x, rate)
     rx = sa.SameReceiverBuilder(rate).build_batch(n_ch, time_parallel=True)
@@ -471,7 +492,7 @@ def test_planning_on_the_plan_stream_and_on_a_callers_stream(sa, monkeypatch):
     monkeypatch.setenv("SAME_PIPE_LANES", "64")
     rate, n_ch = 22050, 4096
     part = 22050 * 3
-    part -= part % 420
+    part -= part % 1260
     x = sa.synth_afsk(n_ch, 4 * part, rate, seed=5151)
     ref = strict_events(sa, x, rate)
     parts = [x[i * part:(i + 1) * part].t().contiguous() for i in range(4)]
@@ -504,7 +525,7 @@ def test_sorted_launches_are_deterministic_and_the_timers_nest(sa, monkeypatch):
     events.  And the demodulation kernel's own timer lies inside the launch's."""
     rate, n_ch = 22050, 4096
     n = 22050 * 6
-    n -= n % 420
+    n -= n % 1260
     xc = sa.synth_afsk(n_ch, n, rate, seed=777).t().contiguous()
     runs = []
     for _ in range(2):
@@ -527,7 +548,7 @@ def test_per_channel_boundaries_fall_back_when_there_is_no_quiet_instant(sa, mon
     import torch
     monkeypatch.setenv("SAME_PIPE_LANES", "64")
     rate, n_ch, n = 22050, 128, 22050 * 8
-    n -= n % 420
+    n -= n % 1260
     x = sa.synth_afsk(n_ch, n, rate, seed=77)
     gen = torch.Generator(device="cuda"); gen.manual_seed(5)
     x[:, ::4] += torch.randn((n, n_ch // 4), device="cuda", generator=gen) * 3000.0      # every fourth channel drowned in noise
@@ -558,7 +579,7 @@ def test_streaming_channel_major_calls_with_noise_and_forced_cuts(sa, monkeypatc
     monkeypatch.setenv("SAME_PIPE_LANES", "64")
     rate, n_ch = 22050, 256
     part = 22050 * 5
-    part -= part % 420
+    part -= part % 1260
     x = sa.synth_afsk(n_ch, 4 * part, rate, seed=8181, noise_sigma=0.03)
     gen = torch.Generator(device="cuda"); gen.manual_seed(9)
     x[:, ::8] += torch.randn((4 * part, n_ch // 8), device="cuda", generator=gen) * 3000.0
@@ -624,7 +645,7 @@ def test_a_weak_burst_beside_a_strong_one(sa, monkeypatch):
     monkeypatch.setenv("SAME_PIPE_LANES", "64")
     rate, n_ch = 22050, 256
     n = 22050 * 12
-    n -= n % 420
+    n -= n % 1260
     x = sa.synth_afsk(n_ch, n, rate, seed=5150)
     ev = split(strict_events(sa, x, rate, link_only=True), n_ch)
     scale = torch.ones((n, n_ch), device=x.device)

@@ -105,7 +105,26 @@ def prof(rx):
     print(f"  steps {steps}, T passes {v[13]}, feedback rounds {v[14]} ({100.0*v[14]/steps:.1f} % of steps); E's filter {v[15]/max(v[13],1):.0f} clk/pass, waiting for S's {v[17]/max(v[13],1):.0f}, timing+post {v[16]/max(v[13],1):.0f} clk/pass", flush=True)
 
 
+def marks(rx):
+    import ctypes
+    L = rx._L
+    if not hasattr(L, "same_debug_profile_sym_marks"):
+        return
+    out = (ctypes.c_ulonglong * 15)()
+    if L.same_debug_profile_sym_marks(out, 1) != 0:
+        return
+    v = list(out)
+    names = ["other (mailbox, barrier, idle)", "squelch", "equalizer step", "byte/framer", "events", "-"]
+    tot = sum(v[:6]) or 1
+    for n, x in zip(names, v[:6]):
+        print(f"  Y {n:32s} {x:14d} clk  {100.0*x/tot:5.1f} %")
+
+
 what = sys.argv[1] if len(sys.argv) > 1 else "all"
+if what == "marks":
+    os.environ["SAME_SYM"] = "1"
+    rx = timeit(32768, 2.0, reps=2); marks(rx)
+    rx = timeit(4096, 10.0, tp=True, cm=True, reps=2); marks(rx)
 if what in ("parity", "all"):
     parity()
     parity(noise=0.05, seed=12)
