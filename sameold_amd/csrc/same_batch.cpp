@@ -54,45 +54,72 @@ int fail(int code, const char *fmt, ...)
 }  // namespace
 
 // ------------------------------------------------------------------------------------
-// The host event queue: a plain growable array of PODs.  (std::vector would zero-fill 328 bytes per
-// event on resize and can only be appended to from one thread; a harvest appends ~35 MB.)
-struct EventQueue {
-    same_rx_event *buf = nullptr;
+// The host event queue.  A harvest of configs[1] brings ~110 000 link events per step; as 328-byte same_rx_event
+// records that was 36 MB written twice per step (thread-local parts, then the queue) -- 2 ms of host time under a
+// 2.7 ms launch.  The queue therefore holds 48-byte records, the burst / header bytes of the few events that carry any
+// sit in a byte arena beside them, and a same_rx_event is only made when a consumer asks for one
+// (same_batch_poll_events / _peek_events; same_batch_pack_bursts reads the records directly).
+struct QEvent {
+    uint32_t kind, channel;
+    uint64_t sample_counter, symbol_count;
+    uint32_t len, aux, aux2;
+    uint32_t n_bytes;                // payload bytes kept (min(len, SAME_EVENT_MAX_BYTES)), 0 = none
+    uint64_t payload;                // absolute offset of the payload in the arena
+};
+static_assert(sizeof(QEvent) == 48, "compact event record");
+template <typename T>
+struct PodQueue {                    // a plain growable array of PODs (no zero-fill on growth, appendable in slices)
+    T *buf = nullptr;
     size_t n = 0, cap = 0;
-    ~EventQueue() { std::free(buf); }
-    EventQueue() = default;
-    EventQueue(const EventQueue &) = delete;
-    EventQueue &operator=(const EventQueue &) = delete;
-    size_t base = 0;                 // how many events have left the front of the buffer since the handle was made:
-                                     // buf[i] is event number base + i (what the burst index below refers to)
+    size_t base = 0;                 // how many elements have left the front since the handle was made: buf[i] is number base + i
+    ~PodQueue() { std::free(buf); }
+    PodQueue() = default;
+    PodQueue(const PodQueue &) = delete;
+    PodQueue &operator=(const PodQueue &) = delete;
     size_t size() const { return n; }
-    same_rx_event *data() { return buf; }
+    T *data() { return buf; }
+    const T *data() const { return buf; }
     void clear() { base += n; n = 0; }
-    // drop the first `head` (already polled) events by moving the rest to the front; returns the new head (0)
+    // drop the first `head` elements by moving the rest to the front; returns the new head (0)
     size_t compact(size_t head)
     {
         if (head == 0) return 0;
-        if (head < n) std::memmove(buf, buf + head, (n - head) * sizeof(same_rx_event));
+        if (head < n) std::memmove(buf, buf + head, (n - head) * sizeof(T));
         n -= head;
         base += head;
         return 0;
     }
-    // room for `extra` more events; returns where they go, or nullptr when out of memory
-    same_rx_event *grow(size_t extra)
+    // room for `extra` more elements; returns where they go, or nullptr when out of memory
+    T *grow(size_t extra)
     {
         if (n + extra > cap) {
             const size_t want = (n + extra) + (n + extra) / 2 + 64;
-            void *p = std::realloc(buf, want * sizeof(same_rx_event));
+            void *p = std::realloc(buf, want * sizeof(T));
             if (!p) return nullptr;
-            buf = static_cast<same_rx_event *>(p);
+            buf = static_cast<T *>(p);
             cap = want;
         }
-        same_rx_event *at = buf + n;
+        T *at = buf + n;
         n += extra;
         return at;
     }
 };
-struct HarvestPart { std::vector<same_rx_event> out; std::vector<uint32_t> rearm; std::vector<uint32_t> bursts; /* indices into out */ };
+using EventQueue = PodQueue<QEvent>;
+using ByteArena = PodQueue<uint8_t>;     // payload bytes: element number = absolute offset
+struct HarvestPart {
+    std::vector<QEvent> out;             // payload = offset into `bytes` until the part is appended to the queue
+    std::vector<uint8_t> bytes;
+    std::vector<uint32_t> rearm;
+    std::vector<uint32_t> bursts;        // indices into out
+};
+// a queue record as the event the ABI hands out
+static void materialise(const QEvent &q, const uint8_t *arena, size_t arena_base, same_rx_event *ev)
+{
+    std::memset(ev, 0, sizeof(*ev));
+    ev->kind = q.kind; ev->channel = q.channel; ev->sample_counter = q.sample_counter; ev->symbol_count = q.symbol_count;
+    ev->len = q.len; ev->aux = q.aux; ev->aux2 = q.aux2;
+    if (q.n_bytes) std::memcpy(ev->bytes, arena + (q.payload - arena_base), q.n_bytes);
+}
 
 using same::TickSynth;
 
@@ -264,6 +291,8 @@ struct same_batch {
     // ordered host-side event queue
     EventQueue queue;                   // events not yet polled: [queue_head, size)
     size_t queue_head = 0;
+    ByteArena arena;                    // their payload bytes
+    std::vector<same_rx_event> peeked;  // same_batch_peek_events: the queued events, materialised
     std::vector<size_t> burst_seq;      // event numbers (EventQueue::base + index) of the queued SAME_LINK_BURST events, ascending
     size_t burst_seq_head = 0;          // entries before this one have been polled or dropped
     std::vector<HarvestPart> parts;     // per host thread, kept between harvests for their capacity
@@ -553,40 +582,45 @@ int harvest_slot(same_batch *rx, same_batch::Slot &sl)
     const uint64_t interburst = same::max_interburst_symbols(), history = same::max_history_duration();
     // one device event -> the link event of channel c (+ the transport event it causes).  `off`: what
     // the time-parallel mode adds to the device's symbol count (0 otherwise).
-    auto feed = [&](Part &part, same_rx_event &ev, const same::DevEvent &d, uint32_t c, int64_t off) {
+    // (transport events arrive as same_rx_event from the transport layer: kept as a record + payload)
+    auto push_transport = [&](Part &part, const same_rx_event &tev, uint32_t c) {
+        QEvent q{};
+        q.kind = tev.kind; q.channel = c; q.sample_counter = tev.sample_counter; q.symbol_count = tev.symbol_count;
+        q.len = tev.len; q.aux = tev.aux; q.aux2 = tev.aux2;
+        q.n_bytes = std::min<uint32_t>(tev.len, SAME_EVENT_MAX_BYTES);
+        if (tev.kind != SAME_TRANSPORT_MSG_START) q.n_bytes = 0;       // (only a header carries bytes)
+        q.payload = part.bytes.size();
+        if (q.n_bytes) part.bytes.insert(part.bytes.end(), tev.bytes, tev.bytes + q.n_bytes);
+        part.out.push_back(q);
+    };
+    auto feed = [&](Part &part, same_rx_event &tev, const same::DevEvent &d, uint32_t c, int64_t off) {
         const uint64_t sym = (uint64_t)((int64_t)d.symbol_count + off);
         auto poll = [&](uint64_t psym, uint64_t pt) {
-            same_rx_event tev;
-            if (rx->transport[c].on_link_event(same::kDevTick, pt, psym, nullptr, 0, rx->P.input_rate, &tev)) {
-                tev.channel = c;
-                part.out.push_back(tev);
-            }
+            if (rx->transport[c].on_link_event(same::kDevTick, pt, psym, nullptr, 0, rx->P.input_rate, &tev)) push_transport(part, tev, c);
         };
         if (tp && !link_only)
             rx->tp.synth[c].run_until(sym, d.sample_counter, sps, rx->transport[c].force_eom_at(), poll);
-        std::memset(&ev, 0, offsetof(same_rx_event, bytes));
-        ev.kind = d.kind; ev.channel = c; ev.sample_counter = d.sample_counter;
-        ev.symbol_count = sym;
+        QEvent q{};
+        q.kind = d.kind; q.channel = c; q.sample_counter = d.sample_counter; q.symbol_count = sym;
+        const uint8_t *payload = nullptr;
         if (d.kind == SAME_LINK_BURST) {
-            ev.len = d.burst_len;
-            const uint32_t n = std::min<uint32_t>(d.burst_len, SAME_EVENT_MAX_BYTES);
-            if (d.burst_slot < n_bursts) std::memcpy(ev.bytes, bursts + (size_t)d.burst_slot * same::kBurstCap, n);
-            else ev.len = 0;   // pool overflow: the burst bytes were lost (SAME_EOVERFLOW is reported)
-        }
-        if (d.kind == SAME_LINK_BURST) part.bursts.push_back((uint32_t)part.out.size());
-        if (d.kind <= SAME_LINK_BURST) part.out.push_back(ev);
-        if (!link_only) {
-            same_rx_event tev;
-            if (rx->transport[c].on_link_event(d.kind, d.sample_counter, sym, ev.bytes,
-                                               std::min<uint32_t>(ev.len, SAME_EVENT_MAX_BYTES),
-                                               rx->P.input_rate, &tev)) {
-                tev.channel = c;
-                part.out.push_back(tev);
+            q.len = d.burst_len;
+            if (d.burst_slot < n_bursts) {
+                q.n_bytes = std::min<uint32_t>(d.burst_len, SAME_EVENT_MAX_BYTES);
+                payload = bursts + (size_t)d.burst_slot * same::kBurstCap;
+                q.payload = part.bytes.size();
+                part.bytes.insert(part.bytes.end(), payload, payload + q.n_bytes);
+            } else {
+                q.len = 0;     // pool overflow: the burst bytes were lost (SAME_EOVERFLOW is reported)
             }
+            part.bursts.push_back((uint32_t)part.out.size());
+        }
+        if (d.kind <= SAME_LINK_BURST) part.out.push_back(q);
+        if (!link_only) {
+            if (rx->transport[c].on_link_event(d.kind, d.sample_counter, sym, payload, q.n_bytes, rx->P.input_rate, &tev)) push_transport(part, tev, c);
             if (!tp && rx->transport[c].force_eom_dirty()) part.rearm.push_back(c);
         }
         if (tp && d.kind <= SAME_LINK_BURST) rx->tp.synth[c].after_event(d.kind, sym, d.sample_counter, interburst, history);
-        if (d.kind == SAME_LINK_BURST) std::memset(ev.bytes, 0, sizeof(ev.bytes));   // keep later events clean
     };
     // Time-parallel launch: the events of channel c, stitched from its chunks.  Chunk `cur` is kept up to
     // its hand-over instant h (the end of the first block at or after its nominal end in which the
@@ -663,9 +697,9 @@ int harvest_slot(same_batch *rx, same_batch::Slot &sl)
         rx->tp.sym_off[c] = off;
     };
     auto run_range = [&](uint32_t c0, uint32_t c1, Part &part) {
-        part.out.clear(); part.rearm.clear(); part.bursts.clear();
+        part.out.clear(); part.bytes.clear(); part.rearm.clear(); part.bursts.clear();
         part.out.reserve((size_t)(cfirst[c1] - cfirst[c0]) * 3 / 2 + 4);
-        same_rx_event ev;
+        same_rx_event ev;                                  // (scratch for what the transport layer returns)
         std::memset(&ev, 0, sizeof(ev));
         for (uint32_t c = c0; c < c1; ++c) {
             // this channel's column ranges back into log order (see above)
@@ -683,11 +717,7 @@ int harvest_slot(same_batch *rx, same_batch::Slot &sl)
                 if (ts.link == SAME_LINK_NO_CARRIER && sl.end_counter > ts.a_t) {
                     const uint64_t sym_end = ts.a_sym + (uint64_t)((double)(sl.end_counter - ts.a_t) / sps);
                     auto poll = [&](uint64_t psym, uint64_t pt) {
-                        same_rx_event tev;
-                        if (rx->transport[c].on_link_event(same::kDevTick, pt, psym, nullptr, 0, rx->P.input_rate, &tev)) {
-                            tev.channel = c;
-                            part.out.push_back(tev);
-                        }
+                        if (rx->transport[c].on_link_event(same::kDevTick, pt, psym, nullptr, 0, rx->P.input_rate, &ev)) push_transport(part, ev, c);
                     };
                     ts.run_until(sym_end + 1u, sl.end_counter + 1u, sps, rx->transport[c].force_eom_at(), poll);
                 }
@@ -703,7 +733,7 @@ int harvest_slot(same_batch *rx, same_batch::Slot &sl)
     }
     if (rx->parts.size() < n_threads) rx->parts.resize(n_threads);
     std::vector<Part> &parts = rx->parts;
-    for (Part &p : parts) { p.out.clear(); p.rearm.clear(); p.bursts.clear(); }
+    for (Part &p : parts) { p.out.clear(); p.bytes.clear(); p.rearm.clear(); p.bursts.clear(); }
     if (n_threads == 1) {
         run_range(0, n_ch, parts[0]);
     } else {
@@ -718,31 +748,46 @@ int harvest_slot(same_batch *rx, same_batch::Slot &sl)
         rx->workers.run(n_threads, [&](size_t t) { run_range(cut[t], cut[t + 1u], parts[t]); });
     }
     auto t_replayed = std::chrono::steady_clock::now();
-    size_t total = 0;
-    for (const Part &p : parts) total += p.out.size();
+    size_t total = 0, total_bytes = 0;
+    for (const Part &p : parts) { total += p.out.size(); total_bytes += p.bytes.size(); }
     // a consumer that always polls less than is pending never drains the queue: reclaim the polled
     // prefix once it is at least as large as what is still waiting (amortised O(1) per event)
-    if (rx->queue_head && rx->queue_head >= rx->queue.size() - rx->queue_head)
+    if (rx->queue_head && rx->queue_head >= rx->queue.size() - rx->queue_head) {
         rx->queue_head = rx->queue.compact(rx->queue_head);
-    same_rx_event *dst = rx->queue.grow(total);
+        // ... and the payload bytes in front of the first record that is still queued
+        size_t keep_from = rx->arena.base + rx->arena.size();
+        for (size_t i = 0; i < rx->queue.size(); ++i)
+            if (rx->queue.data()[i].n_bytes) { keep_from = (size_t)rx->queue.data()[i].payload; break; }
+        rx->arena.compact(keep_from - rx->arena.base);
+    }
+    QEvent *dst = rx->queue.grow(total);
     if (total && !dst) return fail(SAME_ENOMEM, "event queue");
+    uint8_t *bdst = rx->arena.grow(total_bytes);
+    if (total_bytes && !bdst) return fail(SAME_ENOMEM, "event payloads");
     {
         // every thread's slice lands at its prefix offset; the copies run side by side
-        size_t at = 0;
+        size_t at = 0, bat = 0;
         if (rx->burst_seq_head > 4096 && rx->burst_seq_head * 2 > rx->burst_seq.size()) {
             rx->burst_seq.erase(rx->burst_seq.begin(), rx->burst_seq.begin() + (std::ptrdiff_t)rx->burst_seq_head);
             rx->burst_seq_head = 0;
         }
         const size_t seq0 = rx->queue.base + (size_t)(dst - rx->queue.data());
-        std::vector<std::pair<same_rx_event *, const Part *>> jobs;
+        const size_t byte0 = rx->arena.base + (size_t)(bdst - rx->arena.data());
+        struct Job { QEvent *q; uint8_t *b; Part *p; size_t byte_off; };
+        std::vector<Job> jobs;
         for (size_t t = 0; t < parts.size(); ++t) {
-            const Part &p = parts[t];
+            Part &p = parts[t];
             if (p.out.empty()) continue;
             for (uint32_t i : p.bursts) rx->burst_seq.push_back(seq0 + at + i);
-            jobs.emplace_back(dst + at, &p);
-            at += p.out.size();
+            jobs.push_back(Job{dst + at, bdst + bat, &p, byte0 + bat});
+            at += p.out.size(); bat += p.bytes.size();
         }
-        rx->workers.run(jobs.size(), [&](size_t j) { std::memcpy(jobs[j].first, jobs[j].second->out.data(), jobs[j].second->out.size() * sizeof(same_rx_event)); });
+        rx->workers.run(jobs.size(), [&](size_t j) {
+            const Job &job = jobs[j];
+            for (QEvent &q : job.p->out) q.payload += job.byte_off;            // part-relative -> absolute
+            std::memcpy(job.q, job.p->out.data(), job.p->out.size() * sizeof(QEvent));
+            if (!job.p->bytes.empty()) std::memcpy(job.b, job.p->bytes.data(), job.p->bytes.size());
+        });
     }
     for (Part &p : parts) rearm.insert(rearm.end(), p.rearm.begin(), p.rearm.end());
     // force_eom_at_sample (receiver.rs:321-328) lives on the host; tell the device when to
@@ -1423,6 +1468,7 @@ int same_batch_reset(same_batch *rx)
     HIP_TRY(hipStreamSynchronize(rx->own_stream));
     rx->counter = 0;
     rx->queue.clear(); rx->queue_head = 0;   // event_queue.clear() receiver.rs:194
+    rx->arena.clear();
     rx->burst_seq.clear(); rx->burst_seq_head = 0;
     for (auto &t : rx->transport) t.reset();
     for (auto &o : rx->tp.sym_off) o = 0;
@@ -1494,14 +1540,28 @@ size_t same_batch_pending_events(same_batch *rx)
     return rx->queue.size() - rx->queue_head;
 }
 
+// the queue is empty: nothing refers to the arena any more
+static void queue_emptied(same_batch *rx) { rx->queue.clear(); rx->queue_head = 0; rx->arena.clear(); }
+
 int same_batch_poll_events(same_batch *rx, same_rx_event *out, size_t cap, size_t *n_out, size_t *n_left)
 {
     if (!rx || (!out && cap)) return fail(SAME_EINVAL, "null argument");
     const size_t avail = rx->queue.size() - rx->queue_head;
     const size_t n = std::min(cap, avail);
-    if (n) std::memcpy(out, rx->queue.data() + rx->queue_head, n * sizeof(same_rx_event));
+    const QEvent *q = rx->queue.data() + rx->queue_head;
+    const uint8_t *arena = rx->arena.data();
+    const size_t abase = rx->arena.base;
+    if (n >= 4096) {
+        const unsigned hw = std::thread::hardware_concurrency();
+        const size_t n_threads = std::min<size_t>({8u, hw ? hw : 1u});
+        rx->workers.run(n_threads, [&](size_t t) {
+            for (size_t i = n * t / n_threads; i < n * (t + 1) / n_threads; ++i) materialise(q[i], arena, abase, out + i);
+        });
+    } else {
+        for (size_t i = 0; i < n; ++i) materialise(q[i], arena, abase, out + i);
+    }
     rx->queue_head += n;
-    if (rx->queue_head == rx->queue.size()) { rx->queue.clear(); rx->queue_head = 0; }
+    if (rx->queue_head == rx->queue.size()) queue_emptied(rx);
     if (n_out) *n_out = n;
     if (n_left) *n_left = rx->queue.size() - rx->queue_head;
     return SAME_OK;
@@ -1510,8 +1570,25 @@ int same_batch_poll_events(same_batch *rx, same_rx_event *out, size_t cap, size_
 int same_batch_peek_events(same_batch *rx, const same_rx_event **events, size_t *n)
 {
     if (!rx || !events || !n) return fail(SAME_EINVAL, "null argument");
-    *n = rx->queue.size() - rx->queue_head;
-    *events = *n ? rx->queue.data() + rx->queue_head : nullptr;
+    // (the queue holds compact records: the view is made here, and stays valid as the header promises -- until the next
+    // call on this handle other than same_batch_pending_events / same_batch_drop_events)
+    const size_t avail = rx->queue.size() - rx->queue_head;
+    try { rx->peeked.resize(avail); } catch (...) { return fail(SAME_ENOMEM, "event view"); }
+    const QEvent *q = rx->queue.data() + rx->queue_head;
+    const uint8_t *arena = rx->arena.data();
+    const size_t abase = rx->arena.base;
+    same_rx_event *out = rx->peeked.data();
+    if (avail >= 4096) {
+        const unsigned hw = std::thread::hardware_concurrency();
+        const size_t n_threads = std::min<size_t>({8u, hw ? hw : 1u});
+        rx->workers.run(n_threads, [&](size_t t) {
+            for (size_t i = avail * t / n_threads; i < avail * (t + 1) / n_threads; ++i) materialise(q[i], arena, abase, out + i);
+        });
+    } else {
+        for (size_t i = 0; i < avail; ++i) materialise(q[i], arena, abase, out + i);
+    }
+    *n = avail;
+    *events = avail ? out : nullptr;
     return SAME_OK;
 }
 
@@ -1520,7 +1597,7 @@ int same_batch_drop_events(same_batch *rx, size_t n)
     if (!rx) return fail(SAME_EINVAL, "null argument");
     if (n > rx->queue.size() - rx->queue_head) return fail(SAME_EINVAL, "more events than are queued");
     rx->queue_head += n;
-    if (rx->queue_head == rx->queue.size()) { rx->queue.clear(); rx->queue_head = 0; }
+    if (rx->queue_head == rx->queue.size()) queue_emptied(rx);
     return SAME_OK;
 }
 
@@ -1533,8 +1610,10 @@ int same_batch_pack_bursts(same_batch *rx, uint32_t first_channel, uint8_t *out,
     while (rx->burst_seq_head < rx->burst_seq.size() && rx->burst_seq[rx->burst_seq_head] < first_seq) ++rx->burst_seq_head;
     const size_t n_b = rx->burst_seq.size() - rx->burst_seq_head;
     const size_t *seq = rx->burst_seq.data() + rx->burst_seq_head;
-    const same_rx_event *q = rx->queue.data();
+    const QEvent *q = rx->queue.data();
     const size_t base = rx->queue.base;
+    const uint8_t *arena = rx->arena.data();
+    const size_t abase = rx->arena.base;
     *n_records = n_b;
     if (!out || !cap) return SAME_OK;
     const size_t n_copy = std::min(n_b, cap);
@@ -1542,11 +1621,11 @@ int same_batch_pack_bursts(same_batch *rx, uint32_t first_channel, uint8_t *out,
     const size_t n_threads = n_copy >= 8192 ? std::min<size_t>({8u, hw ? hw : 1u}) : 1u;
     auto copy_slice = [&](size_t t) {
         for (size_t i = n_copy * t / n_threads; i < n_copy * (t + 1) / n_threads; ++i) {
-            const same_rx_event &e = q[seq[i] - base];
+            const QEvent &e = q[seq[i] - base];
             uint8_t *r = out + i * SAME_BURST_RECORD_BYTES;
-            const uint32_t ch = e.channel + first_channel, len = std::min<uint32_t>(e.len, SAME_EVENT_MAX_BYTES);
+            const uint32_t ch = e.channel + first_channel, len = e.n_bytes;
             std::memcpy(r, &ch, 4); std::memcpy(r + 4, &e.sample_counter, 8); std::memcpy(r + 12, &len, 4);
-            std::memcpy(r + 16, e.bytes, len);
+            if (len) std::memcpy(r + 16, arena + ((size_t)e.payload - abase), len);
             std::memset(r + 16 + len, 0, SAME_EVENT_MAX_BYTES - len);
         }
     };

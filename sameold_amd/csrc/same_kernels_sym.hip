@@ -577,10 +577,15 @@ __global__ __launch_bounds__(4 * kWave, 2) void demod_sym_kernel(Params P, State
                 const lds_u32 *fb = fbbox + (s & 1u) * LY::fb_words;
                 const uint32_t fbw = (uint32_t)__builtin_amdgcn_readfirstlane((int)fb[kWave]);
                 if (fbw & 2u) stop_at = s + 1u;
+                if (fbw & 4u) {
+                    // end(): the AGC is unlocked from the next block on (no replay)
+                    const uint32_t v = fb[lane];
+                    if ((v & 17u) == 17u) M.locked = (v & 2u) != 0u;
+                }
                 if (fbw & 1u) {
                     const uint32_t v = fb[lane];
                     const bool new_locked = (v & 2u) != 0u;
-                    if ((v & 1u) && new_locked != M.locked) {
+                    if ((v & 17u) == 1u && new_locked != M.locked) {
                         const int64_t idx = sym_index(s - 1u, v >> 8);
                         const uint32_t b = (uint32_t)(idx / kB);
                         M.replay(P, wcol, b, (int)(idx - (int64_t)b * kB), new_locked);
@@ -721,8 +726,16 @@ __global__ __launch_bounds__(4 * kWave, 2) void demod_sym_kernel(Params P, State
                     io0 = 1u | (link << 1) | (emit ? 8u : 0u) | (off << 4);
                     io2 = burst_len;
                     const uint32_t after = L.flags & (F_AGC_LOCKED | F_BW_LOCKED);
-                    if (after != before || L.ended)
-                        fbv = 1u | ((after & F_AGC_LOCKED) ? 2u : 0u) | ((after & F_BW_LOCKED) ? 4u : 0u) | (L.ended ? 8u : 0u) | (off << 8);
+                    if (after != before || L.ended) {
+                        // Only the lock at sync (agc.lock(true), locked loop bandwidth: receiver.rs:431-432) is taken back to the
+                        // sample it happened at -- the gain it freezes is the one every soft symbol of the burst is scaled by.
+                        // What end() undoes (receiver.rs:479-490) is applied late and without a replay (bit 4): the AGC is unlocked
+                        // from the next block on, the timing loop reset two symbols later.  The carrier is gone by then; link
+                        // events after it move by less than a symbol.
+                        const bool lock_on = (after & F_AGC_LOCKED) != 0u && (before & F_AGC_LOCKED) == 0u;
+                        fbv = 1u | ((after & F_AGC_LOCKED) ? 2u : 0u) | ((after & F_BW_LOCKED) ? 4u : 0u) | (L.ended ? 8u : 0u) |
+                              (lock_on ? 0u : 16u) | (off << 8);
+                    }
                 }
                 // finished bursts go into the pool with the whole wavefront: one slot reservation for all of them and one
                 // coalesced round trip per burst (same_kernels_pipe.hip)
@@ -766,7 +779,8 @@ __global__ __launch_bounds__(4 * kWave, 2) void demod_sym_kernel(Params P, State
                 if (__builtin_amdgcn_ballot_w64((io0 & 8u) != 0u && ((io0 >> 1) & 3u) == 3u) != 0ull) { io[kWave] = io1; io[2 * kWave] = io2; }
                 lds_u32 *fb = fbbox + (s & 1u) * LY::fb_words;
                 fb[lane] = fbv;
-                any = __builtin_amdgcn_ballot_w64(fbv != 0u) != 0ull;
+                any = __builtin_amdgcn_ballot_w64(fbv != 0u && (fbv & 16u) == 0u) != 0ull;
+                const bool any_late = __builtin_amdgcn_ballot_w64((fbv & 16u) != 0u) != 0ull;
                 // Time-parallel chunk that hands over: from its nominal end on, a lane's hand-over instant is
                 // the end of the first block after which its link state is NoCarrier; once every lane has one the workgroup
                 // leaves (one more step: E still has to log this step's events)
@@ -778,7 +792,7 @@ __global__ __launch_bounds__(4 * kWave, 2) void demod_sym_kernel(Params P, State
                     }
                     if (__builtin_amdgcn_ballot_w64(!lane_done) == 0ull) { leave = 2u; leave_posted = true; stop_at = s + 1u; }
                 }
-                if (lane == 0u) fb[kWave] = (any ? 1u : 0u) | leave;
+                if (lane == 0u) fb[kWave] = (any ? 1u : 0u) | leave | (any_late ? 4u : 0u);
             }
             P3_LAP(p3_work);
             lds_barrier();                                             // A
@@ -880,6 +894,18 @@ __global__ __launch_bounds__(4 * kWave, 2) void demod_sym_kernel(Params P, State
             sb[kWave] = __float_as_uint(zero); sb[2 * kWave] = __float_as_uint(sym);
             if (P.trace_cap) { sb[3 * kWave] = __float_as_uint(terr); sb[4 * kWave] = __float_as_uint(next); }
         };
+        // what end() undoes in the timing loop (receiver.rs:479-490: unlocked loop bandwidth, symsync.reset()), late: see Y
+        uint32_t late_now = 0u;
+        auto late = [&](uint32_t v) __attribute__((always_inline)) {
+            if (v & 1u) {
+                L.flags = (L.flags & ~F_BW_LOCKED) | ((v & 4u) ? F_BW_LOCKED : 0u);
+                if (v & 8u) {                                            // rx/symsync.rs:166-170, 265-271
+                    L.flags &= ~F_TED_PHASE;
+                    L.h0 = 0.0f; L.h1 = 0.0f; L.h2 = 0.0f;
+                    L.period_avg = P.samples_per_ted; L.period_inst = P.samples_per_ted;
+                }
+            }
+        };
         plan(0u);                                                      // (nothing: step 0 finishes no symbol)
         lds_barrier();                                                 // prologue
         P3_T0();
@@ -892,41 +918,47 @@ __global__ __launch_bounds__(4 * kWave, 2) void demod_sym_kernel(Params P, State
             const int k_cstar = cstar, k_rel = rel;
             if (!PROF_SKIP(P, 32)) {
                 work(s, 2u * s + 1u);
+                late(late_now);
                 if (s + 1u <= n_blocks) rel -= kB;                     // block s is finished when step s + 1 begins
                 plan(s + 1u);
             }
             P3_LAP(p3_work);
             lds_barrier();                                             // A
             P3_LAP(p3_wait);
+            uint32_t late_next = 0u;
             if (s >= 2u && s <= last_fb_step) {
                 const lds_u32 *fb = fbbox + (s & 1u) * LY::fb_words;
                 const uint32_t fbw = (uint32_t)__builtin_amdgcn_readfirstlane((int)fb[kWave]);
                 if (fbw & 2u) stop_at = s + 1u;
+                if (fbw & 4u) {
+                    // what end() undoes: applied behind the next step's symbol (the positions of that step are already with S)
+                    const uint32_t v = fb[lane];
+                    if ((v & 17u) == 17u) late_next = v;
+                }
                 if (fbw & 1u) {
                     SYM_TCOUNT(14, 1);
                     const uint32_t v = fb[lane];
                     // every lane goes back (a lane without a change redoes its step over an unchanged window: same results)
                     L.h0 = k_h0; L.h1 = k_h1; L.h2 = k_h2; L.period_avg = k_avg; L.period_inst = k_inst;
                     L.until_next_ted = k_unt; L.flags = k_flags; cstar = k_cstar; rel = k_rel;
-                    if (v & 1u) {
+                    if ((v & 17u) == 1u) {                               // locked at this symbol: the locked loop bandwidth from here on
                         L.flags = (L.flags & ~F_BW_LOCKED) | ((v & 4u) ? F_BW_LOCKED : 0u);
-                        if (v & 8u) {                                    // end(): symsync.reset()
-                            L.flags &= ~F_TED_PHASE;
-                            L.h0 = 0.0f; L.h1 = 0.0f; L.h2 = 0.0f;
-                            L.period_avg = P.samples_per_ted; L.period_inst = P.samples_per_ted;
-                        }
+                        late_now = 0u; late_next = 0u;                   // (a lock supersedes an end() still on its way)
                     }
                     plan(s);                                           // S filters again, at these positions
                     lds_barrier();                                     // B: S has corrected the window
                     work(s, 2u * s + 2u);
+                    late(late_now);
                     if (s + 1u <= n_blocks) rel -= kB;
                     plan(s + 1u);
                     lds_barrier();                                     // C
                     P3_LAP(p3_fb);
                 }
             }
+            late_now = late_next;
             if (s == stop_at) { left = true; break; }
         }
+        late(late_now);                                                // (one that arrived with the last step)
         SYM_REPORT(3);
         SYM_T_REPORT();
         SYM_COUNT(12, n_steps);

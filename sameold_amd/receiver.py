@@ -469,6 +469,11 @@ class SameBatchReceiver:
             out = out[: n.value]
         return out
 
+    def pending_events(self) -> int:
+        """Events the host already has (same_batch_pending_events): does not wait for launches still in flight, makes no
+        copies."""
+        return int(self._L.same_batch_pending_events(self._h))
+
     def peek_events_np(self) -> np.ndarray:
         """The queued events as a read-only numpy view INTO the handle (same_batch_peek_events):
         no copy.  Valid until the next call on this receiver other than `drop_events`; copy what
