@@ -1030,7 +1030,11 @@ int process_time_major(same_batch *rx, const SampleT *d_x, size_t n_samples, hip
         // (SAME_RELAXED_KERNEL=solo / duo forces that one)
         same::Params Pfm = rx->P;
         Pfm.knob_pipe_lanes = 64; Pfm.knob_pipe_share = 1; Pfm.knob_pipe_split = 1; Pfm.knob_pipe = 1;
-        const bool plain_fm = rx->relaxed_plain && rx->P.knob_relaxed_kernel == 0 && rx->P.n_channels <= 32768u && same::pipe_relaxed_supported(Pfm);
+        // (the symbol-paced pipeline takes any number of 64-channel workgroups: beyond two per CU they run in rounds)
+        const bool plain_fm = rx->relaxed_plain && rx->P.knob_relaxed_kernel == 0 && same::pipe_relaxed_supported(Pfm) &&
+                              (rx->P.n_channels <= 32768u || (rx->P.n_channels <= 65536u && same::sym_kernel_supported(Pfm)));
+        // (measured, 2 s launches: 49 152 channels 4.53 ms against the two-wavefront relaxed kernel's 5.12, 65 536: 5.41 against
+        // 6.08; 131 072: 10.2 against the one-wavefront kernel's 9.7, 262 144: 19.4 against 18.3)
         rx->last_plain_fm = plain_fm;
         const size_t fb = plain_fm ? fm_block_len(Pfm)
                                    : (rx->relaxed_plain ? same::relaxed_block_len(rx->P) : (rx->use_fast ? same::fast_block_len(rx->P) : 16));
@@ -1260,7 +1264,9 @@ int process_device_any(same_batch *rx, const SampleT *d_x, size_t n_samples, uin
     // them -- successive launches are ordered whatever their streams, so this call's first staging write waits for it)
     for (same_batch::Slot &sl : rx->slot)
         if (sl.in_flight && rx->last_stream != stream) HIP_TRY(hipStreamWaitEvent(stream, sl.ev_done, 0));
-    const size_t slab = std::min<size_t>(n_samples, (size_t)1 << 16);
+    // (slabs of 65 520 samples: whole blocks of every kernel -- 16, 18, 20, 36 and 42 samples -- so that only the call's own
+    // tail goes through the any-configuration kernel, not one per slab)
+    const size_t slab = std::min<size_t>(n_samples, (size_t)65520);
     int rc = ensure_stage(&rx->d_stage2, &rx->stage2_bytes, slab * rx->P.n_channels * sizeof(SampleT));
     if (rc) return rc;
     for (size_t t0 = 0; t0 < n_samples; t0 += slab) {
