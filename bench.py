@@ -53,7 +53,10 @@ def parse():
     ap.add_argument("--check", type=int, default=16, help="channels of rank 0 verified against the oracle")
     ap.add_argument("--traffic", type=float, default=None, help="HBM bytes/launch from a PMC pass (profiles/)")
     ap.add_argument("--cpu-seconds", type=float, default=3.0, help="minimum wall time of the CPU baseline run")
-    ap.add_argument("--no-scaled-long", action="store_true", help="skip the 32768-channel x 10 s time-parallel block (29 GB of input)")
+    ap.add_argument("--scaled-long", action="store_true", help="also the 32768-channel x 10 s time-parallel block (29 GB of input): a full "
+                    "machine gains nothing from a cut in time, the block documents that (DESIGN.md 4.7)")
+    ap.add_argument("--no-scaled-long", action="store_true", help="(accepted for older command lines: the block is off unless --scaled-long)")
+    ap.add_argument("--no-scaled-big", action="store_true", help="skip the 131072-channel block (23 GB of input)")
     ap.add_argument("--mode", choices=["auto", "strict", "time_parallel", "time_parallel_time_major", "time_parallel_strict_chunks", "relaxed"], default="auto",
                     help="which mode the headline value reports: auto = time-parallel when its parity contract holds on this "
                          "run's own first pass (payload bytes of every burst and every transport message equal to strict "
@@ -509,12 +512,12 @@ def main():
         "time_parallel": "channel-major input x[channel][t]; time chunks per channel = state columns side by side, chunk boundaries per channel at idle "
                          "instants (device-side energy scout + planner + sort: inside kernel_ms, which is what `achieved` is priced on, as far as they "
                          "are not hidden under the previous launch's tail on the plan stream; demod_kernel_alone_ms is the demodulation kernel by "
-                         "itself, what rocprofv3 lists), 10 pieces per channel, relaxed arithmetic inside the chunks (the pipeline's FASTMATH build; "
+                         "itself, what rocprofv3 lists), 10 pieces per channel, relaxed arithmetic inside the chunks (the symbol-paced pipeline, same_kernels_sym.hip; "
                          "DESIGN.md 4.6, 4.7)",
         "time_parallel_time_major": "time-major input; uniform chunk boundaries (one row offset per workgroup keeps the loads coalesced), chunks run on "
                                     "until idle, relaxed arithmetic inside the chunks; kernel_ms includes the state column copies",
         "time_parallel_strict_chunks": "as time_parallel with strict arithmetic inside every chunk (SAME_RELAXED=0: round 2's form of the mode)",
-        "relaxed": "ordinary launch (no cut in time), relaxed arithmetic (SAME_BATCH_RELAXED): the pipeline's FASTMATH build up to 32 768 channels, "
+        "relaxed": "ordinary launch (no cut in time), relaxed arithmetic (SAME_BATCH_RELAXED): the symbol-paced pipeline (same_kernels_sym.hip) up to 65 536 channels, "
                    "the relaxed kernel of same_kernels_relaxed.hip beyond",
     }
     layouts = {"time_parallel": "channel-major x[channel][t]", "time_parallel_strict_chunks": "channel-major x[channel][t]"}
@@ -613,8 +616,27 @@ def main():
             if xs is None or xs.shape[1] < cc:
                 xs = x[:, :cc].contiguous().cpu().numpy()
             xcpu = np.ascontiguousarray(xs[:, :cc].T)          # [channel][time]
-            cores = ob.physical_cores()
+            cores_all = ob.physical_cores()
             logical = len(os.sched_getaffinity(0))
+            # A container may be granted fewer CPUs than it can see (cgroup v2 cpu.max = quota period): 128 pinned threads
+            # on a 16-CPU quota are throttled to 16 CPUs' worth of time -- round 3's "10 Msample/s per core against 46 for
+            # the same code on one core".  One worker per physical core, as many as the quota covers.
+            quota = None
+            try:
+                q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+                quota = None if q == "max" else float(q) / float(per)
+            except (OSError, ValueError):
+                pass
+            n_use = len(cores_all) if quota is None else max(1, min(len(cores_all), int(quota)))
+            cores = cores_all[:n_use]
+            # one core by itself first: what the code does when nothing competes with it
+            x1 = xcpu[:8]
+            t1 = time.perf_counter()
+            ob.batch_run_channel_major(cfg, x1, cpus=cores[:1], reps=1)
+            r1 = max(1, int(np.ceil(1.0 / max(time.perf_counter() - t1, 1e-3))))
+            t1 = time.perf_counter()
+            ob.batch_run_channel_major(cfg, x1, cpus=cores[:1], reps=r1)
+            alone = x1.shape[0] * T * r1 / (time.perf_counter() - t1) / 1e6
             ob.batch_run_channel_major(cfg, xcpu, cpus=cores, reps=1)      # warm pass: threads, page faults, caches
             t1 = time.perf_counter()
             ob.batch_run_channel_major(cfg, xcpu, cpus=cores, reps=1)
@@ -631,12 +653,15 @@ def main():
             rate = cc * T * reps / dt / 1e6
             out["cpu_baseline"] = {
                 "value": round(rate, 2), "unit": "Msamples/s", "cores": len(cores), "kind": "port",
-                "per_core": round(rate / len(cores), 2), "logical_cpus": logical,
+                "per_core_all": round(rate / len(cores), 2), "per_core_alone": round(alone, 2),
+                "physical_cores_visible": len(cores_all), "logical_cpus": logical,
+                "cgroup_cpu_quota": quota,
                 "sample": f"first {cc} channels x {T} samples of the same synthetic input, channel-major on the host, "
                           f"{reps} repetition(s), link layer only, {dt:.2f} s wall on {len(cores)} threads pinned one per "
                           f"physical core (scalar C restatement of sameold 0.6.0; the Rust reference cannot be built in this image); "
-                          f"{cc} channels on {len(cores)} cores = {cc / max(len(cores), 1):.0f} per core, so the figure is the all-core "
-                          f"clock and memory system of the host, not one core's 46 Msample/s",
+                          + (f"the container's CPU quota is {quota:g} CPUs of the {len(cores_all)} physical cores it sees, so {len(cores)} "
+                             f"workers were run -- more would only be throttled; " if quota is not None and quota < len(cores_all) else "")
+                          + f"one worker alone on one core: {alone:.1f} Msample/s, each of the {len(cores)} together: {rate / len(cores):.1f}",
             }
             del xcpu
         del xs
@@ -666,7 +691,35 @@ def main():
                 del rx2
             del x2, ev_strict
             torch.cuda.empty_cache()
-            if not args.no_scaled_long:
+            if not args.no_scaled_big:
+                # the regime where the one-wavefront kernels take over: 131072 channels x 2 s, strict and relaxed, with the
+                # relaxed pass held against the strict one (first pass, every channel)
+                try:
+                    Cb = 131072
+                    xb = sa.synth_afsk(Cb, Ts, args.rate, seed=780, device=local_rank)
+                    out["scaled_big"] = {"workload": f"{Cb} channels x {Ts} samples per step"}
+                    ev_b = None
+                    nb = max(args.steps // 2, 5)
+                    for label, kw in (("strict", {}), ("relaxed", {"relaxed": True})):
+                        rxb = sa.SameReceiverBuilder(args.rate).build_batch(Cb, device=local_rank, **kw)
+                        rxb.set_kernel_timing(True)
+                        eb, kb, fb_, _, _ = run_steps(sa, rxb, xb, Ts, stream, nb, 1, lambda r: len(r.pack_bursts_np(0)), lambda: None)
+                        ab = 4.0 * Cb * Ts / (kb * 1e-3) / 1e9
+                        blk = {"value": round(Cb * Ts * nb / eb / 1e6, 2), "unit": "Msamples/s", "kernel_ms": round(kb, 4), "steps": nb,
+                               "ms_per_step": round(eb / nb * 1e3, 3), "kernel": rxb.kernel_name(),
+                               "roofline": {"bound": "hbm", "achieved": round(ab, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ab / HBM_PEAK_GBS, 5)}}
+                        if label == "strict":
+                            ev_b = fb_
+                            out["scaled_big"].update(blk)
+                        else:
+                            blk["contract"] = tp_contract(sa, ev_b, fb_, Cb, 780, "first pass", t_end=Ts, rate=args.rate)[1]
+                            out["scaled_big"]["relaxed"] = blk
+                        del rxb
+                    del xb, ev_b
+                except Exception as exc:      # (a smaller device memory: the block is extra evidence, never the headline)
+                    out["scaled_big"] = {"skipped": repr(exc)[:200]}
+                torch.cuda.empty_cache()
+            if args.scaled_long:
                 # the same shard with 10 s per step (29 GB resident): long enough for the time-parallel cut
                 # -- 4 pieces per channel = 131 072 state columns on the relaxed kernel of same_kernels_relaxed.hip
                 try:

@@ -150,8 +150,12 @@ enum {
      * continues from the channel's state; every other chunk starts from a freshly built receiver a
      * warm-up (64 symbols by default) before the samples it owns, and a chunk keeps running past its
      * end until its channel has been seen idle (LinkState::NoCarrier), where the next chunk takes over.
-     * The arithmetic of every chunk is the strict, bit-exact arithmetic; what is approximated is the
-     * state a chunk starts from.  Contract (tests/test_time_parallel.py): burst bytes, their order and
+     * What is approximated is the state a chunk starts from and -- at 22.05 kHz, where the relaxed kernels exist --
+     * the arithmetic inside the chunks, which is that of SAME_BATCH_RELAXED below (SAME_RELAXED=0 in the
+     * environment keeps the chunks on the strict kernels).  The mode wants a CHANNEL-MAJOR buffer: there every
+     * channel is cut where it is quiet; a time-major buffer is cut at the same rows for all channels and its
+     * chunks run on through whatever burst straddles a cut (a third slower at configs[1]).
+     * Contract (tests/test_time_parallel.py): burst bytes, their order and
      * the transport messages equal the reference's; link events are the same sequence with sample
      * counters within SAME_TP_EVENT_TOLERANCE_SYMBOLS symbols (Searching: anywhere inside the preamble);
      * soft symbols of an open squelch within 0.05 with equal sign; transport events are stamped from a
@@ -160,9 +164,12 @@ enum {
      * not a multiple of 16 run as ordinary strict launches.  Not combinable with
      * SAME_BATCH_TRACE_SYMBOLS. */
     SAME_BATCH_TIME_PARALLEL = 1u << 3,
-    /* Relaxed arithmetic ("fast mode" of the north star; same_kernels_relaxed.hip).  The reference's algorithm, every
-     * decision and feedback path at the sample it happens, with the rounding of the floating-point expressions given
-     * up: matched filters as fused multiply-adds into four partial sums instead of one newest-first chain
+    /* Relaxed arithmetic ("fast mode" of the north star; same_kernels_sym.hip up to 65 536 channels and inside
+     * time-parallel chunks, same_kernels_relaxed.hip beyond).  The reference's algorithm and every decision of it, with
+     * the rounding of the floating-point expressions given up -- and, in same_kernels_sym.hip, with what end() undoes
+     * (AGC unlock, loop bandwidth, symsync.reset(): receiver.rs:479-490) taking effect two to three symbols after the
+     * symbol that ended the burst instead of at it; the lock at sync (receiver.rs:431-432) is taken at its sample:
+     * matched filters as fused multiply-adds into four partial sums instead of one newest-first chain
      * (rx/filter.rs:363-377), |mark| and |space| as an f32 square root instead of hypot (rx/demod.rs:163), the AGC update
      * as gain * (1 - bw |x|) + bw (rx/agc.rs:72-77), reciprocals for the timing loop's and the equalizer's divisions.
      * The timing trajectory is chaotic in the last bit of those sums, so the contract is the

@@ -379,11 +379,14 @@ void read_knobs(same_batch *rx)
     auto tri = [](const char *name) { const char *e = std::getenv(name); return e ? (std::atoi(e) ? 1 : -1) : 0; };
     rx->P.knob_pipe = tri("SAME_PIPE");
     rx->P.knob_pipe_lanes = num("SAME_PIPE_LANES", 0);
-    rx->P.knob_pipe_split = tri("SAME_PIPE_SPLIT");
+    rx->P.knob_pipe_split = tri("SAME_PIPE_SPLIT");            // (test knob: tests/test_gpu_parity.py pits the two stage-2 forms against each other)
+#ifdef SAME_PROFILE
+    // measurement knobs: read by profile builds only (python -m sameold_amd.build with SAME_PROFILE set), never by the shipped library
     rx->P.knob_mirror = tri("SAME_MIRROR");
     rx->P.knob_pipe_share = tri("SAME_PIPE_SHARE");
-    rx->P.knob_fast_dense = tri("SAME_FAST_DENSE");
     rx->P.knob_prio = num("SAME_PIPE_PRIO", 0);
+#endif
+    rx->P.knob_fast_dense = tri("SAME_FAST_DENSE");
     rx->P.knob_sym = tri("SAME_SYM");
     rx->debug = std::getenv("SAME_DEBUG") != nullptr;
     rx->host_threads = std::max(0, num("SAME_HOST_THREADS", 0));

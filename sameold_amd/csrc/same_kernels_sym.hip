@@ -559,7 +559,8 @@ __global__ __launch_bounds__(4 * kWave, 2) void demod_sym_kernel(Params P, State
         auto filter_a = [&](uint32_t s, uint32_t seq) __attribute__((always_inline)) {
             const uint32_t n1 = posbox[(s & 1u) * LY::pos_words + lane];
             if (__builtin_amdgcn_ballot_w64(n1 != 0xffffffffu) == 0ull) return;
-            const float sa1 = sym_demod1<RING>(taps_lds, wcol_lds, n1 == 0xffffffffu ? 0 : (int)n1);
+            // (a profile build's knock-out skips the filter, never the hand-over E waits for)
+            const float sa1 = PROF_SKIP(P, 256) ? 0.0f : sym_demod1<RING>(taps_lds, wcol_lds, n1 == 0xffffffffu ? 0 : (int)n1);
             sabox[lane] = __float_as_uint(sa1);
             if (lane == 0u) seqbox[0] = seq;                           // (LDS operations of a wavefront stay in order)
         };
@@ -568,7 +569,7 @@ __global__ __launch_bounds__(4 * kWave, 2) void demod_sym_kernel(Params P, State
         uint32_t stop_at = 0xffffffffu;
         bool left = false;
         for (uint32_t s = 0; s < n_steps; ++s) {
-            if (s >= 1u && s <= last_t_step && !PROF_SKIP(P, 256)) filter_a(s, 2u * s + 1u);
+            if (s >= 1u && s <= last_t_step) filter_a(s, 2u * s + 1u);
             if (s < n_blocks && !PROF_SKIP(P, 64)) M.block(P, wcol, yring + ((s & 1u) * (uint32_t)kB) * LP + lane, s);
             P3_LAP(p3_work);
             lds_barrier();                                             // A
@@ -863,7 +864,7 @@ __global__ __launch_bounds__(4 * kWave, 2) void demod_sym_kernel(Params P, State
             if (__builtin_amdgcn_ballot_w64(pl_ready) != 0ull) {
                 SYM_T_BEGIN();
                 SYM_TCOUNT(13, 1);
-                const float sa2 = sym_demod1<RING>(taps_lds, wcol_lds, (int)pl_n2);
+                const float sa2 = PROF_SKIP(P, 512) ? 0.0f : sym_demod1<RING>(taps_lds, wcol_lds, (int)pl_n2);
                 SYM_T_LAP(15);
                 float sa1 = 0.0f;
                 if (__builtin_amdgcn_ballot_w64(pl_ready && pl_typeA) != 0ull) {
