@@ -12,7 +12,7 @@ import collections, csv, glob, json, os, re, shutil, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 P = os.path.join(ROOT, "gpurun_out", "prof")
 OUT = os.path.join(ROOT, "profiles")
-R = sys.argv[1] if len(sys.argv) > 1 else "r03"
+R = sys.argv[1] if len(sys.argv) > 1 else "r04"
 
 
 def one(pattern):
@@ -29,7 +29,16 @@ def classify(name, wgs, state, n1):
     <NT, NFF, NFB, MED3, SHARE, LANES, SPLIT, SampleT, FASTMATH, input form> and its workgroup count (bench.py runs the blocks in a fixed
     order; `state` counts what has been seen, n1 = launches per configs[1] block)."""
     if "demod_relaxed_kernel" in name or "demod_duo_kernel" in name:
-        return "scaled_long_time_parallel"
+        return "scaled_big_relaxed"
+    if "demod_sym_kernel" in name:
+        # <NFF, NFB, SampleT, input form>: the symbol-paced pipeline takes every relaxed launch up to 65 536 columns
+        cols = wgs * 64
+        if cols == C:
+            return "relaxed"
+        if cols > 32768:
+            return "time_parallel"
+        state["sym512"] = state.get("sym512", 0) + 1          # 32 768 columns: configs[1] cut uniformly on the time-major buffer first, the shard later
+        return "time_parallel_time_major" if state["sym512"] <= n1 else "scaled_relaxed"
     m = re.search(r"demod_pipe_kernel<(\d+), \d+, \d+, \w+, (\w+), (\d+), \w+, \w+, (\w+)(?:, \d+)?>", name)
     if not m:
         return None
@@ -57,7 +66,7 @@ C, T = bench["config"]["channels_per_gpu"], bench["config"]["samples_per_channel
 CONFIGS1 = ("strict", "time_parallel", "time_parallel_time_major", "time_parallel_strict_chunks", "relaxed")
 
 # ---- per-launch durations, in launch order, per block
-DEMOD = ("demod_pipe_kernel", "demod_fast_kernel", "demod_relaxed_kernel", "demod_duo_kernel")
+DEMOD = ("demod_pipe_kernel", "demod_fast_kernel", "demod_relaxed_kernel", "demod_duo_kernel", "demod_sym_kernel")
 all_rows = list(csv.DictReader(open(one("trace/*/*_kernel_trace.csv"))))
 all_rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 rows = [r for r in all_rows if any(k in r["Kernel_Name"] for k in DEMOD)]
@@ -116,7 +125,7 @@ for d, name in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
     for v, vals in seen.items():
         per[v][name] = (sum(vals) / len(vals), len(vals))
 sizes = {"strict": (C, T), "time_parallel": (C, T), "time_parallel_time_major": (C, T), "time_parallel_strict_chunks": (C, T), "relaxed": (C, T),
-         "scaled": (32768, 44100), "scaled_relaxed": (32768, 44100), "configs2_48k": (16384, 96000)}
+         "scaled": (32768, 44100), "scaled_relaxed": (32768, 44100), "configs2_48k": (16384, 96000), "scaled_big_relaxed": (131072, 44100)}
 for v, d in per.items():
     if "FETCH_SIZE" not in d or "WRITE_SIZE" not in d or v not in sizes:
         continue
