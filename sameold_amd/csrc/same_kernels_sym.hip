@@ -180,29 +180,88 @@ __device__ __forceinline__ void sym_demod2(uint32_t taps_lds, uint32_t wcol_lds,
     *sa2 = __builtin_amdgcn_fmed3f(relax_magnitude(bm0 + bm1) - relax_magnitude(bs0 + bs1), -1.0f, 1.0f);
 }
 
-// ... and at ONE instant: the three chunks' loads software-pipelined across each other as in demod_pair_relaxed_42
-// (same_relaxed_common.h), over this ring's partial mirror
-template <int RING>
-__device__ __forceinline__ float sym_demod1(uint32_t taps_lds, uint32_t wcol_lds, int n)
-{
-    float2v am0 = {0.0f, 0.0f}, am1 = {0.0f, 0.0f}, as0 = {0.0f, 0.0f}, as1 = {0.0f, 0.0f};
-    const uint32_t wa0 = sym_chunk_addr<RING>(wcol_lds, n, 0), wa1 = sym_chunk_addr<RING>(wcol_lds, n, 1), wa2 = sym_chunk_addr<RING>(wcol_lds, n, 2);
-    const uint32_t ta0 = taps_lds, ta1 = taps_lds + 224u, ta2 = taps_lds + 448u;
-    RelaxPart X, Y, Z;
-    RELAX_LOAD_A(X, wa0, ta0);
-    RELAX_LOAD_B(Y, wa0, ta0);
-    RELAX_WAIT_A(X, 9);  RELAX_FMA_A(X);
-    RELAX_LOAD_A(Z, wa1, ta1);
-    RELAX_WAIT_B(Y, 12); RELAX_FMA_B(Y);
-    RELAX_LOAD_B(X, wa1, ta1);
-    RELAX_WAIT_A(Z, 9);  RELAX_FMA_A(Z);
-    RELAX_LOAD_A(Y, wa2, ta2);
-    RELAX_WAIT_B(X, 12); RELAX_FMA_B(X);
-    RELAX_LOAD_B(Z, wa2, ta2);
-    RELAX_WAIT_A(Y, 9);  RELAX_FMA_A(Y);
-    RELAX_WAIT_B(Z, 0);  RELAX_FMA_B(Z);
-    return __builtin_amdgcn_fmed3f(relax_magnitude(am0 + am1) - relax_magnitude(as0 + as1), -1.0f, 1.0f);
-}
+// ... and at ONE instant, with the taps in registers.  The matched filter is a cisoid, h[i] = (2/N) e^{-j phi (N-1-i)}
+// (rx/waveform.rs:39-64), so its second half is the first one mirrored: h[N-1-k] = C conj(h[k]) with C = (N/2) h[0] (a unit
+// phasor; the host's f32 taps obey this to 7e-8).  For a real window w (w_i = the sample tap i meets)
+//     sum_i w_i h_i = A + C conj(B),   A = sum_{k<N/2} w_k h_k,   B = sum_{k<N/2} w_{N-1-k} h_k,
+// i.e. both halves use the SAME 21 taps per tone: 84 registers hold them for the whole launch, and a filter is 21 window
+// loads (two slots each) and 84 packed multiply-adds -- no tap loads (they were two thirds of the filter's LDS traffic and
+// every product waited for one).  Relaxed arithmetic: another association of the same sum.
+struct SymWin { float2v w0, w1, w2, w3, w4, w5, w6; };
+#define SYM_WLOAD(W_, wa_)                                                                                         \
+    asm volatile("ds_read2st64_b32 %[w0], %[wa] offset0:0 offset1:1\n\t"                                          \
+                 "ds_read2st64_b32 %[w1], %[wa] offset0:2 offset1:3\n\t"                                          \
+                 "ds_read2st64_b32 %[w2], %[wa] offset0:4 offset1:5\n\t"                                          \
+                 "ds_read2st64_b32 %[w3], %[wa] offset0:6 offset1:7\n\t"                                          \
+                 "ds_read2st64_b32 %[w4], %[wa] offset0:8 offset1:9\n\t"                                          \
+                 "ds_read2st64_b32 %[w5], %[wa] offset0:10 offset1:11\n\t"                                        \
+                 "ds_read2st64_b32 %[w6], %[wa] offset0:12 offset1:13"                                            \
+                 : [w0] "=&v"(W_.w0), [w1] "=&v"(W_.w1), [w2] "=&v"(W_.w2), [w3] "=&v"(W_.w3), [w4] "=&v"(W_.w4),   \
+                   [w5] "=&v"(W_.w5), [w6] "=&v"(W_.w6)                                                             \
+                 : [wa] "v"(wa_) : "memory")
+#define SYM_WWAIT(W_, n_) asm volatile("s_waitcnt lgkmcnt(" #n_ ")" : "+v"(W_.w0), "+v"(W_.w1), "+v"(W_.w2), "+v"(W_.w3), "+v"(W_.w4), "+v"(W_.w5), "+v"(W_.w6))
+template <int NT>
+struct SymTaps {
+    static constexpr int H = NT / 2;
+    static_assert(NT == 42, "three chunks of 14 taps; N even");
+    float2v tm[H], ts[H];                // taps 0 .. N/2 - 1: mark (re, im), space (re, im)
+    float2v cm, cs;                      // C per tone
+    __device__ __forceinline__ void load(const float4 *__restrict__ taps)
+    {
+        sym_static_for<H>([&](auto k_) __attribute__((always_inline)) {
+            constexpr int k = decltype(k_)::value;
+            const float4 t = taps[k];
+            tm[k] = float2v{t.x, t.y}; ts[k] = float2v{t.z, t.w};
+            // (wave-uniform values: left to itself the compiler keeps them in scalar registers, runs out of those, and
+            // fetches every operand back with v_readlane -- they are vector operands of every product, so vector registers)
+            asm volatile("" : "+v"(tm[k]), "+v"(ts[k]));
+        });
+        cm = tm[0] * float2v{(float)H, (float)H};
+        cs = ts[0] * float2v{(float)H, (float)H};
+        asm volatile("" : "+v"(cm), "+v"(cs));
+    }
+    // |mark| - |space| clamped to +-1 (rx/demod.rs:156-164) at the instant whose sample sits in ring slot n
+    template <int RING>
+    __device__ __forceinline__ float demod(uint32_t wcol_lds, int n) const
+    {
+        const uint32_t wa0 = sym_chunk_addr<RING>(wcol_lds, n, 0), wa1 = sym_chunk_addr<RING>(wcol_lds, n, 1), wa2 = sym_chunk_addr<RING>(wcol_lds, n, 2);
+        // [half A / B][parity of the tap]: two chains per sum
+        float2v am[2] = {{0.0f, 0.0f}, {0.0f, 0.0f}}, as_[2] = {{0.0f, 0.0f}, {0.0f, 0.0f}};
+        float2v bm[2] = {{0.0f, 0.0f}, {0.0f, 0.0f}}, bs[2] = {{0.0f, 0.0f}, {0.0f, 0.0f}};
+        SymWin X, Y, Z;
+        SYM_WLOAD(X, wa0);
+        SYM_WLOAD(Y, wa1);
+        SYM_WLOAD(Z, wa2);
+        // chunk c: pair K = slots lowest + 2K (tap 14 c + 13 - 2K, odd) and lowest + 2K + 1 (tap 14 c + 12 - 2K, even)
+        auto chunk = [&](auto c_, const SymWin &W) __attribute__((always_inline)) {
+            constexpr int c = decltype(c_)::value;
+            auto pair = [&](auto K_, float2v w) __attribute__((always_inline)) {
+                constexpr int K = decltype(K_)::value;
+                constexpr int i_lo = kRelaxChunk * c + 13 - 2 * K, i_hi = i_lo - 1;         // tap indices the two slots meet
+                constexpr int k_lo = i_lo < H ? i_lo : NT - 1 - i_lo, k_hi = i_hi < H ? i_hi : NT - 1 - i_hi;
+                if constexpr (i_lo < H) { pk_fma_lo(am[i_lo & 1], w, tm[k_lo]); pk_fma_lo(as_[i_lo & 1], w, ts[k_lo]); }
+                else { pk_fma_lo(bm[i_lo & 1], w, tm[k_lo]); pk_fma_lo(bs[i_lo & 1], w, ts[k_lo]); }
+                if constexpr (i_hi < H) { pk_fma_hi(am[i_hi & 1], w, tm[k_hi]); pk_fma_hi(as_[i_hi & 1], w, ts[k_hi]); }
+                else { pk_fma_hi(bm[i_hi & 1], w, tm[k_hi]); pk_fma_hi(bs[i_hi & 1], w, ts[k_hi]); }
+            };
+            pair(std::integral_constant<int, 0>{}, W.w0); pair(std::integral_constant<int, 1>{}, W.w1);
+            pair(std::integral_constant<int, 2>{}, W.w2); pair(std::integral_constant<int, 3>{}, W.w3);
+            pair(std::integral_constant<int, 4>{}, W.w4); pair(std::integral_constant<int, 5>{}, W.w5);
+            pair(std::integral_constant<int, 6>{}, W.w6);
+        };
+        SYM_WWAIT(X, 14); chunk(std::integral_constant<int, 0>{}, X);
+        SYM_WWAIT(Y, 7);  chunk(std::integral_constant<int, 1>{}, Y);
+        SYM_WWAIT(Z, 0);  chunk(std::integral_constant<int, 2>{}, Z);
+        auto magnitude = [&](float2v a0, float2v a1, float2v b0, float2v b1, float2v c) __attribute__((always_inline)) -> float {
+            const float2v a = a0 + a1, b = b0 + b1;
+            // a + c conj(b)
+            const float re = __builtin_fmaf(c.x, b.x, __builtin_fmaf(c.y, b.y, a.x));
+            const float im = __builtin_fmaf(c.y, b.x, __builtin_fmaf(-c.x, b.y, a.y));
+            return __builtin_amdgcn_sqrtf(__builtin_fmaf(re, re, im * im));
+        };
+        return __builtin_amdgcn_fmed3f(magnitude(am[0], am[1], bm[0], bm[1], cm) - magnitude(as_[0], as_[1], bs[0], bs[1], cs), -1.0f, 1.0f);
+    }
+};
 
 // ---------------------------------------------------------------------------------------------------------------------
 // T's sample half: input prefetch and DC blocker, one block ahead of S.  Inputs alternate between two register buffers
@@ -549,18 +608,19 @@ __global__ __launch_bounds__(4 * kWave, 2) void demod_sym_kernel(Params P, State
 
     if (role == 0u) {
         // ------------------------------------------ S: AGC + window push, block s -------------------------------------
-        for (uint32_t i = lane; i < (uint32_t)NT; i += kWave) tlds[i] = taps[i];
         P3_HWID(0);
         SymAgc M;
         M.load(P, S, c, C, counter0, wcol);
-        const uint32_t taps_lds = lds_addr(lds), wcol_lds = lds_addr(wcol);
+        const uint32_t wcol_lds = lds_addr(wcol);
+        SymTaps<NT> TP;
+        TP.load(taps);
         if (lane == 0u) seqbox[0] = 0u;
         // the matched filters of the FIRST instant of the step's symbol, at the positions E posted (E takes the second)
         auto filter_a = [&](uint32_t s, uint32_t seq) __attribute__((always_inline)) {
             const uint32_t n1 = posbox[(s & 1u) * LY::pos_words + lane];
             if (__builtin_amdgcn_ballot_w64(n1 != 0xffffffffu) == 0ull) return;
             // (a profile build's knock-out skips the filter, never the hand-over E waits for)
-            const float sa1 = PROF_SKIP(P, 256) ? 0.0f : sym_demod1<RING>(taps_lds, wcol_lds, n1 == 0xffffffffu ? 0 : (int)n1);
+            const float sa1 = PROF_SKIP(P, 256) ? 0.0f : TP.template demod<RING>(wcol_lds, n1 == 0xffffffffu ? 0 : (int)n1);
             sabox[lane] = __float_as_uint(sa1);
             if (lane == 0u) seqbox[0] = seq;                           // (LDS operations of a wavefront stay in order)
         };
@@ -830,7 +890,9 @@ __global__ __launch_bounds__(4 * kWave, 2) void demod_sym_kernel(Params P, State
     } else {
         // ------------------------------------------ E: one symbol per lane and step: matched filters, timing loop --------
         P3_HWID(3);
-        const uint32_t taps_lds = lds_addr(lds), wcol_lds = lds_addr(wcol);
+        const uint32_t wcol_lds = lds_addr(wcol);
+        SymTaps<NT> TP;
+        TP.load(taps);
         Lane L;
         lane_load(L, S, c);
         const float inv_spt = 1.0f / P.samples_per_ted;
@@ -864,7 +926,7 @@ __global__ __launch_bounds__(4 * kWave, 2) void demod_sym_kernel(Params P, State
             if (__builtin_amdgcn_ballot_w64(pl_ready) != 0ull) {
                 SYM_T_BEGIN();
                 SYM_TCOUNT(13, 1);
-                const float sa2 = PROF_SKIP(P, 512) ? 0.0f : sym_demod1<RING>(taps_lds, wcol_lds, (int)pl_n2);
+                const float sa2 = PROF_SKIP(P, 512) ? 0.0f : TP.template demod<RING>(wcol_lds, (int)pl_n2);
                 SYM_T_LAP(15);
                 float sa1 = 0.0f;
                 if (__builtin_amdgcn_ballot_w64(pl_ready && pl_typeA) != 0ull) {
