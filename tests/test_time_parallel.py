@@ -332,7 +332,9 @@ def assert_awgn_tallies_equal(sa, got, ref, payloads, n, grid, strict_arithmetic
         clean = ta["intact"] >= 0.99 * np.maximum(ta["trials"], 1)
         assert clean.any() and np.all(differ[clean] <= 0.03 * ta["trials"][clean] + 2), (differ, clean)
         be_a, be_b = ta["bit_errors"].astype(np.float64), tb["bit_errors"].astype(np.float64)
-        assert np.all(np.abs(be_a - be_b) <= 0.15 * np.maximum(be_a, be_b) + 60), (be_a, be_b)
+        # (bit errors come in lumps -- a trial that loses byte sync for a while contributes dozens -- so a grid point's count is
+        # a sum over a handful of trials and moves by a lump when one marginal trial decodes the other way)
+        assert np.all(np.abs(be_a - be_b) <= 0.30 * np.maximum(be_a, be_b) + 150), (be_a, be_b)
     for k in ("detected", "intact"):
         # binomial: |difference| within 4 sigma of the strict count per grid point
         sig = np.sqrt(np.maximum(ta[k] * (1 - ta[k] / np.maximum(ta["trials"], 1)), 1.0))
