@@ -527,6 +527,25 @@ struct SymAgc {
     }
 };
 
+// Y's context: RelaxFastCtx (equalizer and its snapshot in registers, relaxed equalizer step) with the squelch's sample
+// history in global memory.  The two samples the NEXT symbol's equalizer step takes (rx_symbol: slots +16 / +17 from the
+// squelch's write position, i.e. +18 / +19 from this symbol's) are requested where this symbol's samples are stored: a
+// global round trip is a step long under load, and on gfx950 loads and stores retire in one queue (vmcnt) -- requested
+// at the end of the step they would also wait for the framer's scattered byte stores issued before them.  Only this lane's
+// own symbols write its history, and never those two slots before they are read: they cannot go stale.
+template <int NFF, int NFB>
+struct SymCtx : RelaxFastCtx<NFF, NFB> {
+    float nxt0 = 0.0f, nxt1 = 0.0f;
+    __device__ __forceinline__ void hist_put(uint32_t slot, float v)
+    {
+        if ((slot & 1u) == 0u) {
+            nxt0 = this->hist[(size_t)((slot + 18u) & 63u) * this->hstride];
+            nxt1 = this->hist[(size_t)((slot + 19u) & 63u) * this->hstride];
+        }
+        this->hist[(size_t)slot * this->hstride] = v;
+    }
+};
+
 // ---------------------------------------------------------------------------------------------------------------------
 template <int NFF, int NFB, typename SampleT, int CMODE>
 __global__ __launch_bounds__(4 * kWave, 2) void demod_sym_kernel(Params P, State S, Output O, const float4 *__restrict__ taps,
@@ -731,7 +750,7 @@ __global__ __launch_bounds__(4 * kWave, 2) void demod_sym_kernel(Params P, State
         Lane L;
         lane_load(L, S, c);
         L.ended = 0u;
-        RelaxFastCtx<NFF, NFB> X;
+        SymCtx<NFF, NFB> X;
         // the squelch's sample history stays in global memory: the state array itself, or -- where the columns of a wavefront
         // are permuted -- a copy by grid position (coalesced; the state array is read and written once per launch)
         const bool hist_copy = K.n_chunks > 1u && K.col_perm != nullptr && K.hist_scratch != nullptr;
@@ -752,10 +771,9 @@ __global__ __launch_bounds__(4 * kWave, 2) void demod_sym_kernel(Params P, State
             X.fbc[i] = S.eq_fbc[i * C + c]; X.fbw[i] = S.eq_fbw[i * C + c];
             X.sfbc[i] = S.eq_snap_fbc[i * C + c]; X.sfbw[i] = S.eq_snap_fbw[i * C + c];
         }
-        float pre0, pre1;
         {
             const uint32_t pslot = (uint32_t)(2u * (uint32_t)L.sq_symbols) & 63u;
-            pre0 = X.hist_get((pslot + 16u) & 63u); pre1 = X.hist_get((pslot + 17u) & 63u);
+            X.nxt0 = X.hist_get((pslot + 16u) & 63u); X.nxt1 = X.hist_get((pslot + 17u) & 63u);
         }
         lds_barrier();                                                 // prologue
         P3_T0();
@@ -766,8 +784,8 @@ __global__ __launch_bounds__(4 * kWave, 2) void demod_sym_kernel(Params P, State
             if (s >= 2u && s <= last_fb_step) {
                 const uint32_t blk = min(s - 2u, n_blocks - 1u);       // every symbol up to the end of this block has been seen after this step
                 const lds_u32 *sb = symbox + ((s - 1u) & 1u) * LY::sym_words + lane;
-                // (pre0 / pre1: the two history samples the symbol's equalizer step takes, rx_symbol: slots +16/+17 from the
-                // squelch's write position -- fetched at the end of the step before, see below)
+                // (the two history samples the symbol's equalizer step takes were requested with the lane's last symbol: SymCtx)
+                const float pre0 = X.nxt0, pre1 = X.nxt1;
                 const uint32_t hdr = sb[0], zero_w = sb[kWave], sym_w = sb[2 * kWave];
                 uint32_t fbv = 0, io0 = 0, io1 = 0xffffffffu, io2 = 0;
                 bool want_slot = false;                                // this lane has just finished a burst
@@ -827,13 +845,6 @@ __global__ __launch_bounds__(4 * kWave, 2) void demod_sym_kernel(Params P, State
                             if ((int)lane == j) io1 = 0xffffffffu;
                         }
                     }
-                }
-                // The history samples of this lane's NEXT symbol, whenever it comes: global memory is a step away (1-2 us under
-                // load), so they are requested now.  Only this lane's own symbols write its history, and never those two slots
-                // (the next symbol writes slots +0/+1 of its position, these are +16/+17): they cannot go stale.
-                {
-                    const uint32_t pslot = (uint32_t)(2u * (uint32_t)L.sq_symbols) & 63u;
-                    pre0 = X.hist_get((pslot + 16u) & 63u); pre1 = X.hist_get((pslot + 17u) & 63u);
                 }
                 lds_u32 *io = iobox + (s & 1u) * LY::io_words + lane;
                 io[0] = io0;
