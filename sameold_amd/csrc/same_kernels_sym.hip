@@ -294,11 +294,21 @@ struct SymDc {
                 dst[2 * j] = float2v{v.x, v.y}; dst[2 * j + 1] = float2v{v.z, v.w};
             });
         } else {
+            // buffer loads: the block's first row is the resource's base (re-based per block: a launch may exceed the 4 GB a
+            // resource spans), row k at the scalar offset k * row_bytes, the lane's column as the vector offset -- one
+            // instruction per sample and no address arithmetic on the vector unit (36 x 64-bit adds otherwise)
             const SampleT *xr = x + ((size_t)min(blk, n_blocks - 1u) * B) * Cin;      // wave-uniform
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<SampleT *>(xr), 0, 0x7fffffff, 0x00020000);
+            const uint32_t voff = cin * (uint32_t)sizeof(SampleT);
+            uint32_t row_bytes = Cin * (uint32_t)sizeof(SampleT);
+            asm volatile("" : "+s"(row_bytes));      // (opaque: the 36 row offsets are made here, one multiply each, not kept in 36 scalar registers for the whole launch)
+            auto one = [&](uint32_t k) __attribute__((always_inline)) -> float {
+                if constexpr (sizeof(SampleT) == 4) return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, voff, k * row_bytes, 0));
+                else return (float)(int16_t)__builtin_amdgcn_raw_buffer_load_b16(rs, voff, k * row_bytes, 0);
+            };
             sym_static_for<B / 2>([&](auto h_) __attribute__((always_inline)) {
                 constexpr int h = decltype(h_)::value;
-                const SampleT *r0 = xr + (size_t)(2 * h) * Cin, *r1 = xr + (size_t)(2 * h + 1) * Cin;
-                dst[h] = float2v{(float)r0[cin], (float)r1[cin]};
+                dst[h] = float2v{one(2u * h), one(2u * h + 1u)};
             });
         }
     }
