@@ -10,8 +10,8 @@
 //   * of the two instants of a symbol only the second one (B, the one that completes the symbol) feeds a decision back
 //     into the timing loop; the first (A) just shifts the TED's history and adds the clock offset to the period
 //     (rx/symsync.rs:236-241), so where B falls is known as soon as A's position is -- before either filter has run.
-//     The timing wavefront therefore evaluates BOTH matched-filter pairs of a symbol in one pass (their loads and
-//     accumulation chains interleaved) and runs the two timing updates after them: once per symbol and lane;
+//     The two matched-filter pairs of a symbol are therefore evaluated side by side, on two wavefronts (S at A, E at
+//     B), and E runs the two timing updates after them: once per symbol and lane;
 //   * a step is 36 samples, less than the shortest symbol the timing loop can command (two instants at least 19 samples
 //     apart each: max_block_len), so every lane completes AT MOST one symbol per step and ~85 % of the lanes complete
 //     exactly one: filters, timing loop and symbol path run once per step at ~85 % occupancy;
@@ -24,15 +24,19 @@
 //      (rx/dcblock.rs:45-49) -- handed to S through a two-block LDS ring; then the link events and transport wake-ups of
 //      what Y handed over one step earlier
 //   S  the matched-filter pair at the FIRST instant of the step's symbol (E posts where); then AGC (relaxed) and window push
-//      of block s from the DC blocker's outputs (it keeps those of its last three blocks, packed f16, for the replay of an
-//      AGC lock flip)
+//      of block s from the DC blocker's outputs (it keeps those of its last three blocks, packed f16: the gain an
+//      AGC lock freezes is that of a sample up to two blocks back)
 //   E  the symbol whose instants lie in finished samples (blocks < s): the matched-filter pair at its SECOND instant, then
 //      the two timing updates and where the next symbol's instants fall
 //   Y  symbol path of the symbol E handed over one step earlier: squelch, equalizer, framer (same_dev_common.h); the
 //      squelch's sample history stays in the HBM state arrays (two loads a step, issued ahead)
-// Feedback (agc.lock / loop bandwidth / symsync.reset, receiver.rs:431-432, 479-490) travels back exactly as in
-// same_kernels_pipe.hip: S and E run ahead on their belief, Y posts a change with the sample it happened at, S redoes
-// the AGC from the sample after it, E goes back to its state before the step's symbol and processes it again.
+// Feedback (agc.lock / loop bandwidth / symsync.reset, receiver.rs:431-432, 479-490) never sends a wavefront back: Y posts
+// a change with the symbol it happened at, one word per lane.  S freezes the AGC from its next block on AT THE GAIN IT HAD
+// after that symbol's sample (recomputed from the block's start out of the packed history; the gain every soft symbol
+// of the burst is scaled by is therefore strict mode's to rounding), or releases it from its next block on; E switches the
+// loop bandwidth, or resets the TED, behind its next symbol -- two symbols late.  The first form of this kernel replayed a
+// lock at its sample (two more barriers in ~5 % of the steps, S and E filtering the symbol again): 8 % slower, and
+// nothing the contract below asks for came of it.
 //
 // Window ring: five blocks of 36 slots, the first 13 slots stored twice (a 14-tap filter chunk never wraps).  T reads at
 // most 119 samples back from the end of block s-1 (a lane may lag up to 52 samples behind after a symsync.reset, the
@@ -113,74 +117,7 @@ __device__ __forceinline__ uint32_t sym_chunk_addr(uint32_t wcol_lds, int n, int
     return wcol_lds + (uint32_t)(top - (kRelaxChunk - 1)) * (kWave * 4u);
 }
 
-// FskDemod::demod_now rx/demod.rs:156-164 at TWO instants (ring slots n1, n2) in one pass.  A chunk of 14 taps is read in
-// four parts -- two window pairs of either filter and the four taps they meet (8 LDS loads, 16 packed products), the last
-// part one pair each and two taps -- so one tap load serves both filters; three register sets take the parts in turn and a
-// part's products issue under the next part's latency.  LDS returns in order: "at most N outstanding" names the part that
-// has landed (N = the loads of the one part issued after it).
-struct SymPart { float2v a0, a1, b0, b1; float4v t0, t1, t2, t3; };
-#define SYM_LOAD2(P_, wa_, wb_, ta_, o0, o1, o2, o3, q0, q1, q2, q3)                                              \
-    asm volatile("ds_read2st64_b32 %[a0], %[wa] offset0:" #o0 " offset1:" #o1 "\n\t"                              \
-                 "ds_read2st64_b32 %[b0], %[wb] offset0:" #o0 " offset1:" #o1 "\n\t"                              \
-                 "ds_read_b128 %[t0], %[ta] offset:" #q0 "\n\t"                                                   \
-                 "ds_read_b128 %[t1], %[ta] offset:" #q1 "\n\t"                                                   \
-                 "ds_read2st64_b32 %[a1], %[wa] offset0:" #o2 " offset1:" #o3 "\n\t"                              \
-                 "ds_read2st64_b32 %[b1], %[wb] offset0:" #o2 " offset1:" #o3 "\n\t"                              \
-                 "ds_read_b128 %[t2], %[ta] offset:" #q2 "\n\t"                                                   \
-                 "ds_read_b128 %[t3], %[ta] offset:" #q3                                                          \
-                 : [a0] "=&v"(P_.a0), [a1] "=&v"(P_.a1), [b0] "=&v"(P_.b0), [b1] "=&v"(P_.b1),                    \
-                   [t0] "=&v"(P_.t0), [t1] "=&v"(P_.t1), [t2] "=&v"(P_.t2), [t3] "=&v"(P_.t3)                     \
-                 : [wa] "v"(wa_), [wb] "v"(wb_), [ta] "v"(ta_) : "memory")
-#define SYM_LOAD1(P_, wa_, wb_, ta_, o0, o1, q0, q1)                                                              \
-    asm volatile("ds_read2st64_b32 %[a0], %[wa] offset0:" #o0 " offset1:" #o1 "\n\t"                              \
-                 "ds_read2st64_b32 %[b0], %[wb] offset0:" #o0 " offset1:" #o1 "\n\t"                              \
-                 "ds_read_b128 %[t0], %[ta] offset:" #q0 "\n\t"                                                   \
-                 "ds_read_b128 %[t1], %[ta] offset:" #q1                                                          \
-                 : [a0] "=&v"(P_.a0), [b0] "=&v"(P_.b0), [t0] "=&v"(P_.t0), [t1] "=&v"(P_.t1)                     \
-                 : [wa] "v"(wa_), [wb] "v"(wb_), [ta] "v"(ta_) : "memory")
-// (the values travel through the wait statement so that nothing that reads them can be moved above it)
-#define SYM_WAIT2(P_, n_) asm volatile("s_waitcnt lgkmcnt(" #n_ ")" : "+v"(P_.a0), "+v"(P_.a1), "+v"(P_.b0), "+v"(P_.b1), "+v"(P_.t0), "+v"(P_.t1), "+v"(P_.t2), "+v"(P_.t3))
-#define SYM_WAIT1(P_, n_) asm volatile("s_waitcnt lgkmcnt(" #n_ ")" : "+v"(P_.a0), "+v"(P_.b0), "+v"(P_.t0), "+v"(P_.t1))
-#define SYM_TAPS(fma, win1_, win2_, tap_, m1_, s1_, m2_, s2_) do { const float2v hm_ = {tap_.x, tap_.y}, hs_ = {tap_.z, tap_.w}; \
-        fma(m1_, win1_, hm_); fma(s1_, win1_, hs_); fma(m2_, win2_, hm_); fma(s2_, win2_, hs_); } while (0)
-// pairs {lowest + 2K, lowest + 2K + 1} meet taps {13 - 2K, 12 - 2K}; the lower slot's products go to the ..0 sums, the upper's to ..1
-#define SYM_FMA2(P_) do { SYM_TAPS(pk_fma_lo, P_.a0, P_.b0, P_.t0, am0, as0, bm0, bs0); SYM_TAPS(pk_fma_hi, P_.a0, P_.b0, P_.t1, am1, as1, bm1, bs1); \
-                          SYM_TAPS(pk_fma_lo, P_.a1, P_.b1, P_.t2, am0, as0, bm0, bs0); SYM_TAPS(pk_fma_hi, P_.a1, P_.b1, P_.t3, am1, as1, bm1, bs1); } while (0)
-#define SYM_FMA1(P_) do { SYM_TAPS(pk_fma_lo, P_.a0, P_.b0, P_.t0, am0, as0, bm0, bs0); SYM_TAPS(pk_fma_hi, P_.a0, P_.b0, P_.t1, am1, as1, bm1, bs1); } while (0)
-// the four parts of a chunk: window pairs 0-1 / 2-3 / 4-5 / 6 with taps 13..10 / 9..6 / 5..2 / 1..0 (16 bytes per tap)
-#define SYM_P1(P_, c_) SYM_LOAD2(P_, wa##c_, wb##c_, ta##c_, 0, 1, 2, 3, 208, 192, 176, 160)
-#define SYM_P2(P_, c_) SYM_LOAD2(P_, wa##c_, wb##c_, ta##c_, 4, 5, 6, 7, 144, 128, 112, 96)
-#define SYM_P3(P_, c_) SYM_LOAD2(P_, wa##c_, wb##c_, ta##c_, 8, 9, 10, 11, 80, 64, 48, 32)
-#define SYM_P4(P_, c_) SYM_LOAD1(P_, wa##c_, wb##c_, ta##c_, 12, 13, 16, 0)
-template <int RING>
-__device__ __forceinline__ void sym_demod2(uint32_t taps_lds, uint32_t wcol_lds, int n1, int n2, float *sa1, float *sa2)
-{
-    static_assert(kRelaxChunk == 14, "chunks of 14 taps, written out");
-    float2v am0 = {0.0f, 0.0f}, am1 = {0.0f, 0.0f}, as0 = {0.0f, 0.0f}, as1 = {0.0f, 0.0f};
-    float2v bm0 = {0.0f, 0.0f}, bm1 = {0.0f, 0.0f}, bs0 = {0.0f, 0.0f}, bs1 = {0.0f, 0.0f};
-    const uint32_t wa0 = sym_chunk_addr<RING>(wcol_lds, n1, 0), wa1 = sym_chunk_addr<RING>(wcol_lds, n1, 1), wa2 = sym_chunk_addr<RING>(wcol_lds, n1, 2);
-    const uint32_t wb0 = sym_chunk_addr<RING>(wcol_lds, n2, 0), wb1 = sym_chunk_addr<RING>(wcol_lds, n2, 1), wb2 = sym_chunk_addr<RING>(wcol_lds, n2, 2);
-    const uint32_t ta0 = taps_lds, ta1 = taps_lds + 224u, ta2 = taps_lds + 448u;
-    SymPart X, Y, Z;
-    SYM_P1(X, 0);
-    SYM_P2(Y, 0);
-    SYM_WAIT2(X, 8); SYM_FMA2(X); SYM_P3(Z, 0);
-    SYM_WAIT2(Y, 8); SYM_FMA2(Y); SYM_P4(X, 0);
-    SYM_WAIT2(Z, 4); SYM_FMA2(Z); SYM_P1(Y, 1);
-    SYM_WAIT1(X, 8); SYM_FMA1(X); SYM_P2(Z, 1);
-    SYM_WAIT2(Y, 8); SYM_FMA2(Y); SYM_P3(X, 1);
-    SYM_WAIT2(Z, 8); SYM_FMA2(Z); SYM_P4(Y, 1);
-    SYM_WAIT2(X, 4); SYM_FMA2(X); SYM_P1(Z, 2);
-    SYM_WAIT1(Y, 8); SYM_FMA1(Y); SYM_P2(X, 2);
-    SYM_WAIT2(Z, 8); SYM_FMA2(Z); SYM_P3(Y, 2);
-    SYM_WAIT2(X, 8); SYM_FMA2(X); SYM_P4(Z, 2);
-    SYM_WAIT2(Y, 4); SYM_FMA2(Y);
-    SYM_WAIT1(Z, 0); SYM_FMA1(Z);
-    *sa1 = __builtin_amdgcn_fmed3f(relax_magnitude(am0 + am1) - relax_magnitude(as0 + as1), -1.0f, 1.0f);
-    *sa2 = __builtin_amdgcn_fmed3f(relax_magnitude(bm0 + bm1) - relax_magnitude(bs0 + bs1), -1.0f, 1.0f);
-}
-
-// ... and at ONE instant, with the taps in registers.  The matched filter is a cisoid, h[i] = (2/N) e^{-j phi (N-1-i)}
+// FskDemod::demod_now rx/demod.rs:156-164 at one instant, with the taps in registers.  The matched filter is a cisoid, h[i] = (2/N) e^{-j phi (N-1-i)}
 // (rx/waveform.rs:39-64), so its second half is the first one mirrored: h[N-1-k] = C conj(h[k]) with C = (N/2) h[0] (a unit
 // phasor; the host's f32 taps obey this to 7e-8).  For a real window w (w_i = the sample tap i meets)
 //     sum_i w_i h_i = A + C conj(B),   A = sum_{k<N/2} w_k h_k,   B = sum_{k<N/2} w_{N-1-k} h_k,
@@ -390,7 +327,7 @@ struct SymDc {
 };
 
 // ---------------------------------------------------------------------------------------------------------------------
-// S: AGC and window push, with what a replay needs of its last three blocks
+// S: AGC and window push, with the packed DC-blocker outputs of its last three blocks (the gain a lock freezes)
 // ---------------------------------------------------------------------------------------------------------------------
 struct SymAgc {
     static constexpr int B = SymLayout<42>::B, RING = SymLayout<42>::RING, MIR = SymLayout<42>::MIR;
@@ -399,7 +336,6 @@ struct SymAgc {
     bool locked;                         // this wavefront's belief of the AGC lock
     uint32_t ysh[3][B / 2];              // DC-blocker outputs of the last three blocks, packed f16: [0] newest
     float g0[3];                         // the AGC gain each of them started with
-    uint32_t wp[3];                      // their ring positions
     uint32_t wnext;                      // ring position of the block produced next
     uint32_t last_blk;                   // the block in history slot 0
 
@@ -418,50 +354,11 @@ struct SymAgc {
         locked = (S.flags[c] & F_AGC_LOCKED) != 0u;
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
-            g0[j] = gain; wp[j] = 0;
+            g0[j] = gain;
 #pragma unroll
             for (int k = 0; k < B / 2; ++k) ysh[j][k] = 0u;
         }
         wnext = 0; last_blk = 0;
-    }
-
-    // AGC (rx/agc.rs:72-77, relaxed) and window push (receiver.rs:345-346) of one block from its packed DC-blocker
-    // outputs: bandwidth bwa up to sample fk, bwb after it
-    template <int J>
-    __device__ __forceinline__ float redo(const Params &P, float *wcol, float g, int fk, float bwa, float bwb)
-    {
-        float *wblk = wcol + wp[J] * LP;
-        const bool mirror = wp[J] == 0u;
-        float head[MIR + 1];
-        // (every lane in here locks from the block's first sample on: the gain stands still)
-        const bool frozen = __builtin_amdgcn_ballot_w64(!(bwb == 0.0f && fk < 0)) == 0ull;
-        if (frozen) {
-#pragma unroll
-            for (int k = 0; k < B; k += 2) {
-                float y0, y1;
-                sym_unpack(ysh[J][k / 2], &y0, &y1);
-                const float o0 = y0 * g, o1 = y1 * g;
-                wblk[k * LP] = o0; wblk[(k + 1) * LP] = o1;
-                if (k < MIR) head[k] = o0;
-                if (k + 1 < MIR) head[k + 1] = o1;
-            }
-        } else {
-#pragma unroll
-            for (int k = 0; k < B; k += 2) {
-                float y0, y1;
-                sym_unpack(ysh[J][k / 2], &y0, &y1);
-                const float o0 = agc_step_relaxed(P, y0, g, (k <= fk) ? bwa : bwb);
-                const float o1 = agc_step_relaxed(P, y1, g, (k + 1 <= fk) ? bwa : bwb);
-                wblk[k * LP] = o0; wblk[(k + 1) * LP] = o1;
-                if (k < MIR) head[k] = o0;
-                if (k + 1 < MIR) head[k + 1] = o1;
-            }
-        }
-        if (mirror) {
-#pragma unroll
-            for (int k = 0; k < MIR; ++k) wblk[(k + RING) * LP] = head[k];
-        }
-        return g;
     }
 
     // AGC and window push of block `blk`, whose DC-blocker outputs are y[k * LP]
@@ -473,8 +370,8 @@ struct SymAgc {
         // history moves on by one block
 #pragma unroll
         for (int k = 0; k < B / 2; ++k) { ysh[2][k] = ysh[1][k]; ysh[1][k] = ysh[0][k]; }
-        g0[2] = g0[1]; g0[1] = g0[0]; wp[2] = wp[1]; wp[1] = wp[0];
-        g0[0] = gain; wp[0] = wnext; last_blk = blk;
+        g0[2] = g0[1]; g0[1] = g0[0];
+        g0[0] = gain; last_blk = blk;
         float *wblk = wcol + wnext * LP;
         const bool mirror = wnext == 0u;                               // wave-uniform
         const float bw = locked ? 0.0f : P.agc_bw;
@@ -496,31 +393,32 @@ struct SymAgc {
         if (wnext == (uint32_t)RING) wnext = 0;
     }
 
-    // the lock flipped at sample `fk` of block `b` (this lane; b <= last_blk): redo the AGC from there on.  A flip further
-    // back than the history reaches (a lane that lagged a whole block behind: after a symsync.reset, and only if the very
-    // next symbol locks again) takes effect from the start of the oldest block kept.
-    __device__ __forceinline__ void replay(const Params &P, float *wcol, uint32_t b, int fk, bool new_locked)
+    // the AGC gain after sample `fk` of block `b` (b <= last_blk, this lane's belief of the lock unchanged since then): the
+    // recurrence once more from the block's start, over its packed DC outputs, nothing written.  Further back than the history
+    // reaches: the oldest block's start.
+    template <int J>
+    __device__ __forceinline__ float gain_in(const Params &P, int fk) const
     {
-        const float bw0 = locked ? 0.0f : P.agc_bw;
-        locked = new_locked;
-        const float bw1 = locked ? 0.0f : P.agc_bw;
-        uint32_t j = last_blk - b;
-        if (j > 2u) { j = 2u; fk = -1; }
-        float g = 0.0f;
-        if (j >= 2u) { g = redo<2>(P, wcol, g0[2], fk, bw0, bw1); }
-        if (j >= 1u) {
-            const bool first = j == 1u;
-            const float gs = first ? g0[1] : g;
-            g0[1] = gs;
-            g = redo<1>(P, wcol, gs, first ? fk : -1, bw0, bw1);
+        float g = g0[J];
+        const float bw = P.agc_bw;
+#pragma unroll
+        for (int k = 0; k < B; k += 2) {
+            float y0, y1;
+            sym_unpack(ysh[J][k / 2], &y0, &y1);
+            const float a0 = __builtin_fmaf(-bw, fabsf(y0), 1.0f), a1 = __builtin_fmaf(-bw, fabsf(y1), 1.0f);
+            const float g1 = __builtin_amdgcn_fmed3f(__builtin_fmaf(g, a0, bw), P.agc_min, P.agc_max);
+            g = (k <= fk) ? g1 : g;
+            const float g2 = __builtin_amdgcn_fmed3f(__builtin_fmaf(g, a1, bw), P.agc_min, P.agc_max);
+            g = (k + 1 <= fk) ? g2 : g;
         }
-        {
-            const bool first = j == 0u;
-            const float gs = first ? g0[0] : g;
-            g0[0] = gs;
-            g = redo<0>(P, wcol, gs, first ? fk : -1, bw0, bw1);
-        }
-        gain = g;
+        return g;
+    }
+    __device__ __forceinline__ float gain_at(const Params &P, uint32_t b, int fk) const
+    {
+        const uint32_t j = last_blk - b;
+        if (j == 0u) return gain_in<0>(P, fk);
+        if (j == 1u) return gain_in<1>(P, fk);
+        return gain_in<2>(P, j == 2u ? fk : -1);
     }
 
     __device__ __forceinline__ void store(const Params &P, const State &S, uint32_t c, uint32_t C, uint64_t counter1, const float *wcol)
@@ -668,21 +566,18 @@ __global__ __launch_bounds__(4 * kWave, 2) void demod_sym_kernel(Params P, State
                 const uint32_t fbw = (uint32_t)__builtin_amdgcn_readfirstlane((int)fb[kWave]);
                 if (fbw & 2u) stop_at = s + 1u;
                 if (fbw & 4u) {
-                    // end(): the AGC is unlocked from the next block on (no replay)
+                    // a lock or an unlock: from the next block on
                     const uint32_t v = fb[lane];
-                    if ((v & 17u) == 17u) M.locked = (v & 2u) != 0u;
-                }
-                if (fbw & 1u) {
-                    const uint32_t v = fb[lane];
-                    const bool new_locked = (v & 2u) != 0u;
-                    if ((v & 17u) == 1u && new_locked != M.locked) {
-                        const int64_t idx = sym_index(s - 1u, v >> 8);
-                        const uint32_t b = (uint32_t)(idx / kB);
-                        M.replay(P, wcol, b, (int)(idx - (int64_t)b * kB), new_locked);
+                    if (v & 1u) {
+                        const bool new_locked = (v & 2u) != 0u;
+                        if (new_locked && !M.locked) {
+                            // the gain freezes at the value it had after the symbol's sample
+                            const int64_t idx = sym_index(s - 1u, v >> 8);
+                            const uint32_t b = (uint32_t)(idx / kB);
+                            M.gain = M.gain_at(P, b, (int)(idx - (int64_t)b * kB));
+                        }
+                        M.locked = new_locked;
                     }
-                    lds_barrier();                                     // B: the window is corrected, E has posted the positions again
-                    if (s >= 1u && s <= last_t_step) filter_a(s, 2u * s + 2u);
-                    lds_barrier();                                     // C: E has redone the step's symbol
                     P3_LAP(p3_fb);
                 }
             }
@@ -738,7 +633,6 @@ __global__ __launch_bounds__(4 * kWave, 2) void demod_sym_kernel(Params P, State
                 const lds_u32 *fb = fbbox + (s & 1u) * LY::fb_words;
                 const uint32_t fbw = (uint32_t)__builtin_amdgcn_readfirstlane((int)fb[kWave]);
                 if (fbw & 2u) stop_at = s + 1u;
-                if (fbw & 1u) { lds_barrier(); lds_barrier(); P3_LAP(p3_fb); }       // B, C: the others replay (the DC blocker never does)
             }
             return s == stop_at;
         };
@@ -790,7 +684,6 @@ __global__ __launch_bounds__(4 * kWave, 2) void demod_sym_kernel(Params P, State
         uint32_t stop_at = 0xffffffffu;
         bool left = false, lane_done = false, leave_posted = false;
         for (uint32_t s = 0; s < n_steps; ++s) {
-            bool any = false;
             if (s >= 2u && s <= last_fb_step) {
                 const uint32_t blk = min(s - 2u, n_blocks - 1u);       // every symbol up to the end of this block has been seen after this step
                 const lds_u32 *sb = symbox + ((s - 1u) & 1u) * LY::sym_words + lane;
@@ -816,14 +709,11 @@ __global__ __launch_bounds__(4 * kWave, 2) void demod_sym_kernel(Params P, State
                     io2 = burst_len;
                     const uint32_t after = L.flags & (F_AGC_LOCKED | F_BW_LOCKED);
                     if (after != before || L.ended) {
-                        // Only the lock at sync (agc.lock(true), locked loop bandwidth: receiver.rs:431-432) is taken back to the
-                        // sample it happened at -- the gain it freezes is the one every soft symbol of the burst is scaled by.
-                        // What end() undoes (receiver.rs:479-490) is applied late and without a replay (bit 4): the AGC is unlocked
-                        // from the next block on, the timing loop reset two symbols later.  The carrier is gone by then; link
-                        // events after it move by less than a symbol.
-                        const bool lock_on = (after & F_AGC_LOCKED) != 0u && (before & F_AGC_LOCKED) == 0u;
-                        fbv = 1u | ((after & F_AGC_LOCKED) ? 2u : 0u) | ((after & F_BW_LOCKED) ? 4u : 0u) | (L.ended ? 8u : 0u) |
-                              (lock_on ? 0u : 16u) | (off << 8);
+                        // The lock at sync (agc.lock(true), locked loop bandwidth: receiver.rs:431-432) and what end() undoes
+                        // (receiver.rs:479-490) reach S and E late: the AGC freezes -- at the gain of this symbol's sample -- or
+                        // is released from S's next block on, the timing loop follows two symbols later.  Link events after
+                        // an end() move by less than a symbol (the carrier is gone by then).
+                        fbv = 1u | ((after & F_AGC_LOCKED) ? 2u : 0u) | ((after & F_BW_LOCKED) ? 4u : 0u) | (L.ended ? 8u : 0u) | (off << 8);
                     }
                 }
                 // finished bursts go into the pool with the whole wavefront: one slot reservation for all of them and one
@@ -861,8 +751,7 @@ __global__ __launch_bounds__(4 * kWave, 2) void demod_sym_kernel(Params P, State
                 if (__builtin_amdgcn_ballot_w64((io0 & 8u) != 0u && ((io0 >> 1) & 3u) == 3u) != 0ull) { io[kWave] = io1; io[2 * kWave] = io2; }
                 lds_u32 *fb = fbbox + (s & 1u) * LY::fb_words;
                 fb[lane] = fbv;
-                any = __builtin_amdgcn_ballot_w64(fbv != 0u && (fbv & 16u) == 0u) != 0ull;
-                const bool any_late = __builtin_amdgcn_ballot_w64((fbv & 16u) != 0u) != 0ull;
+                const bool any_late = __builtin_amdgcn_ballot_w64(fbv != 0u) != 0ull;
                 // Time-parallel chunk that hands over: from its nominal end on, a lane's hand-over instant is
                 // the end of the first block after which its link state is NoCarrier; once every lane has one the workgroup
                 // leaves (one more step: E still has to log this step's events)
@@ -874,12 +763,11 @@ __global__ __launch_bounds__(4 * kWave, 2) void demod_sym_kernel(Params P, State
                     }
                     if (__builtin_amdgcn_ballot_w64(!lane_done) == 0ull) { leave = 2u; leave_posted = true; stop_at = s + 1u; }
                 }
-                if (lane == 0u) fb[kWave] = (any ? 1u : 0u) | leave | (any_late ? 4u : 0u);
+                if (lane == 0u) fb[kWave] = leave | (any_late ? 4u : 0u);
             }
             P3_LAP(p3_work);
             lds_barrier();                                             // A
             P3_LAP(p3_wait);
-            if (any) { lds_barrier(); lds_barrier(); P3_LAP(p3_fb); }   // B, C: the earlier wavefronts catch up
             if (s == stop_at) { left = true; break; }
         }
         SYM_REPORT(2);
@@ -919,7 +807,7 @@ __global__ __launch_bounds__(4 * kWave, 2) void demod_sym_kernel(Params P, State
         const float inv_spt = 1.0f / P.samples_per_ted;
         int cstar = next_fire_count(L.until_next_ted, L.ted_clock);
         int rel = cstar - (int)L.ted_clock - 1;        // index of the next instant, relative to the end of the finished samples
-        // The plan of step s, made at the end of step s - 1 (or again after a feedback): per lane the next symbol -- instant A
+        // The plan of step s, made at the end of step s - 1: per lane the next symbol -- instant A
         // (completes nothing: where B falls does not depend on A's sample) and instant B, or B alone right after a
         // symsync.reset -- if both lie in finished samples; in the steps after the last block: one instant whatever it is.
         // S filters at A (where there is one), this wavefront at B.
@@ -978,7 +866,8 @@ __global__ __launch_bounds__(4 * kWave, 2) void demod_sym_kernel(Params P, State
             sb[kWave] = __float_as_uint(zero); sb[2 * kWave] = __float_as_uint(sym);
             if (P.trace_cap) { sb[3 * kWave] = __float_as_uint(terr); sb[4 * kWave] = __float_as_uint(next); }
         };
-        // what end() undoes in the timing loop (receiver.rs:479-490: unlocked loop bandwidth, symsync.reset()), late: see Y
+        // the loop bandwidth of a lock at sync (receiver.rs:431-432) and what end() undoes (receiver.rs:479-490: unlocked
+        // loop bandwidth, symsync.reset()), late: see Y
         uint32_t late_now = 0u;
         auto late = [&](uint32_t v) __attribute__((always_inline)) {
             if (v & 1u) {
@@ -996,10 +885,6 @@ __global__ __launch_bounds__(4 * kWave, 2) void demod_sym_kernel(Params P, State
         uint32_t stop_at = 0xffffffffu;
         bool left = false;
         for (uint32_t s = 0; s < n_steps; ++s) {
-            // this lane's state before the step's symbol, in case Y sends it back there
-            const float k_h0 = L.h0, k_h1 = L.h1, k_h2 = L.h2, k_avg = L.period_avg, k_inst = L.period_inst, k_unt = L.until_next_ted;
-            const uint32_t k_flags = L.flags;
-            const int k_cstar = cstar, k_rel = rel;
             if (!PROF_SKIP(P, 32)) {
                 work(s, 2u * s + 1u);
                 late(late_now);
@@ -1015,28 +900,10 @@ __global__ __launch_bounds__(4 * kWave, 2) void demod_sym_kernel(Params P, State
                 const uint32_t fbw = (uint32_t)__builtin_amdgcn_readfirstlane((int)fb[kWave]);
                 if (fbw & 2u) stop_at = s + 1u;
                 if (fbw & 4u) {
-                    // what end() undoes: applied behind the next step's symbol (the positions of that step are already with S)
+                    // a change of the loop bandwidth or a symsync.reset(): applied behind the next step's symbol (the
+                    // positions of that step are already with S)
                     const uint32_t v = fb[lane];
-                    if ((v & 17u) == 17u) late_next = v;
-                }
-                if (fbw & 1u) {
-                    SYM_TCOUNT(14, 1);
-                    const uint32_t v = fb[lane];
-                    // every lane goes back (a lane without a change redoes its step over an unchanged window: same results)
-                    L.h0 = k_h0; L.h1 = k_h1; L.h2 = k_h2; L.period_avg = k_avg; L.period_inst = k_inst;
-                    L.until_next_ted = k_unt; L.flags = k_flags; cstar = k_cstar; rel = k_rel;
-                    if ((v & 17u) == 1u) {                               // locked at this symbol: the locked loop bandwidth from here on
-                        L.flags = (L.flags & ~F_BW_LOCKED) | ((v & 4u) ? F_BW_LOCKED : 0u);
-                        late_now = 0u; late_next = 0u;                   // (a lock supersedes an end() still on its way)
-                    }
-                    plan(s);                                           // S filters again, at these positions
-                    lds_barrier();                                     // B: S has corrected the window
-                    work(s, 2u * s + 2u);
-                    late(late_now);
-                    if (s + 1u <= n_blocks) rel -= kB;
-                    plan(s + 1u);
-                    lds_barrier();                                     // C
-                    P3_LAP(p3_fb);
+                    if (v & 1u) late_next = v;
                 }
             }
             late_now = late_next;
