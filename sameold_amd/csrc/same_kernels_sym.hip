@@ -74,7 +74,8 @@ template <int NT> struct SymLayout {
     static constexpr uint32_t io_words = 3u * kWave;              // per parity: symbol word, burst-pool slot, burst length
     static constexpr uint32_t pos_words = 2u * kWave;             // per parity: ring slots of the symbol's two instants (-1: none)
     static constexpr uint32_t mail_words = 2u * sym_words + 2u * fb_words + 2u * io_words + 2u * kWave +   // + final TED phase, wake-up flag
-                                           2u * pos_words + kWave;                                        // + the first instant's soft sample, from S
+                                           2u * pos_words + kWave +                                       // + the first instant's soft sample, from S
+                                           (2u * (uint32_t)kTickRing + 1u) * kWave;                       // + T's deadline ring and its count
     static constexpr uint32_t yring_floats = 2u * (uint32_t)B * kWave;
     static constexpr size_t lds_bytes = ((size_t)tap_floats + mail_words + yring_floats + (size_t)(RING + MIR) * kWave) * sizeof(float);
     static_assert(NT == 42 && NT % kRelaxChunk == 0, "three filter chunks of 14 taps");
@@ -326,6 +327,41 @@ struct SymDc {
     }
 };
 
+// T's context for the link events and the transport wake-ups: IoCtx with the deadline ring (kTickRing instants and their
+// count per channel) in LDS for the launch.  In the HBM state arrays every burst and every expired deadline cost T a chain
+// of dependent global round trips -- count, oldest deadline, the ring moved down -- in the wavefront that also issues the
+// input prefetch, behind which they queue (one in eight steps of a 64-channel workgroup has such a lane: 8 % of a
+// launch with the transport layer on).
+struct SymIoCtx : IoCtx {
+    lds_u32 *tk;               // this lane's column: deadline i in words [2 i][lane], [2 i + 1][lane]; the count behind them
+    __device__ __forceinline__ uint32_t tk_count(const State &, uint32_t) const { return tk[2 * kTickRing * kWave]; }
+    __device__ __forceinline__ void tk_set_count(const State &, uint32_t, uint32_t n) const { tk[2 * kTickRing * kWave] = n; }
+    __device__ __forceinline__ uint64_t tk_at(const State &, uint32_t, uint32_t, uint32_t i) const
+    {
+        return (uint64_t)tk[2u * i * kWave] | ((uint64_t)tk[(2u * i + 1u) * kWave] << 32);
+    }
+    __device__ __forceinline__ void tk_set(const State &, uint32_t, uint32_t, uint32_t i, uint64_t v) const
+    {
+        tk[2u * i * kWave] = (uint32_t)v; tk[(2u * i + 1u) * kWave] = (uint32_t)(v >> 32);
+    }
+    __device__ __forceinline__ void ring_load(const Params &P, const State &S, uint32_t c)
+    {
+        if (!P.ticks) return;
+        const TickRingGlobal G;
+#pragma unroll
+        for (uint32_t i = 0; i < (uint32_t)kTickRing; ++i) tk_set(S, P.n_channels, c, i, G.tk_at(S, P.n_channels, c, i));
+        tk_set_count(S, c, G.tk_count(S, c));
+    }
+    __device__ __forceinline__ void ring_store(const Params &P, const State &S, uint32_t c) const
+    {
+        if (!P.ticks) return;
+        const TickRingGlobal G;
+#pragma unroll
+        for (uint32_t i = 0; i < (uint32_t)kTickRing; ++i) G.tk_set(S, P.n_channels, c, i, tk_at(S, P.n_channels, c, i));
+        G.tk_set_count(S, c, tk_count(S, c));
+    }
+};
+
 // ---------------------------------------------------------------------------------------------------------------------
 // S: AGC and window push, with the packed DC-blocker outputs of its last three blocks (the gain a lock freezes)
 // ---------------------------------------------------------------------------------------------------------------------
@@ -514,6 +550,7 @@ __global__ __launch_bounds__(4 * kWave, 2) void demod_sym_kernel(Params P, State
     lds_u32 *againbox = phasebox + kWave;                      // [64] E's final F_TICK_AGAIN bit
     lds_u32 *posbox = againbox + kWave;                        // [2][2][64] ring slots of the two instants of step s's symbol (parity s & 1)
     lds_u32 *sabox = posbox + 2u * LY::pos_words;              // [64] the first instant's soft sample
+    lds_u32 *tkbox = sabox + kWave;                            // [kTickRing][64] u64 deadlines, then [64] their count (T's own)
     lds_u32 *chunkbox = fbbox + kWave + 2u;                    // [2], in the first feedback box's padding
     lds_u32 *seqbox = fbbox + kWave + 4u;                      // S's progress with the first instants' filters: 2 * step + pass
     float *yring = lds + LY::tap_floats + LY::mail_words;      // [2][kB][64]: block b in half b & 1
@@ -595,10 +632,12 @@ __global__ __launch_bounds__(4 * kWave, 2) void demod_sym_kernel(Params P, State
         D.load(S, x, c, C, cin, Cin, counter0, n_blocks);
         Lane L;
         lane_load(L, S, c);      // the event half uses sq_symbols, tk_next, tk_last, wake_*, F_TICK_AGAIN
-        IoCtx X;
+        SymIoCtx X;
         X.chunk = chunkbox;
         chunkbox[0] = 0u; chunkbox[1] = kEvChunk;       // nothing reserved yet
         X.pending_slot = 0xffffffffu;
+        X.tk = tkbox + lane;
+        X.ring_load(P, S, c);
         // prologue: block 0's DC outputs
         if (n_blocks > 1u) D.request(D.xb, x, 1u, n_blocks, cin, Cin);
         D.block(P, yring + lane, D.xa, 0u);
@@ -648,6 +687,7 @@ __global__ __launch_bounds__(4 * kWave, 2) void demod_sym_kernel(Params P, State
         lds_barrier();                                                 // Y merges the flag bits
         D.store(S, c, C, counter1);
         S.tk_next[c] = L.tk_next; S.tk_last[c] = L.tk_last; S.wake_fired[c] = L.wake_fired;
+        X.ring_store(P, S, c);
     } else if (role == 2u) {
         // ------------------------------------------ Y: symbol path --------------------------------------------------
         P3_HWID(2);

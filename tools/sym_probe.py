@@ -77,11 +77,12 @@ def timeit(n_ch, secs, reps=3, relaxed=True, tp=False, cm=False, chunks=0):
     for r in range(reps):
         if r: rx.reset()
         rx.process_tensor(x, layout=sa.LAYOUT_CHANNEL_MAJOR if cm else sa.LAYOUT_TIME_MAJOR); rx.sync()
-        ms = rx.last_kernel_ms(); best = min(best, ms)
+        ms = rx.last_kernel_ms()
         try:
-            dm = rx.last_demod_kernel_ms()
+            d = rx.last_demod_kernel_ms()
         except Exception:
-            dm = ms
+            d = ms
+        if ms < best: best, dm = ms, d
         ev = rx.poll_events_np()
     print(f"SAME_SYM={os.environ.get('SAME_SYM','-')} {n_ch} ch x {n} tp={tp} cm={cm} chunks={rx.time_parallel_chunks()} [{rx.kernel_name()}]: best {best:.3f} ms "
           f"(demod alone {dm:.3f}) = {4*n_ch*n/best/1e9/8*100:.2f} % of 8 TB/s; bursts {int((ev['kind']==3).sum())}", flush=True)
@@ -141,3 +142,8 @@ if what in ("tp", "all"):
         rx = timeit(4096, 10.0, tp=True, cm=True, reps=4)
         if sym == "1": prof(rx)
         timeit(4096, 10.0, tp=True, cm=False, reps=3)
+if what == "sweep":
+    os.environ["SAME_SYM"] = "1"
+    for cm in (True, False):
+        for k in (0, 6, 7, 8, 9, 10, 11, 12, 14, 16):
+            timeit(4096, 10.0, tp=True, cm=cm, reps=4, chunks=k)
