@@ -222,6 +222,7 @@ def run_steps(sa, rx, x, T, stream, steps, warmup, gather, barrier, layout=0, wa
     elapsed = time.perf_counter() - t0
     if os.environ.get("SAME_BENCH_DEBUG"):
         sys.stderr.write("per-pass wall ms (last = drain): " + " ".join(f"{1e3 * (b - a):.2f}" for a, b in zip([t0] + marks[:-1], marks)) + "\n")
+        sys.stderr.write("kernel ms per launch: " + " ".join(f"{k:.3f}" for k in kernel_ms) + " | demod alone: " + " ".join(f"{k:.3f}" for k in demod_ms) + "\n")
     first_ev = np.concatenate(first) if first else np.zeros(0, dtype=sa.receiver.EVENT_DTYPE)
     first_ev = first_ev[first_ev["sample_counter"] <= T]     # the very first pass only
     k_mean = sum(kernel_ms) / max(len(kernel_ms), 1)
@@ -512,7 +513,7 @@ def main():
         "time_parallel": "channel-major input x[channel][t]; time chunks per channel = state columns side by side, chunk boundaries per channel at idle "
                          "instants (device-side energy scout + planner + sort: inside kernel_ms, which is what `achieved` is priced on, as far as they "
                          "are not hidden under the previous launch's tail on the plan stream; demod_kernel_alone_ms is the demodulation kernel by "
-                         "itself, what rocprofv3 lists), 10 pieces per channel, relaxed arithmetic inside the chunks (the symbol-paced pipeline, same_kernels_sym.hip; "
+                         "itself, what rocprofv3 lists), 12 pieces per channel (10 with SAME_RELAXED=0), relaxed arithmetic inside the chunks (the symbol-paced pipeline, same_kernels_sym.hip; "
                          "DESIGN.md 4.6, 4.7)",
         "time_parallel_time_major": "time-major input; uniform chunk boundaries (one row offset per workgroup keeps the loads coalesced), chunks run on "
                                     "until idle, relaxed arithmetic inside the chunks; kernel_ms includes the state column copies",

@@ -204,7 +204,7 @@ struct same_batch {
     struct Slot {
         same::DevEvent *d_events = nullptr; uint32_t event_cap = 0;
         // the log's indices ordered by state column, made on the device behind the launch (launch_event_sort)
-        uint32_t *d_sort = nullptr; size_t sort_words = 0;          // cnt [bins] | first [bins + 1]
+        uint32_t *d_sort = nullptr; size_t sort_words = 0;          // cnt [bins] | first [bins + 1] | the scan's workgroup totals
         uint32_t *h_sort = nullptr; size_t h_sort_words = 0;        // pinned: first [bins + 1]
         same::DevEvent *d_sorted = nullptr; uint32_t sorted_cap = 0; // the log's records in column order
         uint32_t sort_bins = 0;
@@ -421,7 +421,7 @@ int ensure_output(same_batch *rx, same_batch::Slot &sl, size_t n_samples, same::
         sl.burst_cap = (uint32_t)bcap;
     }
     {
-        const size_t need = 2 * n_ch + 1, need_h = n_ch + 1;
+        const size_t need = 2 * n_ch + 1 + same::event_sort_extra_words((uint32_t)n_ch), need_h = n_ch + 1;
         if (sl.event_cap > sl.sorted_cap) {
             if (sl.d_sorted) HIP_TRY(hipFree(sl.d_sorted));
             sl.d_sorted = nullptr; sl.sorted_cap = 0;
@@ -983,7 +983,7 @@ int process_time_major(same_batch *rx, const SampleT *d_x, size_t n_samples, hip
             HIP_TRY(same::launch_counters(sl.d_counters, sl.h_counters_dev, 0, stream));
             if (rx->timing) HIP_TRY(hipEventRecord(sl.ev_start, stream));
             // fresh receivers in every column, the channels' own state into chunk 0's columns
-            HIP_TRY(same::launch_init_state(tp.Pv, tp.Sv, 0, stream));
+            HIP_TRY(same::launch_init_state(tp.Pv, tp.Sv, 0, stream, C));
             HIP_TRY(same::launch_copy_state_columns(tp.d_desc_in, tp.n_desc, C, columns, nullptr, C, stream));
             HIP_TRY(same::launch_fill_u64(sl.d_handover, columns, same::kNoHandover, stream));
             const SampleT *xp = d_x + done * C;
@@ -1105,8 +1105,13 @@ int process_channel_major_native(same_batch *rx, const float *d_x, size_t n, hip
     // 39.9 k samples, with 10 or more 37.5 k), and beyond 10 the extra workgroups only add rounds.  Measured at 4 096
     // channels x 10 s, pieces sorted by length into workgroups: 8 pieces 3.84 ms (unsorted 3.83), 9 3.47, 10 3.45, 11 3.70,
     // 12 3.85, 16 4.2.
-    const uint32_t want_cols = tp.max_chunks ? tp.max_chunks * rx->P.n_channels : 40960u;
-    const uint32_t n_chunks = plan_chunks(rx, n, geom, pc, tp.max_chunks ? (want_cols > 32768u ? 65536u : 32768u) : 40960u);
+    // With the symbol-paced pipeline (round 4; a piece's pace alone on a CU is 1.25 x its pace beside another): 8 pieces
+    // 2.16 ms, 9 2.33, 10 2.14, 11 2.13, 12 2.03, 14 2.13, 16 2.21 -- half as many columns again as the machine holds,
+    // so that the last, long pieces run with a CU to themselves.
+    const bool sym_cols = rx->relaxed && same::sym_kernel_supported(rx->P);
+    const uint32_t dflt_cols = sym_cols ? 49152u : 40960u;
+    const uint32_t want_cols = tp.max_chunks ? tp.max_chunks * rx->P.n_channels : dflt_cols;
+    const uint32_t n_chunks = plan_chunks(rx, n, geom, pc, tp.max_chunks ? (want_cols > 32768u ? 65536u : 32768u) : dflt_cols);
     if (n_chunks < 2u) return 0;
     const uint32_t C = rx->P.n_channels, columns = n_chunks * C, fb = geom.block_len;
     const bool wave = tp.kernel == same_batch::TimePar::kWaveRelaxed;
@@ -1189,7 +1194,7 @@ int process_channel_major_native(same_batch *rx, const float *d_x, size_t n, hip
         HIP_TRY(hipStreamWaitEvent(stream, sl.ev_planned, 0));
     }
     if (lpt) { d_perm = d_perm2; d_wg = d_wg2; }
-    HIP_TRY(same::launch_init_state(tp.Pv, tp.Sv, 0, stream));
+    HIP_TRY(same::launch_init_state(tp.Pv, tp.Sv, 0, stream, C));
     HIP_TRY(same::launch_copy_state_columns(tp.d_desc_in, tp.n_desc, C, columns, nullptr, C, stream));
     HIP_TRY(same::launch_fill_u64(sl.d_handover, columns, same::kNoHandover, stream));
     pc.handover = sl.d_handover;

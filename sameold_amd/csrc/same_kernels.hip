@@ -179,9 +179,9 @@ __global__ __launch_bounds__(256) void transpose_to_time_major(const T *__restri
 // ---------------------------------------------------------------------------------
 // state initialisation: SameReceiver::from(&builder) receiver.rs:539-558 and reset() :182-198
 // ---------------------------------------------------------------------------------
-__global__ void init_state_kernel(Params P, State S, int is_reset)
+__global__ void init_state_kernel(Params P, State S, int is_reset, uint32_t first_col)
 {
-    const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t c = first_col + blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t C = P.n_channels;
     if (c >= C) return;
     for (uint32_t i = 0; i < P.dc_len; ++i) { S.dc_ff_ring[i * C + c] = 0.0f; S.dc_fb_ring[i * C + c] = 0.0f; }
@@ -240,22 +240,35 @@ __global__ void ev_hist_kernel(const DevEvent *__restrict__ ev, const uint32_t *
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
         if (ev[i].kind != kDevEventNone) atomicAdd(&cnt[min(ev[i].channel, n_bins - 1u)], 1u);
 }
-__global__ __launch_bounds__(1024) void ev_scan_kernel(uint32_t n_bins, uint32_t *__restrict__ cnt, uint32_t *__restrict__ first)
+// The exclusive scan, two launches of one workgroup per 1 024 columns: the scan inside each workgroup (coalesced: a thread per
+// column) with the workgroups' totals set aside, then every workgroup adds the totals before it.  (One workgroup walking
+// contiguous stretches per thread -- 48 dependent, uncoalesced loads and as many stores each at 49 152 columns -- took
+// 111 us between two demodulation launches.)
+constexpr uint32_t kScanThreads = 1024;
+__global__ __launch_bounds__(kScanThreads) void ev_scan_local_kernel(uint32_t n_bins, const uint32_t *__restrict__ cnt, uint32_t *__restrict__ first,
+                                                                      uint32_t *__restrict__ tot)
 {
-    // one workgroup: a thread owns a contiguous stretch of columns; cnt becomes the scatter's running offsets
-    __shared__ uint32_t wave_sum[1024 / kWave];
-    const uint32_t tid = threadIdx.x, lane = tid & (kWave - 1u), wave = tid / kWave;
-    const uint32_t per = (n_bins + 1023u) / 1024u, c0 = min(tid * per, n_bins), c1 = min(c0 + per, n_bins);
-    uint32_t mine = 0;
-    for (uint32_t c = c0; c < c1; ++c) mine += cnt[c];
+    __shared__ uint32_t wave_sum[kScanThreads / kWave];
+    const uint32_t tid = threadIdx.x, lane = tid & (kWave - 1u), wave = tid / kWave, c = blockIdx.x * kScanThreads + tid;
+    const uint32_t mine = c < n_bins ? cnt[c] : 0u;
     uint32_t incl = mine;
     for (int off = 1; off < (int)kWave; off <<= 1) { const uint32_t t = (uint32_t)__shfl_up((int)incl, off); if ((int)lane >= off) incl += t; }
     if (lane == kWave - 1u) wave_sum[wave] = incl;
     __syncthreads();
     uint32_t run = incl - mine;
     for (uint32_t w = 0; w < wave; ++w) run += wave_sum[w];
-    for (uint32_t c = c0; c < c1; ++c) { const uint32_t k = cnt[c]; first[c] = run; cnt[c] = run; run += k; }
-    if (tid == 1023u) first[n_bins] = run;          // (the last thread's stretch ends with the last column, or is empty behind it)
+    if (c < n_bins) first[c] = run;
+    if (tid == kScanThreads - 1u) tot[blockIdx.x] = run + mine;
+}
+__global__ __launch_bounds__(kScanThreads) void ev_scan_base_kernel(uint32_t n_bins, uint32_t *__restrict__ cnt, uint32_t *__restrict__ first,
+                                                                     const uint32_t *__restrict__ tot)
+{
+    // cnt becomes the scatter's running offsets
+    uint32_t base = 0;
+    for (uint32_t j = 0; j < blockIdx.x; ++j) base += tot[j];          // (wave-uniform: scalar loads)
+    const uint32_t c = blockIdx.x * kScanThreads + threadIdx.x;
+    if (c < n_bins) { const uint32_t v = first[c] + base; first[c] = v; cnt[c] = v; }
+    if (blockIdx.x + 1u == gridDim.x && threadIdx.x == 0u) first[n_bins] = base + tot[blockIdx.x];
 }
 __global__ void ev_scatter_kernel(const DevEvent *__restrict__ ev, const uint32_t *__restrict__ counters, uint32_t cap, uint32_t n_bins,
                                   uint32_t *__restrict__ fill, DevEvent *__restrict__ sorted)
@@ -272,13 +285,17 @@ __global__ void ev_scatter_kernel(const DevEvent *__restrict__ ev, const uint32_
         sorted[pos] = e;
     }
 }
+uint32_t event_sort_extra_words(uint32_t n_bins) { return (n_bins + kScanThreads - 1u) / kScanThreads; }
 hipError_t launch_event_sort(const DevEvent *ev, const uint32_t *counters, uint32_t cap, uint32_t n_bins, uint32_t *cnt, uint32_t *first,
                              DevEvent *sorted, hipStream_t stream)
 {
     hipError_t e = hipMemsetAsync(cnt, 0, (size_t)n_bins * sizeof(uint32_t), stream);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(ev_hist_kernel, dim3(256), dim3(256), 0, stream, ev, counters, cap, n_bins, cnt);
-    hipLaunchKernelGGL(ev_scan_kernel, dim3(1), dim3(1024), 0, stream, n_bins, cnt, first);
+    const uint32_t scan_grid = (n_bins + kScanThreads - 1u) / kScanThreads;
+    uint32_t *tot = first + n_bins + 1u;                   // (first: n_bins + 1 + event_sort_extra_words(n_bins) words)
+    hipLaunchKernelGGL(ev_scan_local_kernel, dim3(scan_grid), dim3(kScanThreads), 0, stream, n_bins, cnt, first, tot);
+    hipLaunchKernelGGL(ev_scan_base_kernel, dim3(scan_grid), dim3(kScanThreads), 0, stream, n_bins, cnt, first, tot);
     hipLaunchKernelGGL(ev_scatter_kernel, dim3(256), dim3(256), 0, stream, ev, counters, cap, n_bins, cnt, sorted);
     return hipGetLastError();
 }
@@ -318,10 +335,11 @@ hipError_t launch_demod_i16(const Params &P, const State &S, const Output &O, co
 size_t demod_lds_bytes(const Params &P)
 { return (size_t)(2 * P.dc_len + P.win_ring) * kWave * sizeof(float); }
 
-hipError_t launch_init_state(const Params &P, const State &S, int is_reset, hipStream_t stream)
+hipError_t launch_init_state(const Params &P, const State &S, int is_reset, hipStream_t stream, uint32_t first_col)
 {
-    const uint32_t grid = (P.n_channels + 255) / 256;
-    hipLaunchKernelGGL(init_state_kernel, dim3(grid), dim3(256), 0, stream, P, S, is_reset);
+    if (first_col >= P.n_channels) return hipSuccess;
+    const uint32_t grid = (P.n_channels - first_col + 255) / 256;
+    hipLaunchKernelGGL(init_state_kernel, dim3(grid), dim3(256), 0, stream, P, S, is_reset, first_col);
     return hipGetLastError();
 }
 
@@ -338,17 +356,19 @@ __global__ void copy_state_columns_kernel(const StateArrayDesc *desc, uint32_t C
     const uint32_t w = d.elem_words;
     const uint32_t *src = reinterpret_cast<const uint32_t *>(d.src);
     uint32_t *dst = reinterpret_cast<uint32_t *>(d.dst);
-    for (uint32_t r = 0; r < d.rows; ++r) {
-        const uint32_t *s = src + ((size_t)r * Csrc + sc) * w;
-        uint32_t *t = dst + ((size_t)r * Cdst + col) * w;
-        for (uint32_t i = 0; i < w; ++i) t[i] = s[i];
+    // (the words of a column spread over blockIdx.z: one thread walking the 64 rows of a window ring, or the 72 words of a
+    // framer row, is that many dependent round trips)
+    const uint32_t n = d.rows * w;
+    for (uint32_t k = blockIdx.z; k < n; k += gridDim.z) {
+        const uint32_t r = k / w, i = k - r * w;
+        dst[((size_t)r * Cdst + col) * w + i] = src[((size_t)r * Csrc + sc) * w + i];
     }
 }
 hipError_t launch_copy_state_columns(const StateArrayDesc *desc, uint32_t n_desc, uint32_t src_channels,
                                      uint32_t dst_channels, const uint32_t *src_col, uint32_t n_cols, hipStream_t stream,
                                      uint32_t src_base)
 {
-    hipLaunchKernelGGL(copy_state_columns_kernel, dim3((n_cols + 255) / 256, n_desc), dim3(256), 0, stream, desc,
+    hipLaunchKernelGGL(copy_state_columns_kernel, dim3((n_cols + 255) / 256, n_desc, 16), dim3(256), 0, stream, desc,
                        src_channels, dst_channels, src_col, n_cols, src_base);
     return hipGetLastError();
 }

@@ -60,9 +60,11 @@ hipError_t launch_demod_fast_i16(const Params &P, const State &S, const Output &
 hipError_t launch_counters(uint32_t *dev, uint32_t *host_mapped, int publish, hipStream_t stream);
 // the log ordered by state column: first [n_bins + 1] (exclusive offsets), sorted [cap] (the records, a column's in any
 // order, their `channel` replaced by their index in the log), cnt [n_bins] scratch; counters[0] = events logged
+uint32_t event_sort_extra_words(uint32_t n_bins);      // words `first` needs behind its n_bins + 1 (the scan's workgroup totals)
 hipError_t launch_event_sort(const DevEvent *ev, const uint32_t *counters, uint32_t cap, uint32_t n_bins, uint32_t *cnt, uint32_t *first,
                              DevEvent *sorted, hipStream_t stream);
-hipError_t launch_init_state(const Params &P, const State &S, int is_reset, hipStream_t stream);
+// (first_col: columns before it are left alone -- the time-parallel launches copy the channels' own state over them next)
+hipError_t launch_init_state(const Params &P, const State &S, int is_reset, hipStream_t stream, uint32_t first_col = 0);
 // Column copies between state blobs of different widths: for every array of `desc` (device memory,
 // n_desc entries) and every column col < n_cols, dst[row][col] = src[row][src_col ? src_col[col] : col + src_base].
 hipError_t launch_copy_state_columns(const StateArrayDesc *desc, uint32_t n_desc, uint32_t src_channels,

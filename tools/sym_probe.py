@@ -99,9 +99,9 @@ def prof(rx):
         return
     v = list(out)
     steps = max(v[19], 1)
-    names = ["S sample", "T timing", "Y symbol", "E events"]
+    names = ["S agc+flt A", "T dc+events", "Y symbol", "E flt B+ted"]
     for r in range(4):
-        print(f"  {names[r]:9s} work {v[3*r]/steps:8.1f}  barrier wait {v[3*r+1]/steps:8.1f}  feedback {v[3*r+2]/steps:8.1f}  clk/step")
+        print(f"  {names[r]:12s} work {v[3*r]/steps:8.1f}  barrier wait {v[3*r+1]/steps:8.1f}  feedback {v[3*r+2]/steps:8.1f}  clk/step")
     print(f"  workgroup 0: {v[18]} launches, {steps} steps, {sum(v[0:3])/steps:.0f} clk per step;", end="")
     print(f"  steps {steps}, T passes {v[13]}, feedback rounds {v[14]} ({100.0*v[14]/steps:.1f} % of steps); E's filter {v[15]/max(v[13],1):.0f} clk/pass, waiting for S's {v[17]/max(v[13],1):.0f}, timing+post {v[16]/max(v[13],1):.0f} clk/pass", flush=True)
 
