@@ -750,18 +750,24 @@ def main():
             C3, R3 = 16384, 48000
             T3 = R3 * 2
             x3 = sa.synth_afsk(C3, T3, R3, seed=778, device=local_rank)
-            rx3 = sa.SameReceiverBuilder(R3).build_batch(C3, device=local_rank)
-            rx3.set_kernel_timing(True)
-            e3, k3, _, _, _ = run_steps(sa, rx3, x3, T3, stream, n2, 2, lambda r: len(r.pack_bursts_np(0)), lambda: None)
-            a3 = 4.0 * C3 * T3 / (k3 * 1e-3) / 1e9
-            out["configs2_48k"] = {
-                "workload": f"{C3} channels x {T3} samples per step at {R3} Hz (BASELINE.json configs[2], 2 s of its 10 s)",
-                "value": round(C3 * T3 * n2 / e3 / 1e6, 2), "unit": "Msamples/s", "kernel_ms": round(k3, 4), "steps": n2,
-                "ms_per_step": round(e3 / n2 * 1e3, 3),
-                "kernel": rx3.kernel_name(),
-                "roofline": {"bound": "hbm", "achieved": round(a3, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                             "frac": round(a3 / HBM_PEAK_GBS, 5)},
-            }
+            out["configs2_48k"] = {"workload": f"{C3} channels x {T3} samples per step at {R3} Hz (BASELINE.json configs[2], 2 s of its 10 s)"}
+            ev3 = None
+            for label, kw in (("strict", {}), ("relaxed", {"relaxed": True})):
+                rx3 = sa.SameReceiverBuilder(R3).build_batch(C3, device=local_rank, **kw)
+                rx3.set_kernel_timing(True)
+                e3, k3, f3, _, _ = run_steps(sa, rx3, x3, T3, stream, n2, 2, lambda r: len(r.pack_bursts_np(0)), lambda: None)
+                a3 = 4.0 * C3 * T3 / (k3 * 1e-3) / 1e9
+                blk = {"value": round(C3 * T3 * n2 / e3 / 1e6, 2), "unit": "Msamples/s", "kernel_ms": round(k3, 4), "steps": n2,
+                       "ms_per_step": round(e3 / n2 * 1e3, 3), "kernel": rx3.kernel_name(),
+                       "roofline": {"bound": "hbm", "achieved": round(a3, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(a3 / HBM_PEAK_GBS, 5)}}
+                if label == "strict":
+                    ev3 = f3
+                    out["configs2_48k"].update(blk)
+                else:
+                    blk["contract"] = tp_contract(sa, ev3, f3, C3, 778, "first pass", t_end=T3, rate=R3)[1]
+                    out["configs2_48k"]["relaxed"] = blk
+                del rx3
+            del x3, ev3
     if rank == 0:
         print(json.dumps(out), flush=True)
     if distributed:

@@ -272,6 +272,7 @@ struct same_batch {
     bool use_fast = false;           // configuration has a latency-optimised kernel
     bool relaxed = false;            // relaxed arithmetic in time-parallel chunks (SAME_BATCH_TIME_PARALLEL or SAME_BATCH_RELAXED)
     bool last_plain_fm = false;      // the last ordinary launch ran the pipeline's FASTMATH build
+    bool last_plain_wave = false;    // ... the one- / two-wavefront relaxed kernel
     bool last_fm_sym = false;        // ... or rather the symbol-paced pipeline (same_kernels_sym.hip)
     bool relaxed_plain = false;      // ... and in ordinary launches: the one-wavefront relaxed kernel runs whole blocks (SAME_BATCH_RELAXED)
     int knob_relaxed = 0;            // SAME_RELAXED: -1 never (time-parallel chunks keep the strict pipeline), +1 as if SAME_BATCH_RELAXED were set
@@ -460,6 +461,13 @@ int ensure_stage(void **p, size_t *have, size_t need)
 
 // The relaxed-arithmetic pipeline of a launch over Pv.n_channels state columns: the symbol-paced one (36-sample steps,
 // same_kernels_sym.hip) where it is built, else the FASTMATH build of the 20-sample pipeline
+// the configuration as the pipeline's FASTMATH build takes it: 64-channel workgroups, the split form
+same::Params fm_params(const same::Params &P)
+{
+    same::Params Pfm = P;
+    Pfm.knob_pipe_lanes = 64; Pfm.knob_pipe_share = 1; Pfm.knob_pipe_split = 1; Pfm.knob_pipe = 1;
+    return Pfm;
+}
 uint32_t fm_block_len(const same::Params &Pv) { return same::sym_kernel_supported(Pv) ? same::sym_block_len(Pv) : same::pipe_block_len(Pv); }
 template <typename SampleT>
 hipError_t launch_fm(const same::Params &Pv, const same::State &Sv, const same::Output &O, const float4 *taps, const SampleT *x,
@@ -860,7 +868,7 @@ uint32_t plan_chunks(same_batch *rx, size_t n, same::ChunkGeom &geom, same::Pipe
     // Relaxed batches: the pipeline's FASTMATH build while the state columns fit the pipeline (whole 64-channel
     // workgroups), the one-wavefront relaxed kernel beyond (SAME_TP_KERNEL=pipe / wave overrides)
     const bool pipe_fm = rx->relaxed && tp.knob_kernel != 2 && C % same::kWave == 0u && C <= 16384u;
-    if (rx->relaxed && !pipe_fm && tp.knob_kernel != 1 && C % same::kWave == 0u && C <= 65536u) {
+    if (rx->relaxed && !pipe_fm && tp.knob_kernel != 1 && C % same::kWave == 0u && C <= 65536u && same::relaxed_kernel_supported(rx->P)) {
         // one wavefront per 64 state columns, any number of them
         // (up to 262 144 state columns, 16 pieces per channel unless the caller asks for more: a piece is a burst with its
         // margins at least, so more only sit empty)
@@ -1031,22 +1039,23 @@ int process_time_major(same_batch *rx, const SampleT *d_x, size_t n_samples, hip
         // SAME_BATCH_RELAXED on an ordinary launch: the pipeline's FASTMATH build while the batch fits it (whole 64-channel
         // workgroups, up to 32 768 channels: four wavefronts per 64 channels), the one- / two-wavefront relaxed kernel beyond
         // (SAME_RELAXED_KERNEL=solo / duo forces that one)
-        same::Params Pfm = rx->P;
-        Pfm.knob_pipe_lanes = 64; Pfm.knob_pipe_share = 1; Pfm.knob_pipe_split = 1; Pfm.knob_pipe = 1;
+        const same::Params Pfm = fm_params(rx->P);
         // (the symbol-paced pipeline takes any number of 64-channel workgroups: beyond two per CU they run in rounds)
         const bool plain_fm = rx->relaxed_plain && rx->P.knob_relaxed_kernel == 0 && same::pipe_relaxed_supported(Pfm) &&
                               (rx->P.n_channels <= 32768u || (rx->P.n_channels <= 65536u && same::sym_kernel_supported(Pfm)));
         // (measured, 2 s launches: 49 152 channels 4.53 ms against the two-wavefront relaxed kernel's 5.12, 65 536: 5.41 against
         // 6.08; 131 072: 10.2 against the one-wavefront kernel's 9.7, 262 144: 19.4 against 18.3)
-        rx->last_plain_fm = plain_fm;
+        // (44.1 / 48 kHz have the FASTMATH pipeline only: a batch beyond it runs strict)
+        const bool plain_wave = rx->relaxed_plain && !plain_fm && same::relaxed_kernel_supported(rx->P);
+        rx->last_plain_fm = plain_fm; rx->last_plain_wave = plain_wave;
         const size_t fb = plain_fm ? fm_block_len(Pfm)
-                                   : (rx->relaxed_plain ? same::relaxed_block_len(rx->P) : (rx->use_fast ? same::fast_block_len(rx->P) : 16));
+                                   : (plain_wave ? same::relaxed_block_len(rx->P) : (rx->use_fast ? same::fast_block_len(rx->P) : 16));
         size_t n_fast = (rx->use_fast && !rx->force_generic) ? (n / fb) * fb : 0;
         if (n_fast && plain_fm) {
             e = launch_fm(Pfm, rx->S, O, rx->d_taps, xp, (uint32_t)(n_fast / fb), rx->counter, stream, same::PipeChunks{});
             rx->last_fm_sym = same::sym_kernel_supported(Pfm);
             if (e != hipSuccess) return fail(SAME_EHIP, "relaxed pipeline launch failed: %s", hipGetErrorString(e));
-        } else if (n_fast && rx->relaxed_plain) {
+        } else if (n_fast && plain_wave) {
             if constexpr (sizeof(SampleT) == 4)
                 e = same::launch_demod_relaxed(rx->P, rx->S, O, rx->d_taps, (const float *)xp, (uint32_t)(n_fast / fb), rx->counter, stream);
             else
@@ -1389,7 +1398,8 @@ int same_batch_new(const same_rx_builder *b, uint32_t n_channels, int device, ui
     // Relaxed arithmetic: asked for (SAME_BATCH_RELAXED), or implied by the time-parallel mode, whose contract is the
     // same one (SAME_RELAXED=0 keeps that mode on the strict pipeline kernel; =1 turns it on for any batch)
     rx->relaxed = (((flags & (SAME_BATCH_RELAXED | SAME_BATCH_TIME_PARALLEL)) != 0 && rx->knob_relaxed >= 0) || rx->knob_relaxed > 0) &&
-                  rx->use_fast && !rx->force_generic && same::relaxed_kernel_supported(rx->P);
+                  rx->use_fast && !rx->force_generic &&
+                  (same::relaxed_kernel_supported(rx->P) || (rx->P.n_channels % same::kWave == 0u && same::pipe_relaxed_supported(fm_params(rx->P))));
     // (a call of a time-parallel batch that is too short to be cut stays strict unless relaxed arithmetic was asked for)
     rx->relaxed_plain = rx->relaxed && ((flags & SAME_BATCH_RELAXED) != 0 || rx->knob_relaxed > 0);
     if (same::demod_lds_bytes(rx->P) > 160 * 1024)
@@ -1710,7 +1720,8 @@ const char *same_batch_kernel_name(const same_batch *rx)
         default: return "demod_pipe_kernel";
         }
     }
-    if (rx->relaxed_plain) return rx->last_plain_fm ? (rx->last_fm_sym ? "demod_sym_kernel" : "demod_pipe_kernel<fastmath>") : "demod_relaxed_kernel";
+    if (rx->relaxed_plain && rx->last_plain_fm) return rx->last_fm_sym ? "demod_sym_kernel" : "demod_pipe_kernel<fastmath>";
+    if (rx->relaxed_plain && rx->last_plain_wave) return "demod_relaxed_kernel";
     if (rx->use_fast && !rx->force_generic) 
     {
         const uint32_t st = same::pipe_kernel_stages(rx->P);

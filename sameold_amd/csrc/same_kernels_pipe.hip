@@ -60,8 +60,11 @@ template <int NT> struct PipeLayout {
     // blocks -- the one being written, the one stage 1 consumes, two more for a replay
     static constexpr uint32_t dcw_blocks = 4u;
     static constexpr uint32_t dcw_ring_floats = dcw_blocks * (uint32_t)B * kWave;
-    static constexpr uint32_t tap_floats = (uint32_t)((NT * 4 + PIPE_PROF_TAP_PAD + 63) / 64 * 64);
-    static_assert(B <= RING - NT + 1, "the first block's low copy would be read");
+    // (the FASTMATH filters take the taps in chunks of kRelaxChunk: 92 taps are followed by 6 zero taps, which meet
+    // window slots further back -- finite values, the ring holds 5 blocks)
+    static constexpr int NTP = (NT + kRelaxChunk - 1) / kRelaxChunk * kRelaxChunk;
+    static constexpr uint32_t tap_floats = (uint32_t)((NTP * 4 + PIPE_PROF_TAP_PAD + 63) / 64 * 64);
+    static_assert(B <= RING - NTP + 1, "the first block's low copy would be read");
 };
 
 // =====================================================================================
@@ -552,7 +555,7 @@ struct DcStage {
     }
 };
 
-template <int NT_, bool MED3>
+template <int NT_, bool MED3, bool FM = false>
 struct AgcStage {
     static constexpr int kB = PipeLayout<NT_>::B, RING = PipeLayout<NT_>::RING;
     static constexpr int DEPTH = 3;                     // blocks a replay reaches back over, the current one included
@@ -597,7 +600,7 @@ struct AgcStage {
         float *wlow = wcol + (wp[j] == 0u ? (uint32_t)RING : wp[j]) * LP;
 #pragma unroll
         for (int k = 0; k < kB; ++k) {
-            const float out = agc_step<MED3>(P, yv[k], g, (k <= fk) ? bw0 : bw1);
+            const float out = FM ? agc_step_relaxed(P, yv[k], g, (k <= fk) ? bw0 : bw1) : agc_step<MED3>(P, yv[k], g, (k <= fk) ? bw0 : bw1);
             wlow[k * LP] = out;
             wblk[(k + RING) * LP] = out;
         }
@@ -670,7 +673,9 @@ __global__ __launch_bounds__((pipe_dcw<NT, LANES, SPLIT>() ? 5 : 4) * kWave, SHA
                                                                 const SampleT *__restrict__ x,
                                                                 uint32_t n_blocks, uint64_t counter0, PipeChunks K)
 {
-    static_assert(!FM || (SPLIT && SHARE && NT == 42 && LANES == 64), "FASTMATH is built for the 64-channel two-per-CU form");
+    static_assert(!FM || (SPLIT && LANES == 64 && SHARE == (NT == 42)),
+                  "FASTMATH is built for 64-channel workgroups: two per CU at 22.05 kHz, one (with the DC wavefront) at 44.1 / 48 kHz");
+    constexpr int NTP = PipeLayout<NT>::NTP;
     if constexpr (CMODE == 0) { K.col_row0 = nullptr; K.col_perm = nullptr; }       // (the host launches this build for nothing else)
     constexpr int kB = PipeLayout<NT>::B, RING = PipeLayout<NT>::RING;
     constexpr uint32_t LP = kWave, kPipeTapFloats = PipeLayout<NT>::tap_floats;
@@ -681,7 +686,8 @@ __global__ __launch_bounds__((pipe_dcw<NT, LANES, SPLIT>() ? 5 : 4) * kWave, SHA
     // 22.05 kHz, where the helper runs both filters in every lane with their accumulation chains interleaved
     // (demod_pair) -- 32 768 channels x 2 s 4.34 -> 4.21 ms, the time-parallel launch of configs[1] 4.49 -> 4.39 ms
     // on one box; at 48 kHz (92 taps, one workgroup per CU) the same is 4 % slower, so not there.
-    constexpr bool HELPER_BOTH = PACKED || (SPLIT && SHARE && NT == 42);
+    // (FASTMATH: both filters share their window loads, demod_pair_relaxed -- always the helper's)
+    constexpr bool HELPER_BOTH = PACKED || (SPLIT && SHARE && NT == 42) || FM;
     // DCW: a fifth wavefront runs the DC blocker one block ahead (DcStage / AgcStage above)
     constexpr bool DCW = pipe_dcw<NT, LANES, SPLIT>();
     static_assert(kB <= 64, "the sample index travels in six bits of the stage 3 -> 4 word");
@@ -791,10 +797,10 @@ __global__ __launch_bounds__((pipe_dcw<NT, LANES, SPLIT>() ? 5 : 4) * kWave, SHA
         D.store(S, c, C, counter1);
     } else if (DCW && role == 0u) {
         // ------------------------------ stage 1 (DCW): AGC + window push, block s ------------------
-        for (uint32_t i = lane; i < (uint32_t)NT; i += kWave) tlds[i] = taps[i];
+        for (uint32_t i = lane; i < (uint32_t)NTP; i += kWave) tlds[i] = i < (uint32_t)NT ? taps[i] : float4{0.0f, 0.0f, 0.0f, 0.0f};
         if (LANES < (int)kWave && lane >= (uint32_t)LANES) return;
         P3_HWID(0);
-        AgcStage<NT, MED3> M;
+        AgcStage<NT, MED3, FM> M;
         M.ycol = dcw_ring + lane;
         M.load(P, S, c, C, counter0, wcol);
         lds_barrier();                                                 // prologue: block 0's DC outputs are in the ring
@@ -829,7 +835,7 @@ __global__ __launch_bounds__((pipe_dcw<NT, LANES, SPLIT>() ? 5 : 4) * kWave, SHA
         M.store(P, S, c, C, counter1, wcol);
     } else if (role == 0u) {
         // ------------------------------ stage 1: sample phase, block s -------------------------
-        for (uint32_t i = lane; i < (uint32_t)NT; i += kWave) tlds[i] = taps[i];
+        for (uint32_t i = lane; i < (uint32_t)NTP; i += kWave) tlds[i] = i < (uint32_t)NT ? taps[i] : float4{0.0f, 0.0f, 0.0f, 0.0f};
         if (LANES < (int)kWave && lane >= (uint32_t)LANES) return;      // (the wavefront goes on without them)
         P3_HWID(0);
         SampleStage<NT, MED3, SampleT, FM, CMODE> M;
@@ -941,7 +947,7 @@ __global__ __launch_bounds__((pipe_dcw<NT, LANES, SPLIT>() ? 5 : 4) * kWave, SHA
                     float sa2;
                     if constexpr (FM) {
                         float hm2, hs2;
-                        demod_pair_relaxed<NT, RING, false>(lds_addr(lds), lds_addr(wcol), wpos + (uint32_t)fk2, &hm2, &hs2);
+                        demod_pair_relaxed<NTP, RING, false>(lds_addr(lds), lds_addr(wcol), wpos + (uint32_t)fk2, &hm2, &hs2);
                         sa2 = __builtin_amdgcn_fmed3f(hm2 - hs2, -1.0f, 1.0f);
                     } else {
                         sa2 = demod_fast<NT, RING, true>(tlds, wring, lane, wpos + (uint32_t)fk2);
@@ -1185,7 +1191,8 @@ __global__ __launch_bounds__((pipe_dcw<NT, LANES, SPLIT>() ? 5 : 4) * kWave, SHA
                 (which ? spacebox : markbox)[fch] = __float_as_uint(mag);
             } else if constexpr (HELPER_BOTH) {
                 float hm, hs;
-                if constexpr (FM) demod_pair_relaxed_42<RING>(lds_addr(lds), lds_addr(wcol), wpos + pos, &hm, &hs);
+                if constexpr (FM && NT == 42) demod_pair_relaxed_42<RING>(lds_addr(lds), lds_addr(wcol), wpos + pos, &hm, &hs);
+                else if constexpr (FM) demod_pair_relaxed_chunks<NTP / kRelaxChunk, RING>(lds_addr(lds), lds_addr(wcol), wpos + pos, &hm, &hs);
                 else demod_pair<NT, RING>(tlds, wring, lane, wpos + pos, &hm, &hs);
                 markbox[lane] = __float_as_uint(hm); spacebox[lane] = __float_as_uint(hs);
             } else {
@@ -1302,7 +1309,7 @@ static hipError_t launch_pipe_one(const Params &P, const State &S, const Output 
     constexpr size_t lds = pipe_lds_bytes<NT, DCW>();
     // The two-per-CU builds (what time-parallel launches and batches beyond 16 384 channels run): one build per input
     // form (see SampleStage); everything else decides at run time
-    constexpr bool FORMS = FM || (SHARE && SPLIT && LANES == 64);
+    constexpr bool FORMS = (FM && NT == 42) || (SHARE && SPLIT && LANES == 64);
     const bool cm = K.n_chunks > 1u && K.col_row0 != nullptr;
     auto *kernel = !FORMS ? demod_pipe_kernel<NT, NFF, NFB, M3, SHARE, LANES, SPLIT, SampleT, FM, 2>
                           : (cm ? demod_pipe_kernel<NT, NFF, NFB, M3, SHARE, LANES, SPLIT, SampleT, FM, FORMS ? 1 : 2>
@@ -1338,7 +1345,13 @@ static hipError_t launch_pipe_cfg(const Params &P, const State &S, const Output 
             return launch_pipe_one<NT, 1, 1, true, true, 64, true, SampleT, true>(P, S, O, taps, x, n_blocks, counter0, stream, K);
         }
     } else {
-        if (relaxed) return hipErrorInvalidValue;
+        // FASTMATH at 44.1 / 48 kHz: the one-per-CU form with the DC wavefront
+        if (relaxed) {
+            if (!pipe_relaxed_supported(P)) return hipErrorInvalidValue;
+            if (P.eq_nff == 6u && P.eq_nfb == 4u)
+                return launch_pipe_one<NT, 6, 4, true, false, 64, true, SampleT, true>(P, S, O, taps, x, n_blocks, counter0, stream, K);
+            return launch_pipe_one<NT, 1, 1, true, false, 64, true, SampleT, true>(P, S, O, taps, x, n_blocks, counter0, stream, K);
+        }
     }
     // two workgroups per CU (22.05 kHz only, where their LDS allows it): the register-capped build, with
     // stage 2 split (same box, 32 768 channels x 2 s: 4.27-4.29 ms unsplit, 4.18-4.24 ms split).  Which stages
@@ -1388,11 +1401,12 @@ hipError_t launch_demod_pipe(const Params &P, const State &S, const Output &O, c
 hipError_t launch_demod_pipe_i16(const Params &P, const State &S, const Output &O, const float4 *taps,
                                  const int16_t *x, uint32_t n_blocks, uint64_t counter0, hipStream_t stream, const PipeChunks &K, bool relaxed)
 { return launch_pipe_t<int16_t>(P, S, O, taps, x, n_blocks, counter0, stream, K, relaxed); }
-// The FASTMATH build exists for 22.05 kHz in 64-channel workgroups (whole groups of 64 state columns), default or disabled
-// equalizer, a non-negative AGC floor
+// The FASTMATH build exists for the three rates the pipeline is built for, in 64-channel workgroups (whole groups of 64
+// state columns), default or disabled equalizer, a non-negative AGC floor
 bool pipe_relaxed_supported(const Params &P)
 {
-    return P.ntaps == 42u && P.dc_len == 16u && (P.n_channels % kWave) == 0u && P.agc_min >= 0.0f && pipe_kernel_stages(P) != 0u &&
+    const bool geom = (P.ntaps == 42u && P.dc_len == 16u) || (P.ntaps == 92u && P.dc_len == 35u) || (P.ntaps == 84u && P.dc_len == 32u);
+    return geom && (P.n_channels % kWave) == 0u && P.agc_min >= 0.0f && pipe_kernel_stages(P) != 0u &&
            pipe_lanes(P) == kWave && ((P.eq_nff == 6u && P.eq_nfb == 4u) || (P.eq_nff == 1u && P.eq_nfb == 1u));
 }
 uint32_t pipe_workgroup_channels(const Params &P) { return pipe_lanes(P); }

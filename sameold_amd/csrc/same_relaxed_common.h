@@ -8,6 +8,9 @@
 
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+#include <utility>
+
 #include "same_dev_common.h"
 #include "same_device.h"
 #include "same_fast_common.h"
@@ -243,6 +246,49 @@ __device__ __forceinline__ void demod_pair_relaxed_42(uint32_t taps_lds, uint32_
     RELAX_LOAD_B(Z, wa2, ta2);             // A2 12, B2 9
     RELAX_WAIT_A(Y, 9);  RELAX_FMA_A(Y);
     RELAX_WAIT_B(Z, 0);  RELAX_FMA_B(Z);
+    *hm_out = relax_magnitude(am0 + am1);
+    *hs_out = relax_magnitude(as0 + as1);
+}
+
+// ... and for any number of whole chunks (84 taps: 6; 92 taps padded with zero taps: 7), the same software pipeline written
+// once: part k (chunk k / 2, A then B) lives in register set k % 3, is waited for with only part k + 1 still in flight, and
+// part k + 2 is requested as soon as its products have been issued.  (The chunk-at-a-time loop of demod_pair_relaxed
+// exposes two LDS round trips per chunk: at 48 kHz the helper wavefront, which runs both filters of the FASTMATH build, was
+// 14 round trips per instant behind.)
+template <typename F, int... I>
+__device__ __forceinline__ void relax_static_for_(F &&f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
+template <int NCH, int RING>
+__device__ __forceinline__ void demod_pair_relaxed_chunks(uint32_t taps_lds, uint32_t wlane_lds, uint32_t newest, float *hm_out, float *hs_out)
+{
+    static_assert(kRelaxChunk == 14, "chunks of 14 taps, written out");
+    float2v am0 = {0.0f, 0.0f}, am1 = {0.0f, 0.0f}, as0 = {0.0f, 0.0f}, as1 = {0.0f, 0.0f};
+    const uint32_t wa0 = wlane_lds + (newest + (uint32_t)RING - 13u) * (kWave * 4u);
+    RelaxPart X, Y, Z;
+    constexpr int NP = 2 * NCH;
+    auto part = [&](auto kc, auto &&fn) __attribute__((always_inline)) {
+        constexpr int k = decltype(kc)::value;
+        if constexpr (k % 3 == 0) fn(X); else if constexpr (k % 3 == 1) fn(Y); else fn(Z);
+    };
+    auto load = [&](auto kc) __attribute__((always_inline)) {
+        constexpr int k = decltype(kc)::value, c = k / 2;
+        const uint32_t wa = wa0 - (uint32_t)(14 * c) * (kWave * 4u), ta = taps_lds + (uint32_t)(224 * c);
+        part(kc, [&](RelaxPart &R) __attribute__((always_inline)) { if constexpr (k % 2 == 0) RELAX_LOAD_A(R, wa, ta); else RELAX_LOAD_B(R, wa, ta); });
+    };
+    load(std::integral_constant<int, 0>{});
+    load(std::integral_constant<int, 1>{});
+    relax_static_for_([&](auto kc) __attribute__((always_inline)) {
+        constexpr int k = decltype(kc)::value;
+        part(kc, [&](RelaxPart &R) __attribute__((always_inline)) {
+            if constexpr (k % 2 == 0) {
+                if constexpr (k + 1 < NP) RELAX_WAIT_A(R, 9); else RELAX_WAIT_A(R, 0);
+                RELAX_FMA_A(R);
+            } else {
+                if constexpr (k + 1 < NP) RELAX_WAIT_B(R, 12); else RELAX_WAIT_B(R, 0);
+                RELAX_FMA_B(R);
+            }
+        });
+        if constexpr (k + 2 < NP) load(std::integral_constant<int, k + 2>{});
+    }, std::make_integer_sequence<int, NP>{});
     *hm_out = relax_magnitude(am0 + am1);
     *hs_out = relax_magnitude(as0 + as1);
 }

@@ -104,6 +104,33 @@ def test_relaxed_streaming_calls_and_input_forms(sa):
     assert_contract(sa, got[np.lexsort((np.arange(len(got)), got["channel"]))], ref, rate, n_ch, pay, what="channel-major")
 
 
+def soft_symbol_differences(full, rel, n_ch, rate, every=3):
+    """Strict (full) against relaxed (rel) soft symbols while the squelch is open: per compared symbol the distance of the
+    instants in samples and of the values, the number of sign differences, the number of bursts looked at."""
+    sps = rate / 520.83
+    ev = split(full.poll_events_np(), n_ch)
+    all_dt, all_err, sign_flips, checked = [], [], 0, 0
+    for c in range(0, n_ch, every):
+        reading = ev[c][ev[c]["kind"] == 2]["sample_counter"]
+        bursts = ev[c][ev[c]["kind"] == 3]["sample_counter"]
+        ta, tb = full.read_trace(c, cap=4096), rel.read_trace(c, cap=4096)
+        for t_read, t_burst in zip(reading, bursts):
+            t_read, t_burst = int(t_read), int(t_burst)
+            a = ta[(ta["sample_counter"] > t_read) & (ta["sample_counter"] < t_burst - int(5 * 8 * sps + 8))]
+            b = tb[(tb["sample_counter"] > t_read - int(3 * sps)) & (tb["sample_counter"] < t_burst + int(3 * sps))]
+            if len(a) < 50 or len(b) < 50:
+                continue
+            idx = np.clip(np.searchsorted(b["sample_counter"], a["sample_counter"]), 1, len(b) - 1)
+            ta_ = a["sample_counter"].astype(np.int64)
+            near = np.where(np.abs(b["sample_counter"][idx].astype(np.int64) - ta_)
+                            < np.abs(b["sample_counter"][idx - 1].astype(np.int64) - ta_), idx, idx - 1)
+            all_dt.append(np.abs(b["sample_counter"][near].astype(np.int64) - ta_))
+            all_err.append(np.abs(b["sym"][near] - a["sym"]))
+            sign_flips += int(np.sum(np.sign(b["sym"][near]) != np.sign(a["sym"])))
+            checked += 1
+    return np.concatenate(all_dt), np.concatenate(all_err), sign_flips, checked
+
+
 def test_relaxed_soft_symbols_within_the_stated_tolerance(sa):
     """The soft-symbol stream of the relaxed kernel against strict mode's, symbol by symbol, while the squelch is open
     (Reading ... the end of the transmitted bytes): instants within SOFT_INSTANT_TOLERANCE samples, values within
@@ -115,28 +142,8 @@ def test_relaxed_soft_symbols_within_the_stated_tolerance(sa):
     rel = sa.SameReceiverBuilder(rate).build_batch(n_ch, trace_symbols=True, link_only=True, relaxed=True)
     rel.process_tensor(x); rel.sync()
     assert rel.kernel_name() == "demod_relaxed_kernel"
-    ev = split(full.poll_events_np(), n_ch)
-    all_dt, all_err, sign_flips, checked = [], [], 0, 0
-    for c in range(0, n_ch, 3):
-        reading = ev[c][ev[c]["kind"] == 2]["sample_counter"]
-        bursts = ev[c][ev[c]["kind"] == 3]["sample_counter"]
-        ta, tb = full.read_trace(c, cap=4096), rel.read_trace(c, cap=4096)
-        for t_read, t_burst in zip(reading, bursts):
-            t_read, t_burst = int(t_read), int(t_burst)
-            a = ta[(ta["sample_counter"] > t_read) & (ta["sample_counter"] < t_burst - 5 * 8 * 43)]
-            b = tb[(tb["sample_counter"] > t_read - 64) & (tb["sample_counter"] < t_burst + 64)]
-            if len(a) < 50 or len(b) < 50:
-                continue
-            idx = np.clip(np.searchsorted(b["sample_counter"], a["sample_counter"]), 1, len(b) - 1)
-            ta_ = a["sample_counter"].astype(np.int64)
-            near = np.where(np.abs(b["sample_counter"][idx].astype(np.int64) - ta_)
-                            < np.abs(b["sample_counter"][idx - 1].astype(np.int64) - ta_), idx, idx - 1)
-            all_dt.append(np.abs(b["sample_counter"][near].astype(np.int64) - ta_))
-            all_err.append(np.abs(b["sym"][near] - a["sym"]))
-            sign_flips += int(np.sum(np.sign(b["sym"][near]) != np.sign(a["sym"])))
-            checked += 1
+    dt, err, sign_flips, checked = soft_symbol_differences(full, rel, n_ch, rate)
     assert checked >= 20
-    dt, err = np.concatenate(all_dt), np.concatenate(all_err)
     stats = (f"{len(dt)} symbols of {checked} bursts: instants max {dt.max()} samples apart (mean {dt.mean():.2f}); "
              f"soft symbols max |diff| {err.max():.4f}, {np.mean(err <= SOFT_SYMBOL_TOLERANCE):.5f} within {SOFT_SYMBOL_TOLERANCE}, "
              f"{sign_flips} sign differences")
@@ -199,10 +206,37 @@ def test_relaxed_batches_on_the_pipeline(sa, monkeypatch):
                         garbled_per_mille=(1 if noise > 0.0 else 0), t_end=n)
 
 
+@pytest.mark.parametrize("rate,n_ch", [(48000, 256), (44100, 128)])
+def test_relaxed_batches_on_the_pipeline_at_the_other_rates(sa, monkeypatch, rate, n_ch):
+    """44.1 and 48 kHz (84 / 92 taps): the pipeline's FASTMATH build in its one-workgroup-per-CU form, with the DC
+    wavefront.  Same contract; state carried over calls that are not whole blocks."""
+    monkeypatch.delenv("SAME_RELAXED_KERNEL", raising=False)
+    n = rate * 6
+    for noise, seed in ((0.0, 81), (0.03, 82)):
+        x = sa.synth_afsk(n_ch, n, rate, seed=seed, noise_sigma=noise)
+        ref = strict_events(sa, x, rate)
+        rx, got = relaxed_events(sa, x, rate, calls=[2 * rate + 11, 77, n - 2 * rate - 88])
+        assert rx.kernel_name() == "demod_pipe_kernel<fastmath>"
+        assert_contract(sa, got, ref, rate, n_ch, lambda c: sa.synth_payload(seed, c), exact_bursts=(noise == 0.0), what=f"pipeline fastmath {rate}",
+                        garbled_per_mille=(1 if noise > 0.0 else 0), t_end=n)
+    # its soft symbols
+    x = sa.synth_afsk(64, n, rate, seed=83)
+    full = sa.SameReceiverBuilder(rate).build_batch(64, trace_symbols=True, link_only=True)
+    rel = sa.SameReceiverBuilder(rate).build_batch(64, trace_symbols=True, link_only=True, relaxed=True)
+    for r in (full, rel):
+        r.process_tensor(x); r.sync()
+    assert rel.kernel_name() == "demod_pipe_kernel<fastmath>"
+    dt, err, sign_flips, checked = soft_symbol_differences(full, rel, 64, rate, every=5)
+    stats = f"{len(dt)} symbols of {checked} bursts: instants max {dt.max()} samples apart, soft symbols max |diff| {err.max():.4f}, {sign_flips} sign differences"
+    print(stats)
+    assert checked >= 10 and sign_flips == 0, stats
+    assert dt.max() <= SOFT_INSTANT_TOLERANCE * rate // 22050 + 1 and err.max() <= SOFT_SYMBOL_TOLERANCE, stats
+
+
 def test_configurations_without_a_relaxed_kernel_run_strict(sa):
     """Other sample rates, other equalizer orders, a negative AGC floor: SAME_BATCH_RELAXED is accepted and the batch
     runs the strict kernels, bit for bit."""
-    for rate, eq, agc in ((48000, None, None), (22050, (8, 3), None), (22050, None, (-1.0, 1.0e6))):
+    for rate, eq, agc in ((32000, None, None), (22050, (8, 3), None), (22050, None, (-1.0, 1.0e6))):
         b = sa.SameReceiverBuilder(rate)
         if eq:
             b.with_adaptive_equalizer(eq[0], eq[1], 0.05, 1.0e-5)

@@ -35,7 +35,7 @@ SOFT_INSTANT_TOLERANCE = 8       # samples (a fifth of a symbol at 22.05 kHz; me
 @pytest.fixture(autouse=True, params=["fastmath", "strict"])
 def arith(request, monkeypatch):
     """The arithmetic inside the chunks: the default (relaxed: the pipeline's FASTMATH build wherever the batch is
-    whole 64-channel workgroups at 22.05 kHz) or strict (SAME_RELAXED=0); read when a batch is created."""
+    whole 64-channel workgroups at 22.05 / 44.1 / 48 kHz) or strict (SAME_RELAXED=0); read when a batch is created."""
     if request.param == "strict":
         monkeypatch.setenv("SAME_RELAXED", "0")
     else:
@@ -187,10 +187,12 @@ def test_time_parallel_meets_the_contract(sa, ob, arith, n_ch, seconds, chunks, 
     rx.process_tensor(x)
     rx.sync()
     assert rx.time_parallel_chunks() == chunks
+    # relaxed arithmetic inside the chunks at all three rates the pipeline is built for (whole 64-channel groups)
+    assert rx.kernel_name() == ("demod_pipe_kernel" if arith == "strict" else "demod_sym_kernel" if rate == 22050 else "demod_pipe_kernel<fastmath>")
     got = rx.poll_events_np()
     assert len(got[got["kind"] == 3]) >= 2 * n_ch
     assert_contract(sa, got, ref, rate, n_ch, lambda c: sa.synth_payload(1000 + n_ch, c), exact_bursts=(noise == 0.0),
-                    garbled_per_mille=(1 if noise > 0.0 and arith == "fastmath" and rate == 22050 else 0))
+                    garbled_per_mille=(1 if noise > 0.0 and arith == "fastmath" else 0))
 
 
 def test_time_parallel_streaming_calls_continue_the_channel_state(sa):
