@@ -482,60 +482,17 @@ hipError_t launch_fm(const same::Params &Pv, const same::State &Sv, const same::
     }
 }
 
-// Collect the finished launch: copy its event log back, order it, run the transport
-// layer, append to the queue.
-int harvest_slot(same_batch *rx, same_batch::Slot &sl)
+// The host half of a harvest: the launch's ordered event log, burst pool, hand-over instants and chunk geometry are in the
+// slot's host buffers; order each column's records, replay the channels (stitch + transport layer) on the worker threads and
+// append to the queue.  Touches no device: same_debug_harvest_replay runs it on a recorded launch without one.
+struct HarvestTimes { std::chrono::steady_clock::time_point sorted, replayed; uint32_t n_threads = 1; };
+int harvest_host(same_batch *rx, same_batch::Slot &sl, uint32_t n_events, uint32_t n_bursts, std::vector<uint32_t> &rearm, HarvestTimes &times)
 {
-    if (!sl.in_flight) return SAME_OK;
     const bool dbg = rx->debug;
-    auto t_begin = std::chrono::steady_clock::now();
-    // wait for THIS launch only (its cursors have landed in pinned memory); a later launch
-    // may still be running on the compute stream
-    HIP_TRY(hipEventSynchronize(sl.ev_done));
-    sl.in_flight = false;
-    if (rx->timing) {
-        HIP_TRY(hipEventElapsedTime(&rx->last_ms, sl.ev_start, sl.ev_stop));
-        rx->last_demod_ms = rx->last_ms;
-        if (sl.have_k) HIP_TRY(hipEventElapsedTime(&rx->last_demod_ms, sl.ev_k0, sl.ev_k1));
-        rx->have_timing = true;
-    }
-    auto t_waited = std::chrono::steady_clock::now();
-    const uint32_t n_events = std::min(sl.h_counters[0], sl.event_cap);
-    if (dbg)
-        std::fprintf(stderr, "[same] harvest: %u device events (%u bursts), cap %u/%u\n", sl.h_counters[0],
-                     sl.h_counters[1], sl.event_cap, sl.burst_cap);
-    const uint32_t n_bursts = std::min(sl.h_counters[1], sl.burst_cap);
-    if (sl.h_counters[2]) rx->overflowed = true;
-    const size_t ev_bytes = (size_t)n_events * sizeof(same::DevEvent), bu_bytes = (size_t)n_bursts * same::kBurstCap;
-    auto grow = [](void **p, size_t *have, size_t need) -> hipError_t {
-        if (need <= *have) return hipSuccess;
-        if (*p) { (void)hipHostFree(*p); *p = nullptr; *have = 0; }
-        const size_t want = need + need / 2 + 4096;
-        hipError_t e = hipHostMalloc(p, want, hipHostMallocDefault);
-        if (e == hipSuccess) *have = want;
-        return e;
-    };
-    HIP_TRY(grow(&sl.h_events, &sl.h_events_bytes, ev_bytes));
-    HIP_TRY(grow(&sl.h_bursts, &sl.h_bursts_bytes, bu_bytes));
     const same::DevEvent *evs = static_cast<const same::DevEvent *>(sl.h_events);
     const uint8_t *bursts = static_cast<const uint8_t *>(sl.h_bursts);
-    // the event log first: it is what the sort below needs, and the sort runs while the burst pool (the larger copy) and
-    // the chunk geometry are still on their way
     const uint32_t n_ch = rx->P.n_channels;
     const uint32_t n_bins = sl.chunked ? sl.geom.n_chunks * n_ch : n_ch;     // state columns of the launch
-    if (n_bins != sl.sort_bins) return fail(SAME_EINVAL, "internal: event sort made for %u columns, launch has %u", sl.sort_bins, n_bins);
-    // (the log arrives ordered by column, with the columns' offsets: the device did that behind the launch; at most
-    // n_events records are real, the exact count is the last offset)
-    HIP_TRY(hipMemcpyAsync(sl.h_sort, sl.d_sort + n_bins, ((size_t)n_bins + 1) * sizeof(uint32_t), hipMemcpyDeviceToHost, rx->copy_stream));
-    if (n_events) HIP_TRY(hipMemcpyAsync(sl.h_events, sl.d_sorted, ev_bytes, hipMemcpyDeviceToHost, rx->copy_stream));
-    HIP_TRY(hipStreamSynchronize(rx->copy_stream));
-    if (n_bursts) HIP_TRY(hipMemcpyAsync(sl.h_bursts, sl.d_bursts, bu_bytes, hipMemcpyDeviceToHost, rx->copy_stream));
-    if (sl.chunked) {
-        HIP_TRY(hipMemcpyAsync(sl.h_handover, sl.d_handover, (size_t)n_bins * sizeof(uint64_t), hipMemcpyDeviceToHost, rx->copy_stream));
-        if (sl.per_channel)
-            HIP_TRY(hipMemcpyAsync(sl.h_geom, sl.d_geom, (size_t)2 * n_bins * sizeof(uint32_t), hipMemcpyDeviceToHost, rx->copy_stream));
-    }
-    auto t_copied = std::chrono::steady_clock::now();
     // Per column the device emits in time order (a lane takes its log slots one after the other); across lanes the
     // atomic cursor interleaves.  The device has counted the events per column and moved the records into column
     // ranges (launch_event_sort: `evs` is that ordered copy, a record's `channel` holding its index in the log); inside
@@ -548,7 +505,6 @@ int harvest_slot(same_batch *rx, same_batch::Slot &sl)
     if (n_real > n_events) return fail(SAME_EHIP, "internal: event sort counted %u of %u events", n_real, n_events);
     // (what follows indexes the ordered copy directly)
     struct Identity { uint32_t operator[](uint32_t i) const { return i; } } order;
-    if (n_bursts || sl.chunked) HIP_TRY(hipStreamSynchronize(rx->copy_stream));      // bursts, hand-overs, geometry
     if (dbg && sl.chunked && sl.per_channel) {
         // how the per-channel boundaries came out: chunk lengths (own range + warm-up) and run-ons, in samples
         const same::ChunkGeom &g = sl.geom;
@@ -583,8 +539,7 @@ int harvest_slot(same_batch *rx, same_batch::Slot &sl)
     const std::vector<uint32_t> &cfirst = sl.chunked ? chan_first : first;
     const bool link_only = (rx->flags & SAME_BATCH_LINK_ONLY) != 0;
     const bool tp = rx->tp.enabled;
-    std::vector<uint32_t> rearm;     // channels whose forced-EOM instant changed
-    auto t_sorted = std::chrono::steady_clock::now();
+    times.sorted = std::chrono::steady_clock::now();
 
     // Channels are independent (one Transport each), so contiguous channel ranges are replayed
     // on separate host threads; each produces its slice of the output queue, in order.
@@ -713,6 +668,17 @@ int harvest_slot(same_batch *rx, same_batch::Slot &sl)
         same_rx_event ev;                                  // (scratch for what the transport layer returns)
         std::memset(&ev, 0, sizeof(ev));
         for (uint32_t c = c0; c < c1; ++c) {
+            // (the next channel's transport state: its first lines are what a poll reads, and they are cold)
+            // -- and all of it when a burst is on its way there: the assembler then walks its burst history and message texts
+            if (!link_only && c + 1u < c1) {
+                const char *nx = reinterpret_cast<const char *>(&rx->transport[c + 1u]);
+                __builtin_prefetch(nx); __builtin_prefetch(nx + 64);
+                if (!sl.chunked) {
+                    bool burst = false;
+                    for (uint32_t k = first[c + 1u]; k < first[c + 2u]; ++k) burst |= evs[k].kind == SAME_LINK_BURST;
+                    if (burst) for (size_t o = 128; o < sizeof(same::Transport); o += 64) __builtin_prefetch(nx + o);
+                }
+            }
             // this channel's column ranges back into log order (see above)
             for (uint32_t col = c; col < n_bins; col += n_ch)
                 if (first[col + 1u] - first[col] > 1u)
@@ -758,7 +724,8 @@ int harvest_slot(same_batch *rx, same_batch::Slot &sl)
         }
         rx->workers.run(n_threads, [&](size_t t) { run_range(cut[t], cut[t + 1u], parts[t]); });
     }
-    auto t_replayed = std::chrono::steady_clock::now();
+    times.replayed = std::chrono::steady_clock::now();
+    times.n_threads = n_threads;
     size_t total = 0, total_bytes = 0;
     for (const Part &p : parts) { total += p.out.size(); total_bytes += p.bytes.size(); }
     // a consumer that always polls less than is pending never drains the queue: reclaim the polled
@@ -801,6 +768,68 @@ int harvest_slot(same_batch *rx, same_batch::Slot &sl)
         });
     }
     for (Part &p : parts) rearm.insert(rearm.end(), p.rearm.begin(), p.rearm.end());
+    return SAME_OK;
+}
+
+int record_harvest(same_batch *rx, same_batch::Slot &sl, uint32_t n_events, uint32_t n_bursts, const char *path);
+
+// Collect the finished launch (device half): wait for it, copy its ordered log, burst pool and geometry back
+int harvest_slot(same_batch *rx, same_batch::Slot &sl)
+{
+    if (!sl.in_flight) return SAME_OK;
+    const bool dbg = rx->debug;
+    auto t_begin = std::chrono::steady_clock::now();
+    // wait for THIS launch only (its cursors have landed in pinned memory); a later launch
+    // may still be running on the compute stream
+    HIP_TRY(hipEventSynchronize(sl.ev_done));
+    sl.in_flight = false;
+    if (rx->timing) {
+        HIP_TRY(hipEventElapsedTime(&rx->last_ms, sl.ev_start, sl.ev_stop));
+        rx->last_demod_ms = rx->last_ms;
+        if (sl.have_k) HIP_TRY(hipEventElapsedTime(&rx->last_demod_ms, sl.ev_k0, sl.ev_k1));
+        rx->have_timing = true;
+    }
+    auto t_waited = std::chrono::steady_clock::now();
+    const uint32_t n_events = std::min(sl.h_counters[0], sl.event_cap);
+    if (dbg)
+        std::fprintf(stderr, "[same] harvest: %u device events (%u bursts), cap %u/%u\n", sl.h_counters[0],
+                     sl.h_counters[1], sl.event_cap, sl.burst_cap);
+    const uint32_t n_bursts = std::min(sl.h_counters[1], sl.burst_cap);
+    if (sl.h_counters[2]) rx->overflowed = true;
+    const size_t ev_bytes = (size_t)n_events * sizeof(same::DevEvent), bu_bytes = (size_t)n_bursts * same::kBurstCap;
+    auto grow = [](void **p, size_t *have, size_t need) -> hipError_t {
+        if (need <= *have) return hipSuccess;
+        if (*p) { (void)hipHostFree(*p); *p = nullptr; *have = 0; }
+        const size_t want = need + need / 2 + 4096;
+        hipError_t e = hipHostMalloc(p, want, hipHostMallocDefault);
+        if (e == hipSuccess) *have = want;
+        return e;
+    };
+    HIP_TRY(grow(&sl.h_events, &sl.h_events_bytes, ev_bytes));
+    HIP_TRY(grow(&sl.h_bursts, &sl.h_bursts_bytes, bu_bytes));
+    // the event log first: it is what the sort below needs, and the sort runs while the burst pool (the larger copy) and
+    // the chunk geometry are still on their way
+    const uint32_t n_ch = rx->P.n_channels;
+    const uint32_t n_bins = sl.chunked ? sl.geom.n_chunks * n_ch : n_ch;     // state columns of the launch
+    if (n_bins != sl.sort_bins) return fail(SAME_EINVAL, "internal: event sort made for %u columns, launch has %u", sl.sort_bins, n_bins);
+    // (the log arrives ordered by column, with the columns' offsets: the device did that behind the launch; at most
+    // n_events records are real, the exact count is the last offset)
+    HIP_TRY(hipMemcpyAsync(sl.h_sort, sl.d_sort + n_bins, ((size_t)n_bins + 1) * sizeof(uint32_t), hipMemcpyDeviceToHost, rx->copy_stream));
+    if (n_events) HIP_TRY(hipMemcpyAsync(sl.h_events, sl.d_sorted, ev_bytes, hipMemcpyDeviceToHost, rx->copy_stream));
+    HIP_TRY(hipStreamSynchronize(rx->copy_stream));
+    if (n_bursts) HIP_TRY(hipMemcpyAsync(sl.h_bursts, sl.d_bursts, bu_bytes, hipMemcpyDeviceToHost, rx->copy_stream));
+    if (sl.chunked) {
+        HIP_TRY(hipMemcpyAsync(sl.h_handover, sl.d_handover, (size_t)n_bins * sizeof(uint64_t), hipMemcpyDeviceToHost, rx->copy_stream));
+        if (sl.per_channel)
+            HIP_TRY(hipMemcpyAsync(sl.h_geom, sl.d_geom, (size_t)2 * n_bins * sizeof(uint32_t), hipMemcpyDeviceToHost, rx->copy_stream));
+    }
+    if (n_bursts || sl.chunked) HIP_TRY(hipStreamSynchronize(rx->copy_stream));      // bursts, hand-overs, geometry
+    auto t_copied = std::chrono::steady_clock::now();
+    if (const char *path = std::getenv("SAME_RECORD_HARVEST")) record_harvest(rx, sl, n_events, n_bursts, path);
+    std::vector<uint32_t> rearm;     // channels whose forced-EOM instant changed
+    HarvestTimes times;
+    int rc = harvest_host(rx, sl, n_events, n_bursts, rearm, times);
+    if (rc) return rc;
     // force_eom_at_sample (receiver.rs:321-328) lives on the host; tell the device when to
     // wake the transport layer for it.  Launches are capped well below the 135 s timeout,
     // so the instant is always armed before the device reaches it.
@@ -822,8 +851,8 @@ int harvest_slot(same_batch *rx, same_batch::Slot &sl)
         auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
         std::fprintf(stderr, "[same] harvest timing: wait %.2f ms, copy %.2f ms, sort %.2f ms, replay on %u threads %.2f ms, "
                              "queue %.2f ms\n",
-                     ms(t_begin, t_waited), ms(t_waited, t_copied), ms(t_copied, t_sorted), n_threads,
-                     ms(t_sorted, t_replayed), ms(t_replayed, t_end));
+                     ms(t_begin, t_waited), ms(t_waited, t_copied), ms(t_copied, times.sorted), times.n_threads,
+                     ms(times.sorted, times.replayed), ms(times.replayed, t_end));
     }
     return SAME_OK;
 }
@@ -841,6 +870,39 @@ int harvest(same_batch *rx)
 }
 
 int harvest(same_batch *rx);
+
+// ---- a harvest on file (tools/host_step_probe.py --ranks N: the host half of a step without a device) ----------------
+// SAME_RECORD_HARVEST=<path>: the third harvest of a batch writes what the host half reads -- the ordered log, the columns'
+// offsets, the burst pool, hand-over instants and chunk geometry -- to <path>.
+struct HarvestFileHeader {
+    uint64_t magic;                  // "SAMEHRV1"
+    uint32_t n_channels, n_bins, n_events, n_bursts, chunked, per_channel, flags, input_rate, tp_enabled, pad;
+    same::ChunkGeom geom;
+    uint64_t end_blocks, end_counter;
+};
+constexpr uint64_t kHarvestMagic = 0x3156524845'4d4153ull;
+int record_harvest(same_batch *rx, same_batch::Slot &sl, uint32_t n_events, uint32_t n_bursts, const char *path)
+{
+    if (sl.seq != 3u) return SAME_OK;
+    std::FILE *f = std::fopen(path, "wb");
+    if (!f) return fail(SAME_EINVAL, "SAME_RECORD_HARVEST: cannot write %s", path);
+    const uint32_t n_ch = rx->P.n_channels, n_bins = sl.chunked ? sl.geom.n_chunks * n_ch : n_ch;
+    HarvestFileHeader h{};
+    h.magic = kHarvestMagic;
+    h.n_channels = n_ch; h.n_bins = n_bins; h.n_events = n_events; h.n_bursts = n_bursts;
+    h.chunked = sl.chunked; h.per_channel = sl.per_channel; h.flags = rx->flags; h.input_rate = rx->P.input_rate; h.tp_enabled = rx->tp.enabled;
+    h.geom = sl.geom; h.end_blocks = sl.end_blocks; h.end_counter = sl.end_counter;
+    bool ok = std::fwrite(&h, sizeof(h), 1, f) == 1;
+    ok = ok && std::fwrite(sl.h_sort, sizeof(uint32_t), (size_t)n_bins + 1, f) == (size_t)n_bins + 1;
+    ok = ok && (!n_events || std::fwrite(sl.h_events, sizeof(same::DevEvent), n_events, f) == n_events);
+    ok = ok && (!n_bursts || std::fwrite(sl.h_bursts, same::kBurstCap, n_bursts, f) == n_bursts);
+    if (sl.chunked) {
+        ok = ok && std::fwrite(sl.h_handover, sizeof(uint64_t), n_bins, f) == n_bins;
+        if (sl.per_channel) ok = ok && std::fwrite(sl.h_geom, sizeof(uint32_t), (size_t)2 * n_bins, f) == (size_t)2 * n_bins;
+    }
+    std::fclose(f);
+    return ok ? SAME_OK : fail(SAME_EINVAL, "SAME_RECORD_HARVEST: short write to %s", path);
+}
 
 // How a call of n samples is cut into time-parallel chunks: fills geom / pc and returns the number of
 // chunks, or 1 when the call runs as one strict launch (mode off, configuration without a pipeline kernel,
@@ -1739,6 +1801,72 @@ const char *same_batch_kernel_name(const same_batch *rx)
 // ------------------------------------------------------------------------------------
 // single receiver with the reference's pull semantics
 // ------------------------------------------------------------------------------------
+
+// The host half of a step on a recorded launch, `reps` times on `threads` harvest threads, without a device: wall time of
+// each repetition in ms_out[reps] (the record's counters are moved on by the launch's length every time, so the transport
+// layer sees a stream that continues).  Returns the number of queue records one repetition produced, or a negative error.
+long same_debug_harvest_replay(const char *path, int threads, int reps, double *ms_out)
+{
+    if (!path || reps <= 0 || !ms_out) return -(long)fail(SAME_EINVAL, "null argument");
+    std::FILE *f = std::fopen(path, "rb");
+    if (!f) return -(long)fail(SAME_EINVAL, "cannot read %s", path);
+    HarvestFileHeader h{};
+    bool ok = std::fread(&h, sizeof(h), 1, f) == 1 && h.magic == kHarvestMagic && h.n_bins >= h.n_channels && h.n_channels > 0;
+    std::vector<uint32_t> first, geom;
+    std::vector<same::DevEvent> ev0, ev;
+    std::vector<uint8_t> bursts;
+    std::vector<uint64_t> hand0, hand;
+    if (ok) {
+        first.resize((size_t)h.n_bins + 1); ev0.resize(h.n_events); bursts.resize((size_t)h.n_bursts * same::kBurstCap);
+        ok = std::fread(first.data(), sizeof(uint32_t), first.size(), f) == first.size();
+        ok = ok && (!h.n_events || std::fread(ev0.data(), sizeof(same::DevEvent), h.n_events, f) == h.n_events);
+        ok = ok && (!h.n_bursts || std::fread(bursts.data(), same::kBurstCap, h.n_bursts, f) == h.n_bursts);
+        if (ok && h.chunked) {
+            hand0.resize(h.n_bins);
+            ok = std::fread(hand0.data(), sizeof(uint64_t), h.n_bins, f) == h.n_bins;
+            if (ok && h.per_channel) { geom.resize((size_t)2 * h.n_bins); ok = std::fread(geom.data(), sizeof(uint32_t), geom.size(), f) == geom.size(); }
+        }
+    }
+    std::fclose(f);
+    if (!ok) return -(long)fail(SAME_EINVAL, "%s is not a harvest record", path);
+    same_batch *rx = new (std::nothrow) same_batch;
+    if (!rx) return -(long)fail(SAME_ENOMEM, "out of memory");
+    rx->P.n_channels = h.n_channels; rx->P.input_rate = h.input_rate; rx->flags = h.flags;
+    if (std::getenv("SAME_REPLAY_LINK_ONLY")) rx->flags |= SAME_BATCH_LINK_ONLY;      // (what the transport layer's share is)
+    rx->tp.enabled = h.tp_enabled != 0; rx->host_threads = threads;
+    if (!(h.flags & SAME_BATCH_LINK_ONLY)) rx->transport.resize(h.n_channels);
+    if (rx->tp.enabled) { rx->tp.sym_off.assign(h.n_channels, 0); rx->tp.synth.assign(h.n_channels, TickSynth{}); }
+    same_batch::Slot &sl = rx->slot[0];
+    ev = ev0; hand = hand0;
+    sl.h_sort = first.data(); sl.h_events = ev.data(); sl.h_bursts = bursts.data();
+    sl.h_handover = hand.data(); sl.h_geom = geom.data();
+    sl.chunked = h.chunked != 0; sl.per_channel = h.per_channel != 0; sl.sort_bins = h.n_bins;
+    const uint64_t span = h.end_counter - h.geom.counter0;        // (an ordinary launch: geom is zero, the span the end counter -- fine for a stride)
+    const double sps = (double)h.input_rate / 520.83;
+    const uint64_t span_sym = (uint64_t)((double)span / sps);
+    long produced = 0;
+    int rc = SAME_OK;
+    for (int r = 0; r < reps && rc == SAME_OK; ++r) {
+        const uint64_t dt = span * (uint64_t)r, ds = span_sym * (uint64_t)r;
+        for (size_t i = 0; i < ev0.size(); ++i) { ev[i] = ev0[i]; ev[i].sample_counter += dt; if (!sl.chunked) ev[i].symbol_count += ds; }
+        for (size_t i = 0; i < hand0.size(); ++i) hand[i] = hand0[i] == same::kNoHandover ? hand0[i] : hand0[i] + dt;
+        sl.geom = h.geom; sl.geom.counter0 += dt;
+        sl.end_blocks = h.end_blocks + dt; sl.end_counter = h.end_counter + dt;
+        std::vector<uint32_t> rearm;
+        HarvestTimes times;
+        const auto t0 = std::chrono::steady_clock::now();
+        rc = harvest_host(rx, sl, h.n_events, h.n_bursts, rearm, times);
+        ms_out[r] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        produced = (long)(rx->queue.size() - rx->queue_head);
+        // the consumer's side: everything polled
+        rx->queue_head = rx->queue.size();
+        rx->burst_seq_head = rx->burst_seq.size();
+    }
+    sl.h_sort = nullptr; sl.h_events = nullptr; sl.h_bursts = nullptr; sl.h_handover = nullptr; sl.h_geom = nullptr;
+    delete rx;
+    return rc == SAME_OK ? produced : -(long)rc;
+}
+
 }  // extern "C"
 
 struct same_rx {

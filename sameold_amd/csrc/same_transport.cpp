@@ -17,16 +17,25 @@ uint64_t max_interburst_symbols()
 }
 uint64_t max_history_duration() { return 2 * (max_interburst_symbols() + 8 * (uint64_t)kMaxMessageLength); }
 
-bool is_allowed_byte(uint8_t c)
-{
-    switch (c) {
-    case '-': case '/': case '?': case '(': case ')': case '[': case ']': case '.': case '_': case ',':
-    case '+': case ' ':
-        return true;
-    default:
-        return (c >= '0' && c <= '9') || (c >= 'A' && c <= 'Z') || (c >= 'a' && c <= 'z');
+// (a table: combine() asks for every byte of every burst of every channel)
+struct AllowedTable {
+    bool ok[256];
+    constexpr AllowedTable() : ok()
+    {
+        for (int c = 0; c < 256; ++c) {
+            bool a = (c >= '0' && c <= '9') || (c >= 'A' && c <= 'Z') || (c >= 'a' && c <= 'z');
+            switch (c) {
+            case '-': case '/': case '?': case '(': case ')': case '[': case ']': case '.': case '_': case ',':
+            case '+': case ' ':
+                a = true; break;
+            default: break;
+            }
+            ok[c] = a;
+        }
     }
-}
+};
+static constexpr AllowedTable kAllowed{};
+bool is_allowed_byte(uint8_t c) { return kAllowed.ok[c]; }
 
 void bit_vote_detect(uint8_t b0, uint8_t b1, uint8_t *out, uint32_t *errs)
 {
@@ -106,19 +115,34 @@ bool combine(const BurstBuf *bursts, uint32_t nbursts, MessageResult *res)
     // estimate_message rx/combiner.rs:154-203
     uint8_t msg[kMaxMessageLength], cnt[kMaxMessageLength], errs[kMaxMessageLength];
     const size_t nb = std::min<size_t>(nbursts, 3);
-    size_t pos[3] = {0, 0, 0};
     size_t n = 0;
-    while (n < kMaxMessageLength) {
+    // Every burst is read from its first byte on, so at position n exactly the bursts longer than n take part: first the
+    // stretch all of them cover (the usual case: three bursts of one length), then the general walk.
+    size_t common = kMaxMessageLength;
+    for (size_t i = 0; i < nb; ++i) common = std::min<size_t>(common, bursts[i].len);
+    bool stopped = false;
+    if (nb == 3) {
+        const uint8_t *a = bursts[0].data, *b = bursts[1].data, *c = bursts[2].data;
+        for (; n < common; ++n) {
+            const uint8_t x = a[n], y = b[n], z = c[n];
+            const uint8_t msb = (uint8_t)((x | y | z) >> 7);
+            uint8_t est; uint32_t be;
+            bit_vote_correct(x & 0x7f, y & 0x7f, z & 0x7f, &est, &be);
+            if (!kAllowed.ok[est]) { stopped = true; break; }
+            msg[n] = est; cnt[n] = 3; errs[n] = (uint8_t)(be + msb);
+        }
+    }
+    while (!stopped && n < kMaxMessageLength) {
         uint8_t cur[3]; uint32_t k = 0; bool msb = false;
         for (size_t i = 0; i < nb; ++i)
-            if (pos[i] < bursts[i].len) cur[k++] = bursts[i].data[pos[i]++];
+            if (n < bursts[i].len) cur[k++] = bursts[i].data[n];
         for (uint32_t i = 0; i < k; ++i) { msb |= (cur[i] & 0x80) != 0; cur[i] &= 0x7f; }
         if (k == 0) break;
         uint8_t est; uint32_t be = 0;
         if (k == 1) est = cur[0];
         else if (k == 2) bit_vote_detect(cur[0], cur[1], &est, &be);
         else bit_vote_correct(cur[0], cur[1], cur[2], &est, &be);
-        if (!is_allowed_byte(est)) break;
+        if (!kAllowed.ok[est]) break;
         msg[n] = est; cnt[n] = (uint8_t)k; errs[n] = (uint8_t)(be + (msb ? 1u : 0u));
         ++n;
     }
@@ -146,10 +170,10 @@ void Assembler::prune_history(uint64_t now)
     // rx/assembler.rs:362-368: retain unexpired entries, then keep at most the two newest
     uint32_t w = 0;
     for (uint32_t i = 0; i < nhist_; ++i)
-        if (!(history_[i].deadline <= now)) { if (w != i) history_[w] = history_[i]; ++w; }
+        if (!(hist_deadline_[i] <= now)) { if (w != i) { history_[w] = history_[i]; hist_deadline_[w] = hist_deadline_[i]; } ++w; }
     nhist_ = w;
     while (nhist_ > 2) {
-        for (uint32_t i = 1; i < nhist_; ++i) history_[i - 1] = history_[i];
+        for (uint32_t i = 1; i < nhist_; ++i) { history_[i - 1] = history_[i]; hist_deadline_[i - 1] = hist_deadline_[i]; }
         --nhist_;
     }
 }
@@ -172,7 +196,7 @@ void Assembler::accept(const MessageResult &m, uint64_t now)
 uint32_t Assembler::idle(uint64_t now, MessageResult *msg)
 {
     // rx/assembler.rs:205-234
-    if (nhist_ > 2 || (nhist_ && history_[0].deadline <= now)) prune_history(now);   // deadlines are pushed in increasing order
+    if (nhist_ > 2 || (nhist_ && hist_deadline_[0] <= now)) prune_history(now);   // deadlines are pushed in increasing order
     if (pending_ && pend_deadline_ <= now) {             // PendingResult::poll :336-345
         *msg = pend_;
         pending_ = false;
@@ -189,10 +213,10 @@ uint32_t Assembler::assemble(const uint8_t *burst, size_t n, uint64_t now, Messa
     if (n == 0) return idle(now, msg);
     prune_history(now);
     if (have_prev_ && prev_deadline_ <= now) have_prev_ = false;   // prune_previous :371-376
+    hist_deadline_[nhist_] = now + max_history_duration();
     BurstBuf &t = history_[nhist_++];                               // at most 2 survive the prune
     t.len = (uint32_t)std::min(n, kMaxMessageLength);
     std::memcpy(t.data, burst, t.len);
-    t.deadline = now + max_history_duration();
     MessageResult res;
     if (combine(history_, nhist_, &res)) {
         // deduplicate :245-265: messages are duplicates when string-equal

@@ -59,13 +59,18 @@ struct MessageResult {
     }
 };
 
-// one burst as the assembler keeps it (truncated to MAX_MESSAGE_LENGTH, rx/assembler.rs:163-169)
-struct BurstBuf { uint32_t len = 0; uint64_t deadline = 0; uint8_t data[kMaxMessageLength]; };
+// one burst as the assembler keeps it (truncated to MAX_MESSAGE_LENGTH, rx/assembler.rs:163-169); its deadline lives beside
+// the assembler's other scalars
+struct BurstBuf { uint32_t len = 0; uint8_t data[kMaxMessageLength]; };
 
 // combine() rx/combiner.rs:32-80 over up to three bursts; false = None
 bool combine(const BurstBuf *bursts, uint32_t n, MessageResult *out);
 
-// Assembler rx/assembler.rs:108-266
+// Assembler rx/assembler.rs:108-266.
+// Layout: a batch keeps one of these per channel (1.8 KB each, 60 MB for a 32 768-channel shard) and walks them once per
+// launch, so every cache line a poll touches is a DRAM miss.  What an idle poll reads -- the counts, flags and deadlines --
+// therefore sits together at the front (one line with the Transport's own scalars); the burst bytes and message texts
+// behind it are only touched when a burst arrives or a message is due.
 class Assembler {
 public:
     void reset();
@@ -76,9 +81,12 @@ public:
 private:
     void prune_history(uint64_t now);
     void accept(const MessageResult &m, uint64_t now);
-    BurstBuf history_[3]; uint32_t nhist_ = 0;     // VecDeque<TimedData<Burst>>, oldest first
-    bool pending_ = false; MessageResult pend_; uint64_t pend_deadline_ = 0;
-    bool have_prev_ = false; MessageResult prev_; uint64_t prev_deadline_ = 0;
+    uint32_t nhist_ = 0;                           // VecDeque<TimedData<Burst>>, oldest first: history_[i] until hist_deadline_[i]
+    bool pending_ = false, have_prev_ = false;
+    uint64_t hist_deadline_[3] = {0, 0, 0};
+    uint64_t pend_deadline_ = 0, prev_deadline_ = 0;
+    BurstBuf history_[3];
+    MessageResult pend_, prev_;
 };
 
 // per-channel transport state of SameReceiver (receiver.rs:79, 85, 89, 291-333)
@@ -95,14 +103,14 @@ public:
     void set_input_sample_counter_bias(int64_t) {}
 
 private:
-    Assembler asm_;
     uint32_t state_kind_ = SAME_TRANSPORT_IDLE;
-    MessageResult state_msg_;
     bool have_force_eom_ = false;
-    uint64_t force_eom_at_ = 0;
     bool dirty_ = false;
     bool have_polled_ = false;
+    uint64_t force_eom_at_ = 0;
     uint64_t last_polled_symbol_ = 0;
+    Assembler asm_;
+    MessageResult state_msg_;
 };
 
 
