@@ -215,6 +215,7 @@ struct same_batch {
         hipEvent_t ev_start = nullptr, ev_stop = nullptr, ev_done = nullptr, ev_planned = nullptr;
         hipEvent_t ev_k0 = nullptr, ev_k1 = nullptr;         // around the demodulation kernel alone (time-parallel launches bracket more with ev_start / ev_stop)
         bool have_k = false;
+        bool timed = false;               // ev_start / ev_stop were recorded for this launch (latched when it was made)
         // pinned landing buffers of the read-back, grown on demand.  A copy into pageable memory
         // is staged by the runtime (blit kernel + host memcpy per chunk) and, queued beside the
         // next launch, holds that launch up for as long as the host is busy.
@@ -783,7 +784,7 @@ int harvest_slot(same_batch *rx, same_batch::Slot &sl)
     // may still be running on the compute stream
     HIP_TRY(hipEventSynchronize(sl.ev_done));
     sl.in_flight = false;
-    if (rx->timing) {
+    if (sl.timed) {
         HIP_TRY(hipEventElapsedTime(&rx->last_ms, sl.ev_start, sl.ev_stop));
         rx->last_demod_ms = rx->last_ms;
         if (sl.have_k) HIP_TRY(hipEventElapsedTime(&rx->last_demod_ms, sl.ev_k0, sl.ev_k1));
@@ -1051,7 +1052,7 @@ int process_time_major(same_batch *rx, const SampleT *d_x, size_t n_samples, hip
             pc.handover = sl.d_handover;
             same_batch::TimePar &tp = rx->tp;
             HIP_TRY(same::launch_counters(sl.d_counters, sl.h_counters_dev, 0, stream));
-            if (rx->timing) HIP_TRY(hipEventRecord(sl.ev_start, stream));
+            sl.timed = rx->timing; if (sl.timed) HIP_TRY(hipEventRecord(sl.ev_start, stream));
             // fresh receivers in every column, the channels' own state into chunk 0's columns
             HIP_TRY(same::launch_init_state(tp.Pv, tp.Sv, 0, stream, C));
             HIP_TRY(same::launch_copy_state_columns(tp.d_desc_in, tp.n_desc, C, columns, nullptr, C, stream));
@@ -1092,7 +1093,7 @@ int process_time_major(same_batch *rx, const SampleT *d_x, size_t n_samples, hip
         rc = ensure_output(rx, sl, n, O);
         if (rc) return rc;
         HIP_TRY(same::launch_counters(sl.d_counters, sl.h_counters_dev, 0, stream));
-        if (rx->timing) HIP_TRY(hipEventRecord(sl.ev_start, stream));
+        sl.timed = rx->timing; if (sl.timed) HIP_TRY(hipEventRecord(sl.ev_start, stream));
         const SampleT *xp = d_x + done * rx->P.n_channels;
         hipError_t e = hipSuccess;
         // whole blocks (16 or 18 samples) go to the latency-optimised kernel when the
@@ -1142,7 +1143,7 @@ int process_time_major(same_batch *rx, const SampleT *d_x, size_t n_samples, hip
             if (e != hipSuccess) return fail(SAME_EHIP, "demod kernel launch failed: %s", hipGetErrorString(e));
         }
         }
-        if (rx->timing) HIP_TRY(hipEventRecord(sl.ev_stop, stream));
+        if (sl.timed) HIP_TRY(hipEventRecord(sl.ev_stop, stream));
         HIP_TRY(same::launch_event_sort(sl.d_events, sl.d_counters, sl.event_cap, sl.sort_bins, sl.d_sort, sl.d_sort + sl.sort_bins,
                                         sl.d_sorted, stream));
         HIP_TRY(same::launch_counters(sl.d_counters, sl.h_counters_dev, 1, stream));
@@ -1243,7 +1244,7 @@ int process_channel_major_native(same_batch *rx, const float *d_x, size_t n, hip
     // every CU pays (round 2).
     const int sort_mode = tp.sort_mode >= 0 ? (tp.sort_mode ? 1 : 0) : (columns > 32768u ? 1 : 0);
     HIP_TRY(same::launch_counters(sl.d_counters, sl.h_counters_dev, 0, stream));
-    if (rx->timing) HIP_TRY(hipEventRecord(sl.ev_start, stream));
+    sl.timed = rx->timing; if (sl.timed) HIP_TRY(hipEventRecord(sl.ev_start, stream));
     // (sorted: the workgroups once more, longest first whatever their group -- those that wait for a free CU are then the short ones)
     const bool lpt = sort_mode != 0;
     // On the library's own stream the planning kernels go to the plan stream: they need the input (ordered by
@@ -1282,13 +1283,13 @@ int process_channel_major_native(same_batch *rx, const float *d_x, size_t n, hip
         }
         pc.hist_scratch = tp.d_hist;
     }
-    sl.have_k = rx->timing;
-    if (rx->timing) HIP_TRY(hipEventRecord(sl.ev_k0, stream));
+    sl.have_k = sl.timed;
+    if (sl.timed) HIP_TRY(hipEventRecord(sl.ev_k0, stream));
     hipError_t e = wave ? same::launch_demod_relaxed(tp.Pv, tp.Sv, O, rx->d_taps, d_x, (uint32_t)(n / fb), rx->counter, stream, pc)
                         : (tp.kernel == same_batch::TimePar::kPipeRelaxed ? launch_fm(tp.Pv, tp.Sv, O, rx->d_taps, d_x, (uint32_t)(n / fb), rx->counter, stream, pc)
                                                                           : same::launch_demod_pipe(tp.Pv, tp.Sv, O, rx->d_taps, d_x, (uint32_t)(n / fb), rx->counter, stream, pc, false));
     if (e != hipSuccess) return fail(SAME_EHIP, "time-parallel demod kernel launch failed: %s", hipGetErrorString(e));
-    if (rx->timing) HIP_TRY(hipEventRecord(sl.ev_k1, stream));
+    if (sl.timed) HIP_TRY(hipEventRecord(sl.ev_k1, stream));
     // The channels' state afterwards: that of the chunk the hand-over chain ends in, as the host's stitch follows it --
     // the last chunk as a rule (its columns end with the input); an earlier one where a burst ran on to the end of the
     // call without a hand-over (a forced cut on a channel that is never quiet: its events are the ones that are kept).
@@ -1309,7 +1310,7 @@ int process_channel_major_native(same_batch *rx, const float *d_x, size_t n, hip
     sl.chunked = true; sl.per_channel = true;
     sl.geom = geom;
     sl.end_blocks = rx->counter + n;
-    if (rx->timing) HIP_TRY(hipEventRecord(sl.ev_stop, stream));
+    if (sl.timed) HIP_TRY(hipEventRecord(sl.ev_stop, stream));
     HIP_TRY(same::launch_event_sort(sl.d_events, sl.d_counters, sl.event_cap, sl.sort_bins, sl.d_sort, sl.d_sort + sl.sort_bins,
                                     sl.d_sorted, stream));
     HIP_TRY(same::launch_counters(sl.d_counters, sl.h_counters_dev, 1, stream));

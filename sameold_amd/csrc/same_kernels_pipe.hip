@@ -1413,4 +1413,54 @@ uint32_t pipe_workgroup_channels(const Params &P) { return pipe_lanes(P); }
 
 }  // namespace same
 
+// ---- the software-pipelined matched filters against the chunk-at-a-time loop ----------------------------------------
+// demod_pair_relaxed_42 / demod_pair_relaxed_chunks keep up to 21 LDS loads in flight and name the part that has landed
+// with s_waitcnt lgkmcnt(9 / 12): that relies on LDS returning in order and on the counter (4 bits) holding issue back
+// rather than wrapping.  They add the same products in the same order as demod_pair_relaxed, whose waits are all
+// lgkmcnt(0): the three must agree bit for bit on any window (tests/test_gpu_parity.py).
+namespace same {
+constexpr int kFormsRing = 160;
+template <int NCH>
+__global__ __launch_bounds__(kWave) void filter_forms_kernel(const float4 *__restrict__ taps, const float *__restrict__ win, float *__restrict__ out)
+{
+    constexpr int NTP = NCH * kRelaxChunk, RING = kFormsRing;
+    constexpr uint32_t tap_floats = (uint32_t)((NTP * 4 + 63) / 64 * 64);
+    extern __shared__ float lds[];
+    const uint32_t lane = threadIdx.x;
+    float4 *tlds = reinterpret_cast<float4 *>(lds);
+    for (uint32_t i = lane; i < (uint32_t)NTP; i += kWave) tlds[i] = taps[i];
+    float *wcol = lds + tap_floats + lane;
+    for (int s = 0; s < RING; ++s) { const float v = win[s * (int)kWave + (int)lane]; wcol[s * (int)kWave] = v; wcol[(s + RING) * (int)kWave] = v; }
+    __syncthreads();
+    for (uint32_t newest = 0; newest < (uint32_t)RING; ++newest) {
+        float am, as, bm, bs, cm, cs;
+        demod_pair_relaxed<NTP, RING, false>(lds_addr(lds), lds_addr(wcol), newest, &am, &as);
+        demod_pair_relaxed_chunks<NCH, RING>(lds_addr(lds), lds_addr(wcol), newest, &bm, &bs);
+        if constexpr (NCH == 3) demod_pair_relaxed_42<RING>(lds_addr(lds), lds_addr(wcol), newest, &cm, &cs);
+        else { cm = bm; cs = bs; }
+        float *o = out + ((size_t)newest * kWave + lane) * 6u;
+        o[0] = am; o[1] = as; o[2] = bm; o[3] = bs; o[4] = cm; o[5] = cs;
+    }
+}
+}  // namespace same
+
+// taps: n_chunks * 14 float4 (mark re/im, space re/im), win: [160][64] f32, out: [160][64][6] f32 -- all device pointers
+extern "C" int same_debug_filter_forms(int n_chunks, const void *d_taps, const float *d_win, float *d_out)
+{
+    using namespace same;
+    const size_t lds = ((size_t)((n_chunks * kRelaxChunk * 4 + 63) / 64 * 64) + (size_t)2 * kFormsRing * kWave) * sizeof(float);
+    const float4 *t = static_cast<const float4 *>(d_taps);
+    auto go = [&](auto kernel) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return 1;
+        hipLaunchKernelGGL(kernel, dim3(1), dim3(kWave), lds, nullptr, t, d_win, d_out);
+        return hipDeviceSynchronize() == hipSuccess && hipGetLastError() == hipSuccess ? 0 : 1;
+    };
+    switch (n_chunks) {
+    case 3: return go(filter_forms_kernel<3>);
+    case 6: return go(filter_forms_kernel<6>);
+    case 7: return go(filter_forms_kernel<7>);
+    default: return 2;
+    }
+}
+
 PIPE_PROFILE_EXPORTS()

@@ -658,7 +658,7 @@ __global__ __launch_bounds__(2 * kWave, 2) void demod_duo_kernel(Params P, State
                 const uint32_t g = (uint32_t)(counter1 - (uint64_t)m) & (G - 1u);
                 float *row = S.win_ring + (size_t)g * C;
                 const uint32_t j = wnext >= m ? wnext - m : wnext + (uint32_t)RING - m;
-                row[c] = wcol[j * LP];
+                row[c] = m <= (uint32_t)RING ? wcol[j * LP] : 0.0f;       // (a state ring longer than this kernel's: nothing older is kept)
             }
             const uint32_t dpos = (uint32_t)(counter1 % (uint64_t)DCL);
 #pragma unroll

@@ -932,3 +932,25 @@ def test_awgn_batch_tally_equals_the_oracles(sa, ob):
     assert res["events_equal"] and res["tally_rows_equal"]
     assert res["rows_gpu"] == res["rows_oracle"]
     assert sum(r["trials"] for r in res["rows_gpu"]) == 8192
+
+
+@pytest.mark.parametrize("n_chunks", [3, 6, 7])
+def test_pipelined_matched_filters_equal_the_chunk_loop_bit_for_bit(sa, n_chunks):
+    """The software-pipelined relaxed matched filters (up to 21 LDS loads in flight, waits on a partial count) add the
+    same products in the same order as the chunk-at-a-time loop, whose waits are all lgkmcnt(0): equal bit for bit on
+    random windows at every ring position, 42 / 84 / 98 taps."""
+    import torch
+    L = sa.load_library()
+    L.same_debug_filter_forms.restype = C.c_int
+    L.same_debug_filter_forms.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    g = torch.Generator(device="cpu").manual_seed(900 + n_chunks)
+    for scale in (1.0, 1.0e-3, 37.0):
+        taps = (torch.rand(n_chunks * 14, 4, generator=g) * 2 - 1).mul(2.0 / (n_chunks * 14)).cuda().contiguous()
+        win = ((torch.rand(160, 64, generator=g) * 2 - 1) * scale).cuda().contiguous()
+        out = torch.full((160, 64, 6), float("nan"), device="cuda")
+        assert L.same_debug_filter_forms(n_chunks, taps.data_ptr(), win.data_ptr(), out.data_ptr()) == 0
+        o = out.cpu().numpy().view(np.uint32)
+        assert np.isfinite(out.cpu().numpy()).all()
+        assert np.array_equal(o[..., 0:2], o[..., 2:4]), "demod_pair_relaxed_chunks differs from demod_pair_relaxed"
+        assert np.array_equal(o[..., 0:2], o[..., 4:6]), "demod_pair_relaxed_42 differs from demod_pair_relaxed"
+        assert float(out[..., 0].abs().max()) > 0.0
