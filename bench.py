@@ -497,7 +497,7 @@ def main():
     def pmc_traffic(kind):
         if args.traffic is not None:
             return args.traffic
-        for name in ("r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
+        for name in ("r04_traffic.json", "r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
             try:
                 with open(os.path.join(ROOT, "profiles", name)) as f:
                     tj = json.load(f)

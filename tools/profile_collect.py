@@ -44,7 +44,7 @@ def classify(name, wgs, state, n1):
         return None
     nt, share, lanes, fm = int(m.group(1)), m.group(2) in ("true", "1"), int(m.group(3)), m.group(4) in ("true", "1")
     if nt == 92:
-        return "configs2_48k"
+        return "configs2_48k_relaxed" if fm else "configs2_48k"
     if lanes == 16:
         return "strict"
     cols = wgs * 64
@@ -125,7 +125,8 @@ for d, name in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
     for v, vals in seen.items():
         per[v][name] = (sum(vals) / len(vals), len(vals))
 sizes = {"strict": (C, T), "time_parallel": (C, T), "time_parallel_time_major": (C, T), "time_parallel_strict_chunks": (C, T), "relaxed": (C, T),
-         "scaled": (32768, 44100), "scaled_relaxed": (32768, 44100), "configs2_48k": (16384, 96000), "scaled_big_relaxed": (131072, 44100)}
+         "scaled": (32768, 44100), "scaled_relaxed": (32768, 44100), "configs2_48k": (16384, 96000), "configs2_48k_relaxed": (16384, 96000),
+         "scaled_big_relaxed": (131072, 44100)}
 for v, d in per.items():
     if "FETCH_SIZE" not in d or "WRITE_SIZE" not in d or v not in sizes:
         continue
@@ -135,7 +136,7 @@ for v, d in per.items():
     corr = 1.0 if v == "strict" else 2.0
     cc, tt = sizes[v]
     hbm = int(round(d["FETCH_SIZE"][0] * 1024 * corr + d["WRITE_SIZE"][0] * 1024))
-    traffic.append({"mode": v if v in CONFIGS1 else ("relaxed" if v == "scaled_relaxed" else "strict"), "block": v, "workload": f"{cc} ch x {tt} samples",
+    traffic.append({"mode": v if v in CONFIGS1 else ("relaxed" if v.endswith("_relaxed") else "strict"), "block": v, "workload": f"{cc} ch x {tt} samples",
                     "hbm_bytes_per_launch": hbm, "algorithmic_bytes_per_launch": 4 * cc * tt, "ratio": round(hbm / (4.0 * cc * tt), 4),
                     "fetch_size_kb": round(d["FETCH_SIZE"][0], 1), "write_size_kb": round(d["WRITE_SIZE"][0], 1), "fetch_correction": corr,
                     "launches": d["FETCH_SIZE"][1],
