@@ -89,7 +89,8 @@ constexpr uint32_t kP3FbWords = kWave + 32u;              // per parity: one wor
 constexpr uint32_t kP3IoWords = 3u * kWave;               // per parity: symbol word, burst-pool slot, burst length
 constexpr uint32_t kP3MailWords = 2u * kP3SymWords + 2u * kP3FbWords + 2u * kP3IoWords +
                                   2u * kWave +             // + the final TED-phase and wake-up flag bits
-                                  4u * kWave;              // + SPLIT: instant positions [2][64], space and mark magnitudes [64] each
+                                  4u * kWave +             // + SPLIT: instant positions [2][64], space and mark magnitudes [64] each
+                                  kIoRingWords;            // + stage 4's deadline ring and its count (IoCtxLds)
 // (the log-chunk words and SPLIT's sequence word live in the padding of the first feedback box)
 
 // One of the two matched filters (WHICH 0: mark, 1: space) over the mirrored window: the half of
@@ -748,6 +749,7 @@ __global__ __launch_bounds__((pipe_dcw<NT, LANES, SPLIT>() ? 5 : 4) * kWave, SHA
     lds_u32 *posbox = againbox + kWave;                        // SPLIT: [2][64] sample index of block b's instant
     lds_u32 *spacebox = posbox + 2u * kWave;                   // SPLIT: [64] space-filter magnitude
     lds_u32 *markbox = spacebox + kWave;                       // PACKED: [64] mark-filter magnitude
+    lds_u32 *tkbox = markbox + kWave;                          // [kTickRing][64] u64 deadlines, then [64] their count (stage 4's own)
     float *hcol = lds + kPipeTapFloats + kP3MailWords + lane;
     float *wring = lds + kPipeTapFloats + kP3MailWords + (kSquelchHist - kB) * LP;   // logical slot 0
     float *wcol = wring + lane;
@@ -1176,10 +1178,12 @@ __global__ __launch_bounds__((pipe_dcw<NT, LANES, SPLIT>() ? 5 : 4) * kWave, SHA
         Lane L;
         if (evt_lane) lane_load(L, S, c);      // uses sq_symbols, tk_next, tk_last, wake_*, F_TICK_AGAIN
         P3_HWID(3);
-        IoCtx X;
+        IoCtxLds X;
         X.chunk = chunkbox;
         chunkbox[0] = 0u; chunkbox[1] = kEvChunk;       // nothing reserved yet
         X.pending_slot = 0xffffffffu;
+        X.tk = tkbox + lane;
+        if (evt_lane) X.ring_load(P, S, c);
         uint32_t wpos = 0;                     // SPLIT: ring slot of block s-1's first sample
         if (SPLIT && lane == 0u) seqbox[0] = 0u;
         uint32_t stop_at = 0xffffffffu;
@@ -1250,7 +1254,7 @@ __global__ __launch_bounds__((pipe_dcw<NT, LANES, SPLIT>() ? 5 : 4) * kWave, SHA
         if (left) return;
         if (evt_lane) againbox[lane] = L.flags & F_TICK_AGAIN;
         lds_barrier();                                                 // stage 3 merges the flag bits
-        if (evt_lane) { S.tk_next[c] = L.tk_next; S.tk_last[c] = L.tk_last; S.wake_fired[c] = L.wake_fired; }
+        if (evt_lane) { S.tk_next[c] = L.tk_next; S.tk_last[c] = L.tk_last; S.wake_fired[c] = L.wake_fired; X.ring_store(P, S, c); }
     }
 }
 

@@ -75,7 +75,7 @@ template <int NT> struct SymLayout {
     static constexpr uint32_t pos_words = 2u * kWave;             // per parity: ring slots of the symbol's two instants (-1: none)
     static constexpr uint32_t mail_words = 2u * sym_words + 2u * fb_words + 2u * io_words + 2u * kWave +   // + final TED phase, wake-up flag
                                            2u * pos_words + kWave +                                       // + the first instant's soft sample, from S
-                                           (2u * (uint32_t)kTickRing + 1u) * kWave;                       // + T's deadline ring and its count
+                                           kIoRingWords;                                                  // + T's deadline ring and its count
     static constexpr uint32_t yring_floats = 2u * (uint32_t)B * kWave;
     static constexpr size_t lds_bytes = ((size_t)tap_floats + mail_words + yring_floats + (size_t)(RING + MIR) * kWave) * sizeof(float);
     static_assert(NT == 42 && NT % kRelaxChunk == 0, "three filter chunks of 14 taps");
@@ -324,41 +324,6 @@ struct SymDc {
             (S.dc_ff_ring + (size_t)s0 * C)[c] = xp[h].x; (S.dc_ff_ring + (size_t)s1 * C)[c] = xp[h].y;
             (S.dc_fb_ring + (size_t)s0 * C)[c] = mp[h].x; (S.dc_fb_ring + (size_t)s1 * C)[c] = mp[h].y;
         });
-    }
-};
-
-// T's context for the link events and the transport wake-ups: IoCtx with the deadline ring (kTickRing instants and their
-// count per channel) in LDS for the launch.  In the HBM state arrays every burst and every expired deadline cost T a chain
-// of dependent global round trips -- count, oldest deadline, the ring moved down -- in the wavefront that also issues the
-// input prefetch, behind which they queue (one in eight steps of a 64-channel workgroup has such a lane: 8 % of a
-// launch with the transport layer on).
-struct SymIoCtx : IoCtx {
-    lds_u32 *tk;               // this lane's column: deadline i in words [2 i][lane], [2 i + 1][lane]; the count behind them
-    __device__ __forceinline__ uint32_t tk_count(const State &, uint32_t) const { return tk[2 * kTickRing * kWave]; }
-    __device__ __forceinline__ void tk_set_count(const State &, uint32_t, uint32_t n) const { tk[2 * kTickRing * kWave] = n; }
-    __device__ __forceinline__ uint64_t tk_at(const State &, uint32_t, uint32_t, uint32_t i) const
-    {
-        return (uint64_t)tk[2u * i * kWave] | ((uint64_t)tk[(2u * i + 1u) * kWave] << 32);
-    }
-    __device__ __forceinline__ void tk_set(const State &, uint32_t, uint32_t, uint32_t i, uint64_t v) const
-    {
-        tk[2u * i * kWave] = (uint32_t)v; tk[(2u * i + 1u) * kWave] = (uint32_t)(v >> 32);
-    }
-    __device__ __forceinline__ void ring_load(const Params &P, const State &S, uint32_t c)
-    {
-        if (!P.ticks) return;
-        const TickRingGlobal G;
-#pragma unroll
-        for (uint32_t i = 0; i < (uint32_t)kTickRing; ++i) tk_set(S, P.n_channels, c, i, G.tk_at(S, P.n_channels, c, i));
-        tk_set_count(S, c, G.tk_count(S, c));
-    }
-    __device__ __forceinline__ void ring_store(const Params &P, const State &S, uint32_t c) const
-    {
-        if (!P.ticks) return;
-        const TickRingGlobal G;
-#pragma unroll
-        for (uint32_t i = 0; i < (uint32_t)kTickRing; ++i) G.tk_set(S, P.n_channels, c, i, tk_at(S, P.n_channels, c, i));
-        G.tk_set_count(S, c, tk_count(S, c));
     }
 };
 
@@ -632,7 +597,7 @@ __global__ __launch_bounds__(4 * kWave, 2) void demod_sym_kernel(Params P, State
         D.load(S, x, c, C, cin, Cin, counter0, n_blocks);
         Lane L;
         lane_load(L, S, c);      // the event half uses sq_symbols, tk_next, tk_last, wake_*, F_TICK_AGAIN
-        SymIoCtx X;
+        IoCtxLds X;
         X.chunk = chunkbox;
         chunkbox[0] = 0u; chunkbox[1] = kEvChunk;       // nothing reserved yet
         X.pending_slot = 0xffffffffu;

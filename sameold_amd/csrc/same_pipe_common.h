@@ -77,4 +77,40 @@ struct IoCtx : TickRingGlobal {
     }
 };
 
+// The event wavefront's context with the deadline ring (kTickRing instants and their
+// count per channel) in LDS for the launch.  In the HBM state arrays every burst and every expired deadline cost that wavefront a chain
+// of dependent global round trips -- count, oldest deadline, the ring moved down -- and it is the wavefront that also issues
+// the input prefetch (same_kernels_sym.hip) or runs the matched filters stage 2 waits for (same_kernels_pipe.hip).  One in
+// eight steps of a 64-channel workgroup has such a lane: 8 % of a 22.05 kHz launch with the transport layer on, 12 % at 48 kHz.
+constexpr uint32_t kIoRingWords = (2u * (uint32_t)kTickRing + 1u) * kWave;
+struct IoCtxLds : IoCtx {
+    lds_u32 *tk;               // this lane's column: deadline i in words [2 i][lane], [2 i + 1][lane]; the count behind them
+    __device__ __forceinline__ uint32_t tk_count(const State &, uint32_t) const { return tk[2 * kTickRing * kWave]; }
+    __device__ __forceinline__ void tk_set_count(const State &, uint32_t, uint32_t n) const { tk[2 * kTickRing * kWave] = n; }
+    __device__ __forceinline__ uint64_t tk_at(const State &, uint32_t, uint32_t, uint32_t i) const
+    {
+        return (uint64_t)tk[2u * i * kWave] | ((uint64_t)tk[(2u * i + 1u) * kWave] << 32);
+    }
+    __device__ __forceinline__ void tk_set(const State &, uint32_t, uint32_t, uint32_t i, uint64_t v) const
+    {
+        tk[2u * i * kWave] = (uint32_t)v; tk[(2u * i + 1u) * kWave] = (uint32_t)(v >> 32);
+    }
+    __device__ __forceinline__ void ring_load(const Params &P, const State &S, uint32_t c)
+    {
+        if (!P.ticks) return;
+        const TickRingGlobal G;
+#pragma unroll
+        for (uint32_t i = 0; i < (uint32_t)kTickRing; ++i) tk_set(S, P.n_channels, c, i, G.tk_at(S, P.n_channels, c, i));
+        tk_set_count(S, c, G.tk_count(S, c));
+    }
+    __device__ __forceinline__ void ring_store(const Params &P, const State &S, uint32_t c) const
+    {
+        if (!P.ticks) return;
+        const TickRingGlobal G;
+#pragma unroll
+        for (uint32_t i = 0; i < (uint32_t)kTickRing; ++i) G.tk_set(S, P.n_channels, c, i, tk_at(S, P.n_channels, c, i));
+        G.tk_set_count(S, c, tk_count(S, c));
+    }
+};
+
 }  // namespace same

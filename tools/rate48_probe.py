@@ -8,8 +8,8 @@ import sameold_amd as sa
 for rate in (48000, 44100):
     C, T = 16384, rate * 2
     x = sa.synth_afsk(C, T, rate, seed=778); torch.cuda.synchronize()
-    for relaxed in (False, True):
-        rx = sa.SameReceiverBuilder(rate).build_batch(C, relaxed=relaxed, link_only=True); rx.set_kernel_timing(True)
+    for relaxed, link_only in ((False, True), (True, True), (False, False), (True, False)):
+        rx = sa.SameReceiverBuilder(rate).build_batch(C, relaxed=relaxed, link_only=link_only); rx.set_kernel_timing(True)
         ms = []
         for k in range(11):
             rx.process_tensor(x)
@@ -17,4 +17,4 @@ for rate in (48000, 44100):
             rx.drop_events(rx.pending_events())
         rx.sync(); ms.append(rx.last_kernel_ms())
         best = min(ms[2:])
-        print(f"{rate} Hz {C} ch x {T}: relaxed={relaxed} [{rx.kernel_name()}] kernel ms min {best:.3f} mean {np.mean(ms[2:]):.3f} = {4*C*T/best/1e9/8*100:.2f} % of 8 TB/s", flush=True)
+        print(f"{rate} Hz {C} ch x {T}: relaxed={relaxed} link_only={link_only} [{rx.kernel_name()}] kernel ms min {best:.3f} mean {np.mean(ms[2:]):.3f} = {4*C*T/best/1e9/8*100:.2f} % of 8 TB/s", flush=True)
