@@ -146,15 +146,16 @@ enum {
     SAME_BATCH_GENERIC_KERNEL = 1u << 2,/* always use the any-configuration kernel (tests) */
     /* Time-parallel ("fast") mode.  A long call on few channels is a few serial instruction streams on a
      * machine with a thousand SIMDs; with this flag a call is cut into K time chunks per channel that
-     * run side by side (K * n_channels <= 32 768 state columns through the wavefront pipeline).  Chunk 0
+     * run side by side (K * n_channels state columns: 32 768 fill the machine, the channel-major path takes 49 152).  Chunk 0
      * continues from the channel's state; every other chunk starts from a freshly built receiver a
      * warm-up (64 symbols by default) before the samples it owns, and a chunk keeps running past its
      * end until its channel has been seen idle (LinkState::NoCarrier), where the next chunk takes over.
-     * What is approximated is the state a chunk starts from and -- at 22.05 kHz, where the relaxed kernels exist --
-     * the arithmetic inside the chunks, which is that of SAME_BATCH_RELAXED below (SAME_RELAXED=0 in the
+     * What is approximated is the state a chunk starts from and -- where relaxed kernels exist: whole groups of 64
+     * channels at 22.05 / 44.1 / 48 kHz -- the arithmetic inside the chunks, which is that of SAME_BATCH_RELAXED below (SAME_RELAXED=0 in the
      * environment keeps the chunks on the strict kernels).  The mode wants a CHANNEL-MAJOR buffer: there every
      * channel is cut where it is quiet; a time-major buffer is cut at the same rows for all channels and its
-     * chunks run on through whatever burst straddles a cut (a third slower at configs[1]).
+     * chunks run on through whatever burst straddles a cut (an eighth slower at configs[1] and twice the HBM traffic,
+     * DESIGN.md 6).
      * Contract (tests/test_time_parallel.py): burst bytes, their order and
      * the transport messages equal the reference's; link events are the same sequence with sample
      * counters within SAME_TP_EVENT_TOLERANCE_SYMBOLS symbols (Searching: anywhere inside the preamble);
@@ -164,20 +165,23 @@ enum {
      * not a multiple of 16 run as ordinary strict launches.  Not combinable with
      * SAME_BATCH_TRACE_SYMBOLS. */
     SAME_BATCH_TIME_PARALLEL = 1u << 3,
-    /* Relaxed arithmetic ("fast mode" of the north star; same_kernels_sym.hip up to 65 536 channels and inside
-     * time-parallel chunks, same_kernels_relaxed.hip beyond).  The reference's algorithm and every decision of it, with
-     * the rounding of the floating-point expressions given up -- and, in same_kernels_sym.hip, with what end() undoes
-     * (AGC unlock, loop bandwidth, symsync.reset(): receiver.rs:479-490) taking effect two to three symbols after the
-     * symbol that ended the burst instead of at it; the lock at sync (receiver.rs:431-432) is taken at its sample:
-     * matched filters as fused multiply-adds into four partial sums instead of one newest-first chain
-     * (rx/filter.rs:363-377), |mark| and |space| as an f32 square root instead of hypot (rx/demod.rs:163), the AGC update
-     * as gain * (1 - bw |x|) + bw (rx/agc.rs:72-77), reciprocals for the timing loop's and the equalizer's divisions.
+    /* Relaxed arithmetic ("fast mode" of the north star; same_kernels_sym.hip up to 65 536 channels at 22.05 kHz and
+     * inside time-parallel chunks, same_kernels_relaxed.hip beyond, the FASTMATH build of same_kernels_pipe.hip at
+     * 44.1 / 48 kHz).  The reference's algorithm and every decision of it, with the rounding of the floating-point
+     * expressions given up: matched filters as fused multiply-adds into four partial sums instead of one newest-first
+     * chain (rx/filter.rs:363-377), |mark| and |space| as an f32 square root instead of hypot (rx/demod.rs:163), the AGC
+     * update as gain * (1 - bw |x|) + bw (rx/agc.rs:72-77), reciprocals for the timing loop's and the equalizer's
+     * divisions.  In same_kernels_sym.hip, additionally, what the symbol path feeds back -- the lock at sync (AGC lock,
+     * locked loop bandwidth: receiver.rs:431-432) and what end() undoes (receiver.rs:479-490) -- takes effect from the
+     * next 36-sample block on (AGC; a lock freezes the gain the AGC had at the symbol's sample) and two symbols later
+     * (timing loop) instead of at the sample of the symbol that caused it.
      * The timing trajectory is chaotic in the last bit of those sums, so the contract is the
      * time-parallel mode's, whose chunks run this arithmetic as well (SAME_RELAXED=0 in the environment keeps them
      * strict): transmitted burst bytes and transport messages EQUAL, link events within
      * SAME_TP_EVENT_TOLERANCE_SYMBOLS symbols, soft symbols of an open squelch within 0.05 with equal sign
-     * (tests/test_relaxed.py).  22.05 kHz with the default DC-blocker length, default or disabled equalizer and a
-     * non-negative AGC floor; any other configuration runs strict.  Strict mode (no flag) stays bit-exact. */
+     * (tests/test_relaxed.py, tests/test_sym_kernel.py).  22.05, 44.1 and 48 kHz with the default DC-blocker length,
+     * default or disabled equalizer and a non-negative AGC floor (44.1 / 48 kHz: whole groups of 64 channels, up to
+     * 32 768 of them); any other configuration runs strict.  Strict mode (no flag) stays bit-exact. */
     SAME_BATCH_RELAXED = 1u << 4
 };
 #define SAME_TP_EVENT_TOLERANCE_SYMBOLS 2
