@@ -52,6 +52,12 @@ def ob():
     return binding
 
 
+def wave_kernel_param(monkeypatch):
+    """What the autouse fixture set for this run."""
+    import os
+    return os.environ.get("SAME_RELAXED_KERNEL")
+
+
 def relaxed_events(sa, x, rate, builder=None, calls=None, **kw):
     n_ch = x.shape[1]
     rx = (builder or sa.SameReceiverBuilder(rate)).build_batch(n_ch, relaxed=True, **kw)
@@ -275,3 +281,28 @@ def test_time_parallel_chunks_on_the_relaxed_kernel(sa, monkeypatch, layout):
     # (t_end: a message whose hold time runs out within a few symbols of the end of the input is reported by the mode
     # whose host-side symbol clock runs a few symbols fast and not yet by the other)
     assert_contract(sa, got, ref, rate, n_ch, lambda c: sa.synth_payload(4242, c), what=layout, t_end=2 * n)
+
+
+@pytest.mark.parametrize("n_ch,kernel", [(131072, None), (65536, "duo")])
+def test_relaxed_large_batches_meet_the_contract(sa, ob, monkeypatch, n_ch, kernel):
+    """The regimes beyond the pipelines: 131 072 channels x 2 s on the one-wavefront relaxed kernel (its two-per-SIMD
+    build, what such a batch runs by default and what bench.py's `scaled_big` block prices) and 65 536 channels on the
+    two-wavefront kernel.  Every channel against strict mode; strict mode against the oracle on a 4 096-channel slab."""
+    from helpers.oracle_compare import assert_every_channel_matches_oracle
+    if wave_kernel_param(monkeypatch) != "solo":
+        pytest.skip("one run is enough: the kernel is chosen below")
+    if kernel:
+        monkeypatch.setenv("SAME_RELAXED_KERNEL", kernel)
+    else:
+        monkeypatch.delenv("SAME_RELAXED_KERNEL", raising=False)
+    rate, seed = 22050, 780
+    n = 2 * rate
+    x = sa.synth_afsk(n_ch, n, rate, seed=seed)
+    ref = strict_events(sa, x, rate)
+    rx, got = relaxed_events(sa, x, rate)
+    assert rx.kernel_name() == "demod_relaxed_kernel"
+    assert_contract(sa, got, ref, rate, n_ch, lambda c: sa.synth_payload(seed, c), exact_bursts=True, what=f"{n_ch} channels", t_end=n)
+    slab = slice(n_ch // 2, n_ch // 2 + 4096)
+    sub = ref[(ref["channel"] >= slab.start) & (ref["channel"] < slab.stop)].copy()
+    sub["channel"] -= slab.start
+    assert assert_every_channel_matches_oracle(ob, ob.default_config(rate), x[:, slab].contiguous(), sub) > 4096
