@@ -152,8 +152,8 @@ enum {
      * end until its channel has been seen idle (LinkState::NoCarrier), where the next chunk takes over.
      * What is approximated is the state a chunk starts from and -- where relaxed kernels exist: whole groups of 64
      * channels at 22.05 / 44.1 / 48 kHz -- the arithmetic inside the chunks, which is that of SAME_BATCH_RELAXED below (SAME_RELAXED=0 in the
-     * environment keeps the chunks on the strict kernels).  The mode wants a CHANNEL-MAJOR buffer: there every
-     * channel is cut where it is quiet; a time-major buffer is cut at the same rows for all channels and its
+     * environment keeps the chunks on the strict kernels).  At 22.05 kHz the mode wants a CHANNEL-MAJOR buffer: there
+     * every channel is cut where it is quiet (at 44.1 / 48 kHz a channel-major call is transposed on the device first); a time-major buffer is cut at the same rows for all channels and its
      * chunks run on through whatever burst straddles a cut (an eighth slower at configs[1] and twice the HBM traffic,
      * DESIGN.md 6).
      * Contract (tests/test_time_parallel.py): burst bytes, their order and

@@ -1169,6 +1169,10 @@ int process_channel_major_native(same_batch *rx, const float *d_x, size_t n, hip
 {
     same_batch::TimePar &tp = rx->tp;
     if (!tp.enabled || n > ((size_t)1 << 22)) return 0;
+    // 22.05 kHz only: per-lane input streams are read by the sample stage of the 64-channel pipeline forms and by the
+    // relaxed kernels; the 44.1 / 48 kHz pipeline reads its input on the DC wavefront, which takes time-major rows only
+    // (such a call is transposed on the device and cut uniformly)
+    if (rx->P.ntaps != 42u) return 0;
     same::ChunkGeom geom{};
     same::PipeChunks pc{};
     // A quarter more state columns than the machine holds at once (40 960: 10 pieces per channel at 4 096 channels) unless

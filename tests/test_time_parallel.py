@@ -440,6 +440,28 @@ def test_per_channel_boundaries_on_channel_major_input(sa, ob, arith, monkeypatc
     assert len(again[again["kind"] == 3]) >= len(got[got["kind"] == 3]) - n_ch // 8
 
 
+@pytest.mark.parametrize("rate,n_ch,chunks", [(48000, 256, 6), (44100, 128, 5)])
+def test_per_channel_boundaries_at_the_other_rates(sa, ob, arith, rate, n_ch, chunks):
+    """A channel-major call at 44.1 / 48 kHz: the pipeline of those rates reads its input on the DC wavefront, in time-major
+    rows, so the call is transposed on the device slab by slab (65 520 samples each: cut in time where a slab is long enough
+    for it, ordinary launches otherwise).  Same contract; until round 4 such a call went down the per-lane path and
+    delivered nothing."""
+    n = rate * 8
+    n -= n % (32 * 36 * 4)
+    x = sa.synth_afsk(n_ch, n, rate, seed=3300 + n_ch)
+    ref = strict_events(sa, x, rate)
+    xc = x.t().contiguous()
+    rx = sa.SameReceiverBuilder(rate).build_batch(n_ch, time_parallel=True)
+    rx.time_parallel_config(max_chunks=chunks)
+    rx.process_tensor(xc, layout=sa.LAYOUT_CHANNEL_MAJOR)
+    rx.sync()
+    assert not rx.time_parallel_per_channel() and rx.kernel_name().startswith("demod_pipe_kernel")
+    got = rx.poll_events_np()
+    got = got[np.lexsort((np.arange(len(got)), got["channel"]))]      # (events come per launch)
+    assert len(got[got["kind"] == 3]) >= 2 * n_ch
+    assert_contract(sa, got, ref, rate, n_ch, lambda c: sa.synth_payload(3300 + n_ch, c), exact_bursts=True, t_end=n, what=f"channel-major {rate}")
+
+
 def test_channel_major_call_that_is_not_whole_blocks(sa, ob, arith, monkeypatch):
     """A channel-major call whose length is no multiple of the kernel's block still takes the per-channel path: the
     samples behind the last whole block go through the any-configuration kernel on the channels' own state, and the next
