@@ -225,6 +225,17 @@ def test_relaxed_batches_on_the_pipeline_at_the_other_rates(sa, monkeypatch, rat
         assert rx.kernel_name() == "demod_pipe_kernel<fastmath>"
         assert_contract(sa, got, ref, rate, n_ch, lambda c: sa.synth_payload(seed, c), exact_bursts=(noise == 0.0), what=f"pipeline fastmath {rate}",
                         garbled_per_mille=(1 if noise > 0.0 else 0), t_end=n)
+    # int16 input and a channel-major buffer (transposed on the device) give what f32 time-major gives
+    import torch
+    xi = torch.round(sa.synth_afsk(n_ch, n, rate, seed=84)).contiguous()
+    ref = strict_events(sa, xi, rate)
+    for what, feed in (("i16", lambda r: r.process_tensor(xi.to(torch.int16))),
+                       ("channel-major", lambda r: r.process_tensor(xi.t().contiguous(), layout=sa.LAYOUT_CHANNEL_MAJOR))):
+        rx = sa.SameReceiverBuilder(rate).build_batch(n_ch, relaxed=True)
+        feed(rx); rx.sync()
+        assert rx.kernel_name() == "demod_pipe_kernel<fastmath>"
+        got = rx.poll_events_np()
+        assert_contract(sa, got[np.lexsort((np.arange(len(got)), got["channel"]))], ref, rate, n_ch, lambda c: sa.synth_payload(84, c), what=f"{what} {rate}", t_end=n)
     # its soft symbols
     x = sa.synth_afsk(64, n, rate, seed=83)
     full = sa.SameReceiverBuilder(rate).build_batch(64, trace_symbols=True, link_only=True)
