@@ -69,7 +69,7 @@ def timeit(n_ch, secs, reps=3, relaxed=True, tp=False, cm=False, chunks=0):
     if cm:
         x = x.t().contiguous()
     torch.cuda.synchronize()
-    rx = sa.SameReceiverBuilder(rate).build_batch(n_ch, link_only=True, relaxed=relaxed, time_parallel=tp)
+    rx = sa.SameReceiverBuilder(rate).build_batch(n_ch, link_only=not os.environ.get("SYM_TRANSPORT"), relaxed=relaxed, time_parallel=tp)
     if tp and chunks:
         rx.time_parallel_config(max_chunks=chunks)
     rx.set_kernel_timing(True)
