@@ -17,10 +17,13 @@ roofline: algorithmic bytes = 4 B per input sample divide
 demodulation kernel's duration, measured with HIP events on the stream the kernel runs on.
 cpu_baseline: the oracle (scalar C port of the reference's Rust path; the reference
 itself cannot be built in this image) on a bounded sample of the same input, all host
-cores.  `scaled`: 32 768 channels (the per-GPU shard of BASELINE.json configs[3]) in strict
-and in relaxed arithmetic, `scaled_long`: the same shard with 10 s per step in time-parallel
-mode, `configs2_48k`: 16 384 channels at 48 kHz (configs[2]) -- all reported beside, never
-instead of, the configs[1] value (rank 0, N = 1 only).  `--workload configs3` makes the
+cores the container's CPU quota covers.  `scaled`: 32 768 channels (the per-GPU shard of
+BASELINE.json configs[3]) in strict and in relaxed arithmetic, `scaled_big`: 131 072 channels
+likewise (the regime of the one-wavefront kernels), `configs2_48k`: 16 384 channels at 48 kHz
+(configs[2]) in strict and in relaxed arithmetic, `scaled_long` (behind --scaled-long): the
+32 768-channel shard with 10 s per step in time-parallel mode -- every relaxed block with its
+contract check against the strict pass, all reported beside, never instead of, the configs[1]
+value (rank 0, N = 1 only).  `--workload configs3` makes the
 32 768-channel shard (2 s per step) the workload of every rank: the 8-GPU form of configs[3].
 """
 import argparse
