@@ -19,7 +19,7 @@ cpu_baseline: the oracle (scalar C port of the reference's Rust path; the refere
 itself cannot be built in this image) on a bounded sample of the same input, all host
 cores the container's CPU quota covers.  `scaled`: 32 768 channels (the per-GPU shard of
 BASELINE.json configs[3]) in strict and in relaxed arithmetic, `scaled_big`: 131 072 channels
-likewise (the regime of the one-wavefront kernels), `configs2_48k`: 16 384 channels at 48 kHz
+likewise (strict: the one-wavefront kernel; relaxed: the symbol-paced pipeline in rounds), `configs2_48k`: 16 384 channels at 48 kHz
 (configs[2]) in strict and in relaxed arithmetic, `scaled_long` (behind --scaled-long): the
 32 768-channel shard with 10 s per step in time-parallel mode -- every relaxed block with its
 contract check against the strict pass, all reported beside, never instead of, the configs[1]
@@ -521,8 +521,7 @@ def main():
         "time_parallel_time_major": "time-major input; uniform chunk boundaries (one row offset per workgroup keeps the loads coalesced), chunks run on "
                                     "until idle, relaxed arithmetic inside the chunks; kernel_ms includes the state column copies",
         "time_parallel_strict_chunks": "as time_parallel with strict arithmetic inside every chunk (SAME_RELAXED=0: round 2's form of the mode)",
-        "relaxed": "ordinary launch (no cut in time), relaxed arithmetic (SAME_BATCH_RELAXED): the symbol-paced pipeline (same_kernels_sym.hip) up to 65 536 channels, "
-                   "the relaxed kernel of same_kernels_relaxed.hip beyond",
+        "relaxed": "ordinary launch (no cut in time), relaxed arithmetic (SAME_BATCH_RELAXED): the symbol-paced pipeline (same_kernels_sym.hip)",
     }
     layouts = {"time_parallel": "channel-major x[channel][t]", "time_parallel_strict_chunks": "channel-major x[channel][t]"}
     modes = {}
@@ -696,7 +695,7 @@ def main():
             del x2, ev_strict
             torch.cuda.empty_cache()
             if not args.no_scaled_big:
-                # the regime where the one-wavefront kernels take over: 131072 channels x 2 s, strict and relaxed, with the
+                # four times the machine: 131072 channels x 2 s, strict (one-wavefront kernel) and relaxed (the symbol-paced pipeline in rounds), with the
                 # relaxed pass held against the strict one (first pass, every channel)
                 try:
                     Cb = 131072

@@ -280,6 +280,7 @@ struct same_batch {
     bool force_generic = false;      // SAME_BATCH_GENERIC_KERNEL (tests compare both kernels)
     bool debug = false;              // SAME_DEBUG: harvest statistics on stderr
     int host_threads = 0;            // SAME_HOST_THREADS: harvest threads (0 = choose)
+    uint32_t sym_max_channels = 1u << 30;
     // staging for host / channel-major inputs
     void *d_stage = nullptr; size_t stage_bytes = 0;
     void *d_stage2 = nullptr; size_t stage2_bytes = 0;
@@ -390,6 +391,7 @@ void read_knobs(same_batch *rx)
 #endif
     rx->P.knob_fast_dense = tri("SAME_FAST_DENSE");
     rx->P.knob_sym = tri("SAME_SYM");
+    rx->sym_max_channels = (uint32_t)std::max(0, num("SAME_SYM_MAX", 1 << 30));     // (measurement knob: up to where an ordinary relaxed launch takes the symbol-paced pipeline; default: always)
     rx->debug = std::getenv("SAME_DEBUG") != nullptr;
     rx->host_threads = std::max(0, num("SAME_HOST_THREADS", 0));
     rx->tp.sort_mode = num("SAME_TP_SORT", -1);
@@ -1099,15 +1101,19 @@ int process_time_major(same_batch *rx, const SampleT *d_x, size_t n_samples, hip
         // whole blocks (16 or 18 samples) go to the latency-optimised kernel when the
         // configuration has one; the generic kernel takes the remainder (and every other
         // configuration)
-        // SAME_BATCH_RELAXED on an ordinary launch: the pipeline's FASTMATH build while the batch fits it (whole 64-channel
-        // workgroups, up to 32 768 channels: four wavefronts per 64 channels), the one- / two-wavefront relaxed kernel beyond
-        // (SAME_RELAXED_KERNEL=solo / duo forces that one)
+        // SAME_BATCH_RELAXED on an ordinary launch of whole 64-channel groups: the symbol-paced pipeline at 22.05 kHz (any
+        // number of channels), the pipeline's FASTMATH build at 44.1 / 48 kHz (up to 32 768 channels); the one- / two-wavefront
+        // relaxed kernel takes batches that are not whole groups of 64 and whatever SAME_RELAXED_KERNEL=solo / duo sends it
         const same::Params Pfm = fm_params(rx->P);
-        // (the symbol-paced pipeline takes any number of 64-channel workgroups: beyond two per CU they run in rounds)
+        // (the symbol-paced pipeline takes any number of 64-channel workgroups: beyond two per CU they run in rounds -- and
+        // it is the faster kernel at every channel count)
         const bool plain_fm = rx->relaxed_plain && rx->P.knob_relaxed_kernel == 0 && same::pipe_relaxed_supported(Pfm) &&
-                              (rx->P.n_channels <= 32768u || (rx->P.n_channels <= 65536u && same::sym_kernel_supported(Pfm)));
-        // (measured, 2 s launches: 49 152 channels 4.53 ms against the two-wavefront relaxed kernel's 5.12, 65 536: 5.41 against
-        // 6.08; 131 072: 10.2 against the one-wavefront kernel's 9.7, 262 144: 19.4 against 18.3)
+                              (rx->P.n_channels <= 32768u || (rx->P.n_channels <= rx->sym_max_channels && same::sym_kernel_supported(Pfm)));
+        // (measured, 2 s launches back to back with the transport layer on, the way a stream is fed: 49 152 channels 4.26 ms;
+        // 98 304: 7.2 ms against the one-wavefront relaxed kernel's 12.3; 131 072: 9.45 against 15.35; 196 608: 13.95 against
+        // 24.9; 262 144: 19.5 against 29.3 -- 30 % of HBM against 18-20 %.  Round 3's figures for the one-wavefront kernel, up to
+        // 26 %, were single launches on an idle machine with the link layer only; sustained, its eight wavefronts per SIMD fall
+        // back launch by launch: tools/big_sustained.py.  SAME_RELAXED_KERNEL=solo / duo still selects it.)
         // (44.1 / 48 kHz have the FASTMATH pipeline only: a batch beyond it runs strict)
         const bool plain_wave = rx->relaxed_plain && !plain_fm && same::relaxed_kernel_supported(rx->P);
         rx->last_plain_fm = plain_fm; rx->last_plain_wave = plain_wave;

@@ -294,18 +294,16 @@ def test_time_parallel_chunks_on_the_relaxed_kernel(sa, monkeypatch, layout):
     assert_contract(sa, got, ref, rate, n_ch, lambda c: sa.synth_payload(4242, c), what=layout, t_end=2 * n)
 
 
-@pytest.mark.parametrize("n_ch,kernel", [(131072, None), (65536, "duo")])
+@pytest.mark.parametrize("n_ch,kernel", [(131072, "solo"), (65536, "duo")])
 def test_relaxed_large_batches_meet_the_contract(sa, ob, monkeypatch, n_ch, kernel):
-    """The regimes beyond the pipelines: 131 072 channels x 2 s on the one-wavefront relaxed kernel (its two-per-SIMD
-    build, what such a batch runs by default and what bench.py's `scaled_big` block prices) and 65 536 channels on the
-    two-wavefront kernel.  Every channel against strict mode; strict mode against the oracle on a 4 096-channel slab."""
+    """The one- and two-wavefront relaxed kernels at the sizes they were built for: 131 072 channels x 2 s on the
+    one-wavefront kernel (its two-per-SIMD build) and 65 536 channels on the two-wavefront kernel (SAME_RELAXED_KERNEL; by
+    default such batches run the symbol-paced pipeline: tests/test_sym_kernel.py).  Every channel against strict mode; strict
+    mode against the oracle on a 4 096-channel slab."""
     from helpers.oracle_compare import assert_every_channel_matches_oracle
     if wave_kernel_param(monkeypatch) != "solo":
         pytest.skip("one run is enough: the kernel is chosen below")
-    if kernel:
-        monkeypatch.setenv("SAME_RELAXED_KERNEL", kernel)
-    else:
-        monkeypatch.delenv("SAME_RELAXED_KERNEL", raising=False)
+    monkeypatch.setenv("SAME_RELAXED_KERNEL", kernel)
     rate, seed = 22050, 780
     n = 2 * rate
     x = sa.synth_afsk(n_ch, n, rate, seed=seed)

@@ -193,10 +193,10 @@ def test_disabled_equalizer_and_samedec_limits(sa):
         assert_contract(sa, ordered(rx.poll_events_np()), ref, rate, n_ch, lambda c: sa.synth_payload(seed, c), exact_bursts=True)
 
 
-@pytest.mark.parametrize("n_ch", [32768, 65536])
+@pytest.mark.parametrize("n_ch", [32768, 65536, 131072])
 def test_large_batches(sa, n_ch):
     """The regimes the bench prices: the 32 768-channel shard of configs[3] (two workgroups per CU, everything resident) and
-    65 536 channels (two rounds of workgroups).  Strict mode on the same input is the reference for every channel; strict
+    65 536 / 131 072 channels (two / four rounds of workgroups; the latter is bench.py's `scaled_big` block).  Strict mode on the same input is the reference for every channel; strict
     mode itself against the oracle on a slab of them."""
     from oracle import binding as ob
     from helpers.oracle_compare import assert_every_channel_matches_oracle

@@ -35,6 +35,8 @@ def classify(name, wgs, state, n1):
         cols = wgs * 64
         if cols == C:
             return "relaxed"
+        if cols == 131072:
+            return "scaled_big_relaxed"
         if cols > 32768:
             return "time_parallel"
         state["sym512"] = state.get("sym512", 0) + 1          # 32 768 columns: configs[1] cut uniformly on the time-major buffer first, the shard later
