@@ -1298,7 +1298,10 @@ uint32_t pipe_kernel_stages(const Params &P)
     if (!((P.eq_nff == 6u && P.eq_nfb == 4u) || (P.eq_nff == 1u && P.eq_nfb == 1u))) return 0;
     if (P.block_len != 16u || max_block_len(P) < (r22 ? (uint32_t)kBlockMirror : pipe_block_len(P))) return 0;
     if (P.knob_pipe != 0) return P.knob_pipe > 0 ? 4u : 0u;
-    return P.n_channels <= 32768u ? 4u : 0u;
+    // beyond two workgroups per CU the pipeline runs in rounds; 22.05 kHz, sustained 2 s launches with the transport layer on
+    // (tools/big_sustained_strict.py): 65 536 channels 7.97 ms against the one-wavefront kernel's 9.06, 131 072: 15.6 against
+    // 15.0, 262 144: 30.5 against 29.2
+    return P.n_channels <= (r22 ? 65536u : 32768u) ? 4u : 0u;
 }
 bool pipe_kernel_selected(const Params &P) { return pipe_kernel_stages(P) != 0u; }
 uint32_t pipe_block_len(const Params &P)
