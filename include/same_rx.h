@@ -165,9 +165,9 @@ enum {
      * not a multiple of 16 run as ordinary strict launches.  Not combinable with
      * SAME_BATCH_TRACE_SYMBOLS. */
     SAME_BATCH_TIME_PARALLEL = 1u << 3,
-    /* Relaxed arithmetic ("fast mode" of the north star; same_kernels_sym.hip up to 65 536 channels at 22.05 kHz and
-     * inside time-parallel chunks, same_kernels_relaxed.hip beyond, the FASTMATH build of same_kernels_pipe.hip at
-     * 44.1 / 48 kHz).  The reference's algorithm and every decision of it, with the rounding of the floating-point
+    /* Relaxed arithmetic ("fast mode" of the north star; same_kernels_sym.hip at 22.05 kHz -- batches of any size in whole
+     * groups of 64 channels, and inside time-parallel chunks --, the FASTMATH build of same_kernels_pipe.hip at
+     * 44.1 / 48 kHz, same_kernels_relaxed.hip for 22.05 kHz batches that are not whole groups of 64).  The reference's algorithm and every decision of it, with the rounding of the floating-point
      * expressions given up: matched filters as fused multiply-adds into four partial sums instead of one newest-first
      * chain (rx/filter.rs:363-377), |mark| and |space| as an f32 square root instead of hypot (rx/demod.rs:163), the AGC
      * update as gain * (1 - bw |x|) + bw (rx/agc.rs:72-77), reciprocals for the timing loop's and the equalizer's

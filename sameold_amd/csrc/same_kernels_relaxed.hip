@@ -777,6 +777,9 @@ bool relaxed_kernel_supported(const Params &P)
     if (!(P.agc_min >= 0.0f)) return false;
     return max_block_len(P) >= (uint32_t)kBlockMirror;
 }
+// (Since round 4 these kernels take relaxed batches that are not whole groups of 64 channels, time-parallel calls beyond
+// 16 384 channels and what SAME_RELAXED_KERNEL sends them; everything else runs the symbol-paced pipeline, which is faster
+// at every channel count under sustained launches: same_batch.cpp.)
 // Which form runs a launch over P.n_channels state columns: 1 duo (two wavefronts per 64 columns) while that leaves the
 // launch at no more than two wavefronts per SIMD (65 536 columns), 0 solo beyond -- or what SAME_RELAXED_KERNEL asks for.  Whole groups
 // of 64 columns for duo.  (A third form -- sample phase | filters + timing loop | symbol path on three wavefronts, 18-sample
