@@ -910,7 +910,7 @@ int record_harvest(same_batch *rx, same_batch::Slot &sl, uint32_t n_events, uint
 // How a call of n samples is cut into time-parallel chunks: fills geom / pc and returns the number of
 // chunks, or 1 when the call runs as one strict launch (mode off, configuration without a pipeline kernel,
 // call too short).
-uint32_t plan_chunks(same_batch *rx, size_t n, same::ChunkGeom &geom, same::PipeChunks &pc, uint32_t column_cap = 32768u)
+uint32_t plan_chunks(same_batch *rx, size_t n, same::ChunkGeom &geom, same::PipeChunks &pc, uint32_t column_cap = 32768u, bool channel_major = false)
 {
     same_batch::TimePar &tp = rx->tp;
     if (!tp.enabled || !rx->use_fast || rx->force_generic) return 1;
@@ -933,6 +933,13 @@ uint32_t plan_chunks(same_batch *rx, size_t n, same::ChunkGeom &geom, same::Pipe
     // Relaxed batches: the pipeline's FASTMATH build while the state columns fit the pipeline (whole 64-channel
     // workgroups), the one-wavefront relaxed kernel beyond (SAME_TP_KERNEL=pipe / wave overrides)
     const bool pipe_fm = rx->relaxed && tp.knob_kernel != 2 && C % same::kWave == 0u && C <= 16384u;
+    // A batch that fills the machine by itself (more than 16 384 channels, i.e. more than one workgroup per CU before any
+    // cut) gains nothing from a cut in time -- its ordinary relaxed launches run the symbol-paced pipeline at ~30 % of HBM,
+    // 262 144 state columns on the one-wavefront kernel ran at 13 % (round 3's `scaled_long`): such time-major calls are not
+    // cut, and same_batch_new has made them relaxed launches (32 768 ch x 10 s: 21 ms per call against 31.6; SAME_TP_KERNEL=wave
+    // still cuts them).  A channel-major call keeps the cut: read where it lies by the one-wavefront kernel it is 31.6 ms,
+    // transposed slab by slab first 38.6.
+    if (rx->relaxed && !pipe_fm && !channel_major && tp.knob_kernel == 0 && C % same::kWave == 0u && same::sym_kernel_supported(fm_params(rx->P))) return 1;
     if (rx->relaxed && !pipe_fm && tp.knob_kernel != 1 && C % same::kWave == 0u && C <= 65536u && same::relaxed_kernel_supported(rx->P)) {
         // one wavefront per 64 state columns, any number of them
         // (up to 262 144 state columns, 16 pieces per channel unless the caller asks for more: a piece is a burst with its
@@ -1193,7 +1200,7 @@ int process_channel_major_native(same_batch *rx, const float *d_x, size_t n, hip
     const bool sym_cols = rx->relaxed && same::sym_kernel_supported(rx->P);
     const uint32_t dflt_cols = sym_cols ? 49152u : 40960u;
     const uint32_t want_cols = tp.max_chunks ? tp.max_chunks * rx->P.n_channels : dflt_cols;
-    const uint32_t n_chunks = plan_chunks(rx, n, geom, pc, tp.max_chunks ? (want_cols > 32768u ? 65536u : 32768u) : dflt_cols);
+    const uint32_t n_chunks = plan_chunks(rx, n, geom, pc, tp.max_chunks ? (want_cols > 32768u ? 65536u : 32768u) : dflt_cols, true);
     if (n_chunks < 2u) return 0;
     const uint32_t C = rx->P.n_channels, columns = n_chunks * C, fb = geom.block_len;
     const bool wave = tp.kernel == same_batch::TimePar::kWaveRelaxed;
@@ -1474,7 +1481,10 @@ int same_batch_new(const same_rx_builder *b, uint32_t n_channels, int device, ui
                   rx->use_fast && !rx->force_generic &&
                   (same::relaxed_kernel_supported(rx->P) || (rx->P.n_channels % same::kWave == 0u && same::pipe_relaxed_supported(fm_params(rx->P))));
     // (a call of a time-parallel batch that is too short to be cut stays strict unless relaxed arithmetic was asked for)
-    rx->relaxed_plain = rx->relaxed && ((flags & SAME_BATCH_RELAXED) != 0 || rx->knob_relaxed > 0);
+    // (... nor a batch of more than 16 384 channels, which is never cut: plan_chunks)
+    rx->relaxed_plain = rx->relaxed && ((flags & SAME_BATCH_RELAXED) != 0 || rx->knob_relaxed > 0 ||
+                                        ((flags & SAME_BATCH_TIME_PARALLEL) != 0 && n_channels > 16384u && n_channels % same::kWave == 0u &&
+                                         same::sym_kernel_supported(fm_params(rx->P))));
     if (same::demod_lds_bytes(rx->P) > 160 * 1024)
         return cleanup(fail(SAME_EINVAL, "configuration needs %zu bytes of LDS per wavefront (limit 160 KiB)", same::demod_lds_bytes(rx->P)));
     TRY_OR_CLEAN(hipStreamCreateWithFlags(&rx->own_stream, hipStreamNonBlocking));
