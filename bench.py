@@ -516,7 +516,7 @@ def main():
         "time_parallel": "channel-major input x[channel][t]; time chunks per channel = state columns side by side, chunk boundaries per channel at idle "
                          "instants (device-side energy scout + planner + sort: inside kernel_ms, which is what `achieved` is priced on, as far as they "
                          "are not hidden under the previous launch's tail on the plan stream; demod_kernel_alone_ms is the demodulation kernel by "
-                         "itself, what rocprofv3 lists), 12 pieces per channel (10 with SAME_RELAXED=0), relaxed arithmetic inside the chunks (the symbol-paced pipeline, same_kernels_sym.hip; "
+                         "itself, what rocprofv3 lists), 8 pieces per channel = one round of workgroups (10 with SAME_RELAXED=0), relaxed arithmetic inside the chunks (the symbol-paced pipeline, same_kernels_sym.hip; "
                          "DESIGN.md 4.6, 4.7)",
         "time_parallel_time_major": "time-major input; uniform chunk boundaries (one row offset per workgroup keeps the loads coalesced), chunks run on "
                                     "until idle, relaxed arithmetic inside the chunks; kernel_ms includes the state column copies",

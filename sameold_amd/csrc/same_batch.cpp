@@ -1194,11 +1194,13 @@ int process_channel_major_native(same_batch *rx, const float *d_x, size_t n, hip
     // 39.9 k samples, with 10 or more 37.5 k), and beyond 10 the extra workgroups only add rounds.  Measured at 4 096
     // channels x 10 s, pieces sorted by length into workgroups: 8 pieces 3.84 ms (unsorted 3.83), 9 3.47, 10 3.45, 11 3.70,
     // 12 3.85, 16 4.2.
-    // With the symbol-paced pipeline (round 4; a piece's pace alone on a CU is 1.25 x its pace beside another): 8 pieces
-    // 2.16 ms, 9 2.33, 10 2.14, 11 2.13, 12 2.03, 14 2.13, 16 2.21 -- half as many columns again as the machine holds,
-    // so that the last, long pieces run with a CU to themselves.
+    // With the symbol-paced pipeline (round 4): exactly the columns the machine holds at once (32 768: 8 pieces per channel at
+    // 4 096 channels, one round of workgroups in grid order).  Single launches on an idle machine favour 12 pieces (8: 2.16 ms,
+    // 10: 2.14, 12: 2.03, 16: 2.21 -- the long pieces finish with a CU to themselves), but calls back to back, the way a stream
+    // is fed, do not: 40 steps with 8 pieces 2.20 ms per step (kernel 2.05-2.08, launch to launch +-3 %), with 10: 2.38-2.42,
+    // 12: 2.41-2.48 (kernel 2.26-2.35, launch to launch 2.06-3.1), 16: 2.46 (tools/headline_steady.py).
     const bool sym_cols = rx->relaxed && same::sym_kernel_supported(rx->P);
-    const uint32_t dflt_cols = sym_cols ? 49152u : 40960u;
+    const uint32_t dflt_cols = sym_cols ? 32768u : 40960u;
     const uint32_t want_cols = tp.max_chunks ? tp.max_chunks * rx->P.n_channels : dflt_cols;
     const uint32_t n_chunks = plan_chunks(rx, n, geom, pc, tp.max_chunks ? (want_cols > 32768u ? 65536u : 32768u) : dflt_cols, true);
     if (n_chunks < 2u) return 0;

@@ -9,6 +9,7 @@ C, T = 4096, 220500
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 30
 x = sa.synth_afsk(C, T, 22050, seed=20260000).t().contiguous(); torch.cuda.synchronize()
 rx = sa.SameReceiverBuilder(22050).build_batch(C, time_parallel=True); rx.set_kernel_timing(True)
+if os.environ.get("TP_CHUNKS"): rx.time_parallel_config(max_chunks=int(os.environ["TP_CHUNKS"]))
 k, d = [], []
 for i in range(steps + 5):
     if i == 5:
@@ -20,5 +21,5 @@ for i in range(steps + 5):
     if n: rx.pack_bursts_np(0); rx.drop_events(n)
 rx.sync(); wall = (time.perf_counter() - t0) / steps * 1e3
 k, d = np.array(k), np.array(d)
-print(f"SAME_STREAM_PRIO={os.environ.get('SAME_STREAM_PRIO','-')} SAME_TP_PLAN_STREAM={os.environ.get('SAME_TP_PLAN_STREAM','-')}: wall {wall:.3f} ms/step; launch mean {k.mean():.3f} min {k.min():.3f} max {k.max():.3f}; "
+print(f"pieces {rx.time_parallel_chunks()} SAME_TP_PLAN_STREAM={os.environ.get('SAME_TP_PLAN_STREAM','-')}: wall {wall:.3f} ms/step; launch mean {k.mean():.3f} min {k.min():.3f} max {k.max():.3f}; "
       f"demod alone mean {d.mean():.3f} min {d.min():.3f} p90 {np.percentile(d,90):.3f} max {d.max():.3f}", flush=True)
