@@ -33,13 +33,13 @@ def classify(name, wgs, state, n1):
     if "demod_sym_kernel" in name:
         # <NFF, NFB, SampleT, input form>: the symbol-paced pipeline takes every relaxed launch up to 65 536 columns
         cols = wgs * 64
+        if re.search(r"demod_sym_kernel<\d+, \d+, \w+, 1>", name):
+            return "time_parallel"                             # per-lane input streams: the channel-major time-parallel launch (8 pieces: 32 768 columns)
         if cols == C:
             return "relaxed"
         if cols == 131072:
             return "scaled_big_relaxed"
-        if cols > 32768:
-            return "time_parallel"
-        state["sym512"] = state.get("sym512", 0) + 1          # 32 768 columns: configs[1] cut uniformly on the time-major buffer first, the shard later
+        state["sym512"] = state.get("sym512", 0) + 1          # 32 768 columns, time-major rows: configs[1] cut uniformly first, the shard later
         return "time_parallel_time_major" if state["sym512"] <= n1 else "scaled_relaxed"
     m = re.search(r"demod_pipe_kernel<(\d+), \d+, \d+, \w+, (\w+), (\d+), \w+, \w+, (\w+)(?:, \d+)?>", name)
     if not m:
