@@ -146,7 +146,7 @@ enum {
     SAME_BATCH_GENERIC_KERNEL = 1u << 2,/* always use the any-configuration kernel (tests) */
     /* Time-parallel ("fast") mode.  A long call on few channels is a few serial instruction streams on a
      * machine with a thousand SIMDs; with this flag a call is cut into K time chunks per channel that
-     * run side by side (K * n_channels state columns: 32 768 fill the machine, the channel-major path takes 49 152).  Chunk 0
+     * run side by side (K * n_channels state columns: 32 768 fill the machine exactly once, which is the default).  Chunk 0
      * continues from the channel's state; every other chunk starts from a freshly built receiver a
      * warm-up (64 symbols by default) before the samples it owns, and a chunk keeps running past its
      * end until its channel has been seen idle (LinkState::NoCarrier), where the next chunk takes over.
