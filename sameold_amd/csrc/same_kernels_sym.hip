@@ -75,7 +75,8 @@ template <int NT> struct SymLayout {
     static constexpr uint32_t pos_words = 2u * kWave;             // per parity: ring slots of the symbol's two instants (-1: none)
     static constexpr uint32_t mail_words = 2u * sym_words + 2u * fb_words + 2u * io_words + 2u * kWave +   // + final TED phase, wake-up flag
                                            2u * pos_words + kWave +                                       // + the first instant's soft sample, from S
-                                           kIoRingWords;                                                  // + T's deadline ring and its count
+                                           kIoRingWords +                                                 // + T's deadline ring and its count
+                                           kWave;                                                         // + Y -> T: this lane has handed over
     static constexpr uint32_t yring_floats = 2u * (uint32_t)B * kWave;
     static constexpr size_t lds_bytes = ((size_t)tap_floats + mail_words + yring_floats + (size_t)(RING + MIR) * kWave) * sizeof(float);
     static_assert(NT == 42 && NT % kRelaxChunk == 0, "three filter chunks of 14 taps");
@@ -220,10 +221,14 @@ struct SymDc {
     Pairs xa, xb;                        // inputs: block b waits in (b & 1 ? xb : xa)
     const SampleT *xl = nullptr;         // CMODE 1: this lane's own stream
     uint32_t avail = 0;                  // ... and the blocks it holds
+    bool done = false;                   // ... and whether the lane's piece has handed over: nothing it computes from here on is kept
 
     __device__ __forceinline__ void request(Pairs &dst, const SampleT *__restrict__ x, uint32_t blk, uint32_t n_blocks, uint32_t cin, uint32_t Cin) const
     {
         if constexpr (CMODE == 1) {
+            // (a lane that has handed over stops reading: in grid order the pieces of a workgroup differ in length, and the
+            // short ones otherwise read on to the end of the longest -- 0.3 x the algorithmic bytes of a configs[1] launch)
+            if (done) return;
             const uint32_t b = min(blk, avail - 1u);                 // (avail >= 1: the planner leaves two scout blocks behind every cut)
             const float4 *p4 = reinterpret_cast<const float4 *>(xl + (size_t)b * B);
             sym_static_for<B / 4>([&](auto j_) __attribute__((always_inline)) {
@@ -516,6 +521,7 @@ __global__ __launch_bounds__(4 * kWave, 2) void demod_sym_kernel(Params P, State
     lds_u32 *posbox = againbox + kWave;                        // [2][2][64] ring slots of the two instants of step s's symbol (parity s & 1)
     lds_u32 *sabox = posbox + 2u * LY::pos_words;              // [64] the first instant's soft sample
     lds_u32 *tkbox = sabox + kWave;                            // [kTickRing][64] u64 deadlines, then [64] their count (T's own)
+    lds_u32 *donebox = tkbox + kIoRingWords;                   // [64] Y -> T: the lane's piece has handed over (its input is no longer needed)
     lds_u32 *chunkbox = fbbox + kWave + 2u;                    // [2], in the first feedback box's padding
     lds_u32 *seqbox = fbbox + kWave + 4u;                      // S's progress with the first instants' filters: 2 * step + pass
     float *yring = lds + LY::tap_floats + LY::mail_words;      // [2][kB][64]: block b in half b & 1
@@ -603,6 +609,7 @@ __global__ __launch_bounds__(4 * kWave, 2) void demod_sym_kernel(Params P, State
         X.pending_slot = 0xffffffffu;
         X.tk = tkbox + lane;
         X.ring_load(P, S, c);
+        donebox[lane] = 0u;
         // prologue: block 0's DC outputs
         if (n_blocks > 1u) D.request(D.xb, x, 1u, n_blocks, cin, Cin);
         D.block(P, yring + lane, D.xa, 0u);
@@ -611,6 +618,7 @@ __global__ __launch_bounds__(4 * kWave, 2) void demod_sym_kernel(Params P, State
         uint32_t stop_at = 0xffffffffu;
         auto step = [&](uint32_t s, auto buf) __attribute__((always_inline)) -> bool {
             constexpr int BUF = decltype(buf)::value;                  // block s + 1 waits in buffer BUF = (s + 1) & 1
+            if constexpr (CMODE == 1) D.done = donebox[lane] != 0u;
             if (s + 1u < n_blocks && !PROF_SKIP(P, 128)) {
                 float *y = yring + (((s + 1u) & 1u) * (uint32_t)kB) * LP + lane;
                 if constexpr (BUF == 0) { D.request(D.xb, x, s + 2u, n_blocks, cin, Cin); D.block(P, y, D.xa, s + 1u); }
@@ -765,6 +773,7 @@ __global__ __launch_bounds__(4 * kWave, 2) void demod_sym_kernel(Params P, State
                     if (!lane_done && blk + 1u >= n_nominal && (L.flags & F_LINK_MASK) == 0u && (xl == nullptr || blk < avail_l)) {
                         lane_done = true;
                         K.handover[c] = counter0 + (int64_t)row_l + (uint64_t)(blk + 1u) * kB;
+                        donebox[lane] = 1u;
                     }
                     if (__builtin_amdgcn_ballot_w64(!lane_done) == 0ull) { leave = 2u; leave_posted = true; stop_at = s + 1u; }
                 }
