@@ -393,21 +393,16 @@ __device__ __forceinline__ uint32_t eq_symbol_relaxed(const Params &P, Lane &L, 
         if (!fb_zero(i)) qb = __builtin_fmaf(fbw[i], fbw[i], qb);
     }
     const float sym_val = (f0 + f1) - fb;
-    float sym_est, err;
-    bool evolve = true;
-    if (mode == 2u) {                                  // EnabledTraining :278-301
-        sym_est = (L.eq_word & 1u) ? 1.0f : -1.0f;
-        L.eq_word >>= 1;
-        err = sym_est - sym_val;
-        L.eq_count += 1;
-        if (L.eq_count >= 32u) mode = 1u;
-    } else if (mode == 1u) {                           // EnabledFeedback :266-277
-        sym_est = rs_signum(sym_val);
-        err = sym_est - sym_val;
-    } else {                                           // Disabled :262-265
-        sym_est = rs_signum(sym_val); err = 0.0f; evolve = false;
-    }
-    if (evolve) {
+    // The three modes -- EnabledTraining :278-301, EnabledFeedback :266-277, Disabled :262-265 -- as selects: a wavefront has
+    // lanes in all of them at once (a burst trains for 32 symbols, then decides by itself), and three exec-mask regions of
+    // three instructions each cost more than the instructions.  Disabled: err = 0, and the update below adds exact zeros.
+    const bool training = mode == 2u, evolve = mode != 0u;
+    const float sym_est = training ? ((L.eq_word & 1u) ? 1.0f : -1.0f) : rs_signum(sym_val);
+    const float err = evolve ? sym_est - sym_val : 0.0f;
+    L.eq_word = training ? L.eq_word >> 1 : L.eq_word;
+    L.eq_count = training ? L.eq_count + 1u : L.eq_count;
+    mode = (training && L.eq_count >= 32u) ? 1u : mode;
+    {
         const float gf = P.eq_relaxation * __builtin_amdgcn_rcpf(P.eq_regularization + (q0 + q1));
         const float gb = P.eq_relaxation * __builtin_amdgcn_rcpf(P.eq_regularization + qb);
         const float ge = gf * err, gn = -(gb * err);
