@@ -153,6 +153,23 @@ int derive_params(const same_rx_builder &b, uint32_t n_channels, Params &P, std:
         taps[4 * i + 0] = mre[i]; taps[4 * i + 1] = mim[i];
         taps[4 * i + 2] = sre[i]; taps[4 * i + 3] = sim[i];
     }
+    // The same taps once more, CENTRED, behind them (even tap counts; relaxed kernels only -- same_kernels_sym.hip).  The
+    // filter is a cisoid h[i] = (2/N) e^{-j a (N-1-i)} (rx/waveform.rs:54-64) and only its output's magnitude is used
+    // (rx/demod.rs:156-164), so it may be turned by any unit phasor: u[k] = h[k] e^{+j a (N-1)/2} = (2/N) e^{j a (k - (N-1)/2)}
+    // has u[N-1-k] = conj(u[k]), and for a real window  sum_i w_i u_i = sum_{k<N/2} (w_k + w_{N-1-k}) Re u_k + j (w_k - w_{N-1-k}) Im u_k.
+    // Entry k < N/2: (Re u_k mark, Re u_k space, Im u_k mark, Im u_k space); the reference's own f32 taps turned in f64.
+    if (ntaps % 2 == 0) {
+        taps.resize(4 * ntaps + 4 * (ntaps / 2));
+        const float am = (2.0f * PI_F32) * (FSK_MARK_HZ / (float)b.input_rate), as = (2.0f * PI_F32) * (FSK_SPACE_HZ / (float)b.input_rate);
+        const double hm = (double)am * 0.5 * (double)(ntaps - 1), hs = (double)as * 0.5 * (double)(ntaps - 1);
+        for (size_t k = 0; k < ntaps / 2; ++k) {
+            float *t = &taps[4 * ntaps + 4 * k];
+            t[0] = (float)((double)mre[k] * std::cos(hm) - (double)mim[k] * std::sin(hm));
+            t[1] = (float)((double)sre[k] * std::cos(hs) - (double)sim[k] * std::sin(hs));
+            t[2] = (float)((double)mre[k] * std::sin(hm) + (double)mim[k] * std::cos(hm));
+            t[3] = (float)((double)sre[k] * std::sin(hs) + (double)sim[k] * std::cos(hs));
+        }
+    }
 
     // timing loop: rx/symsync.rs:142-163
     loop_alphabeta(b.timing_bandwidth_unlocked, P.alpha_unlocked, P.beta_unlocked);

@@ -36,7 +36,8 @@ float rs_clamp_h(float x, float mn, float mx);
 void builder_defaults(same_rx_builder &b, uint32_t input_rate);
 
 // Derive the per-batch constants.  Returns 0 or a SAME_E* code where the reference
-// panics.  `taps` receives ntaps entries of (mark.re, mark.im, space.re, space.im).
+// panics.  `taps` receives ntaps entries of (mark.re, mark.im, space.re, space.im) and, for an even tap count, ntaps / 2
+// entries of the same taps centred (Re mark, Re space, Im mark, Im space: same_config.cpp) behind them.
 int derive_params(const same_rx_builder &b, uint32_t n_channels, Params &P,
                   std::vector<float> &taps);
 

@@ -67,7 +67,10 @@ namespace same {
 constexpr int kSymBlock = 36;
 constexpr uint32_t kSymDrain = 5u;        // steps after the last block in which T processes the instants left before the end of the input, one per step
 template <int NT> struct SymLayout {
-    static constexpr int B = kSymBlock, DCL = 16, NBLK = 5, RING = NBLK * B, MIR = kRelaxChunk - 1;
+    // The window ring holds SIX blocks: the four the filters may reach into, the one S is turning from DC-blocker outputs into
+    // AGC outputs IN PLACE, and the one T is writing DC-blocker outputs to (there is no hand-over ring between T and S).  Its first
+    // NT - 1 slots are stored twice: a filter's 42 samples never wrap.
+    static constexpr int B = kSymBlock, DCL = 16, NBLK = 6, RING = NBLK * B, MIR = NT - 1;
     static constexpr uint32_t tap_floats = (uint32_t)((NT * 4 + PIPE_PROF_TAP_PAD + 63) / 64 * 64);
     static constexpr uint32_t sym_words = 5u * kWave;             // per parity: header, zero, sym, terr, until
     static constexpr uint32_t fb_words = kWave + 32u;             // per parity: one word per lane + the any-flag
@@ -77,12 +80,12 @@ template <int NT> struct SymLayout {
                                            2u * pos_words + kWave +                                       // + the first instant's soft sample, from S
                                            kIoRingWords +                                                 // + T's deadline ring and its count
                                            kWave;                                                         // + Y -> T: this lane has handed over
-    static constexpr uint32_t yring_floats = 2u * (uint32_t)B * kWave;
-    static constexpr size_t lds_bytes = ((size_t)tap_floats + mail_words + yring_floats + (size_t)(RING + MIR) * kWave) * sizeof(float);
-    static_assert(NT == 42 && NT % kRelaxChunk == 0, "three filter chunks of 14 taps");
+    static constexpr size_t lds_bytes = ((size_t)tap_floats + mail_words + (size_t)(RING + MIR) * kWave) * sizeof(float);
+    static_assert(NT == 42, "the filter's load sequence is written out for 42 taps");
     static_assert(B % 4 == 0 && B >= DCL && B % 2 == 0, "16-byte loads per lane; the DC windows are the tail of a block");
+    static_assert(MIR <= 2 * B, "the mirrored slots are the first block and the head of the second");
     // reach: lag <= 52, first instant of a symbol <= 25 before the second, NT - 1 taps back
-    static_assert(52 + 1 + 25 + (NT - 1) <= (NBLK - 1) * B, "the filters would read the block being written");
+    static_assert(52 + 1 + 25 + (NT - 1) <= (NBLK - 2) * B, "the filters would read a block that is being written");
     static_assert(lds_bytes <= 80u * 1024u, "two workgroups per CU");
 };
 
@@ -96,109 +99,88 @@ __device__ __forceinline__ void sym_static_for_(F &&f, std::integer_sequence<int
 template <int N, typename F>
 __device__ __forceinline__ void sym_static_for(F &&f) { sym_static_for_(static_cast<F &&>(f), std::make_integer_sequence<int, N>{}); }
 
-// two DC-blocker outputs as packed f16 (round toward zero: a finite value never becomes an infinity)
-__device__ __forceinline__ uint32_t sym_pack(float a, float b)
-{
-    return __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(a, b));
-}
-__device__ __forceinline__ void sym_unpack(uint32_t w, float *a, float *b)
-{
-    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
-    const h2 h = __builtin_bit_cast(h2, w);
-    *a = (float)h.x; *b = (float)h.y;
-}
-
-// LDS byte address of the lowest window slot of chunk c (taps 14 c .. 14 c + 13) of a filter whose newest sample sits in
-// ring slot n: slots n - 14 c - 13 .. n - 14 c modulo RING, read upwards, moved into the mirror when they would wrap
-template <int RING>
-__device__ __forceinline__ uint32_t sym_chunk_addr(uint32_t wcol_lds, int n, int c)
-{
-    int top = n - kRelaxChunk * c;
-    top += top < 0 ? RING : 0;
-    top += top < kRelaxChunk - 1 ? RING : 0;              // slots RING .. RING + 12 repeat slots 0 .. 12
-    return wcol_lds + (uint32_t)(top - (kRelaxChunk - 1)) * (kWave * 4u);
-}
-
-// FskDemod::demod_now rx/demod.rs:156-164 at one instant, with the taps in registers.  The matched filter is a cisoid, h[i] = (2/N) e^{-j phi (N-1-i)}
-// (rx/waveform.rs:39-64), so its second half is the first one mirrored: h[N-1-k] = C conj(h[k]) with C = (N/2) h[0] (a unit
-// phasor; the host's f32 taps obey this to 7e-8).  For a real window w (w_i = the sample tap i meets)
-//     sum_i w_i h_i = A + C conj(B),   A = sum_{k<N/2} w_k h_k,   B = sum_{k<N/2} w_{N-1-k} h_k,
-// i.e. both halves use the SAME 21 taps per tone: 84 registers hold them for the whole launch, and a filter is 21 window
-// loads (two slots each) and 84 packed multiply-adds -- no tap loads (they were two thirds of the filter's LDS traffic and
-// every product waited for one).  Relaxed arithmetic: another association of the same sum.
+// FskDemod::demod_now rx/demod.rs:156-164 at one instant, with the taps in registers.  The matched filter is a cisoid, h[i] = (2/N) e^{-j a (N-1-i)}
+// (rx/waveform.rs:39-64), and only its output's magnitude is used, so it may be turned by a unit phasor: u[k] = h[k] e^{j a (N-1)/2}
+// has u[N-1-k] = conj(u[k]) (same_config.cpp derives u from the reference's f32 taps), and for a real window w (w_i = the
+// sample tap i meets)
+//     sum_i w_i u_i = sum_{k<N/2} (w_k + w_{N-1-k}) Re u_k  +  j sum_{k<N/2} (w_k - w_{N-1-k}) Im u_k.
+// Per k: ONE LDS load brings w_k and w_{N-1-k} (slots base + N-1-k and base + k of a ring whose first N - 1 slots are stored
+// twice, so nothing wraps), one packed add makes (sum, difference), and two packed multiply-adds serve the real parts of both
+// tones and the imaginary parts of both tones: 63 vector instructions and 21 loads for both filters (the A + C conj(B)
+// form of round 4: 84 multiply-adds and a complex fix-up per tone).  42 registers pairs hold the taps for the whole launch.
+// Relaxed arithmetic: another association of the same sum (rx/filter.rs:363-377 adds 42 products newest first).
 struct SymWin { float2v w0, w1, w2, w3, w4, w5, w6; };
-#define SYM_WLOAD(W_, wa_)                                                                                         \
-    asm volatile("ds_read2st64_b32 %[w0], %[wa] offset0:0 offset1:1\n\t"                                          \
-                 "ds_read2st64_b32 %[w1], %[wa] offset0:2 offset1:3\n\t"                                          \
-                 "ds_read2st64_b32 %[w2], %[wa] offset0:4 offset1:5\n\t"                                          \
-                 "ds_read2st64_b32 %[w3], %[wa] offset0:6 offset1:7\n\t"                                          \
-                 "ds_read2st64_b32 %[w4], %[wa] offset0:8 offset1:9\n\t"                                          \
-                 "ds_read2st64_b32 %[w5], %[wa] offset0:10 offset1:11\n\t"                                        \
-                 "ds_read2st64_b32 %[w6], %[wa] offset0:12 offset1:13"                                            \
+// pair K of group G: k = 7 G + K -> slots base + k (the sample tap N-1-k meets) and base + N-1-k (tap k)
+#define SYM_WLOAD_(W_, wa_, o0_, o1_, o2_, o3_, o4_, o5_, o6_, p0_, p1_, p2_, p3_, p4_, p5_, p6_)                     \
+    asm volatile("ds_read2st64_b32 %[w0], %[wa] offset0:" #o0_ " offset1:" #p0_ "\n\t"                           \
+                 "ds_read2st64_b32 %[w1], %[wa] offset0:" #o1_ " offset1:" #p1_ "\n\t"                           \
+                 "ds_read2st64_b32 %[w2], %[wa] offset0:" #o2_ " offset1:" #p2_ "\n\t"                           \
+                 "ds_read2st64_b32 %[w3], %[wa] offset0:" #o3_ " offset1:" #p3_ "\n\t"                           \
+                 "ds_read2st64_b32 %[w4], %[wa] offset0:" #o4_ " offset1:" #p4_ "\n\t"                           \
+                 "ds_read2st64_b32 %[w5], %[wa] offset0:" #o5_ " offset1:" #p5_ "\n\t"                           \
+                 "ds_read2st64_b32 %[w6], %[wa] offset0:" #o6_ " offset1:" #p6_                                     \
                  : [w0] "=&v"(W_.w0), [w1] "=&v"(W_.w1), [w2] "=&v"(W_.w2), [w3] "=&v"(W_.w3), [w4] "=&v"(W_.w4),   \
                    [w5] "=&v"(W_.w5), [w6] "=&v"(W_.w6)                                                             \
                  : [wa] "v"(wa_) : "memory")
+#define SYM_WLOAD0(W_, wa_) SYM_WLOAD_(W_, wa_, 0, 1, 2, 3, 4, 5, 6, 41, 40, 39, 38, 37, 36, 35)
+#define SYM_WLOAD1(W_, wa_) SYM_WLOAD_(W_, wa_, 7, 8, 9, 10, 11, 12, 13, 34, 33, 32, 31, 30, 29, 28)
+#define SYM_WLOAD2(W_, wa_) SYM_WLOAD_(W_, wa_, 14, 15, 16, 17, 18, 19, 20, 27, 26, 25, 24, 23, 22, 21)
 #define SYM_WWAIT(W_, n_) asm volatile("s_waitcnt lgkmcnt(" #n_ ")" : "+v"(W_.w0), "+v"(W_.w1), "+v"(W_.w2), "+v"(W_.w3), "+v"(W_.w4), "+v"(W_.w5), "+v"(W_.w6))
+// (lo, hi) = (w.hi + w.lo, w.hi - w.lo): the sample tap k meets is the pair's second word
+__device__ __forceinline__ float2v sym_sum_diff(float2v w)
+{
+    float2v r;
+    asm volatile("v_pk_add_f32 %0, %1, %1 op_sel:[1,0] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(w));
+    return r;
+}
 template <int NT>
 struct SymTaps {
     static constexpr int H = NT / 2;
-    static_assert(NT == 42, "three chunks of 14 taps; N even");
-    float2v tm[H], ts[H];                // taps 0 .. N/2 - 1: mark (re, im), space (re, im)
-    float2v cm, cs;                      // C per tone
+    static_assert(NT == 42, "three groups of 7 tap pairs");
+    float2v tc[H], ts[H];                // Re u_k (mark, space), Im u_k (mark, space)
     __device__ __forceinline__ void load(const float4 *__restrict__ taps)
     {
         sym_static_for<H>([&](auto k_) __attribute__((always_inline)) {
             constexpr int k = decltype(k_)::value;
-            const float4 t = taps[k];
-            tm[k] = float2v{t.x, t.y}; ts[k] = float2v{t.z, t.w};
+            const float4 t = taps[NT + k];
+            tc[k] = float2v{t.x, t.y}; ts[k] = float2v{t.z, t.w};
             // (wave-uniform values: left to itself the compiler keeps them in scalar registers, runs out of those, and
             // fetches every operand back with v_readlane -- they are vector operands of every product, so vector registers)
-            asm volatile("" : "+v"(tm[k]), "+v"(ts[k]));
+            asm volatile("" : "+v"(tc[k]), "+v"(ts[k]));
         });
-        cm = tm[0] * float2v{(float)H, (float)H};
-        cs = ts[0] * float2v{(float)H, (float)H};
-        asm volatile("" : "+v"(cm), "+v"(cs));
     }
     // |mark| - |space| clamped to +-1 (rx/demod.rs:156-164) at the instant whose sample sits in ring slot n
     template <int RING>
     __device__ __forceinline__ float demod(uint32_t wcol_lds, int n) const
     {
-        const uint32_t wa0 = sym_chunk_addr<RING>(wcol_lds, n, 0), wa1 = sym_chunk_addr<RING>(wcol_lds, n, 1), wa2 = sym_chunk_addr<RING>(wcol_lds, n, 2);
-        // [half A / B][parity of the tap]: two chains per sum
-        float2v am[2] = {{0.0f, 0.0f}, {0.0f, 0.0f}}, as_[2] = {{0.0f, 0.0f}, {0.0f, 0.0f}};
-        float2v bm[2] = {{0.0f, 0.0f}, {0.0f, 0.0f}}, bs[2] = {{0.0f, 0.0f}, {0.0f, 0.0f}};
+        int base = n - (NT - 1);
+        base += base < 0 ? RING : 0;                          // slots RING .. RING + NT - 2 repeat slots 0 .. NT - 2
+        const uint32_t wa = wcol_lds + (uint32_t)base * (kWave * 4u);
+        // [parity of k]: two chains per sum; .x mark, .y space
+        float2v re[2] = {{0.0f, 0.0f}, {0.0f, 0.0f}}, im[2] = {{0.0f, 0.0f}, {0.0f, 0.0f}};
         SymWin X, Y, Z;
-        SYM_WLOAD(X, wa0);
-        SYM_WLOAD(Y, wa1);
-        SYM_WLOAD(Z, wa2);
-        // chunk c: pair K = slots lowest + 2K (tap 14 c + 13 - 2K, odd) and lowest + 2K + 1 (tap 14 c + 12 - 2K, even)
-        auto chunk = [&](auto c_, const SymWin &W) __attribute__((always_inline)) {
-            constexpr int c = decltype(c_)::value;
+        SYM_WLOAD0(X, wa);
+        SYM_WLOAD1(Y, wa);
+        SYM_WLOAD2(Z, wa);
+        auto group = [&](auto g_, const SymWin &W) __attribute__((always_inline)) {
+            constexpr int g = decltype(g_)::value;
             auto pair = [&](auto K_, float2v w) __attribute__((always_inline)) {
-                constexpr int K = decltype(K_)::value;
-                constexpr int i_lo = kRelaxChunk * c + 13 - 2 * K, i_hi = i_lo - 1;         // tap indices the two slots meet
-                constexpr int k_lo = i_lo < H ? i_lo : NT - 1 - i_lo, k_hi = i_hi < H ? i_hi : NT - 1 - i_hi;
-                if constexpr (i_lo < H) { pk_fma_lo(am[i_lo & 1], w, tm[k_lo]); pk_fma_lo(as_[i_lo & 1], w, ts[k_lo]); }
-                else { pk_fma_lo(bm[i_lo & 1], w, tm[k_lo]); pk_fma_lo(bs[i_lo & 1], w, ts[k_lo]); }
-                if constexpr (i_hi < H) { pk_fma_hi(am[i_hi & 1], w, tm[k_hi]); pk_fma_hi(as_[i_hi & 1], w, ts[k_hi]); }
-                else { pk_fma_hi(bm[i_hi & 1], w, tm[k_hi]); pk_fma_hi(bs[i_hi & 1], w, ts[k_hi]); }
+                constexpr int k = 7 * g + decltype(K_)::value;
+                const float2v sd = sym_sum_diff(w);
+                pk_fma_lo(re[k & 1], sd, tc[k]);
+                pk_fma_hi(im[k & 1], sd, ts[k]);
             };
             pair(std::integral_constant<int, 0>{}, W.w0); pair(std::integral_constant<int, 1>{}, W.w1);
             pair(std::integral_constant<int, 2>{}, W.w2); pair(std::integral_constant<int, 3>{}, W.w3);
             pair(std::integral_constant<int, 4>{}, W.w4); pair(std::integral_constant<int, 5>{}, W.w5);
             pair(std::integral_constant<int, 6>{}, W.w6);
         };
-        SYM_WWAIT(X, 14); chunk(std::integral_constant<int, 0>{}, X);
-        SYM_WWAIT(Y, 7);  chunk(std::integral_constant<int, 1>{}, Y);
-        SYM_WWAIT(Z, 0);  chunk(std::integral_constant<int, 2>{}, Z);
-        auto magnitude = [&](float2v a0, float2v a1, float2v b0, float2v b1, float2v c) __attribute__((always_inline)) -> float {
-            const float2v a = a0 + a1, b = b0 + b1;
-            // a + c conj(b)
-            const float re = __builtin_fmaf(c.x, b.x, __builtin_fmaf(c.y, b.y, a.x));
-            const float im = __builtin_fmaf(c.y, b.x, __builtin_fmaf(-c.x, b.y, a.y));
-            return __builtin_amdgcn_sqrtf(__builtin_fmaf(re, re, im * im));
-        };
-        return __builtin_amdgcn_fmed3f(magnitude(am[0], am[1], bm[0], bm[1], cm) - magnitude(as_[0], as_[1], bs[0], bs[1], cs), -1.0f, 1.0f);
+        SYM_WWAIT(X, 14); group(std::integral_constant<int, 0>{}, X);
+        SYM_WWAIT(Y, 7);  group(std::integral_constant<int, 1>{}, Y);
+        SYM_WWAIT(Z, 0);  group(std::integral_constant<int, 2>{}, Z);
+        const float2v r = re[0] + re[1], i = im[0] + im[1];
+        const float2v q = __builtin_elementwise_fma(i, i, r * r);       // (|mark|^2, |space|^2)
+        return __builtin_amdgcn_fmed3f(__builtin_amdgcn_sqrtf(q.x) - __builtin_amdgcn_sqrtf(q.y), -1.0f, 1.0f);
     }
 };
 
@@ -210,15 +192,22 @@ struct SymTaps {
 // ---------------------------------------------------------------------------------------------------------------------
 template <typename SampleT, int CMODE>
 struct SymDc {
-    static constexpr int B = SymLayout<42>::B, DCL = SymLayout<42>::DCL;
+    static constexpr int B = SymLayout<42>::B, DCL = SymLayout<42>::DCL, RING = SymLayout<42>::RING;
     static constexpr uint32_t LP = kWave;
     // Everything is kept as aligned PAIRS (samples 2 i, 2 i + 1) and every access is a whole pair with a compile-time index:
     // the packed operations want aligned register pairs anyway, and an array that is read as pairs at both even and odd
     // offsets does not survive as registers (see sym_static_for).
     typedef float2v Pairs[B / 2];
-    float sum0, sum1;
-    float2v xp[DCL / 2], mp[DCL / 2];    // the last DCL inputs / first-stage averages, oldest first
+    // The DC blocker (rx/dcblock.rs:45-49, 104-108) is two moving averages of DCL = 16 samples:
+    //     sum0 += x - x[-16];  ma0 = sum0 / 16;  sum1 += ma0 - ma0[-16];  ma1 = sum1 / 16;  y = x[-15] - ma1.
+    // A division by 16 is exact, and adding, subtracting and rounding commute with a scaling by a power of two, so the second
+    // average may run on the UNSCALED first sums -- S1 = 16 sum1 exactly, sample for sample -- and y = x[-15] - S1 / 256 is one
+    // fused multiply-add whose only rounding is the reference's own (S1 / 256 is exact): the same bits with 3.5 vector
+    // instructions per sample instead of 5.  The state arrays keep the reference's scaling (load / store).
+    float sum0, sum1;                    // sum1: 16 x the reference's
+    float2v xp[DCL / 2], sp[DCL / 2];    // the last DCL inputs / first-stage SUMS, oldest first
     Pairs xa, xb;                        // inputs: block b waits in (b & 1 ? xb : xa)
+    uint32_t wpos = 0;                   // ring slot of the block written next
     const SampleT *xl = nullptr;         // CMODE 1: this lane's own stream
     uint32_t avail = 0;                  // ... and the blocks it holds
     bool done = false;                   // ... and whether the lane's piece has handed over: nothing it computes from here on is kept
@@ -258,7 +247,7 @@ struct SymDc {
     __device__ __forceinline__ void load(const State &S, const SampleT *__restrict__ x, uint32_t c, uint32_t C, uint32_t cin, uint32_t Cin,
                                          uint64_t counter0, uint32_t n_blocks)
     {
-        sum0 = S.dc_sum0[c]; sum1 = S.dc_sum1[c];
+        sum0 = S.dc_sum0[c]; sum1 = S.dc_sum1[c] * (float)DCL;
         const uint32_t dpos = (uint32_t)(counter0 % (uint64_t)DCL);
         sym_static_for<DCL / 2>([&](auto h_) __attribute__((always_inline)) {
             constexpr int h = decltype(h_)::value;
@@ -266,60 +255,72 @@ struct SymDc {
             if (s0 >= (uint32_t)DCL) s0 -= (uint32_t)DCL;
             if (s1 >= (uint32_t)DCL) s1 -= (uint32_t)DCL;
             xp[h] = float2v{(S.dc_ff_ring + (size_t)s0 * C)[c], (S.dc_ff_ring + (size_t)s1 * C)[c]};
-            mp[h] = float2v{(S.dc_fb_ring + (size_t)s0 * C)[c], (S.dc_fb_ring + (size_t)s1 * C)[c]};
+            sp[h] = float2v{(S.dc_fb_ring + (size_t)s0 * C)[c] * (float)DCL, (S.dc_fb_ring + (size_t)s1 * C)[c] * (float)DCL};
         });
         sym_static_for<B / 2>([&](auto h_) __attribute__((always_inline)) { xb[decltype(h_)::value] = float2v{0.0f, 0.0f}; });
         request(xa, x, 0u, n_blocks, cin, Cin);
     }
-    // DC blocker (rx/dcblock.rs:45-49, 104-108: the reference's operations in its order) of block `blk`, whose inputs are
-    // X; outputs to y[k * LP]
-    __device__ __forceinline__ void block(const Params &P, float *y, Pairs &X, uint32_t blk)
+    // DC blocker of block `blk`, whose inputs are X; outputs into the window ring's next block (S turns them into AGC
+    // outputs in place, one step later)
+    __device__ __forceinline__ void block(const Params &P, float *wcol, Pairs &X, uint32_t blk)
     {
         if constexpr (CMODE == 1) {
-            // per lane: its stream ends where the input does, and silence follows it
+            // per lane: its stream ends where the input does, and silence follows it (the last steps of a launch only)
             const bool live = blk < avail;
-            sym_static_for<B / 2>([&](auto h_) __attribute__((always_inline)) {
-                constexpr int h = decltype(h_)::value;
-                X[h] = float2v{live ? X[h].x : 0.0f, live ? X[h].y : 0.0f};
-            });
+            if (__builtin_amdgcn_ballot_w64(!live) != 0ull) {
+                sym_static_for<B / 2>([&](auto h_) __attribute__((always_inline)) {
+                    constexpr int h = decltype(h_)::value;
+                    X[h] = float2v{live ? X[h].x : 0.0f, live ? X[h].y : 0.0f};
+                });
+            }
         }
-        Pairs mnew;
-        const float2v inv = {P.dc_inv_len, P.dc_inv_len};
+        float *y = wcol + wpos * LP;
+        wpos += (uint32_t)B;
+        if (wpos == (uint32_t)RING) wpos = 0u;
+        Pairs snew;
+        constexpr float kScale = -1.0f / (float)(DCL * DCL);
+        static_assert(DCL == 16, "a power of two: the scalings above are exact");
+        const float2v nscale = {kScale, kScale};
+        float s1_last = 0.0f;                                          // S1 after the odd sample of the pair before
         sym_static_for<B / 2>([&](auto h_) __attribute__((always_inline)) {
             constexpr int h = decltype(h_)::value;                     // samples k = 2 h, 2 h + 1
-            // the input window before this block, oldest first, as pairs: 0 .. DCL/2 - 1 the history, then this block's inputs
+            // the windows before this block, oldest first, as pairs: 0 .. DCL/2 - 1 the history, then this block's
             auto xw = [&](auto i_) __attribute__((always_inline)) -> float2v {
                 constexpr int i = decltype(i_)::value;
                 if constexpr (i < DCL / 2) return xp[i]; else return X[i - DCL / 2];
             };
-            auto mw = [&](auto i_) __attribute__((always_inline)) -> float2v {
+            auto sw = [&](auto i_) __attribute__((always_inline)) -> float2v {
                 constexpr int i = decltype(i_)::value;
-                if constexpr (i < DCL / 2) return mp[i]; else return mnew[i - DCL / 2];
+                if constexpr (i < DCL / 2) return sp[i]; else return snew[i - DCL / 2];
             };
-            const float2v xo = xw(std::integral_constant<int, h>{}), xn = xw(std::integral_constant<int, h + 1>{});
+            const float2v xo = xw(std::integral_constant<int, h>{});   // inputs 2 h - 16, 2 h - 15
             const float2v d0 = X[h] - xo;
             const float s0a = sum0 + d0.x, s0b = s0a + d0.y;
             sum0 = s0b;
             const float2v s0 = {s0a, s0b};
-            const float2v ma0 = s0 * inv;
-            const float2v d1 = ma0 - mw(std::integral_constant<int, h>{});
+            snew[h] = s0;
+            const float2v d1 = s0 - sw(std::integral_constant<int, h>{});
             const float s1a = sum1 + d1.x, s1b = s1a + d1.y;
             sum1 = s1b;
-            const float2v s1 = {s1a, s1b};
-            const float2v ma1 = s1 * inv;
-            mnew[h] = ma0;
-            // the delayed input (front of the window after the push): window entries k + 1, k + 2
-            y[(2 * h) * LP] = xo.y - ma1.x;
-            y[(2 * h + 1) * LP] = xn.x - ma1.y;
+            // y[k] = x[k - 15] - S1[k] / 256: the pair (y[2 h - 1], y[2 h]) meets the ALIGNED input pair xo
+            if constexpr (h == 0) {
+                y[0] = __builtin_fmaf(s1a, kScale, xo.y);
+            } else {
+                const float2v yy = __builtin_elementwise_fma(float2v{s1_last, s1a}, nscale, xo);
+                y[(2 * h - 1) * LP] = yy.x; y[(2 * h) * LP] = yy.y;
+            }
+            s1_last = s1b;
+            if constexpr (h == B / 2 - 1) y[(B - 1) * LP] = __builtin_fmaf(s1b, kScale, xw(std::integral_constant<int, h + 1>{}).x);
         });
         sym_static_for<DCL / 2>([&](auto h_) __attribute__((always_inline)) {
             constexpr int h = decltype(h_)::value;
-            xp[h] = X[(B - DCL) / 2 + h]; mp[h] = mnew[(B - DCL) / 2 + h];
+            xp[h] = X[(B - DCL) / 2 + h]; sp[h] = snew[(B - DCL) / 2 + h];
         });
     }
     __device__ __forceinline__ void store(const State &S, uint32_t c, uint32_t C, uint64_t counter1)
     {
-        S.dc_sum0[c] = sum0; S.dc_sum1[c] = sum1;
+        constexpr float inv = 1.0f / (float)DCL;
+        S.dc_sum0[c] = sum0; S.dc_sum1[c] = sum1 * inv;
         const uint32_t dpos = (uint32_t)(counter1 % (uint64_t)DCL);
         sym_static_for<DCL / 2>([&](auto h_) __attribute__((always_inline)) {
             constexpr int h = decltype(h_)::value;
@@ -327,104 +328,101 @@ struct SymDc {
             if (s0 >= (uint32_t)DCL) s0 -= (uint32_t)DCL;
             if (s1 >= (uint32_t)DCL) s1 -= (uint32_t)DCL;
             (S.dc_ff_ring + (size_t)s0 * C)[c] = xp[h].x; (S.dc_ff_ring + (size_t)s1 * C)[c] = xp[h].y;
-            (S.dc_fb_ring + (size_t)s0 * C)[c] = mp[h].x; (S.dc_fb_ring + (size_t)s1 * C)[c] = mp[h].y;
+            (S.dc_fb_ring + (size_t)s0 * C)[c] = sp[h].x * inv; (S.dc_fb_ring + (size_t)s1 * C)[c] = sp[h].y * inv;
         });
     }
 };
 
 // ---------------------------------------------------------------------------------------------------------------------
-// S: AGC and window push, with the packed DC-blocker outputs of its last three blocks (the gain a lock freezes)
+// S: AGC over the window ring's newest block, in place (T left the DC blocker's outputs there), and the gain a lock freezes
 // ---------------------------------------------------------------------------------------------------------------------
 struct SymAgc {
     static constexpr int B = SymLayout<42>::B, RING = SymLayout<42>::RING, MIR = SymLayout<42>::MIR;
     static constexpr uint32_t LP = kWave;
     float gain;
     bool locked;                         // this wavefront's belief of the AGC lock
-    uint32_t ysh[3][B / 2];              // DC-blocker outputs of the last three blocks, packed f16: [0] newest
-    float g0[3];                         // the AGC gain each of them started with
-    uint32_t wnext;                      // ring position of the block produced next
-    uint32_t last_blk;                   // the block in history slot 0
+    float g0a, g0b, g0c;                 // the AGC gain the last three blocks started with: a newest (scalars: an array indexed by a lane's block ends up in scratch memory)
+    uint32_t wnext;                      // ring position of the block processed next
+    uint32_t last_blk;                   // the block g0a belongs to
 
     __device__ __forceinline__ void load(const Params &P, const State &S, uint32_t c, uint32_t C, uint64_t counter0, float *wcol)
     {
         // the window the last launch left: sample counter0 - m sits in the state's slot (counter0 - m) mod win_ring; the
-        // launch's first sample goes to ring slot 0, so it belongs in slot RING - m (never one of the mirrored slots)
+        // launch's first sample goes to ring slot 0, so it belongs in slot RING - m (never one of the mirrored slots, nor one
+        // of the two blocks T writes before the filters first run)
         const uint32_t G = P.win_ring;
 #pragma unroll 2
         for (uint32_t m = 1; m <= G; ++m) {
             const uint32_t g = (uint32_t)(counter0 - (uint64_t)m) & (G - 1u);
             const float *row = S.win_ring + (size_t)g * C;
-            if (m <= (uint32_t)(RING - B)) wcol[((uint32_t)RING - m) * LP] = row[c];
+            if (m <= (uint32_t)(RING - 2 * B)) wcol[((uint32_t)RING - m) * LP] = row[c];
         }
         gain = S.agc_gain[c];
         locked = (S.flags[c] & F_AGC_LOCKED) != 0u;
-#pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            g0[j] = gain;
-#pragma unroll
-            for (int k = 0; k < B / 2; ++k) ysh[j][k] = 0u;
-        }
+        g0a = gain; g0b = gain; g0c = gain;
         wnext = 0; last_blk = 0;
     }
 
-    // AGC and window push of block `blk`, whose DC-blocker outputs are y[k * LP]
-    __device__ __forceinline__ void block(const Params &P, float *wcol, const float *y, uint32_t blk)
+    // AGC (rx/agc.rs:72-77, relaxed: same_relaxed_common.h agc_step_relaxed) of block `blk`, whose DC-blocker outputs wait in
+    // the ring's block at wnext; the AGC outputs replace them
+    __device__ __forceinline__ void block(const Params &P, float *wcol, uint32_t blk)
     {
-        float yv[B];
-#pragma unroll
-        for (int k = 0; k < B; ++k) yv[k] = y[k * LP];
-        // history moves on by one block
-#pragma unroll
-        for (int k = 0; k < B / 2; ++k) { ysh[2][k] = ysh[1][k]; ysh[1][k] = ysh[0][k]; }
-        g0[2] = g0[1]; g0[1] = g0[0];
-        g0[0] = gain; last_blk = blk;
         float *wblk = wcol + wnext * LP;
-        const bool mirror = wnext == 0u;                               // wave-uniform
+        float2v yv[B / 2];
+#pragma unroll
+        for (int h = 0; h < B / 2; ++h) yv[h] = float2v{wblk[(2 * h) * LP], wblk[(2 * h + 1) * LP]};
+        g0c = g0b; g0b = g0a;
+        g0a = gain; last_blk = blk;
         const float bw = locked ? 0.0f : P.agc_bw;
-        float head[MIR + 1];
+        float2v ov[B / 2];
 #pragma unroll
-        for (int k = 0; k < B; k += 2) {
-            ysh[0][k / 2] = sym_pack(yv[k], yv[k + 1]);
-            const float o0 = agc_step_relaxed(P, yv[k], gain, bw);
-            const float o1 = agc_step_relaxed(P, yv[k + 1], gain, bw);
-            wblk[k * LP] = o0; wblk[(k + 1) * LP] = o1;
-            if (k < MIR) head[k] = o0;
-            if (k + 1 < MIR) head[k + 1] = o1;
+        for (int h = 0; h < B / 2; ++h) {
+            // out = y * gain;  gain <- clamp(gain (1 - bw |y|) + bw): two operations on the gain's chain per sample, the
+            // two products of a pair as one packed multiply
+            const float a0 = __builtin_fmaf(-bw, fabsf(yv[h].x), 1.0f), a1 = __builtin_fmaf(-bw, fabsf(yv[h].y), 1.0f);
+            const float g1 = __builtin_amdgcn_fmed3f(__builtin_fmaf(gain, a0, bw), P.agc_min, P.agc_max);
+            const float g2 = __builtin_amdgcn_fmed3f(__builtin_fmaf(g1, a1, bw), P.agc_min, P.agc_max);
+            ov[h] = yv[h] * float2v{gain, g1};
+            gain = g2;
+            wblk[(2 * h) * LP] = ov[h].x; wblk[(2 * h + 1) * LP] = ov[h].y;
         }
-        if (mirror) {
+        // ring slots 0 .. MIR - 1 (the first block and the head of the second) once more behind the ring
+        if (wnext == 0u) {                                             // wave-uniform
 #pragma unroll
-            for (int k = 0; k < MIR; ++k) wblk[(k + RING) * LP] = head[k];
+            for (int h = 0; h < B / 2; ++h) { wblk[(2 * h + RING) * LP] = ov[h].x; wblk[(2 * h + 1 + RING) * LP] = ov[h].y; }
+        } else if (wnext == (uint32_t)B) {
+#pragma unroll
+            for (int k = 0; k < MIR - B; ++k) wblk[(k + RING) * LP] = (k & 1) ? ov[k / 2].y : ov[k / 2].x;
         }
         wnext += B;
         if (wnext == (uint32_t)RING) wnext = 0;
     }
 
-    // the AGC gain after sample `fk` of block `b` (b <= last_blk, this lane's belief of the lock unchanged since then): the
-    // recurrence once more from the block's start, over its packed DC outputs, nothing written.  Further back than the history
-    // reaches: the oldest block's start.
-    template <int J>
-    __device__ __forceinline__ float gain_in(const Params &P, int fk) const
+    // The AGC gain after sample `fk` of block `b` (b <= last_blk, this lane's AGC unlocked since then): the reference's own
+    // recurrence, gain += bw (1 - |out|) (rx/agc.rs:72-77), once more from the block's start over the AGC OUTPUTS, which are
+    // what the window ring holds -- f32, whatever the input's scale, and no history of its own (round 4 kept three blocks of
+    // DC-blocker outputs as packed f16 in 54 registers, rotated through 64 moves a step, for this).  Further back than three
+    // blocks: the oldest one's start.  Rare (a lock: once per burst and lane), so a loop.
+    __device__ __forceinline__ float gain_at(const Params &P, const float *wcol, uint32_t b, int fk) const
+    { return gain_at_(P, wcol, wnext, last_blk - b, g0a, g0b, g0c, fk); }
+    // (the three gains BY VALUE: selected through the struct's members the compiler selects an address, and the whole struct
+    // stays in scratch memory)
+    static __device__ __forceinline__ float gain_at_(const Params &P, const float *wcol, uint32_t wnext_, uint32_t j, float ga, float gb, float gc, int fk)
     {
-        float g = g0[J];
+        float g = j == 0u ? ga : (j == 1u ? gb : gc);
+        if (j > 2u) return g;
+        // block last_blk sits B slots before wnext
+        int pos = (int)wnext_ - (int)(j + 1u) * B;
+        pos += pos < 0 ? RING : 0;
+        const float *w = wcol + (uint32_t)pos * LP;
         const float bw = P.agc_bw;
-#pragma unroll
-        for (int k = 0; k < B; k += 2) {
-            float y0, y1;
-            sym_unpack(ysh[J][k / 2], &y0, &y1);
-            const float a0 = __builtin_fmaf(-bw, fabsf(y0), 1.0f), a1 = __builtin_fmaf(-bw, fabsf(y1), 1.0f);
-            const float g1 = __builtin_amdgcn_fmed3f(__builtin_fmaf(g, a0, bw), P.agc_min, P.agc_max);
+#pragma unroll 4
+        for (int k = 0; k < B; ++k) {
+            const float o = w[k * LP];
+            const float g1 = __builtin_amdgcn_fmed3f(__builtin_fmaf(bw, 1.0f - fabsf(o), g), P.agc_min, P.agc_max);
             g = (k <= fk) ? g1 : g;
-            const float g2 = __builtin_amdgcn_fmed3f(__builtin_fmaf(g, a1, bw), P.agc_min, P.agc_max);
-            g = (k + 1 <= fk) ? g2 : g;
         }
         return g;
-    }
-    __device__ __forceinline__ float gain_at(const Params &P, uint32_t b, int fk) const
-    {
-        const uint32_t j = last_blk - b;
-        if (j == 0u) return gain_in<0>(P, fk);
-        if (j == 1u) return gain_in<1>(P, fk);
-        return gain_in<2>(P, j == 2u ? fk : -1);
     }
 
     __device__ __forceinline__ void store(const Params &P, const State &S, uint32_t c, uint32_t C, uint64_t counter1, const float *wcol)
@@ -510,7 +508,7 @@ __global__ __launch_bounds__(4 * kWave, 2) void demod_sym_kernel(Params P, State
             n_nominal = may_leave ? K.nominal_blocks : n_blocks;
         }
     }
-    // LDS: taps | mailboxes | DC-blocker outputs [2][36][64] | window ring [RING + MIR][64]
+    // LDS: taps | mailboxes | window ring [RING + MIR][64]
     float4 *tlds = reinterpret_cast<float4 *>(lds);
     lds_u32 *mail = (lds_u32 *)(lds + LY::tap_floats);
     lds_u32 *symbox = mail;                                    // [2][5][64]
@@ -524,8 +522,7 @@ __global__ __launch_bounds__(4 * kWave, 2) void demod_sym_kernel(Params P, State
     lds_u32 *donebox = tkbox + kIoRingWords;                   // [64] Y -> T: the lane's piece has handed over (its input is no longer needed)
     lds_u32 *chunkbox = fbbox + kWave + 2u;                    // [2], in the first feedback box's padding
     lds_u32 *seqbox = fbbox + kWave + 4u;                      // S's progress with the first instants' filters: 2 * step + pass
-    float *yring = lds + LY::tap_floats + LY::mail_words;      // [2][kB][64]: block b in half b & 1
-    float *wring = yring + LY::yring_floats;                   // ring slot 0
+    float *wring = lds + LY::tap_floats + LY::mail_words;     // ring slot 0
     float *wcol = wring + lane;
     const uint64_t counter1 = counter0 + (uint64_t)n_blocks * kB;
     // Steps: T computes the DC blocker of block s + 1 in step s (block 0 before the first), S the AGC of block s in step
@@ -565,7 +562,7 @@ __global__ __launch_bounds__(4 * kWave, 2) void demod_sym_kernel(Params P, State
         bool left = false;
         for (uint32_t s = 0; s < n_steps; ++s) {
             if (s >= 1u && s <= last_t_step) filter_a(s, 2u * s + 1u);
-            if (s < n_blocks && !PROF_SKIP(P, 64)) M.block(P, wcol, yring + ((s & 1u) * (uint32_t)kB) * LP + lane, s);
+            if (s < n_blocks && !PROF_SKIP(P, 64)) M.block(P, wcol, s);
             P3_LAP(p3_work);
             lds_barrier();                                             // A
             P3_LAP(p3_wait);
@@ -582,7 +579,7 @@ __global__ __launch_bounds__(4 * kWave, 2) void demod_sym_kernel(Params P, State
                             // the gain freezes at the value it had after the symbol's sample
                             const int64_t idx = sym_index(s - 1u, v >> 8);
                             const uint32_t b = (uint32_t)(idx / kB);
-                            M.gain = M.gain_at(P, b, (int)(idx - (int64_t)b * kB));
+                            M.gain = M.gain_at(P, wcol, b, (int)(idx - (int64_t)b * kB));
                         }
                         M.locked = new_locked;
                     }
@@ -612,7 +609,7 @@ __global__ __launch_bounds__(4 * kWave, 2) void demod_sym_kernel(Params P, State
         donebox[lane] = 0u;
         // prologue: block 0's DC outputs
         if (n_blocks > 1u) D.request(D.xb, x, 1u, n_blocks, cin, Cin);
-        D.block(P, yring + lane, D.xa, 0u);
+        D.block(P, wcol, D.xa, 0u);
         lds_barrier();
         P3_T0();
         uint32_t stop_at = 0xffffffffu;
@@ -620,9 +617,8 @@ __global__ __launch_bounds__(4 * kWave, 2) void demod_sym_kernel(Params P, State
             constexpr int BUF = decltype(buf)::value;                  // block s + 1 waits in buffer BUF = (s + 1) & 1
             if constexpr (CMODE == 1) D.done = donebox[lane] != 0u;
             if (s + 1u < n_blocks && !PROF_SKIP(P, 128)) {
-                float *y = yring + (((s + 1u) & 1u) * (uint32_t)kB) * LP + lane;
-                if constexpr (BUF == 0) { D.request(D.xb, x, s + 2u, n_blocks, cin, Cin); D.block(P, y, D.xa, s + 1u); }
-                else { D.request(D.xa, x, s + 2u, n_blocks, cin, Cin); D.block(P, y, D.xb, s + 1u); }
+                if constexpr (BUF == 0) { D.request(D.xb, x, s + 2u, n_blocks, cin, Cin); D.block(P, wcol, D.xa, s + 1u); }
+                else { D.request(D.xa, x, s + 2u, n_blocks, cin, Cin); D.block(P, wcol, D.xb, s + 1u); }
             }
             // the link event and the wake-ups of what Y handed over in the last step
             if (s >= 3u && !PROF_SKIP(P, 8)) {

@@ -76,7 +76,7 @@ def test_contract_against_strict_mode(sa, n_ch, seconds, noise):
     ref = strict_events(sa, x, rate)
     _, got = run(sa, x)
     assert_contract(sa, got, ref, rate, n_ch, lambda c: sa.synth_payload(seed, c), exact_bursts=(noise == 0.0),
-                    garbled_per_mille=(1 if noise > 0.0 else 0), what=f"{n_ch} channels")
+                    garbled_per_mille=(1 if noise > 0.0 else 0), what=f"{n_ch} channels", t_end=n)
 
 
 def test_other_input_forms_and_repeatability(sa):
@@ -93,7 +93,7 @@ def test_other_input_forms_and_repeatability(sa):
         assert np.array_equal(a["bytes"], other["bytes"])
     ref = strict_events(sa, x, rate)
     _, c = run(sa, x, layout="cm")
-    assert_contract(sa, c, ref, rate, n_ch, lambda ch: sa.synth_payload(seed, ch), exact_bursts=True, what="channel-major")
+    assert_contract(sa, c, ref, rate, n_ch, lambda ch: sa.synth_payload(seed, ch), exact_bursts=True, what="channel-major", t_end=22050 * 6)
 
 
 def test_state_is_carried_from_call_to_call(sa):
