@@ -51,6 +51,8 @@
 
 #include <cmath>
 #include <cstdlib>
+#include <mutex>
+#include <set>
 #include <type_traits>
 #include <utility>
 
@@ -75,18 +77,20 @@ template <int NT> struct SymLayout {
     static constexpr uint32_t sym_words = 5u * kWave;             // per parity: header, zero, sym, terr, until
     static constexpr uint32_t fb_words = kWave + 32u;             // per parity: one word per lane + the any-flag
     static constexpr uint32_t io_words = 3u * kWave;              // per parity: symbol word, burst-pool slot, burst length
-    static constexpr uint32_t pos_words = 2u * kWave;             // per parity: ring slots of the symbol's two instants (-1: none)
-    static constexpr uint32_t mail_words = 2u * sym_words + 2u * fb_words + 2u * io_words + 2u * kWave +   // + final TED phase, wake-up flag
-                                           2u * pos_words + kWave +                                       // + the first instant's soft sample, from S
-                                           kIoRingWords +                                                 // + T's deadline ring and its count
-                                           kWave;                                                         // + Y -> T: this lane has handed over
+    static constexpr uint32_t mail_words = 2u * sym_words + 2u * kWave +           // E -> Y1, Y1 -> Y2
+                                           4u * fb_words + 2u * io_words +          // feedback from Y1 and from Y2, Y2 -> A
+                                           3u * kWave +                             // final TED phase, wake-up flag, Y1's flag bits
+                                           2u * kWave + kWave +                     // ring slot of the symbol's first instant (per parity), its soft sample
+                                           kIoRingWords +                           // A's deadline ring and its count
+                                           kWave +                                  // Y2 -> T: this lane has handed over
+                                           kWave;                                   // the roles' progress words (six of them)
     static constexpr size_t lds_bytes = ((size_t)tap_floats + mail_words + (size_t)(RING + MIR) * kWave) * sizeof(float);
     static_assert(NT == 42, "the filter's load sequence is written out for 42 taps");
     static_assert(B % 4 == 0 && B >= DCL && B % 2 == 0, "16-byte loads per lane; the DC windows are the tail of a block");
     static_assert(MIR <= 2 * B, "the mirrored slots are the first block and the head of the second");
     // reach: lag <= 52, first instant of a symbol <= 25 before the second, NT - 1 taps back
     static_assert(52 + 1 + 25 + (NT - 1) <= (NBLK - 2) * B, "the filters would read a block that is being written");
-    static_assert(lds_bytes <= 80u * 1024u, "two workgroups per CU");
+    static_assert(lds_bytes <= 80u * 1024u, "two groups of 64 columns per workgroup and CU");
 };
 
 // f(integral_constant<int, 0>) ... f(integral_constant<int, N - 1>): a loop that is straight-line code from the start.  A
@@ -439,43 +443,239 @@ struct SymAgc {
     }
 };
 
-// Y's context: RelaxFastCtx (equalizer and its snapshot in registers, relaxed equalizer step) with the squelch's sample
-// history in global memory.  The two samples the NEXT symbol's equalizer step takes (rx_symbol: slots +16 / +17 from the
-// squelch's write position, i.e. +18 / +19 from this symbol's) are requested where this symbol's samples are stored: a
-// global round trip is a step long under load, and on gfx950 loads and stores retire in one queue (vmcnt) -- requested
-// at the end of the step they would also wait for the framer's scattered byte stores issued before them.  Only this lane's
-// own symbols write its history, and never those two slots before they are read: they cannot go stale.
+// ---------------------------------------------------------------------------------------------------------------------
+// Y1: squelch and equalizer of one symbol (rx/codesquelch.rs:228-304, rx/equalize.rs:249-308), the relaxed-only cut of
+// same_dev_common.h's rx_symbol.  The strict kernels keep that function bit for bit; here the symbol path is TWO wavefronts --
+// Y1 = squelch + equalizer, Y2 = framer + link state + bursts -- one step apart, so what the framer decides (squelch.lock(true)
+// on Reading, end() on NoCarrier / Burst: receiver.rs:457-471) reaches the squelch one symbol late.  Neither can matter to a
+// symbol in between: a locked squelch only stops looking for a NEW sync, which needs 32 matching preamble bits, and after an
+// end() the byte clock Y1 kept running for one more symbol is overwritten; the equalizer step it took is undone by the reset.
+// ---------------------------------------------------------------------------------------------------------------------
+// Y1 -> Y2, one word per lane and step
+enum : uint32_t { YM_VALID = 1u, YM_READY = 2u, YM_ADJUSTED = 4u, YM_READING = 8u, YM_DROP = 16u, YM_BYTE_SHIFT = 8, YM_OFF_SHIFT = 16 };
+// feedback words (Y1 / Y2 -> S, E; Y2 -> Y1): bit 0 valid, 1 AGC locked, 2 loop bandwidth locked, 3 end(), 8.. the symbol's offset;
+// bit 4 (Y2 -> Y1 only, without bit 0): squelch.lock(true)
+enum : uint32_t { FB_VALID = 1u, FB_AGC = 2u, FB_BW = 4u, FB_END = 8u, FB_SQLOCK = 16u };
+
 template <int NFF, int NFB>
-struct SymCtx : RelaxFastCtx<NFF, NFB> {
+struct SymSquelch {
+    Lane L;                              // sq_*, eq_word, eq_count, flags (AGC / BW / squelch locks, equalizer mode and bits)
+    uint32_t nsym;                       // low word of the symbol counter
+    float ffc[NFF], ffw[NFF], fbc[NFB], fbw[NFB];
+    float sffc[NFF], sffw[NFF], sfbc[NFB], sfbw[NFB];   // equalizer at the last completed byte
+    // The squelch's sample history stays in global memory (LDS is full): one wave-uniform base and 32-bit byte offsets, so an
+    // access is two vector instructions (round 4: a 64-bit multiply-add and a 64-bit add each).  The two samples the NEXT
+    // symbol's equalizer step takes (slots +16 / +17 from the squelch's write position, i.e. +18 / +19 from this symbol's) are
+    // requested where this symbol's are stored: a global round trip is a step long under load.  Only this lane's own symbols
+    // write its history, and never those two slots before they are read.
+    char *hbase;
+    uint32_t hcol4, hrow4;               // byte offset of the lane's column; bytes between two slots
     float nxt0 = 0.0f, nxt1 = 0.0f;
-    __device__ __forceinline__ void hist_put(uint32_t slot, float v)
+    __device__ __forceinline__ float *hptr(uint32_t slot) const { return reinterpret_cast<float *>(hbase + (size_t)(__umul24(slot, hrow4) + hcol4)); }
+
+    __device__ __forceinline__ void eq_reset()
     {
-        if ((slot & 1u) == 0u) {
-            nxt0 = this->hist[(size_t)((slot + 18u) & 63u) * this->hstride];
-            nxt1 = this->hist[(size_t)((slot + 19u) & 63u) * this->hstride];
+#pragma unroll
+        for (int i = 0; i < NFF; ++i) { ffc[i] = (i == 0) ? 1.0f : 0.0f; ffw[i] = 0.0f; }
+#pragma unroll
+        for (int i = 0; i < NFB; ++i) { fbc[i] = (i == 0) ? 1.0f : 0.0f; fbw[i] = 0.0f; }
+    }
+    // what SameReceiver::end (receiver.rs:479-490) does to this wavefront's state; S and E get theirs as feedback
+    __device__ __forceinline__ void end()
+    {
+        L.flags &= ~(F_AGC_LOCKED | F_SQ_LOCK | F_BW_LOCKED);
+        L.sq_clock = -1;                                   // squelch.end() rx/codesquelch.rs:336-339
+        eq_reset();                                        // Equalizer::reset rx/equalize.rs:191-196 (mode preserved)
+    }
+    // One symbol.  Returns the word for Y2; *fb = the feedback word for S and E (0: none).
+    __device__ __forceinline__ uint32_t symbol(const Params &P, float zero, float sym, uint32_t off, uint32_t *fb)
+    {
+        const uint32_t before = L.flags & (F_AGC_LOCKED | F_BW_LOCKED);
+        // --- CodeAndPowerSquelch::input rx/codesquelch.rs:228-304
+        const uint32_t slot = (2u * nsym) & 63u;
+        const float eq_in0 = nxt0, eq_in1 = nxt1;          // history slots slot + 16 / + 17, requested a symbol ago
+        {
+            float *pn = hptr((slot + 18u) & 63u), *pw = hptr(slot);
+            nxt0 = pn[0]; nxt1 = *reinterpret_cast<float *>(reinterpret_cast<char *>(pn) + hrow4);
+            pw[0] = zero; *reinterpret_cast<float *>(reinterpret_cast<char *>(pw) + hrow4) = sym;
         }
-        this->hist[(size_t)slot * this->hstride] = v;
+        const uint32_t fill = min(64u, L.sq_fill + 2u);
+        L.sq_fill = fill;
+        L.sq_data = (L.sq_data >> 1) | ((sym >= 0.0f) ? 0x80000000u : 0u);      // CodeCorrelator::search :421-428
+        const uint32_t nerr = __popc(P.sync_word ^ L.sq_data);
+        const float pwr = fmaxf(__builtin_fmaf(__builtin_fmaf(sym, sym, -L.sq_power), P.sq_bw, L.sq_power), 0.0f);   // PowerTracker::track :483-488
+        L.sq_power = pwr;
+        L.sq_phist = (L.sq_phist << 1) | ((pwr >= P.sq_power_close) ? 1u : 0u);
+        nsym += 1u;
+        const int32_t clock_before = L.sq_clock;           // byte clock before this symbol (-1: no sync)
+        const bool full = fill >= 64u;                     // sample_history.is_full() :237
+        const bool locked = (L.flags & F_SQ_LOCK) != 0u;
+        const bool sync_now = full & !locked & (nerr <= P.sq_max_errors) & (pwr >= P.sq_power_open);     // :244-265
+        const bool adjusted = sync_now & (clock_before != 0);
+        const bool drop = full & !sync_now & (clock_before >= 0) & ((L.sq_phist & 0x80000000u) == 0u);  // :266-273
+        int32_t clk = sync_now ? 0 : clock_before;
+        clk = drop ? -1 : clk;
+        const bool ready = full & (clk == 0);              // :277-303 byte clock
+        const bool reading = full & (clk > 0);
+        clk = ready ? 1 : (reading ? ((clk + 1) & 7) : clk);
+        L.sq_clock = clk;
+        // Equalizer schedule (same_dev_common.h rx_symbol): while a channel is in byte sync, symbol j of the next byte is
+        // equalized during the j-th symbol before the byte is due -- the reference equalizes all eight when it is due,
+        // rx/codesquelch.rs:283-299, over the OLDEST 16 history samples, which were known 24 symbols earlier.
+        if ((clock_before >= 0) & !adjusted & (ready | reading)) {
+            const uint32_t j = (uint32_t)(clock_before + 7) & 7u;   // clock 1..7 -> symbol 0..6, clock 0 -> 7
+            const uint32_t ebit = eq_symbol_relaxed<NFF, NFB>(P, L, ffc, ffw, fbc, fbw, eq_in0, eq_in1);
+            uint32_t bits = (j == 0u) ? 0u : ((L.flags & F_EQ_BITS_MASK) >> F_EQ_BITS_SHIFT);
+            bits |= ebit << j;
+            L.flags = (L.flags & ~F_EQ_BITS_MASK) | (bits << F_EQ_BITS_SHIFT);
+        }
+        uint32_t byte = (L.flags & F_EQ_BITS_MASK) >> F_EQ_BITS_SHIFT;
+        if (ready & adjusted) {
+            // sync acquired or the byte clock re-aligned (receiver.rs:423-446): lock AGC and loop bandwidth, train on the sync
+            // word over the oldest 16 samples of the history (rx/codesquelch.rs:288-294)
+            if (clock_before >= 0) {                       // drop the symbols equalized ahead for a byte the reference never forms
+#pragma unroll
+                for (int i = 0; i < NFF; ++i) { ffc[i] = sffc[i]; ffw[i] = sffw[i]; }
+#pragma unroll
+                for (int i = 0; i < NFB; ++i) { fbc[i] = sfbc[i]; fbw[i] = sfbw[i]; }
+            }
+            L.flags |= F_AGC_LOCKED | F_BW_LOCKED;
+            L.flags = (L.flags & ~F_EQ_MODE_MASK) | (2u << F_EQ_MODE_SHIFT);   // equalizer.train()
+            L.eq_word = P.sync_word; L.eq_count = 0;
+            const uint32_t head = (2u * nsym) & 63u;       // oldest sample
+            float samples[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) samples[i] = *hptr((head + (uint32_t)i) & 63u);
+            byte = 0u;
+#pragma unroll 1
+            for (int b = 0; b < 8; ++b) byte |= eq_symbol_relaxed<NFF, NFB>(P, L, ffc, ffw, fbc, fbw, samples[2 * b], samples[2 * b + 1]) << b;
+        }
+        // a re-alignment is still possible: remember the equalizer as of this completed byte (a byte the framer ends the burst
+        // on takes a snapshot nobody restores: the end() that follows leaves no byte clock to re-align)
+        if (ready & !(L.flags & F_SQ_LOCK)) {
+#pragma unroll
+            for (int i = 0; i < NFF; ++i) { sffc[i] = ffc[i]; sffw[i] = ffw[i]; }
+#pragma unroll
+            for (int i = 0; i < NFB; ++i) { sfbc[i] = fbc[i]; sfbw[i] = fbw[i]; }
+        }
+        if (drop) end();                                   // lost sync: receiver.rs:410-422 -> end()
+        const uint32_t after = L.flags & (F_AGC_LOCKED | F_BW_LOCKED);
+        *fb = (after != before || drop) ? (FB_VALID | ((after & F_AGC_LOCKED) ? FB_AGC : 0u) | ((after & F_BW_LOCKED) ? FB_BW : 0u) | (drop ? FB_END : 0u) | (off << 8)) : 0u;
+        return YM_VALID | (ready ? YM_READY : 0u) | (adjusted ? YM_ADJUSTED : 0u) | (reading ? YM_READING : 0u) | (drop ? YM_DROP : 0u) |
+               (byte << YM_BYTE_SHIFT) | (off << YM_OFF_SHIFT);
     }
 };
 
 // ---------------------------------------------------------------------------------------------------------------------
-template <int NFF, int NFB, typename SampleT, int CMODE>
-__global__ __launch_bounds__(4 * kWave, 2) void demod_sym_kernel(Params P, State S, Output O, const float4 *__restrict__ taps,
-                                                                 const SampleT *__restrict__ x, uint32_t n_blocks, uint64_t counter0,
-                                                                 PipeChunks K)
+// Y2: framer and link state of the symbol Y1 handed over (receiver.rs:410-471, rx/framing.rs:109-164).  Returns the LinkState
+// kind; *fb2 = what goes back to Y1 (squelch.lock(true)) and, for an end(), to S and E as well.
+// ---------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t sym_framer_step(const Params &P, Lane &L, const State &S, uint32_t c, uint32_t m, uint32_t *burst_len, uint32_t *fb2)
 {
+    const bool ready = (m & YM_READY) != 0u, reading = (m & YM_READING) != 0u;
+    uint32_t link;
+    if (ready) {
+        const uint32_t byte = (m >> YM_BYTE_SHIFT) & 0xffu;
+        if (m & YM_ADJUSTED) {
+            uint32_t blen = 0;
+            const uint32_t out = framer_end(L, &blen);      // Framer::input restart arm rx/framing.rs:109-123
+            if (out == 3u) *burst_len = blen;
+            fr_set_state(L, 1); L.fr_word = 0; L.fr_count = 0;
+            uint32_t dummy = 0;
+            (void)framer_feed(P, L, S, c, byte, &dummy);
+            link = (out == 3u) ? 3u : 1u;
+        } else {
+            link = framer_feed(P, L, S, c, byte, burst_len);
+        }
+        if (link == 2u) *fb2 = FB_SQLOCK;                   // squelch.lock(true) receiver.rs:462
+        else if (link == 0u || link == 3u) *fb2 = FB_VALID | FB_END | (((m >> YM_OFF_SHIFT) & 127u) << 8);   // end() receiver.rs:466-470
+    } else {
+        // Reading: framer.state(); NoCarrier / DroppedCarrier: framer.end()  receiver.rs:410-422.  (The symbol after an
+        // end() arrives as "reading" -- Y1 had not heard of it -- and finds the framer idle: NoCarrier, as in the reference.)
+        const uint32_t fst = fr_state(L);
+        const bool was_reading_burst = !reading & (fst == 2u);
+        link = reading ? fst : (was_reading_burst ? 3u : 0u);
+        if (was_reading_burst) *burst_len = L.fr_len;
+        if (!reading) fr_set_state(L, 0);
+    }
+    return link;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Issue priority of a role (s_setprio).  Three wavefronts share a SIMD and the arbiter prefers the OLDEST: left alone, the second
+// half's filter wavefronts (A, E -- the longest chain of a step: filters -> timing update -> where the next symbol falls) sit behind
+// the first half's AGC / DC / squelch wavefronts, which have slack to spare, and the whole workgroup's step is theirs (measured:
+// E 3 690 clk of a 4 150-clk step in the second half against 2 650 in the first).  Profile builds pick other tables with
+// SAME_PIPE_PRIO bits 12-13 (1: no priorities).
+template <int PRIO> __device__ __forceinline__ void sym_setprio(const Params &P)
+{
+    const uint32_t variant = ((uint32_t)P.knob_prio >> 12) & 3u;
+    if (variant == 1u) return;
+    if (variant == 2u) { __builtin_amdgcn_s_setprio(PRIO >= 2 ? 3 : 0); return; }
+    __builtin_amdgcn_s_setprio(PRIO);
+}
+
+// next_fire_count (same_fast_common.h) for a clock at zero, in float and without the general case's loop: the first count c >= 1 with
+// fl(s - c) < 0.5, searched from floor(s) - 1, is reached within two increments (s - (floor(s) - 1) >= 1 fails, s - floor(s) is the
+// fraction, s - (floor(s) + 1) is negative); a third one for good measure.  Counts are far below 2^24, so the float is exact.
+__device__ __forceinline__ float sym_next_fire(float s)
+{
+    float c = fmaxf(floorf(s) - 1.0f, 1.0f);
+    c += ((s - c) < 0.5f) ? 0.0f : 1.0f;
+    c += ((s - c) < 0.5f) ? 0.0f : 1.0f;
+    c += ((s - c) < 0.5f) ? 0.0f : 1.0f;
+    return c;
+}
+
+// The kernel's argument list as a struct: the kernarg segment has this layout (natural alignment, in order).  The roles read
+// State / Output / PipeChunks from it WHEN THEY NEED THEM -- before and after their loops -- through a pointer the compiler cannot
+// see through.  Taken as ordinary by-value parameters, all of the ~70 pointers are loaded at the kernel's entry and stay live
+// across every role's loop for the stores at its end: a hundred scalar registers spilled into vector-register lanes, and every
+// use of one of them inside a loop a v_readlane -- vector issue slots, the resource this kernel is short of (345 of them in the
+// six-role build before this).
+struct SymKernArgs { Params P; State S; Output O; const float4 *taps; const void *x; uint32_t n_blocks; uint64_t counter0; PipeChunks K; };
+typedef const __attribute__((address_space(4))) char *sym_kernarg_ptr;
+template <typename T> __device__ __forceinline__ T sym_fresh_arg(sym_kernarg_ptr ka, size_t off)
+{
+    uint64_t p = (uint64_t)(uintptr_t)ka + off;
+    asm volatile("" : "+s"(p));
+    T r;
+    __builtin_memcpy(&r, reinterpret_cast<const __attribute__((address_space(4))) void *>(p), sizeof(T));      // scalar loads of the fields that are used
+    return r;
+}
+
+// Six role-wavefronts per 64 state columns, and TWO such groups per workgroup: twelve wavefronts land three per SIMD whatever
+// else runs (the dispatcher deals a workgroup's wavefronts round the four SIMDs in turn), while two six-wavefront workgroups
+// never share a CU -- the second one's wavefronts would pile four-deep on the SIMDs that already hold two, past the register
+// file (tools/ubench_wave_place.hip: one resident workgroup per CU, half the machine).  The two halves share nothing but the
+// step barrier; a half that is done simply ends (s_barrier counts the surviving wavefronts only).
+constexpr int kSymRoles = 6, kSymHalves = 2;
+template <int NFF, int NFB, typename SampleT, int CMODE>
+__global__ __launch_bounds__(kSymHalves * kSymRoles * kWave, 3) void demod_sym_kernel(Params P, State S_arg_, Output O_arg_, const float4 *__restrict__ taps,
+                                                                         const SampleT *__restrict__ x, uint32_t n_blocks, uint64_t counter0,
+                                                                         PipeChunks K)
+{
+    (void)S_arg_; (void)O_arg_;                                     // read through the kernarg segment where they are needed (SymKernArgs)
+    const sym_kernarg_ptr ka = (sym_kernarg_ptr)__builtin_amdgcn_kernarg_segment_ptr();
+    auto fresh_state = [&]() __attribute__((always_inline)) -> State { return sym_fresh_arg<State>(ka, offsetof(SymKernArgs, S)); };
+    auto fresh_output = [&]() __attribute__((always_inline)) -> Output { return sym_fresh_arg<Output>(ka, offsetof(SymKernArgs, O)); };
     constexpr int NT = 42;
     using LY = SymLayout<NT>;
     constexpr int kB = LY::B, RING = LY::RING;
     constexpr uint32_t LP = kWave;
     static_assert(CMODE == 0 || std::is_same<SampleT, float>::value, "channel-major streams are f32");
     if constexpr (CMODE == 0) { K.col_row0 = nullptr; K.col_perm = nullptr; }       // (the host launches this build for nothing else)
-    extern __shared__ float lds[];
+    extern __shared__ float lds_all[];
     const uint32_t lane = threadIdx.x & (kWave - 1u);
-    const uint32_t role = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // 0 S, 1 T, 2 Y, 3 E
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const uint32_t half = wave >= (uint32_t)kSymRoles ? 1u : 0u;
+    const uint32_t role = wave - half * (uint32_t)kSymRoles;                                   // 0 S, 1 T, 2 A, 3 E, 4 Y1, 5 Y2
     const uint32_t C = P.n_channels;
-    // state column of this lane (time-parallel launches may permute them: pieces of similar length share a workgroup)
-    const uint32_t c = (K.n_chunks > 1u && K.col_perm) ? K.col_perm[blockIdx.x * kWave + lane] : blockIdx.x * kWave + lane;
+    const uint32_t vwg = blockIdx.x * (uint32_t)kSymHalves + half;                              // this half's group of 64 state columns
+    if (vwg * kWave >= C) return;                                                              // (an odd number of groups: the last workgroup's second half)
+    float *lds = lds_all + half * (uint32_t)(LY::lds_bytes / sizeof(float));
+    // state column of this lane (time-parallel launches may permute them: pieces of similar length share a group)
+    const uint32_t c = (K.n_chunks > 1u && K.col_perm) ? K.col_perm[vwg * kWave + lane] : vwg * kWave + lane;
     // Time-parallel chunks, exactly as demod_pipe_kernel takes them
     uint32_t cin = c, Cin = C, n_nominal = n_blocks;
     bool may_leave = false;
@@ -491,15 +691,15 @@ __global__ __launch_bounds__(4 * kWave, 2) void demod_sym_kernel(Params P, State
             const uint32_t row_abs = K.col_row0[c];
             xl = x + (size_t)cin * K.in_samples + row_abs;
             avail_l = (K.whole_samples - row_abs) / (uint32_t)kB;
-            n_blocks = K.wg_blocks[blockIdx.x];
+            n_blocks = K.wg_blocks[vwg];
             n_nominal = may_leave ? K.col_nominal[c] : n_blocks;
             const uint32_t row_first = (uint32_t)__builtin_amdgcn_readfirstlane((int)row_abs);
             counter0 += (uint64_t)row_first;
             row_l = (int32_t)(row_abs - row_first);
         } else {
             const uint32_t wgs = K.in_channels / kWave;
-            const uint32_t chunk = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x / wgs));
-            cin = (blockIdx.x - chunk * wgs) * kWave + lane;
+            const uint32_t chunk = (uint32_t)__builtin_amdgcn_readfirstlane((int)(vwg / wgs));
+            cin = (vwg - chunk * wgs) * kWave + lane;
             may_leave = chunk + 1u < K.n_chunks;
             const uint32_t first_block = chunk * K.stride_blocks;
             x += (size_t)first_block * kB * Cin;
@@ -508,104 +708,131 @@ __global__ __launch_bounds__(4 * kWave, 2) void demod_sym_kernel(Params P, State
             n_nominal = may_leave ? K.nominal_blocks : n_blocks;
         }
     }
-    // LDS: taps | mailboxes | window ring [RING + MIR][64]
-    float4 *tlds = reinterpret_cast<float4 *>(lds);
+    // LDS: taps (profile builds: section marks) | mailboxes | window ring [RING + MIR][64]
     lds_u32 *mail = (lds_u32 *)(lds + LY::tap_floats);
-    lds_u32 *symbox = mail;                                    // [2][5][64]
-    lds_u32 *fbbox = mail + 2u * LY::sym_words;                // [2][64 + flag]
-    lds_u32 *iobox = fbbox + 2u * LY::fb_words;                // [2][3][64]
-    lds_u32 *phasebox = iobox + 2u * LY::io_words;             // [64] T's final TED phase bit
-    lds_u32 *againbox = phasebox + kWave;                      // [64] E's final F_TICK_AGAIN bit
-    lds_u32 *posbox = againbox + kWave;                        // [2][2][64] ring slots of the two instants of step s's symbol (parity s & 1)
-    lds_u32 *sabox = posbox + 2u * LY::pos_words;              // [64] the first instant's soft sample
-    lds_u32 *tkbox = sabox + kWave;                            // [kTickRing][64] u64 deadlines, then [64] their count (T's own)
-    lds_u32 *donebox = tkbox + kIoRingWords;                   // [64] Y -> T: the lane's piece has handed over (its input is no longer needed)
-    lds_u32 *chunkbox = fbbox + kWave + 2u;                    // [2], in the first feedback box's padding
-    lds_u32 *seqbox = fbbox + kWave + 4u;                      // S's progress with the first instants' filters: 2 * step + pass
+    lds_u32 *symbox = mail;                                    // [2][5][64]  E -> Y1: header, the symbol's two soft samples (trace: timing error, period)
+    lds_u32 *ybox = symbox + 2u * LY::sym_words;               // [2][64]     Y1 -> Y2
+    lds_u32 *fb1box = ybox + 2u * kWave;                       // [2][64 + flag]  Y1 -> S, E: the lock at sync; end() on a lost sync
+    lds_u32 *fb2box = fb1box + 2u * LY::fb_words;              // [2][64 + flag]  Y2 -> S, E, Y1: end() from the framer; -> Y1: squelch.lock; flag word bit 1: leave
+    lds_u32 *iobox = fb2box + 2u * LY::fb_words;               // [2][3][64]  Y2 -> A: link word, burst-pool slot, burst length
+    lds_u32 *phasebox = iobox + 2u * LY::io_words;             // [64] E's final TED phase bit
+    lds_u32 *againbox = phasebox + kWave;                      // [64] A's final F_TICK_AGAIN bit
+    lds_u32 *flagbox = againbox + kWave;                       // [64] Y1's final flag bits
+    lds_u32 *posbox = flagbox + kWave;                         // [2][64] ring slot of the FIRST instant of step s's symbol (parity s & 1; -1: none)
+    lds_u32 *sabox = posbox + 2u * kWave;                      // [64] that instant's soft sample, from A
+    lds_u32 *tkbox = sabox + kWave;                            // [kTickRing][64] u64 deadlines, then [64] their count (A's own)
+    lds_u32 *donebox = tkbox + kIoRingWords;                   // [64] Y2 -> T: the lane's piece has handed over (its input is no longer needed)
+    lds_u32 *chunkbox = fb1box + kWave + 2u;                   // [2], in the first feedback box's padding: A's event-log run
+    lds_u32 *seqbox = fb1box + kWave + 4u;                     // A's progress with the first instants' filters: 2 * step + 1
+    static_assert((size_t)(2u * LY::sym_words + 2u * kWave + 4u * LY::fb_words + 2u * LY::io_words + 3u * kWave + 2u * kWave + kWave + kIoRingWords + kWave + kWave) <= LY::mail_words, "mailboxes");
     float *wring = lds + LY::tap_floats + LY::mail_words;     // ring slot 0
     float *wcol = wring + lane;
     const uint64_t counter1 = counter0 + (uint64_t)n_blocks * kB;
     // Steps: T computes the DC blocker of block s + 1 in step s (block 0 before the first), S the AGC of block s in step
-    // s < n_blocks; T finishes symbols that end before sample 36 s in steps 1 .. n_blocks and the instants left before the
-    // end of the input, one per step, in the kSymDrain steps after; Y runs one step behind T, E's events one behind Y.
-    const uint32_t last_t_step = n_blocks + kSymDrain;
-    const uint32_t last_fb_step = last_t_step + 1u;            // Y runs in steps 2 .. last_t_step + 1
-    const uint32_t n_steps = last_t_step + 3u;
-    // A symbol travels as `off` = its sample index - 36 * base, base = s_T - 2 for the step s_T <= n_blocks T finished it
-    // in, n_blocks - 3 in the steps after: 0 <= off < 128.  Y (one step later) and E (two) rebuild the index.
-    auto sym_index = [&](uint32_t s_t, uint32_t off) __attribute__((always_inline)) -> int64_t {
-        const int64_t base = s_t <= n_blocks ? (int64_t)s_t - 2 : (int64_t)n_blocks - 3;
+    // s < n_blocks; E finishes symbols that end before sample 36 s in steps 1 .. n_blocks and the instants left before the
+    // end of the input, one per step, in the kSymDrain steps after; Y1 runs one step behind E, Y2 one behind Y1, A's events
+    // one behind Y2.
+    const uint32_t last_e_step = n_blocks + kSymDrain;
+    const uint32_t last_y1_step = last_e_step + 1u, last_y2_step = last_e_step + 2u, last_a_step = last_e_step + 3u;
+    const uint32_t n_steps = last_e_step + 4u;
+    // A symbol travels as `off` = its sample index - 36 * base, base = s_E - 2 for the step s_E <= n_blocks E finished it
+    // in, n_blocks - 3 in the steps after: 0 <= off < 128.  The wavefronts behind E rebuild the index.
+    auto sym_index = [&](uint32_t s_e, uint32_t off) __attribute__((always_inline)) -> int64_t {
+        const int64_t base = s_e <= n_blocks ? (int64_t)s_e - 2 : (int64_t)n_blocks - 3;
         return (int64_t)kB * base + (int64_t)off;
     };
+    // Synchronisation: no step barrier.  Every role publishes, once per step, ONE word -- steps completed << 16 | the step's
+    // flags in the byte of its parity -- and a role starts step s when the roles it exchanges data with have completed step
+    // s - 1 (kDeps: producers of what it reads, consumers of the double-buffered boxes it is about to overwrite).  One LDS
+    // read per step brings all six words, i.e. the go-ahead AND the feedback flags (a barrier followed by two or three flag
+    // reads cost three round trips); a wavefront waits for the ones it needs, not for the slowest of twelve, so a long step of one
+    // role is absorbed by the slack of the others instead of stalling the workgroup (measured with the barrier: every role
+    // waited >= 730 clk of a 3 780-clk step although the longest worked 2 900), and the two halves never meet.
+    lds_u32 *prog = donebox + kWave;                               // [6]
+    // (A waiting wavefront costs vector issue slots -- the resource this kernel is short of -- with every poll: roles with slack
+    // sleep longer between polls than the ones on the step's critical chain.)
+    const uint32_t prog_idx = lane < (uint32_t)kSymRoles ? lane : 0u;
+    uint32_t *const err_flags = fresh_output().n_events + 2;
+    auto wait_for = [&](uint32_t s, uint32_t deps, uint32_t *w_y1, uint32_t *w_y2, auto nap_) __attribute__((always_inline)) {
+        constexpr int NAP = decltype(nap_)::value;
+        uint32_t v, spins = 0;
+        for (;;) {
+            v = prog[prog_idx];
+            const uint32_t ok = (uint32_t)__builtin_amdgcn_ballot_w64((v >> 16) >= s);
+            if ((ok & deps) == deps) break;
+            __builtin_amdgcn_s_sleep(NAP);
+            // (bounded: a protocol error ends in an error code, not in a hung GPU)
+            if (++spins > (1u << 22)) { if (lane == 0u) atomicOr(err_flags, 4u); break; }
+        }
+        *w_y1 = (uint32_t)__builtin_amdgcn_readlane((int)v, 4);
+        *w_y2 = (uint32_t)__builtin_amdgcn_readlane((int)v, 5);
+    };
+    constexpr std::integral_constant<int, 1> kNapShort{};
+    constexpr std::integral_constant<int, 4> kNapLong{};
+    // flags of step s - 1 in a progress word read at the start of step s (its writer may be one step further: two parities)
+    auto flags_of_last = [&](uint32_t w, uint32_t s) __attribute__((always_inline)) -> uint32_t { return s == 0u ? 0u : (w >> (8u * ((s - 1u) & 1u))) & 0xffu; };
+    auto publish = [&](uint32_t s, uint32_t flags, uint32_t flags_before) __attribute__((always_inline)) {
+        if (lane == 0u) prog[role] = ((s + 1u) << 16) | (flags << (8u * (s & 1u))) | (flags_before << (8u * ((s + 1u) & 1u)));
+    };
+    enum : uint32_t { R_S = 1u, R_T = 2u, R_A = 4u, R_E = 8u, R_Y1 = 16u, R_Y2 = 32u };
+    enum : uint32_t { Y1F_ANY = 1u, Y2F_END = 1u, Y2F_LEAVE = 2u, Y2F_LOCK = 4u };
+    // What a role waits for, and where in its step (a wait names the roles that must have completed step s - 1):
+    //   S  before anything: T (the DC outputs of its block), A and E (done with the mirrored slots it rewrites), Y1 and Y2 (feedback)
+    //   T  before the DC blocker: A and E (done with the ring block it overwrites); before publishing: Y2 (hand-over flag)
+    //   A  before its filter: S (blocks), E (positions; E is done with the last soft sample); before the events: Y2 (link words)
+    //   E  before its filter: S; before the timing updates: A (done with the positions), Y1 (done with the symbol box; feedback), Y2
+    //   Y1 before the symbol: E (symbols), Y2 (feedback; done with the word box); before posting feedback: S (has read the box of two steps ago)
+    //   Y2 before the framer: Y1 (words); before posting: everybody (has read the flags and feedback of two steps ago; A the link box)
+    constexpr uint32_t kDepsS = R_T | R_A | R_E | R_Y1 | R_Y2;
+    if (role == 0u && lane < (uint32_t)kSymRoles) prog[lane] = 0u;
 
     if (role == 0u) {
-        // ------------------------------------------ S: AGC + window push, block s -------------------------------------
-        P3_HWID(0);
+        // ------------------------------------------ S: AGC of block s, in place ------------------------------------------
+        sym_setprio<0>(P);
         SymAgc M;
-        M.load(P, S, c, C, counter0, wcol);
-        const uint32_t wcol_lds = lds_addr(wcol);
-        SymTaps<NT> TP;
-        TP.load(taps);
-        if (lane == 0u) seqbox[0] = 0u;
-        // the matched filters of the FIRST instant of the step's symbol, at the positions E posted (E takes the second)
-        auto filter_a = [&](uint32_t s, uint32_t seq) __attribute__((always_inline)) {
-            const uint32_t n1 = posbox[(s & 1u) * LY::pos_words + lane];
-            if (__builtin_amdgcn_ballot_w64(n1 != 0xffffffffu) == 0ull) return;
-            // (a profile build's knock-out skips the filter, never the hand-over E waits for)
-            const float sa1 = PROF_SKIP(P, 256) ? 0.0f : TP.template demod<RING>(wcol_lds, n1 == 0xffffffffu ? 0 : (int)n1);
-            sabox[lane] = __float_as_uint(sa1);
-            if (lane == 0u) seqbox[0] = seq;                           // (LDS operations of a wavefront stay in order)
-        };
-        lds_barrier();                                                 // prologue: block 0's DC outputs are in the ring
+        { const State S = fresh_state(); M.load(P, S, c, C, counter0, wcol); }
+        lds_barrier();                                                 // prologue: block 0's DC outputs are in the ring, every box is initialised
         P3_T0();
         uint32_t stop_at = 0xffffffffu;
         bool left = false;
         for (uint32_t s = 0; s < n_steps; ++s) {
-            if (s >= 1u && s <= last_t_step) filter_a(s, 2u * s + 1u);
-            if (s < n_blocks && !PROF_SKIP(P, 64)) M.block(P, wcol, s);
-            P3_LAP(p3_work);
-            lds_barrier();                                             // A
+            uint32_t w1, w2;
+            wait_for(s, kDepsS, &w1, &w2, kNapLong);
             P3_LAP(p3_wait);
-            if (s >= 2u && s <= last_fb_step) {
-                const lds_u32 *fb = fbbox + (s & 1u) * LY::fb_words;
-                const uint32_t fbw = (uint32_t)__builtin_amdgcn_readfirstlane((int)fb[kWave]);
-                if (fbw & 2u) stop_at = s + 1u;
-                if (fbw & 4u) {
-                    // a lock or an unlock: from the next block on
-                    const uint32_t v = fb[lane];
-                    if (v & 1u) {
-                        const bool new_locked = (v & 2u) != 0u;
-                        if (new_locked && !M.locked) {
-                            // the gain freezes at the value it had after the symbol's sample
-                            const int64_t idx = sym_index(s - 1u, v >> 8);
-                            const uint32_t b = (uint32_t)(idx / kB);
-                            M.gain = M.gain_at(P, wcol, b, (int)(idx - (int64_t)b * kB));
-                        }
-                        M.locked = new_locked;
-                    }
-                    P3_LAP(p3_fb);
-                }
+            const uint32_t f1 = flags_of_last(w1, s), f2 = flags_of_last(w2, s);
+            if (f2 & Y2F_LEAVE) stop_at = s;
+            // Feedback of step s - 1 (agc.lock receiver.rs:431, 480), from this block on.  Y2's (an end() at an older symbol) first.
+            if ((f2 & Y2F_END) && s >= 1u) {
+                if (fb2box[((s - 1u) & 1u) * LY::fb_words + lane] & FB_VALID) M.locked = false;
             }
+            if ((f1 & Y1F_ANY) && s >= 1u) {
+                const uint32_t v = fb1box[((s - 1u) & 1u) * LY::fb_words + lane];
+                if (v & FB_VALID) {
+                    const bool new_locked = (v & FB_AGC) != 0u;
+                    if (new_locked && !M.locked) {
+                        // the gain freezes at the value it had after the symbol's sample (Y1 saw it in step s - 1, E finished it in s - 2)
+                        const int64_t idx = sym_index(s - 2u, v >> 8);
+                        const uint32_t b = (uint32_t)(idx / kB);
+                        M.gain = M.gain_at(P, wcol, b, (int)(idx - (int64_t)b * kB));
+                    }
+                    M.locked = new_locked;
+                }
+                P3_LAP(p3_fb);
+            }
+            if (s < n_blocks && !PROF_SKIP(P, 64)) M.block(P, wcol, s);
+            publish(s, 0u, 0u);
+            P3_LAP(p3_work);
             if (s == stop_at) { left = true; break; }
         }
         SYM_REPORT(0);
         if (left) return;                                              // handed over: this chunk's state is not needed
-        lds_barrier();                                                 // (E -> Y: final TED phase)
-        M.store(P, S, c, C, counter1, wcol);
+        { const State S = fresh_state(); M.store(P, S, c, C, counter1, wcol); }
     } else if (role == 1u) {
-        // ------------------------------------------ T: input prefetch and DC blocker of block s + 1; link events + wake-ups ----
-        P3_HWID(1);
+        // ------------------------------------------ T: input prefetch and DC blocker of block s + 1 --------------------
+        sym_setprio<0>(P);
         SymDc<SampleT, CMODE> D;
         D.xl = xl; D.avail = avail_l;
-        D.load(S, x, c, C, cin, Cin, counter0, n_blocks);
-        Lane L;
-        lane_load(L, S, c);      // the event half uses sq_symbols, tk_next, tk_last, wake_*, F_TICK_AGAIN
-        IoCtxLds X;
-        X.chunk = chunkbox;
-        chunkbox[0] = 0u; chunkbox[1] = kEvChunk;       // nothing reserved yet
-        X.pending_slot = 0xffffffffu;
-        X.tk = tkbox + lane;
-        X.ring_load(P, S, c);
+        { const State S = fresh_state(); D.load(S, x, c, C, cin, Cin, counter0, n_blocks); }
         donebox[lane] = 0u;
         // prologue: block 0's DC outputs
         if (n_blocks > 1u) D.request(D.xb, x, 1u, n_blocks, cin, Cin);
@@ -615,33 +842,18 @@ __global__ __launch_bounds__(4 * kWave, 2) void demod_sym_kernel(Params P, State
         uint32_t stop_at = 0xffffffffu;
         auto step = [&](uint32_t s, auto buf) __attribute__((always_inline)) -> bool {
             constexpr int BUF = decltype(buf)::value;                  // block s + 1 waits in buffer BUF = (s + 1) & 1
+            uint32_t w1, w2;
+            wait_for(s, R_A | R_E, &w1, &w2, kNapLong);                          // the filters are done with the ring block this step overwrites
+            P3_LAP(p3_wait);
             if constexpr (CMODE == 1) D.done = donebox[lane] != 0u;
             if (s + 1u < n_blocks && !PROF_SKIP(P, 128)) {
                 if constexpr (BUF == 0) { D.request(D.xb, x, s + 2u, n_blocks, cin, Cin); D.block(P, wcol, D.xa, s + 1u); }
                 else { D.request(D.xa, x, s + 2u, n_blocks, cin, Cin); D.block(P, wcol, D.xb, s + 1u); }
             }
-            // the link event and the wake-ups of what Y handed over in the last step
-            if (s >= 3u && !PROF_SKIP(P, 8)) {
-                const lds_u32 *io = iobox + ((s - 1u) & 1u) * LY::io_words + lane;
-                const uint32_t io0 = io[0];
-                if (io0 & 1u) {
-                    L.sq_symbols += 1;         // as rx_symbol counted it (rx/codesquelch.rs:232)
-                    const uint32_t link = (io0 >> 1) & 3u, off = (io0 >> 4) & 127u;
-                    const bool burst = (io0 & 8u) != 0u && link == 3u;
-                    uint32_t burst_len = 0;
-                    if (burst) { X.pending_slot = io[kWave]; burst_len = io[2 * kWave]; }
-                    const uint64_t counter = counter0 + (int64_t)row_l + (uint64_t)sym_index(s - 2u, off) + 1u;
-                    symbol_io(P, L, S, O, X, c, link, (io0 & 8u) != 0u, counter, burst_len);
-                }
-            }
+            wait_for(s, R_Y2, &w1, &w2, kNapLong);                               // has Y2 called the hand-over?
+            if (flags_of_last(w2, s) & Y2F_LEAVE) stop_at = s;
+            publish(s, 0u, 0u);
             P3_LAP(p3_work);
-            lds_barrier();                                             // A
-            P3_LAP(p3_wait);
-            if (s >= 2u && s <= last_fb_step) {
-                const lds_u32 *fb = fbbox + (s & 1u) * LY::fb_words;
-                const uint32_t fbw = (uint32_t)__builtin_amdgcn_readfirstlane((int)fb[kWave]);
-                if (fbw & 2u) stop_at = s + 1u;
-            }
             return s == stop_at;
         };
         bool left = false;
@@ -650,80 +862,368 @@ __global__ __launch_bounds__(4 * kWave, 2) void demod_sym_kernel(Params P, State
             if (!left && s + 1u < n_steps) left = step(s + 1u, std::integral_constant<int, 0>{});
         }
         SYM_REPORT(1);
-        X.retire(O, lane, kWave);
         if (left) return;
-        againbox[lane] = L.flags & F_TICK_AGAIN;
-        lds_barrier();                                                 // Y merges the flag bits
-        D.store(S, c, C, counter1);
-        S.tk_next[c] = L.tk_next; S.tk_last[c] = L.tk_last; S.wake_fired[c] = L.wake_fired;
-        X.ring_store(P, S, c);
+        { const State S = fresh_state(); D.store(S, c, C, counter1); }
     } else if (role == 2u) {
-        // ------------------------------------------ Y: symbol path --------------------------------------------------
-        P3_HWID(2);
+        // ------------------------------------------ A: the matched-filter pair at the FIRST instant of the step's symbol; link events + wake-ups ----
+        sym_setprio<3>(P);
+        const uint32_t wcol_lds = lds_addr(wcol);
+        SymTaps<NT> TP;
+        TP.load(taps);
         Lane L;
-        lane_load(L, S, c);
-        L.ended = 0u;
-        SymCtx<NFF, NFB> X;
-        // the squelch's sample history stays in global memory: the state array itself, or -- where the columns of a wavefront
-        // are permuted -- a copy by grid position (coalesced; the state array is read and written once per launch)
-        const bool hist_copy = K.n_chunks > 1u && K.col_perm != nullptr && K.hist_scratch != nullptr;
-        X.hist = hist_copy ? K.hist_scratch + (blockIdx.x * kWave + lane) : S.sq_hist + c;
-        X.hstride = C;
-        if (hist_copy) {
-#pragma unroll 4
-            for (int i = 0; i < kSquelchHist; ++i) X.hist[(size_t)i * C] = S.sq_hist[(size_t)i * C + c];
-        }
-        P3_MARKS_BEGIN(X, lds, NT);
-#pragma unroll
-        for (int i = 0; i < NFF; ++i) {
-            X.ffc[i] = S.eq_ffc[i * C + c]; X.ffw[i] = S.eq_ffw[i * C + c];
-            X.sffc[i] = S.eq_snap_ffc[i * C + c]; X.sffw[i] = S.eq_snap_ffw[i * C + c];
-        }
-#pragma unroll
-        for (int i = 0; i < NFB; ++i) {
-            X.fbc[i] = S.eq_fbc[i * C + c]; X.fbw[i] = S.eq_fbw[i * C + c];
-            X.sfbc[i] = S.eq_snap_fbc[i * C + c]; X.sfbw[i] = S.eq_snap_fbw[i * C + c];
-        }
+        IoCtxLds X;
+        X.chunk = chunkbox;
+        if (lane == 0u) { chunkbox[0] = 0u; chunkbox[1] = kEvChunk; seqbox[0] = 0u; }      // nothing reserved yet; no pass posted yet
+        X.pending_slot = 0xffffffffu;
+        X.tk = tkbox + lane;
         {
-            const uint32_t pslot = (uint32_t)(2u * (uint32_t)L.sq_symbols) & 63u;
-            X.nxt0 = X.hist_get((pslot + 16u) & 63u); X.nxt1 = X.hist_get((pslot + 17u) & 63u);
+            const State S = fresh_state();
+            lane_load(L, S, c);      // the event half uses sq_symbols, tk_next, tk_last, wake_*, F_TICK_AGAIN
+            X.ring_load(P, S, c);
         }
+        const State Snone{};         // (the event log's context keeps what it needs in LDS; nothing of the state arrays)
+        Output O{};
+        { const Output Of = fresh_output(); O.events = Of.events; O.n_events = Of.n_events; O.event_cap = Of.event_cap; }
         lds_barrier();                                                 // prologue
         P3_T0();
         uint32_t stop_at = 0xffffffffu;
-        bool left = false, lane_done = false, leave_posted = false;
+        bool left = false;
         for (uint32_t s = 0; s < n_steps; ++s) {
-            if (s >= 2u && s <= last_fb_step) {
-                const uint32_t blk = min(s - 2u, n_blocks - 1u);       // every symbol up to the end of this block has been seen after this step
+            uint32_t w1, w2;
+            wait_for(s, R_S | R_E, &w1, &w2, kNapShort);                          // S's blocks, E's positions (and E is done with the last soft sample)
+            P3_LAP(p3_wait);
+            // the filters at the positions E posted (E takes the second instant and waits for this one's soft sample)
+            if (s >= 1u && s <= last_e_step) {
+                const uint32_t n1 = posbox[(s & 1u) * kWave + lane];
+                if (__builtin_amdgcn_ballot_w64(n1 != 0xffffffffu) != 0ull) {
+                    // (a profile build's knock-out skips the filter, never the hand-over E waits for)
+                    const float sa1 = PROF_SKIP(P, 256) ? 0.0f : TP.template demod<RING>(wcol_lds, n1 == 0xffffffffu ? 0 : (int)n1);
+                    sabox[lane] = __float_as_uint(sa1);
+                    if (lane == 0u) seqbox[0] = 2u * s + 1u;           // (LDS operations of a wavefront stay in order)
+                }
+            }
+            sym_setprio<1>(P);
+            wait_for(s, R_Y2, &w1, &w2, kNapLong);                               // Y2's link words; has it called the hand-over?
+            if (flags_of_last(w2, s) & Y2F_LEAVE) stop_at = s;
+            // the link event and the wake-ups of what Y2 handed over in the last step
+            if (s >= 4u && s <= last_a_step && !PROF_SKIP(P, 8)) {
+                const lds_u32 *io = iobox + ((s - 1u) & 1u) * LY::io_words + lane;
+                const uint32_t io0 = io[0];
+                if (io0 & 1u) {
+                    L.sq_symbols += 1;         // as the squelch counted it (rx/codesquelch.rs:232)
+                    const uint32_t link = (io0 >> 1) & 3u, off = (io0 >> 4) & 127u;
+                    const bool burst = (io0 & 8u) != 0u && link == 3u;
+                    uint32_t burst_len = 0;
+                    if (burst) { X.pending_slot = io[kWave]; burst_len = io[2 * kWave]; }
+                    // the counter is that of the sample after the symbol's
+                    const uint64_t counter = counter0 + (int64_t)row_l + (uint64_t)sym_index(s - 3u, off) + 1u;
+                    symbol_io(P, L, Snone, O, X, c, link, (io0 & 8u) != 0u, counter, burst_len);
+                }
+            }
+            if (s + 1u == n_steps) againbox[lane] = L.flags & F_TICK_AGAIN;      // (Y2 merges the flag bits)
+            publish(s, 0u, 0u);
+            sym_setprio<3>(P);
+            P3_LAP(p3_work);
+            if (s == stop_at) { left = true; break; }
+        }
+        SYM_REPORT(2);
+        X.retire(O, lane, kWave);
+        if (left) return;
+        {
+            const State S = fresh_state();
+            S.tk_next[c] = L.tk_next; S.tk_last[c] = L.tk_last; S.wake_fired[c] = L.wake_fired;
+            X.ring_store(P, S, c);
+        }
+    } else if (role == 3u) {
+        // ------------------------------------------ E: one symbol per lane and step: the filter pair at its SECOND instant, timing loop ----
+        sym_setprio<3>(P);
+        const uint32_t wcol_lds = lds_addr(wcol);
+        SymTaps<NT> TP;
+        TP.load(taps);
+        Lane L;
+        { const State S = fresh_state(); lane_load(L, S, c); }
+        const float inv_spt = 1.0f / P.samples_per_ted;
+        int cstar = next_fire_count(L.until_next_ted, L.ted_clock);
+        int rel = cstar - (int)L.ted_clock - 1;        // index of the next instant, relative to the end of the finished samples
+        float cstar_f = (float)cstar;
+        // The plan of step s, made at the end of step s - 1: per lane the next symbol -- instant A
+        // (completes nothing: where B falls does not depend on A's sample) and instant B, or B alone right after a
+        // symsync.reset -- if both lie in finished samples; in the steps after the last block: one instant whatever it is.
+        // Wavefront A filters at A (where there is one), this one at B.
+        SYM_T_DECL();
+        bool pl_typeA = false, pl_ready = false, pl_single = false;
+        int pl_p2 = 0;
+        uint32_t pl_n2 = 0;
+        float pl_rem1 = 0.0f, pl_instA = 0.0f, pl_c2 = 0.0f;
+        auto plan = [&](uint32_t s) __attribute__((always_inline)) {
+            pl_single = s > n_blocks;
+            const uint32_t wb = (min(s, n_blocks) % (uint32_t)LY::NBLK) * (uint32_t)kB;      // ring slot of the sample at rel 0
+            pl_typeA = !pl_single && (L.flags & F_TED_PHASE) != 0u;
+            pl_rem1 = L.until_next_ted - cstar_f;                                      // receiver.rs:352
+            pl_instA = L.period_inst + __builtin_amdgcn_fmed3f(pl_rem1, -0.5f, 0.5f);   // rx/symsync.rs:236-241
+            pl_c2 = sym_next_fire(pl_instA);
+            pl_p2 = pl_typeA ? rel + (int)pl_c2 : rel;
+            pl_ready = pl_p2 < 0 && s >= 1u && s <= last_e_step;
+            auto slot = [&](int p) __attribute__((always_inline)) { int n = (int)wb + p; n += n < 0 ? RING : 0; return (uint32_t)n; };
+            pl_n2 = pl_ready ? slot(pl_p2) : 0u;
+            posbox[(s & 1u) * kWave + lane] = (pl_ready && pl_typeA) ? slot(rel) : 0xffffffffu;
+        };
+        float sa1 = 0.0f, sa2 = 0.0f;
+        // the filters of the step's symbol: its second instant here, its first on wavefront A
+        auto filters = [&](uint32_t seq) __attribute__((always_inline)) {
+            sa1 = 0.0f; sa2 = 0.0f;
+            if (__builtin_amdgcn_ballot_w64(pl_ready) != 0ull) {
+                SYM_T_BEGIN();
+                SYM_TCOUNT(20, 1);
+                sa2 = PROF_SKIP(P, 512) ? 0.0f : TP.template demod<RING>(wcol_lds, (int)pl_n2);
+                SYM_T_LAP(22);
+                if (__builtin_amdgcn_ballot_w64(pl_ready && pl_typeA) != 0ull) {
+                    // A has posted this pass (both wavefronts decide from the same posbox words whether there is one).  Bounded:
+                    // should the two ever disagree, the launch reports an error instead of hanging the GPU.
+                    uint32_t spins = 0;
+                    while ((int32_t)(seqbox[0] - seq) < 0) {
+                        __builtin_amdgcn_s_sleep(1);
+                        if (++spins > (1u << 22)) { if (lane == 0u) atomicOr(err_flags, 4u); break; }
+                    }
+                    sa1 = __uint_as_float(sabox[lane]);
+                }
+                SYM_T_LAP(24);
+            }
+        };
+        // The two timing updates of the symbol, and the symbol itself to Y1: straight-line, committed by selects (a wavefront has
+        // lanes with both instants in this step, lanes with one, lanes with none: as branches the update existed twice, with
+        // the register shuffling of two exec-mask regions around it -- ~210 vector instructions a step).
+        auto work = [&](uint32_t s) __attribute__((always_inline)) {
+            uint32_t hdr = 0;
+            float zero = 0.0f, sym = 0.0f, terr = 0.0f, next = 0.0f;
+            if (__builtin_amdgcn_ballot_w64(pl_ready) != 0ull) {
+                SYM_T_BEGIN();
+                const bool tA = pl_typeA;
+                // the TED as the second instant finds it: behind the first one (ZeroCrossingTed::input + TimingLoop::input without
+                // a symbol, rx/symsync.rs:236-241, 278-287) where the step has one
+                const float p1 = tA ? L.h2 : L.h1, p2 = tA ? sa1 : L.h2;
+                const float inst_pre = tA ? pl_instA : L.period_inst;
+                const float rem = tA ? pl_instA - pl_c2 : pl_rem1;
+                const uint32_t flags_new = tA ? L.flags : (L.flags ^ F_TED_PHASE);       // (two toggles, or one)
+                const bool have = (flags_new & F_TED_PHASE) != 0u;
+                // ZeroCrossingTed::input + TimingLoop::advance_loop (rx/symsync.rs:198-287), relaxed: same_relaxed_common.h ted_timing_relaxed
+                const float dsg = rs_signum(p1) - rs_signum(sa2);
+                const float te = p2 * dsg;
+                const float offset = __builtin_amdgcn_fmed3f(rem, -0.5f, 0.5f);
+                const float e = __builtin_amdgcn_fmed3f(__builtin_fmaf(-offset, inv_spt, te), -1.0f, 1.0f);
+                const bool bw_locked = (L.flags & F_BW_LOCKED) != 0u;
+                const float alpha = bw_locked ? P.alpha_locked : P.alpha_unlocked;
+                const float beta = bw_locked ? P.beta_locked : P.beta_unlocked;
+                const float avg1 = __builtin_amdgcn_fmed3f(__builtin_fmaf(beta, e, L.period_avg), P.period_min, P.period_max);
+                float inst1 = __builtin_fmaf(alpha, e, avg1) + offset;
+                inst1 = (inst1 < 0.0f) ? avg1 : inst1;
+                const float inst_new = have ? inst1 : inst_pre + offset;
+                const float cs = sym_next_fire(inst_new);
+                if (pl_ready) {
+                    L.h0 = p1; L.h1 = p2; L.h2 = sa2;
+                    L.flags = flags_new;
+                    L.period_avg = have ? avg1 : L.period_avg;
+                    L.period_inst = inst_new; L.until_next_ted = inst_new;
+                    cstar_f = cs; cstar = (int)cs;
+                    rel = pl_p2 + cstar;
+                    if (have) { hdr = 1u | ((uint32_t)(pl_p2 + (pl_single ? 3 * kB : 2 * kB)) << 8); zero = p2; sym = sa2; terr = te; next = inst_new; }
+                }
+                SYM_T_LAP(23);
+            }
+            lds_u32 *sb = symbox + (s & 1u) * LY::sym_words + lane;
+            sb[0] = hdr;
+            sb[kWave] = __float_as_uint(zero); sb[2 * kWave] = __float_as_uint(sym);
+            if (P.trace_cap) { sb[3 * kWave] = __float_as_uint(terr); sb[4 * kWave] = __float_as_uint(next); }
+        };
+        // the loop bandwidth of a lock at sync (receiver.rs:431-432) and what end() undoes (receiver.rs:479-490: unlocked
+        // loop bandwidth, symsync.reset()), late: see Y1 / Y2
+        auto late = [&](uint32_t v) __attribute__((always_inline)) {
+            if (v & FB_VALID) {
+                L.flags = (L.flags & ~F_BW_LOCKED) | ((v & FB_BW) ? F_BW_LOCKED : 0u);
+                if (v & FB_END) {                                        // rx/symsync.rs:166-170, 265-271
+                    L.flags &= ~F_TED_PHASE;
+                    L.h0 = 0.0f; L.h1 = 0.0f; L.h2 = 0.0f;
+                    L.period_avg = P.samples_per_ted; L.period_inst = P.samples_per_ted;
+                }
+            }
+        };
+        plan(0u);                                                      // (nothing: step 0 finishes no symbol)
+        lds_barrier();                                                 // prologue
+        P3_T0();
+        uint32_t stop_at = 0xffffffffu;
+        bool left = false;
+        for (uint32_t s = 0; s < n_steps; ++s) {
+            // The step's chain -- filters -> timing updates -> where the next symbol's instants fall -> (next step) filters -- is the
+            // longest of the pipeline: it starts as soon as S has the samples, and only then waits for what is needed later.
+            uint32_t w1, w2;
+            wait_for(s, R_S, &w1, &w2, kNapShort);
+            P3_LAP(p3_wait);
+            if (!PROF_SKIP(P, 32)) filters(2u * s + 1u);
+            wait_for(s, R_A | R_Y1 | R_Y2, &w1, &w2, kNapShort);                  // A is done with the positions, Y1 with the symbol box; feedback of Y1 and Y2
+            const uint32_t f1 = flags_of_last(w1, s), f2 = flags_of_last(w2, s);
+            if (f2 & Y2F_LEAVE) stop_at = s;
+            // a change of the loop bandwidth or a symsync.reset() posted in step s - 1: applied behind this step's symbol (its
+            // positions are already with A)
+            uint32_t late1 = 0u, late2 = 0u;
+            if ((f1 & Y1F_ANY) && s >= 1u) late1 = fb1box[((s - 1u) & 1u) * LY::fb_words + lane];
+            if ((f2 & Y2F_END) && s >= 1u) late2 = fb2box[((s - 1u) & 1u) * LY::fb_words + lane];
+            if (!PROF_SKIP(P, 32)) {
+                work(s);
+                if (__builtin_amdgcn_ballot_w64(((late1 | late2) & FB_VALID) != 0u) != 0ull) { late(late2); late(late1); }       // (Y2's is of an older symbol)
+                if (s + 1u <= n_blocks) rel -= kB;                     // block s is finished when step s + 1 begins
+                plan(s + 1u);
+            }
+            if (s + 1u == n_steps) phasebox[lane] = L.flags & F_TED_PHASE;       // (Y2 merges the phase bit)
+            publish(s, 0u, 0u);
+            P3_LAP(p3_work);
+            if (s == stop_at) { left = true; break; }
+        }
+        SYM_REPORT(3);
+        SYM_T_REPORT();
+        if (left) return;
+        L.ted_clock = (uint32_t)(cstar - rel - 1);
+        {
+            const State S = fresh_state();
+            S.until_next_ted[c] = L.until_next_ted; S.ted_clock[c] = L.ted_clock;
+            S.ted_h0[c] = L.h0; S.ted_h1[c] = L.h1; S.ted_h2[c] = L.h2;
+            S.period_avg[c] = L.period_avg; S.period_inst[c] = L.period_inst;
+        }
+    } else if (role == 4u) {
+        // ------------------------------------------ Y1: squelch + equalizer ---------------------------------------------
+        sym_setprio<2>(P);
+        SymSquelch<NFF, NFB> Q;
+        uint64_t symbols0;
+        // the squelch's sample history stays in global memory: the state array itself, or -- where the columns of a wavefront
+        // are permuted -- a copy by grid position (coalesced; the state array is read and written once per launch)
+        const bool hist_copy = K.n_chunks > 1u && K.col_perm != nullptr && K.hist_scratch != nullptr;
+        {
+            const State S = fresh_state();
+            lane_load(Q.L, S, c);
+            symbols0 = Q.L.sq_symbols;
+            Q.nsym = (uint32_t)symbols0;
+            Q.hbase = reinterpret_cast<char *>(hist_copy ? K.hist_scratch : S.sq_hist);
+            Q.hcol4 = (hist_copy ? vwg * kWave + lane : c) * 4u;
+            Q.hrow4 = C * 4u;
+            if (hist_copy) {
+#pragma unroll 4
+                for (int i = 0; i < kSquelchHist; ++i) *Q.hptr((uint32_t)i) = S.sq_hist[(size_t)i * C + c];
+            }
+#pragma unroll
+            for (int i = 0; i < NFF; ++i) {
+                Q.ffc[i] = S.eq_ffc[i * C + c]; Q.ffw[i] = S.eq_ffw[i * C + c];
+                Q.sffc[i] = S.eq_snap_ffc[i * C + c]; Q.sffw[i] = S.eq_snap_ffw[i * C + c];
+            }
+#pragma unroll
+            for (int i = 0; i < NFB; ++i) {
+                Q.fbc[i] = S.eq_fbc[i * C + c]; Q.fbw[i] = S.eq_fbw[i * C + c];
+                Q.sfbc[i] = S.eq_snap_fbc[i * C + c]; Q.sfbw[i] = S.eq_snap_fbw[i * C + c];
+            }
+            const uint32_t pslot = (2u * Q.nsym) & 63u;
+            Q.nxt0 = *Q.hptr((pslot + 16u) & 63u); Q.nxt1 = *Q.hptr((pslot + 17u) & 63u);
+        }
+        lds_barrier();                                                 // prologue
+        P3_T0();
+        uint32_t stop_at = 0xffffffffu, flags_before = 0u;
+        bool left = false;
+        for (uint32_t s = 0; s < n_steps; ++s) {
+            uint32_t w1, w2;
+            wait_for(s, R_E | R_Y2, &w1, &w2, kNapShort);                         // E's symbols, Y2's feedback (and Y2 is done with the word box)
+            P3_LAP(p3_wait);
+            const uint32_t f2 = flags_of_last(w2, s);
+            if (f2 & Y2F_LEAVE) stop_at = s;
+            // what the framer decided in step s - 1 (squelch.lock(true) on Reading, end() on NoCarrier / Burst)
+            if ((f2 & (Y2F_END | Y2F_LOCK)) && s >= 1u) {
+                const uint32_t from_y2 = fb2box[((s - 1u) & 1u) * LY::fb_words + lane];
+                if (from_y2 & FB_SQLOCK) Q.L.flags |= F_SQ_LOCK;
+                if (from_y2 & FB_END) Q.end();
+            }
+            uint32_t flags = 0u;
+            if (s >= 2u && s <= last_y1_step) {
                 const lds_u32 *sb = symbox + ((s - 1u) & 1u) * LY::sym_words + lane;
-                // (the two history samples the symbol's equalizer step takes were requested with the lane's last symbol: SymCtx)
-                const float pre0 = X.nxt0, pre1 = X.nxt1;
                 const uint32_t hdr = sb[0], zero_w = sb[kWave], sym_w = sb[2 * kWave];
-                uint32_t fbv = 0, io0 = 0, io1 = 0xffffffffu, io2 = 0;
-                bool want_slot = false;                                // this lane has just finished a burst
+                uint32_t msg = 0u, fbv = 0u;
                 if ((hdr & 1u) && !PROF_SKIP(P, 16)) {
                     const uint32_t off = hdr >> 8;
                     const float zero = __uint_as_float(zero_w), sym = __uint_as_float(sym_w);
-                    float terr = 0.0f, unt = 0.0f;
-                    if (P.trace_cap) { terr = __uint_as_float(sb[3 * kWave]); unt = __uint_as_float(sb[4 * kWave]); }
-                    const uint32_t before = L.flags & (F_AGC_LOCKED | F_BW_LOCKED);
-                    L.ended = 0u;
-                    uint32_t burst_len = 0;
-                    bool emit = false;
-                    // the counter is that of the sample after the symbol's
-                    const uint64_t counter = counter0 + (int64_t)row_l + (uint64_t)sym_index(s - 1u, off) + 1u;
-                    const uint32_t link = symbol_link(P, L, S, X, c, zero, sym, terr, unt, counter, &burst_len, &emit, true, pre0, pre1);
-                    want_slot = emit && link == 3u;
-                    io0 = 1u | (link << 1) | (emit ? 8u : 0u) | (off << 4);
-                    io2 = burst_len;
-                    const uint32_t after = L.flags & (F_AGC_LOCKED | F_BW_LOCKED);
-                    if (after != before || L.ended) {
-                        // The lock at sync (agc.lock(true), locked loop bandwidth: receiver.rs:431-432) and what end() undoes
-                        // (receiver.rs:479-490) reach S and E late: the AGC freezes -- at the gain of this symbol's sample -- or
-                        // is released from S's next block on, the timing loop follows two symbols later.  Link events after
-                        // an end() move by less than a symbol (the carrier is gone by then).
-                        fbv = 1u | ((after & F_AGC_LOCKED) ? 2u : 0u) | ((after & F_BW_LOCKED) ? 4u : 0u) | (L.ended ? 8u : 0u) | (off << 8);
+                    if (P.trace_cap) {
+                        // the soft-symbol trace (tests): the counter is that of the sample after the symbol's
+                        const State S = fresh_state();
+                        const uint64_t counter = counter0 + (int64_t)row_l + (uint64_t)sym_index(s - 1u, off) + 1u;
+                        const uint32_t n = S.trace_n[c];
+                        if (n < P.trace_cap) {
+                            float *t = S.trace + ((size_t)c * P.trace_cap + n) * 4;
+                            t[0] = zero; t[1] = sym; t[2] = __uint_as_float(sb[3 * kWave]); t[3] = __uint_as_float(sb[4 * kWave]);
+                            S.trace_idx[(size_t)c * P.trace_cap + n] = counter;
+                        }
+                        S.trace_n[c] = n + 1;
                     }
+                    msg = Q.symbol(P, zero, sym, off, &fbv);
+                }
+                ybox[(s & 1u) * kWave + lane] = msg;
+                if (__builtin_amdgcn_ballot_w64(fbv != 0u) != 0ull) {
+                    uint32_t u1, u2;
+                    wait_for(s, R_S, &u1, &u2, kNapLong);                        // S (like E) has read the feedback box of two steps ago
+                    fb1box[(s & 1u) * LY::fb_words + lane] = fbv; flags = Y1F_ANY;
+                }
+            }
+            if (s + 1u == n_steps) flagbox[lane] = Q.L.flags & (F_AGC_LOCKED | F_BW_LOCKED | F_SQ_LOCK | F_EQ_MODE_MASK | F_EQ_BITS_MASK);   // (Y2 merges the flag bits)
+            publish(s, flags, flags_before);
+            flags_before = flags;
+            P3_LAP(p3_work);
+            if (s == stop_at) { left = true; break; }
+        }
+        SYM_REPORT(4);
+        if (left) return;
+        const State S = fresh_state();
+        S.sq_data[c] = Q.L.sq_data; S.sq_power[c] = Q.L.sq_power; S.sq_phist[c] = Q.L.sq_phist;
+        S.sq_fill[c] = Q.L.sq_fill; S.sq_clock[c] = Q.L.sq_clock; S.sq_symbols[c] = symbols0 + (uint64_t)(Q.nsym - (uint32_t)symbols0);
+        S.eq_word[c] = Q.L.eq_word; S.eq_count[c] = Q.L.eq_count;
+        if (hist_copy) {
+#pragma unroll 4
+            for (int i = 0; i < kSquelchHist; ++i) S.sq_hist[(size_t)i * C + c] = *Q.hptr((uint32_t)i);
+        }
+#pragma unroll
+        for (int i = 0; i < NFF; ++i) {
+            S.eq_ffc[i * C + c] = Q.ffc[i]; S.eq_ffw[i * C + c] = Q.ffw[i];
+            S.eq_snap_ffc[i * C + c] = Q.sffc[i]; S.eq_snap_ffw[i * C + c] = Q.sffw[i];
+        }
+#pragma unroll
+        for (int i = 0; i < NFB; ++i) {
+            S.eq_fbc[i * C + c] = Q.fbc[i]; S.eq_fbw[i * C + c] = Q.fbw[i];
+            S.eq_snap_fbc[i * C + c] = Q.sfbc[i]; S.eq_snap_fbw[i * C + c] = Q.sfbw[i];
+        }
+    } else {
+        // ------------------------------------------ Y2: framer, link state, bursts, hand-over ----------------------------
+        sym_setprio<2>(P);
+        Lane L;
+        State S{};                   // in the loop: the framer's rows only
+        { const State S0 = fresh_state(); lane_load(L, S0, c); S.fr_msg = S0.fr_msg; }
+        Output O{};
+        { const Output Of = fresh_output(); O.n_events = Of.n_events; O.bursts = Of.bursts; O.burst_cap = Of.burst_cap; }
+        lds_barrier();                                                 // prologue
+        P3_T0();
+        uint32_t stop_at = 0xffffffffu, flags_before = 0u;
+        bool left = false, lane_done = false, leave_posted = false;
+        for (uint32_t s = 0; s < n_steps; ++s) {
+            uint32_t w1, w2;
+            wait_for(s, R_Y1, &w1, &w2, kNapShort);                               // Y1's words
+            P3_LAP(p3_wait);
+            uint32_t flags = 0u;
+            if (s >= 3u && s <= last_y2_step) {
+                const uint32_t blk = min(s - 3u, n_blocks - 1u);       // every symbol up to the end of this block has been seen after this step
+                const uint32_t m = ybox[((s - 1u) & 1u) * kWave + lane];
+                uint32_t fbv = 0, io0 = 0, io1 = 0xffffffffu, io2 = 0;
+                bool want_slot = false;                                // this lane has just finished a burst
+                if ((m & YM_VALID) && !PROF_SKIP(P, 1024)) {
+                    uint32_t burst_len = 0;
+                    const uint32_t link = sym_framer_step(P, L, S, c, m, &burst_len, &fbv);
+                    // receiver.rs:246-253: report on change; a Burst always differs from its predecessor
+                    const uint32_t last = (L.flags & F_LINK_MASK) >> F_LINK_SHIFT;
+                    const bool emit = link != last || link == 3u;
+                    if (emit) L.flags = (L.flags & ~F_LINK_MASK) | (link << F_LINK_SHIFT);
+                    want_slot = emit && link == 3u;
+                    io0 = 1u | (link << 1) | (emit ? 8u : 0u) | (((m >> YM_OFF_SHIFT) & 127u) << 4);
+                    io2 = burst_len;
                 }
                 // finished bursts go into the pool with the whole wavefront: one slot reservation for all of them and one
                 // coalesced round trip per burst (same_kernels_pipe.hip)
@@ -755,181 +1255,44 @@ __global__ __launch_bounds__(4 * kWave, 2) void demod_sym_kernel(Params P, State
                         }
                     }
                 }
+                wait_for(s, R_S | R_T | R_A | R_E, &w1, &w2, kNapLong);          // everybody has read the flags and feedback of two steps ago; A is done with the link box
                 lds_u32 *io = iobox + (s & 1u) * LY::io_words + lane;
                 io[0] = io0;
                 if (__builtin_amdgcn_ballot_w64((io0 & 8u) != 0u && ((io0 >> 1) & 3u) == 3u) != 0ull) { io[kWave] = io1; io[2 * kWave] = io2; }
-                lds_u32 *fb = fbbox + (s & 1u) * LY::fb_words;
-                fb[lane] = fbv;
-                const bool any_late = __builtin_amdgcn_ballot_w64(fbv != 0u) != 0ull;
+                const bool any_end = __builtin_amdgcn_ballot_w64((fbv & FB_VALID) != 0u) != 0ull;
+                const bool any_lock = __builtin_amdgcn_ballot_w64((fbv & FB_SQLOCK) != 0u) != 0ull;
+                if (any_end || any_lock) fb2box[(s & 1u) * LY::fb_words + lane] = fbv;
+                flags = (any_end ? Y2F_END : 0u) | (any_lock ? Y2F_LOCK : 0u);
                 // Time-parallel chunk that hands over: from its nominal end on, a lane's hand-over instant is
-                // the end of the first block after which its link state is NoCarrier; once every lane has one the workgroup
-                // leaves (one more step: E still has to log this step's events)
-                uint32_t leave = 0u;
+                // the end of the first block after which its link state is NoCarrier; once every lane has one the group
+                // leaves (one more step: A still has to log this step's events)
                 if (may_leave && !leave_posted) {
                     if (!lane_done && blk + 1u >= n_nominal && (L.flags & F_LINK_MASK) == 0u && (xl == nullptr || blk < avail_l)) {
                         lane_done = true;
                         K.handover[c] = counter0 + (int64_t)row_l + (uint64_t)(blk + 1u) * kB;
                         donebox[lane] = 1u;
                     }
-                    if (__builtin_amdgcn_ballot_w64(!lane_done) == 0ull) { leave = 2u; leave_posted = true; stop_at = s + 1u; }
+                    if (__builtin_amdgcn_ballot_w64(!lane_done) == 0ull) { flags |= Y2F_LEAVE; leave_posted = true; stop_at = s + 1u; }
                 }
-                if (lane == 0u) fb[kWave] = leave | (any_late ? 4u : 0u);
             }
+            if (!(s >= 3u && s <= last_y2_step)) wait_for(s, R_S | R_T | R_A | R_E, &w1, &w2, kNapLong);
+            publish(s, flags, flags_before);
+            flags_before = flags;
             P3_LAP(p3_work);
-            lds_barrier();                                             // A
-            P3_LAP(p3_wait);
             if (s == stop_at) { left = true; break; }
         }
-        SYM_REPORT(2);
-        SYM_COUNT(18, 1);                                              // launches of workgroup 0 ...
+        SYM_REPORT(5);
+        SYM_COUNT(18, 1);                                              // launches of the reporting group ...
         SYM_COUNT(19, left ? stop_at + 1u : n_steps);                  // ... and the steps they ran
-        P3_MARKS_REPORT(X);
         if (left) return;
-        lds_barrier();                                                 // T's TED phase, E's wake-up flag
-        L.flags = (L.flags & ~(F_TED_PHASE | F_TICK_AGAIN)) | (phasebox[lane] & F_TED_PHASE) | (againbox[lane] & F_TICK_AGAIN);
-        S.sq_data[c] = L.sq_data; S.sq_power[c] = L.sq_power; S.sq_phist[c] = L.sq_phist;
-        S.sq_fill[c] = L.sq_fill; S.sq_clock[c] = L.sq_clock; S.sq_symbols[c] = L.sq_symbols;
-        S.eq_word[c] = L.eq_word; S.eq_count[c] = L.eq_count;
-        S.fr_word[c] = L.fr_word; S.fr_count[c] = L.fr_count; S.fr_invalid[c] = L.fr_invalid;
-        S.fr_len[c] = L.fr_len; S.flags[c] = L.flags;
-        if (hist_copy) {
-#pragma unroll 4
-            for (int i = 0; i < kSquelchHist; ++i) S.sq_hist[(size_t)i * C + c] = X.hist[(size_t)i * C];
-        }
-#pragma unroll
-        for (int i = 0; i < NFF; ++i) {
-            S.eq_ffc[i * C + c] = X.ffc[i]; S.eq_ffw[i * C + c] = X.ffw[i];
-            S.eq_snap_ffc[i * C + c] = X.sffc[i]; S.eq_snap_ffw[i * C + c] = X.sffw[i];
-        }
-#pragma unroll
-        for (int i = 0; i < NFB; ++i) {
-            S.eq_fbc[i * C + c] = X.fbc[i]; S.eq_fbw[i * C + c] = X.fbw[i];
-            S.eq_snap_fbc[i * C + c] = X.sfbc[i]; S.eq_snap_fbw[i * C + c] = X.sfbw[i];
-        }
-    } else {
-        // ------------------------------------------ E: one symbol per lane and step: matched filters, timing loop --------
-        P3_HWID(3);
-        const uint32_t wcol_lds = lds_addr(wcol);
-        SymTaps<NT> TP;
-        TP.load(taps);
-        Lane L;
-        lane_load(L, S, c);
-        const float inv_spt = 1.0f / P.samples_per_ted;
-        int cstar = next_fire_count(L.until_next_ted, L.ted_clock);
-        int rel = cstar - (int)L.ted_clock - 1;        // index of the next instant, relative to the end of the finished samples
-        // The plan of step s, made at the end of step s - 1: per lane the next symbol -- instant A
-        // (completes nothing: where B falls does not depend on A's sample) and instant B, or B alone right after a
-        // symsync.reset -- if both lie in finished samples; in the steps after the last block: one instant whatever it is.
-        // S filters at A (where there is one), this wavefront at B.
-        SYM_T_DECL();
-        bool pl_typeA = false, pl_ready = false, pl_single = false;
-        int pl_p2 = 0, pl_c2 = 0;
-        uint32_t pl_n2 = 0;
-        float pl_rem1 = 0.0f, pl_instA = 0.0f;
-        auto plan = [&](uint32_t s) __attribute__((always_inline)) {
-            pl_single = s > n_blocks;
-            const uint32_t wb = (min(s, n_blocks) % (uint32_t)LY::NBLK) * (uint32_t)kB;      // ring slot of the sample at rel 0
-            pl_typeA = !pl_single && (L.flags & F_TED_PHASE) != 0u;
-            pl_rem1 = L.until_next_ted - (float)cstar;                                 // receiver.rs:352
-            pl_instA = L.period_inst + __builtin_amdgcn_fmed3f(pl_rem1, -0.5f, 0.5f);   // rx/symsync.rs:236-241
-            pl_c2 = next_fire_count(pl_instA, 0u);
-            pl_p2 = pl_typeA ? rel + pl_c2 : rel;
-            pl_ready = pl_p2 < 0 && s >= 1u && s <= last_t_step;
-            auto slot = [&](int p) __attribute__((always_inline)) { int n = (int)wb + p; n += n < 0 ? RING : 0; return (uint32_t)n; };
-            pl_n2 = pl_ready ? slot(pl_p2) : 0u;
-            posbox[(s & 1u) * LY::pos_words + lane] = (pl_ready && pl_typeA) ? slot(rel) : 0xffffffffu;
-        };
-        auto work = [&](uint32_t s, uint32_t seq) __attribute__((always_inline)) {
-            uint32_t hdr = 0;
-            float zero = 0.0f, sym = 0.0f, terr = 0.0f, next = 0.0f;
-            if (__builtin_amdgcn_ballot_w64(pl_ready) != 0ull) {
-                SYM_T_BEGIN();
-                SYM_TCOUNT(13, 1);
-                const float sa2 = PROF_SKIP(P, 512) ? 0.0f : TP.template demod<RING>(wcol_lds, (int)pl_n2);
-                SYM_T_LAP(15);
-                float sa1 = 0.0f;
-                if (__builtin_amdgcn_ballot_w64(pl_ready && pl_typeA) != 0ull) {
-                    while ((int32_t)(seqbox[0] - seq) < 0) {}           // S has posted this pass
-                    sa1 = __uint_as_float(sabox[lane]);
-                }
-                SYM_T_LAP(17);
-                if (pl_ready) {
-                    float z, sy, te;
-                    bool have;
-                    if (pl_typeA) {
-                        // ZeroCrossingTed::input + TimingLoop::input without a symbol, rx/symsync.rs:236-241, 278-287
-                        L.h0 = L.h1; L.h1 = L.h2; L.h2 = sa1;
-                        L.flags ^= F_TED_PHASE;
-                        L.period_inst = pl_instA; L.until_next_ted = pl_instA;
-                        have = ted_timing_relaxed(P, L, inv_spt, sa2, pl_instA - (float)pl_c2, &z, &sy, &te);
-                    } else {
-                        have = ted_timing_relaxed(P, L, inv_spt, sa2, pl_rem1, &z, &sy, &te);
-                    }
-                    cstar = next_fire_count(L.until_next_ted, 0u);
-                    rel = pl_p2 + cstar;
-                    if (have) { hdr = 1u | ((uint32_t)(pl_p2 + (pl_single ? 3 * kB : 2 * kB)) << 8); zero = z; sym = sy; terr = te; next = L.until_next_ted; }
-                }
-                SYM_T_LAP(16);
-            }
-            lds_u32 *sb = symbox + (s & 1u) * LY::sym_words + lane;
-            sb[0] = hdr;
-            sb[kWave] = __float_as_uint(zero); sb[2 * kWave] = __float_as_uint(sym);
-            if (P.trace_cap) { sb[3 * kWave] = __float_as_uint(terr); sb[4 * kWave] = __float_as_uint(next); }
-        };
-        // the loop bandwidth of a lock at sync (receiver.rs:431-432) and what end() undoes (receiver.rs:479-490: unlocked
-        // loop bandwidth, symsync.reset()), late: see Y
-        uint32_t late_now = 0u;
-        auto late = [&](uint32_t v) __attribute__((always_inline)) {
-            if (v & 1u) {
-                L.flags = (L.flags & ~F_BW_LOCKED) | ((v & 4u) ? F_BW_LOCKED : 0u);
-                if (v & 8u) {                                            // rx/symsync.rs:166-170, 265-271
-                    L.flags &= ~F_TED_PHASE;
-                    L.h0 = 0.0f; L.h1 = 0.0f; L.h2 = 0.0f;
-                    L.period_avg = P.samples_per_ted; L.period_inst = P.samples_per_ted;
-                }
-            }
-        };
-        plan(0u);                                                      // (nothing: step 0 finishes no symbol)
-        lds_barrier();                                                 // prologue
-        P3_T0();
-        uint32_t stop_at = 0xffffffffu;
-        bool left = false;
-        for (uint32_t s = 0; s < n_steps; ++s) {
-            if (!PROF_SKIP(P, 32)) {
-                work(s, 2u * s + 1u);
-                late(late_now);
-                if (s + 1u <= n_blocks) rel -= kB;                     // block s is finished when step s + 1 begins
-                plan(s + 1u);
-            }
-            P3_LAP(p3_work);
-            lds_barrier();                                             // A
-            P3_LAP(p3_wait);
-            uint32_t late_next = 0u;
-            if (s >= 2u && s <= last_fb_step) {
-                const lds_u32 *fb = fbbox + (s & 1u) * LY::fb_words;
-                const uint32_t fbw = (uint32_t)__builtin_amdgcn_readfirstlane((int)fb[kWave]);
-                if (fbw & 2u) stop_at = s + 1u;
-                if (fbw & 4u) {
-                    // a change of the loop bandwidth or a symsync.reset(): applied behind the next step's symbol (the
-                    // positions of that step are already with S)
-                    const uint32_t v = fb[lane];
-                    if (v & 1u) late_next = v;
-                }
-            }
-            late_now = late_next;
-            if (s == stop_at) { left = true; break; }
-        }
-        late(late_now);                                                // (one that arrived with the last step)
-        SYM_REPORT(3);
-        SYM_T_REPORT();
-        SYM_COUNT(12, n_steps);
-        if (left) return;
-        phasebox[lane] = L.flags & F_TED_PHASE;
-        lds_barrier();                                                 // Y merges the phase bit
-        L.ted_clock = (uint32_t)(cstar - rel - 1);
-        S.until_next_ted[c] = L.until_next_ted; S.ted_clock[c] = L.ted_clock;
-        S.ted_h0[c] = L.h0; S.ted_h1[c] = L.h1; S.ted_h2[c] = L.h2;
-        S.period_avg[c] = L.period_avg; S.period_inst[c] = L.period_inst;
+        // E's TED phase, A's wake-up flag, Y1's locks and equalizer bits: written before their last step was published
+        uint32_t w1, w2;
+        wait_for(n_steps, R_A | R_E | R_Y1, &w1, &w2, kNapShort);
+        constexpr uint32_t kMine = F_FR_STATE_MASK | F_LINK_MASK;
+        L.flags = (L.flags & kMine) | (phasebox[lane] & F_TED_PHASE) | (againbox[lane] & F_TICK_AGAIN) | flagbox[lane];
+        const State S1 = fresh_state();
+        S1.fr_word[c] = L.fr_word; S1.fr_count[c] = L.fr_count; S1.fr_invalid[c] = L.fr_invalid;
+        S1.fr_len[c] = L.fr_len; S1.flags[c] = L.flags;
     }
 }
 
@@ -943,6 +1306,7 @@ bool sym_kernel_supported(const Params &P)
 {
     if (P.knob_sym < 0) return false;
     if (!(P.ntaps == 42u && P.dc_len == 16u && P.win_ring >= 64u && (P.n_channels % kWave) == 0u)) return false;
+    if (P.n_channels >= (1u << 22)) return false;                    // (the squelch history's 24-bit row pitch, SymSquelch::hptr)
     if (!((P.eq_nff == 6u && P.eq_nfb == 4u) || (P.eq_nff == 1u && P.eq_nfb == 1u))) return false;
     if (!(P.agc_min >= 0.0f)) return false;
     return 2u * (max_block_len(P) + 1u) > (uint32_t)kSymBlock;
@@ -953,24 +1317,29 @@ template <int NFF, int NFB, typename SampleT>
 static hipError_t launch_sym_one(const Params &P, const State &S, const Output &O, const float4 *taps, const SampleT *x,
                                  uint32_t n_blocks, uint64_t counter0, hipStream_t stream, const PipeChunks &K)
 {
-    constexpr size_t lds = SymLayout<42>::lds_bytes;
+    constexpr size_t lds = (size_t)kSymHalves * SymLayout<42>::lds_bytes;
+    static_assert(lds <= 160u * 1024u, "one workgroup per CU");
     const bool cm = K.n_chunks > 1u && K.col_row0 != nullptr;
     if (cm && !std::is_same<SampleT, float>::value) return hipErrorInvalidValue;
     if (K.n_chunks > 1u && (K.in_channels % kWave) != 0u) return hipErrorInvalidValue;   // a workgroup would straddle chunks
     if (n_blocks == 0u) return hipSuccess;
     auto go = [&](auto kernel) -> hipError_t {
         if (lds > 64u * 1024u) {
-            // more than the default 64 KB of dynamic LDS per workgroup: opt in, once per kernel and device
-            static bool opted_in[64] = {};
+            // more than the default 64 KB of dynamic LDS per workgroup: opt in, once per kernel and device.  (Keyed on the
+            // kernel's address: the time-major and the channel-major build share this lambda's instantiation.)
+            static std::mutex mu;
+            static std::set<std::pair<const void *, int>> opted_in;
             int dev = 0;
-            if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
-            if (!opted_in[dev]) {
-                const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (hipGetDevice(&dev) != hipSuccess) return hipErrorInvalidDevice;
+            const std::pair<const void *, int> key(reinterpret_cast<const void *>(kernel), dev);
+            std::lock_guard<std::mutex> lock(mu);
+            if (opted_in.find(key) == opted_in.end()) {
+                const hipError_t e = hipFuncSetAttribute(key.first, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
                 if (e != hipSuccess) return e;
-                opted_in[dev] = true;
+                opted_in.insert(key);
             }
         }
-        hipLaunchKernelGGL(kernel, dim3(P.n_channels / kWave), dim3(4 * kWave), lds, stream, P, S, O, taps, x, n_blocks, counter0, K);
+        hipLaunchKernelGGL(kernel, dim3((P.n_channels / kWave + kSymHalves - 1u) / kSymHalves), dim3(kSymHalves * kSymRoles * kWave), lds, stream, P, S, O, taps, x, n_blocks, counter0, K);
         return hipGetLastError();
     };
     if constexpr (std::is_same<SampleT, float>::value) {

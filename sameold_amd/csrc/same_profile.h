@@ -60,24 +60,24 @@ namespace same { static __device__ unsigned long long g_same_prof_relaxed[8]; }
         return 0;                                                                                               \
     }
 #define PIPE_PROF_TAP_PAD 20
-// symbol-paced pipeline (same_kernels_sym.hip), workgroup 0: [3 r .. 3 r + 2] cycles role r (sample, timing, symbol, events) worked /
-// waited at the step barrier / spent in feedback rounds; [12] steps, [13] units the timing wavefront processed (wavefront passes),
-// [14] feedback rounds, [15] cycles of the timing wavefront's filters, [16] of its timing updates and posting
-namespace same { static __device__ unsigned long long g_same_prof_sym[20]; }
-#define SYM_REPORT(role_) do { if (blockIdx.x == 0 && lane == 0) { same::g_same_prof_sym[3 * (role_)] += p3_work; \
+// symbol-paced pipeline (same_kernels_sym.hip), workgroup 0: [3 r .. 3 r + 2] cycles role r (S, T, A, E, Y1, Y2) worked / waited at
+// the step barrier / spent on feedback; [18] launches, [19] steps, [20] passes of E with a symbol, [22] cycles of E's filters,
+// [23] of its timing updates and posting, [24] waiting for A's soft sample.  The group of 64 columns that reports: SAME_PIPE_PRIO >> 16
+namespace same { static __device__ unsigned long long g_same_prof_sym[32]; }
+#define SYM_REPORT(role_) do { if (vwg == ((uint32_t)P.knob_prio >> 16) && lane == 0) { same::g_same_prof_sym[3 * (role_)] += p3_work; \
         same::g_same_prof_sym[3 * (role_) + 1] += p3_wait; same::g_same_prof_sym[3 * (role_) + 2] += p3_fb; } } while (0)
-#define SYM_COUNT(i_, n_) do { if (blockIdx.x == 0 && lane == 0) same::g_same_prof_sym[i_] += (n_); } while (0)
-#define SYM_TCOUNT(i_, n_) do { symt_n[(i_) - 13] += (n_); } while (0)
+#define SYM_COUNT(i_, n_) do { if (vwg == ((uint32_t)P.knob_prio >> 16) && lane == 0) same::g_same_prof_sym[i_] += (n_); } while (0)
+#define SYM_TCOUNT(i_, n_) do { symt_n[(i_) - 20] += (n_); } while (0)
 #define SYM_T_DECL() unsigned long long symt_acc[3] = {0, 0, 0}, symt_n[2] = {0, 0}, symt_t = 0
 #define SYM_T_BEGIN() do { symt_t = clock64(); } while (0)
-#define SYM_T_LAP(i_) do { const unsigned long long t_ = clock64(); symt_acc[(i_) - 15] += t_ - symt_t; symt_t = t_; } while (0)
-#define SYM_T_REPORT() do { if (blockIdx.x == 0 && lane == 0) { for (int i_ = 0; i_ < 3; ++i_) same::g_same_prof_sym[15 + i_] += symt_acc[i_]; \
-        same::g_same_prof_sym[13] += symt_n[0]; same::g_same_prof_sym[14] += symt_n[1]; } } while (0)
+#define SYM_T_LAP(i_) do { const unsigned long long t_ = clock64(); symt_acc[(i_) - 22] += t_ - symt_t; symt_t = t_; } while (0)
+#define SYM_T_REPORT() do { if (vwg == ((uint32_t)P.knob_prio >> 16) && lane == 0) { for (int i_ = 0; i_ < 3; ++i_) same::g_same_prof_sym[22 + i_] += symt_acc[i_]; \
+        same::g_same_prof_sym[20] += symt_n[0]; same::g_same_prof_sym[21] += symt_n[1]; } } while (0)
 #define SYM_PROFILE_EXPORTS()                                                                                   \
-    extern "C" int same_debug_profile_sym(unsigned long long *out20, int reset)                                 \
+    extern "C" int same_debug_profile_sym(unsigned long long *out32, int reset)                                 \
     {                                                                                                           \
-        unsigned long long z[20] = {0};                                                                         \
-        if (hipMemcpyFromSymbol(out20, HIP_SYMBOL(same::g_same_prof_sym), sizeof(z)) != hipSuccess) return -1;  \
+        unsigned long long z[32] = {0};                                                                         \
+        if (hipMemcpyFromSymbol(out32, HIP_SYMBOL(same::g_same_prof_sym), sizeof(z)) != hipSuccess) return -1;  \
         if (reset && hipMemcpyToSymbol(HIP_SYMBOL(same::g_same_prof_sym), z, sizeof(z)) != hipSuccess) return -1; \
         return 0;                                                                                               \
     }                                                                                                           \

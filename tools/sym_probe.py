@@ -94,16 +94,16 @@ def prof(rx):
     L = rx._L
     if not hasattr(L, "same_debug_profile_sym"):
         return
-    out = (ctypes.c_ulonglong * 20)()
+    out = (ctypes.c_ulonglong * 32)()
     if L.same_debug_profile_sym(out, 1) != 0:
         return
     v = list(out)
     steps = max(v[19], 1)
-    names = ["S agc+flt A", "T dc+events", "Y symbol", "E flt B+ted"]
-    for r in range(4):
-        print(f"  {names[r]:12s} work {v[3*r]/steps:8.1f}  barrier wait {v[3*r+1]/steps:8.1f}  feedback {v[3*r+2]/steps:8.1f}  clk/step")
+    names = ["S agc", "T dc", "A flt A+events", "E flt B+ted", "Y1 squelch+eq", "Y2 framer"]
+    for r in range(6):
+        print(f"  {names[r]:16s} work {v[3*r]/steps:8.1f}  barrier wait {v[3*r+1]/steps:8.1f}  feedback {v[3*r+2]/steps:8.1f}  clk/step")
     print(f"  workgroup 0: {v[18]} launches, {steps} steps, {sum(v[0:3])/steps:.0f} clk per step;", end="")
-    print(f"  steps {steps}, T passes {v[13]}, feedback rounds {v[14]} ({100.0*v[14]/steps:.1f} % of steps); E's filter {v[15]/max(v[13],1):.0f} clk/pass, waiting for S's {v[17]/max(v[13],1):.0f}, timing+post {v[16]/max(v[13],1):.0f} clk/pass", flush=True)
+    print(f"  E passes {v[20]}; E's filter {v[22]/max(v[20],1):.0f} clk/pass, waiting for A's {v[24]/max(v[20],1):.0f}, timing+post {v[23]/max(v[20],1):.0f} clk/pass", flush=True)
 
 
 def marks(rx):

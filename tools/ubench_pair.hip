@@ -115,9 +115,11 @@ __device__ __forceinline__ void agc2(float2v *w, float2v &gain, float bw, float 
     }
 }
 
-// one workgroup = T + S over 64 lanes; n_blocks blocks of 36 samples; x: time-major rows of `row` floats
-template <int MODE>
-__global__ __launch_bounds__(2 * kWave, 4) void pair_kernel(const float *__restrict__ x, uint32_t row, uint32_t n_blocks, float bw, float gmin, float gmax,
+// one workgroup = T + S over 64 lanes; n_blocks blocks of 36 samples; x: time-major rows of `row` floats.
+// ROLES: 1 = T alone (S only keeps the barrier), 2 = S alone, 3 = both.  T requests block b + 1 before it computes block b (the
+// shipped kernel's prefetch), so its loads have a whole step to arrive.
+template <int MODE, int ROLES>
+__global__ __launch_bounds__(2 * kWave, 2) void pair_kernel(const float *__restrict__ x, uint32_t row, uint32_t n_blocks, float bw, float gmin, float gmax,
                                                             float *out, unsigned long long *clk)
 {
     extern __shared__ float lds[];
@@ -130,39 +132,53 @@ __global__ __launch_bounds__(2 * kWave, 4) void pair_kernel(const float *__restr
         if constexpr (MODE == 1) {
             Dc1 D;
             static_for<kDCL / 2>([&](auto h_) __attribute__((always_inline)) { constexpr int h = decltype(h_)::value; D.xp[h] = float2v{0.0f, 0.0f}; D.sp[h] = float2v{0.0f, 0.0f}; });
-            Dc1::Pairs X;
-            for (uint32_t b = 0; b < n_blocks; ++b) {
-                const float *xr = x + (size_t)b * kB * row + col;
+            Dc1::Pairs XA, XB;
+            auto request = [&](Dc1::Pairs &X, uint32_t b) __attribute__((always_inline)) {
+                const float *xr = x + (size_t)(b < n_blocks ? b : n_blocks - 1u) * kB * row + col;
                 static_for<kB / 2>([&](auto h_) __attribute__((always_inline)) { constexpr int h = decltype(h_)::value; X[h] = float2v{xr[(size_t)(2 * h) * row], xr[(size_t)(2 * h + 1) * row]}; });
-                D.block(ring + ((b % kRingBlocks) * kB) * kWave, X);
+            };
+            request(XA, 0u);
+            for (uint32_t b = 0; b < n_blocks; b += 2u) {
+                request(XB, b + 1u);
+                if (ROLES & 1) D.block(ring + ((b % kRingBlocks) * kB) * kWave, XA);
+                lds_barrier();
+                request(XA, b + 2u);
+                if (ROLES & 1) D.block(ring + (((b + 1u) % kRingBlocks) * kB) * kWave, XB);
                 lds_barrier();
             }
-            out[col] = D.sum1;
+            out[col] = D.sum1 + XA[0].x;
         } else {
             Dc2 D;
             static_for<kDCL>([&](auto k_) __attribute__((always_inline)) { constexpr int k = decltype(k_)::value; D.xp[k] = float2v{0.0f, 0.0f}; D.sp[k] = float2v{0.0f, 0.0f}; });
-            Dc2::Block X;
-            for (uint32_t b = 0; b < n_blocks; ++b) {
-                const float *xr = x + (size_t)b * kB * row + col;
+            Dc2::Block XA, XB;
+            auto request = [&](Dc2::Block &X, uint32_t b) __attribute__((always_inline)) {
+                const float *xr = x + (size_t)(b < n_blocks ? b : n_blocks - 1u) * kB * row + col;
                 static_for<kB>([&](auto k_) __attribute__((always_inline)) { constexpr int k = decltype(k_)::value; X[k] = *reinterpret_cast<const float2v *>(xr + (size_t)k * row); });
-                D.block(reinterpret_cast<float2v *>(ring + ((b % kRingBlocks) * kB) * kWave * 2), X);
+            };
+            request(XA, 0u);
+            for (uint32_t b = 0; b < n_blocks; b += 2u) {
+                request(XB, b + 1u);
+                if (ROLES & 1) D.block(reinterpret_cast<float2v *>(ring + ((b % kRingBlocks) * kB) * kWave * 2), XA);
+                lds_barrier();
+                request(XA, b + 2u);
+                if (ROLES & 1) D.block(reinterpret_cast<float2v *>(ring + (((b + 1u) % kRingBlocks) * kB) * kWave * 2), XB);
                 lds_barrier();
             }
-            out[col] = D.sum1.x + D.sum1.y;
+            out[col] = D.sum1.x + D.sum1.y + XA[0].x;
         }
     } else {
         if constexpr (MODE == 1) {
             float gain = 1.0e-4f;
             for (uint32_t b = 0; b < n_blocks; ++b) {
                 lds_barrier();
-                agc1(ring + ((b % kRingBlocks) * kB) * kWave, gain, bw, gmin, gmax);
+                if (ROLES & 2) agc1(ring + ((b % kRingBlocks) * kB) * kWave, gain, bw, gmin, gmax);
             }
             out[col] += gain;
         } else {
             float2v gain = {1.0e-4f, 1.0e-4f};
             for (uint32_t b = 0; b < n_blocks; ++b) {
                 lds_barrier();
-                agc2(reinterpret_cast<float2v *>(ring + ((b % kRingBlocks) * kB) * kWave * 2), gain, bw, gmin, gmax);
+                if (ROLES & 2) agc2(reinterpret_cast<float2v *>(ring + ((b % kRingBlocks) * kB) * kWave * 2), gain, bw, gmin, gmax);
             }
             out[col] += gain.x + gain.y;
         }
@@ -172,27 +188,28 @@ __global__ __launch_bounds__(2 * kWave, 4) void pair_kernel(const float *__restr
 
 #define CHECK(e) do { hipError_t e_ = (e); if (e_ != hipSuccess) { fprintf(stderr, "%s:%d %s\n", __FILE__, __LINE__, hipGetErrorString(e_)); exit(1); } } while (0)
 
-template <int MODE>
+template <int MODE, int ROLES>
 static void run(uint32_t wgs, uint32_t n_blocks, const float *x, uint32_t row, float *out, unsigned long long *clk)
 {
     const size_t lds = (size_t)kRingBlocks * kB * kWave * MODE * sizeof(float);
-    CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(pair_kernel<MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(pair_kernel<MODE, ROLES>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipEvent_t e0, e1;
     CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
     for (int rep = 0; rep < 3; ++rep) {
         CHECK(hipEventRecord(e0));
-        hipLaunchKernelGGL(pair_kernel<MODE>, dim3(wgs), dim3(2 * kWave), lds, 0, x, row, n_blocks, 1.9e-5f, 3.05e-5f, 5.0e-3f, out, clk);
+        hipLaunchKernelGGL((pair_kernel<MODE, ROLES>), dim3(wgs), dim3(2 * kWave), lds, 0, x, row, n_blocks, 1.9e-5f, 3.05e-5f, 5.0e-3f, out, clk);
         CHECK(hipEventRecord(e1)); CHECK(hipEventSynchronize(e1));
     }
     float ms = 0; CHECK(hipEventElapsedTime(&ms, e0, e1));
     std::vector<unsigned long long> h(2 * wgs);
     CHECK(hipMemcpy(h.data(), clk, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-    double t = 0, s = 0;
-    for (uint32_t i = 0; i < wgs; ++i) { t += (double)h[2 * i]; s += (double)h[2 * i + 1]; }
-    t /= wgs; s /= wgs;
+    double t = 0;
+    for (uint32_t i = 0; i < wgs; ++i) t += (double)h[2 * i];
+    t /= wgs;
     const double ch = 64.0 * MODE, samples = (double)n_blocks * kB * ch * wgs;
-    printf("MODE %d (%d channel%s per lane)  %5u workgroups  %.3f ms  %.1f Gsample/s | T %.0f clk/block = %.3f clk per channel-sample, S %.0f clk/block = %.3f\n",
-           MODE, MODE, MODE == 1 ? "" : "s", wgs, ms, samples / ms * 1e-6, t / n_blocks, t / n_blocks / (kB * ch) * 64.0, s / n_blocks, s / n_blocks / (kB * ch) * 64.0);
+    printf("%d channel%s per lane, %s  %5u workgroups  %.3f ms  %7.1f Gsample/s | %.0f clk per 36-sample block = %.2f clk per sample of 64 channels\n",
+           MODE, MODE == 1 ? " " : "s", ROLES == 1 ? "T alone (loads + DC blocker)" : (ROLES == 2 ? "S alone (AGC in place)      " : "T and S                     "),
+           wgs, ms, samples / ms * 1e-6, t / n_blocks, t / n_blocks / kB / MODE);
 }
 
 int main()
@@ -204,12 +221,11 @@ int main()
     CHECK(hipMemset(x, 0x3c, rows * row * sizeof(float)));
     CHECK(hipMalloc(&out, (size_t)row * 2 * sizeof(float)));
     CHECK(hipMalloc(&clk, 2 * 8192 * sizeof(unsigned long long)));
-    // 1 024 SIMDs: 512 two-wave workgroups = one wave per SIMD, 1 024 = two, 2 048 = four (the shipped kernel keeps two)
-    for (uint32_t wgs : {256u, 512u, 1024u, 2048u}) {
-        run<1>(wgs, n_blocks, x, row, out, clk);
-        run<2>(wgs / 2 ? wgs / 2 : 1, n_blocks, x, row, out, clk);     // the same channels on half the lanes
-        run<2>(wgs, n_blocks, x, row, out, clk);                        // the same lanes with twice the channels
+    // 1 024 SIMDs and two wavefronts per workgroup: 512 workgroups = one wavefront per SIMD, 1 024 = two, 1 536 = three (the shipped kernel)
+    for (uint32_t wgs : {512u, 1024u, 1536u}) {
+        run<1, 1>(wgs, n_blocks, x, row, out, clk); run<1, 2>(wgs, n_blocks, x, row, out, clk); run<1, 3>(wgs, n_blocks, x, row, out, clk);
+        run<2, 1>(wgs / 2, n_blocks, x, row, out, clk); run<2, 2>(wgs / 2, n_blocks, x, row, out, clk); run<2, 3>(wgs / 2, n_blocks, x, row, out, clk);   // the same channels on half the wavefronts
     }
-    printf("clk per channel-sample x 64 = wavefront-clocks per workgroup-sample of 64 channels (the unit of DESIGN.md's instruction budgets)\n");
+    printf("(clk per sample of 64 channels: wavefront-clocks per workgroup-sample, the unit of DESIGN.md's instruction budgets; two channels per lane: per 64 of its 128 channels)\n");
     return 0;
 }
