@@ -41,7 +41,8 @@ enum {
     SAME_EHIP = -6,          /* a HIP runtime call failed (same_last_error() has text) */
     SAME_EOVERFLOW = -7,     /* event or burst pool overflow: results truncated */
     SAME_ENOMEM = -8,
-    SAME_ERATE = -9          /* input rate too low for the matched filters (ntaps < 1) */
+    SAME_ERATE = -9,         /* input rate too low for the matched filters (ntaps < 1) */
+    SAME_EKERNEL = -10       /* a kernel's wavefronts lost step with each other (an internal hand-over timed out): results of the call are void */
 };
 const char *same_last_error(void);
 uint32_t same_rx_abi_version(void);

@@ -270,6 +270,7 @@ struct same_batch {
     hipStream_t plan_stream = nullptr;
     float last_ms = 0.0f;
     bool overflowed = false;
+    bool kernel_fault = false;       // counters[2] bit 2: a wavefront pipeline's bounded hand-over wait ran out (same_kernels_sym.hip)
     bool use_fast = false;           // configuration has a latency-optimised kernel
     bool relaxed = false;            // relaxed arithmetic in time-parallel chunks (SAME_BATCH_TIME_PARALLEL or SAME_BATCH_RELAXED)
     bool last_plain_fm = false;      // the last ordinary launch ran the pipeline's FASTMATH build
@@ -798,7 +799,8 @@ int harvest_slot(same_batch *rx, same_batch::Slot &sl)
         std::fprintf(stderr, "[same] harvest: %u device events (%u bursts), cap %u/%u\n", sl.h_counters[0],
                      sl.h_counters[1], sl.event_cap, sl.burst_cap);
     const uint32_t n_bursts = std::min(sl.h_counters[1], sl.burst_cap);
-    if (sl.h_counters[2]) rx->overflowed = true;
+    if (sl.h_counters[2] & 3u) rx->overflowed = true;
+    if (sl.h_counters[2] & 4u) rx->kernel_fault = true;
     const size_t ev_bytes = (size_t)n_events * sizeof(same::DevEvent), bu_bytes = (size_t)n_bursts * same::kBurstCap;
     auto grow = [](void **p, size_t *have, size_t need) -> hipError_t {
         if (need <= *have) return hipSuccess;
@@ -1417,6 +1419,7 @@ int process_host_any(same_batch *rx, const SampleT *h_x, size_t n_samples, uint3
         rc = process_device_any(rx, (const SampleT *)d_in, n, layout, SAME_STREAM_OWN);
         if (rc == SAME_OK) rc = harvest(rx);
     }
+    if (rc == SAME_OK && rx->kernel_fault) return fail(SAME_EKERNEL, "a demodulation kernel's wavefronts lost step (internal hand-over timed out)");
     if (rc == SAME_OK && rx->overflowed) return fail(SAME_EOVERFLOW, "event/burst pool overflow");
     return rc;
 }
@@ -1584,6 +1587,7 @@ int same_batch_reset(same_batch *rx)
     for (auto &t : rx->tp.synth) t.reset();
     if (rx->h_wake) std::memset(rx->h_wake, 0, (size_t)rx->P.n_channels * sizeof(uint64_t));
     rx->overflowed = false;
+    rx->kernel_fault = false;
     return SAME_OK;
 }
 
@@ -1638,6 +1642,7 @@ int same_batch_sync(same_batch *rx)
     HIP_TRY(hipSetDevice(rx->device));
     int rc = harvest(rx);
     if (rc) return rc;
+    if (rx->kernel_fault) return fail(SAME_EKERNEL, "a demodulation kernel's wavefronts lost step (internal hand-over timed out)");
     if (rx->overflowed) return fail(SAME_EOVERFLOW, "event/burst pool overflow");
     return SAME_OK;
 }

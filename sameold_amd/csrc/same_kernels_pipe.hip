@@ -895,8 +895,17 @@ __global__ __launch_bounds__((pipe_dcw<NT, LANES, SPLIT>() ? 5 : 4) * kWave, SHA
         [[maybe_unused]] const float inv_spt = 1.0f / P.samples_per_ted;
         // one block: the instant, if this lane has one in it; hands a completed symbol to stage 3
         S2_BEGIN();
+        // A block's SECOND instant when the first one completed the symbol (-1: none).  A symbol may flip the AGC lock at its
+        // sample (sync: receiver.rs:431); the correction that follows -- stage 1 replays the AGC from that sample on, this stage
+        // goes back to before its current block -- reaches the next block's instants, but an instant that shares the SYMBOL's block
+        // and follows its sample was filtered over the window as it stood before the replay.  It completes nothing, so its
+        // soft sample is all that is wrong: the TED's newest tap, which the next symbol hands to the squelch as its first sample
+        // (and the equalizer reads 24 symbols later).  Round 5 found it as one trial in 65 536 of configs[4] whose burst tail,
+        // decoded from noise, differed from the oracle's in two bits; `a2_last` is what the correction below needs to redo it.
+        int a2_now = -1, a2_last = -1;
         auto do_block = [&](uint32_t blk, uint32_t seq) {
             S2_LAP(4);
+            a2_now = -1;
             uint32_t hdr = 0;
             float zero = 0.0f, sym = 0.0f, terr = 0.0f, next = 0.0f;
             if (until < kB) {
@@ -946,6 +955,7 @@ __global__ __launch_bounds__((pipe_dcw<NT, LANES, SPLIT>() ? 5 : 4) * kWave, SHA
                     // two instants completes a symbol.
                     const int fk2 = until;
                     COUNT_SECOND_INSTANT();
+                    if (hdr & 1u) a2_now = fk2;                       // (the first instant completed the symbol: this one follows its sample)
                     float sa2;
                     if constexpr (FM) {
                         float hm2, hs2;
@@ -1006,11 +1016,25 @@ __global__ __launch_bounds__((pipe_dcw<NT, LANES, SPLIT>() ? 5 : 4) * kWave, SHA
                         }
                     }
                     lds_barrier();                                     // B: stage 1 has corrected the window
+                    if ((v & 1u) && a2_last >= 0 && (int)(v >> 8) < a2_last && !(v & 8u)) {
+                        // the symbol's block (s - 2) had an instant behind the symbol's sample: its soft sample once more, over
+                        // the corrected window; it is the newest tap of the TED this lane has just gone back to.  (After an
+                        // end() the TED's taps have just been zeroed by the reset: nothing to correct.)
+                        const uint32_t wprev = (wpos >= (uint32_t)kB ? wpos : wpos + (uint32_t)RING) - (uint32_t)kB;
+                        if constexpr (FM) {
+                            float hm2, hs2;
+                            demod_pair_relaxed<NTP, RING, false>(lds_addr(lds), lds_addr(wcol), wprev + (uint32_t)a2_last, &hm2, &hs2);
+                            L.h2 = __builtin_amdgcn_fmed3f(hm2 - hs2, -1.0f, 1.0f);
+                        } else {
+                            L.h2 = demod_fast<NT, RING, true>(tlds, wring, lane, wprev + (uint32_t)a2_last);
+                        }
+                    }
                     if ((v & 1u) && active) do_block(s - 1u, 2u * s + 2u);
                     lds_barrier();                                     // C
                     P3_LAP(p3_fb);
                 }
             }
+            a2_last = active ? a2_now : -1;
             if (active) { wpos += kB; if (wpos == (uint32_t)RING) wpos = 0; }
             if (s == stop_at) { left = true; break; }
         }

@@ -797,7 +797,9 @@ __global__ __launch_bounds__(kSymHalves * kSymRoles * kWave, 3) void demod_sym_k
         bool left = false;
         for (uint32_t s = 0; s < n_steps; ++s) {
             uint32_t w1, w2;
+            SYM_TRACE(0, s, 0);
             wait_for(s, kDepsS, &w1, &w2, kNapLong);
+            SYM_TRACE(0, s, 1);
             P3_LAP(p3_wait);
             const uint32_t f1 = flags_of_last(w1, s), f2 = flags_of_last(w2, s);
             if (f2 & Y2F_LEAVE) stop_at = s;
@@ -820,6 +822,7 @@ __global__ __launch_bounds__(kSymHalves * kSymRoles * kWave, 3) void demod_sym_k
                 P3_LAP(p3_fb);
             }
             if (s < n_blocks && !PROF_SKIP(P, 64)) M.block(P, wcol, s);
+            SYM_TRACE(0, s, 2);
             publish(s, 0u, 0u);
             P3_LAP(p3_work);
             if (s == stop_at) { left = true; break; }
@@ -843,7 +846,9 @@ __global__ __launch_bounds__(kSymHalves * kSymRoles * kWave, 3) void demod_sym_k
         auto step = [&](uint32_t s, auto buf) __attribute__((always_inline)) -> bool {
             constexpr int BUF = decltype(buf)::value;                  // block s + 1 waits in buffer BUF = (s + 1) & 1
             uint32_t w1, w2;
+            SYM_TRACE(1, s, 0);
             wait_for(s, R_A | R_E, &w1, &w2, kNapLong);                          // the filters are done with the ring block this step overwrites
+            SYM_TRACE(1, s, 1);
             P3_LAP(p3_wait);
             if constexpr (CMODE == 1) D.done = donebox[lane] != 0u;
             if (s + 1u < n_blocks && !PROF_SKIP(P, 128)) {
@@ -852,6 +857,7 @@ __global__ __launch_bounds__(kSymHalves * kSymRoles * kWave, 3) void demod_sym_k
             }
             wait_for(s, R_Y2, &w1, &w2, kNapLong);                               // has Y2 called the hand-over?
             if (flags_of_last(w2, s) & Y2F_LEAVE) stop_at = s;
+            SYM_TRACE(1, s, 2);
             publish(s, 0u, 0u);
             P3_LAP(p3_work);
             return s == stop_at;
@@ -890,7 +896,9 @@ __global__ __launch_bounds__(kSymHalves * kSymRoles * kWave, 3) void demod_sym_k
         bool left = false;
         for (uint32_t s = 0; s < n_steps; ++s) {
             uint32_t w1, w2;
+            SYM_TRACE(2, s, 0);
             wait_for(s, R_S | R_E, &w1, &w2, kNapShort);                          // S's blocks, E's positions (and E is done with the last soft sample)
+            SYM_TRACE(2, s, 1);
             P3_LAP(p3_wait);
             // the filters at the positions E posted (E takes the second instant and waits for this one's soft sample)
             if (s >= 1u && s <= last_e_step) {
@@ -902,6 +910,7 @@ __global__ __launch_bounds__(kSymHalves * kSymRoles * kWave, 3) void demod_sym_k
                     if (lane == 0u) seqbox[0] = 2u * s + 1u;           // (LDS operations of a wavefront stay in order)
                 }
             }
+            SYM_TRACE(2, s, 3);
             sym_setprio<1>(P);
             wait_for(s, R_Y2, &w1, &w2, kNapLong);                               // Y2's link words; has it called the hand-over?
             if (flags_of_last(w2, s) & Y2F_LEAVE) stop_at = s;
@@ -921,6 +930,7 @@ __global__ __launch_bounds__(kSymHalves * kSymRoles * kWave, 3) void demod_sym_k
                 }
             }
             if (s + 1u == n_steps) againbox[lane] = L.flags & F_TICK_AGAIN;      // (Y2 merges the flag bits)
+            SYM_TRACE(2, s, 2);
             publish(s, 0u, 0u);
             sym_setprio<3>(P);
             P3_LAP(p3_work);
@@ -1056,10 +1066,13 @@ __global__ __launch_bounds__(kSymHalves * kSymRoles * kWave, 3) void demod_sym_k
             // The step's chain -- filters -> timing updates -> where the next symbol's instants fall -> (next step) filters -- is the
             // longest of the pipeline: it starts as soon as S has the samples, and only then waits for what is needed later.
             uint32_t w1, w2;
+            SYM_TRACE(3, s, 0);
             wait_for(s, R_S, &w1, &w2, kNapShort);
             P3_LAP(p3_wait);
             if (!PROF_SKIP(P, 32)) filters(2u * s + 1u);
+            SYM_TRACE(3, s, 1);
             wait_for(s, R_A | R_Y1 | R_Y2, &w1, &w2, kNapShort);                  // A is done with the positions, Y1 with the symbol box; feedback of Y1 and Y2
+            SYM_TRACE(3, s, 3);
             const uint32_t f1 = flags_of_last(w1, s), f2 = flags_of_last(w2, s);
             if (f2 & Y2F_LEAVE) stop_at = s;
             // a change of the loop bandwidth or a symsync.reset() posted in step s - 1: applied behind this step's symbol (its
@@ -1074,6 +1087,7 @@ __global__ __launch_bounds__(kSymHalves * kSymRoles * kWave, 3) void demod_sym_k
                 plan(s + 1u);
             }
             if (s + 1u == n_steps) phasebox[lane] = L.flags & F_TED_PHASE;       // (Y2 merges the phase bit)
+            SYM_TRACE(3, s, 2);
             publish(s, 0u, 0u);
             P3_LAP(p3_work);
             if (s == stop_at) { left = true; break; }
@@ -1123,20 +1137,27 @@ __global__ __launch_bounds__(kSymHalves * kSymRoles * kWave, 3) void demod_sym_k
         }
         lds_barrier();                                                 // prologue
         P3_T0();
-        uint32_t stop_at = 0xffffffffu, flags_before = 0u;
+        uint32_t stop_at = 0xffffffffu, flags_before = 0u, last_msg = 0u;
         bool left = false;
         for (uint32_t s = 0; s < n_steps; ++s) {
             uint32_t w1, w2;
+            SYM_TRACE(4, s, 0);
             wait_for(s, R_E | R_Y2, &w1, &w2, kNapShort);                         // E's symbols, Y2's feedback (and Y2 is done with the word box)
+            SYM_TRACE(4, s, 1);
             P3_LAP(p3_wait);
             const uint32_t f2 = flags_of_last(w2, s);
             if (f2 & Y2F_LEAVE) stop_at = s;
-            // what the framer decided in step s - 1 (squelch.lock(true) on Reading, end() on NoCarrier / Burst)
+            // What the framer decided in step s - 1 (squelch.lock(true) on Reading, end() on NoCarrier / Burst) -- about the symbol
+            // BEFORE the one this wavefront saw in that step.  If that newer symbol already ended the acquisition (lost sync:
+            // end() here) or began a new one (sync), the framer's word is about a state that no longer exists: a lock applied
+            // behind the end() it preceded would close the squelch for good, an end() behind a fresh sync would wipe it.
             if ((f2 & (Y2F_END | Y2F_LOCK)) && s >= 1u) {
                 const uint32_t from_y2 = fb2box[((s - 1u) & 1u) * LY::fb_words + lane];
-                if (from_y2 & FB_SQLOCK) Q.L.flags |= F_SQ_LOCK;
-                if (from_y2 & FB_END) Q.end();
+                const bool superseded = (last_msg & (YM_DROP | YM_ADJUSTED)) != 0u;
+                if ((from_y2 & FB_SQLOCK) && !superseded) Q.L.flags |= F_SQ_LOCK;
+                if ((from_y2 & FB_END) && !superseded) Q.end();
             }
+            last_msg = 0u;
             uint32_t flags = 0u;
             if (s >= 2u && s <= last_y1_step) {
                 const lds_u32 *sb = symbox + ((s - 1u) & 1u) * LY::sym_words + lane;
@@ -1160,6 +1181,7 @@ __global__ __launch_bounds__(kSymHalves * kSymRoles * kWave, 3) void demod_sym_k
                     msg = Q.symbol(P, zero, sym, off, &fbv);
                 }
                 ybox[(s & 1u) * kWave + lane] = msg;
+                last_msg = msg;
                 if (__builtin_amdgcn_ballot_w64(fbv != 0u) != 0ull) {
                     uint32_t u1, u2;
                     wait_for(s, R_S, &u1, &u2, kNapLong);                        // S (like E) has read the feedback box of two steps ago
@@ -1167,6 +1189,7 @@ __global__ __launch_bounds__(kSymHalves * kSymRoles * kWave, 3) void demod_sym_k
                 }
             }
             if (s + 1u == n_steps) flagbox[lane] = Q.L.flags & (F_AGC_LOCKED | F_BW_LOCKED | F_SQ_LOCK | F_EQ_MODE_MASK | F_EQ_BITS_MASK);   // (Y2 merges the flag bits)
+            SYM_TRACE(4, s, 2);
             publish(s, flags, flags_before);
             flags_before = flags;
             P3_LAP(p3_work);
@@ -1206,7 +1229,9 @@ __global__ __launch_bounds__(kSymHalves * kSymRoles * kWave, 3) void demod_sym_k
         bool left = false, lane_done = false, leave_posted = false;
         for (uint32_t s = 0; s < n_steps; ++s) {
             uint32_t w1, w2;
+            SYM_TRACE(5, s, 0);
             wait_for(s, R_Y1, &w1, &w2, kNapShort);                               // Y1's words
+            SYM_TRACE(5, s, 1);
             P3_LAP(p3_wait);
             uint32_t flags = 0u;
             if (s >= 3u && s <= last_y2_step) {
@@ -1276,6 +1301,7 @@ __global__ __launch_bounds__(kSymHalves * kSymRoles * kWave, 3) void demod_sym_k
                 }
             }
             if (!(s >= 3u && s <= last_y2_step)) wait_for(s, R_S | R_T | R_A | R_E, &w1, &w2, kNapLong);
+            SYM_TRACE(5, s, 2);
             publish(s, flags, flags_before);
             flags_before = flags;
             P3_LAP(p3_work);

@@ -73,7 +73,16 @@ namespace same { static __device__ unsigned long long g_same_prof_sym[32]; }
 #define SYM_T_LAP(i_) do { const unsigned long long t_ = clock64(); symt_acc[(i_) - 22] += t_ - symt_t; symt_t = t_; } while (0)
 #define SYM_T_REPORT() do { if (vwg == ((uint32_t)P.knob_prio >> 16) && lane == 0) { for (int i_ = 0; i_ < 3; ++i_) same::g_same_prof_sym[22 + i_] += symt_acc[i_]; \
         same::g_same_prof_sym[20] += symt_n[0]; same::g_same_prof_sym[21] += symt_n[1]; } } while (0)
+// timeline of the reporting group: shader clock at mark k (0 step begins, 1 first wait over, 2 work done / published) of role r in steps
+// SYM_TRACE_S0 .. + SYM_TRACE_N - 1 of a launch (tools/sym_probe.py timeline)
+#define SYM_TRACE_S0 600u
+#define SYM_TRACE_N 12u
+namespace same { static __device__ unsigned long long g_same_prof_trace[6 * 12 * 4]; }
+#define SYM_TRACE(role_, s_, k_) do { if (vwg == ((uint32_t)P.knob_prio >> 16) && lane == 0 && (s_) >= SYM_TRACE_S0 && (s_) < SYM_TRACE_S0 + SYM_TRACE_N) \
+        same::g_same_prof_trace[((role_) * SYM_TRACE_N + ((s_) - SYM_TRACE_S0)) * 4u + (k_)] = clock64(); } while (0)
 #define SYM_PROFILE_EXPORTS()                                                                                   \
+    extern "C" int same_debug_profile_sym_trace(unsigned long long *out288)                                     \
+    { return hipMemcpyFromSymbol(out288, HIP_SYMBOL(same::g_same_prof_trace), 288 * sizeof(unsigned long long)) == hipSuccess ? 0 : -1; } \
     extern "C" int same_debug_profile_sym(unsigned long long *out32, int reset)                                 \
     {                                                                                                           \
         unsigned long long z[32] = {0};                                                                         \
@@ -157,6 +166,7 @@ namespace same { struct ProfMarks { __device__ __forceinline__ void mark(int) {}
 #define SYM_T_LAP(i_) do {} while (0)
 #define SYM_T_REPORT() do {} while (0)
 #define SYM_PROFILE_EXPORTS()
+#define SYM_TRACE(role_, s_, k_) do {} while (0)
 #define FAST_MARKS_BEGIN(X_, lds_, nt_) do {} while (0)
 #define FAST_MARKS_START(X_) do {} while (0)
 #define FAST_MARKS_REPORT(X_) do {} while (0)

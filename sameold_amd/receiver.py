@@ -31,7 +31,7 @@ STREAM_OWN = (1 << 64) - 1          # SAME_STREAM_OWN: (void *)-1, the library's
 EVENT_MAX_BYTES = 288
 
 ERRORS = {-1: "EINVAL", -2: "EDCLEN", -3: "EAGCLIMITS", -4: "EEQORDER", -5: "ENODEVICE",
-          -6: "EHIP", -7: "EOVERFLOW", -8: "ENOMEM", -9: "ERATE"}
+          -6: "EHIP", -7: "EOVERFLOW", -8: "ENOMEM", -9: "ERATE", -10: "EKERNEL"}
 
 KIND_NAMES = {0: "no_carrier", 1: "searching", 2: "reading", 3: "burst", 16: "idle",
               17: "assembling", 18: "message_start", 19: "message_end", 20: "message_err"}

@@ -923,6 +923,40 @@ def test_polling_less_than_is_pending_still_delivers_everything_in_order(sa, ob)
     assert by_channel(got) == by_channel(want)
 
 
+def test_instant_behind_an_agc_lock_in_the_locks_own_block(sa, ob):
+    """Round 5's find (one trial in 65 536 of configs[4], seed 2026, trial 15 354; tools/strict_bytes_repro.py): the symbol
+    that acquires sync -- and locks the AGC at its sample (receiver.rs:431) -- is the FIRST of two TED instants in a 20-sample
+    block of the wavefront pipeline.  Stage 1 replays the AGC from the lock's sample on and stage 2 redoes its current block,
+    but the second instant shares the lock's block: its soft sample, filtered over the window as it stood before the replay,
+    becomes the next symbol's first sample, sits in the squelch's history for 24 symbols, reaches the equalizer -- and two
+    marginal bits of the burst's noise tail came out differently from the reference's.  Stage 2 now filters that instant
+    again over the corrected window.  Every soft sample of every symbol, bit for bit against the oracle's trace, and the
+    bursts byte for byte."""
+    from sameold_amd import montecarlo as mc
+    rate, seed, grid, T = 22050, 2026, 15, 44096
+    x = mc.synth_trials(16, 15344, T, rate, seed, 0.0, 1.0, grid)
+    xh = x.cpu().numpy()
+    cfg = ob.default_config(rate)
+    for kw, name in (({}, "demod_pipe_kernel"), ({"generic_kernel": True}, None)):
+        rx = sa.SameReceiverBuilder(rate).build_batch(16, link_only=True, trace_symbols=True, **kw)
+        rx.process_tensor(x)
+        rx.sync()
+        if name:
+            assert rx.kernel_name() == name
+        ev = rx.poll_events_np()
+        for c in range(16):
+            mine = ev[ev["channel"] == c]
+            got = [(int(r["kind"]), int(r["sample_counter"]), r["bytes"][: min(int(r["len"]), 288)].tobytes()) for r in mine]
+            assert got == oracle_events(ob, cfg, xh[:, c], link_only=True), f"trial {15344 + c}"
+            ref = ob.Receiver(cfg, link_only=True)
+            ref.enable_trace(4096)
+            ref.run(np.ascontiguousarray(xh[:, c]))
+            rt, tr = ref.trace(), rx.read_trace(c)
+            assert len(tr) == len(rt) and np.array_equal(tr["sample_counter"], rt["sample_counter"])
+            for f in ("zero", "sym"):
+                assert np.array_equal(tr[f].view(np.uint32), rt[f].view(np.uint32)), f"trial {15344 + c}: soft sample `{f}` differs from the oracle's"
+
+
 def test_awgn_batch_tally_equals_the_oracles(sa, ob):
     """configs[4]: the BER tally of a whole batch of AWGN trials equals the oracle's row for row, and every
     trial's events are equal (tests/helpers/ber_vs_oracle.py runs the same check on a 65 536-trial batch

@@ -195,7 +195,7 @@ def test_relaxed_awgn_tally_statistically_equal(sa):
     ref = strict_events(sa, x, rate, link_only=True)
     _, got = relaxed_events(sa, x, rate, link_only=True)
     payloads = [sa.synth_payload(seed, c) for c in range(n)]
-    assert_awgn_tallies_equal(sa, got, ref, payloads, n, grid, strict_arithmetic=False)
+    assert_awgn_tallies_equal(sa, got, ref, payloads, n, grid, strict_arithmetic=False, tight=True)
 
 
 def test_relaxed_batches_on_the_pipeline(sa, monkeypatch):
@@ -207,7 +207,7 @@ def test_relaxed_batches_on_the_pipeline(sa, monkeypatch):
         x = sa.synth_afsk(n_ch, n, rate, seed=seed, noise_sigma=noise)
         ref = strict_events(sa, x, rate)
         rx, got = relaxed_events(sa, x, rate, calls=[60000, 77, n - 60077])
-        assert rx.kernel_name() in ("demod_sym_kernel", "demod_pipe_kernel<fastmath>")
+        assert rx.kernel_name() == "demod_sym_kernel"             # (22.05 kHz; the other rates: test_relaxed_batches_on_the_pipeline_at_the_other_rates)
         assert_contract(sa, got, ref, rate, n_ch, lambda c: sa.synth_payload(seed, c), exact_bursts=(noise == 0.0), what="pipeline fastmath",
                         garbled_per_mille=(1 if noise > 0.0 else 0), t_end=n)
 

@@ -79,6 +79,116 @@ def test_contract_against_strict_mode(sa, n_ch, seconds, noise):
                     garbled_per_mille=(1 if noise > 0.0 else 0), what=f"{n_ch} channels", t_end=n)
 
 
+@pytest.mark.parametrize("amplitude,limits", [(0.5, "default"), (1.0, "default"), (300.0, "default"), (30000.0, "default"), (2.0e5, "default"), (1.0e6, "default"),
+                                              (3000.0, "samedec"), (30000.0, "samedec"), (2.0e5, "samedec"), (1.0e6, "samedec")])
+def test_any_input_scale(sa, amplitude, limits):
+    """The reference's AGC floor is 0 by default and its input "need not be scaled" (lib.rs:78-81, receiver/builder.rs:55): f32
+    samples of any magnitude are legal.  Round 4's kernel kept three blocks of DC-blocker outputs as packed f16 (clipping at
+    65 504) to recompute the gain an AGC lock freezes; this one recomputes it from the window ring's f32 AGC outputs
+    (SymAgc::gain_at), so nothing in it depends on the input's scale.  The synthetic carriers (2 000 .. 30 000) scaled to
+    `amplitude` at their loudest, with the default gain limits (0, 1e6) and with samedec's (1/32767, 1/200 -- a gain ceiling
+    under which a carrier of ~60-100 sits AT the squelch's power threshold, where either mode hears a burst or not by
+    rounding: samedec's runs start at 3 000, i.e. carriers of 200 and more): the contract against strict mode, which sees
+    the same samples.
+
+    Beyond |x| = 1 / agc_bw (5.2e4 at the default bandwidth and 22.05 kHz) the REFERENCE's own AGC is unstable: gain +=
+    bw (1 - |x gain|) overshoots zero, is clamped, and the gain flips between the floor and bw every other sample
+    (receiver/agc.rs:72-77).  What either mode decodes from that is a matter of rounding, so there the test only asks that
+    both run and that relaxed mode hears a comparable number of correct headers (include/same_rx.h states the precondition)."""
+    rate, n_ch, seed = 22050, 128, 4100
+    n = 22050 * 6
+    x = sa.synth_afsk(n_ch, n, rate, seed=seed) * (amplitude / 30000.0)
+    builder = lambda: (sa.SameReceiverBuilder(rate).samedec() if limits == "samedec" else sa.SameReceiverBuilder(rate))
+    ref = strict_events(sa, x, rate, builder=builder())
+    rx = builder().build_batch(n_ch, relaxed=True)
+    rx.process_tensor(x); rx.sync()
+    assert rx.kernel_name() == KERNEL
+    got = ordered(rx.poll_events_np())
+    n_bursts = int((ref["kind"] == sa.LINK_BURST).sum())
+    if amplitude * 1.9201e-5 < 1.0:
+        assert_contract(sa, got, ref, rate, n_ch, lambda c: sa.synth_payload(seed, c), exact_bursts=True, what=f"amplitude {amplitude} {limits}", t_end=n)
+        if amplitude >= 300.0:                           # (below: a gain that starts at the floor of 0 takes seconds to get there)
+            assert n_bursts >= n_ch, f"strict mode itself hears only {n_bursts} bursts at amplitude {amplitude}"
+    else:
+        def good(ev):
+            k = 0
+            for r in ev[ev["kind"] == sa.LINK_BURST]:
+                pay = sa.synth_payload(seed, int(r["channel"]))
+                k += bytes(r["bytes"][: len(pay)]) == pay or bytes(r["bytes"][:4]) == b"NNNN"
+            return k
+        g_ref, g_got = good(ref), good(got)
+        print(f"amplitude {amplitude} {limits}: correct headers strict {g_ref} of {n_bursts} bursts, relaxed {g_got}")
+        assert g_got >= 0.7 * g_ref - 8
+
+
+def test_relaxed_kernel_against_the_oracle_directly(sa):
+    """The contract once more with the ORACLE (the CPU restatement of the reference) as the yardstick instead of strict mode
+    -- the chain relaxed = strict = oracle closed in one step: every burst the oracle delivers, the symbol-paced kernel
+    delivers with the same transmitted bytes, link events within the stated two symbols."""
+    from oracle import binding as ob
+    rate, n_ch, seed = 22050, 64, 611
+    n = 22050 * 8
+    x = sa.synth_afsk(n_ch, n, rate, seed=seed)
+    xs = x.cpu().numpy()
+    rows = []
+    for c in range(n_ch):
+        for e in ob.Receiver(ob.default_config(rate)).run(np.ascontiguousarray(xs[:, c])):
+            t = e.as_tuple()
+            if t[0] <= sa.LINK_BURST:
+                rows.append((t[0], c, t[1], t[2]))
+    ref = np.zeros(len(rows), dtype=sa.receiver.EVENT_DTYPE)
+    for i, (kind, c, counter, data) in enumerate(rows):
+        ref[i]["kind"] = kind; ref[i]["channel"] = c; ref[i]["sample_counter"] = counter
+        ref[i]["len"] = len(data); ref[i]["bytes"][: len(data)] = np.frombuffer(data, dtype=np.uint8)[:288]
+    rx = sa.SameReceiverBuilder(rate).build_batch(n_ch, relaxed=True, link_only=True)
+    rx.process_tensor(x); rx.sync()
+    assert rx.kernel_name() == KERNEL
+    got = ordered(rx.poll_events_np())
+    assert_contract(sa, got, ordered(ref), rate, n_ch, lambda c: sa.synth_payload(seed, c), exact_bursts=True, what="against the oracle", t_end=n)
+
+
+@pytest.mark.parametrize("n_ch", [64, 192, 320])
+def test_odd_numbers_of_column_groups(sa, n_ch):
+    """A workgroup is two groups of 64 columns; with an odd number of groups the last workgroup's second half has nothing to
+    do and ends at once (s_barrier counts the surviving wavefronts only)."""
+    rate, seed = 22050, 7000 + n_ch
+    n = 22050 * 5
+    x = sa.synth_afsk(n_ch, n, rate, seed=seed)
+    ref = strict_events(sa, x, rate)
+    rx, got = run(sa, x)
+    assert_contract(sa, got, ref, rate, n_ch, lambda c: sa.synth_payload(seed, c), exact_bursts=True, what=f"{n_ch} channels", t_end=n)
+
+
+def test_awgn_on_the_shipped_kernel(sa):
+    """configs[4] through plain SAME_BATCH_RELAXED on the kernel that ships (tests/test_relaxed.py runs its AWGN test on the
+    one- / two-wavefront kernels it forces).  The symbol-paced kernel's departures under noise are algorithmic, not rounding --
+    AGC lock and loop bandwidth follow a sync by a block / two symbols, the framer's answers reach the squelch a symbol late
+    -- so it gets a bound of its own, from the measured curve (profiles/r05_ber_vs_oracle_1M.json: 1 048 576 trials, strict =
+    oracle row for row; relaxed within 0.02 dB of strict at 50 % detection, 50 % intact headers and BER 1e-3): detection and
+    intact headers per Eb/N0 point within 4 sigma of strict mode's, bit errors per point within 25 % + 100 (the one- / two-wavefront
+    kernels keep 15 % + 60 in tests/test_relaxed.py), and the whole sweep's BER within 5 % of strict mode's."""
+    from sameold_amd import montecarlo as mc
+    from test_time_parallel import assert_awgn_tallies_equal
+    n, grid, rate, seed = 8192, 15, 22050, 31
+    T = 2 * rate - (2 * rate) % 36
+    x = mc.synth_trials(n, 0, T, rate, seed, 0.0, 1.0, grid)
+    ref = strict_events(sa, x, rate, link_only=True)
+    rx = sa.SameReceiverBuilder(rate).build_batch(n, link_only=True, relaxed=True)
+    rx.process_tensor(x); rx.sync()
+    assert rx.kernel_name() == KERNEL
+    got = rx.poll_events_np()
+    payloads = [sa.synth_payload(seed, c) for c in range(n)]
+    assert_awgn_tallies_equal(sa, got, ref, payloads, n, grid, strict_arithmetic=False, tight="paced")
+    ta, tb = mc.new_tally(grid), mc.new_tally(grid)
+    mc.score_bursts(ref, payloads, 0, n, grid, ta)
+    mc.score_bursts(got, payloads, 0, n, grid, tb)
+    ber_strict = ta["bit_errors"].sum() / max(ta["bits"].sum(), 1)
+    ber_relaxed = tb["bit_errors"].sum() / max(tb["bits"].sum(), 1)
+    print(f"whole-sweep BER strict {ber_strict:.5f} relaxed {ber_relaxed:.5f}; detected {int(ta['detected'].sum())} / {int(tb['detected'].sum())}; "
+          f"intact {int(ta['intact'].sum())} / {int(tb['intact'].sum())}")
+    assert ber_relaxed <= 1.05 * ber_strict + 2e-4
+
+
 def test_other_input_forms_and_repeatability(sa):
     """The same call twice gives the same events (nothing in the kernel depends on how its wavefronts interleave); int16
     samples give what the f32 call gives, event for event -- the kernel sees the same numbers; a channel-major buffer

@@ -309,7 +309,7 @@ def test_soft_symbols_of_a_chunk_that_starts_fresh(sa, ob):
     assert err.max() <= SOFT_SYMBOL_TOLERANCE, stats
 
 
-def assert_awgn_tallies_equal(sa, got, ref, payloads, n, grid, strict_arithmetic):
+def assert_awgn_tallies_equal(sa, got, ref, payloads, n, grid, strict_arithmetic, tight=False):
     """AWGN Monte-Carlo trials (configs[4]) decoded two ways.  Strict arithmetic on both sides: all but a handful of
     marginal trials decode to the same bytes.  Relaxed arithmetic on one side: at the grid points where noise puts bit
     errors into a burst, WHICH marginal symbols flip is chaotic in the last bit of the matched-filter sums, so there the
@@ -336,7 +336,14 @@ def assert_awgn_tallies_equal(sa, got, ref, payloads, n, grid, strict_arithmetic
         be_a, be_b = ta["bit_errors"].astype(np.float64), tb["bit_errors"].astype(np.float64)
         # (bit errors come in lumps -- a trial that loses byte sync for a while contributes dozens -- so a grid point's count is
         # a sum over a handful of trials and moves by a lump when one marginal trial decodes the other way)
-        assert np.all(np.abs(be_a - be_b) <= 0.30 * np.maximum(be_a, be_b) + 150), (be_a, be_b)
+        # tight: an ordinary launch (one receiver per trial, as strict mode has it); otherwise a time-parallel launch, whose
+        # chunks also start from approximated state in the middle of the trial's burst
+        # "paced": an ordinary launch of the symbol-paced pipeline, whose feedback rules (lock a block late, framer's answers a
+        # symbol late) move marginal acquisitions at 3-6 dB: over 1 048 576 trials its bit errors per grid point are within 4 %
+        # of strict mode's and its curves within 0.02 dB (profiles/r05_ber_vs_oracle_1M.json); a grid point of this test is ~550
+        # trials, a handful of which decode, and one marginal trial going the other way moves it by a lump of dozens of bits
+        slack = (0.25, 100) if tight == "paced" else ((0.15, 60) if tight else (0.30, 150))
+        assert np.all(np.abs(be_a - be_b) <= slack[0] * np.maximum(be_a, be_b) + slack[1]), (be_a, be_b)
     for k in ("detected", "intact"):
         # binomial: |difference| within 4 sigma of the strict count per grid point
         sig = np.sqrt(np.maximum(ta[k] * (1 - ta[k] / np.maximum(ta["trials"], 1)), 1.0))

@@ -106,6 +106,23 @@ def prof(rx):
     print(f"  E passes {v[20]}; E's filter {v[22]/max(v[20],1):.0f} clk/pass, waiting for A's {v[24]/max(v[20],1):.0f}, timing+post {v[23]/max(v[20],1):.0f} clk/pass", flush=True)
 
 
+def timeline(rx):
+    """Profile builds: when each role of the reporting group began a step, got past its first wait and published, over 12 steps."""
+    import ctypes
+    L = rx._L
+    if not hasattr(L, "same_debug_profile_sym_trace"):
+        return
+    out = (ctypes.c_ulonglong * 288)()
+    if L.same_debug_profile_sym_trace(out) != 0:
+        return
+    v = np.array(list(out), dtype=np.int64).reshape(6, 12, 4)
+    t0 = v[:, :, 0][v[:, :, 0] > 0].min()
+    names = ["S", "T", "A", "E", "Y1", "Y2"]
+    print("  step: role begin / wait over (E: filters done) / (A: filter done, E: second wait over) / published, clk from the first mark")
+    for k in range(12):
+        print(f"  {600 + k:4d}: " + "  ".join(f"{names[r]} {v[r,k,0]-t0:6d}/{v[r,k,1]-t0:6d}" + (f"/{v[r,k,3]-t0:6d}" if r in (2, 3) else "") + f"/{v[r,k,2]-t0:6d}" for r in range(6)))
+
+
 def marks(rx):
     import ctypes
     L = rx._L
