@@ -500,7 +500,7 @@ def main():
     def pmc_traffic(kind):
         if args.traffic is not None:
             return args.traffic
-        for name in ("r04_traffic.json", "r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
+        for name in ("r05_traffic.json", "r04_traffic.json", "r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
             try:
                 with open(os.path.join(ROOT, "profiles", name)) as f:
                     tj = json.load(f)
@@ -509,6 +509,22 @@ def main():
                         return ent["hbm_bytes_per_launch"]
             except Exception:
                 pass
+        return None
+
+    def pmc_issue(kind, workload=None):
+        """What limits the kernel when it is not HBM (it is not): vector instructions per 64-column sample and the fraction of a
+        wavefront's cycles in which it issues one, from the round's SQ counter pass over this same command (tools/profile_round.sh,
+        profiles/r05_pmc_instruction_mix.txt); null when no pass has been filed."""
+        try:
+            with open(os.path.join(ROOT, "profiles", "r05_issue.json")) as f:
+                for ent in json.load(f):
+                    if ent.get("workload") == (workload or f"{C} ch x {T} samples") and ent.get("mode") == kind:
+                        return {"kind": "valu_issue", "valu_per_workgroup_sample": ent["valu_per_workgroup_sample"],
+                                "valu_issue_fraction_of_wave_cycles": ent["valu_issue_fraction_of_wave_cycles"],
+                                "budget_for_60pct_hbm": "<= 21-27 VALU per 64-column sample (1 024 SIMDs x f / 4 instructions/s over 1.875e10 column-group samples/s at f = 1.8-2.35 GHz, 85 % busy)",
+                                "source": ent["source"]}
+        except Exception:
+            pass
         return None
 
     notes = {
@@ -535,7 +551,10 @@ def main():
             "roofline": {"bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": pmc_traffic(name), "kernel_ms": round(kms, 4),
                          "demod_kernel_alone_ms": round(fc["demod_ms"], 4),
-                         "algorithmic_bytes_per_launch": 4 * C * T, "note": notes[name]},
+                         "algorithmic_bytes_per_launch": 4 * C * T,
+                         # `bound` names the roofline `frac` is priced against (the north star's: HBM); `limiter` is what the counters
+                         # say actually limits the kernel
+                         "limiter": pmc_issue(name), "note": notes[name]},
         }
         if name != "strict":
             modes[name].update(chunks=fc["chunks"], per_channel_boundaries=fc["per_channel"],
@@ -684,7 +703,8 @@ def main():
                 a2 = 4.0 * Cs * Ts / (k2 * 1e-3) / 1e9
                 blk = {"value": round(Cs * Ts * n2 / e2 / 1e6, 2), "unit": "Msamples/s", "kernel_ms": round(k2, 4), "steps": n2,
                        "ms_per_step": round(e2 / n2 * 1e3, 3), "kernel": rx2.kernel_name(),
-                       "roofline": {"bound": "hbm", "achieved": round(a2, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(a2 / HBM_PEAK_GBS, 5)}}
+                       "roofline": {"bound": "hbm", "achieved": round(a2, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(a2 / HBM_PEAK_GBS, 5),
+                                    "limiter": pmc_issue(label, f"{Cs} ch x {Ts} samples")}}
                 if label == "strict":
                     ev_strict = f2
                     out["scaled"].update(blk)                       # (the strict figures stay where round 1 and 2 put them)

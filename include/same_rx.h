@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define SAME_RX_ABI_VERSION 2   /* 2: hip_stream NULL is the legacy default stream (SAME_STREAM_OWN selects the library's); SAME_BATCH_RELAXED */
+#define SAME_RX_ABI_VERSION 2   /* 2: hip_stream NULL is the legacy default stream (SAME_STREAM_OWN selects the library's); SAME_BATCH_RELAXED; SAME_EKERNEL (an added error value) */
 
 /* ------------------------------------------------------------------ errors */
 enum {
@@ -172,10 +172,20 @@ enum {
      * expressions given up: matched filters as fused multiply-adds into four partial sums instead of one newest-first
      * chain (rx/filter.rs:363-377), |mark| and |space| as an f32 square root instead of hypot (rx/demod.rs:163), the AGC
      * update as gain * (1 - bw |x|) + bw (rx/agc.rs:72-77), reciprocals for the timing loop's and the equalizer's
-     * divisions.  In same_kernels_sym.hip, additionally, what the symbol path feeds back -- the lock at sync (AGC lock,
-     * locked loop bandwidth: receiver.rs:431-432) and what end() undoes (receiver.rs:479-490) -- takes effect from the
-     * next 36-sample block on (AGC; a lock freezes the gain the AGC had at the symbol's sample) and two symbols later
-     * (timing loop) instead of at the sample of the symbol that caused it.
+     * divisions (the DC blocker keeps the reference's bits: its divisions by 16 are exact).  In same_kernels_sym.hip,
+     * additionally, the stages of the receiver run as wavefronts one 36-sample step apart, and what one stage feeds back
+     * to an earlier one arrives LATE by a fixed number of steps instead of at the sample of the symbol that caused it:
+     *   - the lock at sync (AGC lock, locked loop bandwidth: receiver.rs:431-432) and what end() undoes (receiver.rs:479-490)
+     *     take effect from the AGC's next block on -- a lock freezes the gain the AGC HAD at the symbol's sample, recomputed
+     *     from the window's f32 samples, so the burst's soft symbols keep the reference's scale whatever the input's --
+     *     and behind the timing loop's next symbol but one;
+     *   - what the framer decides (squelch.lock(true) on Reading, end() on NoCarrier / Burst: receiver.rs:457-471) reaches
+     *     the squelch and the equalizer one symbol late; a decision that a newer symbol has overtaken (the squelch lost or
+     *     found sync in between) is dropped.
+     * Precondition on the input: |x| * agc_bandwidth * samples_per_symbol / rate < 1 (|x| < 5.2e4 with the defaults at
+     * 22.05 kHz).  Beyond it the REFERENCE's AGC overshoots zero and is clamped every other sample (rx/agc.rs:72-77); what
+     * any arithmetic decodes from that limit cycle is a matter of rounding, and the two modes differ
+     * (tests/test_sym_kernel.py::test_any_input_scale covers 0.5 .. 1e6).
      * The timing trajectory is chaotic in the last bit of those sums, so the contract is the
      * time-parallel mode's, whose chunks run this arithmetic as well (SAME_RELAXED=0 in the environment keeps them
      * strict): transmitted burst bytes and transport messages EQUAL, link events within
@@ -244,10 +254,13 @@ int same_batch_sync(same_batch *rx);
 int same_batch_poll_events(same_batch *rx, same_rx_event *out, size_t cap, size_t *n_out,
                            size_t *n_left);
 size_t same_batch_pending_events(same_batch *rx);
-/* The same queue without the copy: *events points at *n queued events inside the handle, valid
- * until the next call on this handle other than same_batch_pending_events; same_batch_drop_events
- * then removes the first n of them (n <= *n of the last peek).  For consumers that scan the queue
- * once and keep only the few events they care about (the bursts, say). */
+/* The same queue as an array inside the handle: *events points at *n queued events, valid until the
+ * next call on this handle other than same_batch_pending_events / same_batch_drop_events;
+ * same_batch_drop_events then removes the first n of them (n <= *n of the last peek).  For consumers that
+ * scan the queue once and keep only the few events they care about (the bursts, say).  The handle queues
+ * compact 48-byte records; the first peek after new events arrived builds the 328-byte same_rx_event array
+ * (O(queue), on up to 8 threads), later peeks re-use it as long as events were only dropped; the array is
+ * released when the queue runs empty. */
 int same_batch_peek_events(same_batch *rx, const same_rx_event **events, size_t *n);
 int same_batch_drop_events(same_batch *rx, size_t n);
 /* The queued SAME_LINK_BURST events as fixed 304-byte records, in queue order: u32 channel +

@@ -270,6 +270,7 @@ struct same_batch {
     hipStream_t plan_stream = nullptr;
     float last_ms = 0.0f;
     bool overflowed = false;
+    std::string record_path;         // SAME_RECORD_HARVEST (measurement aid of tools/host_step_probe.py: read once per batch, like every knob)
     bool kernel_fault = false;       // counters[2] bit 2: a wavefront pipeline's bounded hand-over wait ran out (same_kernels_sym.hip)
     bool use_fast = false;           // configuration has a latency-optimised kernel
     bool relaxed = false;            // relaxed arithmetic in time-parallel chunks (SAME_BATCH_TIME_PARALLEL or SAME_BATCH_RELAXED)
@@ -296,7 +297,9 @@ struct same_batch {
     EventQueue queue;                   // events not yet polled: [queue_head, size)
     size_t queue_head = 0;
     ByteArena arena;                    // their payload bytes
-    std::vector<same_rx_event> peeked;  // same_batch_peek_events: the queued events, materialised
+    std::vector<same_rx_event> peeked;  // same_batch_peek_events: the queued events, materialised (328 bytes each) ...
+    bool peeked_valid = false;          // ... and whether it still mirrors queue[peeked_head ..) (a harvest appends: invalid)
+    size_t peeked_head = 0;
     std::vector<size_t> burst_seq;      // event numbers (EventQueue::base + index) of the queued SAME_LINK_BURST events, ascending
     size_t burst_seq_head = 0;          // entries before this one have been polled or dropped
     std::vector<HarvestPart> parts;     // per host thread, kept between harvests for their capacity
@@ -394,6 +397,7 @@ void read_knobs(same_batch *rx)
     rx->P.knob_sym = tri("SAME_SYM");
     rx->sym_max_channels = (uint32_t)std::max(0, num("SAME_SYM_MAX", 1 << 30));     // (measurement knob: up to where an ordinary relaxed launch takes the symbol-paced pipeline; default: always)
     rx->debug = std::getenv("SAME_DEBUG") != nullptr;
+    { const char *e = std::getenv("SAME_RECORD_HARVEST"); rx->record_path = e ? e : ""; }
     rx->host_threads = std::max(0, num("SAME_HOST_THREADS", 0));
     rx->tp.sort_mode = num("SAME_TP_SORT", -1);
     rx->tp.knob_plan_stream = tri("SAME_TP_PLAN_STREAM");
@@ -734,6 +738,7 @@ int harvest_host(same_batch *rx, same_batch::Slot &sl, uint32_t n_events, uint32
     for (const Part &p : parts) { total += p.out.size(); total_bytes += p.bytes.size(); }
     // a consumer that always polls less than is pending never drains the queue: reclaim the polled
     // prefix once it is at least as large as what is still waiting (amortised O(1) per event)
+    rx->peeked_valid = false;                 // (the queue is about to move and grow: a materialised view of it is stale)
     if (rx->queue_head && rx->queue_head >= rx->queue.size() - rx->queue_head) {
         rx->queue_head = rx->queue.compact(rx->queue_head);
         // ... and the payload bytes in front of the first record that is still queued
@@ -830,7 +835,7 @@ int harvest_slot(same_batch *rx, same_batch::Slot &sl)
     }
     if (n_bursts || sl.chunked) HIP_TRY(hipStreamSynchronize(rx->copy_stream));      // bursts, hand-overs, geometry
     auto t_copied = std::chrono::steady_clock::now();
-    if (const char *path = std::getenv("SAME_RECORD_HARVEST")) record_harvest(rx, sl, n_events, n_bursts, path);
+    if (!rx->record_path.empty()) { const int rrc = record_harvest(rx, sl, n_events, n_bursts, rx->record_path.c_str()); if (rrc != SAME_OK) return rrc; }
     std::vector<uint32_t> rearm;     // channels whose forced-EOM instant changed
     HarvestTimes times;
     int rc = harvest_host(rx, sl, n_events, n_bursts, rearm, times);
@@ -1655,7 +1660,12 @@ size_t same_batch_pending_events(same_batch *rx)
 }
 
 // the queue is empty: nothing refers to the arena any more
-static void queue_emptied(same_batch *rx) { rx->queue.clear(); rx->queue_head = 0; rx->arena.clear(); }
+static void queue_emptied(same_batch *rx)
+{
+    rx->queue.clear(); rx->queue_head = 0; rx->arena.clear();
+    rx->peeked_valid = false; rx->peeked_head = 0;
+    std::vector<same_rx_event>().swap(rx->peeked);        // (the view of a large queue is tens of MB: not kept for the handle's life)
+}
 
 int same_batch_poll_events(same_batch *rx, same_rx_event *out, size_t cap, size_t *n_out, size_t *n_left)
 {
@@ -1687,7 +1697,20 @@ int same_batch_peek_events(same_batch *rx, const same_rx_event **events, size_t 
     // (the queue holds compact records: the view is made here, and stays valid as the header promises -- until the next
     // call on this handle other than same_batch_pending_events / same_batch_drop_events)
     const size_t avail = rx->queue.size() - rx->queue_head;
+    if (rx->peeked_valid && rx->peeked_head == rx->queue_head && rx->peeked.size() == avail) {     // (nothing was queued or dropped since)
+        *n = avail; *events = avail ? rx->peeked.data() : nullptr;
+        return SAME_OK;
+    }
+    if (rx->peeked_valid && rx->peeked_head <= rx->queue_head && rx->queue_head - rx->peeked_head <= rx->peeked.size() &&
+        rx->peeked.size() - (rx->queue_head - rx->peeked_head) == avail) {
+        // only drops since the last peek (the usual consumer: peek, keep a few, drop): the view moves up, nothing is rebuilt
+        rx->peeked.erase(rx->peeked.begin(), rx->peeked.begin() + (ptrdiff_t)(rx->queue_head - rx->peeked_head));
+        rx->peeked_head = rx->queue_head;
+        *n = avail; *events = avail ? rx->peeked.data() : nullptr;
+        return SAME_OK;
+    }
     try { rx->peeked.resize(avail); } catch (...) { return fail(SAME_ENOMEM, "event view"); }
+    rx->peeked_valid = true; rx->peeked_head = rx->queue_head;
     const QEvent *q = rx->queue.data() + rx->queue_head;
     const uint8_t *arena = rx->arena.data();
     const size_t abase = rx->arena.base;
@@ -1856,7 +1879,20 @@ long same_debug_harvest_replay(const char *path, int threads, int reps, double *
         }
     }
     std::fclose(f);
-    if (!ok) return -(long)fail(SAME_EINVAL, "%s is not a harvest record", path);
+    if (ok) {
+        // a record is data from a file: nothing in it is trusted before it has been checked against the sizes that were read
+        ok = first[h.n_bins] <= h.n_events && h.n_bins % h.n_channels == 0;
+        for (size_t i = 0; ok && i < (size_t)h.n_bins; ++i) ok = first[i] <= first[i + 1];
+        for (size_t i = 0; ok && i < ev0.size(); ++i)
+            ok = (ev0[i].burst_slot == 0xffffffffu || ev0[i].burst_slot < h.n_bursts) && (ev0[i].kind == same::kDevEventNone || ev0[i].kind <= 8u);
+        if (ok && h.chunked) {
+            ok = h.geom.n_chunks >= 1 && (uint64_t)h.geom.n_chunks * h.n_channels == h.n_bins && h.geom.block_len >= 1 && h.geom.stride_blocks >= 1;
+            for (size_t i = 0; ok && h.per_channel && i < geom.size(); ++i) ok = geom[i] <= 0x7fffffffu;
+        } else if (ok) {
+            ok = h.n_bins == h.n_channels;
+        }
+    }
+    if (!ok) return -(long)fail(SAME_EINVAL, "%s is not a (consistent) harvest record", path);
     same_batch *rx = new (std::nothrow) same_batch;
     if (!rx) return -(long)fail(SAME_ENOMEM, "out of memory");
     rx->P.n_channels = h.n_channels; rx->P.input_rate = h.input_rate; rx->flags = h.flags;

@@ -615,16 +615,13 @@ template <int PRIO> __device__ __forceinline__ void sym_setprio(const Params &P)
     __builtin_amdgcn_s_setprio(PRIO);
 }
 
-// next_fire_count (same_fast_common.h) for a clock at zero, in float and without the general case's loop: the first count c >= 1 with
-// fl(s - c) < 0.5, searched from floor(s) - 1, is reached within two increments (s - (floor(s) - 1) >= 1 fails, s - floor(s) is the
-// fraction, s - (floor(s) + 1) is negative); a third one for good measure.  Counts are far below 2^24, so the float is exact.
+// next_fire_count (same_fast_common.h) for a clock at zero, in closed form: the sample clock fires at the first count c >= 1 with
+// fl(s - c) < 0.5 (receiver.rs:352-353).  For counts next to s (s / 2 <= c <= 2 s) the difference is exact in f32, and so is
+// s - 0.5 (a multiple of s's ulp), so the condition is c > s - 0.5, i.e. c = floor(s - 0.5) + 1 -- three operations on the chain
+// timing update -> where the next instant falls -> next filter, where the search from floor(s) - 1 took a dozen.
 __device__ __forceinline__ float sym_next_fire(float s)
 {
-    float c = fmaxf(floorf(s) - 1.0f, 1.0f);
-    c += ((s - c) < 0.5f) ? 0.0f : 1.0f;
-    c += ((s - c) < 0.5f) ? 0.0f : 1.0f;
-    c += ((s - c) < 0.5f) ? 0.0f : 1.0f;
-    return c;
+    return fmaxf(floorf(s - 0.5f) + 1.0f, 1.0f);
 }
 
 // The kernel's argument list as a struct: the kernarg segment has this layout (natural alignment, in order).  The roles read
@@ -758,7 +755,7 @@ __global__ __launch_bounds__(kSymHalves * kSymRoles * kWave, 3) void demod_sym_k
         uint32_t v, spins = 0;
         for (;;) {
             v = prog[prog_idx];
-            const uint32_t ok = (uint32_t)__builtin_amdgcn_ballot_w64((v >> 16) >= s);
+            const uint32_t ok = (uint32_t)__builtin_amdgcn_ballot_w64(v >= (s << 16));     // (the flags below bit 16 cannot carry)
             if ((ok & deps) == deps) break;
             __builtin_amdgcn_s_sleep(NAP);
             // (bounded: a protocol error ends in an error code, not in a hung GPU)

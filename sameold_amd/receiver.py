@@ -475,9 +475,10 @@ class SameBatchReceiver:
         return int(self._L.same_batch_pending_events(self._h))
 
     def peek_events_np(self) -> np.ndarray:
-        """The queued events as a read-only numpy view INTO the handle (same_batch_peek_events):
-        no copy.  Valid until the next call on this receiver other than `drop_events`; copy what
-        you keep, then `drop_events(len(view))`."""
+        """The queued events as a read-only numpy view of the array the handle builds for them
+        (same_batch_peek_events: built once per batch of new events, re-used while events are only
+        dropped; no copy on the Python side).  Valid until the next call on this receiver other than
+        `drop_events`; copy what you keep, then `drop_events(len(view))`."""
         ptr, n = C.POINTER(Event)(), C.c_size_t()
         _check(self._L.same_batch_peek_events(self._h, C.byref(ptr), C.byref(n)))
         if not n.value:

@@ -12,7 +12,7 @@ import collections, csv, glob, json, os, re, shutil, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 P = os.path.join(ROOT, "gpurun_out", "prof")
 OUT = os.path.join(ROOT, "profiles")
-R = sys.argv[1] if len(sys.argv) > 1 else "r04"
+R = sys.argv[1] if len(sys.argv) > 1 else "r05"
 
 
 def one(pattern):
@@ -31,8 +31,9 @@ def classify(name, wgs, state, n1):
     if "demod_relaxed_kernel" in name or "demod_duo_kernel" in name:
         return "scaled_big_relaxed"
     if "demod_sym_kernel" in name:
-        # <NFF, NFB, SampleT, input form>: the symbol-paced pipeline takes every relaxed launch up to 65 536 columns
-        cols = wgs * 64
+        # <NFF, NFB, SampleT, input form>: the symbol-paced pipeline takes every relaxed launch; since round 5 a workgroup is
+        # twelve wavefronts = two groups of 64 state columns
+        cols = wgs * 128
         if re.search(r"demod_sym_kernel<\d+, \d+, \w+, 1>", name):
             return "time_parallel"                             # per-lane input streams: the channel-major time-parallel launch (8 pieces: 32 768 columns)
         if cols == C:
@@ -178,6 +179,24 @@ try:
                     f"  (= {c['SQ_INSTS_VALU'] / per / wg * 64 / 64:.2f} VALU per channel-sample x {wg})\n")
             wc = c["SQ_WAVE_CYCLES"]
             o.write(f"  wave cycles {wc / max(c['SQ_WAVES'], 1):.3e} per wavefront; VALU issuing {c['SQ_ACTIVE_INST_VALU'] / wc:.1%} of wave cycles, waiting (any) {c['SQ_WAIT_ANY'] / wc:.1%}\n\n")
+    # what bench.py quotes beside roofline.frac: vector instructions per 64-column sample and how busy a SIMD's vector unit is
+    # (instructions x 4 clk, over the launch's cycles on 1 024 SIMDs: SQ_WAVE_CYCLES counts per wavefront, a SIMD holds
+    # waves_per_simd of them)
+    issue = []
+    for v, c in mix.items():
+        if v not in sizes:
+            continue
+        cc, tt = sizes[v]
+        n = len(seen_disp[v])
+        wg = lanes.get(v, 64)
+        per = cc / wg * tt * n
+        wc, waves = c["SQ_WAVE_CYCLES"], max(c["SQ_WAVES"], 1)
+        issue.append({"mode": v if v in CONFIGS1 else ("relaxed" if v.endswith("_relaxed") else "strict"), "block": v, "workload": f"{cc} ch x {tt} samples",
+                      "valu_per_workgroup_sample": round(c["SQ_INSTS_VALU"] / per, 2), "salu_per_workgroup_sample": round(c["SQ_INSTS_SALU"] / per, 2),
+                      "lds_per_workgroup_sample": round(c["SQ_INSTS_LDS"] / per, 2),
+                      "valu_issue_fraction_of_wave_cycles": round(c["SQ_ACTIVE_INST_VALU"] / wc, 4),
+                      "source": f"profiles/{R}_pmc_instruction_mix.txt"})
+    json.dump(issue, open(os.path.join(OUT, f"{R}_issue.json"), "w"), indent=1)
     print(open(os.path.join(OUT, f"{R}_pmc_instruction_mix.txt")).read())
 except Exception as e:      # an old profile directory without the SQ pass
     print("no instruction mix:", e)
