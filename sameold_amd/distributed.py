@@ -94,20 +94,36 @@ def _pinned_bytes(tag: str, n_rows: int) -> torch.Tensor:
     return t
 
 
+_device_rows: dict = {}
+
+
+def _device_rows_buffer(tag, rows: int, device) -> torch.Tensor:
+    """A cached device tensor of at least [rows, RECORD_BYTES] uint8 (grown by half when it is too small): the gather's send
+    and receive buffers are not allocated and cleared again every step -- at configs[3]'s shape that was 8 x 7.5 MB of
+    torch.zeros per step on rank 0.  Rows beyond a rank's count are never read, so nothing needs clearing."""
+    key = (tag, str(device))
+    t = _device_rows.get(key)
+    if t is None or t.shape[0] < rows:
+        t = torch.empty((max(rows + rows // 2, 1024), RECORD_BYTES), dtype=torch.uint8, device=device)
+        _device_rows[key] = t
+    return t
+
+
 def gather_records(recs: np.ndarray, device: torch.device, dst: int = 0) -> Optional[np.ndarray]:
     """Gather packed records ([n, RECORD_BYTES] uint8 per rank) on rank `dst`: one all_gather of
-    the counts, one gather of the records padded to the largest count.  Returns the
-    concatenation on `dst` (rank order), None elsewhere; the identity without a process group."""
+    the counts (a single tensor, one host synchronisation), one gather of the records padded to the largest count, through
+    cached device and pinned host buffers.  Returns the concatenation on `dst` (rank order; on a GPU a view of the cached
+    landing buffer, valid until the next call), None elsewhere; the identity without a process group."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return recs
     world, rank = dist.get_world_size(), dist.get_rank()
     on_gpu = torch.device(device).type == "cuda"
     n = torch.tensor([len(recs)], dtype=torch.int64, device=device)
-    counts = [torch.zeros_like(n) for _ in range(world)]
-    dist.all_gather(counts, n)
-    counts = [int(c.item()) for c in counts]
+    all_n = torch.empty(world, dtype=torch.int64, device=device)
+    dist.all_gather_into_tensor(all_n, n)
+    counts = [int(v) for v in all_n.tolist()]                   # (the step's one device -> host synchronisation)
     m = max(max(counts), 1)
-    buf = torch.zeros((m, RECORD_BYTES), dtype=torch.uint8, device=device)
+    buf = _device_rows_buffer("send", m, device)[:m]
     if len(recs):
         src = torch.from_numpy(np.ascontiguousarray(recs))
         if on_gpu:
@@ -116,7 +132,10 @@ def gather_records(recs: np.ndarray, device: torch.device, dst: int = 0) -> Opti
             buf[: len(recs)].copy_(stage, non_blocking=True)
         else:
             buf[: len(recs)] = src
-    out = [torch.zeros_like(buf) for _ in range(world)] if rank == dst else None
+    out = None
+    if rank == dst:
+        big = _device_rows_buffer("recv", m * world, device)
+        out = [big[r * m:(r + 1) * m] for r in range(world)]
     dist.gather(buf, out, dst=dst)
     if rank != dst:
         return None

@@ -2,7 +2,7 @@
 """Shader clock and power while the demodulation kernel runs (back the "~1.5 GHz with every CU
 busy" figure, inferred from SQ_WAVE_CYCLES, with a reading taken during the launch).
 
-    python tools/clock_probe.py CHANNELS SECONDS [time_parallel]
+    python tools/clock_probe.py CHANNELS SECONDS [time_parallel | relaxed]
 
 A thread keeps launching the kernel back to back for ~4 s; the main thread samples the SMU's own figures
 every 20 ms from sysfs (hwmon freq1_input = sclk in Hz, power1_average / power1_input in microwatts,
@@ -46,9 +46,10 @@ def sensors():
 
 def main():
     C = int(sys.argv[1]); secs = float(sys.argv[2]); tp = len(sys.argv) > 3 and sys.argv[3] == "time_parallel"
+    relaxed = len(sys.argv) > 3 and sys.argv[3] == "relaxed"
     T = int(22050 * secs)
     x = sa.synth_afsk(C, T, 22050, seed=1)
-    rx = sa.SameReceiverBuilder(22050).build_batch(C, link_only=True, time_parallel=tp)
+    rx = sa.SameReceiverBuilder(22050).build_batch(C, link_only=True, time_parallel=tp, relaxed=relaxed)
     rx.set_kernel_timing(True)
     rx.process_tensor(x); rx.sync(); rx.poll_events_np()
     print("idle:", sensors())
@@ -75,7 +76,7 @@ def main():
         smi = f"rocm-smi unavailable: {e}"
     stop.set(); th.join()
     keys = sorted({k for s in samples for k in s})
-    print(f"{C} channels x {T} samples, {'time-parallel' if tp else 'strict'} [{rx.kernel_name()}]: {len(ms)} launches, "
+    print(f"{C} channels x {T} samples, {'time-parallel' if tp else ('relaxed' if relaxed else 'strict')} [{rx.kernel_name()}]: {len(ms)} launches, "
           f"kernel ms mean {sum(ms) / max(len(ms), 1):.3f}; {len(samples)} sensor samples while launches ran back to back")
     for k in keys:
         vals = [s[k] for s in samples if k in s]
