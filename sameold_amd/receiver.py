@@ -488,12 +488,22 @@ class SameBatchReceiver:
         out.flags.writeable = False
         return out
 
-    def pack_bursts_np(self, first_channel: int = 0) -> np.ndarray:
+    def pack_bursts_np(self, first_channel: int = 0, out: np.ndarray | None = None) -> np.ndarray:
         """The queued bursts as uint8 [n, 304] records with global channel numbers (same_batch_pack_bursts;
-        the layout of sameold_amd.distributed).  The queue is left as it is."""
+        the layout of sameold_amd.distributed).  The queue is left as it is.  `out`: a C-contiguous uint8 [cap, 304] array
+        to fill instead of a fresh one (a consumer that packs every step keeps its pages: at 131 072 channels the fresh
+        40 MB array costs more in page faults than the copy, tools/big_host_split.py); the result is then the view
+        out[:n], and a ValueError if the bursts do not fit."""
         n = C.c_size_t()
         _check(self._L.same_batch_pack_bursts(self._h, first_channel, None, 0, C.byref(n)))
-        out = np.empty((n.value, 304), dtype=np.uint8)
+        if out is None:
+            out = np.empty((n.value, 304), dtype=np.uint8)
+        else:
+            if out.dtype != np.uint8 or out.ndim != 2 or out.shape[1] != 304 or not out.flags.c_contiguous:
+                raise ValueError("out must be a C-contiguous uint8 [cap, 304] array")
+            if out.shape[0] < n.value:
+                raise ValueError(f"out holds {out.shape[0]} records, {n.value} bursts are queued")
+            out = out[:n.value]
         if n.value:
             _check(self._L.same_batch_pack_bursts(self._h, first_channel, C.c_void_p(out.ctypes.data), n.value, C.byref(n)))
         return out

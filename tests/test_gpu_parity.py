@@ -576,6 +576,14 @@ def test_pack_bursts_matches_the_python_packer(sa):
         assert len(ev) > (32768 if n_ch > 64 else 0) and got.shape == want.shape and len(got) > n_ch
         assert np.array_equal(got, want)
         assert len(rx.peek_events_np()) == len(ev)          # the queue is untouched
+        # ... and into a buffer the caller keeps: a view of it, the same records; too small a buffer is refused
+        buf = np.full((len(want) + 7, 304), 0xAA, dtype=np.uint8)
+        view = rx.pack_bursts_np(first_channel=1000, out=buf)
+        assert view.base is buf and np.array_equal(view, want) and (buf[len(want):] == 0xAA).all()
+        with pytest.raises(ValueError):
+            rx.pack_bursts_np(out=buf[:len(want) - 1])
+        with pytest.raises(ValueError):
+            rx.pack_bursts_np(out=np.empty((len(want), 300), dtype=np.uint8))
 
 
 def test_peek_and_drop_events_equal_poll(sa):
