@@ -83,7 +83,8 @@ template <int NT> struct SymLayout {
                                            2u * kWave + kWave +                     // ring slot of the symbol's first instant (per parity), its soft sample
                                            kIoRingWords +                           // A's deadline ring and its count
                                            kWave +                                  // Y2 -> T: this lane has handed over
-                                           kWave;                                   // the roles' progress words (six of them)
+                                           kWave +                                  // the roles' progress words (six of them)
+                                           (SYM_TL_WORDS + 63u) / 64u * 64u;        // (timeline builds: their marks)
     static constexpr size_t lds_bytes = ((size_t)tap_floats + mail_words + (size_t)(RING + MIR) * kWave) * sizeof(float);
     static_assert(NT == 42, "the filter's load sequence is written out for 42 taps");
     static_assert(B % 4 == 0 && B >= DCL && B % 2 == 0, "16-byte loads per lane; the DC windows are the tail of a block");
@@ -166,11 +167,14 @@ struct SymTaps {
         SYM_WLOAD0(X, wa);
         SYM_WLOAD1(Y, wa);
         SYM_WLOAD2(Z, wa);
-        auto group = [&](auto g_, const SymWin &W) __attribute__((always_inline)) {
+        // (all seven sums / differences of a group first, then the products: a packed operation that reads the result of the
+        // instruction before it costs a wait state -- an s_nop and an issue slot each, 21 per filter)
+        auto group = [&](auto g_, SymWin &W) __attribute__((always_inline)) {
             constexpr int g = decltype(g_)::value;
-            auto pair = [&](auto K_, float2v w) __attribute__((always_inline)) {
+            W.w0 = sym_sum_diff(W.w0); W.w1 = sym_sum_diff(W.w1); W.w2 = sym_sum_diff(W.w2); W.w3 = sym_sum_diff(W.w3);
+            W.w4 = sym_sum_diff(W.w4); W.w5 = sym_sum_diff(W.w5); W.w6 = sym_sum_diff(W.w6);
+            auto pair = [&](auto K_, float2v sd) __attribute__((always_inline)) {
                 constexpr int k = 7 * g + decltype(K_)::value;
-                const float2v sd = sym_sum_diff(w);
                 pk_fma_lo(re[k & 1], sd, tc[k]);
                 pk_fma_hi(im[k & 1], sd, ts[k]);
             };
@@ -567,37 +571,56 @@ struct SymSquelch {
 };
 
 // ---------------------------------------------------------------------------------------------------------------------
-// Y2: framer and link state of the symbol Y1 handed over (receiver.rs:410-471, rx/framing.rs:109-164).  Returns the LinkState
-// kind; *fb2 = what goes back to Y1 (squelch.lock(true)) and, for an end(), to S and E as well.
+// Y2: framer and link state of the symbol Y1 handed over (receiver.rs:410-471, rx/framing.rs:109-186), the relaxed-only cut of
+// same_dev_common.h's framer_end / framer_feed / rx_symbol tail: the same decisions as ONE straight line committed by selects
+// (the strict kernels' form -- restart arm, ordinary arm and "no byte" arm as three regions, the feed expanded twice -- cost
+// this wavefront ~35 branches and their register shuffling a step; it is the role with the longest step).  Returns the LinkState
+// kind; *burst_len = the length of a burst that has just ended (its bytes are still in `row`), *fb2 = what goes back to Y1
+// (squelch.lock(true)) and, for an end(), to S and E as well; *emit = report the link state (receiver.rs:246-253).
 // ---------------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t sym_framer_step(const Params &P, Lane &L, const State &S, uint32_t c, uint32_t m, uint32_t *burst_len, uint32_t *fb2)
+struct SymFramer { uint32_t st, last, word, count, invalid, len; };      // Framer's state (0 idle, 1 prefix search, 2 data read), the last reported link kind
+__device__ __forceinline__ uint32_t sym_framer_step(const Params &P, SymFramer &F, uint8_t *row, uint32_t m, uint32_t *burst_len, uint32_t *fb2, bool *emit)
 {
-    const bool ready = (m & YM_READY) != 0u, reading = (m & YM_READING) != 0u;
-    uint32_t link;
-    if (ready) {
-        const uint32_t byte = (m >> YM_BYTE_SHIFT) & 0xffu;
-        if (m & YM_ADJUSTED) {
-            uint32_t blen = 0;
-            const uint32_t out = framer_end(L, &blen);      // Framer::input restart arm rx/framing.rs:109-123
-            if (out == 3u) *burst_len = blen;
-            fr_set_state(L, 1); L.fr_word = 0; L.fr_count = 0;
-            uint32_t dummy = 0;
-            (void)framer_feed(P, L, S, c, byte, &dummy);
-            link = (out == 3u) ? 3u : 1u;
-        } else {
-            link = framer_feed(P, L, S, c, byte, burst_len);
-        }
-        if (link == 2u) *fb2 = FB_SQLOCK;                   // squelch.lock(true) receiver.rs:462
-        else if (link == 0u || link == 3u) *fb2 = FB_VALID | FB_END | (((m >> YM_OFF_SHIFT) & 127u) << 8);   // end() receiver.rs:466-470
-    } else {
-        // Reading: framer.state(); NoCarrier / DroppedCarrier: framer.end()  receiver.rs:410-422.  (The symbol after an
-        // end() arrives as "reading" -- Y1 had not heard of it -- and finds the framer idle: NoCarrier, as in the reference.)
-        const uint32_t fst = fr_state(L);
-        const bool was_reading_burst = !reading & (fst == 2u);
-        link = reading ? fst : (was_reading_burst ? 3u : 0u);
-        if (was_reading_burst) *burst_len = L.fr_len;
-        if (!reading) fr_set_state(L, 0);
-    }
+    const bool valid = (m & YM_VALID) != 0u, ready = (m & YM_READY) != 0u, reading = (m & YM_READING) != 0u;
+    const uint32_t byte = (m >> YM_BYTE_SHIFT) & 0xffu;
+    // Framer::input's restart arm rx/framing.rs:109-123: end() -- a burst being read ends here -- then a prefix search from scratch
+    const bool restart = (m & (YM_READY | YM_ADJUSTED)) == (YM_READY | YM_ADJUSTED);
+    const uint32_t st = F.st;
+    const bool burst_at_restart = restart & (st == 2u);
+    const uint32_t st1 = restart ? 1u : st;
+    const uint32_t word0 = restart ? 0u : F.word, count0 = restart ? 0u : F.count;
+    // PrefixSearch rx/framing.rs:128-150
+    const bool searching = ready & (st1 == 1u), rd = ready & (st1 == 2u);
+    const uint32_t word = (word0 << 8) | byte, count = count0 + 1u;
+    const uint32_t e0 = __popc(word ^ 0x5a435a43u);          // "ZCZC" rx/framing.rs:235-243
+    const uint32_t e1 = __popc(word ^ 0x4e4e4e4eu);          // "NNNN"
+    const bool found = searching & (min(e0, e1) <= P.fr_max_prefix_errors);
+    const bool give_up = searching & !found & (count > 21u); // PREFIX_SEARCH_LEN :201
+    // DataRead :153-163
+    const uint32_t invalid = F.invalid + (is_allowed_byte(byte) ? 0u : 1u);
+    const bool over = rd & (invalid > P.fr_max_invalid);
+    const bool keep = rd & !over;
+    F.word = searching ? word : word0;
+    F.count = searching ? count : count0;
+    F.invalid = found ? 0u : (rd ? invalid : F.invalid);
+    if (found) *reinterpret_cast<uint32_t *>(row) = __builtin_bswap32(word);      // the prefix as received seeds the burst :136-138 (rows are 288 bytes apart)
+    if (keep && F.len < (uint32_t)kBurstCap) row[F.len] = (uint8_t)byte;
+    // Reading without a byte: framer.state(); NoCarrier / DroppedCarrier: framer.end()  receiver.rs:410-422.  (The symbol after
+    // an end() arrives as "reading" -- Y1 had not heard of it -- and finds the framer idle: NoCarrier, as in the reference.)
+    const bool was_reading_burst = valid & !ready & !reading & (st == 2u);
+    *burst_len = (over | burst_at_restart | was_reading_burst) ? F.len : 0u;       // Framer::end() rx/framing.rs:174-186: the burst without this byte
+    F.len = found ? 4u : (keep ? F.len + 1u : F.len);
+    const uint32_t nst = found ? 2u : ((give_up | over) ? 0u : st1);
+    const uint32_t link_ready = restart ? (burst_at_restart ? 3u : 1u) : (over ? 3u : nst);
+    const uint32_t link_quiet = reading ? st : (st == 2u ? 3u : 0u);
+    const uint32_t link = ready ? link_ready : link_quiet;
+    F.st = ready ? nst : ((valid & !reading) ? 0u : st);
+    // squelch.lock(true) receiver.rs:462; end() receiver.rs:466-470
+    const uint32_t fb_end = FB_VALID | FB_END | (((m >> YM_OFF_SHIFT) & 127u) << 8);
+    *fb2 = ready ? (link == 2u ? (uint32_t)FB_SQLOCK : ((link == 0u || link == 3u) ? fb_end : 0u)) : 0u;
+    // receiver.rs:246-253: report on change; a Burst always differs from its predecessor
+    *emit = valid & ((link != F.last) | (link == 3u));
+    F.last = *emit ? link : F.last;
     return link;
 }
 
@@ -609,9 +632,13 @@ __device__ __forceinline__ uint32_t sym_framer_step(const Params &P, Lane &L, co
 // SAME_PIPE_PRIO bits 12-13 (1: no priorities).
 template <int PRIO> __device__ __forceinline__ void sym_setprio(const Params &P)
 {
+#ifdef SAME_PROFILE
     const uint32_t variant = ((uint32_t)P.knob_prio >> 12) & 3u;
     if (variant == 1u) return;
     if (variant == 2u) { __builtin_amdgcn_s_setprio(PRIO >= 2 ? 3 : 0); return; }
+#else
+    (void)P;
+#endif
     __builtin_amdgcn_s_setprio(PRIO);
 }
 
@@ -665,8 +692,21 @@ __global__ __launch_bounds__(kSymHalves * kSymRoles * kWave, 3) void demod_sym_k
     extern __shared__ float lds_all[];
     const uint32_t lane = threadIdx.x & (kWave - 1u);
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const uint32_t half = wave >= (uint32_t)kSymRoles ? 1u : 0u;
-    const uint32_t role = wave - half * (uint32_t)kSymRoles;                                   // 0 S, 1 T, 2 A, 3 E, 4 Y1, 5 Y2
+    // wavefront -> (half, role), 4 bits each.  Wavefronts w, w + 4, w + 8 share a SIMD; which roles do is worth +-2-5 % (profile
+    // builds pick a table with SAME_PIPE_PRIO bits 14-15): the order of the launch by role is within 1 % of the best found.
+    constexpr uint64_t kDeal0 = 0xdcba98543210ull;     // S0 T0 A0 E0 | Y1_0 Y2_0 S1 T1 | A1 E1 Y1_1 Y2_1
+#ifdef SAME_PROFILE
+    const uint32_t deal = ((uint32_t)P.knob_prio >> 14) & 3u;
+    constexpr uint64_t kDeal1 = 0x805d192ab3c4ull;     // Y1_0 Y1_1 E0 E1 | A1 A0 T1 T0 | Y2_1 Y2_0 S0 S1
+    constexpr uint64_t kDeal2 = 0x08d591a2b3c4ull;     // Y1_0 Y1_1 E0 E1 | A0 A1 T0 T1 | Y2_0 Y2_1 S1 S0
+    constexpr uint64_t kDeal3 = 0x2ad51908b3c4ull;     // Y1_0 Y1_1 E0 E1 | S1 S0 T1 T0 | Y2_0 Y2_1 A1 A0
+    const uint64_t tbl = deal == 0u ? kDeal0 : (deal == 1u ? kDeal1 : (deal == 2u ? kDeal2 : kDeal3));
+#else
+    constexpr uint64_t tbl = kDeal0;
+#endif
+    const uint32_t hr = (uint32_t)(tbl >> (4u * wave)) & 15u;
+    const uint32_t half = hr >> 3;
+    const uint32_t role = hr & 7u;                                                             // 0 S, 1 T, 2 A, 3 E, 4 Y1, 5 Y2
     const uint32_t C = P.n_channels;
     const uint32_t vwg = blockIdx.x * (uint32_t)kSymHalves + half;                              // this half's group of 64 state columns
     if (vwg * kWave >= C) return;                                                              // (an odd number of groups: the last workgroup's second half)
@@ -746,6 +786,9 @@ __global__ __launch_bounds__(kSymHalves * kSymRoles * kWave, 3) void demod_sym_k
     // role is absorbed by the slack of the others instead of stalling the workgroup (measured with the barrier: every role
     // waited >= 730 clk of a 3 780-clk step although the longest worked 2 900), and the two halves never meet.
     lds_u32 *prog = donebox + kWave;                               // [6]
+#ifdef SAME_SYM_TL
+    lds_u32 *tlbox = prog + kWave;
+#endif
     // (A waiting wavefront costs vector issue slots -- the resource this kernel is short of -- with every poll: roles with slack
     // sleep longer between polls than the ones on the step's critical chain.)
     const uint32_t prog_idx = lane < (uint32_t)kSymRoles ? lane : 0u;
@@ -1001,46 +1044,43 @@ __global__ __launch_bounds__(kSymHalves * kSymRoles * kWave, 3) void demod_sym_k
         // lanes with both instants in this step, lanes with one, lanes with none: as branches the update existed twice, with
         // the register shuffling of two exec-mask regions around it -- ~210 vector instructions a step).
         auto work = [&](uint32_t s) __attribute__((always_inline)) {
-            uint32_t hdr = 0;
-            float zero = 0.0f, sym = 0.0f, terr = 0.0f, next = 0.0f;
-            if (__builtin_amdgcn_ballot_w64(pl_ready) != 0ull) {
-                SYM_T_BEGIN();
-                const bool tA = pl_typeA;
-                // the TED as the second instant finds it: behind the first one (ZeroCrossingTed::input + TimingLoop::input without
-                // a symbol, rx/symsync.rs:236-241, 278-287) where the step has one
-                const float p1 = tA ? L.h2 : L.h1, p2 = tA ? sa1 : L.h2;
-                const float inst_pre = tA ? pl_instA : L.period_inst;
-                const float rem = tA ? pl_instA - pl_c2 : pl_rem1;
-                const uint32_t flags_new = tA ? L.flags : (L.flags ^ F_TED_PHASE);       // (two toggles, or one)
-                const bool have = (flags_new & F_TED_PHASE) != 0u;
-                // ZeroCrossingTed::input + TimingLoop::advance_loop (rx/symsync.rs:198-287), relaxed: same_relaxed_common.h ted_timing_relaxed
-                const float dsg = rs_signum(p1) - rs_signum(sa2);
-                const float te = p2 * dsg;
-                const float offset = __builtin_amdgcn_fmed3f(rem, -0.5f, 0.5f);
-                const float e = __builtin_amdgcn_fmed3f(__builtin_fmaf(-offset, inv_spt, te), -1.0f, 1.0f);
-                const bool bw_locked = (L.flags & F_BW_LOCKED) != 0u;
-                const float alpha = bw_locked ? P.alpha_locked : P.alpha_unlocked;
-                const float beta = bw_locked ? P.beta_locked : P.beta_unlocked;
-                const float avg1 = __builtin_amdgcn_fmed3f(__builtin_fmaf(beta, e, L.period_avg), P.period_min, P.period_max);
-                float inst1 = __builtin_fmaf(alpha, e, avg1) + offset;
-                inst1 = (inst1 < 0.0f) ? avg1 : inst1;
-                const float inst_new = have ? inst1 : inst_pre + offset;
-                const float cs = sym_next_fire(inst_new);
-                if (pl_ready) {
-                    L.h0 = p1; L.h1 = p2; L.h2 = sa2;
-                    L.flags = flags_new;
-                    L.period_avg = have ? avg1 : L.period_avg;
-                    L.period_inst = inst_new; L.until_next_ted = inst_new;
-                    cstar_f = cs; cstar = (int)cs;
-                    rel = pl_p2 + cstar;
-                    if (have) { hdr = 1u | ((uint32_t)(pl_p2 + (pl_single ? 3 * kB : 2 * kB)) << 8); zero = p2; sym = sa2; terr = te; next = inst_new; }
-                }
-                SYM_T_LAP(23);
-            }
+            SYM_T_BEGIN();
+            const bool rdy = pl_ready, tA = pl_typeA;
+            // the TED as the second instant finds it: behind the first one (ZeroCrossingTed::input + TimingLoop::input without
+            // a symbol, rx/symsync.rs:236-241, 278-287) where the step has one
+            const float p1 = tA ? L.h2 : L.h1, p2 = tA ? sa1 : L.h2;
+            const float inst_pre = tA ? pl_instA : L.period_inst;
+            const float rem = tA ? pl_instA - pl_c2 : pl_rem1;
+            const uint32_t flags_new = tA ? L.flags : (L.flags ^ F_TED_PHASE);       // (two toggles, or one)
+            const bool have = (flags_new & F_TED_PHASE) != 0u;
+            // ZeroCrossingTed::input + TimingLoop::advance_loop (rx/symsync.rs:198-287), relaxed: same_relaxed_common.h ted_timing_relaxed
+            const float dsg = rs_signum(p1) - rs_signum(sa2);
+            const float te = p2 * dsg;
+            const float offset = __builtin_amdgcn_fmed3f(rem, -0.5f, 0.5f);
+            const float e = __builtin_amdgcn_fmed3f(__builtin_fmaf(-offset, inv_spt, te), -1.0f, 1.0f);
+            const bool bw_locked = (L.flags & F_BW_LOCKED) != 0u;
+            const float alpha = bw_locked ? P.alpha_locked : P.alpha_unlocked;
+            const float beta = bw_locked ? P.beta_locked : P.beta_unlocked;
+            const float avg1 = __builtin_amdgcn_fmed3f(__builtin_fmaf(beta, e, L.period_avg), P.period_min, P.period_max);
+            float inst1 = __builtin_fmaf(alpha, e, avg1) + offset;
+            inst1 = (inst1 < 0.0f) ? avg1 : inst1;
+            const float inst_new = have ? inst1 : inst_pre + offset;
+            const float cs = sym_next_fire(inst_new);
+            // committed lane by lane with selects: as one region under `if (ready)` every value that leaves it is copied twice
+            // (~60 register moves a step around ~45 instructions of arithmetic)
+            const bool take = rdy & have;
+            L.h0 = rdy ? p1 : L.h0; L.h1 = rdy ? p2 : L.h1; L.h2 = rdy ? sa2 : L.h2;
+            L.flags = rdy ? flags_new : L.flags;
+            L.period_avg = take ? avg1 : L.period_avg;
+            L.period_inst = rdy ? inst_new : L.period_inst; L.until_next_ted = rdy ? inst_new : L.until_next_ted;
+            cstar_f = rdy ? cs : cstar_f;
+            rel = rdy ? pl_p2 + (int)cs : rel;
+            const uint32_t hdr = take ? (1u | ((uint32_t)(pl_p2 + (pl_single ? 3 * kB : 2 * kB)) << 8)) : 0u;
+            SYM_T_LAP(23);
             lds_u32 *sb = symbox + (s & 1u) * LY::sym_words + lane;
             sb[0] = hdr;
-            sb[kWave] = __float_as_uint(zero); sb[2 * kWave] = __float_as_uint(sym);
-            if (P.trace_cap) { sb[3 * kWave] = __float_as_uint(terr); sb[4 * kWave] = __float_as_uint(next); }
+            sb[kWave] = __float_as_uint(p2); sb[2 * kWave] = __float_as_uint(sa2);             // (read where the header says so)
+            if (P.trace_cap) { sb[3 * kWave] = __float_as_uint(te); sb[4 * kWave] = __float_as_uint(inst_new); }
         };
         // the loop bandwidth of a lock at sync (receiver.rs:431-432) and what end() undoes (receiver.rs:479-490: unlocked
         // loop bandwidth, symsync.reset()), late: see Y1 / Y2
@@ -1065,9 +1105,9 @@ __global__ __launch_bounds__(kSymHalves * kSymRoles * kWave, 3) void demod_sym_k
             uint32_t w1, w2;
             SYM_TRACE(3, s, 0);
             wait_for(s, R_S, &w1, &w2, kNapShort);
+            SYM_TRACE(3, s, 1);
             P3_LAP(p3_wait);
             if (!PROF_SKIP(P, 32)) filters(2u * s + 1u);
-            SYM_TRACE(3, s, 1);
             wait_for(s, R_A | R_Y1 | R_Y2, &w1, &w2, kNapShort);                  // A is done with the positions, Y1 with the symbol box; feedback of Y1 and Y2
             SYM_TRACE(3, s, 3);
             const uint32_t f1 = flags_of_last(w1, s), f2 = flags_of_last(w2, s);
@@ -1092,7 +1132,7 @@ __global__ __launch_bounds__(kSymHalves * kSymRoles * kWave, 3) void demod_sym_k
         SYM_REPORT(3);
         SYM_T_REPORT();
         if (left) return;
-        L.ted_clock = (uint32_t)(cstar - rel - 1);
+        L.ted_clock = (uint32_t)((int)cstar_f - rel - 1);
         {
             const State S = fresh_state();
             S.until_next_ted[c] = L.until_next_ted; S.ted_clock[c] = L.ted_clock;
@@ -1216,8 +1256,12 @@ __global__ __launch_bounds__(kSymHalves * kSymRoles * kWave, 3) void demod_sym_k
         // ------------------------------------------ Y2: framer, link state, bursts, hand-over ----------------------------
         sym_setprio<2>(P);
         Lane L;
-        State S{};                   // in the loop: the framer's rows only
-        { const State S0 = fresh_state(); lane_load(L, S0, c); S.fr_msg = S0.fr_msg; }
+        SymFramer F;
+        uint8_t *fr_rows;            // in the loop: the framer's rows only
+        { const State S0 = fresh_state(); lane_load(L, S0, c); fr_rows = S0.fr_msg; }
+        F.st = fr_state(L); F.last = (L.flags & F_LINK_MASK) >> F_LINK_SHIFT;
+        F.word = L.fr_word; F.count = L.fr_count; F.invalid = L.fr_invalid; F.len = L.fr_len;
+        uint8_t *const row = fr_rows + (size_t)c * kBurstCap;
         Output O{};
         { const Output Of = fresh_output(); O.n_events = Of.n_events; O.bursts = Of.bursts; O.burst_cap = Of.burst_cap; }
         lds_barrier();                                                 // prologue
@@ -1227,29 +1271,23 @@ __global__ __launch_bounds__(kSymHalves * kSymRoles * kWave, 3) void demod_sym_k
         for (uint32_t s = 0; s < n_steps; ++s) {
             uint32_t w1, w2;
             SYM_TRACE(5, s, 0);
-            wait_for(s, R_Y1, &w1, &w2, kNapShort);                               // Y1's words
+            // Y1's words; and everybody has read the flags and feedback of two steps ago, A is done with the link box (ONE wait: this
+            // role's step is the longest of the six, the others have long published when it begins)
+            wait_for(s, R_Y1 | R_S | R_T | R_A | R_E, &w1, &w2, kNapShort);
             SYM_TRACE(5, s, 1);
             P3_LAP(p3_wait);
             uint32_t flags = 0u;
             if (s >= 3u && s <= last_y2_step) {
-                const uint32_t blk = min(s - 3u, n_blocks - 1u);       // every symbol up to the end of this block has been seen after this step
-                const uint32_t m = ybox[((s - 1u) & 1u) * kWave + lane];
-                uint32_t fbv = 0, io0 = 0, io1 = 0xffffffffu, io2 = 0;
-                bool want_slot = false;                                // this lane has just finished a burst
-                if ((m & YM_VALID) && !PROF_SKIP(P, 1024)) {
-                    uint32_t burst_len = 0;
-                    const uint32_t link = sym_framer_step(P, L, S, c, m, &burst_len, &fbv);
-                    // receiver.rs:246-253: report on change; a Burst always differs from its predecessor
-                    const uint32_t last = (L.flags & F_LINK_MASK) >> F_LINK_SHIFT;
-                    const bool emit = link != last || link == 3u;
-                    if (emit) L.flags = (L.flags & ~F_LINK_MASK) | (link << F_LINK_SHIFT);
-                    want_slot = emit && link == 3u;
-                    io0 = 1u | (link << 1) | (emit ? 8u : 0u) | (((m >> YM_OFF_SHIFT) & 127u) << 4);
-                    io2 = burst_len;
-                }
+                const uint32_t m = PROF_SKIP(P, 1024) ? 0u : ybox[((s - 1u) & 1u) * kWave + lane];
+                uint32_t fbv = 0, burst_len = 0, io1 = 0xffffffffu;
+                bool emit = false;
+                const uint32_t link = sym_framer_step(P, F, row, m, &burst_len, &fbv, &emit);
+                const bool want_slot = emit & (link == 3u);            // this lane has just finished a burst
+                const uint32_t io0 = (m & YM_VALID) ? (1u | (link << 1) | (emit ? 8u : 0u) | (((m >> YM_OFF_SHIFT) & 127u) << 4)) : 0u;
                 // finished bursts go into the pool with the whole wavefront: one slot reservation for all of them and one
                 // coalesced round trip per burst (same_kernels_pipe.hip)
                 uint64_t pend = __builtin_amdgcn_ballot_w64(want_slot);
+                lds_u32 *io = iobox + (s & 1u) * LY::io_words + lane;
                 if (pend != 0ull) {
                     const uint32_t n_new = (uint32_t)__popcll(pend);
                     uint32_t base = 0;
@@ -1262,7 +1300,7 @@ __global__ __launch_bounds__(kSymHalves * kSymRoles * kWave, 3) void demod_sym_k
                         const uint32_t b = base + k++;
                         const uint32_t cj = (uint32_t)__builtin_amdgcn_readlane((int)c, j);
                         if (b < O.burst_cap) {
-                            const uint32_t *src = reinterpret_cast<const uint32_t *>(S.fr_msg + (size_t)cj * kBurstCap);
+                            const uint32_t *src = reinterpret_cast<const uint32_t *>(fr_rows + (size_t)cj * kBurstCap);
                             uint32_t *dst = reinterpret_cast<uint32_t *>(O.bursts + (size_t)b * kBurstCap);
                             constexpr uint32_t kWords = (uint32_t)kBurstCap / 4u, kPer = (kWords + kWave - 1u) / kWave;
                             uint32_t t[kPer];
@@ -1276,11 +1314,9 @@ __global__ __launch_bounds__(kSymHalves * kSymRoles * kWave, 3) void demod_sym_k
                             if ((int)lane == j) io1 = 0xffffffffu;
                         }
                     }
+                    io[kWave] = io1; io[2 * kWave] = burst_len;
                 }
-                wait_for(s, R_S | R_T | R_A | R_E, &w1, &w2, kNapLong);          // everybody has read the flags and feedback of two steps ago; A is done with the link box
-                lds_u32 *io = iobox + (s & 1u) * LY::io_words + lane;
                 io[0] = io0;
-                if (__builtin_amdgcn_ballot_w64((io0 & 8u) != 0u && ((io0 >> 1) & 3u) == 3u) != 0ull) { io[kWave] = io1; io[2 * kWave] = io2; }
                 const bool any_end = __builtin_amdgcn_ballot_w64((fbv & FB_VALID) != 0u) != 0ull;
                 const bool any_lock = __builtin_amdgcn_ballot_w64((fbv & FB_SQLOCK) != 0u) != 0ull;
                 if (any_end || any_lock) fb2box[(s & 1u) * LY::fb_words + lane] = fbv;
@@ -1289,7 +1325,8 @@ __global__ __launch_bounds__(kSymHalves * kSymRoles * kWave, 3) void demod_sym_k
                 // the end of the first block after which its link state is NoCarrier; once every lane has one the group
                 // leaves (one more step: A still has to log this step's events)
                 if (may_leave && !leave_posted) {
-                    if (!lane_done && blk + 1u >= n_nominal && (L.flags & F_LINK_MASK) == 0u && (xl == nullptr || blk < avail_l)) {
+                    const uint32_t blk = min(s - 3u, n_blocks - 1u);   // every symbol up to the end of this block has been seen after this step
+                    if (!lane_done && blk + 1u >= n_nominal && F.last == 0u && (xl == nullptr || blk < avail_l)) {
                         lane_done = true;
                         K.handover[c] = counter0 + (int64_t)row_l + (uint64_t)(blk + 1u) * kB;
                         donebox[lane] = 1u;
@@ -1297,7 +1334,6 @@ __global__ __launch_bounds__(kSymHalves * kSymRoles * kWave, 3) void demod_sym_k
                     if (__builtin_amdgcn_ballot_w64(!lane_done) == 0ull) { flags |= Y2F_LEAVE; leave_posted = true; stop_at = s + 1u; }
                 }
             }
-            if (!(s >= 3u && s <= last_y2_step)) wait_for(s, R_S | R_T | R_A | R_E, &w1, &w2, kNapLong);
             SYM_TRACE(5, s, 2);
             publish(s, flags, flags_before);
             flags_before = flags;
@@ -1311,11 +1347,10 @@ __global__ __launch_bounds__(kSymHalves * kSymRoles * kWave, 3) void demod_sym_k
         // E's TED phase, A's wake-up flag, Y1's locks and equalizer bits: written before their last step was published
         uint32_t w1, w2;
         wait_for(n_steps, R_A | R_E | R_Y1, &w1, &w2, kNapShort);
-        constexpr uint32_t kMine = F_FR_STATE_MASK | F_LINK_MASK;
-        L.flags = (L.flags & kMine) | (phasebox[lane] & F_TED_PHASE) | (againbox[lane] & F_TICK_AGAIN) | flagbox[lane];
+        const uint32_t flags_out = (F.st << F_FR_STATE_SHIFT) | (F.last << F_LINK_SHIFT) | (phasebox[lane] & F_TED_PHASE) | (againbox[lane] & F_TICK_AGAIN) | flagbox[lane];
         const State S1 = fresh_state();
-        S1.fr_word[c] = L.fr_word; S1.fr_count[c] = L.fr_count; S1.fr_invalid[c] = L.fr_invalid;
-        S1.fr_len[c] = L.fr_len; S1.flags[c] = L.flags;
+        S1.fr_word[c] = F.word; S1.fr_count[c] = F.count; S1.fr_invalid[c] = F.invalid;
+        S1.fr_len[c] = F.len; S1.flags[c] = flags_out;
     }
 }
 

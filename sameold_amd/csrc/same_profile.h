@@ -158,15 +158,39 @@ namespace same { struct ProfMarks { __device__ __forceinline__ void mark(int) {}
 #define RX_REPORT() do {} while (0)
 #define RELAXED_PROFILE_EXPORTS()
 #define PIPE_PROF_TAP_PAD 0
+#ifndef SAME_SYM_TL
 #define SYM_REPORT(role_) do {} while (0)
+#endif
 #define SYM_COUNT(i_, n_) do {} while (0)
 #define SYM_TCOUNT(i_, n_) do {} while (0)
 #define SYM_T_DECL() do {} while (0)
 #define SYM_T_BEGIN() do {} while (0)
 #define SYM_T_LAP(i_) do {} while (0)
 #define SYM_T_REPORT() do {} while (0)
+#ifdef SAME_SYM_TL
+// A timeline of the symbol-paced pipeline that barely disturbs it (release code otherwise; python -m sameold_amd.build with
+// SAME_SYM_TL set): lane 0 of every role of ONE group of 64 columns notes the shader clock's low word in LDS at mark k (0 step begins,
+// 1 first wait over, 2 about to publish, 3 role-specific) of steps SYM_TRACE_S0 .. + SYM_TRACE_N - 1; the rows go to a global array
+// when the role ends.  tools/sym_probe.py timeline.
+#ifndef SYM_TL_GROUP
+#define SYM_TL_GROUP 0u
+#endif
+#define SYM_TRACE_S0 600u
+#define SYM_TRACE_N 12u
+#define SYM_TL_WORDS (6u * SYM_TRACE_N * 4u)
+namespace same { static __device__ unsigned long long g_same_prof_trace[6 * 12 * 4]; }
+#define SYM_TRACE(role_, s_, k_) do { if (vwg == SYM_TL_GROUP && lane == 0 && (s_) >= SYM_TRACE_S0 && (s_) < SYM_TRACE_S0 + SYM_TRACE_N) \
+        tlbox[((role_) * SYM_TRACE_N + ((s_) - SYM_TRACE_S0)) * 4u + (k_)] = (uint32_t)clock64(); } while (0)
+#define SYM_REPORT(role_) do { if (vwg == SYM_TL_GROUP && lane < SYM_TRACE_N * 4u) \
+        same::g_same_prof_trace[(role_) * SYM_TRACE_N * 4u + lane] = tlbox[(role_) * SYM_TRACE_N * 4u + lane]; } while (0)
+#define SYM_PROFILE_EXPORTS()                                                                                   \
+    extern "C" int same_debug_profile_sym_trace(unsigned long long *out288)                                     \
+    { return hipMemcpyFromSymbol(out288, HIP_SYMBOL(same::g_same_prof_trace), 288 * sizeof(unsigned long long)) == hipSuccess ? 0 : -1; }
+#else
+#define SYM_TL_WORDS 0u
 #define SYM_PROFILE_EXPORTS()
 #define SYM_TRACE(role_, s_, k_) do {} while (0)
+#endif
 #define FAST_MARKS_BEGIN(X_, lds_, nt_) do {} while (0)
 #define FAST_MARKS_START(X_) do {} while (0)
 #define FAST_MARKS_REPORT(X_) do {} while (0)

@@ -107,7 +107,8 @@ def prof(rx):
 
 
 def timeline(rx):
-    """Profile builds: when each role of the reporting group began a step, got past its first wait and published, over 12 steps."""
+    """Profile builds and SAME_SYM_TL builds: when each role of the reporting group began a step, got past its first wait and
+    published, over 12 steps -- and which of the roles it waits for arrived last (the step's critical graph)."""
     import ctypes
     L = rx._L
     if not hasattr(L, "same_debug_profile_sym_trace"):
@@ -117,10 +118,35 @@ def timeline(rx):
         return
     v = np.array(list(out), dtype=np.int64).reshape(6, 12, 4)
     t0 = v[:, :, 0][v[:, :, 0] > 0].min()
+    v = (v - t0) & 0xffffffff
     names = ["S", "T", "A", "E", "Y1", "Y2"]
-    print("  step: role begin / wait over (E: filters done) / (A: filter done, E: second wait over) / published, clk from the first mark")
+    print("  step: role begin / first wait over / (A: filter done, E: second wait over) / published, clk from the first mark")
     for k in range(12):
-        print(f"  {600 + k:4d}: " + "  ".join(f"{names[r]} {v[r,k,0]-t0:6d}/{v[r,k,1]-t0:6d}" + (f"/{v[r,k,3]-t0:6d}" if r in (2, 3) else "") + f"/{v[r,k,2]-t0:6d}" for r in range(6)))
+        print(f"  {600 + k:4d}: " + "  ".join(f"{names[r]} {v[r,k,0]:6d}/{v[r,k,1]:6d}" + (f"/{v[r,k,3]:6d}" if r in (2, 3) else "") + f"/{v[r,k,2]:6d}" for r in range(6)))
+    first = {0: (1, 2, 3, 4, 5), 1: (2, 3), 2: (0, 3), 3: (0,), 4: (3, 5), 5: (4,)}
+    second = {1: (5,), 2: (5,), 3: (2, 4, 5), 5: (0, 1, 2, 3)}
+    print("  per role, averaged over steps 601..611: period; begin -> first wait over; the role that arrived last at the first wait (how often) and")
+    print("  how long after its publish mark the wait was over; first wait over -> publish")
+    for r in range(6):
+        per = np.diff(v[r, :, 2]).mean()
+        w = (v[r, 1:, 1] - v[r, 1:, 0]).mean()
+        work = (v[r, 1:, 2] - v[r, 1:, 1]).mean()
+        last, lag = {}, []
+        for k in range(1, 12):
+            cand = [(v[d, k - 1, 2], d) for d in first[r]]
+            t, d = max(cand)
+            own = v[r, k, 0]
+            who = names[d] if t > own else "self"
+            last[who] = last.get(who, 0) + 1
+            lag.append(v[r, k, 1] - max(t, own))
+        extra = ""
+        if r in second:
+            lag2 = []
+            for k in range(1, 12):
+                t, d = max((v[d, k - 1, 2], d) for d in second[r])
+                lag2.append((v[r, k, 3] if r == 3 else v[r, k, 2]) - t)
+            extra = f"; second wait's last role published {np.mean(lag2):.0f} before " + ("the wait was over" if r == 3 else "this role published")
+        print(f"    {names[r]:2s} period {per:6.0f}  begin->wait over {w:5.0f}  last: {last}  lag {np.mean(lag):5.0f}  wait over->publish {work:5.0f}{extra}")
 
 
 def marks(rx):
@@ -159,6 +185,14 @@ if what in ("tp", "all"):
         rx = timeit(4096, 10.0, tp=True, cm=True, reps=4)
         if sym == "1": prof(rx)
         timeit(4096, 10.0, tp=True, cm=False, reps=3)
+if what == "timeline":
+    os.environ["SAME_SYM"] = "1"
+    rx = timeit(32768, 2.0, reps=2); timeline(rx)
+    rx = timeit(4096, 10.0, tp=True, cm=True, reps=2); timeline(rx)
+if what == "quick":
+    os.environ["SAME_SYM"] = "1"
+    timeit(32768, 2.0, reps=5)
+    timeit(4096, 10.0, tp=True, cm=True, reps=5)
 if what == "sweep":
     os.environ["SAME_SYM"] = "1"
     for cm in (True, False):
