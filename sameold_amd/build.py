@@ -43,6 +43,7 @@ def flags() -> list:
       + (["-DSAME_P3_MARKS=1"] if os.environ.get("SAME_P3_MARKS") else []) \
       + (["-DSAME_P1_SPLIT=1"] if os.environ.get("SAME_P1_SPLIT") else []) \
       + (["-DSAME_SYM_TL=1"] if os.environ.get("SAME_SYM_TL") else []) \
+      + ([f"-DSYM_PRIOS=0x{os.environ['SAME_SYM_PRIOS']}"] if os.environ.get("SAME_SYM_PRIOS") else []) \
       + ([f"-DSYM_TL_GROUP={int(os.environ['SAME_SYM_TL_GROUP'])}u"] if os.environ.get("SAME_SYM_TL_GROUP") else [])
 
 

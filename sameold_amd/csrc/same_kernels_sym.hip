@@ -214,26 +214,35 @@ struct SymDc {
     // instructions per sample instead of 5.  The state arrays keep the reference's scaling (load / store).
     float sum0, sum1;                    // sum1: 16 x the reference's
     float2v xp[DCL / 2], sp[DCL / 2];    // the last DCL inputs / first-stage SUMS, oldest first
-    Pairs xa, xb;                        // inputs: block b waits in (b & 1 ? xb : xa)
+    // Input buffers: two, block b in (b & 1 ? xb : xa).  Time-major rows (CMODE 0): 36 buffer loads a block, issued just before the
+    // block before theirs is computed, whose waits the compiler counts exactly.  Channel-major streams (CMODE 1): nine 16-byte loads
+    // a block, issued by hand (inline assembly, explicit s_waitcnt vmcnt) INTO THE BUFFER A BLOCK HAS JUST BEEN COMPUTED FROM, i.e.
+    // for the block after next: ~1.6 steps ahead with no third buffer (three do not fit the register file).  By hand, because the
+    // compiler's wait insertion gives up on loads in flight across the loop's back edge and waited for ALL of them -- the ones just
+    // issued included -- before a block's first read: a whole round trip to HBM in every step of the role that paces the headline
+    // launch.  (Nothing in that role's loop may spill: a scratch access counts in vmcnt.)
+    struct InBuf { Pairs p; float4v q[B / 4]; };
+    InBuf xa, xb;
     uint32_t wpos = 0;                   // ring slot of the block written next
     const SampleT *xl = nullptr;         // CMODE 1: this lane's own stream
     uint32_t avail = 0;                  // ... and the blocks it holds
     bool done = false;                   // ... and whether the lane's piece has handed over: nothing it computes from here on is kept
 
-    __device__ __forceinline__ void request(Pairs &dst, const SampleT *__restrict__ x, uint32_t blk, uint32_t n_blocks, uint32_t cin, uint32_t Cin) const
+    __device__ __forceinline__ void request(InBuf &buf, const SampleT *__restrict__ x, uint32_t blk, uint32_t n_blocks, uint32_t cin, uint32_t Cin) const
     {
         if constexpr (CMODE == 1) {
-            // (a lane that has handed over stops reading: in grid order the pieces of a workgroup differ in length, and the
-            // short ones otherwise read on to the end of the longest -- 0.3 x the algorithmic bytes of a configs[1] launch)
-            if (done) return;
-            const uint32_t b = min(blk, avail - 1u);                 // (avail >= 1: the planner leaves two scout blocks behind every cut)
+            // (a lane that has handed over stops streaming: in grid order the pieces of a workgroup differ in length, and the
+            // short ones otherwise read on to the end of the longest -- 0.3 x the algorithmic bytes of a configs[1] launch.  It
+            // re-reads its first block instead, from the cache: no load is ever behind a condition, and the count of loads in
+            // flight -- what take() waits by -- is the same for every lane and step)
+            const uint32_t b = done ? 0u : min(blk, avail - 1u);     // (avail >= 1: the planner leaves two scout blocks behind every cut)
             const float4 *p4 = reinterpret_cast<const float4 *>(xl + (size_t)b * B);
-            sym_static_for<B / 4>([&](auto j_) __attribute__((always_inline)) {
-                constexpr int j = decltype(j_)::value;
-                const float4 v = p4[j];
-                dst[2 * j] = float2v{v.x, v.y}; dst[2 * j + 1] = float2v{v.z, v.w};
-            });
+            static_assert(B / 4 == 9, "nine loads per block");
+#define SYM_LD_(j_) asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=v"(buf.q[j_]) : "v"(p4), "n"(16 * (j_)) : "memory")
+            SYM_LD_(0); SYM_LD_(1); SYM_LD_(2); SYM_LD_(3); SYM_LD_(4); SYM_LD_(5); SYM_LD_(6); SYM_LD_(7); SYM_LD_(8);
+#undef SYM_LD_
         } else {
+            Pairs &dst = buf.p;
             // buffer loads: the block's first row is the resource's base (re-based per block: a launch may exceed the 4 GB a
             // resource spans), row k at the scalar offset k * row_bytes, the lane's column as the vector offset -- one
             // instruction per sample and no address arithmetic on the vector unit (36 x 64-bit adds otherwise)
@@ -252,6 +261,25 @@ struct SymDc {
             });
         }
     }
+    // The inputs of a requested block, once they have arrived.  CMODE 1: YOUNGER = the loads issued after this block's (nine: the
+    // next block's); nothing may touch buf.q between request() and here -- the registers are not written yet.
+    template <int YOUNGER>
+    __device__ __forceinline__ void take(InBuf &buf, Pairs &X) const
+    {
+        if constexpr (CMODE == 1) {
+            static_assert(B / 4 == 9, "nine loads per block");
+            asm volatile("s_waitcnt vmcnt(%9)"
+                         : "+v"(buf.q[0]), "+v"(buf.q[1]), "+v"(buf.q[2]), "+v"(buf.q[3]), "+v"(buf.q[4]), "+v"(buf.q[5]), "+v"(buf.q[6]),
+                           "+v"(buf.q[7]), "+v"(buf.q[8])
+                         : "n"(YOUNGER) : "memory");
+            sym_static_for<B / 4>([&](auto j_) __attribute__((always_inline)) {
+                constexpr int j = decltype(j_)::value;
+                X[2 * j] = float2v{buf.q[j].x, buf.q[j].y}; X[2 * j + 1] = float2v{buf.q[j].z, buf.q[j].w};
+            });
+        } else {
+            sym_static_for<B / 2>([&](auto h_) __attribute__((always_inline)) { X[decltype(h_)::value] = buf.p[decltype(h_)::value]; });
+        }
+    }
     __device__ __forceinline__ void load(const State &S, const SampleT *__restrict__ x, uint32_t c, uint32_t C, uint32_t cin, uint32_t Cin,
                                          uint64_t counter0, uint32_t n_blocks)
     {
@@ -265,7 +293,7 @@ struct SymDc {
             xp[h] = float2v{(S.dc_ff_ring + (size_t)s0 * C)[c], (S.dc_ff_ring + (size_t)s1 * C)[c]};
             sp[h] = float2v{(S.dc_fb_ring + (size_t)s0 * C)[c] * (float)DCL, (S.dc_fb_ring + (size_t)s1 * C)[c] * (float)DCL};
         });
-        sym_static_for<B / 2>([&](auto h_) __attribute__((always_inline)) { xb[decltype(h_)::value] = float2v{0.0f, 0.0f}; });
+        if constexpr (CMODE == 0) sym_static_for<B / 2>([&](auto h_) __attribute__((always_inline)) { xb.p[decltype(h_)::value] = float2v{0.0f, 0.0f}; });
         request(xa, x, 0u, n_blocks, cin, Cin);
     }
     // DC blocker of block `blk`, whose inputs are X; outputs into the window ring's next block (S turns them into AGC
@@ -630,6 +658,10 @@ __device__ __forceinline__ uint32_t sym_framer_step(const Params &P, SymFramer &
 // the first half's AGC / DC / squelch wavefronts, which have slack to spare, and the whole workgroup's step is theirs (measured:
 // E 3 690 clk of a 4 150-clk step in the second half against 2 650 in the first).  Profile builds pick other tables with
 // SAME_PIPE_PRIO bits 12-13 (1: no priorities).
+#ifndef SYM_PRIOS
+#define SYM_PRIOS 0x0031322      /* S T A A(events) E Y1 Y2, one hex digit each */
+#endif
+constexpr int sym_prio_of(int k) { return (int)((SYM_PRIOS >> (4 * (6 - k))) & 3); }
 template <int PRIO> __device__ __forceinline__ void sym_setprio(const Params &P)
 {
 #ifdef SAME_PROFILE
@@ -828,7 +860,7 @@ __global__ __launch_bounds__(kSymHalves * kSymRoles * kWave, 3) void demod_sym_k
 
     if (role == 0u) {
         // ------------------------------------------ S: AGC of block s, in place ------------------------------------------
-        sym_setprio<0>(P);
+        sym_setprio<sym_prio_of(0)>(P);
         SymAgc M;
         { const State S = fresh_state(); M.load(P, S, c, C, counter0, wcol); }
         lds_barrier();                                                 // prologue: block 0's DC outputs are in the ring, every box is initialised
@@ -872,14 +904,25 @@ __global__ __launch_bounds__(kSymHalves * kSymRoles * kWave, 3) void demod_sym_k
         { const State S = fresh_state(); M.store(P, S, c, C, counter1, wcol); }
     } else if (role == 1u) {
         // ------------------------------------------ T: input prefetch and DC blocker of block s + 1 --------------------
-        sym_setprio<0>(P);
+        sym_setprio<sym_prio_of(1)>(P);
         SymDc<SampleT, CMODE> D;
         D.xl = xl; D.avail = avail_l;
         { const State S = fresh_state(); D.load(S, x, c, C, cin, Cin, counter0, n_blocks); }
         donebox[lane] = 0u;
         // prologue: block 0's DC outputs
-        if (n_blocks > 1u) D.request(D.xb, x, 1u, n_blocks, cin, Cin);
-        D.block(P, wcol, D.xa, 0u);
+        {
+            typename SymDc<SampleT, CMODE>::Pairs X0;
+            if constexpr (CMODE == 1) {
+                D.request(D.xb, x, 1u, n_blocks, cin, Cin);                // (clamped to the lane's stream)
+                D.template take<9>(D.xa, X0);
+                D.block(P, wcol, X0, 0u);
+                D.request(D.xa, x, 2u, n_blocks, cin, Cin);
+            } else {
+                if (n_blocks > 1u) D.request(D.xb, x, 1u, n_blocks, cin, Cin);
+                D.template take<0>(D.xa, X0);
+                D.block(P, wcol, X0, 0u);
+            }
+        }
         lds_barrier();
         P3_T0();
         uint32_t stop_at = 0xffffffffu;
@@ -892,8 +935,16 @@ __global__ __launch_bounds__(kSymHalves * kSymRoles * kWave, 3) void demod_sym_k
             P3_LAP(p3_wait);
             if constexpr (CMODE == 1) D.done = donebox[lane] != 0u;
             if (s + 1u < n_blocks && !PROF_SKIP(P, 128)) {
-                if constexpr (BUF == 0) { D.request(D.xb, x, s + 2u, n_blocks, cin, Cin); D.block(P, wcol, D.xa, s + 1u); }
-                else { D.request(D.xa, x, s + 2u, n_blocks, cin, Cin); D.block(P, wcol, D.xb, s + 1u); }
+                typename SymDc<SampleT, CMODE>::Pairs X;
+                if constexpr (CMODE == 1) {
+                    // in flight: this block's loads and the next one's; block s + 3's go out when this block's registers are free
+                    if constexpr (BUF == 0) { D.template take<9>(D.xa, X); D.block(P, wcol, X, s + 1u); D.request(D.xa, x, s + 3u, n_blocks, cin, Cin); }
+                    else { D.template take<9>(D.xb, X); D.block(P, wcol, X, s + 1u); D.request(D.xb, x, s + 3u, n_blocks, cin, Cin); }
+                } else {
+                    if constexpr (BUF == 0) { D.request(D.xb, x, s + 2u, n_blocks, cin, Cin); D.template take<0>(D.xa, X); }
+                    else { D.request(D.xa, x, s + 2u, n_blocks, cin, Cin); D.template take<0>(D.xb, X); }
+                    D.block(P, wcol, X, s + 1u);
+                }
             }
             wait_for(s, R_Y2, &w1, &w2, kNapLong);                               // has Y2 called the hand-over?
             if (flags_of_last(w2, s) & Y2F_LEAVE) stop_at = s;
@@ -912,7 +963,7 @@ __global__ __launch_bounds__(kSymHalves * kSymRoles * kWave, 3) void demod_sym_k
         { const State S = fresh_state(); D.store(S, c, C, counter1); }
     } else if (role == 2u) {
         // ------------------------------------------ A: the matched-filter pair at the FIRST instant of the step's symbol; link events + wake-ups ----
-        sym_setprio<3>(P);
+        sym_setprio<sym_prio_of(2)>(P);
         const uint32_t wcol_lds = lds_addr(wcol);
         SymTaps<NT> TP;
         TP.load(taps);
@@ -951,7 +1002,7 @@ __global__ __launch_bounds__(kSymHalves * kSymRoles * kWave, 3) void demod_sym_k
                 }
             }
             SYM_TRACE(2, s, 3);
-            sym_setprio<1>(P);
+            sym_setprio<sym_prio_of(3)>(P);
             wait_for(s, R_Y2, &w1, &w2, kNapLong);                               // Y2's link words; has it called the hand-over?
             if (flags_of_last(w2, s) & Y2F_LEAVE) stop_at = s;
             // the link event and the wake-ups of what Y2 handed over in the last step
@@ -972,7 +1023,7 @@ __global__ __launch_bounds__(kSymHalves * kSymRoles * kWave, 3) void demod_sym_k
             if (s + 1u == n_steps) againbox[lane] = L.flags & F_TICK_AGAIN;      // (Y2 merges the flag bits)
             SYM_TRACE(2, s, 2);
             publish(s, 0u, 0u);
-            sym_setprio<3>(P);
+            sym_setprio<sym_prio_of(2)>(P);
             P3_LAP(p3_work);
             if (s == stop_at) { left = true; break; }
         }
@@ -986,7 +1037,7 @@ __global__ __launch_bounds__(kSymHalves * kSymRoles * kWave, 3) void demod_sym_k
         }
     } else if (role == 3u) {
         // ------------------------------------------ E: one symbol per lane and step: the filter pair at its SECOND instant, timing loop ----
-        sym_setprio<3>(P);
+        sym_setprio<sym_prio_of(4)>(P);
         const uint32_t wcol_lds = lds_addr(wcol);
         SymTaps<NT> TP;
         TP.load(taps);
@@ -1141,7 +1192,7 @@ __global__ __launch_bounds__(kSymHalves * kSymRoles * kWave, 3) void demod_sym_k
         }
     } else if (role == 4u) {
         // ------------------------------------------ Y1: squelch + equalizer ---------------------------------------------
-        sym_setprio<2>(P);
+        sym_setprio<sym_prio_of(5)>(P);
         SymSquelch<NFF, NFB> Q;
         uint64_t symbols0;
         // the squelch's sample history stays in global memory: the state array itself, or -- where the columns of a wavefront
@@ -1254,7 +1305,7 @@ __global__ __launch_bounds__(kSymHalves * kSymRoles * kWave, 3) void demod_sym_k
         }
     } else {
         // ------------------------------------------ Y2: framer, link state, bursts, hand-over ----------------------------
-        sym_setprio<2>(P);
+        sym_setprio<sym_prio_of(6)>(P);
         Lane L;
         SymFramer F;
         uint8_t *fr_rows;            // in the loop: the framer's rows only
