@@ -1125,14 +1125,16 @@ int process_time_major(same_batch *rx, const SampleT *d_x, size_t n_samples, hip
         const same::Params Pfm = fm_params(rx->P);
         // (the symbol-paced pipeline takes any number of 64-channel workgroups: beyond two per CU they run in rounds -- and
         // it is the faster kernel at every channel count)
+        // (at 44.1 / 48 kHz the FASTMATH pipeline is the only relaxed kernel: beyond the 16 384 columns it holds at once its
+        // workgroups run in rounds -- round 4 sent such batches to the strict kernels whatever the flag said)
         const bool plain_fm = rx->relaxed_plain && rx->P.knob_relaxed_kernel == 0 && same::pipe_relaxed_supported(Pfm) &&
-                              (rx->P.n_channels <= 32768u || (rx->P.n_channels <= rx->sym_max_channels && same::sym_kernel_supported(Pfm)));
+                              (rx->P.n_channels <= 32768u || (rx->P.n_channels <= rx->sym_max_channels && same::sym_kernel_supported(Pfm)) ||
+                               !same::relaxed_kernel_supported(rx->P));
         // (measured, 2 s launches back to back with the transport layer on, the way a stream is fed: 49 152 channels 4.26 ms;
         // 98 304: 7.2 ms against the one-wavefront relaxed kernel's 12.3; 131 072: 9.45 against 15.35; 196 608: 13.95 against
         // 24.9; 262 144: 19.5 against 29.3 -- 30 % of HBM against 18-20 %.  Round 3's figures for the one-wavefront kernel, up to
         // 26 %, were single launches on an idle machine with the link layer only; sustained, its eight wavefronts per SIMD fall
         // back launch by launch: tools/big_sustained.py.  SAME_RELAXED_KERNEL=solo / duo still selects it.)
-        // (44.1 / 48 kHz have the FASTMATH pipeline only: a batch beyond it runs strict)
         const bool plain_wave = rx->relaxed_plain && !plain_fm && same::relaxed_kernel_supported(rx->P);
         rx->last_plain_fm = plain_fm; rx->last_plain_wave = plain_wave;
         const size_t fb = plain_fm ? fm_block_len(Pfm)

@@ -250,6 +250,19 @@ def test_relaxed_batches_on_the_pipeline_at_the_other_rates(sa, monkeypatch, rat
     assert dt.max() <= SOFT_INSTANT_TOLERANCE * rate // 22050 + 1 and err.max() <= SOFT_SYMBOL_TOLERANCE, stats
 
 
+def test_large_relaxed_batches_at_48_khz_stay_relaxed(sa, monkeypatch):
+    """More channels than the FASTMATH pipeline holds at once (16 384 at 44.1 / 48 kHz): its workgroups run in rounds; the batch
+    does not fall back to the strict kernels (round 4 did, whatever the flag said).  Same contract."""
+    monkeypatch.delenv("SAME_RELAXED_KERNEL", raising=False)
+    rate, n_ch = 48000, 40960
+    n = rate * 3
+    x = sa.synth_afsk(n_ch, n, rate, seed=91)
+    ref = strict_events(sa, x, rate)
+    rx, got = relaxed_events(sa, x, rate, calls=[rate + 7, n - rate - 7])
+    assert rx.kernel_name() == "demod_pipe_kernel<fastmath>"
+    assert_contract(sa, got, ref, rate, n_ch, lambda c: sa.synth_payload(91, c), what="40 960 channels at 48 kHz", t_end=n)
+
+
 def test_configurations_without_a_relaxed_kernel_run_strict(sa):
     """Other sample rates, other equalizer orders, a negative AGC floor: SAME_BATCH_RELAXED is accepted and the batch
     runs the strict kernels, bit for bit."""
