@@ -960,8 +960,10 @@ __global__ __launch_bounds__(kSymHalves * kSymRoles * kWave, 3) void demod_sym_k
                     D.block(P, wcol, X, s + 1u);
                 }
             }
-            wait_for(s, R_Y2, &w1, &w2, kNapLong);                               // has Y2 called the hand-over?
-            if (flags_of_last(w2, s) & Y2F_LEAVE) stop_at = s;
+            if (may_leave) {                                                     // (wave-uniform; only a time-parallel piece hands over)
+                wait_for(s, R_Y2, &w1, &w2, kNapLong);                           // has Y2 called the hand-over?
+                if (flags_of_last(w2, s) & Y2F_LEAVE) stop_at = s;
+            }
             SYM_TRACE(1, s, 2);
             publish(s, 0u, 0u);
             P3_LAP(p3_work);

@@ -26,7 +26,11 @@ def test_gather_records_device_path(monkeypatch):
         for o in gather_list:
             o.copy_(t)
 
+    def fake_all_gather_into_tensor(out, t):
+        out.view(2, -1).copy_(t.view(1, -1).expand(2, -1))
+
     monkeypatch.setattr(dist, "all_gather", fake_all_gather)
+    monkeypatch.setattr(dist, "all_gather_into_tensor", fake_all_gather_into_tensor)
     monkeypatch.setattr(dist, "gather", fake_gather)
     bursts = [(4096 + i, 1000 * i + (1 << 33), bytes([65 + i % 26]) * (5 + i % 200)) for i in range(3000)]
     recs = sd.pack_bursts(bursts)
