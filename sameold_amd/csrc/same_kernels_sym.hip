@@ -822,34 +822,21 @@ __global__ __launch_bounds__(kSymHalves * kSymRoles * kWave, 3) void demod_sym_k
     lds_u32 *tlbox = prog + kWave;
 #endif
     // (A waiting wavefront costs vector issue slots -- the resource this kernel is short of -- with every poll: roles with slack
-    // sleep longer between polls than the ones on the step's critical chain.)
+    // sleep longer between polls than the ones on the step's critical chain.  The poll as ONE assembly statement -- no inner loop
+    // for the compiler to see -- was 1 % faster with the link layer alone and 7 % slower with the transport layer on: not kept.)
     const uint32_t prog_idx = lane < (uint32_t)kSymRoles ? lane : 0u;
     uint32_t *const err_flags = fresh_output().n_events + 2;
-    // (The poll is ONE assembly statement: as a loop the compiler could see, every role's step began with an inner loop, and the
-    // register allocator split every value that lives across it -- a role's whole state -- around it: 48 register moves at the
-    // head of every step of the squelch wavefront, 30-odd in the others.)
-    const uint32_t prog_lds = (uint32_t)(uintptr_t)(prog + prog_idx);
     auto wait_for = [&](uint32_t s, uint32_t deps, uint32_t *w_y1, uint32_t *w_y2, auto nap_) __attribute__((always_inline)) {
         constexpr int NAP = decltype(nap_)::value;
-        uint32_t v, t, spins;
-        // (bounded: a protocol error ends in an error code, not in a hung GPU; the flags below bit 16 cannot carry)
-        asm volatile("s_mov_b32 %[n], 0\n"
-                     "1:\n\t"
-                     "ds_read_b32 %[v], %[a]\n\t"
-                     "s_waitcnt lgkmcnt(0)\n\t"
-                     "v_cmp_le_u32_e32 vcc, %[tgt], %[v]\n\t"
-                     "s_and_b32 %[t], vcc_lo, %[deps]\n\t"
-                     "s_cmp_eq_u32 %[t], %[deps]\n\t"
-                     "s_cbranch_scc1 2f\n\t"
-                     "s_sleep %[nap]\n\t"
-                     "s_add_u32 %[n], %[n], 1\n\t"
-                     "s_cmp_lt_u32 %[n], 0x400000\n\t"
-                     "s_cbranch_scc1 1b\n"
-                     "2:"
-                     : [v] "=&v"(v), [t] "=&s"(t), [n] "=&s"(spins)
-                     : [a] "v"(prog_lds), [tgt] "s"(s << 16), [deps] "s"(deps), [nap] "n"(NAP)
-                     : "vcc", "scc", "memory");
-        if (spins >= 0x400000u) { if (lane == 0u) atomicOr(err_flags, 4u); }
+        uint32_t v, spins = 0;
+        for (;;) {
+            v = prog[prog_idx];
+            const uint32_t ok = (uint32_t)__builtin_amdgcn_ballot_w64(v >= (s << 16));     // (the flags below bit 16 cannot carry)
+            if ((ok & deps) == deps) break;
+            __builtin_amdgcn_s_sleep(NAP);
+            // (bounded: a protocol error ends in an error code, not in a hung GPU)
+            if (++spins > (1u << 22)) { if (lane == 0u) atomicOr(err_flags, 4u); break; }
+        }
         *w_y1 = (uint32_t)__builtin_amdgcn_readlane((int)v, 4);
         *w_y2 = (uint32_t)__builtin_amdgcn_readlane((int)v, 5);
     };
@@ -1059,7 +1046,6 @@ __global__ __launch_bounds__(kSymHalves * kSymRoles * kWave, 3) void demod_sym_k
         TP.load(taps);
         Lane L;
         { const State S = fresh_state(); lane_load(L, S, c); }
-        const uint32_t seq_lds = (uint32_t)(uintptr_t)seqbox;
         const float inv_spt = 1.0f / P.samples_per_ted;
         int cstar = next_fire_count(L.until_next_ted, L.ted_clock);
         int rel = cstar - (int)L.ted_clock - 1;        // index of the next instant, relative to the end of the finished samples
@@ -1098,24 +1084,11 @@ __global__ __launch_bounds__(kSymHalves * kSymRoles * kWave, 3) void demod_sym_k
                 if (__builtin_amdgcn_ballot_w64(pl_ready && pl_typeA) != 0ull) {
                     // A has posted this pass (both wavefronts decide from the same posbox words whether there is one).  Bounded:
                     // should the two ever disagree, the launch reports an error instead of hanging the GPU.
-                    uint32_t v, t, spins;
-                    asm volatile("s_mov_b32 %[n], 0\n"
-                                 "1:\n\t"
-                                 "ds_read_b32 %[v], %[a]\n\t"
-                                 "s_waitcnt lgkmcnt(0)\n\t"
-                                 "v_readfirstlane_b32 %[t], %[v]\n\t"
-                                 "s_sub_i32 %[t], %[t], %[seq]\n\t"
-                                 "s_cmp_ge_i32 %[t], 0\n\t"
-                                 "s_cbranch_scc1 2f\n\t"
-                                 "s_sleep 1\n\t"
-                                 "s_add_u32 %[n], %[n], 1\n\t"
-                                 "s_cmp_lt_u32 %[n], 0x400000\n\t"
-                                 "s_cbranch_scc1 1b\n"
-                                 "2:"
-                                 : [v] "=&v"(v), [t] "=&s"(t), [n] "=&s"(spins)
-                                 : [a] "v"(seq_lds), [seq] "s"(seq)
-                                 : "scc", "memory");
-                    if (spins >= 0x400000u) { if (lane == 0u) atomicOr(err_flags, 4u); }
+                    uint32_t spins = 0;
+                    while ((int32_t)(seqbox[0] - seq) < 0) {
+                        __builtin_amdgcn_s_sleep(1);
+                        if (++spins > (1u << 22)) { if (lane == 0u) atomicOr(err_flags, 4u); break; }
+                    }
                     sa1 = __uint_as_float(sabox[lane]);
                 }
                 SYM_T_LAP(24);

@@ -11,7 +11,8 @@ rate, n_ch = 22050, 32768
 n = 44100 - 44100 % 180
 x = sa.synth_afsk(n_ch, n, rate, seed=20260000)
 torch.cuda.synchronize()
-for link_only in (True, False):
+modes = {'link': (True,), 'transport': (False,)}.get(sys.argv[1] if len(sys.argv) > 1 else '', (True, False))
+for link_only in modes:
     rx = sa.SameReceiverBuilder(rate).build_batch(n_ch, link_only=link_only, relaxed=True)
     rx.set_kernel_timing(True)
     one = []
