@@ -249,8 +249,7 @@ struct SymDc {
             const SampleT *xr = x + ((size_t)min(blk, n_blocks - 1u) * B) * Cin;      // wave-uniform
             const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<SampleT *>(xr), 0, 0x7fffffff, 0x00020000);
             const uint32_t voff = cin * (uint32_t)sizeof(SampleT);
-            uint32_t row_bytes = Cin * (uint32_t)sizeof(SampleT);
-            asm volatile("" : "+s"(row_bytes));      // (opaque: the 36 row offsets are made here, one multiply each, not kept in 36 scalar registers for the whole launch)
+            const uint32_t row_bytes = Cin * (uint32_t)sizeof(SampleT);     // (the 36 row offsets k * row_bytes are loop invariants: scalar registers for the whole launch)
             auto one = [&](uint32_t k) __attribute__((always_inline)) -> float {
                 if constexpr (sizeof(SampleT) == 4) return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, voff, k * row_bytes, 0));
                 else return (float)(int16_t)__builtin_amdgcn_raw_buffer_load_b16(rs, voff, k * row_bytes, 0);
