@@ -63,7 +63,12 @@ template <int NT> struct PipeLayout {
     // (the FASTMATH filters take the taps in chunks of kRelaxChunk: 92 taps are followed by 6 zero taps, which meet
     // window slots further back -- finite values, the ring holds 5 blocks)
     static constexpr int NTP = (NT + kRelaxChunk - 1) / kRelaxChunk * kRelaxChunk;
-    static constexpr uint32_t tap_floats = (uint32_t)((NTP * 4 + PIPE_PROF_TAP_PAD + 63) / 64 * 64);
+    // 44.1 / 48 kHz: the centred tap table of the FASTMATH build's filters (demod_pair_centred: NT / 2 entries of Re mark, Re space,
+    // Im mark, Im space) behind the taps
+    static constexpr uint32_t ctap_off = (uint32_t)(NTP * 4 + PIPE_PROF_TAP_PAD);
+    static constexpr uint32_t ctap_floats = NT == 42 ? 0u : (uint32_t)(NT / 2 * 4);
+    static constexpr uint32_t tap_floats = (ctap_off + ctap_floats + 63u) / 64u * 64u;
+    static_assert(ctap_off % 4u == 0u, "16-byte entries");
     static_assert(B <= RING - NTP + 1, "the first block's low copy would be read");
 };
 
@@ -800,6 +805,7 @@ __global__ __launch_bounds__((pipe_dcw<NT, LANES, SPLIT>() ? 5 : 4) * kWave, SHA
     } else if (DCW && role == 0u) {
         // ------------------------------ stage 1 (DCW): AGC + window push, block s ------------------
         for (uint32_t i = lane; i < (uint32_t)NTP; i += kWave) tlds[i] = i < (uint32_t)NT ? taps[i] : float4{0.0f, 0.0f, 0.0f, 0.0f};
+        if constexpr (FM && NT != 42) { float4 *ctl = reinterpret_cast<float4 *>(lds + PipeLayout<NT>::ctap_off); for (uint32_t i = lane; i < (uint32_t)(NT / 2); i += kWave) ctl[i] = taps[NT + i]; }
         if (LANES < (int)kWave && lane >= (uint32_t)LANES) return;
         P3_HWID(0);
         AgcStage<NT, MED3, FM> M;
@@ -838,6 +844,7 @@ __global__ __launch_bounds__((pipe_dcw<NT, LANES, SPLIT>() ? 5 : 4) * kWave, SHA
     } else if (role == 0u) {
         // ------------------------------ stage 1: sample phase, block s -------------------------
         for (uint32_t i = lane; i < (uint32_t)NTP; i += kWave) tlds[i] = i < (uint32_t)NT ? taps[i] : float4{0.0f, 0.0f, 0.0f, 0.0f};
+        if constexpr (FM && NT != 42) { float4 *ctl = reinterpret_cast<float4 *>(lds + PipeLayout<NT>::ctap_off); for (uint32_t i = lane; i < (uint32_t)(NT / 2); i += kWave) ctl[i] = taps[NT + i]; }
         if (LANES < (int)kWave && lane >= (uint32_t)LANES) return;      // (the wavefront goes on without them)
         P3_HWID(0);
         SampleStage<NT, MED3, SampleT, FM, CMODE> M;
@@ -959,7 +966,8 @@ __global__ __launch_bounds__((pipe_dcw<NT, LANES, SPLIT>() ? 5 : 4) * kWave, SHA
                     float sa2;
                     if constexpr (FM) {
                         float hm2, hs2;
-                        demod_pair_relaxed<NTP, RING, false>(lds_addr(lds), lds_addr(wcol), wpos + (uint32_t)fk2, &hm2, &hs2);
+                        if constexpr (NT != 42) demod_pair_centred<NT, RING>(lds_addr(lds + PipeLayout<NT>::ctap_off), lds_addr(wcol), wpos + (uint32_t)fk2, &hm2, &hs2);
+                        else demod_pair_relaxed<NTP, RING, false>(lds_addr(lds), lds_addr(wcol), wpos + (uint32_t)fk2, &hm2, &hs2);
                         sa2 = __builtin_amdgcn_fmed3f(hm2 - hs2, -1.0f, 1.0f);
                     } else {
                         sa2 = demod_fast<NT, RING, true>(tlds, wring, lane, wpos + (uint32_t)fk2);
@@ -1023,7 +1031,8 @@ __global__ __launch_bounds__((pipe_dcw<NT, LANES, SPLIT>() ? 5 : 4) * kWave, SHA
                         const uint32_t wprev = (wpos >= (uint32_t)kB ? wpos : wpos + (uint32_t)RING) - (uint32_t)kB;
                         if constexpr (FM) {
                             float hm2, hs2;
-                            demod_pair_relaxed<NTP, RING, false>(lds_addr(lds), lds_addr(wcol), wprev + (uint32_t)a2_last, &hm2, &hs2);
+                            if constexpr (NT != 42) demod_pair_centred<NT, RING>(lds_addr(lds + PipeLayout<NT>::ctap_off), lds_addr(wcol), wprev + (uint32_t)a2_last, &hm2, &hs2);
+                            else demod_pair_relaxed<NTP, RING, false>(lds_addr(lds), lds_addr(wcol), wprev + (uint32_t)a2_last, &hm2, &hs2);
                             L.h2 = __builtin_amdgcn_fmed3f(hm2 - hs2, -1.0f, 1.0f);
                         } else {
                             L.h2 = demod_fast<NT, RING, true>(tlds, wring, lane, wprev + (uint32_t)a2_last);
@@ -1220,7 +1229,7 @@ __global__ __launch_bounds__((pipe_dcw<NT, LANES, SPLIT>() ? 5 : 4) * kWave, SHA
             } else if constexpr (HELPER_BOTH) {
                 float hm, hs;
                 if constexpr (FM && NT == 42) demod_pair_relaxed_42<RING>(lds_addr(lds), lds_addr(wcol), wpos + pos, &hm, &hs);
-                else if constexpr (FM) demod_pair_relaxed_chunks<NTP / kRelaxChunk, RING>(lds_addr(lds), lds_addr(wcol), wpos + pos, &hm, &hs);
+                else if constexpr (FM) demod_pair_centred<NT, RING>(lds_addr(lds + PipeLayout<NT>::ctap_off), lds_addr(wcol), wpos + pos, &hm, &hs);      // 44.1 / 48 kHz: centred taps, 5 instructions per tap pair
                 else demod_pair<NT, RING>(tlds, wring, lane, wpos + pos, &hm, &hs);
                 markbox[lane] = __float_as_uint(hm); spacebox[lane] = __float_as_uint(hs);
             } else {

@@ -293,6 +293,91 @@ __device__ __forceinline__ void demod_pair_relaxed_chunks(uint32_t taps_lds, uin
     *hs_out = relax_magnitude(as0 + as1);
 }
 
+// Both matched filters at one instant on CENTRED taps, taps in LDS: the 44.1 / 48 kHz form of same_kernels_sym.hip's SymTaps::demod
+// (which keeps its 42 taps in registers).  The filter is a cisoid (rx/waveform.rs:39-64) and only its output's magnitude is used
+// (rx/demod.rs:156-164), so it may be turned by a unit phasor: u[k] = h[k] e^{j a (N-1)/2} has u[N-1-k] = conj(u[k]), and for a real
+// window  sum_i w_i u_i = sum_{k<N/2} (w_k + w_{N-1-k}) Re u_k + j (w_k - w_{N-1-k}) Im u_k.  Per tap PAIR: one window load (both
+// samples), one tap load (Re mark, Re space, Im mark, Im space: same_config.cpp appends that table behind the taps), one packed add
+// and two packed multiply-adds -- 5 instructions where demod_pair_relaxed_chunks spends 7 on the two taps (and 98 padded taps for
+// 92).  `ctaps_lds`: LDS byte address of the centred table; `wlane_lds` / `newest` as demod_pair_relaxed (fully mirrored window).
+// Loads in groups of seven pairs, two groups in flight; LDS returns in order, so "at most 14 outstanding" names the older group.
+__device__ __forceinline__ float2v relax_sum_diff(float2v w)       // (lo, hi) = (w.hi + w.lo, w.hi - w.lo): the sample tap k meets is the pair's second word
+{
+    float2v r;
+    asm volatile("v_pk_add_f32 %0, %1, %1 op_sel:[1,0] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(w));
+    return r;
+}
+// (the loads as functions of their own: inline assembly inside a generic lambda under `if constexpr` does not compile)
+template <int K, int NT>
+__device__ __forceinline__ void relax_centred_load(float2v &w, float4v &t, uint32_t wa, uint32_t ta)
+{
+    asm volatile("ds_read2st64_b32 %0, %1 offset0:%2 offset1:%3" : "=&v"(w) : "v"(wa), "n"(K), "n"(NT - 1 - K) : "memory");
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=&v"(t) : "v"(ta), "n"(16 * K) : "memory");
+}
+struct RelaxCentredGroup { float2v w[7]; float4v t[7]; };      // (lgkmcnt counts to 15: seven pairs = 14 loads per group)
+template <int N>
+__device__ __forceinline__ void relax_centred_wait(RelaxCentredGroup &R)
+{
+    static_assert(N <= 15, "lgkmcnt is four bits");
+    asm volatile("s_waitcnt lgkmcnt(%14)"
+                 : "+v"(R.w[0]), "+v"(R.w[1]), "+v"(R.w[2]), "+v"(R.w[3]), "+v"(R.w[4]), "+v"(R.w[5]), "+v"(R.w[6]),
+                   "+v"(R.t[0]), "+v"(R.t[1]), "+v"(R.t[2]), "+v"(R.t[3]), "+v"(R.t[4]), "+v"(R.t[5]), "+v"(R.t[6])
+                 : "n"(N));
+}
+template <int NT, int RING>
+__device__ __forceinline__ void demod_pair_centred(uint32_t ctaps_lds, uint32_t wlane_lds, uint32_t newest, float *hm_out, float *hs_out)
+{
+    constexpr int H = NT / 2, G = 7, NG = (H + G - 1) / G;
+    static_assert(NT % 2 == 0 && NT - 1 <= 255, "tap pairs; ds_read2st64's 8-bit slot offsets");
+    const uint32_t wa = wlane_lds + (newest + (uint32_t)RING - (uint32_t)(NT - 1)) * (kWave * 4u);       // the slot tap N-1 meets
+    using Group = RelaxCentredGroup;
+    Group X, Y;
+    float2v re[2] = {{0.0f, 0.0f}, {0.0f, 0.0f}}, im[2] = {{0.0f, 0.0f}, {0.0f, 0.0f}};      // [parity of k]: .x mark, .y space
+    auto load = [&](auto g_, Group &R) __attribute__((always_inline)) {
+        constexpr int g = decltype(g_)::value;
+        relax_static_for_([&](auto j_) __attribute__((always_inline)) {
+            constexpr int j = decltype(j_)::value, k = g * G + j;
+            if constexpr (k < H) relax_centred_load<k, NT>(R.w[j], R.t[j], wa, ctaps_lds);
+        }, std::make_integer_sequence<int, G>{});
+    };
+    auto wait = [&](auto n_, Group &R) __attribute__((always_inline)) { relax_centred_wait<decltype(n_)::value>(R); };
+    auto products = [&](auto g_, Group &R) __attribute__((always_inline)) {
+        constexpr int g = decltype(g_)::value;
+        // (all sums / differences of a group first, then the products: a packed operation that reads the result of the
+        // instruction before it costs a wait state)
+        relax_static_for_([&](auto j_) __attribute__((always_inline)) {
+            constexpr int j = decltype(j_)::value;
+            if constexpr (g * G + j < H) R.w[j] = relax_sum_diff(R.w[j]);
+        }, std::make_integer_sequence<int, G>{});
+        relax_static_for_([&](auto j_) __attribute__((always_inline)) {
+            constexpr int j = decltype(j_)::value, k = g * G + j;
+            if constexpr (k < H) {
+                pk_fma_lo(re[k & 1], R.w[j], float2v{R.t[j].x, R.t[j].y});
+                pk_fma_hi(im[k & 1], R.w[j], float2v{R.t[j].z, R.t[j].w});
+            }
+        }, std::make_integer_sequence<int, G>{});
+    };
+    // groups still to land behind group g: the next one's loads, if there is one (a short last group issues fewer)
+    auto pending_after = [](int g) constexpr { const int k0 = (g + 1) * G; const int n = k0 >= H ? 0 : (H - k0 < G ? H - k0 : G); return 2 * n; };
+    load(std::integral_constant<int, 0>{}, X);
+    relax_static_for_([&](auto g_) __attribute__((always_inline)) {
+        constexpr int g = decltype(g_)::value;
+        if constexpr (g % 2 == 0) {
+            if constexpr (g + 1 < NG) load(std::integral_constant<int, g + 1>{}, Y);
+            wait(std::integral_constant<int, pending_after(g)>{}, X);
+            products(g_, X);
+        } else {
+            if constexpr (g + 1 < NG) load(std::integral_constant<int, g + 1>{}, X);
+            wait(std::integral_constant<int, pending_after(g)>{}, Y);
+            products(g_, Y);
+        }
+    }, std::make_integer_sequence<int, NG>{});
+    const float2v r = re[0] + re[1], i = im[0] + im[1];
+    const float2v q = __builtin_elementwise_fma(i, i, r * r);         // (|mark|^2, |space|^2)
+    *hm_out = __builtin_amdgcn_sqrtf(q.x);
+    *hs_out = __builtin_amdgcn_sqrtf(q.y);
+}
+
 // One AGC step, rx/agc.rs:72-77, as gain * (1 - bw |y|) + bw: the same update algebraically while gain >= 0 (the
 // launchers check the floor), one fused multiply-add and the clamp on the gain's dependency chain.  bw_eff = 0 for a
 // locked AGC: gain * 1 + 0.
