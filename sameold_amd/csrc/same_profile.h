@@ -75,6 +75,7 @@ namespace same { static __device__ unsigned long long g_same_prof_sym[32]; }
         same::g_same_prof_sym[20] += symt_n[0]; same::g_same_prof_sym[21] += symt_n[1]; } } while (0)
 // timeline of the reporting group: shader clock at mark k (0 step begins, 1 first wait over, 2 work done / published) of role r in steps
 // SYM_TRACE_S0 .. + SYM_TRACE_N - 1 of a launch (tools/sym_probe.py timeline)
+#define SYM_TL_WORDS 0u      /* (the light timeline of release builds keeps its marks in LDS: SAME_SYM_TL) */
 #define SYM_TRACE_S0 600u
 #define SYM_TRACE_N 12u
 namespace same { static __device__ unsigned long long g_same_prof_trace[6 * 12 * 4]; }

@@ -13,7 +13,7 @@ T = int(rate * secs)
 x = sa.synth_afsk(C, T, rate, seed=1, noise_sigma=float(os.environ.get('SAME_NOISE', '0')))
 torch.cuda.synchronize()
 rx = sa.SameReceiverBuilder(rate).build_batch(C, link_only=not os.environ.get('SAME_TRANSPORT'),
-                                             time_parallel=bool(os.environ.get('SAME_TP')))
+                                             time_parallel=bool(os.environ.get('SAME_TP')), relaxed=bool(os.environ.get('SAME_RELAXED_MODE')))
 rx.set_kernel_timing(True)
 for r in range(reps):
     t0 = time.perf_counter()
