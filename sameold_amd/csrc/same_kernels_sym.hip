@@ -10,37 +10,37 @@
 //   * of the two instants of a symbol only the second one (B, the one that completes the symbol) feeds a decision back
 //     into the timing loop; the first (A) just shifts the TED's history and adds the clock offset to the period
 //     (rx/symsync.rs:236-241), so where B falls is known as soon as A's position is -- before either filter has run.
-//     The two matched-filter pairs of a symbol are therefore evaluated side by side, on two wavefronts (S at A, E at
+//     The two matched-filter pairs of a symbol are therefore evaluated side by side, on two wavefronts (A at A, E at
 //     B), and E runs the two timing updates after them: once per symbol and lane;
 //   * a step is 36 samples, less than the shortest symbol the timing loop can command (two instants at least 19 samples
 //     apart each: max_block_len), so every lane completes AT MOST one symbol per step and ~85 % of the lanes complete
 //     exactly one: filters, timing loop and symbol path run once per step at ~85 % occupancy;
-//   * the sample phase (DC blocker, AGC, window push) runs 36 samples per step and barrier: the fixed costs of a step
-//     (barrier, feedback word, mailboxes) are paid per 36 samples instead of per 20.
+//   * the sample phase (DC blocker, AGC, window push) runs 36 samples per step: the fixed costs of a step (progress words,
+//     feedback words, mailboxes) are paid per 36 samples instead of per 20.
 //
-// Four wavefronts per 64 state columns, on the four SIMDs of a CU, their work per step balanced by instruction count
-// (the first cut -- sample phase | filters + timing | symbol path | events -- ran 4 900 / 5 400 / 3 200 / 700 clk per step):
-//   T  input prefetch (a whole step ahead) and DC blocker of block s + 1 -- it takes no feedback from anything
-//      (rx/dcblock.rs:45-49) -- handed to S through a two-block LDS ring; then the link events and transport wake-ups of
-//      what Y handed over one step earlier
-//   S  the matched-filter pair at the FIRST instant of the step's symbol (E posts where); then AGC (relaxed) and window push
-//      of block s from the DC blocker's outputs (it keeps those of its last three blocks, packed f16: the gain an
-//      AGC lock freezes is that of a sample up to two blocks back)
-//   E  the symbol whose instants lie in finished samples (blocks < s): the matched-filter pair at its SECOND instant, then
-//      the two timing updates and where the next symbol's instants fall
-//   Y  symbol path of the symbol E handed over one step earlier: squelch, equalizer, framer (same_dev_common.h); the
-//      squelch's sample history stays in the HBM state arrays (two loads a step, issued ahead)
-// Feedback (agc.lock / loop bandwidth / symsync.reset, receiver.rs:431-432, 479-490) never sends a wavefront back: Y posts
+// Six role-wavefronts per 64 state columns, one step apart (round 5; round 4 had four -- sample phase | filters + timing | symbol
+// path | events -- at 4 900 / 5 400 / 3 200 / 700 clk per step), two such groups per twelve-wavefront workgroup:
+//   T  input prefetch and DC blocker of block s + 1 -- it takes no feedback from anything (rx/dcblock.rs:45-49) -- written straight
+//      into the window ring's next block
+//   S  AGC (relaxed) of block s IN PLACE in the ring; the gain an AGC lock freezes is recomputed from the ring's AGC outputs
+//   A  the matched-filter pair at the FIRST instant of the step's symbol (E posts where); then the link events and transport
+//      wake-ups of what Y2 handed over one step earlier
+//   E  the symbol whose instants lie in finished samples (blocks < s): the matched-filter pair at its SECOND instant, then the
+//      two timing updates and where the next symbol's instants fall
+//   Y1 squelch and equalizer of the symbol E handed over one step earlier (the squelch's sample history stays in the HBM state
+//      arrays: two loads a step, issued a symbol ahead)
+//   Y2 framer, link state, burst rows into the pool, hand-over of time-parallel pieces: one step behind Y1
+// There is no step barrier: every role publishes one progress word per step and waits for the roles it exchanges data with.
+// Feedback (agc.lock / loop bandwidth / symsync.reset, receiver.rs:431-432, 479-490) never sends a wavefront back: Y1 / Y2 post
 // a change with the symbol it happened at, one word per lane.  S freezes the AGC from its next block on AT THE GAIN IT HAD
-// after that symbol's sample (recomputed from the block's start out of the packed history; the gain every soft symbol
-// of the burst is scaled by is therefore strict mode's to rounding), or releases it from its next block on; E switches the
-// loop bandwidth, or resets the TED, behind its next symbol -- two symbols late.  The first form of this kernel replayed a
-// lock at its sample (two more barriers in ~5 % of the steps, S and E filtering the symbol again): 8 % slower, and
-// nothing the contract below asks for came of it.
+// after that symbol's sample (the gain every soft symbol of the burst is scaled by is therefore strict mode's to rounding), or
+// releases it from its next block on; E switches the loop bandwidth, or resets the TED, behind its next symbol -- two symbols
+// late.  The first form of this kernel replayed a lock at its sample (two more barriers in ~5 % of the steps, S and E filtering
+// the symbol again): 8 % slower, and nothing the contract below asks for came of it.
 //
-// Window ring: five blocks of 36 slots, the first 13 slots stored twice (a 14-tap filter chunk never wraps).  T reads at
-// most 119 samples back from the end of block s-1 (a lane may lag up to 52 samples behind after a symsync.reset, the
-// symbol's first filter reaches 25 + 41 further) while S writes block s: four readable blocks and the one being written.
+// Window ring: six blocks of 36 slots -- the four the filters may reach into (a lane may lag up to 52 samples behind after a
+// symsync.reset, the symbol's first filter reaches 25 + 41 further), the one S is turning into AGC outputs, the one T is writing
+// -- with the first 41 slots stored twice (a filter's 42 samples never wrap).  DESIGN.md 4.6 has the full account.
 //
 // Parity contract: that of SAME_BATCH_RELAXED / the time-parallel mode (include/same_rx.h): transmitted bytes and
 // transport messages equal strict mode's, link events within SAME_TP_EVENT_TOLERANCE_SYMBOLS symbols, soft symbols of
