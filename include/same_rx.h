@@ -191,8 +191,8 @@ enum {
      * strict): transmitted burst bytes and transport messages EQUAL, link events within
      * SAME_TP_EVENT_TOLERANCE_SYMBOLS symbols, soft symbols of an open squelch within 0.05 with equal sign
      * (tests/test_relaxed.py, tests/test_sym_kernel.py).  22.05, 44.1 and 48 kHz with the default DC-blocker length,
-     * default or disabled equalizer and a non-negative AGC floor (44.1 / 48 kHz: whole groups of 64 channels, up to
-     * 32 768 of them); any other configuration runs strict.  Strict mode (no flag) stays bit-exact. */
+     * default or disabled equalizer and a non-negative AGC floor (44.1 / 48 kHz: whole groups of 64 channels, any number
+     * of them); any other configuration runs strict.  Strict mode (no flag) stays bit-exact. */
     SAME_BATCH_RELAXED = 1u << 4
 };
 #define SAME_TP_EVENT_TOLERANCE_SYMBOLS 2
