@@ -253,7 +253,7 @@ struct same_batch {
         float *d_hist = nullptr; size_t hist_cap = 0;       // squelch histories by grid position (PipeChunks::hist_scratch)
         hipEvent_t ev_plan_prev = nullptr; bool plan_recorded = false;
         int knob_plan_stream = 0;                            // SAME_TP_PLAN_STREAM=0: planning kernels stay on the launch stream (A/B measurements)
-        int sort_mode = -1;                                  // SAME_TP_SORT: -1 choose, 0 grid order, 1 pieces sorted by length into workgroups
+        int sort_mode = -1;                                  // SAME_TP_SORT: -1 choose, 0 grid order, 1 pieces sorted by length into workgroups, 2 groups of 64 paired long with short
         uint32_t last_chunks = 1;
         bool last_per_channel = false;
         // which kernel runs the chunks of the call being planned: the wavefront pipeline (strict, or its FASTMATH build
@@ -1274,11 +1274,16 @@ int process_channel_major_native(same_batch *rx, const float *d_x, size_t n, hip
     // pieces sorted by length into workgroups only when the workgroups come in more than one round (the long ones first;
     // SAME_TP_SORT=0 / 1 overrides).  Within one round neither the sorted order nor a long workgroup beside a short one on
     // every CU pays (round 2).
-    const int sort_mode = tp.sort_mode >= 0 ? (tp.sort_mode ? 1 : 0) : (columns > 32768u ? 1 : 0);
+    // SAME_TP_SORT=2 (measurement knob): grid order inside the groups of 64 columns, the groups paired longest with shortest into
+    // the symbol-paced pipeline's two-group workgroups, so that a long group runs the second part of its launch alone on its CU
+    // (a step is ~12 % shorter there).  One launch by itself: demodulation kernel 1.746 -> 1.706 ms; launches back to back, the
+    // way the bench and a stream step: 1.695 -> 1.732 (the shorter tail hides less of the next call's planning) -- not the default.
+    const bool pair_groups = tp.sort_mode == 2 && tp.kernel == same_batch::TimePar::kPipeRelaxed && same::sym_kernel_supported(tp.Pv);
+    const int sort_mode = pair_groups ? 0 : (tp.sort_mode >= 0 ? (tp.sort_mode ? 1 : 0) : (columns > 32768u ? 1 : 0));
     HIP_TRY(same::launch_counters(sl.d_counters, sl.h_counters_dev, 0, stream));
     sl.timed = rx->timing; if (sl.timed) HIP_TRY(hipEventRecord(sl.ev_start, stream));
     // (sorted: the workgroups once more, longest first whatever their group -- those that wait for a free CU are then the short ones)
-    const bool lpt = sort_mode != 0;
+    const bool lpt = sort_mode != 0 || pair_groups;
     // On the library's own stream the planning kernels go to the plan stream: they need the input (ordered by
     // same_batch_order_after, which both streams honour) and this slot's geometry buffers (free since the harvest above),
     // not the previous launch -- so they run beside its tail instead of after it (~0.25 ms of small kernels per call at
@@ -1289,7 +1294,7 @@ int process_channel_major_native(same_batch *rx, const float *d_x, size_t n, hip
     // streams the two ran on)
     if (tp.plan_recorded) HIP_TRY(hipStreamWaitEvent(ps, tp.ev_plan_prev, 0));
     HIP_TRY(same::launch_tp_plan(d_x, plan, tp.d_energy, d_own, d_row0, d_nom, d_perm, d_wg, sort_mode != 0, ps,
-                                 lpt ? d_perm2 : nullptr, lpt ? d_wg2 : nullptr));
+                                 lpt ? d_perm2 : nullptr, lpt ? d_wg2 : nullptr, pair_groups));
     if (!tp.ev_plan_prev) HIP_TRY(hipEventCreateWithFlags(&tp.ev_plan_prev, hipEventDisableTiming));
     HIP_TRY(hipEventRecord(tp.ev_plan_prev, ps));
     tp.plan_recorded = true;
@@ -1302,7 +1307,7 @@ int process_channel_major_native(same_batch *rx, const float *d_x, size_t n, hip
     HIP_TRY(same::launch_copy_state_columns(tp.d_desc_in, tp.n_desc, C, columns, nullptr, C, stream));
     HIP_TRY(same::launch_fill_u64(sl.d_handover, columns, same::kNoHandover, stream));
     pc.handover = sl.d_handover;
-    pc.col_row0 = d_row0; pc.col_nominal = d_nom; pc.wg_blocks = d_wg; pc.col_perm = sort_mode != 0 ? d_perm : nullptr;
+    pc.col_row0 = d_row0; pc.col_nominal = d_nom; pc.wg_blocks = d_wg; pc.col_perm = (sort_mode != 0 || pair_groups) ? d_perm : nullptr;
     pc.in_samples = n_call; pc.whole_samples = (uint32_t)n;
     pc.hist_scratch = nullptr;
     if (pc.col_perm && tp.kernel == same_batch::TimePar::kPipeRelaxed && same::sym_kernel_supported(tp.Pv)) {

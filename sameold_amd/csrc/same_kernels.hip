@@ -621,21 +621,25 @@ __global__ void tp_align_kernel(TpPlan g, const uint32_t *__restrict__ perm, uin
 // wait must be the short ones, and the long ones -- which set the launch's length -- should start at time zero.  One
 // wavefront per workgroup of the demodulation launch: its rank among all of them by length (ties by position), then
 // its 64 grid positions and its block count move to that rank.
+// `pairs` (the symbol-paced pipeline, whose workgroup is TWO groups of 64 columns with a CU to themselves): the group of rank r
+// and the group of rank n - 1 - r share a workgroup -- the longest with the shortest -- so that every long group runs the second
+// part of its launch alone on its CU, where a step is ~12 % shorter.
 __global__ void tp_wg_order_kernel(uint32_t n_wg, const uint32_t *__restrict__ perm, const uint32_t *__restrict__ wg_blocks,
-                                   const uint32_t *__restrict__ wg_len, uint32_t *__restrict__ perm_out, uint32_t *__restrict__ wg_blocks_out)
+                                   const uint32_t *__restrict__ wg_len, uint32_t *__restrict__ perm_out, uint32_t *__restrict__ wg_blocks_out,
+                                   uint32_t pairs)
 {
     const uint32_t w = blockIdx.x, lane = threadIdx.x;
     const uint32_t mine = wg_len[w];
     uint32_t rank = 0;
     for (uint32_t j = lane; j < n_wg; j += kWave) { const uint32_t b = wg_len[j]; rank += (b > mine || (b == mine && j < w)) ? 1u : 0u; }
     for (int off = 32; off > 0; off >>= 1) rank += (uint32_t)__shfl_xor((int)rank, off);
-    const uint32_t pos = rank;
+    const uint32_t pos = (pairs && (n_wg & 1u) == 0u) ? (rank < n_wg / 2u ? 2u * rank : 2u * (n_wg - 1u - rank) + 1u) : rank;
     perm_out[pos * kWave + lane] = perm[w * kWave + lane];
     if (lane == 0) wg_blocks_out[pos] = wg_blocks[w];
 }
 hipError_t launch_tp_plan(const float *x, const TpPlan &g, float *energy, uint32_t *own_start, uint32_t *row0,
                           uint32_t *nominal, uint32_t *perm, uint32_t *wg_blocks, bool sorted, hipStream_t stream,
-                          uint32_t *perm_out, uint32_t *wg_blocks_out)
+                          uint32_t *perm_out, uint32_t *wg_blocks_out, bool pairs)
 {
     const size_t n = (size_t)g.channels * g.scout_blocks;
     const uint32_t columns = g.n_chunks * g.channels;
@@ -651,7 +655,7 @@ hipError_t launch_tp_plan(const float *x, const TpPlan &g, float *energy, uint32
     hipLaunchKernelGGL(tp_align_kernel, dim3(columns / kWave), dim3(kWave), 0, stream, g, perm, row0, nominal, wg_blocks, wg_len);
     if (perm_out)
         hipLaunchKernelGGL(tp_wg_order_kernel, dim3(columns / kWave), dim3(kWave), 0, stream, columns / kWave, perm, wg_blocks, wg_len,
-                           perm_out, wg_blocks_out);
+                           perm_out, wg_blocks_out, pairs ? 1u : 0u);
     return hipGetLastError();
 }
 

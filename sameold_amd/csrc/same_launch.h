@@ -89,7 +89,7 @@ struct TpPlan {
 // null; wg_blocks_out [2][workgroups]): the workgroups of perm / wg_blocks once more, longest first
 hipError_t launch_tp_plan(const float *x, const TpPlan &g, float *energy, uint32_t *own_start, uint32_t *row0,
                           uint32_t *nominal, uint32_t *perm, uint32_t *wg_blocks, bool sorted, hipStream_t stream,
-                          uint32_t *perm_out = nullptr, uint32_t *wg_blocks_out = nullptr);
+                          uint32_t *perm_out = nullptr, uint32_t *wg_blocks_out = nullptr, bool pairs = false);
 hipError_t launch_transpose_f32(const float *in, float *out, uint32_t n_channels, uint32_t n_samples,
                                 hipStream_t stream);
 hipError_t launch_transpose_i16(const int16_t *in, int16_t *out, uint32_t n_channels, uint32_t n_samples,
