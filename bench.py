@@ -523,15 +523,18 @@ def main():
         return None
 
     def pmc_issue(kind, workload=None):
-        """What limits the kernel when it is not HBM (it is not): vector instructions per 64-column sample and the fraction of a
-        wavefront's cycles in which it issues one, from the round's SQ counter pass over this same command (tools/profile_round.sh,
+        """What limits the kernel when it is not HBM (it is not): wavefront instructions per 64-column sample by kind and the fraction
+        of a wavefront's cycles in which it issues a vector one, from the round's SQ counter pass over this same command (tools/profile_round.sh,
         profiles/r05_pmc_instruction_mix.txt); null when no pass has been filed."""
         try:
             with open(os.path.join(ROOT, "profiles", "r05_issue.json")) as f:
                 for ent in json.load(f):
                     if ent.get("workload") == (workload or f"{C} ch x {T} samples") and ent.get("mode") == kind:
-                        return {"kind": "valu_issue", "valu_per_workgroup_sample": ent["valu_per_workgroup_sample"],
+                        return {"kind": "instruction_issue_per_wavefront", "valu_per_workgroup_sample": ent["valu_per_workgroup_sample"],
+                                "salu_per_workgroup_sample": ent.get("salu_per_workgroup_sample"), "lds_per_workgroup_sample": ent.get("lds_per_workgroup_sample"),
                                 "valu_issue_fraction_of_wave_cycles": ent["valu_issue_fraction_of_wave_cycles"],
+                                "note": "every role-wavefront of the symbol-paced pipeline is self-bound (profiles/r05_cycle_attribution.txt, light timeline): a launch is "
+                                        "the longest role's instructions of ANY kind at ~8-9 clk each with three wavefronts per SIMD (DESIGN.md 8)",
                                 "budget_for_60pct_hbm": "<= 21-27 VALU per 64-column sample (1 024 SIMDs x f / 4 instructions/s over 1.875e10 column-group samples/s at f = 1.8-2.35 GHz, 85 % busy)",
                                 "source": ent["source"]}
         except Exception:
