@@ -305,7 +305,10 @@ struct same_batch {
     std::vector<HarvestPart> parts;     // per host thread, kept between harvests for their capacity
     WorkerPool workers;
     // transport layer, one assembler per channel (unless SAME_BATCH_LINK_ONLY)
-    std::vector<same::Transport> transport;
+    // (two arrays: one cache line per channel that every poll touches, and the burst bytes / message texts: same_transport.h)
+    std::vector<same::TransportHot> thot;
+    std::vector<same::TransportCold> tcold;
+    same::TransportRef tr(uint32_t c) { return same::TransportRef(thot[c], tcold[c]); }
     uint64_t *h_wake = nullptr;      // host mirror of State::wake_sample (pinned, n_channels words, zero = unarmed)
 };
 
@@ -570,10 +573,10 @@ int harvest_host(same_batch *rx, same_batch::Slot &sl, uint32_t n_events, uint32
     auto feed = [&](Part &part, same_rx_event &tev, const same::DevEvent &d, uint32_t c, int64_t off) {
         const uint64_t sym = (uint64_t)((int64_t)d.symbol_count + off);
         auto poll = [&](uint64_t psym, uint64_t pt) {
-            if (rx->transport[c].on_link_event(same::kDevTick, pt, psym, nullptr, 0, rx->P.input_rate, &tev)) push_transport(part, tev, c);
+            if (rx->tr(c).on_link_event(same::kDevTick, pt, psym, nullptr, 0, rx->P.input_rate, &tev)) push_transport(part, tev, c);
         };
         if (tp && !link_only)
-            rx->tp.synth[c].run_until(sym, d.sample_counter, sps, rx->transport[c].force_eom_at(), poll);
+            rx->tp.synth[c].run_until(sym, d.sample_counter, sps, rx->tr(c).force_eom_at(), poll);
         QEvent q{};
         q.kind = d.kind; q.channel = c; q.sample_counter = d.sample_counter; q.symbol_count = sym;
         const uint8_t *payload = nullptr;
@@ -591,8 +594,8 @@ int harvest_host(same_batch *rx, same_batch::Slot &sl, uint32_t n_events, uint32
         }
         if (d.kind <= SAME_LINK_BURST) part.out.push_back(q);
         if (!link_only) {
-            if (rx->transport[c].on_link_event(d.kind, d.sample_counter, sym, payload, q.n_bytes, rx->P.input_rate, &tev)) push_transport(part, tev, c);
-            if (!tp && rx->transport[c].force_eom_dirty()) part.rearm.push_back(c);
+            if (rx->tr(c).on_link_event(d.kind, d.sample_counter, sym, payload, q.n_bytes, rx->P.input_rate, &tev)) push_transport(part, tev, c);
+            if (!tp && rx->tr(c).force_eom_dirty()) part.rearm.push_back(c);
         }
         if (tp && d.kind <= SAME_LINK_BURST) rx->tp.synth[c].after_event(d.kind, sym, d.sample_counter, interburst, history);
     };
@@ -676,15 +679,15 @@ int harvest_host(same_batch *rx, same_batch::Slot &sl, uint32_t n_events, uint32
         same_rx_event ev;                                  // (scratch for what the transport layer returns)
         std::memset(&ev, 0, sizeof(ev));
         for (uint32_t c = c0; c < c1; ++c) {
-            // (the next channel's transport state: its first lines are what a poll reads, and they are cold)
-            // -- and all of it when a burst is on its way there: the assembler then walks its burst history and message texts
+            // (the next channel's transport state: its hot line is in the cache as a rule -- 2 MB for 32 768 channels -- the burst
+            // history and message texts are not: all of them when a burst is on its way there)
             if (!link_only && c + 1u < c1) {
-                const char *nx = reinterpret_cast<const char *>(&rx->transport[c + 1u]);
-                __builtin_prefetch(nx); __builtin_prefetch(nx + 64);
+                __builtin_prefetch(&rx->thot[c + 1u]);
                 if (!sl.chunked) {
                     bool burst = false;
                     for (uint32_t k = first[c + 1u]; k < first[c + 2u]; ++k) burst |= evs[k].kind == SAME_LINK_BURST;
-                    if (burst) for (size_t o = 128; o < sizeof(same::Transport); o += 64) __builtin_prefetch(nx + o);
+                    const char *nx = reinterpret_cast<const char *>(&rx->tcold[c + 1u]);
+                    if (burst) for (size_t o = 0; o < sizeof(same::TransportCold); o += 64) __builtin_prefetch(nx + o);
                 }
             }
             // this channel's column ranges back into log order (see above)
@@ -702,9 +705,9 @@ int harvest_host(same_batch *rx, same_batch::Slot &sl, uint32_t n_events, uint32
                 if (ts.link == SAME_LINK_NO_CARRIER && sl.end_counter > ts.a_t) {
                     const uint64_t sym_end = ts.a_sym + (uint64_t)((double)(sl.end_counter - ts.a_t) / sps);
                     auto poll = [&](uint64_t psym, uint64_t pt) {
-                        if (rx->transport[c].on_link_event(same::kDevTick, pt, psym, nullptr, 0, rx->P.input_rate, &ev)) push_transport(part, ev, c);
+                        if (rx->tr(c).on_link_event(same::kDevTick, pt, psym, nullptr, 0, rx->P.input_rate, &ev)) push_transport(part, ev, c);
                     };
-                    ts.run_until(sym_end + 1u, sl.end_counter + 1u, sps, rx->transport[c].force_eom_at(), poll);
+                    ts.run_until(sym_end + 1u, sl.end_counter + 1u, sps, rx->tr(c).force_eom_at(), poll);
                 }
             }
         }
@@ -854,7 +857,7 @@ int harvest_slot(same_batch *rx, same_batch::Slot &sl)
             HIP_TRY(hipHostMalloc((void **)&rx->h_wake, (size_t)rx->P.n_channels * sizeof(uint64_t), hipHostMallocDefault));
             std::memset(rx->h_wake, 0, (size_t)rx->P.n_channels * sizeof(uint64_t));
         }
-        for (uint32_t c : rearm) rx->h_wake[c] = rx->transport[c].force_eom_at();
+        for (uint32_t c : rearm) rx->h_wake[c] = rx->tr(c).force_eom_at();
         // the kernels only read this table (it is host-owned), so it may be updated while a
         // later launch runs; launches are capped at 45 s, two launches < the 135 s timeout
         HIP_TRY(hipMemcpyAsync(rx->S.wake_sample, rx->h_wake, (size_t)rx->P.n_channels * sizeof(uint64_t), hipMemcpyHostToDevice, rx->copy_stream));
@@ -1532,7 +1535,7 @@ int same_batch_new(const same_rx_builder *b, uint32_t n_channels, int device, ui
     TRY_OR_CLEAN(same::launch_init_state(rx->P, rx->S, 0, rx->own_stream));
     TRY_OR_CLEAN(hipStreamSynchronize(rx->own_stream));
 #undef TRY_OR_CLEAN
-    if (!(flags & SAME_BATCH_LINK_ONLY)) rx->transport.resize(n_channels);
+    if (!(flags & SAME_BATCH_LINK_ONLY)) { rx->thot.resize(n_channels); rx->tcold.resize(n_channels); }
     if (rx->tp.enabled) { rx->tp.sym_off.assign(n_channels, 0); rx->tp.synth.assign(n_channels, TickSynth{}); }
     *out = rx;
     return SAME_OK;
@@ -1598,7 +1601,7 @@ int same_batch_reset(same_batch *rx)
     rx->queue.clear(); rx->queue_head = 0;   // event_queue.clear() receiver.rs:194
     rx->arena.clear();
     rx->burst_seq.clear(); rx->burst_seq_head = 0;
-    for (auto &t : rx->transport) t.reset();
+    for (uint32_t c = 0; c < (uint32_t)rx->thot.size(); ++c) rx->tr(c).reset();
     for (auto &o : rx->tp.sym_off) o = 0;
     for (auto &t : rx->tp.synth) t.reset();
     if (rx->h_wake) std::memset(rx->h_wake, 0, (size_t)rx->P.n_channels * sizeof(uint64_t));
@@ -1909,7 +1912,7 @@ long same_debug_harvest_replay(const char *path, int threads, int reps, double *
     rx->P.n_channels = h.n_channels; rx->P.input_rate = h.input_rate; rx->flags = h.flags;
     if (std::getenv("SAME_REPLAY_LINK_ONLY")) rx->flags |= SAME_BATCH_LINK_ONLY;      // (what the transport layer's share is)
     rx->tp.enabled = h.tp_enabled != 0; rx->host_threads = threads;
-    if (!(h.flags & SAME_BATCH_LINK_ONLY)) rx->transport.resize(h.n_channels);
+    if (!(h.flags & SAME_BATCH_LINK_ONLY)) { rx->thot.resize(h.n_channels); rx->tcold.resize(h.n_channels); }
     if (rx->tp.enabled) { rx->tp.sym_off.assign(h.n_channels, 0); rx->tp.synth.assign(h.n_channels, TickSynth{}); }
     same_batch::Slot &sl = rx->slot[0];
     ev = ev0; hand = hand0;

@@ -131,6 +131,24 @@ bool combine(const BurstBuf *bursts, uint32_t nbursts, MessageResult *res)
             if (!kAllowed.ok[est]) { stopped = true; break; }
             msg[n] = est; cnt[n] = 3; errs[n] = (uint8_t)(be + msb);
         }
+    } else if (nb == 2) {
+        // (the first and the second burst of a message are two calls in three: the same stretch for one and two bursts)
+        const uint8_t *a = bursts[0].data, *b = bursts[1].data;
+        for (; n < common; ++n) {
+            const uint8_t x = a[n], y = b[n];
+            const uint8_t msb = (uint8_t)((x | y) >> 7);
+            uint8_t est; uint32_t be;
+            bit_vote_detect(x & 0x7f, y & 0x7f, &est, &be);
+            if (!kAllowed.ok[est]) { stopped = true; break; }
+            msg[n] = est; cnt[n] = 2; errs[n] = (uint8_t)(be + msb);
+        }
+    } else if (nb == 1) {
+        const uint8_t *a = bursts[0].data;
+        for (; n < common; ++n) {
+            const uint8_t x = a[n], est = (uint8_t)(x & 0x7f);
+            if (!kAllowed.ok[est]) { stopped = true; break; }
+            msg[n] = est; cnt[n] = 1; errs[n] = (uint8_t)(x >> 7);
+        }
     }
     while (!stopped && n < kMaxMessageLength) {
         uint8_t cur[3]; uint32_t k = 0; bool msb = false;
@@ -160,83 +178,78 @@ bool combine(const BurstBuf *bursts, uint32_t nbursts, MessageResult *res)
     return good != 0;
 }
 
-void Assembler::reset()
-{
-    nhist_ = 0;
-    pending_ = false; have_prev_ = false;
-}
-void Assembler::prune_history(uint64_t now)
+void TransportRef::prune_history(uint64_t now)
 {
     // rx/assembler.rs:362-368: retain unexpired entries, then keep at most the two newest
     uint32_t w = 0;
-    for (uint32_t i = 0; i < nhist_; ++i)
-        if (!(hist_deadline_[i] <= now)) { if (w != i) { history_[w] = history_[i]; hist_deadline_[w] = hist_deadline_[i]; } ++w; }
-    nhist_ = w;
-    while (nhist_ > 2) {
-        for (uint32_t i = 1; i < nhist_; ++i) { history_[i - 1] = history_[i]; hist_deadline_[i - 1] = hist_deadline_[i]; }
-        --nhist_;
+    for (uint32_t i = 0; i < h_.nhist; ++i)
+        if (!(h_.hist_deadline[i] <= now)) { if (w != i) { c_.history[w] = c_.history[i]; h_.hist_deadline[w] = h_.hist_deadline[i]; } ++w; }
+    h_.nhist = (uint8_t)w;
+    while (h_.nhist > 2) {
+        for (uint32_t i = 1; i < h_.nhist; ++i) { c_.history[i - 1] = c_.history[i]; h_.hist_deadline[i - 1] = h_.hist_deadline[i]; }
+        --h_.nhist;
     }
 }
-void Assembler::accept(const MessageResult &m, uint64_t now)
+void TransportRef::accept(const MessageResult &m, uint64_t now)
 {
     // PendingResult::accept rx/assembler.rs:294-328
     const uint64_t deadline = (m.kind == SAME_TRANSPORT_MSG_END) ? now : now + max_interburst_symbols();
-    if (pending_) {
+    if (h_.pending) {
         bool replace;
-        if (pend_.kind == SAME_TRANSPORT_MSG_ERR) replace = true;
-        else if (pend_.kind == SAME_TRANSPORT_MSG_END && m.kind == SAME_TRANSPORT_MSG_START) replace = true;
-        else if (pend_.kind == SAME_TRANSPORT_MSG_START && m.kind == SAME_TRANSPORT_MSG_START)
-            replace = m.voting_bytes >= pend_.voting_bytes;
+        if (c_.pend.kind == SAME_TRANSPORT_MSG_ERR) replace = true;
+        else if (c_.pend.kind == SAME_TRANSPORT_MSG_END && m.kind == SAME_TRANSPORT_MSG_START) replace = true;
+        else if (c_.pend.kind == SAME_TRANSPORT_MSG_START && m.kind == SAME_TRANSPORT_MSG_START)
+            replace = m.voting_bytes >= c_.pend.voting_bytes;
         else replace = false;
-        if (replace) { pend_ = m; pend_deadline_ = deadline; }
+        if (replace) { c_.pend = m; h_.pend_deadline = deadline; }
     } else {
-        pending_ = true; pend_ = m; pend_deadline_ = deadline;
+        h_.pending = 1; c_.pend = m; h_.pend_deadline = deadline;
     }
 }
-uint32_t Assembler::idle(uint64_t now, MessageResult *msg)
+uint32_t TransportRef::idle(uint64_t now, MessageResult *msg)
 {
     // rx/assembler.rs:205-234
-    if (nhist_ > 2 || (nhist_ && hist_deadline_[0] <= now)) prune_history(now);   // deadlines are pushed in increasing order
-    if (pending_ && pend_deadline_ <= now) {             // PendingResult::poll :336-345
-        *msg = pend_;
-        pending_ = false;
+    if (h_.nhist > 2 || (h_.nhist && h_.hist_deadline[0] <= now)) prune_history(now);   // deadlines are pushed in increasing order
+    if (h_.pending && h_.pend_deadline <= now) {         // PendingResult::poll :336-345
+        *msg = c_.pend;
+        h_.pending = 0;
         if (msg->kind != SAME_TRANSPORT_MSG_ERR) {
-            have_prev_ = true; prev_ = *msg; prev_deadline_ = now + max_history_duration();
+            h_.have_prev = 1; c_.prev = *msg; c_.prev_deadline = now + max_history_duration();
         }
         return msg->kind;
     }
-    return nhist_ == 0 ? SAME_TRANSPORT_IDLE : SAME_TRANSPORT_ASSEMBLING;
+    return h_.nhist == 0 ? SAME_TRANSPORT_IDLE : SAME_TRANSPORT_ASSEMBLING;
 }
-uint32_t Assembler::assemble(const uint8_t *burst, size_t n, uint64_t now, MessageResult *msg)
+uint32_t TransportRef::assemble(const uint8_t *burst, size_t n, uint64_t now, MessageResult *msg)
 {
     // rx/assembler.rs:154-184
     if (n == 0) return idle(now, msg);
     prune_history(now);
-    if (have_prev_ && prev_deadline_ <= now) have_prev_ = false;   // prune_previous :371-376
-    hist_deadline_[nhist_] = now + max_history_duration();
-    BurstBuf &t = history_[nhist_++];                               // at most 2 survive the prune
+    if (h_.have_prev && c_.prev_deadline <= now) h_.have_prev = 0;   // prune_previous :371-376
+    h_.hist_deadline[h_.nhist] = now + max_history_duration();
+    BurstBuf &t = c_.history[h_.nhist++];                           // at most 2 survive the prune
     t.len = (uint32_t)std::min(n, kMaxMessageLength);
     std::memcpy(t.data, burst, t.len);
     MessageResult res;
-    if (combine(history_, nhist_, &res)) {
+    if (combine(c_.history, h_.nhist, &res)) {
         // deduplicate :245-265: messages are duplicates when string-equal
         bool keep = true;
-        if (res.kind != SAME_TRANSPORT_MSG_ERR && have_prev_ && prev_.same_text(res)) keep = false;
+        if (res.kind != SAME_TRANSPORT_MSG_ERR && h_.have_prev && c_.prev.same_text(res)) keep = false;
         if (keep) accept(res, now);
     }
     return idle(now, msg);
 }
 
-void Transport::reset()
+void TransportRef::reset()
 {
-    asm_.reset();
-    state_kind_ = SAME_TRANSPORT_IDLE; clear_result(&state_msg_);
-    have_force_eom_ = false; dirty_ = true;
-    have_polled_ = false; last_polled_symbol_ = 0;
+    h_.nhist = 0; h_.pending = 0; h_.have_prev = 0;
+    h_.state_kind = SAME_TRANSPORT_IDLE; clear_result(&c_.state_msg);
+    h_.have_force_eom = 0; h_.dirty = 1;
+    h_.have_polled = 0; h_.last_polled_symbol = 0;
 }
 
-bool Transport::on_link_event(uint32_t kind, uint64_t sample_counter, uint64_t symbol_count,
-                              const uint8_t *bytes, uint32_t len, uint32_t input_rate, same_rx_event *out)
+bool TransportRef::on_link_event(uint32_t kind, uint64_t sample_counter, uint64_t symbol_count,
+                                 const uint8_t *bytes, uint32_t len, uint32_t input_rate, same_rx_event *out)
 {
     // process_transportlayer receiver.rs:291-333
     const uint64_t kMaxMessageDurationSecs = 135;        // receiver.rs:496
@@ -245,33 +258,35 @@ bool Transport::on_link_event(uint32_t kind, uint64_t sample_counter, uint64_t s
     // The reference polls once per symbol.  A wake-up tick that lands on the symbol of a link
     // event just handled (e.g. a deadline that expired while the link was Searching is served
     // by the NoCarrier transition itself) must not poll a second time.
-    if (kind == kDevTick && have_polled_ && symbol_count == last_polled_symbol_) return false;
+    if (kind == kDevTick && h_.have_polled && symbol_count == h_.last_polled_symbol) return false;
     if (kind == SAME_LINK_BURST || kind == SAME_LINK_NO_CARRIER || kind == kDevTick) {
-        have_polled_ = true; last_polled_symbol_ = symbol_count;
+        h_.have_polled = 1; h_.last_polled_symbol = symbol_count;
     }
     if (kind == SAME_LINK_BURST) {
-        st = asm_.assemble(bytes, len, symbol_count, &msg);
+        st = assemble(bytes, len, symbol_count, &msg);
     } else if (kind == SAME_LINK_NO_CARRIER || kind == kDevTick) {
-        if (have_force_eom_ && sample_counter > force_eom_at_) {
+        if (h_.have_force_eom && sample_counter > h_.force_eom_at) {
             st = SAME_TRANSPORT_MSG_END; clear_result(&msg); msg.kind = st;
         } else {
-            st = asm_.idle(symbol_count, &msg);
+            st = idle(symbol_count, &msg);
         }
     } else {
         return false;
     }
     if (st == SAME_TRANSPORT_MSG_START) {
-        have_force_eom_ = true; dirty_ = true;
-        force_eom_at_ = sample_counter + kMaxMessageDurationSecs * (uint64_t)input_rate;
+        h_.have_force_eom = 1; h_.dirty = 1;
+        h_.force_eom_at = sample_counter + kMaxMessageDurationSecs * (uint64_t)input_rate;
     } else if (st == SAME_TRANSPORT_MSG_END) {
-        if (have_force_eom_) dirty_ = true;
-        have_force_eom_ = false;
+        if (h_.have_force_eom) h_.dirty = 1;
+        h_.have_force_eom = 0;
     }
     const bool is_msg = st >= SAME_TRANSPORT_MSG_START;
-    const bool same = (st == state_kind_) && (!is_msg || msg == state_msg_);
+    // (the message text is compared, and the cold record touched, only between two message states)
+    const bool same = (st == h_.state_kind) && (!is_msg || msg == c_.state_msg);
     if (same) return false;
-    state_kind_ = st;
-    if (is_msg) state_msg_ = msg; else clear_result(&state_msg_);
+    const bool was_msg = h_.state_kind >= SAME_TRANSPORT_MSG_START;
+    h_.state_kind = st;
+    if (is_msg) c_.state_msg = msg; else if (was_msg) clear_result(&c_.state_msg);
     std::memset(out, 0, sizeof(*out));          // payload bytes past `len` are zero, never stack contents
     out->kind = st;
     out->sample_counter = sample_counter;

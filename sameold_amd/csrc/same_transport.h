@@ -43,6 +43,15 @@ struct MessageResult {
     uint32_t len = 0;                // header length for StartOfMessage
     uint32_t offset_time = 0, parity_errors = 0, voting_bytes = 0;
     char text[kMaxMessageLength + 4];
+    // (copies move the header fields and the `len` bytes of text that are live, not the 272-byte buffer: a burst makes five of them)
+    MessageResult() = default;
+    MessageResult(const MessageResult &o) { *this = o; }
+    MessageResult &operator=(const MessageResult &o)
+    {
+        kind = o.kind; err = o.err; len = o.len; offset_time = o.offset_time; parity_errors = o.parity_errors; voting_bytes = o.voting_bytes;
+        if (o.len) std::memcpy(text, o.text, o.len <= sizeof(text) ? o.len : sizeof(text));
+        return *this;
+    }
     bool operator==(const MessageResult &o) const
     {
         return kind == o.kind && err == o.err && len == o.len && offset_time == o.offset_time &&
@@ -61,56 +70,80 @@ struct MessageResult {
 
 // one burst as the assembler keeps it (truncated to MAX_MESSAGE_LENGTH, rx/assembler.rs:163-169); its deadline lives beside
 // the assembler's other scalars
-struct BurstBuf { uint32_t len = 0; uint8_t data[kMaxMessageLength]; };
+struct BurstBuf {
+    uint32_t len = 0; uint8_t data[kMaxMessageLength];
+    BurstBuf() = default;
+    BurstBuf(const BurstBuf &o) { *this = o; }
+    BurstBuf &operator=(const BurstBuf &o) { len = o.len; if (o.len) std::memcpy(data, o.data, o.len <= sizeof(data) ? o.len : sizeof(data)); return *this; }
+};
 
 // combine() rx/combiner.rs:32-80 over up to three bursts; false = None
 bool combine(const BurstBuf *bursts, uint32_t n, MessageResult *out);
 
-// Assembler rx/assembler.rs:108-266.
-// Layout: a batch keeps one of these per channel (1.8 KB each, 60 MB for a 32 768-channel shard) and walks them once per
-// launch, so every cache line a poll touches is a DRAM miss.  What an idle poll reads -- the counts, flags and deadlines --
-// therefore sits together at the front (one line with the Transport's own scalars); the burst bytes and message texts
-// behind it are only touched when a burst arrives or a message is due.
-class Assembler {
-public:
-    void reset();
-    // both return the TransportState kind and fill *msg for Message states
-    uint32_t assemble(const uint8_t *burst, size_t n, uint64_t symbol_count, MessageResult *msg);
-    uint32_t idle(uint64_t symbol_count, MessageResult *msg);
-
-private:
-    void prune_history(uint64_t now);
-    void accept(const MessageResult &m, uint64_t now);
-    uint32_t nhist_ = 0;                           // VecDeque<TimedData<Burst>>, oldest first: history_[i] until hist_deadline_[i]
-    bool pending_ = false, have_prev_ = false;
-    uint64_t hist_deadline_[3] = {0, 0, 0};
-    uint64_t pend_deadline_ = 0, prev_deadline_ = 0;
-    BurstBuf history_[3];
-    MessageResult pend_, prev_;
+// Assembler rx/assembler.rs:108-266 and the per-channel transport state of SameReceiver (receiver.rs:79, 85, 89, 291-333).
+//
+// Layout (round 5): a batch keeps the transport state of every channel and walks it once per launch -- four events per channel
+// and launch at the configs[3] shard.  As one 1.8 KB object per channel (60 MB for 32 768 channels) every poll was a DRAM miss on
+// a page of its own: 13.8 CPU-ms per launch, 10.8 of them here.  Now the state is TWO arrays: a HOT record of exactly one cache
+// line per channel -- everything a poll that changes nothing reads or writes: state kind, flags, the forced-EOM instant, the last
+// polled symbol, the burst history's and the pending message's deadlines -- 2 MB for 32 768 channels, which stays in the cache
+// from launch to launch; and a COLD record (burst bytes, message texts) touched only when a burst arrives, a message is due or
+// a message state ends.
+struct TransportHot {
+    uint32_t state_kind = SAME_TRANSPORT_IDLE;
+    uint8_t have_force_eom = 0, dirty = 0, have_polled = 0;          // Transport
+    uint8_t nhist = 0, pending = 0, have_prev = 0;                   // Assembler: VecDeque<TimedData<Burst>> length, PendingResult, previous message
+    uint8_t pad_[2] = {0, 0};
+    uint64_t force_eom_at = 0;
+    uint64_t last_polled_symbol = 0;
+    uint64_t hist_deadline[3] = {0, 0, 0};                           // history[i] until hist_deadline[i], oldest first
+    uint64_t pend_deadline = 0;
+};
+static_assert(sizeof(TransportHot) == 64, "one cache line per channel");
+struct TransportCold {
+    uint64_t prev_deadline = 0;
+    BurstBuf history[3];
+    MessageResult pend, prev, state_msg;
 };
 
-// per-channel transport state of SameReceiver (receiver.rs:79, 85, 89, 291-333)
-class Transport {
+// The operations on one channel's (hot, cold) pair
+class TransportRef {
 public:
+    TransportRef(TransportHot &h, TransportCold &c) : h_(h), c_(c) {}
     void reset();
     // Feed one device event (link event or tick) of this channel, in order.  Returns true
     // and fills *out when the transport state changed (receiver.rs:256-265).
     bool on_link_event(uint32_t kind, uint64_t sample_counter, uint64_t symbol_count,
                        const uint8_t *bytes, uint32_t len, uint32_t input_rate, same_rx_event *out);
     // force_eom_at_sample (receiver.rs:89): 0 = None
-    uint64_t force_eom_at() const { return have_force_eom_ ? force_eom_at_ : 0; }
-    bool force_eom_dirty() { bool d = dirty_; dirty_ = false; return d; }
+    uint64_t force_eom_at() const { return h_.have_force_eom ? h_.force_eom_at : 0; }
+    bool force_eom_dirty() { const bool d = h_.dirty != 0; h_.dirty = 0; return d; }
+
+private:
+    // Assembler: both return the TransportState kind and fill *msg for Message states
+    uint32_t assemble(const uint8_t *burst, size_t n, uint64_t symbol_count, MessageResult *msg);
+    uint32_t idle(uint64_t symbol_count, MessageResult *msg);
+    void prune_history(uint64_t now);
+    void accept(const MessageResult &m, uint64_t now);
+    TransportHot &h_;
+    TransportCold &c_;
+};
+
+// One channel's transport state as an object of its own (the single-channel receiver, tests)
+class Transport {
+public:
+    void reset() { ref().reset(); }
+    bool on_link_event(uint32_t kind, uint64_t sample_counter, uint64_t symbol_count,
+                       const uint8_t *bytes, uint32_t len, uint32_t input_rate, same_rx_event *out)
+    { return ref().on_link_event(kind, sample_counter, symbol_count, bytes, len, input_rate, out); }
+    uint64_t force_eom_at() const { return hot_.have_force_eom ? hot_.force_eom_at : 0; }
+    bool force_eom_dirty() { return ref().force_eom_dirty(); }
     void set_input_sample_counter_bias(int64_t) {}
 
 private:
-    uint32_t state_kind_ = SAME_TRANSPORT_IDLE;
-    bool have_force_eom_ = false;
-    bool dirty_ = false;
-    bool have_polled_ = false;
-    uint64_t force_eom_at_ = 0;
-    uint64_t last_polled_symbol_ = 0;
-    Assembler asm_;
-    MessageResult state_msg_;
+    TransportRef ref() { return TransportRef(hot_, cold_); }
+    TransportHot hot_;
+    TransportCold cold_;
 };
 
 
