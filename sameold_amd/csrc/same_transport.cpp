@@ -121,7 +121,47 @@ bool combine(const BurstBuf *bursts, uint32_t nbursts, MessageResult *res)
     size_t common = kMaxMessageLength;
     for (size_t i = 0; i < nb; ++i) common = std::min<size_t>(common, bursts[i].len);
     bool stopped = false;
-    if (nb == 3) {
+    // Eight bytes at a time where all bursts still have bytes: the bit votes of rx/combiner.rs:216-249 are bitwise, so they
+    // hold for a word as for a byte (majority = (a & b) | (c & (a | b)); a position is in error where the bursts do not all
+    // agree), the per-byte error counts are a byte-wise population count; only the allowed-character test looks at bytes.
+    // (81 % of the transport layer's time was the byte loop below: profiles/r05_host_step_probe.txt.)
+    if (nb >= 2) {
+        constexpr uint64_t k7f = 0x7f7f7f7f7f7f7f7full, k01 = 0x0101010101010101ull;
+        auto bytes_popcount = [](uint64_t x) {
+            x = x - ((x >> 1) & 0x5555555555555555ull);
+            x = (x & 0x3333333333333333ull) + ((x >> 2) & 0x3333333333333333ull);
+            return (x + (x >> 4)) & 0x0f0f0f0f0f0f0f0full;
+        };
+        for (; n + 8 <= common; n += 8) {
+            uint64_t a, b, c = 0, est, dis, hi;
+            std::memcpy(&a, bursts[0].data + n, 8); std::memcpy(&b, bursts[1].data + n, 8);
+            if (nb == 3) {
+                std::memcpy(&c, bursts[2].data + n, 8);
+                hi = ((a | b | c) >> 7) & k01;
+                a &= k7f; b &= k7f; c &= k7f;
+                est = (a & b) | (c & (a | b));               // bit_vote_correct
+                dis = (a ^ b) | (b ^ c);
+            } else {
+                hi = ((a | b) >> 7) & k01;
+                a &= k7f; b &= k7f;
+                dis = a ^ b;                                   // bit_vote_detect: the byte where the two agree, else 0
+                const uint64_t nz = (((dis + k7f) | dis) >> 7) & k01;       // 1 in every byte that differs
+                est = a & ~(nz * 0xffull);
+            }
+            const uint64_t er = bytes_popcount(dis) + hi;
+            uint8_t e8[8], r8[8];
+            std::memcpy(e8, &est, 8); std::memcpy(r8, &er, 8);
+            int j = 0;
+            for (; j < 8; ++j) {
+                if (!kAllowed.ok[e8[j]]) break;
+                msg[n + j] = e8[j]; cnt[n + j] = (uint8_t)nb; errs[n + j] = r8[j];
+            }
+            if (j < 8) { n += (size_t)j; stopped = true; break; }
+        }
+    }
+    if (stopped) {
+        // (a character that is not allowed ends the message: rx/combiner.rs:176-180)
+    } else if (nb == 3) {
         const uint8_t *a = bursts[0].data, *b = bursts[1].data, *c = bursts[2].data;
         for (; n < common; ++n) {
             const uint8_t x = a[n], y = b[n], z = c[n];

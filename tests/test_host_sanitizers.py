@@ -95,3 +95,20 @@ def test_synthesised_transport_polls_reproduce_the_golden_transport_events(drive
     assert [(k, x) for k, _, x in got] == [(k, x) for k, _, x in want]
     tol = 6 * 22050 / 520.83
     assert all(abs(a[1] - b[1]) <= tol for a, b in zip(got, want)), [(a[1], b[1]) for a, b in zip(got, want)]
+
+
+def test_combine_equals_the_byte_walk(tmp_path):
+    """same::combine -- word-wide bit voting (eight bytes at a time), stretches specialised by burst count -- against the plain
+    byte-by-byte walk of rx/combiner.rs:32-80, 154-203 on 200 000 random burst sets (bit errors, high bits, garbage bytes, ragged
+    lengths), under ASan + UBSan."""
+    cxx = shutil.which("g++")
+    if not cxx:
+        pytest.skip("g++ not found")
+    out = str(tmp_path / "combine_fuzz")
+    cmd = [cxx, "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-Wall",
+           os.path.join(ROOT, "tests", "helpers", "combine_fuzz.cpp"), os.path.join(CSRC, "same_transport.cpp"), "-o", out]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-4000:]
+    r = subprocess.run([out, "200000"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "cases equal" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
+    assert "runtime error" not in r.stderr and "AddressSanitizer" not in r.stderr, r.stderr[-4000:]
