@@ -259,8 +259,10 @@ size_t same_batch_pending_events(same_batch *rx);
  * same_batch_drop_events then removes the first n of them (n <= *n of the last peek).  For consumers that
  * scan the queue once and keep only the few events they care about (the bursts, say).  The handle queues
  * compact 48-byte records; the first peek after new events arrived builds the 328-byte same_rx_event array
- * (O(queue), on up to 8 threads), later peeks re-use it as long as events were only dropped; the array is
- * released when the queue runs empty. */
+ * (O(queue), on up to 8 threads), later peeks re-use it as long as events were only dropped.  The array is
+ * not kept for the handle's life: once the queue has run empty it is released by the first call that ends the
+ * view's life anyway (poll, peek, process, sync, reset) -- never by same_batch_drop_events itself, so
+ * "peek, drop everything, finish reading the view" is safe. */
 int same_batch_peek_events(same_batch *rx, const same_rx_event **events, size_t *n);
 int same_batch_drop_events(same_batch *rx, size_t n);
 /* The queued SAME_LINK_BURST events as fixed 304-byte records, in queue order: u32 channel +

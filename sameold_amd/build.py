@@ -88,20 +88,39 @@ def build(force: bool = False, verbose: bool = False) -> str:
     bdir = os.path.join(HERE, "build")
     os.makedirs(bdir, exist_ok=True)
     procs = []
+    # Objects are re-used when nothing they are made of changed: the key is the source, every header (any of them may be
+    # included) and the flags; only same_batch.cpp carries the library-wide source hash (same_rx_source_hash()).
+    hdr = hashlib.sha256()
+    for f in sorted(HEADERS):
+        with open(os.path.join(CSRC, f), "rb") as fh:
+            hdr.update(f.encode() + b"\0" + fh.read() + b"\0")
+    hdr.update(" ".join(flags()).encode())
     for src in SOURCES:
         obj = os.path.join(bdir, os.path.splitext(src)[0] + ".o")
-        cmd = [cc] + flags() + [f'-DSAME_SOURCE_HASH="{digest}"', "-c", os.path.join(CSRC, src), "-o", obj]
+        objs.append(obj)
+        extra = [f'-DSAME_SOURCE_HASH="{digest}"'] if src == "same_batch.cpp" else []
+        with open(os.path.join(CSRC, src), "rb") as fh:
+            key = hashlib.sha256(hdr.digest() + fh.read() + " ".join(extra).encode()).hexdigest()
+        stamp = obj + ".key"
+        if not force and os.path.exists(obj) and os.path.exists(stamp) and open(stamp).read() == key:
+            continue
+        cmd = [cc] + flags() + extra + ["-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd))
-        procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
-        objs.append(obj)
-    for src, p in procs:
+        procs.append((src, stamp, key, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+    failed = None
+    for src, stamp, key, p in procs:
         out, _ = p.communicate()
         if p.returncode != 0:
             sys.stderr.write(out.decode(errors="replace"))
-            raise RuntimeError(f"hipcc failed on {src}")
+            failed = failed or src
+            continue
+        with open(stamp, "w") as fh:
+            fh.write(key)
         if verbose and out:
             print(out.decode(errors="replace"))
+    if failed:
+        raise RuntimeError(f"hipcc failed on {failed}")
     cmd = [cc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB] + objs
     subprocess.run(cmd, check=True)
     cxx = shutil.which("g++") or cc

@@ -299,6 +299,7 @@ struct same_batch {
     ByteArena arena;                    // their payload bytes
     std::vector<same_rx_event> peeked;  // same_batch_peek_events: the queued events, materialised (328 bytes each) ...
     bool peeked_valid = false;          // ... and whether it still mirrors queue[peeked_head ..) (a harvest appends: invalid)
+    bool peeked_release = false;        // the queue ran empty under same_batch_drop_events: the caller may still be reading the view; freed by the next call that ends its life
     size_t peeked_head = 0;
     std::vector<size_t> burst_seq;      // event numbers (EventQueue::base + index) of the queued SAME_LINK_BURST events, ascending
     size_t burst_seq_head = 0;          // entries before this one have been polled or dropped
@@ -311,6 +312,8 @@ struct same_batch {
     same::TransportRef tr(uint32_t c) { return same::TransportRef(thot[c], tcold[c]); }
     uint64_t *h_wake = nullptr;      // host mirror of State::wake_sample (pinned, n_channels words, zero = unarmed)
 };
+
+static void release_stale_view(same_batch *rx);
 
 namespace {
 
@@ -746,6 +749,7 @@ int harvest_host(same_batch *rx, same_batch::Slot &sl, uint32_t n_events, uint32
     // a consumer that always polls less than is pending never drains the queue: reclaim the polled
     // prefix once it is at least as large as what is still waiting (amortised O(1) per event)
     rx->peeked_valid = false;                 // (the queue is about to move and grow: a materialised view of it is stale)
+    release_stale_view(rx);
     if (rx->queue_head && rx->queue_head >= rx->queue.size() - rx->queue_head) {
         rx->queue_head = rx->queue.compact(rx->queue_head);
         // ... and the payload bytes in front of the first record that is still queued
@@ -1600,6 +1604,8 @@ int same_batch_reset(same_batch *rx)
     rx->counter = 0;
     rx->queue.clear(); rx->queue_head = 0;   // event_queue.clear() receiver.rs:194
     rx->arena.clear();
+    rx->peeked_valid = false; rx->peeked_release = false; rx->peeked_head = 0;
+    std::vector<same_rx_event>().swap(rx->peeked);
     rx->burst_seq.clear(); rx->burst_seq_head = 0;
     for (uint32_t c = 0; c < (uint32_t)rx->thot.size(); ++c) rx->tr(c).reset();
     for (auto &o : rx->tp.sym_off) o = 0;
@@ -1673,17 +1679,28 @@ size_t same_batch_pending_events(same_batch *rx)
     return rx->queue.size() - rx->queue_head;
 }
 
+// The view same_batch_peek_events handed out is tens of MB for a large queue and is not kept for the handle's life -- but the
+// header promises it stays readable across same_batch_drop_events, so a drop that empties the queue only marks it; the next
+// call that ends the view's life anyway (poll, peek, a harvest, reset) lets the memory go.
+static void release_stale_view(same_batch *rx)
+{
+    if (!rx->peeked_release) return;
+    rx->peeked_release = false;
+    if (!rx->peeked_valid) std::vector<same_rx_event>().swap(rx->peeked);
+}
 // the queue is empty: nothing refers to the arena any more
-static void queue_emptied(same_batch *rx)
+static void queue_emptied(same_batch *rx, bool view_may_be_read = false)
 {
     rx->queue.clear(); rx->queue_head = 0; rx->arena.clear();
     rx->peeked_valid = false; rx->peeked_head = 0;
-    std::vector<same_rx_event>().swap(rx->peeked);        // (the view of a large queue is tens of MB: not kept for the handle's life)
+    if (view_may_be_read) rx->peeked_release = true;
+    else { rx->peeked_release = false; std::vector<same_rx_event>().swap(rx->peeked); }
 }
 
 int same_batch_poll_events(same_batch *rx, same_rx_event *out, size_t cap, size_t *n_out, size_t *n_left)
 {
     if (!rx || (!out && cap)) return fail(SAME_EINVAL, "null argument");
+    release_stale_view(rx);
     const size_t avail = rx->queue.size() - rx->queue_head;
     const size_t n = std::min(cap, avail);
     const QEvent *q = rx->queue.data() + rx->queue_head;
@@ -1710,6 +1727,7 @@ int same_batch_peek_events(same_batch *rx, const same_rx_event **events, size_t 
     if (!rx || !events || !n) return fail(SAME_EINVAL, "null argument");
     // (the queue holds compact records: the view is made here, and stays valid as the header promises -- until the next
     // call on this handle other than same_batch_pending_events / same_batch_drop_events)
+    release_stale_view(rx);
     const size_t avail = rx->queue.size() - rx->queue_head;
     if (rx->peeked_valid && rx->peeked_head == rx->queue_head && rx->peeked.size() == avail) {     // (nothing was queued or dropped since)
         *n = avail; *events = avail ? rx->peeked.data() : nullptr;
@@ -1748,7 +1766,7 @@ int same_batch_drop_events(same_batch *rx, size_t n)
     if (!rx) return fail(SAME_EINVAL, "null argument");
     if (n > rx->queue.size() - rx->queue_head) return fail(SAME_EINVAL, "more events than are queued");
     rx->queue_head += n;
-    if (rx->queue_head == rx->queue.size()) queue_emptied(rx);
+    if (rx->queue_head == rx->queue.size()) queue_emptied(rx, /*view_may_be_read=*/true);
     return SAME_OK;
 }
 

@@ -825,6 +825,11 @@ __global__ __launch_bounds__(kSymHalves * kSymRoles * kWave, 3) void demod_sym_k
     // for the compiler to see -- was 1 % faster with the link layer alone and 7 % slower with the transport layer on: not kept.)
     const uint32_t prog_idx = lane < (uint32_t)kSymRoles ? lane : 0u;
     uint32_t *const err_flags = fresh_output().n_events + 2;
+    // A wait that gives up (a protocol error: the launch reports SAME_EKERNEL instead of hanging the GPU) makes every later wait
+    // of its wavefront give up after a few polls -- the call is void, and ~27 000 steps of three waits at half a second each
+    // would be hours -- and the wavefront skips its state stores (`gave_up()`); the roles that wait for it follow the same way.
+    uint32_t spin_limit = 1u << 22;
+    auto gave_up = [&]() __attribute__((always_inline)) -> bool { return spin_limit != (1u << 22); };
     auto wait_for = [&](uint32_t s, uint32_t deps, uint32_t *w_y1, uint32_t *w_y2, auto nap_) __attribute__((always_inline)) {
         constexpr int NAP = decltype(nap_)::value;
         uint32_t v, spins = 0;
@@ -833,17 +838,22 @@ __global__ __launch_bounds__(kSymHalves * kSymRoles * kWave, 3) void demod_sym_k
             const uint32_t ok = (uint32_t)__builtin_amdgcn_ballot_w64(v >= (s << 16));     // (the flags below bit 16 cannot carry)
             if ((ok & deps) == deps) break;
             __builtin_amdgcn_s_sleep(NAP);
-            // (bounded: a protocol error ends in an error code, not in a hung GPU)
-            if (++spins > (1u << 22)) { if (lane == 0u) atomicOr(err_flags, 4u); break; }
+            if (++spins > spin_limit) { if (lane == 0u) atomicOr(err_flags, 4u); spin_limit = 8u; break; }
         }
+        // (the ordering of the roles' LDS traffic rests on these words: nothing the wait guards may be read before it -- the
+        // compiler may move plain accesses across volatile ones, and the step barrier whose clobber used to stop it is gone)
+        asm volatile("" ::: "memory");
         *w_y1 = (uint32_t)__builtin_amdgcn_readlane((int)v, 4);
         *w_y2 = (uint32_t)__builtin_amdgcn_readlane((int)v, 5);
     };
     constexpr std::integral_constant<int, 1> kNapShort{};
     constexpr std::integral_constant<int, 4> kNapLong{};
-    // flags of step s - 1 in a progress word read at the start of step s (its writer may be one step further: two parities)
+    // flags of step s - 1 in a progress word read at the start of step s.  Two parities: its writer may be ONE step further, never
+    // two -- every reader of a role's flags is among the roles that role waits for before it publishes (S, T, A, E wait for Y2 and
+    // Y2 for all of them; S, E wait for Y1 and Y1 for both)
     auto flags_of_last = [&](uint32_t w, uint32_t s) __attribute__((always_inline)) -> uint32_t { return s == 0u ? 0u : (w >> (8u * ((s - 1u) & 1u))) & 0xffu; };
     auto publish = [&](uint32_t s, uint32_t flags, uint32_t flags_before) __attribute__((always_inline)) {
+        asm volatile("" ::: "memory");                                 // (... and nothing the step wrote may sink below its progress word)
         if (lane == 0u) prog[role] = ((s + 1u) << 16) | (flags << (8u * (s & 1u))) | (flags_before << (8u * ((s + 1u) & 1u)));
     };
     enum : uint32_t { R_S = 1u, R_T = 2u, R_A = 4u, R_E = 8u, R_Y1 = 16u, R_Y2 = 32u };
@@ -900,7 +910,7 @@ __global__ __launch_bounds__(kSymHalves * kSymRoles * kWave, 3) void demod_sym_k
             if (s == stop_at) { left = true; break; }
         }
         SYM_REPORT(0);
-        if (left) return;                                              // handed over: this chunk's state is not needed
+        if (left || gave_up()) return;                                              // handed over: this chunk's state is not needed
         { const State S = fresh_state(); M.store(P, S, c, C, counter1, wcol); }
     } else if (role == 1u) {
         // ------------------------------------------ T: input prefetch and DC blocker of block s + 1 --------------------
@@ -961,7 +971,7 @@ __global__ __launch_bounds__(kSymHalves * kSymRoles * kWave, 3) void demod_sym_k
             if (!left && s + 1u < n_steps) left = step(s + 1u, std::integral_constant<int, 0>{});
         }
         SYM_REPORT(1);
-        if (left) return;
+        if (left || gave_up()) return;
         { const State S = fresh_state(); D.store(S, c, C, counter1); }
     } else if (role == 2u) {
         // ------------------------------------------ A: the matched-filter pair at the FIRST instant of the step's symbol; link events + wake-ups ----
@@ -1031,7 +1041,7 @@ __global__ __launch_bounds__(kSymHalves * kSymRoles * kWave, 3) void demod_sym_k
         }
         SYM_REPORT(2);
         X.retire(O, lane, kWave);
-        if (left) return;
+        if (left || gave_up()) return;
         {
             const State S = fresh_state();
             S.tk_next[c] = L.tk_next; S.tk_last[c] = L.tk_last; S.wake_fired[c] = L.wake_fired;
@@ -1086,8 +1096,9 @@ __global__ __launch_bounds__(kSymHalves * kSymRoles * kWave, 3) void demod_sym_k
                     uint32_t spins = 0;
                     while ((int32_t)(seqbox[0] - seq) < 0) {
                         __builtin_amdgcn_s_sleep(1);
-                        if (++spins > (1u << 22)) { if (lane == 0u) atomicOr(err_flags, 4u); break; }
+                        if (++spins > spin_limit) { if (lane == 0u) atomicOr(err_flags, 4u); spin_limit = 8u; break; }
                     }
+                    asm volatile("" ::: "memory");
                     sa1 = __uint_as_float(sabox[lane]);
                 }
                 SYM_T_LAP(24);
@@ -1184,7 +1195,7 @@ __global__ __launch_bounds__(kSymHalves * kSymRoles * kWave, 3) void demod_sym_k
         }
         SYM_REPORT(3);
         SYM_T_REPORT();
-        if (left) return;
+        if (left || gave_up()) return;
         L.ted_clock = (uint32_t)((int)cstar_f - rel - 1);
         {
             const State S = fresh_state();
@@ -1232,7 +1243,10 @@ __global__ __launch_bounds__(kSymHalves * kSymRoles * kWave, 3) void demod_sym_k
         for (uint32_t s = 0; s < n_steps; ++s) {
             uint32_t w1, w2;
             SYM_TRACE(4, s, 0);
-            wait_for(s, R_E | R_Y2, &w1, &w2, kNapShort);                         // E's symbols, Y2's feedback (and Y2 is done with the word box)
+            // E's symbols, Y2's feedback (and Y2 is done with the word box); and S, which reads this role's flags of step s - 1 from the
+            // parity byte that publishing step s + 1 overwrites: without it nothing but timing kept Y1 within one step of S (Y1(s + 1)
+            // needs E(s) and Y2(s), Y2(s) only S(s - 1)), and a lock or unlock posted in step s - 1 could be lost.  S runs ahead: free.
+            wait_for(s, R_E | R_Y2 | R_S, &w1, &w2, kNapShort);
             SYM_TRACE(4, s, 1);
             P3_LAP(p3_wait);
             const uint32_t f2 = flags_of_last(w2, s);
@@ -1286,7 +1300,7 @@ __global__ __launch_bounds__(kSymHalves * kSymRoles * kWave, 3) void demod_sym_k
             if (s == stop_at) { left = true; break; }
         }
         SYM_REPORT(4);
-        if (left) return;
+        if (left || gave_up()) return;
         const State S = fresh_state();
         S.sq_data[c] = Q.L.sq_data; S.sq_power[c] = Q.L.sq_power; S.sq_phist[c] = Q.L.sq_phist;
         S.sq_fill[c] = Q.L.sq_fill; S.sq_clock[c] = Q.L.sq_clock; S.sq_symbols[c] = symbols0 + (uint64_t)(Q.nsym - (uint32_t)symbols0);
@@ -1396,10 +1410,11 @@ __global__ __launch_bounds__(kSymHalves * kSymRoles * kWave, 3) void demod_sym_k
         SYM_REPORT(5);
         SYM_COUNT(18, 1);                                              // launches of the reporting group ...
         SYM_COUNT(19, left ? stop_at + 1u : n_steps);                  // ... and the steps they ran
-        if (left) return;
+        if (left || gave_up()) return;
         // E's TED phase, A's wake-up flag, Y1's locks and equalizer bits: written before their last step was published
         uint32_t w1, w2;
         wait_for(n_steps, R_A | R_E | R_Y1, &w1, &w2, kNapShort);
+        if (gave_up()) return;
         const uint32_t flags_out = (F.st << F_FR_STATE_SHIFT) | (F.last << F_LINK_SHIFT) | (phasebox[lane] & F_TED_PHASE) | (againbox[lane] & F_TICK_AGAIN) | flagbox[lane];
         const State S1 = fresh_state();
         S1.fr_word[c] = F.word; S1.fr_count[c] = F.count; S1.fr_invalid[c] = F.invalid;

@@ -89,7 +89,7 @@ bool combine(const BurstBuf *bursts, uint32_t n, MessageResult *out);
 // polled symbol, the burst history's and the pending message's deadlines -- 2 MB for 32 768 channels, which stays in the cache
 // from launch to launch; and a COLD record (burst bytes, message texts) touched only when a burst arrives, a message is due or
 // a message state ends.
-struct TransportHot {
+struct alignas(64) TransportHot {      // (C++17 aligned new: std::vector honours it, so a record never straddles two lines)
     uint32_t state_kind = SAME_TRANSPORT_IDLE;
     uint8_t have_force_eom = 0, dirty = 0, have_polled = 0;          // Transport
     uint8_t nhist = 0, pending = 0, have_prev = 0;                   // Assembler: VecDeque<TimedData<Burst>> length, PendingResult, previous message
@@ -99,7 +99,7 @@ struct TransportHot {
     uint64_t hist_deadline[3] = {0, 0, 0};                           // history[i] until hist_deadline[i], oldest first
     uint64_t pend_deadline = 0;
 };
-static_assert(sizeof(TransportHot) == 64, "one cache line per channel");
+static_assert(sizeof(TransportHot) == 64 && alignof(TransportHot) == 64, "one cache line per channel");
 struct TransportCold {
     uint64_t prev_deadline = 0;
     BurstBuf history[3];

@@ -11,6 +11,13 @@ for row, then writes the rows.
 --batches N runs N such batches on consecutive trial ids and adds the tallies up (16 x 65 536 = the 1 M trials of
 configs[4]); --relaxed also demodulates every batch with SAME_BATCH_RELAXED and files its tally beside the two (that
 mode's contract is statistical under noise: its curve is printed, not asserted equal).
+
+--rate 22050|44100|48000 and --kernel auto|pipe|fast|generic (round 6): every STRICT kernel family soaked the way the one
+replay bug of round 5 was found -- the wavefront pipeline at each rate (batches of at most 32 768 trials at 44.1 / 48 kHz, where
+the dispatch sends anything larger to the one-wavefront kernel), demod_fast_kernel (SAME_PIPE=0, or any 22.05 kHz batch beyond
+65 536 trials) and the generic kernel (SAME_BATCH_GENERIC_KERNEL).  The kernel that ran is asserted and filed.
+
+    python tests/helpers/ber_vs_oracle.py --rate 48000 --kernel pipe --trials 32768 --batches 8 --out profiles/r06_ber_vs_oracle_48k.json
 """
 import argparse
 import json
@@ -26,7 +33,10 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.dirname(HERE))
 
 
-def run(trials=65536, rate=22050, seconds=2.0, seed=2026, grid=15, first_trial=0, slab=4096, relaxed=False):
+KERNELS = {"pipe": "demod_pipe_kernel", "fast": "demod_fast_kernel", "generic": "demod_kernel<B="}
+
+
+def run(trials=65536, rate=22050, seconds=2.0, seed=2026, grid=15, first_trial=0, slab=4096, relaxed=False, kernel="auto"):
     import torch
     import sameold_amd as sa
     from sameold_amd import montecarlo as mc
@@ -38,10 +48,25 @@ def run(trials=65536, rate=22050, seconds=2.0, seed=2026, grid=15, first_trial=0
     n_samples -= n_samples % 16
     t0 = time.perf_counter()
     x = mc.synth_trials(trials, first_trial, n_samples, rate, seed, 0.0, 1.0, grid)
-    rx = sa.SameReceiverBuilder(rate).build_batch(trials, link_only=True)
+    # (the library reads its kernel-selection knobs once, when a batch is created)
+    saved = os.environ.get("SAME_PIPE")
+    if kernel in ("pipe", "fast"):
+        os.environ["SAME_PIPE"] = "1" if kernel == "pipe" else "0"
+    try:
+        rx = sa.SameReceiverBuilder(rate).build_batch(trials, link_only=True, generic_kernel=(kernel == "generic"))
+    finally:
+        if kernel in ("pipe", "fast"):
+            if saved is None:
+                del os.environ["SAME_PIPE"]
+            else:
+                os.environ["SAME_PIPE"] = saved
     rx.set_kernel_timing(True)
     rx.process_tensor(x)
     rx.sync()
+    strict_kernel = rx.kernel_name()
+    if kernel != "auto":
+        assert strict_kernel == KERNELS[kernel] or (kernel == "generic" and strict_kernel.startswith(KERNELS[kernel])), \
+            f"asked for {KERNELS[kernel]}, the batch ran {strict_kernel}"
     ev = rx.poll_events_np()
     t_gpu = time.perf_counter() - t0
     kernel_ms = rx.last_kernel_ms()
@@ -84,7 +109,8 @@ def run(trials=65536, rate=22050, seconds=2.0, seed=2026, grid=15, first_trial=0
         "rows_gpu": mc.summarise(gpu_tally, 0.0, 1.0), "rows_oracle": mc.summarise(cpu_tally, 0.0, 1.0),
         "gpu_seconds_incl_generation": round(t_gpu, 3), "gpu_kernel_ms": round(kernel_ms, 3),
         "oracle_seconds_incl_readback": round(t_cpu, 3), "host_threads": len(os.sched_getaffinity(0)),
-        "_tallies": (gpu_tally, cpu_tally, relaxed_tally), "relaxed_kernel": relaxed_kernel,
+        "_tallies": (gpu_tally, cpu_tally, relaxed_tally), "relaxed_kernel": relaxed_kernel, "strict_kernel": strict_kernel,
+        "samples_per_trial": n_samples,
     }
 
 
@@ -112,22 +138,33 @@ def main():
     ap.add_argument("--seed", type=int, default=2026)
     ap.add_argument("--batches", type=int, default=1)
     ap.add_argument("--relaxed", action="store_true")
+    ap.add_argument("--rate", type=int, default=22050, choices=[22050, 44100, 48000])
+    ap.add_argument("--kernel", default="auto", choices=["auto", "pipe", "fast", "generic"])
     ap.add_argument("--out", default=None)
     a = ap.parse_args()
     from sameold_amd import build as b
     b.build()
     from sameold_amd import montecarlo as mc
     if a.batches <= 1:
-        res = run(a.trials, seed=a.seed, first_trial=a.first_trial, relaxed=a.relaxed)
+        res = run(a.trials, rate=a.rate, seed=a.seed, first_trial=a.first_trial, relaxed=a.relaxed, kernel=a.kernel)
         tallies = res.pop("_tallies")
         if tallies[2] is not None:
             res["rows_relaxed_mode"] = mc.summarise(tallies[2], 0.0, 1.0)
     else:
         total = [None, None, None]
+        failures = []
+        strict_kernel, n_samples, relaxed_kernel = None, 0, None
         n_link = 0
         secs = [0.0, 0.0, 0.0]
         for b in range(a.batches):
-            r = run(a.trials, seed=a.seed, first_trial=a.first_trial + b * a.trials, relaxed=a.relaxed)
+            try:
+                r = run(a.trials, rate=a.rate, seed=a.seed, first_trial=a.first_trial + b * a.trials, relaxed=a.relaxed, kernel=a.kernel)
+            except AssertionError as e:
+                # a soak goes on after a mismatch: every batch that differs is named in the file
+                failures.append({"first_trial": a.first_trial + b * a.trials, "trials": a.trials, "what": str(e)[:400]})
+                print(f"batch {b + 1}/{a.batches}: MISMATCH {e}", file=sys.stderr, flush=True)
+                continue
+            strict_kernel, n_samples = r["strict_kernel"], r["samples_per_trial"]
             for i, t in enumerate(r.pop("_tallies")):
                 if t is None:
                     continue
@@ -140,13 +177,17 @@ def main():
             relaxed_kernel = r.get("relaxed_kernel")
             secs[0] += r["gpu_seconds_incl_generation"]; secs[1] += r["gpu_kernel_ms"]; secs[2] += r["oracle_seconds_incl_readback"]
             print(f"batch {b + 1}/{a.batches}: {r['link_events_compared']} link events equal, tallies equal", file=sys.stderr, flush=True)
+        if total[0] is None:
+            raise SystemExit(f"every batch differed from the oracle: {failures}")
         for k in total[0]:
             assert (total[0][k] == total[1][k]).all()
         n = a.batches * a.trials
         res = {
-            "workload": f"{n} AWGN trials (trial ids {a.first_trial}..{a.first_trial + n - 1}) in {a.batches} batches of {a.trials}, one burst each, 22050 Hz, "
-                        f"44096 samples per trial, Eb/N0 0..14 dB, seed {a.seed}",
-            "link_events_compared": int(n_link), "events_equal": True, "tally_rows_equal": True,
+            "workload": f"{n} AWGN trials (trial ids {a.first_trial}..{a.first_trial + n - 1}) in {a.batches} batches of {a.trials}, one burst each, {a.rate} Hz, "
+                        f"{n_samples} samples per trial, Eb/N0 0..14 dB, seed {a.seed}",
+            "strict_kernel": strict_kernel,
+            "link_events_compared": int(n_link), "events_equal": not failures, "tally_rows_equal": not failures,
+            "batches_that_differ": failures,
             "rows_gpu": mc.summarise(total[0], 0.0, 1.0), "rows_oracle": mc.summarise(total[1], 0.0, 1.0),
             "gpu_seconds_incl_generation": round(secs[0], 3), "gpu_kernel_ms": round(secs[1], 3),
             "oracle_seconds_incl_readback": round(secs[2], 3), "host_threads": len(os.sched_getaffinity(0)),

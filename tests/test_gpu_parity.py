@@ -605,6 +605,10 @@ def test_peek_and_drop_events_equal_poll(sa):
     with pytest.raises(sa.SameError):
         b.drop_events(len(rest) + 1)
     b.drop_events(len(rest))
+    # the header's promise: the view outlives same_batch_drop_events, also the drop that empties the queue (round 5's
+    # build released the array right there: a consumer that peeks, drops everything and then reads read freed memory)
+    assert b.pending_events() == 0
+    assert rest.tobytes() == want[half:].tobytes()
     assert len(b.peek_events_np()) == 0 and len(b.poll_events_np()) == 0
 
 
@@ -974,6 +978,28 @@ def test_awgn_batch_tally_equals_the_oracles(sa, ob):
     assert res["events_equal"] and res["tally_rows_equal"]
     assert res["rows_gpu"] == res["rows_oracle"]
     assert sum(r["trials"] for r in res["rows_gpu"]) == 8192
+
+
+@pytest.mark.parametrize("rate,kernel,trials,batches", [
+    (22050, "pipe", 65536, 1),          # seed 2026, trials 0 .. 65 535: includes trial 15 354, the one round 5's replay bug showed in
+    (48000, "pipe", 32768, 2),          # (at 44.1 / 48 kHz the pipeline takes at most 32 768 channels a launch)
+    (44100, "pipe", 32768, 2),
+    (22050, "fast", 65536, 1),          # demod_fast_kernel: every strict batch beyond 65 536 channels
+    (22050, "generic", 65536, 1),       # the kernel of any configuration and of every call's tail
+])
+def test_awgn_65536_trials_per_strict_kernel_equal_the_oracle(sa, ob, rate, kernel, trials, batches):
+    """The strict-mode bug of round 5 fired in ONE trial of 65 536 with every event counter equal: the noisy batches of this suite
+    were an order of magnitude too small to see it.  Every strict kernel family, at every standard rate the wavefront pipeline
+    runs at, against the oracle on 65 536 noisy trials (configs[4]'s generator, seed 2026): every link event -- kind, sample
+    counter, burst bytes -- and the BER tally row for row.  (profiles/r06_ber_vs_oracle_*.json: the same over 262 144 each.)"""
+    from helpers import ber_vs_oracle
+    done = 0
+    for b in range(batches):
+        res = ber_vs_oracle.run(trials=trials, rate=rate, seed=2026, first_trial=b * trials, kernel=kernel)
+        assert res["events_equal"] and res["tally_rows_equal"] and res["rows_gpu"] == res["rows_oracle"]
+        assert res["strict_kernel"].startswith(ber_vs_oracle.KERNELS[kernel])
+        done += sum(r["trials"] for r in res["rows_gpu"])
+    assert done == 65536
 
 
 @pytest.mark.parametrize("n_chunks", [3, 6, 7])
