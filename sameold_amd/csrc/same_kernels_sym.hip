@@ -66,13 +66,25 @@
 
 namespace same {
 
-constexpr int kSymBlock = 36;
+constexpr int kSymSub = 36;               // samples per SUB-BLOCK: what T loads and DC-blocks at a time (nine 16-byte loads per lane)
 constexpr uint32_t kSymDrain = 5u;        // steps after the last block in which T processes the instants left before the end of the input, one per step
+constexpr uint32_t kSymOffMask = 255u;    // a symbol's offset on its way through the mailboxes: < 3 B = 216 at 44.1 / 48 kHz
+// Geometry per sample rate (filter length NT).  A STEP is B = NSUB sub-blocks: 36 samples at 22.05 kHz, 72 at 44.1 / 48 kHz -- less than
+// the shortest symbol the timing loop can command at that rate (sym_kernel_supported checks it against the configuration), so a
+// lane completes at most one symbol per step and ~78-85 % of the lanes complete exactly one.  HALVES: groups of 64 state columns per
+// workgroup -- the ring of 6 x 72 + 91 slots is 134 KB at 48 kHz: ONE group per CU there (six wavefronts on four SIMDs).
+template <int NT> struct SymGeom;
+template <> struct SymGeom<42> { static constexpr int DCL = 16, NSUB = 1, HALVES = 2; };     // 22.05 kHz
+template <> struct SymGeom<92> { static constexpr int DCL = 35, NSUB = 2, HALVES = 1; };     // 48 kHz
+template <> struct SymGeom<84> { static constexpr int DCL = 32, NSUB = 2, HALVES = 1; };     // 44.1 kHz
 template <int NT> struct SymLayout {
     // The window ring holds SIX blocks: the four the filters may reach into, the one S is turning from DC-blocker outputs into
     // AGC outputs IN PLACE, and the one T is writing DC-blocker outputs to (there is no hand-over ring between T and S).  Its first
-    // NT - 1 slots are stored twice: a filter's 42 samples never wrap.
-    static constexpr int B = kSymBlock, DCL = 16, NBLK = 6, RING = NBLK * B, MIR = NT - 1;
+    // NT - 1 slots are stored twice: a filter's NT samples never wrap.
+    static constexpr int SB = kSymSub, NSUB = SymGeom<NT>::NSUB, B = SB * NSUB, DCL = SymGeom<NT>::DCL, NBLK = 6, RING = NBLK * B, MIR = NT - 1;
+    static constexpr int HALVES = SymGeom<NT>::HALVES;
+    // 22.05 kHz: the taps live in registers (the LDS words are the profile builds' section marks); 44.1 / 48 kHz: the centred tap
+    // table (NT / 2 entries of Re mark, Re space, Im mark, Im space) at the start of the group's LDS
     static constexpr uint32_t tap_floats = (uint32_t)((NT * 4 + PIPE_PROF_TAP_PAD + 63) / 64 * 64);
     static constexpr uint32_t sym_words = 5u * kWave;             // per parity: header, zero, sym, terr, until
     static constexpr uint32_t fb_words = kWave + 32u;             // per parity: one word per lane + the any-flag
@@ -86,12 +98,12 @@ template <int NT> struct SymLayout {
                                            kWave +                                  // the roles' progress words (six of them)
                                            (SYM_TL_WORDS + 63u) / 64u * 64u;        // (timeline builds: their marks)
     static constexpr size_t lds_bytes = ((size_t)tap_floats + mail_words + (size_t)(RING + MIR) * kWave) * sizeof(float);
-    static_assert(NT == 42, "the filter's load sequence is written out for 42 taps");
-    static_assert(B % 4 == 0 && B >= DCL && B % 2 == 0, "16-byte loads per lane; the DC windows are the tail of a block");
-    static_assert(MIR <= 2 * B, "the mirrored slots are the first block and the head of the second");
-    // reach: lag <= 52, first instant of a symbol <= 25 before the second, NT - 1 taps back
-    static_assert(52 + 1 + 25 + (NT - 1) <= (NBLK - 2) * B, "the filters would read a block that is being written");
-    static_assert(lds_bytes <= 80u * 1024u, "two groups of 64 columns per workgroup and CU");
+    static_assert(NT % 2 == 0 && NT - 1 <= 255, "tap pairs; ds_read2st64's 8-bit slot offsets");
+    static_assert(SB % 4 == 0 && SB >= DCL + (DCL & 1), "16-byte loads per lane; the DC windows are the tail of a sub-block");
+    static_assert(MIR <= 2 * B && MIR >= B, "the mirrored slots are the first block and the head of the second");
+    static_assert(3 * B <= (int)kSymOffMask, "a symbol's offset is eight bits");
+    static_assert((size_t)HALVES * lds_bytes <= 160u * 1024u, "the groups of a workgroup share a CU's LDS");
+    static_assert(NT != 42 || lds_bytes <= 80u * 1024u, "22.05 kHz: two groups of 64 columns per workgroup and CU");
 };
 
 // f(integral_constant<int, 0>) ... f(integral_constant<int, N - 1>): a loop that is straight-line code from the start.  A
@@ -192,28 +204,56 @@ struct SymTaps {
     }
 };
 
+// The filter pair of a role-wavefront at any of the three rates: 22.05 kHz keeps its 42 taps in registers (SymTaps); 44.1 / 48 kHz
+// read the centred table from LDS beside the window (demod_pair_centred_at, same_relaxed_common.h: per tap pair one
+// ds_read2st64_b32 for both window samples, one ds_read_b128 for the four tap words, a packed add and two packed multiply-adds --
+// 184 tap registers next to 42 window words in flight do not fit a wavefront's 256).
+template <int NT> struct SymFilter {
+    uint32_t ctaps_lds;
+    __device__ __forceinline__ void load(const float4 *__restrict__, float *lds_group) { ctaps_lds = lds_addr(lds_group); }
+    template <int RING>
+    __device__ __forceinline__ float demod(uint32_t wcol_lds, int n) const
+    {
+        int base = n - (NT - 1);
+        base += base < 0 ? RING : 0;                          // slots RING .. RING + NT - 2 repeat slots 0 .. NT - 2
+        float hm, hs;
+        demod_pair_centred_at<NT>(ctaps_lds, wcol_lds + (uint32_t)base * (kWave * 4u), &hm, &hs);
+        return __builtin_amdgcn_fmed3f(hm - hs, -1.0f, 1.0f);
+    }
+};
+template <> struct SymFilter<42> : SymTaps<42> {
+    __device__ __forceinline__ void load(const float4 *__restrict__ taps, float *) { SymTaps<42>::load(taps); }
+};
+
 // ---------------------------------------------------------------------------------------------------------------------
 // T's sample half: input prefetch and DC blocker, one block ahead of S.  Inputs alternate between two register buffers
 // (block b in buffer b & 1); the loads of block b + 1 are issued just before block b is computed, unconditionally (a load
 // behind a condition makes the compiler wait for every outstanding load at the reads), so they have a whole
 // step to arrive.  CMODE: 1 = channel-major input with per-lane streams, 0 = time-major rows.
 // ---------------------------------------------------------------------------------------------------------------------
-template <typename SampleT, int CMODE>
+template <typename SampleT, int CMODE, int NT>
 struct SymDc {
-    static constexpr int B = SymLayout<42>::B, DCL = SymLayout<42>::DCL, RING = SymLayout<42>::RING;
+    // B: a SUB-BLOCK (36 samples at every rate: nine 16-byte loads per lane); a step is SymLayout::NSUB of them
+    static constexpr int B = SymLayout<NT>::SB, DCL = SymLayout<NT>::DCL, RING = SymLayout<NT>::RING;
+    static constexpr int HL = DCL + (DCL & 1);        // samples of history kept (whole pairs): 16, 32, 36 (48 kHz: the 36th is never read)
     static constexpr uint32_t LP = kWave;
+    static_assert(CMODE == 0 || NT == 42, "per-lane streams: 22.05 kHz only (same_batch.cpp transposes the other rates' channel-major input)");
+    static_assert(B >= HL && (B - HL) % 2 == 0 && ((DCL & 1) == 0 || HL == B), "the history is the tail of a sub-block, in whole pairs");
     // Everything is kept as aligned PAIRS (samples 2 i, 2 i + 1) and every access is a whole pair with a compile-time index:
     // the packed operations want aligned register pairs anyway, and an array that is read as pairs at both even and odd
     // offsets does not survive as registers (see sym_static_for).
     typedef float2v Pairs[B / 2];
-    // The DC blocker (rx/dcblock.rs:45-49, 104-108) is two moving averages of DCL = 16 samples:
-    //     sum0 += x - x[-16];  ma0 = sum0 / 16;  sum1 += ma0 - ma0[-16];  ma1 = sum1 / 16;  y = x[-15] - ma1.
-    // A division by 16 is exact, and adding, subtracting and rounding commute with a scaling by a power of two, so the second
-    // average may run on the UNSCALED first sums -- S1 = 16 sum1 exactly, sample for sample -- and y = x[-15] - S1 / 256 is one
-    // fused multiply-add whose only rounding is the reference's own (S1 / 256 is exact): the same bits with 3.5 vector
-    // instructions per sample instead of 5.  The state arrays keep the reference's scaling (load / store).
-    float sum0, sum1;                    // sum1: 16 x the reference's
-    float2v xp[DCL / 2], sp[DCL / 2];    // the last DCL inputs / first-stage SUMS, oldest first
+    // The DC blocker (rx/dcblock.rs:45-49, 104-108) is two moving averages of DCL samples:
+    //     sum0 += x - x[-DCL];  ma0 = sum0 / DCL;  sum1 += ma0 - ma0[-DCL];  ma1 = sum1 / DCL;  y = x[-(DCL-1)] - ma1.
+    // DCL = 16 / 32 (22.05 / 44.1 kHz): a division by a power of two is exact, and adding, subtracting and rounding commute with
+    // such a scaling, so the second average may run on the UNSCALED first sums -- S1 = DCL sum1 exactly, sample for sample -- and
+    // y = x[-(DCL-1)] - S1 / DCL^2 is one fused multiply-add whose only rounding is the reference's own (S1 / DCL^2 is exact): the same
+    // bits with 3.5 vector instructions per sample instead of 5.  The state arrays keep the reference's scaling (load / store).
+    // DCL = 35 (48 kHz): ma = sum * (1 / 35) rounds, so every operation of the reference is made, in its order (5.5 per sample:
+    // x[-35] and ma0[-35] of an aligned pair straddle two register pairs -- two scalar subtractions where the even lengths take one
+    // packed one).  The same bits at every rate.
+    float sum0, sum1;                    // sum1: DCL x the reference's (even DCL), the reference's (DCL = 35)
+    float2v xp[HL / 2], sp[HL / 2];      // the last HL inputs / first-stage SUMS (DCL = 35: averages), oldest first
     // Input buffers: two, block b in (b & 1 ? xb : xa).  Time-major rows (CMODE 0): 36 buffer loads a block, issued just before the
     // block before theirs is computed, whose waits the compiler counts exactly.  Channel-major streams (CMODE 1): nine 16-byte loads
     // a block, issued by hand (inline assembly, explicit s_waitcnt vmcnt) INTO THE BUFFER A BLOCK HAS JUST BEEN COMPUTED FROM, i.e.
@@ -279,18 +319,30 @@ struct SymDc {
             sym_static_for<B / 2>([&](auto h_) __attribute__((always_inline)) { X[decltype(h_)::value] = buf.p[decltype(h_)::value]; });
         }
     }
+    // history sample i (0 = oldest of HL) sits in the state ring's slot (dpos + i - (HL - DCL)) mod DCL
+    static __device__ __forceinline__ uint32_t ring_slot(uint32_t dpos, int i)
+    {
+        uint32_t s = dpos + (uint32_t)(i - (HL - DCL));
+        if (s >= (uint32_t)DCL) s -= (uint32_t)DCL;
+        return s;
+    }
     __device__ __forceinline__ void load(const State &S, const SampleT *__restrict__ x, uint32_t c, uint32_t C, uint32_t cin, uint32_t Cin,
                                          uint64_t counter0, uint32_t n_blocks)
     {
-        sum0 = S.dc_sum0[c]; sum1 = S.dc_sum1[c] * (float)DCL;
+        constexpr float up = (DCL & 1) ? 1.0f : (float)DCL;
+        sum0 = S.dc_sum0[c]; sum1 = S.dc_sum1[c] * up;
         const uint32_t dpos = (uint32_t)(counter0 % (uint64_t)DCL);
-        sym_static_for<DCL / 2>([&](auto h_) __attribute__((always_inline)) {
+        sym_static_for<HL / 2>([&](auto h_) __attribute__((always_inline)) {
             constexpr int h = decltype(h_)::value;
-            uint32_t s0 = dpos + (uint32_t)(2 * h), s1 = s0 + 1u;
-            if (s0 >= (uint32_t)DCL) s0 -= (uint32_t)DCL;
-            if (s1 >= (uint32_t)DCL) s1 -= (uint32_t)DCL;
-            xp[h] = float2v{(S.dc_ff_ring + (size_t)s0 * C)[c], (S.dc_ff_ring + (size_t)s1 * C)[c]};
-            sp[h] = float2v{(S.dc_fb_ring + (size_t)s0 * C)[c] * (float)DCL, (S.dc_fb_ring + (size_t)s1 * C)[c] * (float)DCL};
+            if constexpr (2 * h < HL - DCL) {                      // (DCL = 35: history sample 0 is x[-36], which nothing reads)
+                const uint32_t s1 = ring_slot(dpos, 2 * h + 1);
+                xp[h] = float2v{0.0f, (S.dc_ff_ring + (size_t)s1 * C)[c]};
+                sp[h] = float2v{0.0f, (S.dc_fb_ring + (size_t)s1 * C)[c] * up};
+            } else {
+                const uint32_t s0 = ring_slot(dpos, 2 * h), s1 = ring_slot(dpos, 2 * h + 1);
+                xp[h] = float2v{(S.dc_ff_ring + (size_t)s0 * C)[c], (S.dc_ff_ring + (size_t)s1 * C)[c]};
+                sp[h] = float2v{(S.dc_fb_ring + (size_t)s0 * C)[c] * up, (S.dc_fb_ring + (size_t)s1 * C)[c] * up};
+            }
         });
         if constexpr (CMODE == 0) sym_static_for<B / 2>([&](auto h_) __attribute__((always_inline)) { xb.p[decltype(h_)::value] = float2v{0.0f, 0.0f}; });
         request(xa, x, 0u, n_blocks, cin, Cin);
@@ -313,57 +365,79 @@ struct SymDc {
         wpos += (uint32_t)B;
         if (wpos == (uint32_t)RING) wpos = 0u;
         Pairs snew;
-        constexpr float kScale = -1.0f / (float)(DCL * DCL);
-        static_assert(DCL == 16, "a power of two: the scalings above are exact");
-        const float2v nscale = {kScale, kScale};
-        float s1_last = 0.0f;                                          // S1 after the odd sample of the pair before
-        sym_static_for<B / 2>([&](auto h_) __attribute__((always_inline)) {
-            constexpr int h = decltype(h_)::value;                     // samples k = 2 h, 2 h + 1
-            // the windows before this block, oldest first, as pairs: 0 .. DCL/2 - 1 the history, then this block's
-            auto xw = [&](auto i_) __attribute__((always_inline)) -> float2v {
-                constexpr int i = decltype(i_)::value;
-                if constexpr (i < DCL / 2) return xp[i]; else return X[i - DCL / 2];
-            };
-            auto sw = [&](auto i_) __attribute__((always_inline)) -> float2v {
-                constexpr int i = decltype(i_)::value;
-                if constexpr (i < DCL / 2) return sp[i]; else return snew[i - DCL / 2];
-            };
-            const float2v xo = xw(std::integral_constant<int, h>{});   // inputs 2 h - 16, 2 h - 15
-            const float2v d0 = X[h] - xo;
-            const float s0a = sum0 + d0.x, s0b = s0a + d0.y;
-            sum0 = s0b;
-            const float2v s0 = {s0a, s0b};
-            snew[h] = s0;
-            const float2v d1 = s0 - sw(std::integral_constant<int, h>{});
-            const float s1a = sum1 + d1.x, s1b = s1a + d1.y;
-            sum1 = s1b;
-            // y[k] = x[k - 15] - S1[k] / 256: the pair (y[2 h - 1], y[2 h]) meets the ALIGNED input pair xo
-            if constexpr (h == 0) {
-                y[0] = __builtin_fmaf(s1a, kScale, xo.y);
-            } else {
-                const float2v yy = __builtin_elementwise_fma(float2v{s1_last, s1a}, nscale, xo);
-                y[(2 * h - 1) * LP] = yy.x; y[(2 * h) * LP] = yy.y;
-            }
-            s1_last = s1b;
-            if constexpr (h == B / 2 - 1) y[(B - 1) * LP] = __builtin_fmaf(s1b, kScale, xw(std::integral_constant<int, h + 1>{}).x);
-        });
-        sym_static_for<DCL / 2>([&](auto h_) __attribute__((always_inline)) {
+        // the windows before this block, oldest first, as pairs: 0 .. HL/2 - 1 the history, then this block's
+        auto xw = [&](auto i_) __attribute__((always_inline)) -> float2v {
+            constexpr int i = decltype(i_)::value;
+            if constexpr (i < HL / 2) return xp[i]; else return X[i - HL / 2];
+        };
+        auto sw = [&](auto i_) __attribute__((always_inline)) -> float2v {
+            constexpr int i = decltype(i_)::value;
+            if constexpr (i < HL / 2) return sp[i]; else return snew[i - HL / 2];
+        };
+        if constexpr ((DCL & 1) == 0) {
+            constexpr float kScale = -1.0f / (float)(DCL * DCL);
+            static_assert((DCL & (DCL - 1)) == 0, "a power of two: the scalings above are exact");
+            const float2v nscale = {kScale, kScale};
+            float s1_last = 0.0f;                                          // S1 after the odd sample of the pair before
+            sym_static_for<B / 2>([&](auto h_) __attribute__((always_inline)) {
+                constexpr int h = decltype(h_)::value;                     // samples k = 2 h, 2 h + 1
+                const float2v xo = xw(std::integral_constant<int, h>{});   // inputs 2 h - DCL, 2 h - DCL + 1
+                const float2v d0 = X[h] - xo;
+                const float s0a = sum0 + d0.x, s0b = s0a + d0.y;
+                sum0 = s0b;
+                const float2v s0 = {s0a, s0b};
+                snew[h] = s0;
+                const float2v d1 = s0 - sw(std::integral_constant<int, h>{});
+                const float s1a = sum1 + d1.x, s1b = s1a + d1.y;
+                sum1 = s1b;
+                // y[k] = x[k - (DCL - 1)] - S1[k] / DCL^2: the pair (y[2 h - 1], y[2 h]) meets the ALIGNED input pair xo
+                if constexpr (h == 0) {
+                    y[0] = __builtin_fmaf(s1a, kScale, xo.y);
+                } else {
+                    const float2v yy = __builtin_elementwise_fma(float2v{s1_last, s1a}, nscale, xo);
+                    y[(2 * h - 1) * LP] = yy.x; y[(2 * h) * LP] = yy.y;
+                }
+                s1_last = s1b;
+                if constexpr (h == B / 2 - 1) y[(B - 1) * LP] = __builtin_fmaf(s1b, kScale, xw(std::integral_constant<int, h + 1>{}).x);
+            });
+        } else {
+            // DCL = 35 with 36 samples of history: x[k - 35] is history sample k + 1, x[k - 34] (the delayed signal) sample k + 2
+            const float inv = P.dc_inv_len;
+            const float2v inv2 = {inv, inv};
+            sym_static_for<B / 2>([&](auto h_) __attribute__((always_inline)) {
+                constexpr int h = decltype(h_)::value;                     // samples k = 2 h, 2 h + 1
+                const float2v xlo = xw(std::integral_constant<int, h>{}), xhi = xw(std::integral_constant<int, h + 1>{});
+                const float d0a = X[h].x - xlo.y, d0b = X[h].y - xhi.x;    // MovingAverage::filter: moving_sum += input - aged
+                const float s0a = sum0 + d0a, s0b = s0a + d0b;
+                sum0 = s0b;
+                const float2v m0 = float2v{s0a, s0b} * inv2;               // ma0 = moving_sum * inv_len
+                snew[h] = m0;
+                const float2v mlo = sw(std::integral_constant<int, h>{}), mhi = sw(std::integral_constant<int, h + 1>{});
+                const float d1a = m0.x - mlo.y, d1b = m0.y - mhi.x;
+                const float s1a = sum1 + d1a, s1b = s1a + d1b;
+                sum1 = s1b;
+                const float2v yy = xhi - float2v{s1a, s1b} * inv2;         // sig - ma1 (rx/dcblock.rs:45-49): both of the reference's roundings
+                y[(2 * h) * LP] = yy.x; y[(2 * h + 1) * LP] = yy.y;
+            });
+        }
+        sym_static_for<HL / 2>([&](auto h_) __attribute__((always_inline)) {
             constexpr int h = decltype(h_)::value;
-            xp[h] = X[(B - DCL) / 2 + h]; sp[h] = snew[(B - DCL) / 2 + h];
+            xp[h] = X[(B - HL) / 2 + h]; sp[h] = snew[(B - HL) / 2 + h];
         });
     }
     __device__ __forceinline__ void store(const State &S, uint32_t c, uint32_t C, uint64_t counter1)
     {
-        constexpr float inv = 1.0f / (float)DCL;
+        constexpr float inv = (DCL & 1) ? 1.0f : 1.0f / (float)DCL;
         S.dc_sum0[c] = sum0; S.dc_sum1[c] = sum1 * inv;
         const uint32_t dpos = (uint32_t)(counter1 % (uint64_t)DCL);
-        sym_static_for<DCL / 2>([&](auto h_) __attribute__((always_inline)) {
+        sym_static_for<HL / 2>([&](auto h_) __attribute__((always_inline)) {
             constexpr int h = decltype(h_)::value;
-            uint32_t s0 = dpos + (uint32_t)(2 * h), s1 = s0 + 1u;
-            if (s0 >= (uint32_t)DCL) s0 -= (uint32_t)DCL;
-            if (s1 >= (uint32_t)DCL) s1 -= (uint32_t)DCL;
-            (S.dc_ff_ring + (size_t)s0 * C)[c] = xp[h].x; (S.dc_ff_ring + (size_t)s1 * C)[c] = xp[h].y;
-            (S.dc_fb_ring + (size_t)s0 * C)[c] = sp[h].x * inv; (S.dc_fb_ring + (size_t)s1 * C)[c] = sp[h].y * inv;
+            if constexpr (2 * h >= HL - DCL) {
+                const uint32_t s0 = ring_slot(dpos, 2 * h);
+                (S.dc_ff_ring + (size_t)s0 * C)[c] = xp[h].x; (S.dc_fb_ring + (size_t)s0 * C)[c] = sp[h].x * inv;
+            }
+            const uint32_t s1 = ring_slot(dpos, 2 * h + 1);
+            (S.dc_ff_ring + (size_t)s1 * C)[c] = xp[h].y; (S.dc_fb_ring + (size_t)s1 * C)[c] = sp[h].y * inv;
         });
     }
 };
@@ -371,8 +445,9 @@ struct SymDc {
 // ---------------------------------------------------------------------------------------------------------------------
 // S: AGC over the window ring's newest block, in place (T left the DC blocker's outputs there), and the gain a lock freezes
 // ---------------------------------------------------------------------------------------------------------------------
+template <int NT>
 struct SymAgc {
-    static constexpr int B = SymLayout<42>::B, RING = SymLayout<42>::RING, MIR = SymLayout<42>::MIR;
+    static constexpr int B = SymLayout<NT>::B, RING = SymLayout<NT>::RING, MIR = SymLayout<NT>::MIR;
     static constexpr uint32_t LP = kWave;
     float gain;
     bool locked;                         // this wavefront's belief of the AGC lock
@@ -643,7 +718,7 @@ __device__ __forceinline__ uint32_t sym_framer_step(const Params &P, SymFramer &
     const uint32_t link = ready ? link_ready : link_quiet;
     F.st = ready ? nst : ((valid & !reading) ? 0u : st);
     // squelch.lock(true) receiver.rs:462; end() receiver.rs:466-470
-    const uint32_t fb_end = FB_VALID | FB_END | (((m >> YM_OFF_SHIFT) & 127u) << 8);
+    const uint32_t fb_end = FB_VALID | FB_END | (((m >> YM_OFF_SHIFT) & kSymOffMask) << 8);
     *fb2 = ready ? (link == 2u ? (uint32_t)FB_SQLOCK : ((link == 0u || link == 3u) ? fb_end : 0u)) : 0u;
     // receiver.rs:246-253: report on change; a Burst always differs from its predecessor
     *emit = valid & ((link != F.last) | (link == 3u));
@@ -661,6 +736,12 @@ __device__ __forceinline__ uint32_t sym_framer_step(const Params &P, SymFramer &
 #define SYM_PRIOS 0x0031322      /* S T A A(events) E Y1 Y2, one hex digit each */
 #endif
 constexpr int sym_prio_of(int k) { return (int)((SYM_PRIOS >> (4 * (6 - k))) & 3); }
+// 44.1 / 48 kHz: one group per CU, S and Y1 share a SIMD and so do T and Y2 -- and there the SAMPLE roles carry the step (72 samples
+// of AGC / DC blocker against one symbol): they go first
+#ifndef SYM_PRIOS_HI
+#define SYM_PRIOS_HI 0x3321200   /* S T A A(events) E Y1 Y2 */
+#endif
+template <int NT> constexpr int sym_prio(int k) { return NT == 42 ? sym_prio_of(k) : (int)((SYM_PRIOS_HI >> (4 * (6 - k))) & 3); }
 template <int PRIO> __device__ __forceinline__ void sym_setprio(const Params &P)
 {
 #ifdef SAME_PROFILE
@@ -704,9 +785,11 @@ template <typename T> __device__ __forceinline__ T sym_fresh_arg(sym_kernarg_ptr
 // never share a CU -- the second one's wavefronts would pile four-deep on the SIMDs that already hold two, past the register
 // file (tools/ubench_wave_place.hip: one resident workgroup per CU, half the machine).  The two halves share nothing but the
 // step barrier; a half that is done simply ends (s_barrier counts the surviving wavefronts only).
-constexpr int kSymRoles = 6, kSymHalves = 2;
-template <int NFF, int NFB, typename SampleT, int CMODE>
-__global__ __launch_bounds__(kSymHalves * kSymRoles * kWave, 3) void demod_sym_kernel(Params P, State S_arg_, Output O_arg_, const float4 *__restrict__ taps,
+// 44.1 / 48 kHz: ONE group per workgroup and CU (SymGeom::HALVES; the window ring alone is 131-134 KB): six wavefronts on four SIMDs,
+// up to 256 registers each.
+constexpr int kSymRoles = 6;
+template <int NT, int NFF, int NFB, typename SampleT, int CMODE>
+__global__ __launch_bounds__(SymGeom<NT>::HALVES * kSymRoles * kWave, NT == 42 ? 3 : 2) void demod_sym_kernel(Params P, State S_arg_, Output O_arg_, const float4 *__restrict__ taps,
                                                                          const SampleT *__restrict__ x, uint32_t n_blocks, uint64_t counter0,
                                                                          PipeChunks K)
 {
@@ -714,9 +797,9 @@ __global__ __launch_bounds__(kSymHalves * kSymRoles * kWave, 3) void demod_sym_k
     const sym_kernarg_ptr ka = (sym_kernarg_ptr)__builtin_amdgcn_kernarg_segment_ptr();
     auto fresh_state = [&]() __attribute__((always_inline)) -> State { return sym_fresh_arg<State>(ka, offsetof(SymKernArgs, S)); };
     auto fresh_output = [&]() __attribute__((always_inline)) -> Output { return sym_fresh_arg<Output>(ka, offsetof(SymKernArgs, O)); };
-    constexpr int NT = 42;
     using LY = SymLayout<NT>;
-    constexpr int kB = LY::B, RING = LY::RING;
+    constexpr int kB = LY::B, RING = LY::RING, kSB = LY::SB, kNSUB = LY::NSUB;
+    constexpr uint32_t kSymHalves = (uint32_t)LY::HALVES;
     constexpr uint32_t LP = kWave;
     static_assert(CMODE == 0 || std::is_same<SampleT, float>::value, "channel-major streams are f32");
     if constexpr (CMODE == 0) { K.col_row0 = nullptr; K.col_perm = nullptr; }       // (the host launches this build for nothing else)
@@ -735,11 +818,13 @@ __global__ __launch_bounds__(kSymHalves * kSymRoles * kWave, 3) void demod_sym_k
 #else
     constexpr uint64_t tbl = kDeal0;
 #endif
-    const uint32_t hr = (uint32_t)(tbl >> (4u * wave)) & 15u;
-    const uint32_t half = hr >> 3;
+    // (one group per workgroup: wavefronts 0 .. 5 are S T A E Y1 Y2; SIMDs 0 and 1 hold two of them -- S + Y1 and T + Y2, the sample
+    // roles each beside a symbol role with slack)
+    const uint32_t hr = LY::HALVES == 2 ? (uint32_t)(tbl >> (4u * wave)) & 15u : wave;
+    const uint32_t half = LY::HALVES == 2 ? hr >> 3 : 0u;
     const uint32_t role = hr & 7u;                                                             // 0 S, 1 T, 2 A, 3 E, 4 Y1, 5 Y2
     const uint32_t C = P.n_channels;
-    const uint32_t vwg = blockIdx.x * (uint32_t)kSymHalves + half;                              // this half's group of 64 state columns
+    const uint32_t vwg = blockIdx.x * kSymHalves + half;                              // this half's group of 64 state columns
     if (vwg * kWave >= C) return;                                                              // (an odd number of groups: the last workgroup's second half)
     float *lds = lds_all + half * (uint32_t)(LY::lds_bytes / sizeof(float));
     // state column of this lane (time-parallel launches may permute them: pieces of similar length share a group)
@@ -758,7 +843,7 @@ __global__ __launch_bounds__(kSymHalves * kSymRoles * kWave, 3) void demod_sym_k
             may_leave = (uint32_t)__builtin_amdgcn_readfirstlane((int)chunk_l) + 1u < K.n_chunks;
             const uint32_t row_abs = K.col_row0[c];
             xl = x + (size_t)cin * K.in_samples + row_abs;
-            avail_l = (K.whole_samples - row_abs) / (uint32_t)kB;
+            avail_l = (K.whole_samples - row_abs) / (uint32_t)kSB;              // (per-lane streams: 22.05 kHz, where a step is one sub-block)
             n_blocks = K.wg_blocks[vwg];
             n_nominal = may_leave ? K.col_nominal[c] : n_blocks;
             const uint32_t row_first = (uint32_t)__builtin_amdgcn_readfirstlane((int)row_abs);
@@ -870,8 +955,8 @@ __global__ __launch_bounds__(kSymHalves * kSymRoles * kWave, 3) void demod_sym_k
 
     if (role == 0u) {
         // ------------------------------------------ S: AGC of block s, in place ------------------------------------------
-        sym_setprio<sym_prio_of(0)>(P);
-        SymAgc M;
+        sym_setprio<sym_prio<NT>(0)>(P);
+        SymAgc<NT> M;
         { const State S = fresh_state(); M.load(P, S, c, C, counter0, wcol); }
         lds_barrier();                                                 // prologue: block 0's DC outputs are in the ring, every box is initialised
         P3_T0();
@@ -914,30 +999,39 @@ __global__ __launch_bounds__(kSymHalves * kSymRoles * kWave, 3) void demod_sym_k
         { const State S = fresh_state(); M.store(P, S, c, C, counter1, wcol); }
     } else if (role == 1u) {
         // ------------------------------------------ T: input prefetch and DC blocker of block s + 1 --------------------
-        sym_setprio<sym_prio_of(1)>(P);
-        SymDc<SampleT, CMODE> D;
+        sym_setprio<sym_prio<NT>(1)>(P);
+        using Dc = SymDc<SampleT, CMODE, NT>;
+        Dc D;
         D.xl = xl; D.avail = avail_l;
-        { const State S = fresh_state(); D.load(S, x, c, C, cin, Cin, counter0, n_blocks); }
+        // (T counts SUB-BLOCKS of 36 samples: a step's block is kNSUB of them, sub-block q in buffer q & 1)
+        const uint32_t n_sub = n_blocks * (uint32_t)kNSUB;
+        { const State S = fresh_state(); D.load(S, x, c, C, cin, Cin, counter0, n_sub); }
         donebox[lane] = 0u;
+        // time-major rows: the loads of sub-block q + 1 go out just before sub-block q (waiting in buffer PB) is computed
+        auto sub_tm = [&](uint32_t q, auto pb_) __attribute__((always_inline)) {
+            typename Dc::Pairs X;
+            if constexpr (decltype(pb_)::value == 0) { D.request(D.xb, x, q + 1u, n_sub, cin, Cin); D.template take<0>(D.xa, X); }
+            else { D.request(D.xa, x, q + 1u, n_sub, cin, Cin); D.template take<0>(D.xb, X); }
+            D.block(P, wcol, X, q);
+        };
         // prologue: block 0's DC outputs
         {
-            typename SymDc<SampleT, CMODE>::Pairs X0;
             if constexpr (CMODE == 1) {
-                D.request(D.xb, x, 1u, n_blocks, cin, Cin);                // (clamped to the lane's stream)
+                typename Dc::Pairs X0;
+                D.request(D.xb, x, 1u, n_sub, cin, Cin);                   // (clamped to the lane's stream)
                 D.template take<9>(D.xa, X0);
                 D.block(P, wcol, X0, 0u);
-                D.request(D.xa, x, 2u, n_blocks, cin, Cin);
+                D.request(D.xa, x, 2u, n_sub, cin, Cin);
             } else {
-                if (n_blocks > 1u) D.request(D.xb, x, 1u, n_blocks, cin, Cin);
-                D.template take<0>(D.xa, X0);
-                D.block(P, wcol, X0, 0u);
+                sub_tm(0u, std::integral_constant<int, 0>{});
+                if constexpr (kNSUB == 2) sub_tm(1u, std::integral_constant<int, 1>{});
             }
         }
         lds_barrier();
         P3_T0();
         uint32_t stop_at = 0xffffffffu;
         auto step = [&](uint32_t s, auto buf) __attribute__((always_inline)) -> bool {
-            constexpr int BUF = decltype(buf)::value;                  // block s + 1 waits in buffer BUF = (s + 1) & 1
+            constexpr int BUF = decltype(buf)::value;                  // one sub-block per step: block s + 1 waits in buffer BUF = (s + 1) & 1
             uint32_t w1, w2;
             SYM_TRACE(1, s, 0);
             wait_for(s, R_A | R_E, &w1, &w2, kNapLong);                          // the filters are done with the ring block this step overwrites
@@ -945,15 +1039,16 @@ __global__ __launch_bounds__(kSymHalves * kSymRoles * kWave, 3) void demod_sym_k
             P3_LAP(p3_wait);
             if constexpr (CMODE == 1) D.done = donebox[lane] != 0u;
             if (s + 1u < n_blocks && !PROF_SKIP(P, 128)) {
-                typename SymDc<SampleT, CMODE>::Pairs X;
                 if constexpr (CMODE == 1) {
+                    typename Dc::Pairs X;
                     // in flight: this block's loads and the next one's; block s + 3's go out when this block's registers are free
-                    if constexpr (BUF == 0) { D.template take<9>(D.xa, X); D.block(P, wcol, X, s + 1u); D.request(D.xa, x, s + 3u, n_blocks, cin, Cin); }
-                    else { D.template take<9>(D.xb, X); D.block(P, wcol, X, s + 1u); D.request(D.xb, x, s + 3u, n_blocks, cin, Cin); }
+                    if constexpr (BUF == 0) { D.template take<9>(D.xa, X); D.block(P, wcol, X, s + 1u); D.request(D.xa, x, s + 3u, n_sub, cin, Cin); }
+                    else { D.template take<9>(D.xb, X); D.block(P, wcol, X, s + 1u); D.request(D.xb, x, s + 3u, n_sub, cin, Cin); }
+                } else if constexpr (kNSUB == 1) {
+                    sub_tm(s + 1u, buf);
                 } else {
-                    if constexpr (BUF == 0) { D.request(D.xb, x, s + 2u, n_blocks, cin, Cin); D.template take<0>(D.xa, X); }
-                    else { D.request(D.xa, x, s + 2u, n_blocks, cin, Cin); D.template take<0>(D.xb, X); }
-                    D.block(P, wcol, X, s + 1u);
+                    sub_tm(2u * (s + 1u), std::integral_constant<int, 0>{});
+                    sub_tm(2u * (s + 1u) + 1u, std::integral_constant<int, 1>{});
                 }
             }
             if (may_leave) {                                                     // (wave-uniform; only a time-parallel piece hands over)
@@ -975,14 +1070,18 @@ __global__ __launch_bounds__(kSymHalves * kSymRoles * kWave, 3) void demod_sym_k
         { const State S = fresh_state(); D.store(S, c, C, counter1); }
     } else if (role == 2u) {
         // ------------------------------------------ A: the matched-filter pair at the FIRST instant of the step's symbol; link events + wake-ups ----
-        sym_setprio<sym_prio_of(2)>(P);
+        sym_setprio<sym_prio<NT>(2)>(P);
         const uint32_t wcol_lds = lds_addr(wcol);
-        SymTaps<NT> TP;
-        TP.load(taps);
+        SymFilter<NT> TP;
+        TP.load(taps, lds);
         Lane L;
         IoCtxLds X;
         X.chunk = chunkbox;
         if (lane == 0u) { chunkbox[0] = 0u; chunkbox[1] = kEvChunk; seqbox[0] = 0u; }      // nothing reserved yet; no pass posted yet
+        if constexpr (NT != 42) {                                      // 44.1 / 48 kHz: the centred tap table for both filter wavefronts
+            float4 *ctl = reinterpret_cast<float4 *>(lds);
+            for (uint32_t i = lane; i < (uint32_t)(NT / 2); i += kWave) ctl[i] = taps[NT + i];
+        }
         X.pending_slot = 0xffffffffu;
         X.tk = tkbox + lane;
         {
@@ -1014,7 +1113,7 @@ __global__ __launch_bounds__(kSymHalves * kSymRoles * kWave, 3) void demod_sym_k
                 }
             }
             SYM_TRACE(2, s, 3);
-            sym_setprio<sym_prio_of(3)>(P);
+            sym_setprio<sym_prio<NT>(3)>(P);
             wait_for(s, R_Y2, &w1, &w2, kNapLong);                               // Y2's link words; has it called the hand-over?
             if (flags_of_last(w2, s) & Y2F_LEAVE) stop_at = s;
             // the link event and the wake-ups of what Y2 handed over in the last step
@@ -1023,7 +1122,7 @@ __global__ __launch_bounds__(kSymHalves * kSymRoles * kWave, 3) void demod_sym_k
                 const uint32_t io0 = io[0];
                 if (io0 & 1u) {
                     L.sq_symbols += 1;         // as the squelch counted it (rx/codesquelch.rs:232)
-                    const uint32_t link = (io0 >> 1) & 3u, off = (io0 >> 4) & 127u;
+                    const uint32_t link = (io0 >> 1) & 3u, off = (io0 >> 4) & kSymOffMask;
                     const bool burst = (io0 & 8u) != 0u && link == 3u;
                     uint32_t burst_len = 0;
                     if (burst) { X.pending_slot = io[kWave]; burst_len = io[2 * kWave]; }
@@ -1035,7 +1134,7 @@ __global__ __launch_bounds__(kSymHalves * kSymRoles * kWave, 3) void demod_sym_k
             if (s + 1u == n_steps) againbox[lane] = L.flags & F_TICK_AGAIN;      // (Y2 merges the flag bits)
             SYM_TRACE(2, s, 2);
             publish(s, 0u, 0u);
-            sym_setprio<sym_prio_of(2)>(P);
+            sym_setprio<sym_prio<NT>(2)>(P);
             P3_LAP(p3_work);
             if (s == stop_at) { left = true; break; }
         }
@@ -1049,10 +1148,10 @@ __global__ __launch_bounds__(kSymHalves * kSymRoles * kWave, 3) void demod_sym_k
         }
     } else if (role == 3u) {
         // ------------------------------------------ E: one symbol per lane and step: the filter pair at its SECOND instant, timing loop ----
-        sym_setprio<sym_prio_of(4)>(P);
+        sym_setprio<sym_prio<NT>(4)>(P);
         const uint32_t wcol_lds = lds_addr(wcol);
-        SymTaps<NT> TP;
-        TP.load(taps);
+        SymFilter<NT> TP;
+        TP.load(taps, lds);
         Lane L;
         { const State S = fresh_state(); lane_load(L, S, c); }
         const float inv_spt = 1.0f / P.samples_per_ted;
@@ -1205,7 +1304,7 @@ __global__ __launch_bounds__(kSymHalves * kSymRoles * kWave, 3) void demod_sym_k
         }
     } else if (role == 4u) {
         // ------------------------------------------ Y1: squelch + equalizer ---------------------------------------------
-        sym_setprio<sym_prio_of(5)>(P);
+        sym_setprio<sym_prio<NT>(5)>(P);
         SymSquelch<NFF, NFB> Q;
         uint64_t symbols0;
         // the squelch's sample history stays in global memory: the state array itself, or -- where the columns of a wavefront
@@ -1321,7 +1420,7 @@ __global__ __launch_bounds__(kSymHalves * kSymRoles * kWave, 3) void demod_sym_k
         }
     } else {
         // ------------------------------------------ Y2: framer, link state, bursts, hand-over ----------------------------
-        sym_setprio<sym_prio_of(6)>(P);
+        sym_setprio<sym_prio<NT>(6)>(P);
         Lane L;
         SymFramer F;
         uint8_t *fr_rows;            // in the loop: the framer's rows only
@@ -1350,7 +1449,7 @@ __global__ __launch_bounds__(kSymHalves * kSymRoles * kWave, 3) void demod_sym_k
                 bool emit = false;
                 const uint32_t link = sym_framer_step(P, F, row, m, &burst_len, &fbv, &emit);
                 const bool want_slot = emit & (link == 3u);            // this lane has just finished a burst
-                const uint32_t io0 = (m & YM_VALID) ? (1u | (link << 1) | (emit ? 8u : 0u) | (((m >> YM_OFF_SHIFT) & 127u) << 4)) : 0u;
+                const uint32_t io0 = (m & YM_VALID) ? (1u | (link << 1) | (emit ? 8u : 0u) | (((m >> YM_OFF_SHIFT) & kSymOffMask) << 4)) : 0u;
                 // finished bursts go into the pool with the whole wavefront: one slot reservation for all of them and one
                 // coalesced round trip per burst (same_kernels_pipe.hip)
                 uint64_t pend = __builtin_amdgcn_ballot_w64(want_slot);
@@ -1425,28 +1524,45 @@ __global__ __launch_bounds__(kSymHalves * kSymRoles * kWave, 3) void demod_sym_k
 // ---------------------------------------------------------------------------------------------------------------------
 // dispatch
 // ---------------------------------------------------------------------------------------------------------------------
-// 22.05 kHz with the reference's default DC-blocker length, the default or the disabled equalizer, a non-negative AGC
+// 22.05 / 44.1 / 48 kHz with the reference's default DC-blocker length, the default or the disabled equalizer, a non-negative AGC
 // floor, whole groups of 64 state columns, and a timing loop whose shortest symbol is longer than a step (two instants at
-// least max_block_len + 1 = 19 samples apart each)
+// least max_block_len + 1 samples apart each: 19 / 40 / 44) and whose filters stay inside the four finished blocks of the ring
+static uint32_t sym_rate_nt(const Params &P)
+{
+    if (P.ntaps == 42u && P.dc_len == 16u) return 42u;
+    if (P.ntaps == 92u && P.dc_len == 35u) return 92u;
+    if (P.ntaps == 84u && P.dc_len == 32u) return 84u;
+    return 0u;
+}
+uint32_t sym_block_len(const Params &P) { return sym_rate_nt(P) == 42u ? (uint32_t)SymLayout<42>::B : (uint32_t)SymLayout<92>::B; }
 bool sym_kernel_supported(const Params &P)
 {
+    static_assert(SymLayout<92>::B == SymLayout<84>::B && SymLayout<92>::NBLK == SymLayout<42>::NBLK, "one step length beyond 22.05 kHz");
     if (P.knob_sym < 0) return false;
-    if (!(P.ntaps == 42u && P.dc_len == 16u && P.win_ring >= 64u && (P.n_channels % kWave) == 0u)) return false;
+    const uint32_t nt = sym_rate_nt(P);
+    if (nt == 0u || P.win_ring < 64u || P.win_ring < nt || (P.n_channels % kWave) != 0u) return false;
     if (P.n_channels >= (1u << 22)) return false;                    // (the squelch history's 24-bit row pitch, SymSquelch::hptr)
     if (!((P.eq_nff == 6u && P.eq_nfb == 4u) || (P.eq_nff == 1u && P.eq_nfb == 1u))) return false;
     if (!(P.agc_min >= 0.0f)) return false;
-    return 2u * (max_block_len(P) + 1u) > (uint32_t)kSymBlock;
+    const uint32_t B = sym_block_len(P), apart = max_block_len(P) + 1u;
+    if (!(2u * apart > B)) return false;                             // at most one symbol per lane and step
+    // How far back a filter reaches from the end of the finished samples: a lane completes its symbol up to B behind it, one more
+    // B - apart after a symsync.reset() (the next instant completes a symbol by itself), the symbol's first instant lies up to
+    // period_max + alpha + 0.5 (+ rounding) before its second, and the filter takes ntaps - 1 samples before that.
+    const float a = P.alpha_unlocked > P.alpha_locked ? P.alpha_unlocked : P.alpha_locked;
+    const uint32_t reach = (2u * B - apart) + 1u + (uint32_t)std::ceil(P.period_max + a + 1.5f) + (nt - 1u);
+    return reach <= (uint32_t)(SymLayout<42>::NBLK - 2) * B;
 }
-uint32_t sym_block_len(const Params &P) { (void)P; return (uint32_t)kSymBlock; }
 
-template <int NFF, int NFB, typename SampleT>
+template <int NT, int NFF, int NFB, typename SampleT>
 static hipError_t launch_sym_one(const Params &P, const State &S, const Output &O, const float4 *taps, const SampleT *x,
                                  uint32_t n_blocks, uint64_t counter0, hipStream_t stream, const PipeChunks &K)
 {
-    constexpr size_t lds = (size_t)kSymHalves * SymLayout<42>::lds_bytes;
+    constexpr uint32_t kSymHalves = (uint32_t)SymLayout<NT>::HALVES;
+    constexpr size_t lds = (size_t)kSymHalves * SymLayout<NT>::lds_bytes;
     static_assert(lds <= 160u * 1024u, "one workgroup per CU");
     const bool cm = K.n_chunks > 1u && K.col_row0 != nullptr;
-    if (cm && !std::is_same<SampleT, float>::value) return hipErrorInvalidValue;
+    if (cm && (!std::is_same<SampleT, float>::value || NT != 42)) return hipErrorInvalidValue;
     if (K.n_chunks > 1u && (K.in_channels % kWave) != 0u) return hipErrorInvalidValue;   // a workgroup would straddle chunks
     if (n_blocks == 0u) return hipSuccess;
     auto go = [&](auto kernel) -> hipError_t {
@@ -1468,10 +1584,10 @@ static hipError_t launch_sym_one(const Params &P, const State &S, const Output &
         hipLaunchKernelGGL(kernel, dim3((P.n_channels / kWave + kSymHalves - 1u) / kSymHalves), dim3(kSymHalves * kSymRoles * kWave), lds, stream, P, S, O, taps, x, n_blocks, counter0, K);
         return hipGetLastError();
     };
-    if constexpr (std::is_same<SampleT, float>::value) {
-        if (cm) return go(demod_sym_kernel<NFF, NFB, float, 1>);
+    if constexpr (std::is_same<SampleT, float>::value && NT == 42) {
+        if (cm) return go(demod_sym_kernel<NT, NFF, NFB, float, 1>);
     }
-    return go(demod_sym_kernel<NFF, NFB, SampleT, 0>);
+    return go(demod_sym_kernel<NT, NFF, NFB, SampleT, 0>);
 }
 
 template <typename SampleT>
@@ -1479,8 +1595,12 @@ static hipError_t launch_sym_t(const Params &P, const State &S, const Output &O,
                                uint32_t n_blocks, uint64_t counter0, hipStream_t stream, const PipeChunks &K)
 {
     if (!sym_kernel_supported(P)) return hipErrorInvalidValue;
-    if (P.eq_nff == 6u && P.eq_nfb == 4u) return launch_sym_one<6, 4, SampleT>(P, S, O, taps, x, n_blocks, counter0, stream, K);
-    return launch_sym_one<1, 1, SampleT>(P, S, O, taps, x, n_blocks, counter0, stream, K);
+    const bool eq = P.eq_nff == 6u && P.eq_nfb == 4u;
+    switch (sym_rate_nt(P)) {
+    case 42u: return eq ? launch_sym_one<42, 6, 4, SampleT>(P, S, O, taps, x, n_blocks, counter0, stream, K) : launch_sym_one<42, 1, 1, SampleT>(P, S, O, taps, x, n_blocks, counter0, stream, K);
+    case 92u: return eq ? launch_sym_one<92, 6, 4, SampleT>(P, S, O, taps, x, n_blocks, counter0, stream, K) : launch_sym_one<92, 1, 1, SampleT>(P, S, O, taps, x, n_blocks, counter0, stream, K);
+    default:  return eq ? launch_sym_one<84, 6, 4, SampleT>(P, S, O, taps, x, n_blocks, counter0, stream, K) : launch_sym_one<84, 1, 1, SampleT>(P, S, O, taps, x, n_blocks, counter0, stream, K);
+    }
 }
 hipError_t launch_demod_sym(const Params &P, const State &S, const Output &O, const float4 *taps, const float *x,
                             uint32_t n_blocks, uint64_t counter0, hipStream_t stream, const PipeChunks &K)

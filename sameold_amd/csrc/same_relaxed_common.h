@@ -324,12 +324,12 @@ __device__ __forceinline__ void relax_centred_wait(RelaxCentredGroup &R)
                    "+v"(R.t[0]), "+v"(R.t[1]), "+v"(R.t[2]), "+v"(R.t[3]), "+v"(R.t[4]), "+v"(R.t[5]), "+v"(R.t[6])
                  : "n"(N));
 }
-template <int NT, int RING>
-__device__ __forceinline__ void demod_pair_centred(uint32_t ctaps_lds, uint32_t wlane_lds, uint32_t newest, float *hm_out, float *hs_out)
+// `wa`: LDS byte address of the lane's window slot that tap N-1 meets (the oldest of the NT samples, which must not wrap behind it)
+template <int NT>
+__device__ __forceinline__ void demod_pair_centred_at(uint32_t ctaps_lds, uint32_t wa, float *hm_out, float *hs_out)
 {
     constexpr int H = NT / 2, G = 7, NG = (H + G - 1) / G;
     static_assert(NT % 2 == 0 && NT - 1 <= 255, "tap pairs; ds_read2st64's 8-bit slot offsets");
-    const uint32_t wa = wlane_lds + (newest + (uint32_t)RING - (uint32_t)(NT - 1)) * (kWave * 4u);       // the slot tap N-1 meets
     using Group = RelaxCentredGroup;
     Group X, Y;
     float2v re[2] = {{0.0f, 0.0f}, {0.0f, 0.0f}}, im[2] = {{0.0f, 0.0f}, {0.0f, 0.0f}};      // [parity of k]: .x mark, .y space
@@ -376,6 +376,11 @@ __device__ __forceinline__ void demod_pair_centred(uint32_t ctaps_lds, uint32_t 
     const float2v q = __builtin_elementwise_fma(i, i, r * r);         // (|mark|^2, |space|^2)
     *hm_out = __builtin_amdgcn_sqrtf(q.x);
     *hs_out = __builtin_amdgcn_sqrtf(q.y);
+}
+template <int NT, int RING>
+__device__ __forceinline__ void demod_pair_centred(uint32_t ctaps_lds, uint32_t wlane_lds, uint32_t newest, float *hm_out, float *hs_out)
+{
+    demod_pair_centred_at<NT>(ctaps_lds, wlane_lds + (newest + (uint32_t)RING - (uint32_t)(NT - 1)) * (kWave * 4u), hm_out, hs_out);
 }
 
 // One AGC step, rx/agc.rs:72-77, as gain * (1 - bw |y|) + bw: the same update algebraically while gain >= 0 (the

@@ -212,17 +212,21 @@ def test_relaxed_batches_on_the_pipeline(sa, monkeypatch):
                         garbled_per_mille=(1 if noise > 0.0 else 0), t_end=n)
 
 
+@pytest.mark.parametrize("sym", ["1", "0"])
 @pytest.mark.parametrize("rate,n_ch", [(48000, 256), (44100, 128)])
-def test_relaxed_batches_on_the_pipeline_at_the_other_rates(sa, monkeypatch, rate, n_ch):
-    """44.1 and 48 kHz (84 / 92 taps): the pipeline's FASTMATH build in its one-workgroup-per-CU form, with the DC
-    wavefront.  Same contract; state carried over calls that are not whole blocks."""
+def test_relaxed_batches_on_the_pipeline_at_the_other_rates(sa, monkeypatch, rate, n_ch, sym):
+    """44.1 and 48 kHz (84 / 92 taps): since round 6 the symbol-paced pipeline in 72-sample steps, one group of 64 columns per CU
+    (same_kernels_sym.hip: SymGeom<84> / <92>); SAME_SYM=0 still selects round 3's FASTMATH build of the 32- / 36-sample
+    pipeline with the DC wavefront.  Same contract; state carried over calls that are not whole blocks."""
     monkeypatch.delenv("SAME_RELAXED_KERNEL", raising=False)
+    monkeypatch.setenv("SAME_SYM", sym)
+    kernel = "demod_sym_kernel" if sym == "1" else "demod_pipe_kernel<fastmath>"
     n = rate * 6
     for noise, seed in ((0.0, 81), (0.03, 82)):
         x = sa.synth_afsk(n_ch, n, rate, seed=seed, noise_sigma=noise)
         ref = strict_events(sa, x, rate)
         rx, got = relaxed_events(sa, x, rate, calls=[2 * rate + 11, 77, n - 2 * rate - 88])
-        assert rx.kernel_name() == "demod_pipe_kernel<fastmath>"
+        assert rx.kernel_name() == kernel
         assert_contract(sa, got, ref, rate, n_ch, lambda c: sa.synth_payload(seed, c), exact_bursts=(noise == 0.0), what=f"pipeline fastmath {rate}",
                         garbled_per_mille=(1 if noise > 0.0 else 0), t_end=n)
     # int16 input and a channel-major buffer (transposed on the device) give what f32 time-major gives
@@ -233,7 +237,7 @@ def test_relaxed_batches_on_the_pipeline_at_the_other_rates(sa, monkeypatch, rat
                        ("channel-major", lambda r: r.process_tensor(xi.t().contiguous(), layout=sa.LAYOUT_CHANNEL_MAJOR))):
         rx = sa.SameReceiverBuilder(rate).build_batch(n_ch, relaxed=True)
         feed(rx); rx.sync()
-        assert rx.kernel_name() == "demod_pipe_kernel<fastmath>"
+        assert rx.kernel_name() == kernel
         got = rx.poll_events_np()
         assert_contract(sa, got[np.lexsort((np.arange(len(got)), got["channel"]))], ref, rate, n_ch, lambda c: sa.synth_payload(84, c), what=f"{what} {rate}", t_end=n)
     # its soft symbols
@@ -242,7 +246,7 @@ def test_relaxed_batches_on_the_pipeline_at_the_other_rates(sa, monkeypatch, rat
     rel = sa.SameReceiverBuilder(rate).build_batch(64, trace_symbols=True, link_only=True, relaxed=True)
     for r in (full, rel):
         r.process_tensor(x); r.sync()
-    assert rel.kernel_name() == "demod_pipe_kernel<fastmath>"
+    assert rel.kernel_name() == kernel
     dt, err, sign_flips, checked = soft_symbol_differences(full, rel, 64, rate, every=5)
     stats = f"{len(dt)} symbols of {checked} bursts: instants max {dt.max()} samples apart, soft symbols max |diff| {err.max():.4f}, {sign_flips} sign differences"
     print(stats)
@@ -251,15 +255,15 @@ def test_relaxed_batches_on_the_pipeline_at_the_other_rates(sa, monkeypatch, rat
 
 
 def test_large_relaxed_batches_at_48_khz_stay_relaxed(sa, monkeypatch):
-    """More channels than the FASTMATH pipeline holds at once (16 384 at 44.1 / 48 kHz): its workgroups run in rounds; the batch
-    does not fall back to the strict kernels (round 4 did, whatever the flag said).  Same contract."""
+    """More channels than the relaxed pipeline holds at once (16 384 at 44.1 / 48 kHz: one group of 64 columns per CU): its workgroups
+    run in rounds; the batch does not fall back to the strict kernels (round 4 did, whatever the flag said).  Same contract."""
     monkeypatch.delenv("SAME_RELAXED_KERNEL", raising=False)
     rate, n_ch = 48000, 40960
     n = rate * 3
     x = sa.synth_afsk(n_ch, n, rate, seed=91)
     ref = strict_events(sa, x, rate)
     rx, got = relaxed_events(sa, x, rate, calls=[rate + 7, n - rate - 7])
-    assert rx.kernel_name() == "demod_pipe_kernel<fastmath>"
+    assert rx.kernel_name() == "demod_sym_kernel"
     assert_contract(sa, got, ref, rate, n_ch, lambda c: sa.synth_payload(91, c), what="40 960 channels at 48 kHz", t_end=n)
 
 
