@@ -16,7 +16,10 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-LIB = os.path.join(HERE, "libsame_rx.so")
+# SAME_BUILD_VARIANT=name (measurement builds: SAME_PROFILE / SAME_SYM_TL ...) keeps its objects and library apart from the
+# product's -- build/name/, libsame_rx.name.so -- and tools load it with SAME_LIB_VARIANT=name; the product never reads either.
+VARIANT = os.environ.get("SAME_BUILD_VARIANT", "")
+LIB = os.path.join(HERE, f"libsame_rx.{VARIANT}.so" if VARIANT else "libsame_rx.so")
 SOURCES = ["same_kernels.hip", "same_kernels_fast.hip", "same_kernels_pipe.hip", "same_kernels_relaxed.hip", "same_kernels_sym.hip", "same_synth.hip", "same_batch.cpp", "same_config.cpp", "same_transport.cpp", "same_place.cpp"]
 HEADERS = ["same_dev_common.h", "same_fast_common.h", "same_relaxed_common.h", "same_pipe_common.h", "same_profile.h", "same_device.h", "same_launch.h", "same_config.h", "same_transport.h", "../../include/same_rx.h",
            "../../include/same_place.h", "samedec_main.cpp"]
@@ -85,7 +88,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     objs = []
     digest = source_hash()
     cc = hipcc()
-    bdir = os.path.join(HERE, "build")
+    bdir = os.path.join(HERE, "build", VARIANT) if VARIANT else os.path.join(HERE, "build")
     os.makedirs(bdir, exist_ok=True)
     procs = []
     # Objects are re-used when nothing they are made of changed: the key is the source, every header (any of them may be

@@ -86,6 +86,7 @@ template <int NT> struct SymLayout {
     // 22.05 kHz: the taps live in registers (the LDS words are the profile builds' section marks); 44.1 / 48 kHz: the centred tap
     // table (NT / 2 entries of Re mark, Re space, Im mark, Im space) at the start of the group's LDS
     static constexpr uint32_t tap_floats = (uint32_t)((NT * 4 + PIPE_PROF_TAP_PAD + 63) / 64 * 64);
+    static constexpr uint32_t split_words = NT == 42 ? 0u : (2u + 8u) * kWave;
     static constexpr uint32_t sym_words = 5u * kWave;             // per parity: header, zero, sym, terr, until
     static constexpr uint32_t fb_words = kWave + 32u;             // per parity: one word per lane + the any-flag
     static constexpr uint32_t io_words = 3u * kWave;              // per parity: symbol word, burst-pool slot, burst length
@@ -96,7 +97,8 @@ template <int NT> struct SymLayout {
                                            kIoRingWords +                           // A's deadline ring and its count
                                            kWave +                                  // Y2 -> T: this lane has handed over
                                            kWave +                                  // the roles' progress words (six of them)
-                                           (SYM_TL_WORDS + 63u) / 64u * 64u;        // (timeline builds: their marks)
+                                           (SYM_TL_WORDS + 63u) / 64u * 64u +       // (timeline builds: their marks)
+                                           split_words;                             // 44.1 / 48 kHz: second instants' slots (per parity), A's partial sums
     static constexpr size_t lds_bytes = ((size_t)tap_floats + mail_words + (size_t)(RING + MIR) * kWave) * sizeof(float);
     static_assert(NT % 2 == 0 && NT - 1 <= 255, "tap pairs; ds_read2st64's 8-bit slot offsets");
     static_assert(SB % 4 == 0 && SB >= DCL + (DCL & 1), "16-byte loads per lane; the DC windows are the tail of a sub-block");
@@ -204,26 +206,70 @@ struct SymTaps {
     }
 };
 
-// The filter pair of a role-wavefront at any of the three rates: 22.05 kHz keeps its 42 taps in registers (SymTaps); 44.1 / 48 kHz
-// read the centred table from LDS beside the window (demod_pair_centred_at, same_relaxed_common.h: per tap pair one
-// ds_read2st64_b32 for both window samples, one ds_read_b128 for the four tap words, a packed add and two packed multiply-adds --
-// 184 tap registers next to 42 window words in flight do not fit a wavefront's 256).
-template <int NT> struct SymFilter {
-    uint32_t ctaps_lds;
-    __device__ __forceinline__ void load(const float4 *__restrict__, float *lds_group) { ctaps_lds = lds_addr(lds_group); }
+// 44.1 / 48 kHz: 42 / 46 tap pairs are 168 / 184 registers -- next to the window words in flight they do not fit a wavefront's 256,
+// and read from LDS (round 5's demod_pair_centred: one ds_read_b128 per pair) every group of seven pairs waits a whole LDS round trip
+// for 14 loads: the filter was 2 100 clk of E's 3 800-clk step.  So the two filter wavefronts split the TAPS, not the instants: A
+// holds pairs [0, H/2), E pairs [H/2, H) in registers, each adds its partial sums (Re / Im x mark / space) at BOTH instants of the
+// step's symbol, A hands its eight words per lane to E, and E finishes both magnitudes.  No tap loads, half the registers, and the
+// window loads of a whole instant (21 / 23) go out before the first product.
+template <int K, int NT>
+__device__ __forceinline__ void sym_win_load(float2v &w, uint32_t wa)
+{
+    asm volatile("ds_read2st64_b32 %0, %1 offset0:%2 offset1:%3" : "=&v"(w) : "v"(wa), "n"(K), "n"(NT - 1 - K) : "memory");
+}
+// (the loaded words' first consumer, sym_sum_diff, is a volatile asm like the loads and this wait: the three keep their order)
+template <int N>
+__device__ __forceinline__ void sym_win_wait()
+{
+    static_assert(N <= 15, "lgkmcnt is four bits");
+    asm volatile("s_waitcnt lgkmcnt(%0)" :: "n"(N) : "memory");
+}
+template <int NT, int K0, int K1>
+struct SymHalfTaps {
+    static constexpr int NP = K1 - K0, G = 8, NG = (NP + G - 1) / G;
+    static_assert(NP >= 1 && NP <= 24, "three groups of at most eight pairs");
+    float2v tc[NP], ts[NP];              // Re u_k (mark, space), Im u_k (mark, space), k = K0 + i
+    __device__ __forceinline__ void load(const float4 *__restrict__ taps)
+    {
+        sym_static_for<NP>([&](auto i_) __attribute__((always_inline)) {
+            constexpr int i = decltype(i_)::value;
+            const float4 t = taps[NT + K0 + i];
+            tc[i] = float2v{t.x, t.y}; ts[i] = float2v{t.z, t.w};
+            asm volatile("" : "+v"(tc[i]), "+v"(ts[i]));               // (vector registers: see SymTaps::load)
+        });
+    }
+    // this half's share of sum_k (w_k + w_{N-1-k}) Re u_k and of sum_k (w_k - w_{N-1-k}) Im u_k at the instant whose sample sits in ring slot n
     template <int RING>
-    __device__ __forceinline__ float demod(uint32_t wcol_lds, int n) const
+    __device__ __forceinline__ void partial(uint32_t wcol_lds, int n, float2v &re_out, float2v &im_out) const
     {
         int base = n - (NT - 1);
         base += base < 0 ? RING : 0;                          // slots RING .. RING + NT - 2 repeat slots 0 .. NT - 2
-        float hm, hs;
-        demod_pair_centred_at<NT>(ctaps_lds, wcol_lds + (uint32_t)base * (kWave * 4u), &hm, &hs);
-        return __builtin_amdgcn_fmed3f(hm - hs, -1.0f, 1.0f);
+        const uint32_t wa = wcol_lds + (uint32_t)base * (kWave * 4u);
+        float2v w[NP];
+        sym_static_for<NP>([&](auto i_) __attribute__((always_inline)) { constexpr int i = decltype(i_)::value; sym_win_load<K0 + i, NT>(w[i], wa); });
+        float2v re[2] = {{0.0f, 0.0f}, {0.0f, 0.0f}}, im[2] = {{0.0f, 0.0f}, {0.0f, 0.0f}};      // [parity of the pair]: two chains per sum
+        sym_static_for<NG>([&](auto g_) __attribute__((always_inline)) {
+            constexpr int g = decltype(g_)::value, i0 = g * G, i1 = (g + 1) * G < NP ? (g + 1) * G : NP;
+            constexpr int left = NP - i1;                     // loads still to land behind this group (LDS returns in order)
+            sym_win_wait<(left < 15 ? left : 15)>();
+            // (all sums / differences of a group first, then the products: a packed operation that reads the result of the
+            // instruction before it costs a wait state)
+            sym_static_for<i1 - i0>([&](auto j_) __attribute__((always_inline)) { constexpr int i = i0 + decltype(j_)::value; w[i] = sym_sum_diff(w[i]); });
+            sym_static_for<i1 - i0>([&](auto j_) __attribute__((always_inline)) {
+                constexpr int i = i0 + decltype(j_)::value;
+                pk_fma_lo(re[i & 1], w[i], tc[i]);
+                pk_fma_hi(im[i & 1], w[i], ts[i]);
+            });
+        });
+        re_out = re[0] + re[1]; im_out = im[0] + im[1];
     }
 };
-template <> struct SymFilter<42> : SymTaps<42> {
-    __device__ __forceinline__ void load(const float4 *__restrict__ taps, float *) { SymTaps<42>::load(taps); }
-};
+// |mark| - |space| clamped to +-1 (rx/demod.rs:156-164) from the whole sums
+__device__ __forceinline__ float sym_soft_sample(float2v r, float2v i)
+{
+    const float2v q = __builtin_elementwise_fma(i, i, r * r);          // (|mark|^2, |space|^2)
+    return __builtin_amdgcn_fmed3f(__builtin_amdgcn_sqrtf(q.x) - __builtin_amdgcn_sqrtf(q.y), -1.0f, 1.0f);
+}
 
 // ---------------------------------------------------------------------------------------------------------------------
 // T's sample half: input prefetch and DC blocker, one block ahead of S.  Inputs alternate between two register buffers
@@ -902,6 +948,10 @@ __global__ __launch_bounds__(SymGeom<NT>::HALVES * kSymRoles * kWave, NT == 42 ?
     // role is absorbed by the slack of the others instead of stalling the workgroup (measured with the barrier: every role
     // waited >= 730 clk of a 3 780-clk step although the longest worked 2 900), and the two halves never meet.
     lds_u32 *prog = donebox + kWave;                               // [6]
+    // 44.1 / 48 kHz (the filter wavefronts split the taps): ring slot of the symbol's SECOND instant per parity (-1: no symbol this
+    // step), and A's partial sums [instant B: re m, re s, im m, im s | instant A: the same][64]
+    lds_u32 *pos2box = prog + kWave + (SYM_TL_WORDS + 63u) / 64u * 64u;
+    lds_u32 *partbox = pos2box + 2u * kWave;
 #ifdef SAME_SYM_TL
     lds_u32 *tlbox = prog + kWave;
 #endif
@@ -1072,16 +1122,12 @@ __global__ __launch_bounds__(SymGeom<NT>::HALVES * kSymRoles * kWave, NT == 42 ?
         // ------------------------------------------ A: the matched-filter pair at the FIRST instant of the step's symbol; link events + wake-ups ----
         sym_setprio<sym_prio<NT>(2)>(P);
         const uint32_t wcol_lds = lds_addr(wcol);
-        SymFilter<NT> TP;
-        TP.load(taps, lds);
+        std::conditional_t<NT == 42, SymTaps<42>, SymHalfTaps<NT, 0, NT / 4>> TP;       // (44.1 / 48 kHz: the first half of the tap pairs)
+        TP.load(taps);
         Lane L;
         IoCtxLds X;
         X.chunk = chunkbox;
         if (lane == 0u) { chunkbox[0] = 0u; chunkbox[1] = kEvChunk; seqbox[0] = 0u; }      // nothing reserved yet; no pass posted yet
-        if constexpr (NT != 42) {                                      // 44.1 / 48 kHz: the centred tap table for both filter wavefronts
-            float4 *ctl = reinterpret_cast<float4 *>(lds);
-            for (uint32_t i = lane; i < (uint32_t)(NT / 2); i += kWave) ctl[i] = taps[NT + i];
-        }
         X.pending_slot = 0xffffffffu;
         X.tk = tkbox + lane;
         {
@@ -1105,11 +1151,27 @@ __global__ __launch_bounds__(SymGeom<NT>::HALVES * kSymRoles * kWave, NT == 42 ?
             // the filters at the positions E posted (E takes the second instant and waits for this one's soft sample)
             if (s >= 1u && s <= last_e_step) {
                 const uint32_t n1 = posbox[(s & 1u) * kWave + lane];
-                if (__builtin_amdgcn_ballot_w64(n1 != 0xffffffffu) != 0ull) {
-                    // (a profile build's knock-out skips the filter, never the hand-over E waits for)
-                    const float sa1 = PROF_SKIP(P, 256) ? 0.0f : TP.template demod<RING>(wcol_lds, n1 == 0xffffffffu ? 0 : (int)n1);
-                    sabox[lane] = __float_as_uint(sa1);
-                    if (lane == 0u) seqbox[0] = 2u * s + 1u;           // (LDS operations of a wavefront stay in order)
+                if constexpr (NT == 42) {
+                    if (__builtin_amdgcn_ballot_w64(n1 != 0xffffffffu) != 0ull) {
+                        // (a profile build's knock-out skips the filter, never the hand-over E waits for)
+                        const float sa1 = PROF_SKIP(P, 256) ? 0.0f : TP.template demod<RING>(wcol_lds, n1 == 0xffffffffu ? 0 : (int)n1);
+                        sabox[lane] = __float_as_uint(sa1);
+                        if (lane == 0u) seqbox[0] = 2u * s + 1u;       // (LDS operations of a wavefront stay in order)
+                    }
+                } else {
+                    // this wavefront's half of the taps at both instants of every lane's symbol (lanes without one: slot 0, unused)
+                    const uint32_t n2 = pos2box[(s & 1u) * kWave + lane];
+                    if (__builtin_amdgcn_ballot_w64(n2 != 0xffffffffu) != 0ull) {
+                        float2v r2 = {0.0f, 0.0f}, i2 = {0.0f, 0.0f}, r1 = {0.0f, 0.0f}, i1 = {0.0f, 0.0f};
+                        if (!PROF_SKIP(P, 256)) {
+                            TP.template partial<RING>(wcol_lds, n2 == 0xffffffffu ? 0 : (int)n2, r2, i2);
+                            if (__builtin_amdgcn_ballot_w64(n1 != 0xffffffffu) != 0ull) TP.template partial<RING>(wcol_lds, n1 == 0xffffffffu ? 0 : (int)n1, r1, i1);
+                        }
+                        lds_u32 *pb = partbox + lane;
+                        pb[0] = __float_as_uint(r2.x); pb[kWave] = __float_as_uint(r2.y); pb[2 * kWave] = __float_as_uint(i2.x); pb[3 * kWave] = __float_as_uint(i2.y);
+                        pb[4 * kWave] = __float_as_uint(r1.x); pb[5 * kWave] = __float_as_uint(r1.y); pb[6 * kWave] = __float_as_uint(i1.x); pb[7 * kWave] = __float_as_uint(i1.y);
+                        if (lane == 0u) seqbox[0] = 2u * s + 1u;
+                    }
                 }
             }
             SYM_TRACE(2, s, 3);
@@ -1150,8 +1212,8 @@ __global__ __launch_bounds__(SymGeom<NT>::HALVES * kSymRoles * kWave, NT == 42 ?
         // ------------------------------------------ E: one symbol per lane and step: the filter pair at its SECOND instant, timing loop ----
         sym_setprio<sym_prio<NT>(4)>(P);
         const uint32_t wcol_lds = lds_addr(wcol);
-        SymFilter<NT> TP;
-        TP.load(taps, lds);
+        std::conditional_t<NT == 42, SymTaps<42>, SymHalfTaps<NT, NT / 4, NT / 2>> TP;  // (44.1 / 48 kHz: the second half of the tap pairs)
+        TP.load(taps);
         Lane L;
         { const State S = fresh_state(); lane_load(L, S, c); }
         const float inv_spt = 1.0f / P.samples_per_ted;
@@ -1165,7 +1227,7 @@ __global__ __launch_bounds__(SymGeom<NT>::HALVES * kSymRoles * kWave, NT == 42 ?
         SYM_T_DECL();
         bool pl_typeA = false, pl_ready = false, pl_single = false;
         int pl_p2 = 0;
-        uint32_t pl_n2 = 0;
+        uint32_t pl_n2 = 0, pl_n1 = 0xffffffffu;
         float pl_rem1 = 0.0f, pl_instA = 0.0f, pl_c2 = 0.0f;
         auto plan = [&](uint32_t s) __attribute__((always_inline)) {
             pl_single = s > n_blocks;
@@ -1178,7 +1240,9 @@ __global__ __launch_bounds__(SymGeom<NT>::HALVES * kSymRoles * kWave, NT == 42 ?
             pl_ready = pl_p2 < 0 && s >= 1u && s <= last_e_step;
             auto slot = [&](int p) __attribute__((always_inline)) { int n = (int)wb + p; n += n < 0 ? RING : 0; return (uint32_t)n; };
             pl_n2 = pl_ready ? slot(pl_p2) : 0u;
-            posbox[(s & 1u) * kWave + lane] = (pl_ready && pl_typeA) ? slot(rel) : 0xffffffffu;
+            pl_n1 = (pl_ready && pl_typeA) ? slot(rel) : 0xffffffffu;
+            posbox[(s & 1u) * kWave + lane] = pl_n1;
+            if constexpr (NT != 42) pos2box[(s & 1u) * kWave + lane] = pl_ready ? pl_n2 : 0xffffffffu;
         };
         float sa1 = 0.0f, sa2 = 0.0f;
         // the filters of the step's symbol: its second instant here, its first on wavefront A
@@ -1187,18 +1251,40 @@ __global__ __launch_bounds__(SymGeom<NT>::HALVES * kSymRoles * kWave, NT == 42 ?
             if (__builtin_amdgcn_ballot_w64(pl_ready) != 0ull) {
                 SYM_T_BEGIN();
                 SYM_TCOUNT(20, 1);
-                sa2 = PROF_SKIP(P, 512) ? 0.0f : TP.template demod<RING>(wcol_lds, (int)pl_n2);
-                SYM_T_LAP(22);
-                if (__builtin_amdgcn_ballot_w64(pl_ready && pl_typeA) != 0ull) {
-                    // A has posted this pass (both wavefronts decide from the same posbox words whether there is one).  Bounded:
-                    // should the two ever disagree, the launch reports an error instead of hanging the GPU.
+                // A has posted this pass (both wavefronts decide from the same position words whether there is one).  Bounded:
+                // should the two ever disagree, the launch reports an error instead of hanging the GPU.
+                auto wait_for_a = [&]() __attribute__((always_inline)) {
                     uint32_t spins = 0;
                     while ((int32_t)(seqbox[0] - seq) < 0) {
                         __builtin_amdgcn_s_sleep(1);
                         if (++spins > spin_limit) { if (lane == 0u) atomicOr(err_flags, 4u); spin_limit = 8u; break; }
                     }
                     asm volatile("" ::: "memory");
-                    sa1 = __uint_as_float(sabox[lane]);
+                };
+                if constexpr (NT == 42) {
+                    sa2 = PROF_SKIP(P, 512) ? 0.0f : TP.template demod<RING>(wcol_lds, (int)pl_n2);
+                    SYM_T_LAP(22);
+                    if (__builtin_amdgcn_ballot_w64(pl_ready && pl_typeA) != 0ull) {
+                        wait_for_a();
+                        sa1 = __uint_as_float(sabox[lane]);
+                    }
+                } else {
+                    // the second half of the taps at both instants; A's half arrives through partbox
+                    float2v r2 = {0.0f, 0.0f}, i2 = {0.0f, 0.0f}, r1 = {0.0f, 0.0f}, i1 = {0.0f, 0.0f};
+                    const bool any_a = __builtin_amdgcn_ballot_w64(pl_n1 != 0xffffffffu) != 0ull;
+                    if (!PROF_SKIP(P, 512)) {
+                        TP.template partial<RING>(wcol_lds, (int)pl_n2, r2, i2);
+                        if (any_a) TP.template partial<RING>(wcol_lds, pl_n1 == 0xffffffffu ? 0 : (int)pl_n1, r1, i1);
+                    }
+                    SYM_T_LAP(22);
+                    wait_for_a();
+                    const lds_u32 *pb = partbox + lane;
+                    r2 += float2v{__uint_as_float(pb[0]), __uint_as_float(pb[kWave])}; i2 += float2v{__uint_as_float(pb[2 * kWave]), __uint_as_float(pb[3 * kWave])};
+                    sa2 = sym_soft_sample(r2, i2);
+                    if (any_a) {
+                        r1 += float2v{__uint_as_float(pb[4 * kWave]), __uint_as_float(pb[5 * kWave])}; i1 += float2v{__uint_as_float(pb[6 * kWave]), __uint_as_float(pb[7 * kWave])};
+                        sa1 = sym_soft_sample(r1, i1);
+                    }
                 }
                 SYM_T_LAP(24);
             }

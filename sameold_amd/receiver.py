@@ -20,7 +20,8 @@ from typing import Iterator, List, Optional, Sequence
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsame_rx.so")
+# (SAME_LIB_VARIANT: a measurement build made with SAME_BUILD_VARIANT, tools/ only -- see sameold_amd/build.py)
+LIB_PATH = os.path.join(_HERE, f"libsame_rx.{os.environ['SAME_LIB_VARIANT']}.so" if os.environ.get("SAME_LIB_VARIANT") else "libsame_rx.so")
 
 LINK_NO_CARRIER, LINK_SEARCHING, LINK_READING, LINK_BURST = 0, 1, 2, 3
 TRANSPORT_IDLE, TRANSPORT_ASSEMBLING, TRANSPORT_MSG_START, TRANSPORT_MSG_END, TRANSPORT_MSG_ERR = 16, 17, 18, 19, 20

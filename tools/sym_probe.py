@@ -62,9 +62,8 @@ def parity(n_ch=256, secs=10.0, noise=0.0, seed=11, chunked=False):
     print("transport messages equal:", ma == mb, flush=True)
 
 
-def timeit(n_ch, secs, reps=3, relaxed=True, tp=False, cm=False, chunks=0):
-    rate = 22050
-    n = int(rate * secs); n -= n % 180
+def timeit(n_ch, secs, reps=3, relaxed=True, tp=False, cm=False, chunks=0, rate=22050):
+    n = int(rate * secs); n -= n % 360
     x = sa.synth_afsk(n_ch, n, rate, seed=20260000)
     if cm:
         x = x.t().contiguous()
@@ -189,6 +188,14 @@ if what == "timeline":
     os.environ["SAME_SYM"] = "1"
     rx = timeit(32768, 2.0, reps=2); timeline(rx)
     rx = timeit(4096, 10.0, tp=True, cm=True, reps=2); timeline(rx)
+if what == "timeline48":
+    os.environ["SAME_SYM"] = "1"
+    for r in (48000, 44100):
+        rx = timeit(16384, 2.0, reps=2, rate=r); timeline(rx)
+if what == "quick48":
+    os.environ["SAME_SYM"] = "1"
+    for r in (48000, 44100):
+        timeit(16384, 2.0, reps=5, rate=r)
 if what == "quick":
     os.environ["SAME_SYM"] = "1"
     timeit(32768, 2.0, reps=5)
