@@ -488,6 +488,161 @@ struct SymDc {
     }
 };
 
+// T at 44.1 / 48 kHz (time-major rows, one group per CU: up to 256 registers).  The same DC blocker, but NOTHING IS COPIED: the
+// inputs of a sub-block stay in the buffer they were loaded into and ARE the history of the next one (three buffers in rotation: q - 1
+// the history, q being computed, q + 1 in flight), and the first-stage sums / averages alternate between two sets.  SymDc copies the
+// tail of every sub-block into history registers -- 36 64-bit moves per 36 samples at 48 kHz, 12 % of the instructions of the role
+// that paces configs[2].  The pattern repeats every six sub-blocks = three steps: PH = q mod 6 is a compile-time constant.
+template <typename SampleT, int NT>
+struct SymDcRot {
+    static constexpr int B = SymLayout<NT>::SB, DCL = SymLayout<NT>::DCL, RING = SymLayout<NT>::RING;
+    static constexpr int HL = DCL + (DCL & 1), OFF = (B - HL) / 2;          // the history: pairs OFF .. B/2 - 1 of the sub-block before
+    static constexpr uint32_t LP = kWave;
+    static_assert(B >= HL && (B - HL) % 2 == 0, "the history is the tail of a sub-block, in whole pairs");
+    typedef float2v Pairs[B / 2];
+    float sum0, sum1;                    // sum1: DCL x the reference's (even DCL), the reference's (DCL = 35)
+    Pairs xb[3];                         // inputs of sub-blocks q - 1, q, q + 1 (q mod 3)
+    Pairs mb[2];                         // first-stage sums (DCL = 35: averages) of sub-blocks q - 1, q (q mod 2)
+    uint32_t wpos = 0;                   // ring slot of the sub-block written next
+
+    __device__ __forceinline__ void request(Pairs &dst, const SampleT *__restrict__ x, uint32_t blk, uint32_t n_sub, uint32_t cin, uint32_t Cin) const
+    {
+        // (buffer loads with scalar row offsets: see SymDc::request)
+        const SampleT *xr = x + ((size_t)min(blk, n_sub - 1u) * B) * Cin;      // wave-uniform
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<SampleT *>(xr), 0, 0x7fffffff, 0x00020000);
+        const uint32_t voff = cin * (uint32_t)sizeof(SampleT);
+        const uint32_t row_bytes = Cin * (uint32_t)sizeof(SampleT);
+        auto one = [&](uint32_t k) __attribute__((always_inline)) -> float {
+            if constexpr (sizeof(SampleT) == 4) return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, voff, k * row_bytes, 0));
+            else return (float)(int16_t)__builtin_amdgcn_raw_buffer_load_b16(rs, voff, k * row_bytes, 0);
+        };
+        sym_static_for<B / 2>([&](auto h_) __attribute__((always_inline)) {
+            constexpr int h = decltype(h_)::value;
+            dst[h] = float2v{one(2u * h), one(2u * h + 1u)};
+        });
+    }
+    // history sample i (0 = oldest of HL) sits in the state ring's slot (dpos + i - (HL - DCL)) mod DCL
+    static __device__ __forceinline__ uint32_t ring_slot(uint32_t dpos, int i)
+    {
+        uint32_t s = dpos + (uint32_t)(i - (HL - DCL));
+        if (s >= (uint32_t)DCL) s -= (uint32_t)DCL;
+        return s;
+    }
+    // the state's history as "sub-block -1": buffer 2, set 1
+    __device__ __forceinline__ void load(const State &S, const SampleT *__restrict__ x, uint32_t c, uint32_t C, uint32_t cin, uint32_t Cin,
+                                         uint64_t counter0, uint32_t n_sub)
+    {
+        constexpr float up = (DCL & 1) ? 1.0f : (float)DCL;
+        sum0 = S.dc_sum0[c]; sum1 = S.dc_sum1[c] * up;
+        const uint32_t dpos = (uint32_t)(counter0 % (uint64_t)DCL);
+        sym_static_for<B / 2>([&](auto h_) __attribute__((always_inline)) {
+            constexpr int h = decltype(h_)::value;
+            xb[0][h] = float2v{0.0f, 0.0f}; xb[1][h] = float2v{0.0f, 0.0f}; xb[2][h] = float2v{0.0f, 0.0f};
+            mb[0][h] = float2v{0.0f, 0.0f}; mb[1][h] = float2v{0.0f, 0.0f};
+        });
+        sym_static_for<HL / 2>([&](auto h_) __attribute__((always_inline)) {
+            constexpr int h = decltype(h_)::value;
+            const uint32_t s1 = ring_slot(dpos, 2 * h + 1);
+            float x0 = 0.0f, m0 = 0.0f;
+            if constexpr (2 * h >= HL - DCL) {                     // (DCL = 35: history sample 0 is x[-36], which nothing reads)
+                const uint32_t s0 = ring_slot(dpos, 2 * h);
+                x0 = (S.dc_ff_ring + (size_t)s0 * C)[c]; m0 = (S.dc_fb_ring + (size_t)s0 * C)[c] * up;
+            }
+            xb[2][OFF + h] = float2v{x0, (S.dc_ff_ring + (size_t)s1 * C)[c]};
+            mb[1][OFF + h] = float2v{m0, (S.dc_fb_ring + (size_t)s1 * C)[c] * up};
+        });
+        request(xb[0], x, 0u, n_sub, cin, Cin);
+    }
+    // Sub-block q (PH = q mod 6): its successor's loads go out, then its DC-blocker outputs go into the window ring's next 36 slots
+    template <int PH>
+    __device__ __forceinline__ void sub(const Params &P, float *wcol, const SampleT *__restrict__ x, uint32_t q, uint32_t n_sub, uint32_t cin, uint32_t Cin)
+    {
+        constexpr int I = PH % 3, IP = (PH + 2) % 3, IN = (PH + 1) % 3, J = PH % 2, JP = 1 - J;
+        request(xb[IN], x, q + 1u, n_sub, cin, Cin);
+        Pairs &X = xb[I], &XP = xb[IP], &M = mb[J], &MP = mb[JP];
+        float *y = wcol + wpos * LP;
+        wpos += (uint32_t)B;
+        if (wpos == (uint32_t)RING) wpos = 0u;
+        // the windows before this sub-block, oldest first, as pairs: 0 .. HL/2 - 1 the history (the tail of the one before), then this one's
+        auto xw = [&](auto i_) __attribute__((always_inline)) -> float2v {
+            constexpr int i = decltype(i_)::value;
+            if constexpr (i < HL / 2) return XP[OFF + i]; else return X[i - HL / 2];
+        };
+        auto sw = [&](auto i_) __attribute__((always_inline)) -> float2v {
+            constexpr int i = decltype(i_)::value;
+            if constexpr (i < HL / 2) return MP[OFF + i]; else return M[i - HL / 2];
+        };
+        if constexpr ((DCL & 1) == 0) {
+            // the exact-scaling form (SymDc::block): S1 = DCL sum1, y = x[-(DCL-1)] - S1 / DCL^2 in one fused multiply-add
+            constexpr float kScale = -1.0f / (float)(DCL * DCL);
+            static_assert((DCL & (DCL - 1)) == 0, "a power of two: the scalings are exact");
+            const float2v nscale = {kScale, kScale};
+            float s1_last = 0.0f;
+            sym_static_for<B / 2>([&](auto h_) __attribute__((always_inline)) {
+                constexpr int h = decltype(h_)::value;                     // samples k = 2 h, 2 h + 1
+                const float2v xo = xw(std::integral_constant<int, h>{});   // inputs 2 h - DCL, 2 h - DCL + 1
+                const float2v d0 = X[h] - xo;
+                const float s0a = sum0 + d0.x, s0b = s0a + d0.y;
+                sum0 = s0b;
+                const float2v s0 = {s0a, s0b};
+                M[h] = s0;
+                const float2v d1 = s0 - sw(std::integral_constant<int, h>{});
+                const float s1a = sum1 + d1.x, s1b = s1a + d1.y;
+                sum1 = s1b;
+                if constexpr (h == 0) {
+                    y[0] = __builtin_fmaf(s1a, kScale, xo.y);
+                } else {
+                    const float2v yy = __builtin_elementwise_fma(float2v{s1_last, s1a}, nscale, xo);
+                    y[(2 * h - 1) * LP] = yy.x; y[(2 * h) * LP] = yy.y;
+                }
+                s1_last = s1b;
+                if constexpr (h == B / 2 - 1) y[(B - 1) * LP] = __builtin_fmaf(s1b, kScale, xw(std::integral_constant<int, h + 1>{}).x);
+            });
+        } else {
+            // DCL = 35 (SymDc::block): every operation of the reference, in its order
+            const float inv = P.dc_inv_len;
+            const float2v inv2 = {inv, inv};
+            sym_static_for<B / 2>([&](auto h_) __attribute__((always_inline)) {
+                constexpr int h = decltype(h_)::value;
+                const float2v xlo = xw(std::integral_constant<int, h>{}), xhi = xw(std::integral_constant<int, h + 1>{});
+                const float d0a = X[h].x - xlo.y, d0b = X[h].y - xhi.x;
+                const float s0a = sum0 + d0a, s0b = s0a + d0b;
+                sum0 = s0b;
+                const float2v m0 = float2v{s0a, s0b} * inv2;
+                M[h] = m0;
+                const float2v mlo = sw(std::integral_constant<int, h>{}), mhi = sw(std::integral_constant<int, h + 1>{});
+                const float d1a = m0.x - mlo.y, d1b = m0.y - mhi.x;
+                const float s1a = sum1 + d1a, s1b = s1a + d1b;
+                sum1 = s1b;
+                const float2v yy = xhi - float2v{s1a, s1b} * inv2;
+                y[(2 * h) * LP] = yy.x; y[(2 * h + 1) * LP] = yy.y;
+            });
+        }
+    }
+    // `q_last`: the last sub-block computed (its inputs and sums are the history the state keeps)
+    __device__ __forceinline__ void store(const State &S, uint32_t c, uint32_t C, uint64_t counter1, uint32_t q_last)
+    {
+        constexpr float inv = (DCL & 1) ? 1.0f : 1.0f / (float)DCL;
+        S.dc_sum0[c] = sum0; S.dc_sum1[c] = sum1 * inv;
+        const uint32_t dpos = (uint32_t)(counter1 % (uint64_t)DCL);
+        const uint32_t i3 = q_last % 3u, j2 = q_last & 1u;             // wave-uniform
+        sym_static_for<HL / 2>([&](auto h_) __attribute__((always_inline)) {
+            constexpr int h = decltype(h_)::value;
+            // (values first, then the choice: a `?:` of two array elements selects an ADDRESS, and the arrays stay in scratch memory)
+            float2v x0 = xb[0][OFF + h], x1 = xb[1][OFF + h], x2 = xb[2][OFF + h], m0 = mb[0][OFF + h], m1 = mb[1][OFF + h];
+            asm volatile("" : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(m0), "+v"(m1));
+            const float2v xh = i3 == 0u ? x0 : (i3 == 1u ? x1 : x2);
+            const float2v mh = j2 == 0u ? m0 : m1;
+            if constexpr (2 * h >= HL - DCL) {
+                const uint32_t s0 = ring_slot(dpos, 2 * h);
+                (S.dc_ff_ring + (size_t)s0 * C)[c] = xh.x; (S.dc_fb_ring + (size_t)s0 * C)[c] = mh.x * inv;
+            }
+            const uint32_t s1 = ring_slot(dpos, 2 * h + 1);
+            (S.dc_ff_ring + (size_t)s1 * C)[c] = xh.y; (S.dc_fb_ring + (size_t)s1 * C)[c] = mh.y * inv;
+        });
+    }
+};
+
 // ---------------------------------------------------------------------------------------------------------------------
 // S: AGC over the window ring's newest block, in place (T left the DC blocker's outputs there), and the gain a lock freezes
 // ---------------------------------------------------------------------------------------------------------------------
@@ -1050,6 +1205,49 @@ __global__ __launch_bounds__(SymGeom<NT>::HALVES * kSymRoles * kWave, NT == 42 ?
     } else if (role == 1u) {
         // ------------------------------------------ T: input prefetch and DC blocker of block s + 1 --------------------
         sym_setprio<sym_prio<NT>(1)>(P);
+        if constexpr (NT != 42) {
+            // 44.1 / 48 kHz: SymDcRot -- two sub-blocks a step, three input buffers in rotation (sub-block q in buffer q mod 3)
+            static_assert(CMODE == 0 && kNSUB == 2, "time-major rows, two sub-blocks a step");
+            SymDcRot<SampleT, NT> D;
+            const uint32_t n_sub = n_blocks * (uint32_t)kNSUB;
+            { const State S = fresh_state(); D.load(S, x, c, C, cin, Cin, counter0, n_sub); }
+            donebox[lane] = 0u;
+            D.template sub<0>(P, wcol, x, 0u, n_sub, cin, Cin);          // prologue: block 0's DC outputs
+            D.template sub<1>(P, wcol, x, 1u, n_sub, cin, Cin);
+            lds_barrier();
+            P3_T0();
+            uint32_t stop_at = 0xffffffffu;
+            auto step = [&](uint32_t s, auto ph_) __attribute__((always_inline)) -> bool {
+                constexpr int PH = 2 * decltype(ph_)::value;              // block s + 1 = sub-blocks 2 (s + 1), 2 (s + 1) + 1: PH = 2 ((s + 1) mod 3)
+                uint32_t w1, w2;
+                SYM_TRACE(1, s, 0);
+                wait_for(s, R_A | R_E, &w1, &w2, kNapLong);                          // the filters are done with the ring block this step overwrites
+                SYM_TRACE(1, s, 1);
+                P3_LAP(p3_wait);
+                if (s + 1u < n_blocks && !PROF_SKIP(P, 128)) {
+                    D.template sub<PH>(P, wcol, x, 2u * (s + 1u), n_sub, cin, Cin);
+                    D.template sub<PH + 1>(P, wcol, x, 2u * (s + 1u) + 1u, n_sub, cin, Cin);
+                }
+                if (may_leave) {                                                     // (wave-uniform; only a time-parallel piece hands over)
+                    wait_for(s, R_Y2, &w1, &w2, kNapLong);                           // has Y2 called the hand-over?
+                    if (flags_of_last(w2, s) & Y2F_LEAVE) stop_at = s;
+                }
+                SYM_TRACE(1, s, 2);
+                publish(s, 0u, 0u);
+                P3_LAP(p3_work);
+                return s == stop_at;
+            };
+            bool left = false;
+            for (uint32_t s = 0; s < n_steps && !left; s += 3u) {
+                left = step(s, std::integral_constant<int, 1>{});
+                if (!left && s + 1u < n_steps) left = step(s + 1u, std::integral_constant<int, 2>{});
+                if (!left && s + 2u < n_steps) left = step(s + 2u, std::integral_constant<int, 0>{});
+            }
+            SYM_REPORT(1);
+            if (left || gave_up()) return;
+            { const State S = fresh_state(); D.store(S, c, C, counter1, n_sub - 1u); }
+            return;
+        } else {
         using Dc = SymDc<SampleT, CMODE, NT>;
         Dc D;
         D.xl = xl; D.avail = avail_l;
@@ -1118,6 +1316,7 @@ __global__ __launch_bounds__(SymGeom<NT>::HALVES * kSymRoles * kWave, NT == 42 ?
         SYM_REPORT(1);
         if (left || gave_up()) return;
         { const State S = fresh_state(); D.store(S, c, C, counter1); }
+        }
     } else if (role == 2u) {
         // ------------------------------------------ A: the matched-filter pair at the FIRST instant of the step's symbol; link events + wake-ups ----
         sym_setprio<sym_prio<NT>(2)>(P);
