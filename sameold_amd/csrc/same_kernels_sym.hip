@@ -1120,16 +1120,29 @@ __global__ __launch_bounds__(SymGeom<NT>::HALVES * kSymRoles * kWave, NT == 42 ?
     // would be hours -- and the wavefront skips its state stores (`gave_up()`); the roles that wait for it follow the same way.
     uint32_t spin_limit = 1u << 22;
     auto gave_up = [&]() __attribute__((always_inline)) -> bool { return spin_limit != (1u << 22); };
+    // The progress words only grow, and a word that shows "step s - 1 completed" carries that step's flags whenever it was read (its
+    // writer cannot be two steps ahead of a reader, see flags_of_last): a wait first looks at the words this wavefront read LAST --
+    // `seen`, refreshed by peek() where a role has work to hide the LDS round trip behind -- and polls only if they do not say enough
+    // yet.  A self-bound role (most roles in most steps: the ones it waits for published long ago) used to spend 350-460 clk per
+    // wait on a read whose answer was old news.
+    // Measured (round 6, one box each): 44.1 / 48 kHz 2.18 -> 2.15 / 2.45 -> 2.42 ms; 22.05 kHz 1.885 -> 1.895 ms with the link layer
+    // alone and 1.92-2.00 -> 2.05-2.18 ms launch by launch with the transport layer on (twelve wavefronts per CU: roles that start
+    // sooner take issue slots from the ones on the step's critical chain) -- so the 22.05 kHz build keeps polling afresh.
+    constexpr bool kPeek = NT != 42;
+    uint32_t seen = 0u;
+    auto peek = [&]() __attribute__((always_inline)) { if constexpr (kPeek) seen = prog[prog_idx]; };
     auto wait_for = [&](uint32_t s, uint32_t deps, uint32_t *w_y1, uint32_t *w_y2, auto nap_) __attribute__((always_inline)) {
         constexpr int NAP = decltype(nap_)::value;
-        uint32_t v, spins = 0;
+        uint32_t v = seen, spins = 0;
+        if constexpr (!kPeek) v = prog[prog_idx];
         for (;;) {
-            v = prog[prog_idx];
             const uint32_t ok = (uint32_t)__builtin_amdgcn_ballot_w64(v >= (s << 16));     // (the flags below bit 16 cannot carry)
             if ((ok & deps) == deps) break;
-            __builtin_amdgcn_s_sleep(NAP);
+            if (!kPeek || spins != 0u) __builtin_amdgcn_s_sleep(NAP);
             if (++spins > spin_limit) { if (lane == 0u) atomicOr(err_flags, 4u); spin_limit = 8u; break; }
+            v = prog[prog_idx];
         }
+        if constexpr (kPeek) seen = v;
         // (the ordering of the roles' LDS traffic rests on these words: nothing the wait guards may be read before it -- the
         // compiler may move plain accesses across volatile ones, and the step barrier whose clobber used to stop it is gone)
         asm volatile("" ::: "memory");
@@ -1195,6 +1208,7 @@ __global__ __launch_bounds__(SymGeom<NT>::HALVES * kSymRoles * kWave, NT == 42 ?
             }
             if (s < n_blocks && !PROF_SKIP(P, 64)) M.block(P, wcol, s);
             SYM_TRACE(0, s, 2);
+            peek();                                                        // (the next step's first wait looks at these words)
             publish(s, 0u, 0u);
             P3_LAP(p3_work);
             if (s == stop_at) { left = true; break; }
@@ -1233,6 +1247,7 @@ __global__ __launch_bounds__(SymGeom<NT>::HALVES * kSymRoles * kWave, NT == 42 ?
                     if (flags_of_last(w2, s) & Y2F_LEAVE) stop_at = s;
                 }
                 SYM_TRACE(1, s, 2);
+                peek();                                                        // (the next step's first wait looks at these words)
                 publish(s, 0u, 0u);
                 P3_LAP(p3_work);
                 return s == stop_at;
@@ -1304,6 +1319,7 @@ __global__ __launch_bounds__(SymGeom<NT>::HALVES * kSymRoles * kWave, NT == 42 ?
                 if (flags_of_last(w2, s) & Y2F_LEAVE) stop_at = s;
             }
             SYM_TRACE(1, s, 2);
+            peek();                                                        // (the next step's first wait looks at these words)
             publish(s, 0u, 0u);
             P3_LAP(p3_work);
             return s == stop_at;
@@ -1394,6 +1410,7 @@ __global__ __launch_bounds__(SymGeom<NT>::HALVES * kSymRoles * kWave, NT == 42 ?
             }
             if (s + 1u == n_steps) againbox[lane] = L.flags & F_TICK_AGAIN;      // (Y2 merges the flag bits)
             SYM_TRACE(2, s, 2);
+            peek();                                                        // (the next step's first wait looks at these words)
             publish(s, 0u, 0u);
             sym_setprio<sym_prio<NT>(2)>(P);
             P3_LAP(p3_work);
@@ -1573,6 +1590,7 @@ __global__ __launch_bounds__(SymGeom<NT>::HALVES * kSymRoles * kWave, NT == 42 ?
             }
             if (s + 1u == n_steps) phasebox[lane] = L.flags & F_TED_PHASE;       // (Y2 merges the phase bit)
             SYM_TRACE(3, s, 2);
+            peek();                                                        // (the next step's first wait looks at these words)
             publish(s, 0u, 0u);
             P3_LAP(p3_work);
             if (s == stop_at) { left = true; break; }
@@ -1678,6 +1696,7 @@ __global__ __launch_bounds__(SymGeom<NT>::HALVES * kSymRoles * kWave, NT == 42 ?
             }
             if (s + 1u == n_steps) flagbox[lane] = Q.L.flags & (F_AGC_LOCKED | F_BW_LOCKED | F_SQ_LOCK | F_EQ_MODE_MASK | F_EQ_BITS_MASK);   // (Y2 merges the flag bits)
             SYM_TRACE(4, s, 2);
+            peek();                                                        // (the next step's first wait looks at these words)
             publish(s, flags, flags_before);
             flags_before = flags;
             P3_LAP(p3_work);
@@ -1786,6 +1805,7 @@ __global__ __launch_bounds__(SymGeom<NT>::HALVES * kSymRoles * kWave, NT == 42 ?
                 }
             }
             SYM_TRACE(5, s, 2);
+            peek();                                                        // (the next step's first wait looks at these words)
             publish(s, flags, flags_before);
             flags_before = flags;
             P3_LAP(p3_work);
