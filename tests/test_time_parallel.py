@@ -462,7 +462,8 @@ def test_per_channel_boundaries_at_the_other_rates(sa, ob, arith, rate, n_ch, ch
     rx.time_parallel_config(max_chunks=chunks)
     rx.process_tensor(xc, layout=sa.LAYOUT_CHANNEL_MAJOR)
     rx.sync()
-    assert not rx.time_parallel_per_channel() and rx.kernel_name() == ("demod_pipe_kernel" if arith == "strict" else "demod_sym_kernel")
+    # (the last slab of a call may be too short to cut: an ordinary strict launch, whose name is then the last one reported)
+    assert not rx.time_parallel_per_channel() and rx.kernel_name() in (("demod_pipe_kernel",) if arith == "strict" else ("demod_pipe_kernel", "demod_sym_kernel"))
     got = rx.poll_events_np()
     got = got[np.lexsort((np.arange(len(got)), got["channel"]))]      # (events come per launch)
     assert len(got[got["kind"] == 3]) >= 2 * n_ch
