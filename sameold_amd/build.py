@@ -47,7 +47,8 @@ def flags() -> list:
       + (["-DSAME_P1_SPLIT=1"] if os.environ.get("SAME_P1_SPLIT") else []) \
       + (["-DSAME_SYM_TL=1"] if os.environ.get("SAME_SYM_TL") else []) \
       + ([f"-DSYM_PRIOS=0x{os.environ['SAME_SYM_PRIOS']}"] if os.environ.get("SAME_SYM_PRIOS") else []) \
-      + ([f"-DSYM_TL_GROUP={int(os.environ['SAME_SYM_TL_GROUP'])}u"] if os.environ.get("SAME_SYM_TL_GROUP") else [])
+      + ([f"-DSYM_TL_GROUP={int(os.environ['SAME_SYM_TL_GROUP'])}u"] if os.environ.get("SAME_SYM_TL_GROUP") else []) \
+      + [f"-D{d}" for d in os.environ.get("SAME_EXTRA_DEFS", "").split() if d]      # (A/B builds of a variant: SAME_BUILD_VARIANT)
 
 
 def source_hash() -> str:

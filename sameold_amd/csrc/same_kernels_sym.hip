@@ -794,6 +794,164 @@ struct SymSquelch {
         L.sq_clock = -1;                                   // squelch.end() rx/codesquelch.rs:336-339
         eq_reset();                                        // Equalizer::reset rx/equalize.rs:191-196 (mode preserved)
     }
+    // ---- the select-committed form (round 6; -DSYM_Y1_SELECT: NOT the default) ----------------------------------------------------
+    // MEASURED SLOWER than symbol() below although it is fewer instructions in the listing (514 against 669 between the role's step
+    // marks, 105 moves against 177: tools/sym_role_mix.py) and delivers the same events bit for bit (tools/sym_hash.py: five digests
+    // equal): same box, three alternations -- 32 768 channels 1.887 against 1.858 ms, the headline launch 1.839 against 1.775, 48 kHz
+    // 2.49 against 2.45.  Every lane executing every masked step costs more issue slots than the moves it removes, and the moves at
+    // the loop head stay (the rare regions' results live in other registers than the loop's, and the compiler copies on the hot
+    // edge).  Kept as the differential form of symbol(): what the round-5 review's item 1a asked to be tried.
+    // Y1's state is ~60 registers (equalizer 20, its snapshot 20, squelch and byte clock), and symbol() below changes them inside
+    // exec-mask regions nested three deep: for every value that leaves a divergent region changed on some lanes the compiler keeps
+    // two copies -- 177 of the 669 instructions between this role's step marks were register moves, 38 of them at the head of
+    // every step (tools/sym_role_mix.py).  Here nothing is changed under an exec mask: every lane computes the step, the lanes it
+    // applies to COMMIT it with selects, and what is rare (training at sync, restoring / taking the snapshot, end()) sits behind a
+    // wave-uniform branch on a ballot -- an ordinary join the register allocator resolves in place.  Same operations on the same
+    // values: a launch delivers what symbol() delivers, event for event (tools/sym_hash.py).
+    //
+    // Equalizer::estimate_symbol + evolve for the lanes in `act` (eq_symbol_relaxed, same_relaxed_common.h, with the commit masked);
+    // returns the decided bit
+    __device__ __forceinline__ uint32_t eq_step_masked(const Params &P, bool act, float in0, float in1)
+    {
+        const uint32_t mode = (L.flags & F_EQ_MODE_MASK) >> F_EQ_MODE_SHIFT;
+        float w[NFF];                                      // the feed-forward window with this symbol's two samples pushed
+        if constexpr (NFF >= 2) {
+#pragma unroll
+            for (int i = 0; i + 2 < NFF; ++i) w[i] = ffw[i + 2];
+            w[NFF - 2] = in0; w[NFF - 1] = in1;
+        } else {
+            w[0] = in1;
+        }
+        float f0 = 0.0f, f1 = 0.0f, q0 = 0.0f, q1 = 0.0f;
+#pragma unroll
+        for (int i = 0; i < NFF; ++i) {
+            if (i & 1) { f1 = __builtin_fmaf(w[NFF - 1 - i], ffc[i], f1); q1 = __builtin_fmaf(w[i], w[i], q1); }
+            else { f0 = __builtin_fmaf(w[NFF - 1 - i], ffc[i], f0); q0 = __builtin_fmaf(w[i], w[i], q0); }
+        }
+        constexpr auto fb_zero = [](int widx) { return ((NFB - 1 - widx) & 1) == 0; };      // (exact zeros in every other slot: eq_symbol_relaxed)
+        float fbs = 0.0f, qb = 0.0f;
+#pragma unroll
+        for (int i = 0; i < NFB; ++i) {
+            if (!fb_zero(NFB - 1 - i)) fbs = __builtin_fmaf(fbw[NFB - 1 - i], fbc[i], fbs);
+            if (!fb_zero(i)) qb = __builtin_fmaf(fbw[i], fbw[i], qb);
+        }
+        const float sym_val = (f0 + f1) - fbs;
+        const bool training = act & (mode == 2u), evolve = act & (mode != 0u);
+        const float sym_est = (mode == 2u) ? ((L.eq_word & 1u) ? 1.0f : -1.0f) : rs_signum(sym_val);
+        const float err = evolve ? sym_est - sym_val : 0.0f;                                // (0: the updates below add exact zeros)
+        L.eq_word = training ? L.eq_word >> 1 : L.eq_word;
+        L.eq_count = training ? L.eq_count + 1u : L.eq_count;
+        const uint32_t mode1 = (training && L.eq_count >= 32u) ? 1u : mode;
+        const float gf = P.eq_relaxation * __builtin_amdgcn_rcpf(P.eq_regularization + (q0 + q1));
+        const float gb = P.eq_relaxation * __builtin_amdgcn_rcpf(P.eq_regularization + qb);
+        const float ge = gf * err, gn = -(gb * err);
+#pragma unroll
+        for (int i = 0; i < NFF; ++i) ffc[i] = __builtin_fmaf(ge, w[NFF - 1 - i], ffc[i]);
+#pragma unroll
+        for (int i = 0; i < NFB; ++i) { if (!fb_zero(NFB - 1 - i)) fbc[i] = __builtin_fmaf(gn, fbw[NFB - 1 - i], fbc[i]); }
+#pragma unroll
+        for (int i = 0; i < NFF; ++i) ffw[i] = act ? w[i] : ffw[i];
+        if constexpr (NFB >= 2) {
+#pragma unroll
+            for (int i = 0; i + 2 < NFB; ++i) fbw[i] = act ? fbw[i + 2] : fbw[i];
+            fbw[NFB - 2] = act ? sym_est : fbw[NFB - 2];
+            fbw[NFB - 1] = act ? 0.0f : fbw[NFB - 1];
+        } else {
+            fbw[0] = act ? 0.0f : fbw[0];
+        }
+        L.flags = (L.flags & ~F_EQ_MODE_MASK) | (mode1 << F_EQ_MODE_SHIFT);
+        return sym_est >= 0.0f ? 1u : 0u;
+    }
+    // Equalizer::reset rx/equalize.rs:191-196 (mode preserved) + squelch.end() + the locks, for the lanes in `m`
+    __device__ __forceinline__ void end_masked(bool m)
+    {
+        L.flags = m ? (L.flags & ~(F_AGC_LOCKED | F_SQ_LOCK | F_BW_LOCKED)) : L.flags;
+        L.sq_clock = m ? -1 : L.sq_clock;
+#pragma unroll
+        for (int i = 0; i < NFF; ++i) { ffc[i] = m ? ((i == 0) ? 1.0f : 0.0f) : ffc[i]; ffw[i] = m ? 0.0f : ffw[i]; }
+#pragma unroll
+        for (int i = 0; i < NFB; ++i) { fbc[i] = m ? ((i == 0) ? 1.0f : 0.0f) : fbc[i]; fbw[i] = m ? 0.0f : fbw[i]; }
+    }
+    // One symbol for the lanes in `valid` (the others keep their state).  Returns the word for Y2 (0 without a symbol); *fb = the
+    // feedback word for S and E (0: none).
+    __device__ __forceinline__ uint32_t symbol_masked(const Params &P, bool valid, float zero, float sym, uint32_t off, uint32_t *fb)
+    {
+        const uint32_t before = L.flags & (F_AGC_LOCKED | F_BW_LOCKED);
+        // --- CodeAndPowerSquelch::input rx/codesquelch.rs:228-304
+        const uint32_t slot = (2u * nsym) & 63u;
+        const float eq_in0 = nxt0, eq_in1 = nxt1;          // history slots slot + 16 / + 17, requested a symbol ago
+        {
+            float *pn = hptr((slot + 18u) & 63u), *pw = hptr(slot);
+            const float l0 = pn[0], l1 = *reinterpret_cast<float *>(reinterpret_cast<char *>(pn) + hrow4);      // (every lane: the address is its own column's)
+            nxt0 = valid ? l0 : nxt0; nxt1 = valid ? l1 : nxt1;
+            if (valid) { pw[0] = zero; *reinterpret_cast<float *>(reinterpret_cast<char *>(pw) + hrow4) = sym; }      // (stores only: nothing leaves this region)
+        }
+        const uint32_t fill = min(64u, L.sq_fill + 2u);
+        L.sq_fill = valid ? fill : L.sq_fill;
+        const uint32_t data = (L.sq_data >> 1) | ((sym >= 0.0f) ? 0x80000000u : 0u);        // CodeCorrelator::search :421-428
+        L.sq_data = valid ? data : L.sq_data;
+        const uint32_t nerr = __popc(P.sync_word ^ data);
+        const float pwr = fmaxf(__builtin_fmaf(__builtin_fmaf(sym, sym, -L.sq_power), P.sq_bw, L.sq_power), 0.0f);   // PowerTracker::track :483-488
+        L.sq_power = valid ? pwr : L.sq_power;
+        const uint32_t phist = (L.sq_phist << 1) | ((pwr >= P.sq_power_close) ? 1u : 0u);
+        L.sq_phist = valid ? phist : L.sq_phist;
+        nsym += valid ? 1u : 0u;
+        const int32_t clock_before = L.sq_clock;           // byte clock before this symbol (-1: no sync)
+        const bool full = valid & (fill >= 64u);           // sample_history.is_full() :237
+        const bool locked = (L.flags & F_SQ_LOCK) != 0u;
+        const bool sync_now = full & !locked & (nerr <= P.sq_max_errors) & (pwr >= P.sq_power_open);     // :244-265
+        const bool adjusted = sync_now & (clock_before != 0);
+        const bool drop = full & !sync_now & (clock_before >= 0) & ((phist & 0x80000000u) == 0u);      // :266-273
+        int32_t clk = sync_now ? 0 : clock_before;
+        clk = drop ? -1 : clk;
+        const bool ready = full & (clk == 0);              // :277-303 byte clock
+        const bool reading = full & (clk > 0);
+        clk = ready ? 1 : (reading ? ((clk + 1) & 7) : clk);
+        L.sq_clock = clk;                                  // (unchanged where the lane has no symbol: full is false)
+        // Equalizer schedule: see symbol()
+        const bool act = (clock_before >= 0) & !adjusted & (ready | reading);
+        if (__builtin_expect(__builtin_amdgcn_ballot_w64(act) != 0ull, 1)) {
+            const uint32_t j = (uint32_t)(clock_before + 7) & 7u;   // clock 1..7 -> symbol 0..6, clock 0 -> 7
+            const uint32_t ebit = eq_step_masked(P, act, eq_in0, eq_in1);
+            uint32_t bits = (j == 0u) ? 0u : ((L.flags & F_EQ_BITS_MASK) >> F_EQ_BITS_SHIFT);
+            bits |= ebit << j;
+            L.flags = act ? ((L.flags & ~F_EQ_BITS_MASK) | (bits << F_EQ_BITS_SHIFT)) : L.flags;
+        }
+        uint32_t byte = (L.flags & F_EQ_BITS_MASK) >> F_EQ_BITS_SHIFT;
+        const bool train = ready & adjusted;
+        if (__builtin_expect(__builtin_amdgcn_ballot_w64(train) != 0ull, 0)) {
+            // sync acquired or the byte clock re-aligned (receiver.rs:423-446): lock AGC and loop bandwidth, train on the sync
+            // word over the oldest 16 samples of the history (rx/codesquelch.rs:288-294)
+            const bool back = train & (clock_before >= 0);         // drop the symbols equalized ahead for a byte the reference never forms
+#pragma unroll
+            for (int i = 0; i < NFF; ++i) { ffc[i] = back ? sffc[i] : ffc[i]; ffw[i] = back ? sffw[i] : ffw[i]; }
+#pragma unroll
+            for (int i = 0; i < NFB; ++i) { fbc[i] = back ? sfbc[i] : fbc[i]; fbw[i] = back ? sfbw[i] : fbw[i]; }
+            L.flags = train ? ((L.flags & ~F_EQ_MODE_MASK) | (2u << F_EQ_MODE_SHIFT) | F_AGC_LOCKED | F_BW_LOCKED) : L.flags;   // equalizer.train()
+            L.eq_word = train ? P.sync_word : L.eq_word; L.eq_count = train ? 0u : L.eq_count;
+            const uint32_t head = (2u * nsym) & 63u;       // oldest sample
+            float samples[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) samples[i] = *hptr((head + (uint32_t)i) & 63u);
+            uint32_t tb = 0u;
+#pragma unroll 1
+            for (int b = 0; b < 8; ++b) tb |= eq_step_masked(P, train, samples[2 * b], samples[2 * b + 1]) << b;
+            byte = train ? tb : byte;
+        }
+        // a re-alignment is still possible: remember the equalizer as of this completed byte
+        const bool snap = ready & ((L.flags & F_SQ_LOCK) == 0u);
+        if (__builtin_amdgcn_ballot_w64(snap) != 0ull) {
+#pragma unroll
+            for (int i = 0; i < NFF; ++i) { sffc[i] = snap ? ffc[i] : sffc[i]; sffw[i] = snap ? ffw[i] : sffw[i]; }
+#pragma unroll
+            for (int i = 0; i < NFB; ++i) { sfbc[i] = snap ? fbc[i] : sfbc[i]; sfbw[i] = snap ? fbw[i] : sfbw[i]; }
+        }
+        if (__builtin_expect(__builtin_amdgcn_ballot_w64(drop) != 0ull, 0)) end_masked(drop);      // lost sync: receiver.rs:410-422 -> end()
+        const uint32_t after = L.flags & (F_AGC_LOCKED | F_BW_LOCKED);
+        *fb = (valid & ((after != before) | drop)) ? (FB_VALID | ((after & F_AGC_LOCKED) ? FB_AGC : 0u) | ((after & F_BW_LOCKED) ? FB_BW : 0u) | (drop ? FB_END : 0u) | (off << 8)) : 0u;
+        return valid ? (YM_VALID | (ready ? YM_READY : 0u) | (adjusted ? YM_ADJUSTED : 0u) | (reading ? YM_READING : 0u) | (drop ? YM_DROP : 0u) |
+                        (byte << YM_BYTE_SHIFT) | (off << YM_OFF_SHIFT)) : 0u;
+    }
     // One symbol.  Returns the word for Y2; *fb = the feedback word for S and E (0: none).
     __device__ __forceinline__ uint32_t symbol(const Params &P, float zero, float sym, uint32_t off, uint32_t *fb)
     {
@@ -1660,8 +1818,14 @@ __global__ __launch_bounds__(SymGeom<NT>::HALVES * kSymRoles * kWave, NT == 42 ?
             if ((f2 & (Y2F_END | Y2F_LOCK)) && s >= 1u) {
                 const uint32_t from_y2 = fb2box[((s - 1u) & 1u) * LY::fb_words + lane];
                 const bool superseded = (last_msg & (YM_DROP | YM_ADJUSTED)) != 0u;
+#ifdef SYM_Y1_SELECT
+                Q.L.flags |= ((from_y2 & FB_SQLOCK) && !superseded) ? (uint32_t)F_SQ_LOCK : 0u;
+                const bool y2_end = (from_y2 & FB_END) && !superseded;
+                if (__builtin_expect(__builtin_amdgcn_ballot_w64(y2_end) != 0ull, 0)) Q.end_masked(y2_end);
+#else
                 if ((from_y2 & FB_SQLOCK) && !superseded) Q.L.flags |= F_SQ_LOCK;
                 if ((from_y2 & FB_END) && !superseded) Q.end();
+#endif
             }
             last_msg = 0u;
             uint32_t flags = 0u;
@@ -1669,6 +1833,26 @@ __global__ __launch_bounds__(SymGeom<NT>::HALVES * kSymRoles * kWave, NT == 42 ?
                 const lds_u32 *sb = symbox + ((s - 1u) & 1u) * LY::sym_words + lane;
                 const uint32_t hdr = sb[0], zero_w = sb[kWave], sym_w = sb[2 * kWave];
                 uint32_t msg = 0u, fbv = 0u;
+#ifdef SYM_Y1_SELECT
+                {
+                    const bool valid = (hdr & 1u) && !PROF_SKIP(P, 16);
+                    const uint32_t off = hdr >> 8;
+                    const float zero = __uint_as_float(zero_w), sym = __uint_as_float(sym_w);
+                    if (P.trace_cap && valid) {
+                        // the soft-symbol trace (tests): the counter is that of the sample after the symbol's
+                        const State S = fresh_state();
+                        const uint64_t counter = counter0 + (int64_t)row_l + (uint64_t)sym_index(s - 1u, off) + 1u;
+                        const uint32_t n = S.trace_n[c];
+                        if (n < P.trace_cap) {
+                            float *t = S.trace + ((size_t)c * P.trace_cap + n) * 4;
+                            t[0] = zero; t[1] = sym; t[2] = __uint_as_float(sb[3 * kWave]); t[3] = __uint_as_float(sb[4 * kWave]);
+                            S.trace_idx[(size_t)c * P.trace_cap + n] = counter;
+                        }
+                        S.trace_n[c] = n + 1;
+                    }
+                    msg = Q.symbol_masked(P, valid, zero, sym, off, &fbv);
+                }
+#else
                 if ((hdr & 1u) && !PROF_SKIP(P, 16)) {
                     const uint32_t off = hdr >> 8;
                     const float zero = __uint_as_float(zero_w), sym = __uint_as_float(sym_w);
@@ -1686,6 +1870,7 @@ __global__ __launch_bounds__(SymGeom<NT>::HALVES * kSymRoles * kWave, NT == 42 ?
                     }
                     msg = Q.symbol(P, zero, sym, off, &fbv);
                 }
+#endif
                 ybox[(s & 1u) * kWave + lane] = msg;
                 last_msg = msg;
                 if (__builtin_amdgcn_ballot_w64(fbv != 0u) != 0ull) {

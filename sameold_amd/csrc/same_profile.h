@@ -190,7 +190,11 @@ namespace same { static __device__ unsigned long long g_same_prof_trace[6 * 12 *
 #else
 #define SYM_TL_WORDS 0u
 #define SYM_PROFILE_EXPORTS()
+#ifdef SYM_ASM_MARKS   /* analysis listings only (tools/sym_role_mix.py): comments in the assembly where a role's step begins and ends */
+#define SYM_TRACE(role_, s_, k_) asm volatile("; SYMMARK " #role_ " " #k_)
+#else
 #define SYM_TRACE(role_, s_, k_) do {} while (0)
+#endif
 #endif
 #define FAST_MARKS_BEGIN(X_, lds_, nt_) do {} while (0)
 #define FAST_MARKS_START(X_) do {} while (0)
