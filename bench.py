@@ -41,7 +41,7 @@ HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 ac
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", choices=["configs1", "configs3"], default="configs1",
                     help="configs1: 4 096 channels x 10 s per GPU (the metric's configuration); configs3: 32 768 channels x 2 s per GPU "
@@ -511,7 +511,7 @@ def main():
     def pmc_traffic(kind):
         if args.traffic is not None:
             return args.traffic
-        for name in ("r05_traffic.json", "r04_traffic.json", "r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
+        for name in ("r06_traffic.json", "r05_traffic.json", "r04_traffic.json", "r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
             try:
                 with open(os.path.join(ROOT, "profiles", name)) as f:
                     tj = json.load(f)
@@ -526,19 +526,22 @@ def main():
         """What limits the kernel when it is not HBM (it is not): wavefront instructions per 64-column sample by kind and the fraction
         of a wavefront's cycles in which it issues a vector one, from the round's SQ counter pass over this same command (tools/profile_round.sh,
         profiles/r05_pmc_instruction_mix.txt); null when no pass has been filed."""
-        try:
-            with open(os.path.join(ROOT, "profiles", "r05_issue.json")) as f:
-                for ent in json.load(f):
-                    if ent.get("workload") == (workload or f"{C} ch x {T} samples") and ent.get("mode") == kind:
-                        return {"kind": "instruction_issue_per_wavefront", "valu_per_workgroup_sample": ent["valu_per_workgroup_sample"],
-                                "salu_per_workgroup_sample": ent.get("salu_per_workgroup_sample"), "lds_per_workgroup_sample": ent.get("lds_per_workgroup_sample"),
-                                "valu_issue_fraction_of_wave_cycles": ent["valu_issue_fraction_of_wave_cycles"],
-                                "note": "every role-wavefront of the symbol-paced pipeline is self-bound (profiles/r05_cycle_attribution.txt, light timeline): a launch is "
-                                        "the longest role's instructions of ANY kind at ~8-9 clk each with three wavefronts per SIMD (DESIGN.md 8)",
-                                "budget_for_60pct_hbm": "<= 21-27 VALU per 64-column sample (1 024 SIMDs x f / 4 instructions/s over 1.875e10 column-group samples/s at f = 1.8-2.35 GHz, 85 % busy)",
-                                "source": ent["source"]}
-        except Exception:
-            pass
+        for fname in ("r06_issue.json", "r05_issue.json"):
+            try:
+                with open(os.path.join(ROOT, "profiles", fname)) as f:
+                    for ent in json.load(f):
+                        if ent.get("workload") == (workload or f"{C} ch x {T} samples") and ent.get("mode") == kind:
+                            return {"kind": "instruction_issue_per_wavefront", "valu_per_workgroup_sample": ent["valu_per_workgroup_sample"],
+                                    "salu_per_workgroup_sample": ent.get("salu_per_workgroup_sample"), "lds_per_workgroup_sample": ent.get("lds_per_workgroup_sample"),
+                                    "valu_issue_fraction_of_wave_cycles": ent["valu_issue_fraction_of_wave_cycles"],
+                                    "note": "every role-wavefront of the symbol-paced pipeline is self-bound (profiles/r05_cycle_attribution.txt, light timeline): a launch is "
+                                            "the longest role's instructions of ANY kind; one wavefront issues an instruction per ~2.6 ns alone on its SIMD, per ~3.6 ns "
+                                            "with two neighbours (profiles/r06_ubench_simd.txt, DESIGN.md 8)",
+                                    "budget_for_60pct_hbm": "<= ~36 instructions of all kinds per 64-column sample at the measured issue rate (58 in round 5's count); "
+                                                            "the SMU shader clock under this kernel is 2.39 GHz (profiles/r05_clock_power.txt)",
+                                    "source": ent["source"]}
+            except Exception:
+                pass
         return None
 
     notes = {
@@ -562,12 +565,12 @@ def main():
             "ms_per_step": round(el / args.steps * 1e3, 3), "bursts_gathered_last_step": int(nb),
             "bursts_pass_after_the_timed_ones_rank0": int((st["kind"] == 3).sum()),
             "kernel": fc["kernel"], "layout": layouts.get(name, "time-major x[t][channel]"),
-            "roofline": {"bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "roofline": {"bound": "hbm", "binds_in_practice": "instruction_issue", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": pmc_traffic(name), "kernel_ms": round(kms, 4),
                          "demod_kernel_alone_ms": round(fc["demod_ms"], 4),
                          "algorithmic_bytes_per_launch": 4 * C * T,
-                         # `bound` names the roofline `frac` is priced against (the north star's: HBM); `limiter` is what the counters
-                         # say actually limits the kernel
+                         # `bound` names the roofline `frac` is priced against (the north star's and BASELINE.json's metric: HBM);
+                         # `binds_in_practice` / `limiter` are what the counters say limits the kernel -- no block of this line is HBM-bound
                          "limiter": pmc_issue(name), "note": notes[name]},
         }
         if name != "strict":
@@ -707,7 +710,7 @@ def main():
             torch.cuda.empty_cache()
             Cs, Ts = args.scaled_channels, int(args.rate * 2)
             x2 = sa.synth_afsk(Cs, Ts, args.rate, seed=777, device=local_rank)
-            n2 = max(args.steps, 10)          # enough passes for launch k+1 to hide harvest k (first wait and last drain are inside the timed region)
+            n2 = args.steps                   # every block of the line the same number of steps (round 5 doubled one block's: its ratio improved partly by the denominator)
             out["scaled"] = {"workload": f"{Cs} channels x {Ts} samples per step (per-GPU shard of BASELINE.json configs[3])"}
             ev_strict = None
             for label, kw in (("strict", {}), ("relaxed", {"relaxed": True})):
@@ -717,7 +720,7 @@ def main():
                 a2 = 4.0 * Cs * Ts / (k2 * 1e-3) / 1e9
                 blk = {"value": round(Cs * Ts * n2 / e2 / 1e6, 2), "unit": "Msamples/s", "kernel_ms": round(k2, 4), "steps": n2,
                        "ms_per_step": round(e2 / n2 * 1e3, 3), "kernel": rx2.kernel_name(),
-                       "roofline": {"bound": "hbm", "achieved": round(a2, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(a2 / HBM_PEAK_GBS, 5),
+                       "roofline": {"bound": "hbm", "binds_in_practice": "instruction_issue", "achieved": round(a2, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(a2 / HBM_PEAK_GBS, 5),
                                     "limiter": pmc_issue(label, f"{Cs} ch x {Ts} samples")}}
                 if label == "strict":
                     ev_strict = f2
@@ -737,8 +740,8 @@ def main():
                     out["scaled_big"] = {"workload": f"{Cb} channels x {Ts} samples per step"}
                     ev_b = None
                     # (the last launch is drained inside the timed region, one whole harvest that nothing overlaps: at 131 072 channels that
-                    # is ~7 ms, a fifth of a five-step figure -- twice the headline's steps keep it below a twelfth)
-                    nb = max(2 * args.steps, 10)
+                    # is ~7 ms -- a twentieth of this block's figure at the default 20 steps)
+                    nb = args.steps
                     for label, kw in (("strict", {}), ("relaxed", {"relaxed": True})):
                         rxb = sa.SameReceiverBuilder(args.rate).build_batch(Cb, device=local_rank, **kw)
                         rxb.set_kernel_timing(True)
@@ -746,7 +749,7 @@ def main():
                         ab = 4.0 * Cb * Ts / (kb * 1e-3) / 1e9
                         blk = {"value": round(Cb * Ts * nb / eb / 1e6, 2), "unit": "Msamples/s", "kernel_ms": round(kb, 4), "steps": nb,
                                "ms_per_step": round(eb / nb * 1e3, 3), "kernel": rxb.kernel_name(),
-                               "roofline": {"bound": "hbm", "achieved": round(ab, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ab / HBM_PEAK_GBS, 5)}}
+                               "roofline": {"bound": "hbm", "binds_in_practice": "instruction_issue", "achieved": round(ab, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ab / HBM_PEAK_GBS, 5)}}
                         if label == "strict":
                             ev_b = fb_
                             out["scaled_big"].update(blk)
@@ -779,12 +782,13 @@ def main():
                         "value": round(Cs * Tl * n4 / e4 / 1e6, 2), "unit": "Msamples/s", "kernel_ms": round(k4, 4), "steps": n4,
                         "ms_per_step": round(e4 / n4 * 1e3, 3), "kernel": rx4.kernel_name(), "chunks": int(rx4.time_parallel_chunks()),
                         "bursts_first_pass": int((f4["kind"] == 3).sum()),
-                        "roofline": {"bound": "hbm", "achieved": round(a4, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(a4 / HBM_PEAK_GBS, 5)}}
+                        "roofline": {"bound": "hbm", "binds_in_practice": "instruction_issue", "achieved": round(a4, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(a4 / HBM_PEAK_GBS, 5)}}
                     del rx4, x4c
                 except Exception as exc:      # (a smaller device memory: the block is extra evidence, never the headline)
                     out["scaled_long"] = {"skipped": repr(exc)[:200]}
                 torch.cuda.empty_cache()
-            # and configs[2]: 16384 channels at 48 kHz (92-tap filters, 32-sample blocks), 2 s per step
+            # and configs[2]: 16384 channels at 48 kHz (92-tap filters; strict: the pipeline's 32-sample blocks, relaxed: the symbol-paced
+            # pipeline's 72-sample steps, one group of 64 columns per CU -- round 6), 2 s per step
             C3, R3 = 16384, 48000
             T3 = R3 * 2
             x3 = sa.synth_afsk(C3, T3, R3, seed=778, device=local_rank)
@@ -797,7 +801,7 @@ def main():
                 a3 = 4.0 * C3 * T3 / (k3 * 1e-3) / 1e9
                 blk = {"value": round(C3 * T3 * n2 / e3 / 1e6, 2), "unit": "Msamples/s", "kernel_ms": round(k3, 4), "steps": n2,
                        "ms_per_step": round(e3 / n2 * 1e3, 3), "kernel": rx3.kernel_name(),
-                       "roofline": {"bound": "hbm", "achieved": round(a3, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(a3 / HBM_PEAK_GBS, 5)}}
+                       "roofline": {"bound": "hbm", "binds_in_practice": "instruction_issue", "achieved": round(a3, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(a3 / HBM_PEAK_GBS, 5)}}
                 if label == "strict":
                     ev3 = f3
                     out["configs2_48k"].update(blk)
