@@ -309,7 +309,7 @@ def test_soft_symbols_of_a_chunk_that_starts_fresh(sa, ob):
     assert err.max() <= SOFT_SYMBOL_TOLERANCE, stats
 
 
-def assert_awgn_tallies_equal(sa, got, ref, payloads, n, grid, strict_arithmetic, tight=False):
+def assert_awgn_tallies_equal(sa, got, ref, payloads, n, grid, strict_arithmetic, tight=False, trial_by_trial=True):
     """AWGN Monte-Carlo trials (configs[4]) decoded two ways.  Strict arithmetic on both sides: all but a handful of
     marginal trials decode to the same bytes.  Relaxed arithmetic on one side: at the grid points where noise puts bit
     errors into a burst, WHICH marginal symbols flip is chaotic in the last bit of the matched-filter sums, so there the
@@ -332,7 +332,8 @@ def assert_awgn_tallies_equal(sa, got, ref, payloads, n, grid, strict_arithmetic
         assert differ.sum() <= n // 100, f"{differ.sum()} of {n} trials decode differently"
     else:
         clean = ta["intact"] >= 0.99 * np.maximum(ta["trials"], 1)
-        assert clean.any() and np.all(differ[clean] <= 0.03 * ta["trials"][clean] + 2), (differ, clean)
+        if trial_by_trial:
+            assert clean.any() and np.all(differ[clean] <= 0.03 * ta["trials"][clean] + 2), (differ, clean)
         be_a, be_b = ta["bit_errors"].astype(np.float64), tb["bit_errors"].astype(np.float64)
         # (bit errors come in lumps -- a trial that loses byte sync for a while contributes dozens -- so a grid point's count is
         # a sum over a handful of trials and moves by a lump when one marginal trial decodes the other way)
