@@ -362,6 +362,7 @@ struct SymDc {
                 X[2 * j] = float2v{buf.q[j].x, buf.q[j].y}; X[2 * j + 1] = float2v{buf.q[j].z, buf.q[j].w};
             });
         } else {
+            asm volatile("" :: "v"(buf.p[B / 2 - 1]));        // (one s_waitcnt for the block's loads instead of one per register: SymDcRot::sub)
             sym_static_for<B / 2>([&](auto h_) __attribute__((always_inline)) { X[decltype(h_)::value] = buf.p[decltype(h_)::value]; });
         }
     }
@@ -560,6 +561,9 @@ struct SymDcRot {
         constexpr int I = PH % 3, IP = (PH + 2) % 3, IN = (PH + 1) % 3, J = PH % 2, JP = 1 - J;
         request(xb[IN], x, q + 1u, n_sub, cin, Cin);
         Pairs &X = xb[I], &XP = xb[IP], &M = mb[J], &MP = mb[JP];
+        // (the compiler waits before the FIRST use of every loaded register, each time for one load more: 25 s_waitcnt per sub-block for
+        // loads that landed a sub-block ago.  Loads return in order: naming the youngest of this sub-block's first makes it ONE wait)
+        asm volatile("" :: "v"(X[B / 2 - 1]));
         float *y = wcol + wpos * LP;
         wpos += (uint32_t)B;
         if (wpos == (uint32_t)RING) wpos = 0u;
