@@ -31,10 +31,13 @@ def classify(name, wgs, state, n1):
     if "demod_relaxed_kernel" in name or "demod_duo_kernel" in name:
         return "scaled_big_relaxed"
     if "demod_sym_kernel" in name:
-        # <NFF, NFB, SampleT, input form>: the symbol-paced pipeline takes every relaxed launch; since round 5 a workgroup is
-        # twelve wavefronts = two groups of 64 state columns
+        # <NT, NFF, NFB, SampleT, input form> (round 6: NT first): the symbol-paced pipeline takes every relaxed launch; at 22.05 kHz a
+        # workgroup is twelve wavefronts = two groups of 64 state columns, at 44.1 / 48 kHz six wavefronts = one group
+        m = re.search(r"demod_sym_kernel<(\d+), \d+, \d+, \w+, (\d)>", name)
+        if m and int(m.group(1)) != 42:
+            return "configs2_48k_relaxed"
         cols = wgs * 128
-        if re.search(r"demod_sym_kernel<\d+, \d+, \w+, 1>", name):
+        if m and m.group(2) == "1":
             return "time_parallel"                             # per-lane input streams: the channel-major time-parallel launch (8 pieces: 32 768 columns)
         if cols == C:
             return "relaxed"
