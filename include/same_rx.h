@@ -166,14 +166,15 @@ enum {
      * not a multiple of 16 run as ordinary strict launches.  Not combinable with
      * SAME_BATCH_TRACE_SYMBOLS. */
     SAME_BATCH_TIME_PARALLEL = 1u << 3,
-    /* Relaxed arithmetic ("fast mode" of the north star; same_kernels_sym.hip at 22.05 kHz -- batches of any size in whole
-     * groups of 64 channels, and inside time-parallel chunks --, the FASTMATH build of same_kernels_pipe.hip at
-     * 44.1 / 48 kHz, same_kernels_relaxed.hip for 22.05 kHz batches that are not whole groups of 64).  The reference's algorithm and every decision of it, with the rounding of the floating-point
+    /* Relaxed arithmetic ("fast mode" of the north star; same_kernels_sym.hip at 22.05, 44.1 and 48 kHz -- batches of any size in
+     * whole groups of 64 channels, and inside time-parallel chunks --, same_kernels_relaxed.hip for 22.05 kHz batches that are not
+     * whole groups of 64).  The reference's algorithm and every decision of it, with the rounding of the floating-point
      * expressions given up: matched filters as fused multiply-adds into four partial sums instead of one newest-first
      * chain (rx/filter.rs:363-377), |mark| and |space| as an f32 square root instead of hypot (rx/demod.rs:163), the AGC
      * update as gain * (1 - bw |x|) + bw (rx/agc.rs:72-77), reciprocals for the timing loop's and the equalizer's
-     * divisions (the DC blocker keeps the reference's bits: its divisions by 16 are exact).  In same_kernels_sym.hip,
-     * additionally, the stages of the receiver run as wavefronts one 36-sample step apart, and what one stage feeds back
+     * divisions (the DC blocker keeps the reference's bits at every rate: divisions by 16 / 32 are exact, the 35-sample
+     * averages of 48 kHz are computed operation for operation).  In same_kernels_sym.hip,
+     * additionally, the stages of the receiver run as wavefronts one step apart (36 samples at 22.05 kHz, 72 at 44.1 / 48 kHz), and what one stage feeds back
      * to an earlier one arrives LATE by a fixed number of steps instead of at the sample of the symbol that caused it:
      *   - the lock at sync (AGC lock, locked loop bandwidth: receiver.rs:431-432) and what end() undoes (receiver.rs:479-490)
      *     take effect from the AGC's next block on -- a lock freezes the gain the AGC HAD at the symbol's sample, recomputed
@@ -190,7 +191,10 @@ enum {
      * time-parallel mode's, whose chunks run this arithmetic as well (SAME_RELAXED=0 in the environment keeps them
      * strict): transmitted burst bytes and transport messages EQUAL, link events within
      * SAME_TP_EVENT_TOLERANCE_SYMBOLS symbols, soft symbols of an open squelch within 0.05 with equal sign
-     * (tests/test_relaxed.py, tests/test_sym_kernel.py).  22.05, 44.1 and 48 kHz with the default DC-blocker length,
+     * (tests/test_relaxed.py, tests/test_sym_kernel.py; directly against the oracle at all three rates).  A stream fed in
+     * several calls meets the contract like one long call but is not bit-identical to it near a lock or an end(): at a call's end
+     * everything in flight between the stages is applied at once (the samples behind the last whole step go to the strict
+     * any-configuration kernel, which needs a canonical state).  22.05, 44.1 and 48 kHz with the default DC-blocker length,
      * default or disabled equalizer and a non-negative AGC floor (44.1 / 48 kHz: whole groups of 64 channels, any number
      * of them); any other configuration runs strict.  Strict mode (no flag) stays bit-exact. */
     SAME_BATCH_RELAXED = 1u << 4
