@@ -1314,6 +1314,9 @@ __global__ __launch_bounds__(SymGeom<NT>::HALVES * kSymRoles * kWave, NT == 42 ?
         *w_y1 = (uint32_t)__builtin_amdgcn_readlane((int)v, 4);
         *w_y2 = (uint32_t)__builtin_amdgcn_readlane((int)v, 5);
     };
+    // (Round 6: naps four times as long -- 4 / 16 -- measured equal, 1.892 / 1.806 ms against 1.87-1.88 / 1.80; and `s_wakeup` behind
+    // every publish, to end the sleepers' naps at once, ends in a memory access fault on this stack (gfx950, ROCm 7.2) although the
+    // assembler takes it: not used)
     constexpr std::integral_constant<int, 1> kNapShort{};
     constexpr std::integral_constant<int, 4> kNapLong{};
     // flags of step s - 1 in a progress word read at the start of step s.  Two parities: its writer may be ONE step further, never
