@@ -1,4 +1,6 @@
-// same_kernels_sym.hip -- the symbol-paced wavefront pipeline: relaxed arithmetic, 22.05 kHz, 36-sample steps.
+// same_kernels_sym.hip -- the symbol-paced wavefront pipeline: relaxed arithmetic; 22.05 kHz in 36-sample steps (two groups of 64
+// columns per CU), 44.1 / 48 kHz in 72-sample steps (one group per CU: SymGeom, SymDcRot, SymHalfTaps -- round 6).
+// What follows describes the 22.05 kHz form; the other rates differ in geometry only.
 //
 // The four-stage pipeline of same_kernels_pipe.hip steps in blocks of 20 samples, because a block may hold at most one
 // TED instant for the matched filters to be evaluated "after the block".  A symbol, however, is two instants (42.3
