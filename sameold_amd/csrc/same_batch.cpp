@@ -474,7 +474,7 @@ int ensure_stage(void **p, size_t *have, size_t need)
 }
 
 // The relaxed-arithmetic pipeline of a launch over Pv.n_channels state columns: the symbol-paced one (36-sample steps,
-// same_kernels_sym.hip) where it is built, else the FASTMATH build of the 20-sample pipeline
+// same_kernels_sym.hip; 72-sample steps at 44.1 / 48 kHz) where it is built, else the FASTMATH build of the strict pipeline
 // the configuration as the pipeline's FASTMATH build takes it: 64-channel workgroups, the split form
 same::Params fm_params(const same::Params &P)
 {
@@ -1126,14 +1126,15 @@ int process_time_major(same_batch *rx, const SampleT *d_x, size_t n_samples, hip
         // whole blocks (16 or 18 samples) go to the latency-optimised kernel when the
         // configuration has one; the generic kernel takes the remainder (and every other
         // configuration)
-        // SAME_BATCH_RELAXED on an ordinary launch of whole 64-channel groups: the symbol-paced pipeline at 22.05 kHz (any
-        // number of channels), the pipeline's FASTMATH build at 44.1 / 48 kHz (up to 32 768 channels); the one- / two-wavefront
-        // relaxed kernel takes batches that are not whole groups of 64 and whatever SAME_RELAXED_KERNEL=solo / duo sends it
+        // SAME_BATCH_RELAXED on an ordinary launch of whole 64-channel groups: the symbol-paced pipeline at 22.05, 44.1 and 48 kHz
+        // (any number of channels; SAME_SYM=0 puts the pipeline's FASTMATH build in its place -- round 5's relaxed kernel at 44.1 /
+        // 48 kHz, up to 32 768 channels); the one- / two-wavefront relaxed kernel takes batches that are not whole groups of 64 and
+        // whatever SAME_RELAXED_KERNEL=solo / duo sends it
         const same::Params Pfm = fm_params(rx->P);
         // (the symbol-paced pipeline takes any number of 64-channel workgroups: beyond two per CU they run in rounds -- and
         // it is the faster kernel at every channel count)
-        // (at 44.1 / 48 kHz the FASTMATH pipeline is the only relaxed kernel: beyond the 16 384 columns it holds at once its
-        // workgroups run in rounds -- round 4 sent such batches to the strict kernels whatever the flag said)
+        // (at 44.1 / 48 kHz a CU holds one group of 64 columns: beyond 16 384 columns the workgroups run in rounds -- round 4 sent
+        // such batches to the strict kernels whatever the flag said)
         const bool plain_fm = rx->relaxed_plain && rx->P.knob_relaxed_kernel == 0 && same::pipe_relaxed_supported(Pfm) &&
                               (rx->P.n_channels <= 32768u || (rx->P.n_channels <= rx->sym_max_channels && same::sym_kernel_supported(Pfm)) ||
                                !same::relaxed_kernel_supported(rx->P));
