@@ -219,13 +219,15 @@ __device__ __forceinline__ void sym_win_load(float2v &w, uint32_t wa)
 {
     asm volatile("ds_read2st64_b32 %0, %1 offset0:%2 offset1:%3" : "=&v"(w) : "v"(wa), "n"(K), "n"(NT - 1 - K) : "memory");
 }
-// (the loaded words' first consumer, sym_sum_diff, is a volatile asm like the loads and this wait: the three keep their order)
+// (the loaded words' first consumer, sym_sum_diff, is a volatile asm like the loads and this wait: the three keep their order; and
+// every word the wait covers is redefined behind it -- sym_win_landed -- so that nothing made of it before the wait can be used after)
 template <int N>
 __device__ __forceinline__ void sym_win_wait()
 {
     static_assert(N <= 15, "lgkmcnt is four bits");
     asm volatile("s_waitcnt lgkmcnt(%0)" :: "n"(N) : "memory");
 }
+__device__ __forceinline__ void sym_win_landed(float2v &w) { asm volatile("" : "+v"(w)); }
 template <int NT, int K0, int K1>
 struct SymHalfTaps {
     static constexpr int NP = K1 - K0, G = 8, NG = (NP + G - 1) / G;
@@ -254,6 +256,7 @@ struct SymHalfTaps {
             constexpr int g = decltype(g_)::value, i0 = g * G, i1 = (g + 1) * G < NP ? (g + 1) * G : NP;
             constexpr int left = NP - i1;                     // loads still to land behind this group (LDS returns in order)
             sym_win_wait<(left < 15 ? left : 15)>();
+            sym_static_for<i1 - i0>([&](auto j_) __attribute__((always_inline)) { sym_win_landed(w[i0 + decltype(j_)::value]); });
             // (all sums / differences of a group first, then the products: a packed operation that reads the result of the
             // instruction before it costs a wait state)
             sym_static_for<i1 - i0>([&](auto j_) __attribute__((always_inline)) { constexpr int i = i0 + decltype(j_)::value; w[i] = sym_sum_diff(w[i]); });
