@@ -94,6 +94,20 @@ def _pinned_bytes(tag: str, n_rows: int) -> torch.Tensor:
     return t
 
 
+def pinned_send_rows(n_rows: int) -> np.ndarray:
+    """A numpy view [>= n_rows, RECORD_BYTES] of the pinned host buffer `gather_records` stages its send from: a caller that
+    packs its records straight into it (`SameBatchReceiver.pack_bursts_np(out=...)`) saves the copy into the stage -- 7 MB per
+    step and rank at the bench's shapes, and a fresh array's page faults on top.  (Waits for the last send's host-to-device copy out
+    of this buffer, which finished long ago as a rule.)"""
+    ev = _send_done.get("ev")
+    if ev is not None:
+        ev.synchronize()
+    return _pinned_bytes("send", n_rows).numpy()
+
+
+_send_done: dict = {}
+
+
 _device_rows: dict = {}
 
 
@@ -109,11 +123,40 @@ def _device_rows_buffer(tag, rows: int, device) -> torch.Tensor:
     return t
 
 
-def gather_records(recs: np.ndarray, device: torch.device, dst: int = 0) -> Optional[np.ndarray]:
+class LandedRecords:
+    """What `gather_records(..., wait=False)` returns on the destination rank of a GPU gather: the records are on their way from
+    the device's receive buffer to a pinned host buffer on a side stream.  `len()` / `.shape` are known at once (the counts came
+    with the all_gather); `.numpy()` -- or `np.asarray(obj)` -- waits for the copy and returns the view (valid until the call
+    after next: two landing buffers alternate)."""
+
+    def __init__(self, land: torch.Tensor, total: int, done: "torch.cuda.Event"):
+        self._land, self._total, self._done = land, total, done
+        self.shape = (total, RECORD_BYTES)
+
+    def __len__(self) -> int:
+        return self._total
+
+    def numpy(self) -> np.ndarray:
+        self._done.synchronize()
+        return self._land[: self._total].numpy()
+
+    def __array__(self, dtype=None, copy=None):
+        a = self.numpy()
+        return a if dtype is None else a.astype(dtype)
+
+
+_side: dict = {}           # per device: the landing stream, the event of the last landing, which landing buffer is next
+
+
+def gather_records(recs: np.ndarray, device: torch.device, dst: int = 0, wait: bool = True):
     """Gather packed records ([n, RECORD_BYTES] uint8 per rank) on rank `dst`: one all_gather of
     the counts (a single tensor, one host synchronisation), one gather of the records padded to the largest count, through
     cached device and pinned host buffers.  Returns the concatenation on `dst` (rank order; on a GPU a view of the cached
-    landing buffer, valid until the next call), None elsewhere; the identity without a process group."""
+    landing buffer, valid until the next call), None elsewhere; the identity without a process group.
+
+    `wait=False` (GPU, destination rank): the device-to-host landing of the gathered records -- 8 x 7 MB per step at the bench's
+    shapes, over a millisecond of PCIe time that would otherwise sit on rank 0's step and, through the next all_gather, on every
+    rank's -- goes to a side stream and a `LandedRecords` comes back at once; whoever needs the bytes waits for them there."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return recs
     world, rank = dist.get_world_size(), dist.get_rank()
@@ -128,19 +171,43 @@ def gather_records(recs: np.ndarray, device: torch.device, dst: int = 0) -> Opti
         src = torch.from_numpy(np.ascontiguousarray(recs))
         if on_gpu:
             stage = _pinned_bytes("send", len(recs))[: len(recs)]
-            stage.copy_(src)
+            if src.data_ptr() != stage.data_ptr():             # (packed in place by the caller: pinned_send_rows)
+                stage.copy_(src)
             buf[: len(recs)].copy_(stage, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(device))
+            _send_done["ev"] = ev
         else:
             buf[: len(recs)] = src
     out = None
+    side = _side.setdefault(str(device), {"stream": None, "done": None, "flip": 0}) if (on_gpu and rank == dst) else None
     if rank == dst:
         big = _device_rows_buffer("recv", m * world, device)
         out = [big[r * m:(r + 1) * m] for r in range(world)]
+        if side is not None and side["done"] is not None:
+            torch.cuda.current_stream(device).wait_event(side["done"])       # the last landing has read the receive buffer
     dist.gather(buf, out, dst=dst)
     if rank != dst:
         return None
     total = sum(counts)
     if on_gpu:
+        if not wait:
+            if side["stream"] is None:
+                side["stream"] = torch.cuda.Stream(device)
+            side["flip"] ^= 1
+            land = _pinned_bytes("recv%d" % side["flip"], total)
+            arrived = torch.cuda.Event()
+            arrived.record(torch.cuda.current_stream(device))
+            side["stream"].wait_event(arrived)
+            with torch.cuda.stream(side["stream"]):
+                at = 0
+                for r in range(world):
+                    land[at: at + counts[r]].copy_(out[r][: counts[r]], non_blocking=True)
+                    at += counts[r]
+                done = torch.cuda.Event()
+                done.record(side["stream"])
+            side["done"] = done
+            return LandedRecords(land, total, done)
         land = _pinned_bytes("recv", total)
         at = 0
         for r in range(world):

@@ -40,3 +40,12 @@ def test_gather_records_device_path(monkeypatch):
         assert np.array_equal(got[: len(recs)], recs) and np.array_equal(got[len(recs):], recs)
     assert sd.gather_records(recs[:0], dev).shape[0] == 0
     assert sd.unpack_bursts(sd.gather_records(recs[:7], dev))[:7] == bursts[:7]
+    # wait=False (what the multi-GPU bench uses): the landing on a side stream; the count at once, the bytes on demand, two
+    # landing buffers so that the result of one call survives the next
+    a = sd.gather_records(recs, dev, wait=False)
+    b = sd.gather_records(recs[:100], dev, wait=False)
+    assert len(a) == 2 * len(recs) and a.shape == (2 * len(recs), sd.RECORD_BYTES) and len(b) == 200
+    ga, gb = a.numpy(), np.asarray(b)
+    assert np.array_equal(ga[: len(recs)], recs) and np.array_equal(ga[len(recs):], recs)
+    assert np.array_equal(gb[:100], recs[:100]) and np.array_equal(gb[100:], recs[:100])
+    assert len(sd.gather_records(recs[:0], dev, wait=False)) == 0
