@@ -49,3 +49,10 @@ def test_gather_records_device_path(monkeypatch):
     assert np.array_equal(ga[: len(recs)], recs) and np.array_equal(ga[len(recs):], recs)
     assert np.array_equal(gb[:100], recs[:100]) and np.array_equal(gb[100:], recs[:100])
     assert len(sd.gather_records(recs[:0], dev, wait=False)) == 0
+    # records packed straight into the pinned buffer the gather sends from (what bench.py's ranks do: no copy into the stage)
+    for n in (len(recs), 500):
+        view = sd.pinned_send_rows(n + 1000)
+        assert view.shape[0] >= n + 1000 and view.shape[1] == sd.RECORD_BYTES
+        view[:n] = recs[:n]
+        got = sd.gather_records(view[:n], dev, wait=False).numpy()
+        assert np.array_equal(got[:n], recs[:n]) and np.array_equal(got[n:], recs[:n])
