@@ -399,3 +399,23 @@ def test_other_rates_awgn(sa):
     got = rx.poll_events_np()
     payloads = [sa.synth_payload(seed, c) for c in range(n)]
     assert_awgn_tallies_equal(sa, got, ref, payloads, n, grid, strict_arithmetic=False, tight="paced", trial_by_trial=False)
+
+
+@pytest.mark.parametrize("rate", [48000, 22050])
+def test_other_builder_settings_keep_the_kernel_and_the_contract(sa, rate):
+    """Settings that move the kernel's geometry checks (sym_kernel_supported: the shortest symbol against the step, the filters'
+    reach against the ring) or its arithmetic -- timing deviation and bandwidths, squelch thresholds, AGC bandwidth: the batch
+    stays on the symbol-paced kernel and meets the contract against strict mode with the same settings."""
+    n_ch, seed = 128, 1234
+    n = rate * 6
+    x = sa.synth_afsk(n_ch, n, rate, seed=seed)
+    for name, make in (("max deviation 0.02", lambda: sa.SameReceiverBuilder(rate).with_timing_max_deviation(0.02)),
+                       ("max deviation 0.005", lambda: sa.SameReceiverBuilder(rate).with_timing_max_deviation(0.005)),
+                       ("timing bandwidth 0.2 / 0.05", lambda: sa.SameReceiverBuilder(rate).with_timing_bandwidth(0.2, 0.05)),
+                       ("squelch power 0.05 / 0.1", lambda: sa.SameReceiverBuilder(rate).with_squelch_power(0.05, 0.1)),
+                       ("AGC bandwidth 0.02", lambda: sa.SameReceiverBuilder(rate).with_agc_bandwidth(0.02))):
+        ref = strict_events(sa, x, rate, builder=make())
+        rx = make().build_batch(n_ch, relaxed=True)
+        rx.process_tensor(x); rx.sync()
+        assert rx.kernel_name() == KERNEL, name
+        assert_contract(sa, ordered(rx.poll_events_np()), ref, rate, n_ch, lambda c: sa.synth_payload(seed, c), exact_bursts=True, what=name, t_end=n)
