@@ -246,6 +246,8 @@ struct same_batch {
         same::Params Pv{};
         same::State Sv{};
         void *blob = nullptr;
+        void *blob_fresh = nullptr;                           // the same layout, every column a freshly built receiver: the template a launch's prologue copies
+        size_t fresh_bytes = 0;                               // ... and how much of it a launch copies (the [rows][column] arrays; not the framer's rows)
         same::StateArrayDesc *d_desc_in = nullptr, *d_desc_out = nullptr;   // real -> wide, wide -> real
         uint32_t n_desc = 0;
         uint32_t *d_final_col = nullptr;
@@ -1021,13 +1023,25 @@ int ensure_wide_state(same_batch *rx, uint32_t columns)
     if (tp.kernel == same_batch::TimePar::kPipeRelaxed) { tp.Pv.knob_pipe_lanes = 64; tp.Pv.knob_pipe_share = 1; tp.Pv.knob_pipe_split = 1; tp.Pv.knob_pipe = 1; }
     if (columns > tp.cap_columns) {
         if (tp.blob) HIP_TRY(hipFree(tp.blob));
-        tp.blob = nullptr; tp.cap_columns = 0;
+        if (tp.blob_fresh) HIP_TRY(hipFree(tp.blob_fresh));
+        tp.blob = nullptr; tp.blob_fresh = nullptr; tp.cap_columns = 0;
         const size_t bytes = carve_state(tp.Pv, nullptr, tp.Sv);
         HIP_TRY(hipMalloc(&tp.blob, bytes));
         HIP_TRY(hipMemset(tp.blob, 0, bytes));
+        HIP_TRY(hipMalloc(&tp.blob_fresh, bytes));
         tp.cap_columns = columns;
     }
-    carve_state(tp.Pv, (char *)tp.blob, tp.Sv);
+    const size_t blob_bytes = carve_state(tp.Pv, (char *)tp.blob, tp.Sv);
+    {
+        // The template of a launch's fresh state columns (launch_tp_prologue): this layout with SameReceiver::from's state in
+        // every column (receiver.rs:539-558), made once per layout by the kernel that used to run over the columns of every launch
+        same::State Sf{};
+        carve_state(tp.Pv, (char *)tp.blob_fresh, Sf);
+        HIP_TRY(hipMemset(tp.blob_fresh, 0, blob_bytes));
+        HIP_TRY(same::launch_init_state(tp.Pv, Sf, 0, nullptr, 0));
+        HIP_TRY(hipDeviceSynchronize());
+        tp.fresh_bytes = (size_t)(reinterpret_cast<char *>(tp.Sv.fr_msg) - reinterpret_cast<char *>(tp.blob));      // (carved in 256-byte steps)
+    }
     std::vector<same::StateArrayDesc> in, out;
     list_state_arrays(rx->P, rx->S, tp.Sv, in);
     list_state_arrays(rx->P, tp.Sv, rx->S, out);
@@ -1064,6 +1078,7 @@ int process_time_major(same_batch *rx, const SampleT *d_x, size_t n_samples, hip
         const uint32_t n_chunks = plan_chunks(rx, n, geom, pc);
         rx->tp.last_chunks = n_chunks;
         sl.have_k = false;
+        bool sort_bins_empty = false;          // the launch's prologue kernel has emptied the event sort's bins
         same::Output O{};
         if (n_chunks > 1u) {
             // Time-parallel launch: every channel as n_chunks state columns side by side.
@@ -1078,12 +1093,12 @@ int process_time_major(same_batch *rx, const SampleT *d_x, size_t n_samples, hip
             if (rc) return rc;
             pc.handover = sl.d_handover;
             same_batch::TimePar &tp = rx->tp;
-            HIP_TRY(same::launch_counters(sl.d_counters, sl.h_counters_dev, 0, stream));
             sl.timed = rx->timing; if (sl.timed) HIP_TRY(hipEventRecord(sl.ev_start, stream));
-            // fresh receivers in every column, the channels' own state into chunk 0's columns
-            HIP_TRY(same::launch_init_state(tp.Pv, tp.Sv, 0, stream, C));
+            // fresh receivers in every column (with the hand-over records, the event sort's bins and the launch cursors: one
+            // kernel), then the channels' own state into chunk 0's columns
+            HIP_TRY(same::launch_tp_prologue(tp.blob, tp.blob_fresh, tp.fresh_bytes, sl.d_handover, sl.d_sort, columns, sl.d_counters, stream));
             HIP_TRY(same::launch_copy_state_columns(tp.d_desc_in, tp.n_desc, C, columns, nullptr, C, stream));
-            HIP_TRY(same::launch_fill_u64(sl.d_handover, columns, same::kNoHandover, stream));
+            sort_bins_empty = sl.sort_bins == columns;
             const SampleT *xp = d_x + done * C;
             const uint32_t total_blocks = (uint32_t)(n / fbk);
             hipError_t e;
@@ -1179,7 +1194,7 @@ int process_time_major(same_batch *rx, const SampleT *d_x, size_t n_samples, hip
         }
         if (sl.timed) HIP_TRY(hipEventRecord(sl.ev_stop, stream));
         HIP_TRY(same::launch_event_sort(sl.d_events, sl.d_counters, sl.event_cap, sl.sort_bins, sl.d_sort, sl.d_sort + sl.sort_bins,
-                                        sl.d_sorted, stream));
+                                        sl.d_sorted, stream, sort_bins_empty));
         HIP_TRY(same::launch_counters(sl.d_counters, sl.h_counters_dev, 1, stream));
         HIP_TRY(hipEventRecord(sl.ev_done, stream));
         sl.in_flight = true;
@@ -1288,7 +1303,6 @@ int process_channel_major_native(same_batch *rx, const float *d_x, size_t n, hip
     // way the bench and a stream step: 1.695 -> 1.732 (the shorter tail hides less of the next call's planning) -- not the default.
     const bool pair_groups = tp.sort_mode == 2 && tp.kernel == same_batch::TimePar::kPipeRelaxed && same::sym_kernel_supported(tp.Pv);
     const int sort_mode = pair_groups ? 0 : (tp.sort_mode >= 0 ? (tp.sort_mode ? 1 : 0) : (columns > 32768u ? 1 : 0));
-    HIP_TRY(same::launch_counters(sl.d_counters, sl.h_counters_dev, 0, stream));
     sl.timed = rx->timing; if (sl.timed) HIP_TRY(hipEventRecord(sl.ev_start, stream));
     // (sorted: the workgroups once more, longest first whatever their group -- those that wait for a free CU are then the short ones)
     const bool lpt = sort_mode != 0 || pair_groups;
@@ -1311,9 +1325,11 @@ int process_channel_major_native(same_batch *rx, const float *d_x, size_t n, hip
         HIP_TRY(hipStreamWaitEvent(stream, sl.ev_planned, 0));
     }
     if (lpt) { d_perm = d_perm2; d_wg = d_wg2; }
-    HIP_TRY(same::launch_init_state(tp.Pv, tp.Sv, 0, stream, C));
+    // fresh receivers in every column (with the hand-over records, the event sort's bins and the launch cursors: one kernel,
+    // launch_tp_prologue), then the channels' own state into chunk 0's columns
+    HIP_TRY(same::launch_tp_prologue(tp.blob, tp.blob_fresh, tp.fresh_bytes, sl.d_handover, sl.d_sort, columns, sl.d_counters, stream));
     HIP_TRY(same::launch_copy_state_columns(tp.d_desc_in, tp.n_desc, C, columns, nullptr, C, stream));
-    HIP_TRY(same::launch_fill_u64(sl.d_handover, columns, same::kNoHandover, stream));
+    const bool sort_bins_empty = sl.sort_bins == columns;
     pc.handover = sl.d_handover;
     pc.col_row0 = d_row0; pc.col_nominal = d_nom; pc.wg_blocks = d_wg; pc.col_perm = (sort_mode != 0 || pair_groups) ? d_perm : nullptr;
     pc.in_samples = n_call; pc.whole_samples = (uint32_t)n;
@@ -1357,7 +1373,7 @@ int process_channel_major_native(same_batch *rx, const float *d_x, size_t n, hip
     sl.end_blocks = rx->counter + n;
     if (sl.timed) HIP_TRY(hipEventRecord(sl.ev_stop, stream));
     HIP_TRY(same::launch_event_sort(sl.d_events, sl.d_counters, sl.event_cap, sl.sort_bins, sl.d_sort, sl.d_sort + sl.sort_bins,
-                                    sl.d_sorted, stream));
+                                    sl.d_sorted, stream, sort_bins_empty));
     HIP_TRY(same::launch_counters(sl.d_counters, sl.h_counters_dev, 1, stream));
     HIP_TRY(hipEventRecord(sl.ev_done, stream));
     sl.in_flight = true;
@@ -1575,6 +1591,7 @@ void same_batch_free(same_batch *rx)
         if (sl.h_geom) (void)hipHostFree(sl.h_geom);
     }
     if (rx->tp.blob) (void)hipFree(rx->tp.blob);
+    if (rx->tp.blob_fresh) (void)hipFree(rx->tp.blob_fresh);
     if (rx->tp.d_desc_in) (void)hipFree(rx->tp.d_desc_in);
     if (rx->tp.d_desc_out) (void)hipFree(rx->tp.d_desc_out);
     if (rx->tp.d_final_col) (void)hipFree(rx->tp.d_final_col);

@@ -15,6 +15,8 @@
 // Citations: file:line under /root/reference/crates/sameold/src/ ("rx/" = receiver/).
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+
 #include "same_dev_common.h"
 #include "same_device.h"
 #include "same_launch.h"
@@ -287,10 +289,13 @@ __global__ void ev_scatter_kernel(const DevEvent *__restrict__ ev, const uint32_
 }
 uint32_t event_sort_extra_words(uint32_t n_bins) { return (n_bins + kScanThreads - 1u) / kScanThreads; }
 hipError_t launch_event_sort(const DevEvent *ev, const uint32_t *counters, uint32_t cap, uint32_t n_bins, uint32_t *cnt, uint32_t *first,
-                             DevEvent *sorted, hipStream_t stream)
+                             DevEvent *sorted, hipStream_t stream, bool cnt_is_zero)
 {
-    hipError_t e = hipMemsetAsync(cnt, 0, (size_t)n_bins * sizeof(uint32_t), stream);
-    if (e != hipSuccess) return e;
+    // (cnt_is_zero: the launch's prologue kernel emptied the bins -- a memset on the stream costs a launch and a gap of its own)
+    if (!cnt_is_zero) {
+        hipError_t e = hipMemsetAsync(cnt, 0, (size_t)n_bins * sizeof(uint32_t), stream);
+        if (e != hipSuccess) return e;
+    }
     hipLaunchKernelGGL(ev_hist_kernel, dim3(256), dim3(256), 0, stream, ev, counters, cap, n_bins, cnt);
     const uint32_t scan_grid = (n_bins + kScanThreads - 1u) / kScanThreads;
     uint32_t *tot = first + n_bins + 1u;                   // (first: n_bins + 1 + event_sort_extra_words(n_bins) words)
@@ -659,6 +664,30 @@ hipError_t launch_tp_plan(const float *x, const TpPlan &g, float *energy, uint32
     return hipGetLastError();
 }
 
+// The start of a time-parallel launch in ONE kernel (round 6; it was init_state_kernel over the fresh columns -- a thread per
+// column walking ~230 strided words, 70 us for 32 768 columns -- then fill_u64, a memset and the cursor reset: ~90 us with their
+// gaps on the stream of a 1.75 ms demodulation launch).  Fresh receivers in every column: the state arrays are copied, 16 bytes a
+// thread, from a template blob that init_state_kernel filled once when the wide state was laid out (the channels' own state goes
+// over chunk 0's columns next: launch_copy_state_columns); no column has handed over; the event sort's bins are empty; the
+// launch cursors are zero.
+__global__ __launch_bounds__(256) void tp_prologue_kernel(uint4 *__restrict__ dst, const uint4 *__restrict__ src, size_t n16,
+                                                          uint64_t *__restrict__ handover, uint32_t *__restrict__ sort_cnt, uint32_t n_cols,
+                                                          uint32_t *__restrict__ counters)
+{
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = t; i < n16; i += stride) dst[i] = src[i];
+    for (size_t i = t; i < n_cols; i += stride) { handover[i] = kNoHandover; if (sort_cnt) sort_cnt[i] = 0u; }
+    if (t < 3 && counters) counters[t] = 0u;
+}
+hipError_t launch_tp_prologue(void *blob, const void *fresh, size_t bytes, uint64_t *handover, uint32_t *sort_cnt, uint32_t n_cols,
+                              uint32_t *counters, hipStream_t stream)
+{
+    const size_t n16 = bytes / 16;
+    const unsigned grid = (unsigned)std::min<size_t>((n16 + 255) / 256, 256 * 16);
+    hipLaunchKernelGGL(tp_prologue_kernel, dim3(grid ? grid : 1u), dim3(256), 0, stream, reinterpret_cast<uint4 *>(blob),
+                       reinterpret_cast<const uint4 *>(fresh), n16, handover, sort_cnt, n_cols, counters);
+    return hipGetLastError();
+}
 __global__ void fill_u64_kernel(uint64_t *p, size_t n, uint64_t v)
 {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;

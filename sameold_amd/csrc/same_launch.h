@@ -62,7 +62,7 @@ hipError_t launch_counters(uint32_t *dev, uint32_t *host_mapped, int publish, hi
 // order, their `channel` replaced by their index in the log), cnt [n_bins] scratch; counters[0] = events logged
 uint32_t event_sort_extra_words(uint32_t n_bins);      // words `first` needs behind its n_bins + 1 (the scan's workgroup totals)
 hipError_t launch_event_sort(const DevEvent *ev, const uint32_t *counters, uint32_t cap, uint32_t n_bins, uint32_t *cnt, uint32_t *first,
-                             DevEvent *sorted, hipStream_t stream);
+                             DevEvent *sorted, hipStream_t stream, bool cnt_is_zero = false);      // cnt_is_zero: the caller emptied cnt on this stream
 // (first_col: columns before it are left alone -- the time-parallel launches copy the channels' own state over them next)
 hipError_t launch_init_state(const Params &P, const State &S, int is_reset, hipStream_t stream, uint32_t first_col = 0);
 // Column copies between state blobs of different widths: for every array of `desc` (device memory,
@@ -77,6 +77,10 @@ hipError_t launch_chunk_final_column(const uint64_t *handover, uint32_t in_chann
 hipError_t launch_chunk_final_column_pc(const uint64_t *handover, const uint32_t *own_start, uint32_t in_channels, uint32_t n_chunks,
                                         uint64_t counter0, uint32_t *final_col, hipStream_t stream);
 hipError_t launch_fill_u64(uint64_t *p, size_t n, uint64_t v, hipStream_t stream);
+// The start of a time-parallel launch: blob[0 .. bytes) = fresh[0 .. bytes) (a template of freshly built receivers, 16-byte
+// multiples), handover[0 .. n_cols) = kNoHandover, sort_cnt[0 .. n_cols) = 0 (may be null), counters[0 .. 3) = 0 (may be null)
+hipError_t launch_tp_prologue(void *blob, const void *fresh, size_t bytes, uint64_t *handover, uint32_t *sort_cnt, uint32_t n_cols,
+                              uint32_t *counters, hipStream_t stream);
 // Per-channel chunk boundaries for a channel-major input (time-parallel mode): an energy scout over
 // one 64-byte sector per 256-sample block, then per channel the idle instant nearest to every nominal boundary.
 struct TpPlan {
