@@ -1250,7 +1250,7 @@ int process_channel_major_native(same_batch *rx, const float *d_x, size_t n, hip
     // (less than a block) goes through the any-configuration kernel on the channels' own state afterwards.
     const size_t n_call = n;
     n -= n % fb;
-    if (n_call % 4 != 0 || ((uintptr_t)d_x & 15u) != 0u || n < 64u * 256u || n / 256 > 7000u || n_chunks > 63u || C % same::kWave != 0u) return 0;
+    if (n_call % 4 != 0 || ((uintptr_t)d_x & 15u) != 0u || n < 64u * (size_t)same::tp_scout_block() || n / same::tp_scout_block() > 7000u || n_chunks > 63u || C % same::kWave != 0u) return 0;
     if (wave ? fb % 2 != 0 : (fb % 4 != 0 || same::pipe_workgroup_channels(Pv) != (uint32_t)same::kWave)) return 0;
     same_batch::Slot &sl = rx->slot[rx->launch_seq & 1];
     same_batch::Slot &prev = rx->slot[(rx->launch_seq & 1) ^ 1];
@@ -1283,7 +1283,7 @@ int process_channel_major_native(same_batch *rx, const float *d_x, size_t n, hip
         plan.warmup_samples = std::min(geom.warmup_blocks, (warm + fb - 1u) / fb) * fb;
     }
     plan.whole_samples = (uint32_t)n; plan.in_samples = n_call;
-    plan.scout_blocks = (uint32_t)(n / 256);
+    plan.scout_blocks = (uint32_t)(n / same::tp_scout_block());
     const size_t e_need = (size_t)C * plan.scout_blocks;
     if (tp.energy_cap < e_need) {
         if (tp.d_energy) HIP_TRY(hipFree(tp.d_energy));

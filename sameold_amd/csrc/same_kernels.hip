@@ -424,7 +424,11 @@ hipError_t launch_chunk_final_column_pc(const uint64_t *handover, const uint32_t
     return hipGetLastError();
 }
 // ---- per-channel chunk boundaries (channel-major input) ----------------------------------------------------------
-constexpr uint32_t kScoutBlock = 256;        // samples per energy reading (one 64-byte sector of them is read)
+#ifndef SAME_SCOUT_BLOCK
+#define SAME_SCOUT_BLOCK 256
+#endif
+constexpr uint32_t kScoutBlock = SAME_SCOUT_BLOCK;        // samples per energy reading (one 64-byte sector of them is read)
+uint32_t tp_scout_block() { return kScoutBlock; }
 __global__ void tp_scout_kernel(const float *__restrict__ x, TpPlan g, float *__restrict__ energy)
 {
     // four lanes per reading, 16 bytes each: a wavefront's load covers 16 sectors of 64 bytes (one lane per reading with
@@ -463,7 +467,7 @@ __global__ __launch_bounds__(kWave) void tp_boundaries_kernel(const float *__res
     float *e = tp_lds;                                             // [NB]
     int *lastq = reinterpret_cast<int *>(tp_lds + NB);             // [NB] latest allowed instant at or before block j (-1: none)
     int *cut = lastq + NB;                                         // [64]
-    constexpr int kQuietBefore = 8, kQuietAfter = 1;
+    constexpr int kQuietBefore = 2048 / (int)kScoutBlock, kQuietAfter = 1;
     float m = 0.0f;
     for (int j = (int)lane; j < NB; j += (int)kWave) { const float v = energy[(size_t)c * NB + j]; e[j] = v; m = fmaxf(m, v); }
     for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));

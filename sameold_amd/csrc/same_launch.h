@@ -83,6 +83,7 @@ hipError_t launch_tp_prologue(void *blob, const void *fresh, size_t bytes, uint6
                               uint32_t *counters, hipStream_t stream);
 // Per-channel chunk boundaries for a channel-major input (time-parallel mode): an energy scout over
 // one 64-byte sector per 256-sample block, then per channel the idle instant nearest to every nominal boundary.
+uint32_t tp_scout_block();      // samples per energy reading
 struct TpPlan {
     uint32_t channels, n_chunks, block_len, warmup_samples, whole_samples;
     uint64_t in_samples;      // pitch of a channel in the input
