@@ -106,6 +106,17 @@ struct PodQueue {                    // a plain growable array of PODs (no zero-
 };
 using EventQueue = PodQueue<QEvent>;
 using ByteArena = PodQueue<uint8_t>;     // payload bytes: element number = absolute offset
+// SAME_HOST_PROF (measurement builds: SAME_EXTRA_DEFS=SAME_HOST_PROF=1): time-stamp-counter totals of the replay's parts,
+// printed by same_debug_harvest_replay (one thread); nothing in the product build
+#ifdef SAME_HOST_PROF
+#include <x86intrin.h>
+static uint64_t g_hp[8];
+static const char *const g_hp_name[8] = {"range sort", "poll synthesis", "queue record + payload", "transport: burst", "transport: other", "after_event", "stitch scan", "-"};
+struct HpScope { int k; uint64_t t0; explicit HpScope(int k_) : k(k_), t0(__rdtsc()) {} ~HpScope() { g_hp[k] += __rdtsc() - t0; } };
+#define HP(k) HpScope hp_scope_##k(k)
+#else
+#define HP(k) do {} while (0)
+#endif
 struct HarvestPart {
     std::vector<QEvent> out;             // payload = offset into `bytes` until the part is appended to the queue
     std::vector<uint8_t> bytes;
@@ -262,6 +273,7 @@ struct same_batch {
         // when the batch is relaxed) or the one-wavefront relaxed kernel
         enum Kernel { kPipe = 0, kPipeRelaxed = 1, kWaveRelaxed = 2 } kernel = kPipe;
         int knob_kernel = 0;                                  // SAME_TP_KERNEL: 1 pipeline, 2 one-wavefront relaxed kernel, 0 choose
+        int knob_prologue = 0;                                // SAME_TP_PROLOGUE=0: init kernel, fill and cursor reset as separate launches (A/B measurements)
         std::vector<int64_t> sym_off;        // per channel: reported symbol count - the device's
         std::vector<TickSynth> synth;
     } tp;
@@ -409,6 +421,7 @@ void read_knobs(same_batch *rx)
     rx->host_threads = std::max(0, num("SAME_HOST_THREADS", 0));
     rx->tp.sort_mode = num("SAME_TP_SORT", -1);
     rx->tp.knob_plan_stream = tri("SAME_TP_PLAN_STREAM");
+    rx->tp.knob_prologue = tri("SAME_TP_PROLOGUE");
     rx->knob_relaxed = tri("SAME_RELAXED");
     { const char *e = std::getenv("SAME_RELAXED_KERNEL"); rx->P.knob_relaxed_kernel = !e ? 0 : (std::strcmp(e, "solo") == 0 ? 1 : (std::strcmp(e, "duo") == 0 ? 2 : 0)); }
     { const char *e = std::getenv("SAME_TP_KERNEL"); rx->tp.knob_kernel = !e ? 0 : (std::strcmp(e, "wave") == 0 ? 2 : (std::strcmp(e, "pipe") == 0 ? 1 : 0)); }
@@ -580,11 +593,15 @@ int harvest_host(same_batch *rx, same_batch::Slot &sl, uint32_t n_events, uint32
         auto poll = [&](uint64_t psym, uint64_t pt) {
             if (rx->tr(c).on_link_event(same::kDevTick, pt, psym, nullptr, 0, rx->P.input_rate, &tev)) push_transport(part, tev, c);
         };
-        if (tp && !link_only)
+        if (tp && !link_only) {
+            HP(1);
             rx->tp.synth[c].run_until(sym, d.sample_counter, sps, rx->tr(c).force_eom_at(), poll);
+        }
         QEvent q{};
-        q.kind = d.kind; q.channel = c; q.sample_counter = d.sample_counter; q.symbol_count = sym;
         const uint8_t *payload = nullptr;
+        {
+        HP(2);
+        q.kind = d.kind; q.channel = c; q.sample_counter = d.sample_counter; q.symbol_count = sym;
         if (d.kind == SAME_LINK_BURST) {
             q.len = d.burst_len;
             if (d.burst_slot < n_bursts) {
@@ -598,11 +615,15 @@ int harvest_host(same_batch *rx, same_batch::Slot &sl, uint32_t n_events, uint32
             part.bursts.push_back((uint32_t)part.out.size());
         }
         if (d.kind <= SAME_LINK_BURST) part.out.push_back(q);
+        }
         if (!link_only) {
+#ifdef SAME_HOST_PROF
+            HpScope hp_tr(d.kind == SAME_LINK_BURST ? 3 : 4);
+#endif
             if (rx->tr(c).on_link_event(d.kind, d.sample_counter, sym, payload, q.n_bytes, rx->P.input_rate, &tev)) push_transport(part, tev, c);
             if (!tp && rx->tr(c).force_eom_dirty()) part.rearm.push_back(c);
         }
-        if (tp && d.kind <= SAME_LINK_BURST) rx->tp.synth[c].after_event(d.kind, sym, d.sample_counter, interburst, history);
+        { HP(5); if (tp && d.kind <= SAME_LINK_BURST) rx->tp.synth[c].after_event(d.kind, sym, d.sample_counter, interburst, history); }
     };
     // Time-parallel launch: the events of channel c, stitched from its chunks.  Chunk `cur` is kept up to
     // its hand-over instant h (the end of the first block at or after its nominal end in which the
@@ -696,10 +717,12 @@ int harvest_host(same_batch *rx, same_batch::Slot &sl, uint32_t n_events, uint32
                 }
             }
             // this channel's column ranges back into log order (see above)
+            { HP(0);
             for (uint32_t col = c; col < n_bins; col += n_ch)
                 if (first[col + 1u] - first[col] > 1u)
                     std::sort(evs_mut + first[col], evs_mut + first[col + 1u],
                               [](const same::DevEvent &a, const same::DevEvent &b) { return a.channel < b.channel; });
+            }
             if (sl.chunked) stitch(part, ev, c);
             else
                 for (uint32_t k = first[c]; k < first[c + 1u]; ++k)
@@ -1327,9 +1350,17 @@ int process_channel_major_native(same_batch *rx, const float *d_x, size_t n, hip
     if (lpt) { d_perm = d_perm2; d_wg = d_wg2; }
     // fresh receivers in every column (with the hand-over records, the event sort's bins and the launch cursors: one kernel,
     // launch_tp_prologue), then the channels' own state into chunk 0's columns
-    HIP_TRY(same::launch_tp_prologue(tp.blob, tp.blob_fresh, tp.fresh_bytes, sl.d_handover, sl.d_sort, columns, sl.d_counters, stream));
+    bool sort_bins_empty = false;
+    if (tp.knob_prologue >= 0) {
+        HIP_TRY(same::launch_tp_prologue(tp.blob, tp.blob_fresh, tp.fresh_bytes, sl.d_handover, sl.d_sort, columns, sl.d_counters, stream));
+        sort_bins_empty = sl.sort_bins == columns;
+    } else {
+        // (SAME_TP_PROLOGUE=0, A/B measurements: the launches' start as rounds 2-5 made it)
+        HIP_TRY(same::launch_counters(sl.d_counters, sl.h_counters_dev, 0, stream));
+        HIP_TRY(same::launch_init_state(tp.Pv, tp.Sv, 0, stream, C));
+        HIP_TRY(same::launch_fill_u64(sl.d_handover, columns, same::kNoHandover, stream));
+    }
     HIP_TRY(same::launch_copy_state_columns(tp.d_desc_in, tp.n_desc, C, columns, nullptr, C, stream));
-    const bool sort_bins_empty = sl.sort_bins == columns;
     pc.handover = sl.d_handover;
     pc.col_row0 = d_row0; pc.col_nominal = d_nom; pc.wg_blocks = d_wg; pc.col_perm = (sort_mode != 0 || pair_groups) ? d_perm : nullptr;
     pc.in_samples = n_call; pc.whole_samples = (uint32_t)n;
@@ -1977,6 +2008,10 @@ long same_debug_harvest_replay(const char *path, int threads, int reps, double *
         rx->burst_seq_head = rx->burst_seq.size();
     }
     sl.h_sort = nullptr; sl.h_events = nullptr; sl.h_bursts = nullptr; sl.h_handover = nullptr; sl.h_geom = nullptr;
+#ifdef SAME_HOST_PROF
+    { uint64_t tot = 0; for (int k = 0; k < 7; ++k) tot += g_hp[k];
+      for (int k = 0; k < 7; ++k) std::fprintf(stderr, "[same prof] %-24s %8.3f Mclk per harvest (%4.1f %% of the instrumented parts)\n", g_hp_name[k], (double)g_hp[k] / reps / 1e6, tot ? 100.0 * (double)g_hp[k] / (double)tot : 0.0); }
+#endif
     delete rx;
     return rc == SAME_OK ? produced : -(long)rc;
 }

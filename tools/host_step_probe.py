@@ -43,7 +43,8 @@ def record(out_dir):
 
 
 def lib():
-    L = ctypes.CDLL(os.path.join(ROOT, "sameold_amd", "libsame_rx.so"))
+    v = os.environ.get("SAME_LIB_VARIANT")          # (a measurement build: sameold_amd/build.py)
+    L = ctypes.CDLL(os.path.join(ROOT, "sameold_amd", f"libsame_rx.{v}.so" if v else "libsame_rx.so"))
     L.same_debug_harvest_replay.restype = ctypes.c_long
     L.same_debug_harvest_replay.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_double)]
     return L
