@@ -552,6 +552,38 @@ def test_planning_on_the_plan_stream_and_on_a_callers_stream(sa, monkeypatch):
     same = run()
     assert len(same) == len(got) and np.array_equal(same["kind"], got["kind"]) and np.array_equal(same["sample_counter"], got["sample_counter"])
     assert np.array_equal(same["bytes"], got["bytes"])
+    # ... and so must a launch whose fresh state columns, hand-over records, sort bins and cursors are made by separate
+    # kernels (SAME_TP_PROLOGUE=0: rounds 2-5) instead of the one prologue kernel copying a template blob (round 6)
+    monkeypatch.delenv("SAME_TP_PLAN_STREAM")
+    monkeypatch.setenv("SAME_TP_PROLOGUE", "0")
+    same = run()
+    assert len(same) == len(got) and np.array_equal(same["kind"], got["kind"]) and np.array_equal(same["sample_counter"], got["sample_counter"])
+    assert np.array_equal(same["bytes"], got["bytes"])
+
+
+def test_prologue_kernel_on_a_time_major_call_equals_the_separate_launches(sa, monkeypatch):
+    """A time-major time-parallel call (uniform cuts) starts with the same prologue kernel: the events of three streamed
+    calls must equal those of the launches that initialise their columns with init_state_kernel, call for call."""
+    rate, n_ch = 22050, 1024
+    part = 22050 * 4
+    part -= part % 1260
+    x = sa.synth_afsk(n_ch, 3 * part, rate, seed=6262)
+
+    def run():
+        rx = sa.SameReceiverBuilder(rate).build_batch(n_ch, time_parallel=True)
+        for i in range(3):
+            rx.process_tensor(x[i * part:(i + 1) * part])
+            assert rx.time_parallel_chunks() > 1
+        rx.sync()
+        got = rx.poll_events_np()
+        return got[np.lexsort((np.arange(len(got)), got["channel"]))]
+
+    a = run()
+    monkeypatch.setenv("SAME_TP_PROLOGUE", "0")
+    b = run()
+    assert len(a) == len(b) and len(a) > 0 and (a["kind"] == 3).sum() > n_ch
+    assert np.array_equal(a["kind"], b["kind"]) and np.array_equal(a["channel"], b["channel"])
+    assert np.array_equal(a["sample_counter"], b["sample_counter"]) and np.array_equal(a["bytes"], b["bytes"])
 
 
 def test_sorted_launches_are_deterministic_and_the_timers_nest(sa, monkeypatch):
