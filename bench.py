@@ -51,6 +51,9 @@ def parse():
     ap.add_argument("--seconds", type=float, default=None, help="audio per channel per step (default: the workload's)")
     ap.add_argument("--cpu-channels", type=int, default=1024, help="channels of the CPU baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--preheat-ms", type=float, default=350.0,
+                    help="untimed passes of the same step for this long before every block's warm-up, so that the timed steps run at the "
+                         "GPU's sustained clock instead of on its ramp from idle (0: none -- profiling passes, whose launch lists stay short)")
     ap.add_argument("--no-scaled", action="store_true", help="skip the extra 32768-channel and 48 kHz measurements")
     ap.add_argument("--scaled-channels", type=int, default=32768)
     ap.add_argument("--check", type=int, default=16, help="channels of rank 0 verified against the oracle")
@@ -181,6 +184,9 @@ def packed_bursts(rx, first_channel=0, _buf={}):
     return len(rx.pack_bursts_np(first_channel, out=buf))
 
 
+PREHEAT_MS = [350.0]      # --preheat-ms
+
+
 def run_steps(sa, rx, x, T, stream, steps, warmup, gather, barrier, layout=0, want_steady=False):
     """W untimed + K timed passes.  Each pass launches one batch; the library collects the
     previous batch's event log (copy back, ordering, transport layer) while the new launch
@@ -220,12 +226,26 @@ def run_steps(sa, rx, x, T, stream, steps, warmup, gather, barrier, layout=0, wa
     # clocks down (the four launches after such a gap measured 2.0-2.1 ms against 1.76) -- and the library lets that view go at
     # its next harvest (2.9 ms of page-table work): both used to fall into the first timed passes, ~0.2 ms per step over 20 steps.
     # With the last warm-up pass launched and collected after that, the timed region starts on a busy GPU and a clean queue.
-    for _ in range(max(warmup - 1, 0)):
+    #
+    # Pre-heat (--preheat-ms, default 350; untimed, reported as `preheat_ms`): the SMU takes ~300 ms of load to bring an idle
+    # MI355X to its sustained clock -- from idle the headline's demodulation kernel runs 1.85-2.04 ms and settles at 1.66-1.68 only
+    # ~15 launches later, i.e. the 20 timed steps of a block that follows seconds of host-side contract checks measured the
+    # ramp, not the stream (tools/ramp_probe.py: with 300 ms of load just before, the FIRST launch takes 1.63-1.70 ms).  So after
+    # the first warm-up pass the same passes run untimed until the time is up; they are steps of the stream like any other
+    # (their events are consumed), W more untimed passes than --warmup asks for by count, none inside the timed region.
+    if warmup >= 1:
         one_pass()
-    drain()
+        drain()
     if first:
         keep_first[0] = False
-    if warmup >= 1:
+    if PREHEAT_MS[0] > 0.0:
+        t_pre = time.perf_counter()
+        while (time.perf_counter() - t_pre) * 1e3 < PREHEAT_MS[0]:
+            one_pass()
+    for _ in range(max(warmup - 2, 0)):
+        one_pass()
+    drain()
+    if warmup >= 2:
         one_pass()
         drain()
     kernel_ms.clear()
@@ -396,6 +416,7 @@ def main():
         raise SystemExit(spawn_ranks(args))
     if args.plumbing:
         return plumbing(args)
+    PREHEAT_MS[0] = max(0.0, float(args.preheat_ms))
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -603,6 +624,8 @@ def main():
         "n_gpus": world,
         "steps": args.steps,
         "warmup": args.warmup,
+        # (untimed passes of the same step before every block, so that the timed steps run at the sustained GPU clock: run_steps)
+        "preheat_ms": args.preheat_ms,
         "ms_per_step": hb["ms_per_step"],
         "higher_is_better": True,
         "scaling": "weak",
