@@ -213,8 +213,11 @@ def run_steps(sa, rx, x, T, stream, steps, warmup, gather, barrier, layout=0, wa
             last_bursts[0] = gather(rx)    # (copies the burst records out of the queue)
             rx.drop_events(n_ev)
 
+    n_launches = [0]
+
     def one_pass():
         rx.process_device_ptr(x.data_ptr(), T, layout, stream)
+        n_launches[0] += 1
         consume()
 
     def drain():
@@ -274,11 +277,13 @@ def run_steps(sa, rx, x, T, stream, steps, warmup, gather, barrier, layout=0, wa
         # one more pass, untimed, on the state the timed passes left: what a steady-state step delivers
         t_lo = rx.input_sample_counter()
         rx.process_device_ptr(x.data_ptr(), T, layout, stream)
+        n_launches[0] += 1
         rx.sync()
         ev = rx.peek_events_np()
         steady = ev[(ev["sample_counter"] > t_lo)].copy()
         steady["sample_counter"] -= t_lo
         rx.drop_events(len(ev))
+    run_steps.last_launches = n_launches[0]      # (warm-up, pre-heat, timed and the steady pass: tools/profile_collect.py sorts a trace's launches by block with it)
     return elapsed, k_mean, first_ev, last_bursts[0], steady
 
 
@@ -495,7 +500,7 @@ def main():
         el, kms, first_ev, nb, steady = run_steps(sa, r, x if xin is None else xin, T, stream, args.steps, args.warmup, gather, barrier,
                                                   layout=layout, want_steady=True)
         facts = {"kernel": r.kernel_name(), "chunks": int(r.time_parallel_chunks()), "per_channel": bool(r.time_parallel_per_channel()),
-                 "demod_ms": run_steps.last_demod_ms}
+                 "demod_ms": run_steps.last_demod_ms, "launches": run_steps.last_launches}
         del r
         return max_over_ranks(el), kms, first_ev, nb, steady, facts
 
@@ -596,7 +601,7 @@ def main():
             "value": round(C * T * world * args.steps / el / 1e6, 2), "unit": "Msamples/s",
             "ms_per_step": round(el / args.steps * 1e3, 3), "bursts_gathered_last_step": int(nb),
             "bursts_pass_after_the_timed_ones_rank0": int((st["kind"] == 3).sum()),
-            "kernel": fc["kernel"], "layout": layouts.get(name, "time-major x[t][channel]"),
+            "kernel": fc["kernel"], "launches": fc["launches"], "layout": layouts.get(name, "time-major x[t][channel]"),
             "roofline": {"bound": "hbm", "binds_in_practice": "instruction_issue", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": pmc_traffic(name), "kernel_ms": round(kms, 4),
                          "demod_kernel_alone_ms": round(fc["demod_ms"], 4),

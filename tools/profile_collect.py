@@ -79,6 +79,12 @@ rows = [r for r in all_rows if any(k in r["Kernel_Name"] for k in DEMOD)]
 blocks = collections.OrderedDict()
 state = {}
 n1_trace = bench["steps"] + bench["warmup"] + 1          # (+ the untimed pass after the timed ones)
+try:
+    # the traced run's own line says how many launches its blocks made (pre-heat passes run by the clock, not by count)
+    traced = json.loads([l for l in open(os.path.join(P, "trace_bench.log")).read().splitlines() if l.startswith('{"metric"')][-1])
+    n1_trace = int(traced["modes"]["time_parallel_time_major"]["launches"])
+except Exception:
+    pass
 for r in rows:
     wgs = int(r["Grid_Size_X"]) // max(int(r["Workgroup_Size_X"]), 1)
     v = classify(r["Kernel_Name"], wgs, state, n1_trace) or short(r["Kernel_Name"])

@@ -10,7 +10,7 @@ OUT=$R/gpurun_out/prof
 rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 timeout 900 python3 $R/bench.py > $OUT/bench.json 2> $OUT/bench.err
-timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $R/bench.py --no-cpu-baseline --check 0 --no-carried-state-check --preheat-ms 0 > $OUT/trace_bench.log 2>&1
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $R/bench.py --no-cpu-baseline --check 0 --no-carried-state-check > $OUT/trace_bench.log 2>&1
 timeout 900 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- python3 $R/bench.py --no-cpu-baseline --check 0 --no-carried-state-check --preheat-ms 0 --steps 2 --warmup 1 > $OUT/fetch_bench.log 2>&1
 timeout 900 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write -- python3 $R/bench.py --no-cpu-baseline --check 0 --no-carried-state-check --preheat-ms 0 --steps 2 --warmup 1 > $OUT/write_bench.log 2>&1
 timeout 900 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_ANY --output-format csv -d $OUT/sq -- python3 $R/bench.py --no-cpu-baseline --check 0 --no-carried-state-check --preheat-ms 0 --steps 2 --warmup 1 > $OUT/sq_bench.log 2>&1
