@@ -90,8 +90,13 @@ static void clear_result(MessageResult *m)
 static void parse_message(const uint8_t *b, size_t n, const uint8_t *errs, const uint8_t *counts, MessageResult *out)
 {
     clear_result(out);
-    for (size_t i = 0; i < n; ++i)
-        if (b[i] & 0x80) { out->kind = SAME_TRANSPORT_MSG_ERR; out->err = 1; return; }
+    {
+        // (is_ascii, eight bytes at a time; combine()'s estimates are 7-bit by construction, the test is the reference's)
+        size_t i = 0; uint64_t hi = 0;
+        for (; i + 8 <= n; i += 8) { uint64_t w; std::memcpy(&w, b + i, 8); hi |= w; }
+        for (; i < n; ++i) hi |= b[i];
+        if (hi & 0x8080808080808080ull) { out->kind = SAME_TRANSPORT_MSG_ERR; out->err = 1; return; }
+    }
     if (n >= 5 && std::memcmp(b, "ZCZC-", 5) == 0) {
         size_t off = 0, hl = 0;
         if (!check_header(b, n, &off, &hl)) { out->kind = SAME_TRANSPORT_MSG_ERR; out->err = 3; return; }
@@ -99,9 +104,20 @@ static void parse_message(const uint8_t *b, size_t n, const uint8_t *errs, const
         out->len = (uint32_t)hl;
         std::memcpy(out->text, b, hl);
         out->offset_time = (uint32_t)off;
-        for (size_t i = 0; i < hl; ++i) {
-            out->parity_errors += errs[i];
-            out->voting_bytes += counts[i] >= 3 ? 1u : 0u;
+        {
+            // the header's parity errors and voting bytes, eight positions at a time (an error count is at most 8 and a byte of
+            // the running word holds 255: 24 words between two foldings; a count is 1, 2 or 3, "three votes" its bits 0 and 1 together)
+            size_t i = 0; uint32_t pe = 0, vb = 0;
+            while (i + 8 <= hl) {
+                uint64_t se = 0, sv = 0; size_t k = 0;
+                for (; k < 24 && i + 8 <= hl; ++k, i += 8) {
+                    uint64_t e, c; std::memcpy(&e, errs + i, 8); std::memcpy(&c, counts + i, 8);
+                    se += e; sv += c & (c >> 1) & 0x0101010101010101ull;
+                }
+                for (int q = 0; q < 8; ++q) { pe += (uint32_t)((se >> (8 * q)) & 0xffu); vb += (uint32_t)((sv >> (8 * q)) & 0xffu); }
+            }
+            for (; i < hl; ++i) { pe += errs[i]; vb += counts[i] >= 3 ? 1u : 0u; }
+            out->parity_errors = pe; out->voting_bytes = vb;
         }
     } else if (n >= 2 && b[0] == 'N' && b[1] == 'N') {
         out->kind = SAME_TRANSPORT_MSG_END;
@@ -118,6 +134,16 @@ bool combine(const BurstBuf *bursts, uint32_t nbursts, MessageResult *res)
     size_t n = 0;
     // Every burst is read from its first byte on, so at position n exactly the bursts longer than n take part: first the
     // stretch all of them cover (the usual case: three bursts of one length), then the general walk.
+    if (nb == 1) {
+        // One burst (a message's first: one call in three).  Every byte of its estimate has one vote, so no prefix of it is
+        // trusted (truncate_bytes_with_reference keeps nothing: rx/combiner.rs:264-273) and what is left of combine() is the
+        // fast end-of-message (:251-258) on the first two estimated bytes -- 'N' is an allowed character, so the estimate reaches
+        // them exactly when they are there -- or, failing that, "no message" (:75-79 with an empty prefix).
+        const BurstBuf &a = bursts[0];
+        if (a.len == 0 || !kAllowed.ok[a.data[0] & 0x7f]) return false;          // (estimate_message yields nothing: :176-180)
+        if (a.len >= 2 && (a.data[0] & 0x7f) == 'N' && (a.data[1] & 0x7f) == 'N') { clear_result(res); res->kind = SAME_TRANSPORT_MSG_END; return true; }
+        return false;
+    }
     size_t common = kMaxMessageLength;
     for (size_t i = 0; i < nb; ++i) common = std::min<size_t>(common, bursts[i].len);
     bool stopped = false;
@@ -149,15 +175,20 @@ bool combine(const BurstBuf *bursts, uint32_t nbursts, MessageResult *res)
                 est = a & ~(nz * 0xffull);
             }
             const uint64_t er = bytes_popcount(dis) + hi;
-            uint8_t e8[8], r8[8];
-            std::memcpy(e8, &est, 8); std::memcpy(r8, &er, 8);
-            int j = 0;
-            for (; j < 8; ++j) {
-                if (!kAllowed.ok[e8[j]]) break;
-                msg[n + j] = e8[j]; cnt[n + j] = (uint8_t)nb; errs[n + j] = r8[j];
+            // the eight estimates and error counts as two word stores (a byte at or behind a character that is not allowed is
+            // never read: n says where the estimate ends); the counts -- nb everywhere in this stretch -- are filled in below
+            uint8_t e8[8];
+            std::memcpy(e8, &est, 8);
+            std::memcpy(msg + n, &est, 8); std::memcpy(errs + n, &er, 8);
+            const bool all_ok = kAllowed.ok[e8[0]] & kAllowed.ok[e8[1]] & kAllowed.ok[e8[2]] & kAllowed.ok[e8[3]] &
+                                kAllowed.ok[e8[4]] & kAllowed.ok[e8[5]] & kAllowed.ok[e8[6]] & kAllowed.ok[e8[7]];
+            if (!all_ok) {
+                int j = 0;
+                while (kAllowed.ok[e8[j]]) ++j;
+                n += (size_t)j; stopped = true; break;
             }
-            if (j < 8) { n += (size_t)j; stopped = true; break; }
         }
+        std::memset(cnt, (int)nb, n);
     }
     if (stopped) {
         // (a character that is not allowed ends the message: rx/combiner.rs:176-180)
