@@ -185,6 +185,7 @@ def packed_bursts(rx, first_channel=0, _buf={}):
 
 
 PREHEAT_MS = [350.0]      # --preheat-ms
+AGREE = [lambda v: v]     # N ranks: the maximum of v over the ranks (main() sets it)
 
 
 def run_steps(sa, rx, x, T, stream, steps, warmup, gather, barrier, layout=0, want_steady=False):
@@ -242,9 +243,14 @@ def run_steps(sa, rx, x, T, stream, steps, warmup, gather, barrier, layout=0, wa
     if first:
         keep_first[0] = False
     if PREHEAT_MS[0] > 0.0:
+        # (eight passes at a time, then the ranks agree on the time that has passed: a pass of an N-rank run holds a collective,
+        # so every rank must make the same number of them)
         t_pre = time.perf_counter()
-        while (time.perf_counter() - t_pre) * 1e3 < PREHEAT_MS[0]:
-            one_pass()
+        while True:
+            for _ in range(8):
+                one_pass()
+            if AGREE[0]((time.perf_counter() - t_pre) * 1e3) >= PREHEAT_MS[0]:
+                break
     for _ in range(max(warmup - 2, 0)):
         one_pass()
     drain()
@@ -482,6 +488,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
+    AGREE[0] = max_over_ranks
     seed = 20260000 + rank
 
     def run_mode(env, layout=0, xin=None, **kw):
