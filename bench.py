@@ -225,11 +225,10 @@ def run_steps(sa, rx, x, T, stream, steps, warmup, gather, barrier, layout=0, wa
         rx.sync()
         consume()
 
-    # Warm-up: W untimed passes, the LAST of them behind the host-side bookkeeping of the others.  Draining the first passes
-    # materialises their events for the contract checks (a 35 MB view at configs[1]) -- milliseconds in which the GPU idles and
-    # clocks down (the four launches after such a gap measured 2.0-2.1 ms against 1.76) -- and the library lets that view go at
-    # its next harvest (2.9 ms of page-table work): both used to fall into the first timed passes, ~0.2 ms per step over 20 steps.
-    # With the last warm-up pass launched and collected after that, the timed region starts on a busy GPU and a clean queue.
+    # Warm-up: W untimed passes.  The FIRST is drained by itself: draining materialises its events for the contract checks (a
+    # 35 MB view at configs[1]) -- milliseconds of host work in which the GPU idles -- and the library lets that view go at its
+    # next harvest (2.9 ms of page-table work): both used to fall into the first timed passes, ~0.2 ms per step over 20 steps.
+    # The others follow behind that (and behind the pre-heat), so the timed region starts on a busy GPU and a clean queue.
     #
     # Pre-heat (--preheat-ms, default 350; untimed, reported as `preheat_ms`): the SMU takes ~300 ms of load to bring an idle
     # MI355X to its sustained clock -- from idle the headline's demodulation kernel runs 1.85-2.04 ms and settles at 1.66-1.68 only
@@ -251,14 +250,18 @@ def run_steps(sa, rx, x, T, stream, steps, warmup, gather, barrier, layout=0, wa
                 one_pass()
             if AGREE[0]((time.perf_counter() - t_pre) * 1e3) >= PREHEAT_MS[0]:
                 break
-    for _ in range(max(warmup - 2, 0)):
+    for _ in range(max(warmup - 1, 0)):
         one_pass()
-    drain()
-    if warmup >= 2:
-        one_pass()
-        drain()
+    # No drain here: the last untimed launch is collected by the FIRST TIMED pass, the way every pass of a stream collects
+    # the launch before it -- the timed region then holds K launches and K + 1 harvests (one more than it owes) and begins
+    # on a GPU that has been idle for a synchronisation, not for a harvest (whose ~2 ms of idling cost the first timed
+    # launches 5-15 %).  That launch's kernel time is not one of the K.
+    n_untimed_in_flight = 1 if n_launches[0] > (1 if warmup >= 1 else 0) else 0
     kernel_ms.clear()
     demod_ms.clear()
+    import gc
+    gc.collect()
+    gc.disable()             # (a generation-2 collection of this process's objects inside a 36 ms timed region is milliseconds)
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -271,11 +274,13 @@ def run_steps(sa, rx, x, T, stream, steps, warmup, gather, barrier, layout=0, wa
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
+    gc.enable()
     if os.environ.get("SAME_BENCH_DEBUG"):
         sys.stderr.write("per-pass wall ms (last = drain): " + " ".join(f"{1e3 * (b - a):.2f}" for a, b in zip([t0] + marks[:-1], marks)) + "\n")
         sys.stderr.write("kernel ms per launch: " + " ".join(f"{k:.3f}" for k in kernel_ms) + " | demod alone: " + " ".join(f"{k:.3f}" for k in demod_ms) + "\n")
     first_ev = np.concatenate(first) if first else np.zeros(0, dtype=sa.receiver.EVENT_DTYPE)
     first_ev = first_ev[first_ev["sample_counter"] <= T]     # the very first pass only
+    del kernel_ms[:n_untimed_in_flight], demod_ms[:n_untimed_in_flight]      # (the untimed launch the first timed pass collected)
     k_mean = sum(kernel_ms) / max(len(kernel_ms), 1)
     run_steps.last_demod_ms = sum(demod_ms) / max(len(demod_ms), 1)      # (the demodulation kernel alone, for the roofline block's note)
     steady = None
