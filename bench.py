@@ -210,7 +210,10 @@ def run_steps(sa, rx, x, T, stream, steps, warmup, gather, barrier, layout=0, wa
             kernel_ms.append(rx.last_kernel_ms())
             demod_ms.append(rx.last_demod_kernel_ms())
             if keep_first[0]:
+                # (a harvest brings a whole launch: the first events to arrive are the first pass's, all of them -- no later
+                # pass is materialised, whatever --warmup and --preheat-ms are)
                 first.append(rx.peek_events_np().copy())
+                keep_first[0] = False
             last_bursts[0] = gather(rx)    # (copies the burst records out of the queue)
             rx.drop_events(n_ev)
 
