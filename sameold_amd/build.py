@@ -20,7 +20,11 @@ CSRC = os.path.join(HERE, "csrc")
 # product's -- build/name/, libsame_rx.name.so -- and tools load it with SAME_LIB_VARIANT=name; the product never reads either.
 VARIANT = os.environ.get("SAME_BUILD_VARIANT", "")
 LIB = os.path.join(HERE, f"libsame_rx.{VARIANT}.so" if VARIANT else "libsame_rx.so")
-SOURCES = ["same_kernels.hip", "same_kernels_fast.hip", "same_kernels_pipe.hip", "same_kernels_relaxed.hip", "same_kernels_sym.hip", "same_synth.hip", "same_batch.cpp", "same_config.cpp", "same_transport.cpp", "same_place.cpp"]
+SOURCES = ["same_kernels.hip", "same_kernels_fast.hip", "same_kernels_pipe.hip", "same_kernels_relaxed.hip", "same_kernels_sym.hip", "same_kernels_sym_hi.hip", "same_synth.hip", "same_batch.cpp", "same_config.cpp", "same_transport.cpp", "same_place.cpp"]
+# flags of one source only.  same_kernels_sym_hi.hip (the symbol-paced pipeline at 44.1 / 48 kHz, six wavefronts per CU): the
+# machine scheduler set for instruction-level parallelism -- 3.3-3.6 % faster there with the same events; the 22.05 kHz unit
+# (twelve wavefronts per CU) measured up to 10 % SLOWER with it and keeps the default (same_kernels_sym.hip, SYM_SPLIT_TU)
+SOURCE_FLAGS = {"same_kernels_sym_hi.hip": ["-mllvm", "-amdgpu-sched-strategy=max-ilp"]}
 HEADERS = ["same_dev_common.h", "same_fast_common.h", "same_relaxed_common.h", "same_pipe_common.h", "same_profile.h", "same_device.h", "same_launch.h", "same_config.h", "same_transport.h", "../../include/same_rx.h",
            "../../include/same_place.h", "samedec_main.cpp"]
 SAMEDEC = os.path.join(HERE, "samedec_gpu")      # the command-line decoder (host-only program, dlopens LIB)
@@ -48,7 +52,8 @@ def flags() -> list:
       + (["-DSAME_SYM_TL=1"] if os.environ.get("SAME_SYM_TL") else []) \
       + ([f"-DSYM_PRIOS=0x{os.environ['SAME_SYM_PRIOS']}"] if os.environ.get("SAME_SYM_PRIOS") else []) \
       + ([f"-DSYM_TL_GROUP={int(os.environ['SAME_SYM_TL_GROUP'])}u"] if os.environ.get("SAME_SYM_TL_GROUP") else []) \
-      + [f"-D{d}" for d in os.environ.get("SAME_EXTRA_DEFS", "").split() if d]      # (A/B builds of a variant: SAME_BUILD_VARIANT)
+      + [f"-D{d}" for d in os.environ.get("SAME_EXTRA_DEFS", "").split() if d] \
+      + [f for f in os.environ.get("SAME_EXTRA_FLAGS", "").split() if f]      # (A/B builds of a variant: SAME_BUILD_VARIANT; raw compiler flags, e.g. "-mllvm -amdgpu-sched-strategy=max-ilp")
 
 
 def source_hash() -> str:
@@ -58,6 +63,7 @@ def source_hash() -> str:
         with open(os.path.join(CSRC, f), "rb") as fh:
             h.update(f.encode() + b"\0" + fh.read() + b"\0")
     h.update(" ".join(flags()).encode())
+    h.update(repr(sorted(SOURCE_FLAGS.items())).encode())
     return h.hexdigest()
 
 
@@ -95,14 +101,14 @@ def build(force: bool = False, verbose: bool = False) -> str:
     # Objects are re-used when nothing they are made of changed: the key is the source, every header (any of them may be
     # included) and the flags; only same_batch.cpp carries the library-wide source hash (same_rx_source_hash()).
     hdr = hashlib.sha256()
-    for f in sorted(HEADERS):
+    for f in sorted(HEADERS + ["same_kernels_sym.hip"]):      # (same_kernels_sym_hi.hip includes it)
         with open(os.path.join(CSRC, f), "rb") as fh:
             hdr.update(f.encode() + b"\0" + fh.read() + b"\0")
     hdr.update(" ".join(flags()).encode())
     for src in SOURCES:
         obj = os.path.join(bdir, os.path.splitext(src)[0] + ".o")
         objs.append(obj)
-        extra = [f'-DSAME_SOURCE_HASH="{digest}"'] if src == "same_batch.cpp" else []
+        extra = ([f'-DSAME_SOURCE_HASH="{digest}"'] if src == "same_batch.cpp" else []) + SOURCE_FLAGS.get(src, [])
         with open(os.path.join(CSRC, src), "rb") as fh:
             key = hashlib.sha256(hdr.digest() + fh.read() + " ".join(extra).encode()).hexdigest()
         stamp = obj + ".key"

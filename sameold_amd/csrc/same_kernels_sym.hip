@@ -2039,6 +2039,17 @@ static uint32_t sym_rate_nt(const Params &P)
     if (P.ntaps == 84u && P.dc_len == 32u) return 84u;
     return 0u;
 }
+// Two translation units (round 6).  The 44.1 / 48 kHz instantiations are compiled a second time from this file by
+// same_kernels_sym_hi.hip (SYM_TU_HI), which the build schedules for instruction-level parallelism (`-mllvm
+// -amdgpu-sched-strategy=max-ilp`, sameold_amd/build.py): there six wavefronts share four SIMDs and a role's own dependent chains
+// are what it waits for -- 2.43-2.45 -> 2.36 ms at 48 kHz, 2.13-2.16 -> 2.07 at 44.1 kHz, the same events (tools/sym_hash.py).  At
+// 22.05 kHz (twelve wavefronts per CU) the same option is equal with the link layer alone and 10 % SLOWER with the transport layer
+// on (1.91 -> 2.10 ms at 32 768 channels), `max-memory-clause` likewise: this unit keeps the compiler's default.  Profile and
+// timeline builds keep one unit (their counters are per-unit device globals).
+#if !defined(SAME_PROFILE) && !defined(SAME_SYM_TL)
+#define SYM_SPLIT_TU 1
+#endif
+#if !defined(SYM_TU_HI)
 uint32_t sym_block_len(const Params &P) { return sym_rate_nt(P) == 42u ? (uint32_t)SymLayout<42>::B : (uint32_t)SymLayout<92>::B; }
 bool sym_kernel_supported(const Params &P)
 {
@@ -2058,6 +2069,7 @@ bool sym_kernel_supported(const Params &P)
     const uint32_t reach = (2u * B - apart) + 1u + (uint32_t)std::ceil(P.period_max + a + 1.5f) + (nt - 1u);
     return reach <= (uint32_t)(SymLayout<42>::NBLK - 2) * B;
 }
+#endif      // !SYM_TU_HI
 
 template <int NT, int NFF, int NFB, typename SampleT>
 static hipError_t launch_sym_one(const Params &P, const State &S, const Output &O, const float4 *taps, const SampleT *x,
@@ -2095,17 +2107,52 @@ static hipError_t launch_sym_one(const Params &P, const State &S, const Output &
     return go(demod_sym_kernel<NT, NFF, NFB, SampleT, 0>);
 }
 
+// the 44.1 / 48 kHz instantiations (in same_kernels_sym_hi.hip's unit where the build is split)
+template <typename SampleT>
+static hipError_t launch_sym_hi_t(const Params &P, const State &S, const Output &O, const float4 *taps, const SampleT *x,
+                                  uint32_t n_blocks, uint64_t counter0, hipStream_t stream, const PipeChunks &K)
+{
+    const bool eq = P.eq_nff == 6u && P.eq_nfb == 4u;
+    if (sym_rate_nt(P) == 92u)
+        return eq ? launch_sym_one<92, 6, 4, SampleT>(P, S, O, taps, x, n_blocks, counter0, stream, K) : launch_sym_one<92, 1, 1, SampleT>(P, S, O, taps, x, n_blocks, counter0, stream, K);
+    return eq ? launch_sym_one<84, 6, 4, SampleT>(P, S, O, taps, x, n_blocks, counter0, stream, K) : launch_sym_one<84, 1, 1, SampleT>(P, S, O, taps, x, n_blocks, counter0, stream, K);
+}
+#if defined(SYM_TU_HI)
+#if defined(SYM_SPLIT_TU)
+hipError_t launch_demod_sym_hi(const Params &P, const State &S, const Output &O, const float4 *taps, const float *x,
+                               uint32_t n_blocks, uint64_t counter0, hipStream_t stream, const PipeChunks &K)
+{ return launch_sym_hi_t<float>(P, S, O, taps, x, n_blocks, counter0, stream, K); }
+hipError_t launch_demod_sym_hi_i16(const Params &P, const State &S, const Output &O, const float4 *taps, const int16_t *x,
+                                   uint32_t n_blocks, uint64_t counter0, hipStream_t stream, const PipeChunks &K)
+{ return launch_sym_hi_t<int16_t>(P, S, O, taps, x, n_blocks, counter0, stream, K); }
+#endif
+#else
+#if defined(SYM_SPLIT_TU)
+hipError_t launch_demod_sym_hi(const Params &P, const State &S, const Output &O, const float4 *taps, const float *x,
+                               uint32_t n_blocks, uint64_t counter0, hipStream_t stream, const PipeChunks &K);
+hipError_t launch_demod_sym_hi_i16(const Params &P, const State &S, const Output &O, const float4 *taps, const int16_t *x,
+                                   uint32_t n_blocks, uint64_t counter0, hipStream_t stream, const PipeChunks &K);
+static hipError_t launch_sym_hi(const Params &P, const State &S, const Output &O, const float4 *taps, const float *x,
+                                uint32_t n_blocks, uint64_t counter0, hipStream_t stream, const PipeChunks &K)
+{ return launch_demod_sym_hi(P, S, O, taps, x, n_blocks, counter0, stream, K); }
+static hipError_t launch_sym_hi(const Params &P, const State &S, const Output &O, const float4 *taps, const int16_t *x,
+                                uint32_t n_blocks, uint64_t counter0, hipStream_t stream, const PipeChunks &K)
+{ return launch_demod_sym_hi_i16(P, S, O, taps, x, n_blocks, counter0, stream, K); }
+#else
+template <typename SampleT>
+static hipError_t launch_sym_hi(const Params &P, const State &S, const Output &O, const float4 *taps, const SampleT *x,
+                                uint32_t n_blocks, uint64_t counter0, hipStream_t stream, const PipeChunks &K)
+{ return launch_sym_hi_t<SampleT>(P, S, O, taps, x, n_blocks, counter0, stream, K); }
+#endif
 template <typename SampleT>
 static hipError_t launch_sym_t(const Params &P, const State &S, const Output &O, const float4 *taps, const SampleT *x,
                                uint32_t n_blocks, uint64_t counter0, hipStream_t stream, const PipeChunks &K)
 {
     if (!sym_kernel_supported(P)) return hipErrorInvalidValue;
     const bool eq = P.eq_nff == 6u && P.eq_nfb == 4u;
-    switch (sym_rate_nt(P)) {
-    case 42u: return eq ? launch_sym_one<42, 6, 4, SampleT>(P, S, O, taps, x, n_blocks, counter0, stream, K) : launch_sym_one<42, 1, 1, SampleT>(P, S, O, taps, x, n_blocks, counter0, stream, K);
-    case 92u: return eq ? launch_sym_one<92, 6, 4, SampleT>(P, S, O, taps, x, n_blocks, counter0, stream, K) : launch_sym_one<92, 1, 1, SampleT>(P, S, O, taps, x, n_blocks, counter0, stream, K);
-    default:  return eq ? launch_sym_one<84, 6, 4, SampleT>(P, S, O, taps, x, n_blocks, counter0, stream, K) : launch_sym_one<84, 1, 1, SampleT>(P, S, O, taps, x, n_blocks, counter0, stream, K);
-    }
+    if (sym_rate_nt(P) == 42u)
+        return eq ? launch_sym_one<42, 6, 4, SampleT>(P, S, O, taps, x, n_blocks, counter0, stream, K) : launch_sym_one<42, 1, 1, SampleT>(P, S, O, taps, x, n_blocks, counter0, stream, K);
+    return launch_sym_hi(P, S, O, taps, x, n_blocks, counter0, stream, K);
 }
 hipError_t launch_demod_sym(const Params &P, const State &S, const Output &O, const float4 *taps, const float *x,
                             uint32_t n_blocks, uint64_t counter0, hipStream_t stream, const PipeChunks &K)
@@ -2113,7 +2160,10 @@ hipError_t launch_demod_sym(const Params &P, const State &S, const Output &O, co
 hipError_t launch_demod_sym_i16(const Params &P, const State &S, const Output &O, const float4 *taps, const int16_t *x,
                                 uint32_t n_blocks, uint64_t counter0, hipStream_t stream, const PipeChunks &K)
 { return launch_sym_t<int16_t>(P, S, O, taps, x, n_blocks, counter0, stream, K); }
+#endif      // !SYM_TU_HI
 
 }  // namespace same
 
+#if !defined(SYM_TU_HI)
 SYM_PROFILE_EXPORTS()
+#endif
