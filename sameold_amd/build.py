@@ -24,7 +24,11 @@ SOURCES = ["same_kernels.hip", "same_kernels_fast.hip", "same_kernels_pipe.hip",
 # flags of one source only.  same_kernels_sym_hi.hip (the symbol-paced pipeline at 44.1 / 48 kHz, six wavefronts per CU): the
 # machine scheduler set for instruction-level parallelism -- 3.3-3.6 % faster there with the same events; the 22.05 kHz unit
 # (twelve wavefronts per CU) measured up to 10 % SLOWER with it and keeps the default (same_kernels_sym.hip, SYM_SPLIT_TU)
-SOURCE_FLAGS = {"same_kernels_sym_hi.hip": ["-mllvm", "-amdgpu-sched-strategy=max-ilp"]}
+# same_kernels_pipe.hip (the strict wavefront pipeline: a few wavefronts per CU, every one waiting on its own dependent chains):
+# the same option, 0-2 % faster (configs[2] strict 5.79 -> 5.67 ms, the 32 768-channel shard 4.05 -> 4.02, configs[1] equal); the
+# operations and their order are the source's either way (-ffp-contract=off: the scheduler reorders, it does not reassociate)
+SOURCE_FLAGS = {"same_kernels_sym_hi.hip": ["-mllvm", "-amdgpu-sched-strategy=max-ilp"],
+                "same_kernels_pipe.hip": ["-mllvm", "-amdgpu-sched-strategy=max-ilp"]}
 HEADERS = ["same_dev_common.h", "same_fast_common.h", "same_relaxed_common.h", "same_pipe_common.h", "same_profile.h", "same_device.h", "same_launch.h", "same_config.h", "same_transport.h", "../../include/same_rx.h",
            "../../include/same_place.h", "samedec_main.cpp"]
 SAMEDEC = os.path.join(HERE, "samedec_gpu")      # the command-line decoder (host-only program, dlopens LIB)
