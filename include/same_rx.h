@@ -197,7 +197,20 @@ enum {
      * any-configuration kernel, which needs a canonical state).  22.05, 44.1 and 48 kHz with the default DC-blocker length,
      * default or disabled equalizer and a non-negative AGC floor (44.1 / 48 kHz: whole groups of 64 channels, any number
      * of them); any other configuration runs strict.  Strict mode (no flag) stays bit-exact. */
-    SAME_BATCH_RELAXED = 1u << 4
+    SAME_BATCH_RELAXED = 1u << 4,
+    /* Results that do not depend on how the stream is cut into calls, in every mode (round 6).  Strict launches have that
+     * property by themselves.  A relaxed launch drains its pipeline at its end and applies the feedback in flight at once, a
+     * time-parallel launch plans its cuts over what the call delivered: fed in different calls, a stream comes out within the
+     * modes' contracts every time but not event for event the same.  With this flag the batch demodulates the stream in WINDOWS
+     * of 73 728 samples (3.3 s at 22.05 kHz) that begin at fixed positions of the stream -- multiples of the window from the
+     * batch's first sample, or from its last same_batch_flush / same_batch_reset -- whatever the calls look like: any list of
+     * calls that delivers the same samples makes the same launches and therefore the same events, bit for bit.  Samples wait
+     * in a device buffer until their window is whole (whole windows inside a call's buffer are demodulated where they lie): the
+     * events of a window arrive when its last sample has; same_batch_flush demodulates what is waiting before its zeros have
+     * filled the window, same_batch_sync does not.  Channel-major inputs take the transposing path (the per-channel cuts of
+     * SAME_BATCH_TIME_PARALLEL on a channel-major input are planned per call).  same_batch_input_sample_counter counts the
+     * samples accepted, waiting ones included. */
+    SAME_BATCH_CALL_INVARIANT = 1u << 5
 };
 #define SAME_TP_EVENT_TOLERANCE_SYMBOLS 2
 

@@ -279,6 +279,17 @@ struct same_batch {
     } tp;
     uint64_t launch_seq = 0;
     hipStream_t copy_stream = nullptr;   // read-back of finished launches, beside the compute stream
+    // SAME_BATCH_CALL_INVARIANT: the stream is demodulated in windows of kInvWindow samples that begin at fixed positions of the
+    // STREAM (multiples of the window from the batch's first sample, or from its last flush / reset), whatever the calls that
+    // deliver it look like: samples wait in `d_buf` (f32, time-major) until their window is whole
+    struct Windowed {
+        bool on = false;
+        uint32_t window = 0;           // samples per window
+        uint32_t fill = 0;             // samples of the current window that have arrived
+        void *d_buf = nullptr; size_t buf_bytes = 0;
+        hipEvent_t ev_buf = nullptr;   // behind the last operation on d_buf (a later call may come on another stream)
+        hipStream_t buf_stream = nullptr; bool buf_used = false;
+    } inv;
     // Time-parallel launches on the library's own stream: scout, planner and sort of call k + 1 run here, beside the tail of
     // launch k (whose short workgroups have left their CUs by then); the own stream waits for them (Slot::ev_planned)
     hipStream_t plan_stream = nullptr;
@@ -1082,7 +1093,7 @@ int ensure_wide_state(same_batch *rx, uint32_t columns)
 }
 
 template <typename SampleT>
-int process_time_major(same_batch *rx, const SampleT *d_x, size_t n_samples, hipStream_t stream)
+int process_time_major_launches(same_batch *rx, const SampleT *d_x, size_t n_samples, hipStream_t stream)
 {
     // keep one launch comfortably inside u32 sample indices and bounded output pools, and
     // well under the 135 s forced-EOM timeout the host arms one launch late (harvest)
@@ -1230,6 +1241,89 @@ int process_time_major(same_batch *rx, const SampleT *d_x, size_t n_samples, hip
         rc = harvest_slot(rx, prev);
         if (rc) return rc;
     }
+    return SAME_OK;
+}
+
+// SAME_BATCH_CALL_INVARIANT (include/same_rx.h): launches cover whole windows of the stream, from fixed stream positions on.  What
+// a launch computes is a function of the state it starts from and of the samples it covers -- the relaxed kernels drain their
+// pipeline at a launch's end and apply the feedback in flight at once, the time-parallel mode plans its cuts per launch -- so a
+// stream fed in different calls came out different near a lock or an end of burst wherever the calls' boundaries fell.  With the
+// launches' boundaries tied to the stream instead of to the calls, it cannot: any list of calls that delivers the same samples
+// makes the same launches.  The price is latency: the events of a window arrive when its last sample has (same_batch_flush
+// demodulates what is waiting).  Whole windows that lie inside a call's buffer are launched where they lie; the pieces before
+// and behind them are copied into the waiting buffer (f32; int16 pieces are cast the way the kernels cast them: unscaled).
+constexpr uint32_t kInvWindow = 73728;      // 3.3 s at 22.05 kHz, 1.5 s at 48 kHz; whole blocks of every kernel (16, 18, 32, 36, 72)
+static int inv_buffer_wait(same_batch *rx, hipStream_t stream)
+{
+    same_batch::Windowed &iv = rx->inv;
+    if (iv.buf_used && iv.buf_stream != stream) HIP_TRY(hipStreamWaitEvent(stream, iv.ev_buf, 0));
+    return SAME_OK;
+}
+static int inv_buffer_done(same_batch *rx, hipStream_t stream)
+{
+    same_batch::Windowed &iv = rx->inv;
+    if (!iv.ev_buf) HIP_TRY(hipEventCreateWithFlags(&iv.ev_buf, hipEventDisableTiming));
+    HIP_TRY(hipEventRecord(iv.ev_buf, stream));
+    iv.buf_stream = stream; iv.buf_used = true;
+    return SAME_OK;
+}
+template <typename SampleT>
+static int inv_append(same_batch *rx, const SampleT *d_x, size_t n, hipStream_t stream)
+{
+    // n samples (rows of n_channels) behind the ones already waiting
+    same_batch::Windowed &iv = rx->inv;
+    const size_t C = rx->P.n_channels;
+    int rc = ensure_stage(&iv.d_buf, &iv.buf_bytes, (size_t)iv.window * C * sizeof(float));
+    if (rc) return rc;
+    rc = inv_buffer_wait(rx, stream);
+    if (rc) return rc;
+    float *dst = static_cast<float *>(iv.d_buf) + (size_t)iv.fill * C;
+    if constexpr (sizeof(SampleT) == 4) {
+        HIP_TRY(hipMemcpyAsync(dst, d_x, n * C * sizeof(float), hipMemcpyDeviceToDevice, stream));
+    } else {
+        hipError_t e = same::launch_cast_i16_f32((const int16_t *)d_x, dst, n * C, stream);
+        if (e != hipSuccess) return fail(SAME_EHIP, "cast launch failed: %s", hipGetErrorString(e));
+    }
+    iv.fill += (uint32_t)n;
+    return inv_buffer_done(rx, stream);
+}
+// demodulate what is waiting (a whole window, or -- flush -- whatever there is) and begin a new window
+static int inv_launch_waiting(same_batch *rx, hipStream_t stream)
+{
+    same_batch::Windowed &iv = rx->inv;
+    if (!iv.fill) return SAME_OK;
+    int rc = inv_buffer_wait(rx, stream);
+    if (rc) return rc;
+    const uint32_t n = iv.fill;
+    iv.fill = 0;
+    rc = process_time_major_launches<float>(rx, static_cast<const float *>(iv.d_buf), n, stream);
+    if (rc) return rc;
+    return inv_buffer_done(rx, stream);
+}
+template <typename SampleT>
+int process_time_major(same_batch *rx, const SampleT *d_x, size_t n_samples, hipStream_t stream)
+{
+    same_batch::Windowed &iv = rx->inv;
+    if (!iv.on) return process_time_major_launches(rx, d_x, n_samples, stream);
+    const size_t C = rx->P.n_channels;
+    size_t pos = 0;
+    if (iv.fill) {
+        // complete the window that is waiting
+        const size_t take = std::min<size_t>(iv.window - iv.fill, n_samples);
+        int rc = inv_append(rx, d_x, take, stream);
+        if (rc) return rc;
+        pos = take;
+        if (iv.fill < iv.window) return SAME_OK;
+        rc = inv_launch_waiting(rx, stream);
+        if (rc) return rc;
+    }
+    // whole windows where they lie
+    while (n_samples - pos >= iv.window) {
+        int rc = process_time_major_launches(rx, d_x + pos * C, iv.window, stream);
+        if (rc) return rc;
+        pos += iv.window;
+    }
+    if (pos < n_samples) return inv_append(rx, d_x + pos * C, n_samples - pos, stream);
     return SAME_OK;
 }
 
@@ -1428,7 +1522,8 @@ int process_device_any(same_batch *rx, const SampleT *d_x, size_t n_samples, uin
     if (layout == SAME_LAYOUT_TIME_MAJOR) return process_time_major(rx, d_x, n_samples, stream);
     if (layout != SAME_LAYOUT_CHANNEL_MAJOR) return fail(SAME_EINVAL, "unknown layout %u", layout);
     if constexpr (sizeof(SampleT) == 4) {
-        const int done = process_channel_major_native(rx, (const float *)d_x, n_samples, stream);
+        // (its cuts are planned per CALL: a batch that is to be independent of its calls takes the transposing path and windows)
+        const int done = rx->inv.on ? 0 : process_channel_major_native(rx, (const float *)d_x, n_samples, stream);
         if (done) return done < 0 ? done : SAME_OK;
     }
     // channel-major: transpose slabs of time through a staging buffer
@@ -1522,6 +1617,9 @@ int same_batch_new(const same_rx_builder *b, uint32_t n_channels, int device, ui
     rx->builder = *b;
     rx->device = device;
     rx->flags = flags;
+    rx->inv.on = (flags & SAME_BATCH_CALL_INVARIANT) != 0;
+    rx->inv.window = kInvWindow;
+    if (const char *e = std::getenv("SAME_INV_WINDOW")) { const long v = std::atol(e); if (v >= 64 && v <= (1 << 22)) rx->inv.window = (uint32_t)v; }      // (tests: short windows)
     std::vector<float> taps;
     int rc = same::derive_params(*b, n_channels, rx->P, taps);
     if (rc) { delete rx; return fail(rc, "builder rejected (code %d)", rc); }
@@ -1621,6 +1719,8 @@ void same_batch_free(same_batch *rx)
         if (sl.d_geom) (void)hipFree(sl.d_geom);
         if (sl.h_geom) (void)hipHostFree(sl.h_geom);
     }
+    if (rx->inv.d_buf) (void)hipFree(rx->inv.d_buf);
+    if (rx->inv.ev_buf) (void)hipEventDestroy(rx->inv.ev_buf);
     if (rx->tp.blob) (void)hipFree(rx->tp.blob);
     if (rx->tp.blob_fresh) (void)hipFree(rx->tp.blob_fresh);
     if (rx->tp.d_desc_in) (void)hipFree(rx->tp.d_desc_in);
@@ -1651,6 +1751,7 @@ int same_batch_reset(same_batch *rx)
     if (e != hipSuccess) return fail(SAME_EHIP, "reset launch failed: %s", hipGetErrorString(e));
     HIP_TRY(hipStreamSynchronize(rx->own_stream));
     rx->counter = 0;
+    rx->inv.fill = 0;                        // (samples that were waiting for their window are dropped with the rest of the state)
     rx->queue.clear(); rx->queue_head = 0;   // event_queue.clear() receiver.rs:194
     rx->arena.clear();
     rx->peeked_valid = false; rx->peeked_release = false; rx->peeked_head = 0;
@@ -1667,7 +1768,7 @@ int same_batch_reset(same_batch *rx)
 
 uint32_t same_batch_input_rate(const same_batch *rx) { return rx ? rx->P.input_rate : 0; }
 uint32_t same_batch_n_channels(const same_batch *rx) { return rx ? rx->P.n_channels : 0; }
-uint64_t same_batch_input_sample_counter(const same_batch *rx) { return rx ? rx->counter : 0; }
+uint64_t same_batch_input_sample_counter(const same_batch *rx) { return rx ? rx->counter + rx->inv.fill : 0; }      // (samples accepted: demodulated or waiting for their window)
 int same_batch_device(const same_batch *rx) { return rx ? rx->device : -1; }
 
 int same_batch_process_device(same_batch *rx, const float *d_x, size_t n_samples, uint32_t layout, void *hip_stream)
@@ -1694,6 +1795,11 @@ int same_batch_flush(same_batch *rx)
     int rc = SAME_OK;
     for (size_t t0 = 0; t0 < n && rc == SAME_OK; t0 += slab) {
         rc = process_device_any<float>(rx, (const float *)rx->d_zero, std::min(slab, n - t0), SAME_LAYOUT_TIME_MAJOR, SAME_STREAM_OWN);
+        if (rc == SAME_OK) rc = harvest(rx);
+    }
+    if (rc == SAME_OK && rx->inv.on) {
+        // the end of the stream as far as the windows go: what is waiting is demodulated, the next window begins here
+        rc = inv_launch_waiting(rx, rx->own_stream);
         if (rc == SAME_OK) rc = harvest(rx);
     }
     return rc;

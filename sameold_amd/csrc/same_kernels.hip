@@ -692,6 +692,17 @@ hipError_t launch_tp_prologue(void *blob, const void *fresh, size_t bytes, uint6
                        reinterpret_cast<const uint4 *>(fresh), n16, handover, sort_cnt, n_cols, counters);
     return hipGetLastError();
 }
+// int16 samples as the f32 the kernels make of them (unscaled: crates/samedec/src/app.rs:112) -- SAME_BATCH_CALL_INVARIANT's waiting buffer
+__global__ void cast_i16_f32_kernel(const int16_t *__restrict__ in, float *__restrict__ out, size_t n)
+{
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) out[i] = (float)in[i];
+}
+hipError_t launch_cast_i16_f32(const int16_t *in, float *out, size_t n, hipStream_t stream)
+{
+    if (!n) return hipSuccess;
+    hipLaunchKernelGGL(cast_i16_f32_kernel, dim3((unsigned)std::min<size_t>((n + 255) / 256, 65536)), dim3(256), 0, stream, in, out, n);
+    return hipGetLastError();
+}
 __global__ void fill_u64_kernel(uint64_t *p, size_t n, uint64_t v)
 {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;

@@ -77,6 +77,7 @@ hipError_t launch_chunk_final_column(const uint64_t *handover, uint32_t in_chann
 hipError_t launch_chunk_final_column_pc(const uint64_t *handover, const uint32_t *own_start, uint32_t in_channels, uint32_t n_chunks,
                                         uint64_t counter0, uint32_t *final_col, hipStream_t stream);
 hipError_t launch_fill_u64(uint64_t *p, size_t n, uint64_t v, hipStream_t stream);
+hipError_t launch_cast_i16_f32(const int16_t *in, float *out, size_t n, hipStream_t stream);      // out[i] = (float)in[i]
 // The start of a time-parallel launch: blob[0 .. bytes) = fresh[0 .. bytes) (a template of freshly built receivers, 16-byte
 // multiples), handover[0 .. n_cols) = kNoHandover, sort_cnt[0 .. n_cols) = 0 (may be null), counters[0 .. 3) = 0 (may be null)
 hipError_t launch_tp_prologue(void *blob, const void *fresh, size_t bytes, uint64_t *handover, uint32_t *sort_cnt, uint32_t n_cols,

@@ -26,7 +26,7 @@ LIB_PATH = os.path.join(_HERE, f"libsame_rx.{os.environ['SAME_LIB_VARIANT']}.so"
 LINK_NO_CARRIER, LINK_SEARCHING, LINK_READING, LINK_BURST = 0, 1, 2, 3
 TRANSPORT_IDLE, TRANSPORT_ASSEMBLING, TRANSPORT_MSG_START, TRANSPORT_MSG_END, TRANSPORT_MSG_ERR = 16, 17, 18, 19, 20
 LAYOUT_TIME_MAJOR, LAYOUT_CHANNEL_MAJOR = 0, 1
-BATCH_LINK_ONLY, BATCH_TRACE_SYMBOLS, BATCH_GENERIC_KERNEL, BATCH_TIME_PARALLEL, BATCH_RELAXED = 1, 2, 4, 8, 16
+BATCH_LINK_ONLY, BATCH_TRACE_SYMBOLS, BATCH_GENERIC_KERNEL, BATCH_TIME_PARALLEL, BATCH_RELAXED, BATCH_CALL_INVARIANT = 1, 2, 4, 8, 16, 32
 TP_EVENT_TOLERANCE_SYMBOLS = 2      # SAME_TP_EVENT_TOLERANCE_SYMBOLS
 STREAM_OWN = (1 << 64) - 1          # SAME_STREAM_OWN: (void *)-1, the library's own stream
 EVENT_MAX_BYTES = 288
@@ -315,8 +315,11 @@ class SameReceiverBuilder:
 
     def build_batch(self, n_channels: int, device: int = 0, link_only: bool = False,
                     trace_symbols: bool = False, generic_kernel: bool = False,
-                    time_parallel: bool = False, relaxed: bool = False) -> "SameBatchReceiver":
-        return SameBatchReceiver(self, n_channels, device, link_only, trace_symbols, generic_kernel, time_parallel, relaxed)
+                    time_parallel: bool = False, relaxed: bool = False, call_invariant: bool = False) -> "SameBatchReceiver":
+        """call_invariant (SAME_BATCH_CALL_INVARIANT): the stream is demodulated in windows that begin at fixed stream positions,
+        so the events do not depend on how it is cut into calls (they arrive when a window's last sample has; flush() brings in
+        what is waiting)."""
+        return SameBatchReceiver(self, n_channels, device, link_only, trace_symbols, generic_kernel, time_parallel, relaxed, call_invariant)
 
 
 class SameBatchReceiver:
@@ -324,12 +327,12 @@ class SameBatchReceiver:
 
     def __init__(self, builder: SameReceiverBuilder, n_channels: int, device: int = 0,
                  link_only: bool = False, trace_symbols: bool = False, generic_kernel: bool = False,
-                 time_parallel: bool = False, relaxed: bool = False):
+                 time_parallel: bool = False, relaxed: bool = False, call_invariant: bool = False):
         self._L = load_library()
         h = C.c_void_p()
         flags = ((BATCH_LINK_ONLY if link_only else 0) | (BATCH_TRACE_SYMBOLS if trace_symbols else 0)
                  | (BATCH_GENERIC_KERNEL if generic_kernel else 0) | (BATCH_TIME_PARALLEL if time_parallel else 0)
-                 | (BATCH_RELAXED if relaxed else 0))
+                 | (BATCH_RELAXED if relaxed else 0) | (BATCH_CALL_INVARIANT if call_invariant else 0))
         _check(self._L.same_batch_new(builder._h, n_channels, device, flags, C.byref(h)))
         self._h = h
         self._inflight = []          # input tensors of launches that may still be running (process_tensor)

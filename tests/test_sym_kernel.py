@@ -419,3 +419,65 @@ def test_other_builder_settings_keep_the_kernel_and_the_contract(sa, rate):
         rx.process_tensor(x); rx.sync()
         assert rx.kernel_name() == KERNEL, name
         assert_contract(sa, ordered(rx.poll_events_np()), ref, rate, n_ch, lambda c: sa.synth_payload(seed, c), exact_bursts=True, what=name, t_end=n)
+
+
+@pytest.mark.parametrize("rate,n_ch,mode", [(22050, 192, "relaxed"), (22050, 1024, "time_parallel"), (48000, 128, "relaxed"), (22050, 64, "strict")])
+def test_call_invariant_batches_deliver_the_same_events_whatever_the_calls(sa, monkeypatch, rate, n_ch, mode):
+    """SAME_BATCH_CALL_INVARIANT (include/same_rx.h): the stream is demodulated in windows that begin at fixed stream positions, so
+    ANY list of calls that delivers the same samples -- one call, whole steps, single blocks, odd lengths, calls longer than
+    several windows, int16 pieces, channel-major pieces -- yields the same events on EVERY channel, sample counters and burst
+    bytes included (the reference's chunking is invisible: receiver.rs:119-130; without the flag the relaxed modes meet their
+    contract for any call list but not bit for bit: test_state_is_carried_from_call_to_call).  Events of a window arrive with
+    its last sample; flush brings in what is waiting; the result also meets the mode's contract against strict mode."""
+    import torch
+    window = 18432 if rate == 22050 else 36864          # (short windows: several per stream; the default is 73 728)
+    monkeypatch.setenv("SAME_INV_WINDOW", str(window))
+    seed = 4242
+    n = window * 7 + 5555
+    x = sa.synth_afsk(n_ch, n, rate, seed=seed)
+    kw = {"relaxed": True} if mode == "relaxed" else ({"time_parallel": True} if mode == "time_parallel" else {})
+
+    def go(calls, form="f32"):
+        rx = sa.SameReceiverBuilder(rate).build_batch(n_ch, call_invariant=True, **kw)
+        keep, off, seen = [], 0, []
+        for k in calls:
+            part = x[off:off + k]
+            if form == "i16":
+                part = part.round().to(torch.int16).contiguous(); keep.append(part); rx.process_tensor(part)
+            elif form == "cm":
+                part = part.t().contiguous(); keep.append(part); rx.process_tensor(part, layout=sa.LAYOUT_CHANNEL_MAJOR)
+            else:
+                rx.process_tensor(part.contiguous())
+            off += k
+            assert rx.input_sample_counter() == off
+        assert off == n
+        rx.sync()
+        before_flush = rx.poll_events_np()
+        # what has arrived so far belongs to whole windows only
+        assert len(before_flush) == 0 or int(before_flush["sample_counter"].max()) <= (n // window) * window + 8 * 43 * (rate // 22050) * 4
+        rx.flush()
+        ev = np.concatenate([before_flush, rx.poll_events_np()])
+        return ordered(ev)
+
+    one = go([n])
+    assert (one["kind"] == 3).sum() > n_ch
+    lists = [[window] * 7 + [5555], [36, 36 * 7, 36 * 1500, 36, n - 36 * 1509], [60000, 77, 35, 1, n - 60113],
+             [window * 3 + 17, 5, window * 2 - 1, n - (window * 5 + 21)]]
+    for calls in lists:
+        assert sum(calls) == n
+        many = go(calls)
+        assert len(many) == len(one), (mode, calls, len(many), len(one))
+        for f in ("kind", "channel", "sample_counter", "symbol_count", "len", "bytes"):
+            assert np.array_equal(many[f], one[f]), (mode, calls, f)
+    if mode != "strict":
+        # an int16 stream and a channel-major one: int16 samples are cast unscaled (the synthetic samples are whole numbers
+        # only after rounding: compare the two int16 call lists with each other), channel-major pieces are transposed
+        a, b = go([n], "i16"), go(lists[2], "i16")
+        for f in ("kind", "channel", "sample_counter", "bytes"):
+            assert np.array_equal(a[f], b[f]), (mode, "i16", f)
+        c = go(lists[3], "cm")
+        for f in ("kind", "channel", "sample_counter", "bytes"):
+            assert np.array_equal(c[f], one[f]), (mode, "cm", f)
+    ref = strict_events(sa, torch.cat([x, torch.zeros(4 * rate, n_ch, device=x.device)]), rate)
+    if mode != "strict":
+        assert_contract(sa, one, ref, rate, n_ch, lambda ch: sa.synth_payload(seed, ch), exact_bursts=True, what=f"call-invariant {mode}", t_end=n)
