@@ -202,14 +202,16 @@ enum {
      * property by themselves.  A relaxed launch drains its pipeline at its end and applies the feedback in flight at once, a
      * time-parallel launch plans its cuts over what the call delivered: fed in different calls, a stream comes out within the
      * modes' contracts every time but not event for event the same.  With this flag the batch demodulates the stream in WINDOWS
-     * of 73 728 samples (3.3 s at 22.05 kHz) that begin at fixed positions of the stream -- multiples of the window from the
+     * of 18 432 samples (0.84 s at 22.05 kHz; 73 728 for a SAME_BATCH_TIME_PARALLEL batch, whose planner cuts every launch into
+     * pieces; same_batch_set_call_window) that begin at fixed positions of the stream -- multiples of the window from the
      * batch's first sample, or from its last same_batch_flush / same_batch_reset -- whatever the calls look like: any list of
      * calls that delivers the same samples makes the same launches and therefore the same events, bit for bit.  Samples wait
      * in a device buffer until their window is whole (whole windows inside a call's buffer are demodulated where they lie): the
      * events of a window arrive when its last sample has; same_batch_flush demodulates what is waiting before its zeros have
      * filled the window, same_batch_sync does not.  Channel-major inputs take the transposing path (the per-channel cuts of
      * SAME_BATCH_TIME_PARALLEL on a channel-major input are planned per call).  same_batch_input_sample_counter counts the
-     * samples accepted, waiting ones included. */
+     * samples accepted, waiting ones included.  Cost: what of a call does not lie in whole windows is copied once (a call
+     * shorter than a window is copied whole: one more pass over the input), and launches are a window long. */
     SAME_BATCH_CALL_INVARIANT = 1u << 5
 };
 #define SAME_TP_EVENT_TOLERANCE_SYMBOLS 2
@@ -246,6 +248,9 @@ int same_batch_device(const same_batch *rx);
 #define SAME_STREAM_OWN ((void *)(intptr_t)-1)
 int same_batch_process_device(same_batch *rx, const float *d_x, size_t n_samples,
                               uint32_t layout, void *hip_stream);
+/* SAME_BATCH_CALL_INVARIANT: the window length in samples (64 .. 4 194 304), before the batch's first sample (or right behind a
+ * reset).  Two streams come out equal only if they are demodulated with equal windows. */
+int same_batch_set_call_window(same_batch *rx, uint32_t samples);
 /* make the library's own stream wait for everything queued on `producer_stream` so far
  * (a hipStream_t; NULL = the legacy default stream) */
 int same_batch_order_after(same_batch *rx, void *producer_stream);

@@ -1252,7 +1252,12 @@ int process_time_major_launches(same_batch *rx, const SampleT *d_x, size_t n_sam
 // makes the same launches.  The price is latency: the events of a window arrive when its last sample has (same_batch_flush
 // demodulates what is waiting).  Whole windows that lie inside a call's buffer are launched where they lie; the pieces before
 // and behind them are copied into the waiting buffer (f32; int16 pieces are cast the way the kernels cast them: unscaled).
-constexpr uint32_t kInvWindow = 73728;      // 3.3 s at 22.05 kHz, 1.5 s at 48 kHz; whole blocks of every kernel (16, 18, 32, 36, 72)
+// Window lengths (same_batch_set_call_window changes them): whole blocks of the kernels that take such launches (16, 18, 32, 36, 72
+// samples).  Short windows keep the latency and the share of a call that has to be copied low (a call shorter than a window is
+// copied whole: at 32 768 channels a 2-s call costs 4.4 ms with 73 728-sample windows, 3.5 with 18 432, 2.0 without the flag); a
+// time-parallel batch needs long ones -- its planner cuts every LAUNCH into pieces of a burst's length and more.
+constexpr uint32_t kInvWindow = 18432;                 // 0.84 s at 22.05 kHz, 0.38 s at 48 kHz
+constexpr uint32_t kInvWindowTimeParallel = 73728;     // 3.3 s at 22.05 kHz, 1.5 s at 48 kHz
 static int inv_buffer_wait(same_batch *rx, hipStream_t stream)
 {
     same_batch::Windowed &iv = rx->inv;
@@ -1618,7 +1623,7 @@ int same_batch_new(const same_rx_builder *b, uint32_t n_channels, int device, ui
     rx->device = device;
     rx->flags = flags;
     rx->inv.on = (flags & SAME_BATCH_CALL_INVARIANT) != 0;
-    rx->inv.window = kInvWindow;
+    rx->inv.window = (flags & SAME_BATCH_TIME_PARALLEL) ? kInvWindowTimeParallel : kInvWindow;
     if (const char *e = std::getenv("SAME_INV_WINDOW")) { const long v = std::atol(e); if (v >= 64 && v <= (1 << 22)) rx->inv.window = (uint32_t)v; }      // (tests: short windows)
     std::vector<float> taps;
     int rc = same::derive_params(*b, n_channels, rx->P, taps);
@@ -1803,6 +1808,16 @@ int same_batch_flush(same_batch *rx)
         if (rc == SAME_OK) rc = harvest(rx);
     }
     return rc;
+}
+
+int same_batch_set_call_window(same_batch *rx, uint32_t samples)
+{
+    if (!rx) return fail(SAME_EINVAL, "null handle");
+    if (!rx->inv.on) return fail(SAME_EINVAL, "the batch was not made with SAME_BATCH_CALL_INVARIANT");
+    if (samples < 64u || samples > (1u << 22)) return fail(SAME_EINVAL, "window of %u samples (64 .. 4 194 304)", samples);
+    if (rx->counter || rx->inv.fill) return fail(SAME_EINVAL, "the window is set before the first sample (or right behind a reset)");
+    rx->inv.window = samples;
+    return SAME_OK;
 }
 
 int same_batch_order_after(same_batch *rx, void *producer_stream)

@@ -170,6 +170,7 @@ def load_library() -> C.CDLL:
     sig("same_batch_device", C.c_int, vp)
     sig("same_batch_process_device", C.c_int, vp, vp, C.c_size_t, u32, vp)
     sig("same_batch_order_after", C.c_int, vp, vp)
+    sig("same_batch_set_call_window", C.c_int, vp, C.c_uint32)
     sig("same_batch_time_parallel_config", C.c_int, vp, u32, u32, u32)
     sig("same_batch_time_parallel_chunks", u32, vp)
     sig("same_batch_time_parallel_per_channel", C.c_int, vp)
@@ -354,6 +355,10 @@ class SameBatchReceiver:
 
     def kernel_name(self) -> str:
         return self._L.same_batch_kernel_name(self._h).decode()
+
+    def set_call_window(self, samples: int) -> None:
+        """call_invariant batches: the window length in samples, before the first sample (same_batch_set_call_window)."""
+        _check(self._L.same_batch_set_call_window(self._h, int(samples)))
 
     def reset(self):
         _check(self._L.same_batch_reset(self._h))

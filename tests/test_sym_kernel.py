@@ -430,8 +430,7 @@ def test_call_invariant_batches_deliver_the_same_events_whatever_the_calls(sa, m
     contract for any call list but not bit for bit: test_state_is_carried_from_call_to_call).  Events of a window arrive with
     its last sample; flush brings in what is waiting; the result also meets the mode's contract against strict mode."""
     import torch
-    window = 18432 if rate == 22050 else 36864          # (short windows: several per stream; the default is 73 728)
-    monkeypatch.setenv("SAME_INV_WINDOW", str(window))
+    window = 18432 if rate == 22050 else 36864          # (several windows per stream; a time-parallel batch's default is 73 728)
     seed = 4242
     n = window * 7 + 5555
     x = sa.synth_afsk(n_ch, n, rate, seed=seed)
@@ -439,6 +438,7 @@ def test_call_invariant_batches_deliver_the_same_events_whatever_the_calls(sa, m
 
     def go(calls, form="f32"):
         rx = sa.SameReceiverBuilder(rate).build_batch(n_ch, call_invariant=True, **kw)
+        rx.set_call_window(window)
         keep, off, seen = [], 0, []
         for k in calls:
             part = x[off:off + k]
