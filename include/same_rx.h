@@ -194,7 +194,8 @@ enum {
      * (tests/test_relaxed.py, tests/test_sym_kernel.py; directly against the oracle at all three rates).  A stream fed in
      * several calls meets the contract like one long call but is not bit-identical to it near a lock or an end(): at a call's end
      * everything in flight between the stages is applied at once (the samples behind the last whole step go to the strict
-     * any-configuration kernel, which needs a canonical state).  22.05, 44.1 and 48 kHz with the default DC-blocker length,
+     * any-configuration kernel, which needs a canonical state) -- SAME_BATCH_CALL_INVARIANT below ties the launches to the
+     * stream instead of to the calls and makes every call list come out the same.  22.05, 44.1 and 48 kHz with the default DC-blocker length,
      * default or disabled equalizer and a non-negative AGC floor (44.1 / 48 kHz: whole groups of 64 channels, any number
      * of them); any other configuration runs strict.  Strict mode (no flag) stays bit-exact. */
     SAME_BATCH_RELAXED = 1u << 4,
