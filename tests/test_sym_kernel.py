@@ -421,8 +421,9 @@ def test_other_builder_settings_keep_the_kernel_and_the_contract(sa, rate):
         assert_contract(sa, ordered(rx.poll_events_np()), ref, rate, n_ch, lambda c: sa.synth_payload(seed, c), exact_bursts=True, what=name, t_end=n)
 
 
-@pytest.mark.parametrize("rate,n_ch,mode", [(22050, 192, "relaxed"), (22050, 1024, "time_parallel"), (48000, 128, "relaxed"), (22050, 64, "strict")])
-def test_call_invariant_batches_deliver_the_same_events_whatever_the_calls(sa, monkeypatch, rate, n_ch, mode):
+@pytest.mark.parametrize("rate,n_ch,mode,noise", [(22050, 192, "relaxed", 0.0), (22050, 1024, "time_parallel", 0.0), (48000, 128, "relaxed", 0.0),
+                                                  (22050, 64, "strict", 0.0), (22050, 512, "relaxed", 0.08), (44100, 128, "time_parallel", 0.05)])
+def test_call_invariant_batches_deliver_the_same_events_whatever_the_calls(sa, monkeypatch, rate, n_ch, mode, noise):
     """SAME_BATCH_CALL_INVARIANT (include/same_rx.h): the stream is demodulated in windows that begin at fixed stream positions, so
     ANY list of calls that delivers the same samples -- one call, whole steps, single blocks, odd lengths, calls longer than
     several windows, int16 pieces, channel-major pieces -- yields the same events on EVERY channel, sample counters and burst
@@ -433,7 +434,7 @@ def test_call_invariant_batches_deliver_the_same_events_whatever_the_calls(sa, m
     window = 18432 if rate == 22050 else 36864          # (several windows per stream; a time-parallel batch's default is 73 728)
     seed = 4242
     n = window * 7 + 5555
-    x = sa.synth_afsk(n_ch, n, rate, seed=seed)
+    x = sa.synth_afsk(n_ch, n, rate, seed=seed, noise_sigma=noise)      # (noise: marginal acquisitions, false syncs, lost bursts -- the same ones for every call list)
     kw = {"relaxed": True} if mode == "relaxed" else ({"time_parallel": True} if mode == "time_parallel" else {})
 
     def go(calls, form="f32"):
@@ -479,5 +480,5 @@ def test_call_invariant_batches_deliver_the_same_events_whatever_the_calls(sa, m
         for f in ("kind", "channel", "sample_counter", "bytes"):
             assert np.array_equal(c[f], one[f]), (mode, "cm", f)
     ref = strict_events(sa, torch.cat([x, torch.zeros(4 * rate, n_ch, device=x.device)]), rate)
-    if mode != "strict":
+    if mode != "strict" and noise == 0.0:
         assert_contract(sa, one, ref, rate, n_ch, lambda ch: sa.synth_payload(seed, ch), exact_bursts=True, what=f"call-invariant {mode}", t_end=n)
