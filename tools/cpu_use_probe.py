@@ -33,6 +33,6 @@ wall = time.perf_counter() - t0; r1 = resource.getrusage(resource.RUSAGE_SELF); 
 cpu = (r1.ru_utime - r0.ru_utime) + (r1.ru_stime - r0.ru_stime)
 print(f"{steps} steps: wall {wall/steps*1e3:.3f} ms/step, process CPU {cpu/steps*1e3:.2f} CPU-ms/step (user {1e3*(r1.ru_utime-r0.ru_utime)/steps:.2f} + system {1e3*(r1.ru_stime-r0.ru_stime)/steps:.2f}) = {cpu/wall:.1f} CPUs busy; "
       f"SAME_HOST_THREADS={os.environ.get('SAME_HOST_THREADS','-')}")
-print(f"  passes longer than 3 ms: {long_passes}")
+print(f"  passes longer than 3 ms: {len(long_passes)} of {steps}" + (f"; the longest: {sorted(long_passes)[-8:]}" if long_passes else ""))
 for k in ("nr_periods", "nr_throttled", "throttled_usec", "usage_usec"):
     if k in s0 and k in s1: print(f"  cgroup {k}: +{int(s1[k]) - int(s0[k])}")
