@@ -9,7 +9,9 @@ sys.path.insert(0, ROOT)
 from sameold_amd import build as b
 want = sys.argv[1] if len(sys.argv) > 1 else "demod_sym_kernelILi42ELi6ELi4EfLi0"
 out = os.path.join(tempfile.gettempdir(), "sym_marks.s")
-cmd = [b.hipcc()] + b.flags() + ["-DSYM_ASM_MARKS", "--cuda-device-only", "-S", os.path.join(b.CSRC, "same_kernels_sym.hip"), "-o", out]
+# (the 44.1 / 48 kHz instantiations are a translation unit of their own, with flags of their own: sameold_amd/build.py)
+src = "same_kernels_sym.hip" if "ILi42E" in want else "same_kernels_sym_hi.hip"
+cmd = [b.hipcc()] + b.flags() + b.SOURCE_FLAGS.get(src, []) + ["-DSYM_ASM_MARKS", "--cuda-device-only", "-S", os.path.join(b.CSRC, src), "-o", out]
 subprocess.run(cmd, check=True, stderr=subprocess.DEVNULL)
 names = ["S", "T", "A", "E", "Y1", "Y2"]
 inside, cur, counts = False, None, {}
